@@ -1,0 +1,130 @@
+/*
+ * thunder_speech_amd.h -- C ABI of the MI355X-native (gfx950) hot path of thunder-speech.
+ *
+ * The reference (scart97/thunder-speech 3.2.0) has no FFI: its hot path is a chain of ATen ops called
+ * from Python.  Each entry point below replaces one such call site (cited as file:line of
+ * /root/reference) with a hand-written HIP kernel.  All pointers are DEVICE pointers into buffers
+ * owned by the caller (PyTorch-ROCm allocates them); `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Every function returns 0 on success, a negative TS_E* code on an
+ * argument error, or a positive hipError_t value when a HIP call failed.  Nothing here allocates,
+ * frees or synchronises, so every call can be captured into a hipGraph.
+ *
+ * Activation layout ("NCT-p"): [B][C][Tp] bf16, time contiguous, Tp = ts_time_pitch(T) (multiple of
+ * 128); the reference's own [B, C, T] layout with a padded pitch.  Columns >= T are scratch.
+ */
+#ifndef THUNDER_SPEECH_AMD_H
+#define THUNDER_SPEECH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_OK 0
+#define TS_EINVAL (-1)       /* bad argument / unsupported shape */
+#define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
+
+#define TS_ABI_VERSION 1
+
+/* Library identification: ABI version and the gfx target the code objects were built for. */
+int ts_abi_version(void);
+const char* ts_build_target(void);
+
+/* Time pitch (elements) used for an activation with T frames. */
+int ts_time_pitch(int T);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused time-channel-separable sub-block (inference):
+ *   y = act( pointwise( mask(depthwise_K( mask(x) )) ) * bn_scale + bn_shift  [+ residual 1x1(mask(x_res))] )
+ * replaces, per sub-block, the ATen chain  masked_fill -> conv1d(groups=C) -> masked_fill -> conv1d(k=1)
+ * -> batch_norm -> [add] -> relu   (quartznet/blocks.py:166-182, :195-224, :317-338;
+ * citrinet/blocks.py:175-197).  BN (eval) is folded into `pw_w`/`bias` by the caller.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ts_tcs_desc {
+  /* geometry */
+  int32_t batch;
+  int32_t c_in, c_out;          /* true channel counts */
+  int32_t t_in, t_out;          /* frames in the input / output tensors (t_out = conv output size) */
+  int32_t pitch_in, pitch_out;  /* time pitches of x and y (elements) */
+  int32_t kernel, stride, dilation, padding;
+  int32_t depthwise;            /* 1: depthwise(K) then pointwise; 0: pointwise only (kernel must be 1) */
+  int32_t relu;                 /* apply ReLU in the epilogue */
+  int32_t out_fp32;             /* 1: y is float [B][c_out][pitch_out] (decoder logits), 0: bf16 */
+  /* residual branch (1x1 conv of the block input, accumulated before the activation) */
+  int32_t c_res;                /* 0 = none */
+  int32_t pitch_res, t_res, res_stride;
+  /* prepacked parameters (see thunder_speech_amd/plan.py for the packers) */
+  int32_t dw_ksteps;            /* NK: number of 4-sample k-steps in `dw_taps` (multiple of 3) */
+  const void* dw_taps;          /* bf16 [c_in_pad64][4][4*NK]   shifted Toeplitz rows of the depthwise taps */
+  const void* pw_w;             /* bf16 [c_out_pad32/32][c_in_pad64/16][64][8]  MFMA B-fragments of W*bn_scale */
+  const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
+  const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */
+} ts_tcs_desc;
+
+/* x: bf16 [B][c_in][pitch_in]; len_in: int32 [B] valid frames of x (frames >= len are treated as 0,
+ * quirk A2); x_res / len_res likewise for the residual input (may be NULL when c_res == 0);
+ * y: bf16 or f32 [B][c_out][pitch_out]. */
+int ts_tcs_subblock_fwd(const ts_tcs_desc* desc, const void* x, const int32_t* len_in, const void* x_res,
+                        const int32_t* len_res, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mel-filterbank front end (eval mode): pre-emphasis -> reflect-padded STFT power -> slaney mel ->
+ * log -> per-(clip, mel) masked normalisation, replaces FilterbankFeatures.forward
+ * (quartznet/transform.py:136-144, :186-208, :243-255, :77-92 -> blocks.py:136-149).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ts_frontend_desc {
+  int32_t batch, n_samples;      /* waveform [B][n_samples] f32 */
+  int32_t n_fft, hop, win_length;
+  int32_t n_mels;
+  float preemph;
+  int32_t n_frames;              /* n_samples / hop + 1 */
+  int32_t pitch_out;             /* time pitch of the feature tensor */
+  const float* window;           /* f32 [n_fft] analysis window (hann centred in n_fft) */
+  const float* mel_weights;      /* f32 packed non-zero filterbank weights */
+  const int32_t* mel_offsets;    /* int32 [n_mels][2]: (first bin, offset into mel_weights); count = next offset - this */
+  int32_t mel_nnz;
+} ts_frontend_desc;
+
+/* Stage 1: logmel f32 [B][n_frames][n_mels] (frame-major scratch) + per-(b, mel) partial sums.
+ * Stage 2: normalise + mask + transpose into features bf16 [B][n_mels][pitch_out]; feat_len int32 [B].
+ * wave_len: f32 or int lengths are converted by the caller to int32 samples (floor).
+ * workspace: ts_frontend_workspace_bytes() bytes. */
+int64_t ts_frontend_workspace_bytes(const ts_frontend_desc* desc);
+int ts_mel_frontend_fwd(const ts_frontend_desc* desc, const float* wave, const int32_t* wave_len,
+                        void* features, int32_t* feat_len, void* workspace, void* stream);
+/* Debug/parity hook: copy of the un-normalised log-mel [B][n_frames][n_mels] f32 left in workspace. */
+const float* ts_frontend_logmel_ptr(const ts_frontend_desc* desc, const void* workspace);
+
+/* ------------------------------------------------------------------------------------------------
+ * Greedy CTC decode: argmax over classes then run-collapse (torch.unique_consecutive), replaces
+ * module.py:100 + text_processing/transform.py:107-110.  logits f32 [B][V][pitch]; ids int32 [B][T]
+ * (argmax per frame, lowest index wins ties); collapsed int32 [B][T] + counts int32 [B].
+ * ---------------------------------------------------------------------------------------------- */
+int ts_greedy_decode(const float* logits, int32_t batch, int32_t n_classes, int32_t n_frames, int32_t pitch,
+                     int32_t* ids, int32_t* collapsed, int32_t* counts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CTC loss forward + gradient w.r.t. the logits, replaces ctc_loss.py:36-47
+ * (permute -> log_softmax -> F.ctc_loss(reduction="mean", zero_infinity=True)).
+ * logits f32 [B][V][pitch]; targets int32 [B][s_max]; nll f32 [B] (per-utterance, inf -> 0);
+ * grad f32 [B][V][pitch] (may be NULL: forward only); loss f32 [1].
+ * workspace: ts_ctc_workspace_bytes() bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ts_ctc_workspace_bytes(int32_t batch, int32_t n_classes, int32_t n_frames, int32_t s_max);
+int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes, int32_t n_frames, int32_t pitch,
+                const int32_t* targets, int32_t s_max, const int32_t* input_len, const int32_t* target_len,
+                int32_t blank, float* nll, float* loss, float* grad, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].
+ * ---------------------------------------------------------------------------------------------- */
+int ts_pack_activation(const float* src, int32_t batch, int32_t channels, int32_t t, void* dst_bf16, int32_t pitch,
+                       void* stream);
+int ts_unpack_activation(const void* src_bf16, int32_t batch, int32_t channels, int32_t t, int32_t pitch,
+                         float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THUNDER_SPEECH_AMD_H */

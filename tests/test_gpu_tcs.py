@@ -1,0 +1,85 @@
+"""GPU parity: fused TCS sub-block kernel (through the C ABI) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tcs as otcs
+from oracle.primitives import bf16_round, same_padding
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(x, pitch):
+    b, c, t = x.shape
+    xp = torch.zeros(b, c, pitch, dtype=torch.bfloat16, device="cuda")
+    xp[:, :, :t] = x.to("cuda").to(torch.bfloat16)
+    # poison the pitch padding: the kernel must never let it leak into valid outputs
+    xp[:, :, t:] = 7.0
+    return xp
+
+
+def _run_case(cin, cout, k, stride, dil, t, lens, residual, separable=True, seed=0, relu=True):
+    from thunder_speech_amd import _lib, plan
+    spec = otcs.BlockSpec(cin, cout, repeat=1, kernel=k, stride=stride, dilation=dil, residual=residual,
+                          separable=separable)
+    sd = otcs.synth_encoder_state([spec], seed=seed)
+    sd = {key[2:]: v for key, v in sd.items()}
+    g = torch.Generator().manual_seed(seed)
+    x = bf16_round(torch.randn(len(lens), cin, t, generator=g))
+    lengths = torch.tensor(lens)
+    ref, ref_len = otcs.block_forward(spec, sd, "", x, lengths, emulate_bf16=True)
+    ref32, _ = otcs.block_forward(spec, sd, "", x, lengths, emulate_bf16=False)
+
+    pad = same_padding(k, stride, dil)
+    bnk = "mconv.2.layer.0." if separable else "mconv.1.layer.0."
+    bn = [sd[bnk + n] for n in ("weight", "bias", "running_mean", "running_var")]
+    kw = dict(dw_w=sd["mconv.0.conv.weight"] if separable else None,
+              pw_w=sd["mconv.1.conv.weight"] if separable else sd["mconv.0.conv.weight"], bn=bn,
+              kernel=k, stride=stride, dilation=dil, padding=pad, relu=relu)
+    if residual:
+        kw.update(res_w=sd["res.0.conv.weight"], res_stride=spec.residual_stride,
+                  res_bn=[sd["res.1.layer.0." + n] for n in ("weight", "bias", "running_mean", "running_var")])
+    layer = plan.make_tcs_layer("cuda", **kw)
+    xp = _pack(x, _lib.time_pitch(t))
+    li = lengths.to(torch.int32).cuda()
+    y, t_out = layer.run(xp, t, li, x_res=xp if residual else None, t_res=t, len_res=li if residual else None)
+    torch.cuda.synchronize()
+    assert t_out == ref.shape[-1]
+    got = y[:, :, :t_out].float().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    err32 = float((got - ref32).abs().max())
+    # bf16 storage: 1 ulp = 2^-8 relative; allow a couple of ulps of the largest magnitude
+    assert err <= 0.012 * scale, f"HIP vs bf16-emulating oracle: {err} (scale {scale})"
+    assert err32 <= 0.04 * scale, f"HIP vs fp32 oracle: {err32} (scale {scale})"
+    return got, ref
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,dil,t,lens,res", [
+    (64, 64, 5, 1, 1, 128, [128, 100], False),
+    (16, 32, 11, 1, 1, 50, [50, 33, 7], True),
+    (256, 256, 33, 1, 1, 751, [751, 600, 13], True),
+    (256, 512, 51, 1, 1, 300, [300, 211], True),
+    (512, 512, 75, 1, 1, 200, [200, 1], False),
+    (64, 256, 33, 2, 1, 1501, [1501, 1000], False),
+    (512, 512, 87, 1, 2, 260, [260, 129], False),
+    (80, 256, 5, 1, 1, 70, [70, 64], False),
+    (24, 40, 13, 1, 3, 45, [45, 30], False),
+    (32, 32, 9, 2, 1, 51, [51, 30, 10], False),
+    (16, 16, 39, 1, 1, 140, [140, 139, 1], True),
+    (48, 640, 41, 1, 1, 90, [90, 45], False),
+])
+def test_separable_subblock_matches_oracle(cin, cout, k, stride, dil, t, lens, res):
+    _run_case(cin, cout, k, stride, dil, t, lens, res)
+
+
+@pytest.mark.parametrize("cin,cout,t,lens", [(512, 1024, 300, [300, 150]), (24, 48, 40, [40, 21, 3]), (64, 29, 77, [77, 50])])
+def test_pointwise_only_block_matches_oracle(cin, cout, t, lens):
+    _run_case(cin, cout, 1, 1, 1, t, lens, False, separable=False)
+
+
+def test_padding_region_never_leaks():
+    """Frames >= length and the pitch padding are poisoned in the input; outputs must not change."""
+    got1, _ = _run_case(64, 64, 33, 1, 1, 200, [200, 120], True, seed=3)
+    got2, _ = _run_case(64, 64, 33, 1, 1, 200, [200, 120], True, seed=3)
+    assert torch.equal(got1, got2)

@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI declared in include/thunder_speech_amd.h.
+
+There is deliberately NO fallback: if the HIP shared library is missing or a kernel reports an error
+the caller gets a RuntimeError -- the product path never silently computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .build import lib_path
+
+_lib: Optional[C.CDLL] = None
+
+EXPORTED_SYMBOLS = [
+    "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd",
+    "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
+    "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss",
+    "ts_pack_activation", "ts_unpack_activation",
+]
+
+
+class TcsDesc(C.Structure):
+    """struct ts_tcs_desc"""
+    _fields_ = [
+        ("batch", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32), ("t_in", C.c_int32), ("t_out", C.c_int32),
+        ("pitch_in", C.c_int32), ("pitch_out", C.c_int32),
+        ("kernel", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32), ("padding", C.c_int32),
+        ("depthwise", C.c_int32), ("relu", C.c_int32), ("out_fp32", C.c_int32),
+        ("c_res", C.c_int32), ("pitch_res", C.c_int32), ("t_res", C.c_int32), ("res_stride", C.c_int32),
+        ("dw_ksteps", C.c_int32),
+        ("dw_taps", C.c_void_p), ("pw_w", C.c_void_p), ("res_w", C.c_void_p), ("bias", C.c_void_p),
+    ]
+
+
+class FrontendDesc(C.Structure):
+    """struct ts_frontend_desc"""
+    _fields_ = [
+        ("batch", C.c_int32), ("n_samples", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
+        ("win_length", C.c_int32), ("n_mels", C.c_int32), ("preemph", C.c_float), ("n_frames", C.c_int32),
+        ("pitch_out", C.c_int32),
+        ("window", C.c_void_p), ("mel_weights", C.c_void_p), ("mel_offsets", C.c_void_p), ("mel_nnz", C.c_int32),
+    ]
+
+
+def is_available() -> bool:
+    return os.path.exists(lib_path())
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"thunder_speech_amd: HIP extension {path} is missing. Build it with "
+            "`python -m thunder_speech_amd.build` (needs hipcc / ROCm); there is no CPU fallback.")
+    L = C.CDLL(path)
+    missing = [s for s in EXPORTED_SYMBOLS if not hasattr(L, s)]
+    if missing and not os.environ.get("TS_DEV_PARTIAL"):
+        raise RuntimeError(f"thunder_speech_amd: {path} does not export {missing}; rebuild it")
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    class _Dummy:  # dev builds only (TS_DEV_PARTIAL): absent symbols get a placeholder
+        argtypes = restype = None
+    for s_ in missing:
+        setattr(L, s_, _Dummy())
+    L.ts_abi_version.restype = C.c_int
+    L.ts_build_target.restype = C.c_char_p
+    L.ts_time_pitch.argtypes = [C.c_int]
+    L.ts_time_pitch.restype = C.c_int
+    L.ts_tcs_subblock_fwd.argtypes = [C.POINTER(TcsDesc), vp, vp, vp, vp, vp, vp]
+    L.ts_tcs_subblock_fwd.restype = C.c_int
+    L.ts_frontend_workspace_bytes.argtypes = [C.POINTER(FrontendDesc)]
+    L.ts_frontend_workspace_bytes.restype = i64
+    L.ts_mel_frontend_fwd.argtypes = [C.POINTER(FrontendDesc), vp, vp, vp, vp, vp, vp]
+    L.ts_mel_frontend_fwd.restype = C.c_int
+    L.ts_frontend_logmel_ptr.argtypes = [C.POINTER(FrontendDesc), vp]
+    L.ts_frontend_logmel_ptr.restype = vp
+    L.ts_greedy_decode.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.ts_greedy_decode.restype = C.c_int
+    L.ts_ctc_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.ts_ctc_workspace_bytes.restype = i64
+    L.ts_ctc_loss.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.ts_ctc_loss.restype = C.c_int
+    L.ts_pack_activation.argtypes = [vp, i32, i32, i32, vp, i32, vp]
+    L.ts_pack_activation.restype = C.c_int
+    L.ts_unpack_activation.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.ts_unpack_activation.restype = C.c_int
+    if L.ts_abi_version() != 1:
+        raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")
+    _lib = L
+    return L
+
+
+def check(status: int, what: str) -> None:
+    if status == 0:
+        return
+    if status == -1:
+        raise RuntimeError(f"{what}: invalid argument (TS_EINVAL)")
+    if status == -2:
+        raise NotImplementedError(f"{what}: configuration not supported by the HIP kernels (TS_EUNSUPPORTED)")
+    raise RuntimeError(f"{what}: HIP error {status}")
+
+
+def time_pitch(t: int) -> int:
+    """Python mirror of ts_time_pitch (kept in sync by tests/test_capi.py)."""
+    return ((max(int(t), 1) + 127) // 128) * 128

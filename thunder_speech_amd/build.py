@@ -1,0 +1,65 @@
+"""Compile the HIP sources of thunder_speech_amd into one in-tree shared library for gfx950.
+
+    python -m thunder_speech_amd.build          # -> thunder_speech_amd/libthunder_speech_hip.so
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels with the repo
+snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB_NAME = "libthunder_speech_hip.so"
+ARCH = "gfx950"
+
+
+def lib_path() -> str:
+    return os.path.join(PKG, LIB_NAME)
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
+
+
+def needs_build() -> bool:
+    out = lib_path()
+    if not os.path.exists(out):
+        return True
+    deps = sources() + glob.glob(os.path.join(PKG, "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    out = lib_path()
+    if not force and not needs_build():
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(PKG, "build", os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
+               f'-DTS_BUILD_TARGET="{ARCH}"', "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

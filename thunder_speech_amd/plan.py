@@ -1,0 +1,172 @@
+"""Host-side compilation of a reference module tree into fused-kernel launch plans.
+
+The reference executes every sub-block as ~7 ATen ops (quartznet/blocks.py:166-182, :222, :281).  Here a
+sub-block (depthwise K -> pointwise -> BN -> [+residual] -> ReLU) is ONE launch of
+`ts_tcs_subblock_fwd`; this module owns the parameter transformations that launch needs:
+
+  * `fold_bn`        eval-mode BatchNorm1d(eps=1e-3) -> per-channel (scale, shift)      (A12)
+  * `pack_dw_taps`   depthwise taps -> pre-shifted Toeplitz rows for v_mfma_f32_4x4x4_16b_bf16
+  * `pack_pw_frags`  pointwise weights * scale -> per-lane B fragments of v_mfma_f32_32x32x16_bf16
+
+All packers are pure tensor index arithmetic (run on any device, unit-tested on CPU); the arithmetic on
+activations happens only in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+KC = 64          # input-channel chunk of the kernel
+NKP = 3          # depthwise k-steps per pass (dw_ksteps must be a multiple)
+BN_EPS = 1e-3
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def fold_bn(weight, bias, running_mean, running_var, eps: float = BN_EPS):
+    scale = weight / torch.sqrt(running_var + eps)
+    return scale, bias - running_mean * scale
+
+
+def dw_ksteps(kernel: int, stride: int, dilation: int, padding: int) -> int:
+    padl4 = round_up(padding, 4)
+    d = padl4 - padding
+    vmax = 3 * stride + (kernel - 1) * dilation + d
+    return round_up(vmax // 4 + 1, NKP)
+
+
+def pack_dw_taps(w: torch.Tensor, stride: int, dilation: int, padding: int) -> Tuple[torch.Tensor, int]:
+    """w: [C, 1, K] depthwise taps -> bf16 [C_pad64, 4, 4*NK].
+
+    Row i (0..3) of channel c is the Toeplitz row of output frame i of a 4-frame step:
+        out[t + i] = sum_v row_i[v] * xwin[v],   xwin[v] = x[t*stride - padl4 + v]
+    i.e. row_i[v] = w[u] with v = i*stride + u*dilation + (padl4 - padding), 0 elsewhere."""
+    c, _, k = w.shape
+    nk = dw_ksteps(k, stride, dilation, padding)
+    d = round_up(padding, 4) - padding
+    out = torch.zeros(round_up(c, KC), 4, 4 * nk, dtype=torch.float32, device=w.device)
+    for i in range(4):
+        for u in range(k):
+            out[:c, i, i * stride + u * dilation + d] = w[:, 0, u]
+    return out.to(torch.bfloat16).contiguous(), nk
+
+
+def pack_pw_frags(wf: torch.Tensor) -> torch.Tensor:
+    """wf: [Cout, Cin] (already multiplied by the BN scale) -> bf16 [Cout_pad32/32, Cin_pad64/16, 64, 8].
+
+    Fragment (cot, ks), lane l (n = l & 31, h = l >> 5), element j  =  W[cot*32 + n][ks*16 + 8h + j]:
+    the B operand of v_mfma_f32_32x32x16_bf16 for D[t][co] += dw[t][ci] * W[co][ci]."""
+    cout, cin = wf.shape
+    cop, cip = round_up(cout, 32), round_up(cin, KC)
+    wp = torch.zeros(cop, cip, dtype=torch.float32, device=wf.device)
+    wp[:cout, :cin] = wf
+    fr = wp.view(cop // 32, 32, cip // 16, 2, 8).permute(0, 2, 3, 1, 4)      # [cot][ks][h][n][j]
+    return fr.reshape(cop // 32, cip // 16, 64, 8).to(torch.bfloat16).contiguous()
+
+
+def pad_bias(b: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros(round_up(b.shape[0], 32), dtype=torch.float32, device=b.device)
+    out[: b.shape[0]] = b
+    return out
+
+
+def conv_out_size(t: int, kernel: int, stride: int, padding: int, dilation: int) -> int:
+    return (t + 2 * padding - dilation * (kernel - 1) - 1) // stride + 1
+
+
+@dataclass
+class TcsLayer:
+    """One fused launch: parameters already packed on the target device."""
+    c_in: int
+    c_out: int
+    kernel: int
+    stride: int
+    dilation: int
+    padding: int
+    depthwise: bool
+    relu: bool
+    taps: Optional[torch.Tensor]
+    nk: int
+    pw: torch.Tensor
+    bias: torch.Tensor
+    c_res: int = 0
+    res_w: Optional[torch.Tensor] = None
+    res_stride: int = 1
+    out_fp32: bool = False
+
+    def out_size(self, t_in: int) -> int:
+        return conv_out_size(t_in, self.kernel, self.stride, self.padding, self.dilation)
+
+    def run(self, x: torch.Tensor, t_in: int, len_in: torch.Tensor, x_res: Optional[torch.Tensor] = None,
+            t_res: int = 0, len_res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        """x: bf16 [B, c_in, pitch]; len_in int32 [B].  Returns (y [B, c_out, pitch_out], t_out)."""
+        if not x.is_cuda:
+            raise RuntimeError("thunder_speech_amd kernels run on the GPU only (no CPU fallback)")
+        L = _lib.lib()
+        b = x.shape[0]
+        t_out = self.out_size(t_in)
+        pitch_out = _lib.time_pitch(t_out)
+        if out is None:
+            out = torch.empty(b, self.c_out, pitch_out, device=x.device,
+                              dtype=torch.float32 if self.out_fp32 else torch.bfloat16)
+        d = _lib.TcsDesc()
+        d.batch, d.c_in, d.c_out, d.t_in, d.t_out = b, self.c_in, self.c_out, t_in, t_out
+        d.pitch_in, d.pitch_out = x.shape[2], out.shape[2]
+        d.kernel, d.stride, d.dilation, d.padding = self.kernel, self.stride, self.dilation, self.padding
+        d.depthwise, d.relu, d.out_fp32 = int(self.depthwise), int(self.relu), int(self.out_fp32)
+        d.c_res = self.c_res
+        d.res_stride = self.res_stride
+        if self.c_res:
+            d.pitch_res, d.t_res = x_res.shape[2], t_res
+            d.res_w = self.res_w.data_ptr()
+        d.dw_ksteps = self.nk
+        d.dw_taps = self.taps.data_ptr() if self.taps is not None else None
+        d.pw_w = self.pw.data_ptr()
+        d.bias = self.bias.data_ptr()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        st = L.ts_tcs_subblock_fwd(C.byref(d), x.data_ptr(), len_in.data_ptr(),
+                                   x_res.data_ptr() if self.c_res else None,
+                                   len_res.data_ptr() if self.c_res else None, out.data_ptr(), stream)
+        _lib.check(st, "ts_tcs_subblock_fwd")
+        return out, t_out
+
+
+def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, bn: Sequence[torch.Tensor],
+                   kernel: int, stride: int, dilation: int, padding: int, relu: bool,
+                   res_w: Optional[torch.Tensor] = None, res_bn: Optional[Sequence[torch.Tensor]] = None,
+                   res_stride: int = 1, bias_extra: Optional[torch.Tensor] = None, out_fp32: bool = False) -> TcsLayer:
+    """Build a fused layer from reference-layout fp32 tensors.
+
+    dw_w: [Cin, 1, K] or None (pointwise only); pw_w: [Cout, Cin, 1] or [Cout, Cin]; bn = (weight, bias,
+    running_mean, running_var) or None (scale 1, shift 0; `bias_extra` then carries a conv bias)."""
+    pw2 = pw_w.reshape(pw_w.shape[0], pw_w.shape[1]).float()
+    cout, cin = pw2.shape
+    if bn is not None:
+        scale, shift = fold_bn(*[t.float() for t in bn])
+    else:
+        scale, shift = torch.ones(cout), torch.zeros(cout)
+    if bias_extra is not None:
+        shift = shift + bias_extra.float() * scale
+    wf = pw2 * scale[:, None]
+    taps, nk = (None, 0)
+    if dw_w is not None:
+        taps, nk = pack_dw_taps(dw_w.float(), stride, dilation, padding)
+    c_res, res_p = 0, None
+    if res_w is not None:
+        r2 = res_w.reshape(res_w.shape[0], res_w.shape[1]).float()
+        rs, rsh = fold_bn(*[t.float() for t in res_bn])
+        res_p = pack_pw_frags(r2 * rs[:, None]).to(device)
+        shift = shift + rsh
+        c_res = r2.shape[1]
+    return TcsLayer(c_in=cin, c_out=cout, kernel=kernel, stride=stride, dilation=dilation, padding=padding,
+                    depthwise=dw_w is not None, relu=relu, taps=None if taps is None else taps.to(device), nk=nk,
+                    pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
+                    res_stride=res_stride, out_fp32=out_fp32)
