@@ -271,7 +271,7 @@ def _xavier_uniform(rng, shape) -> torch.Tensor:
 
 
 def synth_encoder_state(arch: List[BlockSpec], seed: int = 0, gain: float = 1.0,
-                        calibrate: bool = False) -> Dict[str, torch.Tensor]:
+                        calibrate: bool = False, main_gamma: float = 1.0) -> Dict[str, torch.Tensor]:
     """Deterministic (numpy PCG64) weights: xavier-uniform convs (the reference's default init,
     quartznet/blocks.py:59-90), BN affine ~ (1 +- 0.1, +-0.1), running_mean ~ N(0, 0.1),
     running_var ~ U(0.5, 1.5) so that BN folding is exercised.
@@ -300,10 +300,15 @@ def synth_encoder_state(arch: List[BlockSpec], seed: int = 0, gain: float = 1.0,
                 # depthwise gain: keep the activation scale O(1) through the stack
                 sd[f"{p}mconv.{base}.conv.weight"] = _xavier_uniform(rng, (cin, 1, spec.kernel)) * gain
                 sd[f"{p}mconv.{base + 1}.conv.weight"] = _xavier_uniform(rng, (spec.out_ch, cin, 1)) * gain
-                bn(f"{p}mconv.{base + 2}.layer.0.", spec.out_ch)
+                bnp = f"{p}mconv.{base + 2}.layer.0."
             else:
                 sd[f"{p}mconv.{base}.conv.weight"] = _xavier_uniform(rng, (spec.out_ch, cin, spec.kernel)) * gain
-                bn(f"{p}mconv.{base + 1}.layer.0.", spec.out_ch)
+                bnp = f"{p}mconv.{base + 1}.layer.0."
+            bn(bnp, spec.out_ch)
+            if spec.residual and r == spec.repeat - 1:
+                # trained residual nets keep the skip path dominant; a random 5-layer main branch at full weight
+                # makes the stack chaotic (bf16 rounding noise then grows ~1.3x per block)
+                sd[bnp + "weight"] = sd[bnp + "weight"] * main_gamma
             cin = spec.out_ch
         if spec.has_se:
             se_idx = (spec.repeat - 1) * spec.mconv_step + (3 if spec.separable else 2)

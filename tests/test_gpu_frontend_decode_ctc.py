@@ -1,0 +1,103 @@
+"""GPU parity of the mel front end, greedy decode and CTC kernels (through the C ABI) vs oracle + fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctc as octc
+from oracle import decode as odec
+from oracle import frontend as ofe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag,kw", [("qn", {}), ("cn", dict(n_window_size=400, nfilt=80))])
+def test_frontend_matches_reference_fixture(golden, tag, kw):
+    from thunder_speech_amd.quartznet.transform import FilterbankFeatures
+    g = golden(f"frontend_{tag}.npz")
+    fb = FilterbankFeatures(**kw).cuda().eval()
+    feats, flen = fb(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["lengths"]).cuda())
+    torch.cuda.synchronize()
+    assert feats.shape == g["features"].shape
+    assert np.array_equal(flen.cpu().numpy(), g["feat_lengths"]) and flen.dtype == torch.int64
+    logmel = fb.last_logmel().cpu().numpy().transpose(0, 2, 1)           # [B, mel, frame]
+    np.testing.assert_allclose(logmel, g["logmel"], atol=2e-3)           # fp32 FFT vs torch.stft
+    got = feats.float().cpu().numpy()
+    # output is bf16: |x| <= ~4 -> half-ulp 2^-7 ; the reference's own CPU/GPU tolerance is 1e-3 on top
+    np.testing.assert_allclose(got, g["features"], atol=2e-2)
+    for b, n in enumerate(g["feat_lengths"]):
+        assert np.all(got[b, :, n:] == 0)
+
+
+def test_frontend_long_clip_matches_oracle():
+    from thunder_speech_amd.quartznet.transform import FilterbankFeatures
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = torch.from_numpy((0.1 * rng.standard_normal((3, 48000))).astype(np.float32))
+    x[1, 40000:] = 0
+    lengths = torch.tensor([48000, 40000, 47999])
+    ref = ofe.filterbank_features(x, lengths, return_stages=True)
+    fb = FilterbankFeatures().cuda().eval()
+    feats, flen = fb(x.cuda(), lengths.cuda())
+    assert torch.equal(flen.cpu(), ref["lengths"])
+    np.testing.assert_allclose(fb.last_logmel().cpu().numpy().transpose(0, 2, 1), ref["logmel"].numpy(), atol=2e-3)
+    np.testing.assert_allclose(feats.float().cpu().numpy(), ref["features"].numpy(), atol=2e-2)
+
+
+def test_greedy_decode_matches_oracle_and_reference_cases():
+    from thunder_speech_amd.module import greedy_decode
+    from thunder_speech_amd.text_processing.transform import BatchTextTransformer
+    labels = [" "] + [chr(ord("a") + i) for i in range(26)] + ["'"]
+    tt = BatchTextTransformer(tokens=list(labels))
+    vocab = odec.Vocab(list(labels))
+    rng = np.random.Generator(np.random.PCG64(9))
+    for t in (1, 7, 256, 257, 751):
+        logits = rng.standard_normal((5, 29, t)).astype(np.float32)
+        logits[1, 28, :] += 10.0                               # all blank
+        logits[2, 3, : t // 2] += 10.0                         # long run then noise
+        ids, collapsed, counts = greedy_decode(torch.from_numpy(logits).cuda())
+        ref_ids = odec.argmax_classes(logits)
+        assert np.array_equal(ids.cpu().numpy(), ref_ids)
+        strings = tt.decode_collapsed(collapsed, counts)
+        assert strings == odec.decode_prediction(ref_ids, vocab)
+        assert strings == tt.decode_prediction(ids)            # host path of the same API
+        for b in range(5):
+            n = int(counts[b])
+            assert np.array_equal(collapsed[b, :n].cpu().numpy(), odec.collapse_repeats(ref_ids[b]))
+    # reference known answers (tests/text/test_transforms.py:59-91)
+    a, bb, blank = vocab.stoi["a"], vocab.stoi["b"], vocab.blank_idx
+
+    def one_hot(seq):
+        lg = np.zeros((1, 29, len(seq)), dtype=np.float32)
+        lg[0, seq, np.arange(len(seq))] = 5.0
+        return torch.from_numpy(lg).cuda()
+    for seq, want in (([blank] * 10, ""), ([a] * 5 + [bb] * 5, "ab"), ([a] * 4 + [blank] + [a] * 4, "aa")):
+        _, col, cnt = greedy_decode(one_hot(seq))
+        assert tt.decode_collapsed(col, cnt) == [want]
+
+
+def test_ctc_loss_and_grad_match_reference_fixture(golden):
+    from thunder_speech_amd.ctc_loss import calculate_ctc
+    g = golden("ctc.npz")
+    logits = torch.from_numpy(g["logits"]).cuda().requires_grad_(True)
+    loss = calculate_ctc(logits, torch.from_numpy(g["targets"]).cuda(), torch.from_numpy(g["input_lengths"]).cuda(),
+                         torch.from_numpy(g["target_lengths"]).cuda(), int(g["blank"]))
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g["grad"], atol=2e-5)
+
+
+def test_ctc_matches_oracle_on_training_like_shapes():
+    from thunder_speech_amd.ctc_loss import calculate_ctc
+    rng = np.random.Generator(np.random.PCG64(4))
+    B, V, T = 6, 29, 251
+    logits = (1.5 * rng.standard_normal((B, V, T))).astype(np.float32)
+    tl = rng.integers(30, 100, B)
+    tg = np.full((B, 100), 28, dtype=np.int64)
+    for b in range(B):
+        tg[b, : tl[b]] = rng.integers(0, 28, tl[b])
+    il = rng.integers(200, T + 1, B).astype(np.float32)
+    want_loss, want_grad, _ = octc.calculate_ctc(logits, tg, il, tl, 28)
+    lg = torch.from_numpy(logits).cuda().requires_grad_(True)
+    loss = calculate_ctc(lg, torch.from_numpy(tg).cuda(), torch.from_numpy(il).cuda(), torch.from_numpy(tl).cuda(), 28)
+    (2.0 * loss).backward()
+    np.testing.assert_allclose(float(loss.detach()), want_loss, rtol=2e-5)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), 2.0 * want_grad, atol=2e-5)

@@ -59,13 +59,9 @@ def lib() -> C.CDLL:
             "`python -m thunder_speech_amd.build` (needs hipcc / ROCm); there is no CPU fallback.")
     L = C.CDLL(path)
     missing = [s for s in EXPORTED_SYMBOLS if not hasattr(L, s)]
-    if missing and not os.environ.get("TS_DEV_PARTIAL"):
+    if missing:
         raise RuntimeError(f"thunder_speech_amd: {path} does not export {missing}; rebuild it")
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
-    class _Dummy:  # dev builds only (TS_DEV_PARTIAL): absent symbols get a placeholder
-        argtypes = restype = None
-    for s_ in missing:
-        setattr(L, s_, _Dummy())
     L.ts_abi_version.restype = C.c_int
     L.ts_build_target.restype = C.c_char_p
     L.ts_time_pitch.argtypes = [C.c_int]

@@ -1,0 +1,146 @@
+"""Shared building blocks -- mirror of the reference's src/thunder/blocks.py public names.
+
+`MultiSequential`, `Masked`, `lengths_to_mask`, `get_same_padding`, `conv1d_decoder`, `linear_decoder`,
+`SwapLastDimension`, `normalize_tensor` keep the reference signatures (blocks.py:9-19).  The decoders run
+the fused pointwise HIP kernel; the small tensor helpers are host-side plumbing.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import plan as _plan
+from . import tensors as _t
+
+__all__ = ["MultiSequential", "Masked", "normalize_tensor", "lengths_to_mask", "get_same_padding",
+           "conv1d_decoder", "SwapLastDimension", "linear_decoder"]
+
+
+class MultiSequential(nn.Sequential):
+    """nn.Sequential with two inputs / outputs (reference blocks.py:94-102)."""
+
+    def forward(self, audio: Tensor, audio_lengths: Tensor) -> Tuple[Tensor, Tensor]:
+        for module in self.children():
+            audio, audio_lengths = module(audio, audio_lengths)
+        return audio, audio_lengths
+
+
+class Masked(nn.Module):
+    """Wraps single-input layers into the (x, lengths) convention (reference blocks.py:105-115).
+    Kept for state-dict key parity ("...layer.0.weight"); fused parents never call it on the hot path."""
+
+    def __init__(self, *layers):
+        super().__init__()
+        self.layer = nn.Sequential(*layers)
+
+    def forward(self, audio: Tensor, audio_lengths: Tensor) -> Tuple[Tensor, Tensor]:
+        return self.layer(audio), audio_lengths
+
+
+def lengths_to_mask(lengths: Tensor, max_length: int) -> Tensor:
+    """reference blocks.py:156-170"""
+    lengths = lengths.type(torch.long)
+    return torch.arange(max_length, device=lengths.device).expand(lengths.shape[0], max_length) < lengths.unsqueeze(1)
+
+
+def get_same_padding(kernel_size: int, stride: int, dilation: int) -> int:
+    """reference blocks.py:173-196"""
+    if stride > 1 and dilation > 1:
+        raise ValueError("Only stride OR dilation may be greater than 1")
+    if dilation > 1:
+        return (dilation * (kernel_size - 1) + 1) // 2
+    return kernel_size // 2
+
+
+def normalize_tensor(input_values: Tensor, mask: Optional[Tensor] = None, div_guard: float = 1e-7, dim: int = -1) -> Tensor:
+    """reference blocks.py:118-153 (incl. quirk A1 for the masked branch).  Host-side helper used by the
+    wav2vec2 pre-processing; the mel front end normalises inside its HIP kernel."""
+    if mask is not None:
+        valid = mask.type(torch.bool)
+        x = torch.where(valid, input_values, torch.zeros_like(input_values))
+        n = valid.sum(dim=dim, keepdim=True)
+        mean = x.sum(dim=dim, keepdim=True) / n
+        std = ((x - mean).pow(2).sum(dim=dim, keepdim=True) / n).sqrt()
+        return torch.where(valid, (x - mean) / (std + div_guard), torch.zeros_like(x))
+    mean = input_values.mean(dim=dim, keepdim=True)
+    std = (input_values.var(dim=dim, keepdim=True) + div_guard).sqrt()
+    return (input_values - mean) / std
+
+
+class _PackedCache:
+    """Lazily (re)builds packed kernel parameters when the fp32 master tensors change."""
+
+    def __init__(self):
+        self._key = None
+        self._value = None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+        if key != self._key:
+            self._value = build()
+            self._key = key
+        return self._value
+
+
+class _Conv1dDecoder(nn.Conv1d):
+    """1x1 conv + bias -> fp32 logits [B, V, T'] (reference conv1d_decoder, blocks.py:199-216).
+    state-dict keys: weight [V, C, 1], bias [V]."""
+
+    def __init__(self, in_channels: int, num_classes: int):
+        super().__init__(in_channels, num_classes, kernel_size=1, bias=True)
+        self._cache = _PackedCache()
+
+    def _layer(self):
+        return self._cache.get([self.weight, self.bias], lambda: _plan.make_tcs_layer(
+            self.weight.device, dw_w=None, pw_w=self.weight.detach(), bn=None, kernel=1, stride=1, dilation=1,
+            padding=0, relu=False, bias_extra=self.bias.detach(), out_fp32=True))
+
+    def forward(self, x: Tensor) -> Tensor:
+        _t.require_gpu(x, "conv1d_decoder")
+        xi = _t.pack(x)
+        b, _, t = xi.shape
+        full = torch.full((b,), t, dtype=torch.int32, device=xi.device)   # the decoder conv is not masked
+        y, t_out = self._layer().run(_t.backing(xi), t, full)
+        return y[:, :, :t_out]
+
+
+def conv1d_decoder(decoder_input_channels: int, num_classes: int) -> nn.Module:
+    decoder = _Conv1dDecoder(decoder_input_channels, num_classes)
+    nn.init.xavier_uniform_(decoder.weight, gain=1.0)
+    return decoder
+
+
+class SwapLastDimension(nn.Module):
+    def forward(self, x: Tensor) -> Tensor:
+        return x.transpose(-1, -2)
+
+
+class _LinearDecoder(nn.Sequential):
+    """transpose -> dropout -> Linear -> transpose (reference linear_decoder, blocks.py:226-248); keys
+    "2.weight" / "2.bias".  Eval mode runs the same fused pointwise kernel on the [B, C, T] layout (the two
+    transposes cancel)."""
+
+    def __init__(self, in_channels: int, num_classes: int, decoder_dropout: float):
+        super().__init__(SwapLastDimension(), nn.Dropout(decoder_dropout), nn.Linear(in_channels, num_classes),
+                         SwapLastDimension())
+        self._cache = _PackedCache()
+
+    def forward(self, x: Tensor) -> Tensor:
+        _t.require_gpu(x, "linear_decoder")
+        if self.training and self[1].p > 0:
+            raise NotImplementedError("linear_decoder: dropout in training mode has no HIP kernel yet")
+        lin = self[2]
+        layer = self._cache.get([lin.weight, lin.bias], lambda: _plan.make_tcs_layer(
+            lin.weight.device, dw_w=None, pw_w=lin.weight.detach(), bn=None, kernel=1, stride=1, dilation=1,
+            padding=0, relu=False, bias_extra=lin.bias.detach(), out_fp32=True))
+        xi = _t.pack(x)
+        b, _, t = xi.shape
+        full = torch.full((b,), t, dtype=torch.int32, device=xi.device)
+        y, t_out = layer.run(_t.backing(xi), t, full)
+        return y[:, :, :t_out]
+
+
+def linear_decoder(decoder_input_channels: int, num_classes: int, decoder_dropout: float) -> nn.Module:
+    return _LinearDecoder(decoder_input_channels, num_classes, decoder_dropout)

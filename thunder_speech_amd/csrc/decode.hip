@@ -1,0 +1,65 @@
+// Greedy CTC decode for gfx950: per-frame argmax over the classes, then run-collapse of each row.
+// Replaces module.py:100 (pred.argmax(1)) and the per-row torch.unique_consecutive Python loop of
+// text_processing/transform.py:107-110.  All T' frames are decoded (out_lengths are ignored, quirk A9);
+// blank removal and the id -> token mapping stay on the host (string work).
+#include "ts_common.hpp"
+
+namespace ts {
+
+// one workgroup per clip; frames are processed in chunks of 256 with a running output offset
+__global__ __launch_bounds__(256) void greedy_kernel(const float* __restrict__ logits, int n_classes, int n_frames, int pitch,
+                                                     int* __restrict__ ids, int* __restrict__ collapsed,
+                                                     int* __restrict__ counts) {
+  __shared__ int wave_sum[4];
+  __shared__ int carry_s;
+  __shared__ int last_id_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* base = logits + (size_t)b * n_classes * pitch;
+  if (tid == 0) { carry_s = 0; last_id_s = -1; }
+  __syncthreads();
+  for (int t0 = 0; t0 < n_frames; t0 += 256) {
+    const int t = t0 + tid;
+    int best = 0;
+    if (t < n_frames) {
+      float bv = base[t];
+      for (int v = 1; v < n_classes; ++v) {          // coalesced over t; lowest index wins ties
+        const float x = base[(size_t)v * pitch + t];
+        if (x > bv) { bv = x; best = v; }
+      }
+      ids[(size_t)b * n_frames + t] = best;
+    }
+    // previous frame's id: neighbour lane, or the last id of the previous chunk
+    int prev = __shfl_up(best, 1);
+    __shared__ int edge[4];
+    if (lane == 63) edge[wave] = best;
+    __syncthreads();
+    if (lane == 0) prev = wave == 0 ? last_id_s : edge[wave - 1];
+    const int keep = (t < n_frames) && (best != prev);
+    // exclusive scan of `keep` over the workgroup
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_sum[wave] = __popcll(m);
+    __syncthreads();
+    int off = carry_s;
+    for (int w = 0; w < wave; ++w) off += wave_sum[w];
+    if (keep) collapsed[(size_t)b * n_frames + off + before] = best;
+    __syncthreads();
+    if (tid == 255) {
+      carry_s = off + before + keep;
+      last_id_s = (t0 + 255 < n_frames) ? best : last_id_s;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) counts[b] = carry_s;
+}
+
+}  // namespace ts
+
+extern "C" int ts_greedy_decode(const float* logits, int32_t batch, int32_t n_classes, int32_t n_frames, int32_t pitch,
+                                int32_t* ids, int32_t* collapsed, int32_t* counts, void* stream) {
+  if (!logits || !ids || !collapsed || !counts) return TS_EINVAL;
+  if (batch <= 0 || n_classes <= 0 || n_frames <= 0 || pitch < n_frames) return TS_EINVAL;
+  hipLaunchKernelGGL(ts::greedy_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, logits, n_classes, n_frames,
+                     pitch, ids, collapsed, counts);
+  return ts::hip_status(hipGetLastError());
+}

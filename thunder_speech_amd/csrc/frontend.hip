@@ -1,0 +1,323 @@
+// Mel-filterbank front end for gfx950: pre-emphasis -> reflect-padded STFT power -> slaney mel -> log
+// -> per-(clip, mel) masked normalisation, writing the bf16 NCT-p feature tensor the TCS stack consumes.
+//
+// Replaces FilterbankFeatures.forward in eval mode (reference: quartznet/transform.py:136-144 pre-emphasis,
+// :186-208 torch.stft(center=True, reflect) + |.|^2, :243-255 mel matmul + log(x + 2^-24), :77-92 ->
+// blocks.py:136-149 masked normalisation incl. quirk A1).  The reference materialises the complex
+// spectrum (197 MB for 64 x 15 s) and six more full passes; here the waveform is read once, everything up
+// to the log-mel stays in LDS/registers, and a second small kernel applies the per-row statistics.
+//
+// Kernel 1 (stft_mel_kernel): one workgroup = 16 frames, 16 lanes per frame.  A 512-point real FFT is done
+// as a 256-point complex FFT of z[n] = x[2n] + i x[2n+1] by the four-step method (16 x 16): each lane runs
+// a 16-point FFT in registers, the 16 lanes of a frame exchange through a padded LDS transpose, second
+// 16-point FFT, then the real-FFT split, |X|^2, sparse triangular mel filters (CSR) and log.
+// Kernel 2 (normalize_kernel): reduces the per-workgroup partial sums in fp64, normalises, masks frames
+// >= length, transposes [frame][mel] -> [mel][frame] through LDS and stores bf16 rows.
+#include "ts_common.hpp"
+
+namespace ts {
+
+constexpr int FPW = 16;            // frames per workgroup
+constexpr int NFFT = 512;
+constexpr int NC = NFFT / 2;       // complex FFT length
+constexpr float LOG_FLOOR = 5.9604644775390625e-08f;   // 2^-24
+
+struct Cx { float r, i; };
+__device__ __forceinline__ Cx cmul(Cx a, Cx b) { return Cx{a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
+
+// 16-point forward DFT in registers (decimation 4 x 4), natural-order in and out.
+__device__ __forceinline__ void fft16(Cx (&a)[16]) {
+  Cx b[16];
+  // stage 1: 4-point DFTs over n1 for each n2 (input index 4 n1 + n2), result index [n2][k1]
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    const Cx x0 = a[n2], x1 = a[4 + n2], x2 = a[8 + n2], x3 = a[12 + n2];
+    const Cx s02{x0.r + x2.r, x0.i + x2.i}, d02{x0.r - x2.r, x0.i - x2.i};
+    const Cx s13{x1.r + x3.r, x1.i + x3.i}, d13{x1.r - x3.r, x1.i - x3.i};
+    b[n2 * 4 + 0] = Cx{s02.r + s13.r, s02.i + s13.i};
+    b[n2 * 4 + 1] = Cx{d02.r + d13.i, d02.i - d13.r};     // x0 - i x1 - x2 + i x3
+    b[n2 * 4 + 2] = Cx{s02.r - s13.r, s02.i - s13.i};
+    b[n2 * 4 + 3] = Cx{d02.r - d13.i, d02.i + d13.r};     // x0 + i x1 - x2 - i x3
+  }
+  // twiddles W16^(n2 k1)
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+  const Cx w[10] = {Cx{1.f, 0.f}, Cx{C1, -S1}, Cx{R2, -R2}, Cx{S1, -C1}, Cx{0.f, -1.f},
+                    Cx{-S1, -C1}, Cx{-R2, -R2}, Cx{-C1, -S1}, Cx{-1.f, 0.f}, Cx{-C1, S1}};
+#pragma unroll
+  for (int n2 = 1; n2 < 4; ++n2)
+#pragma unroll
+    for (int k1 = 1; k1 < 4; ++k1) b[n2 * 4 + k1] = cmul(b[n2 * 4 + k1], w[n2 * k1]);
+  // stage 2: 4-point DFTs over n2 for each k1, output index k1 + 4 k2
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    const Cx x0 = b[k1], x1 = b[4 + k1], x2 = b[8 + k1], x3 = b[12 + k1];
+    const Cx s02{x0.r + x2.r, x0.i + x2.i}, d02{x0.r - x2.r, x0.i - x2.i};
+    const Cx s13{x1.r + x3.r, x1.i + x3.i}, d13{x1.r - x3.r, x1.i - x3.i};
+    a[k1 + 0] = Cx{s02.r + s13.r, s02.i + s13.i};
+    a[k1 + 4] = Cx{d02.r + d13.i, d02.i - d13.r};
+    a[k1 + 8] = Cx{s02.r - s13.r, s02.i - s13.i};
+    a[k1 + 12] = Cx{d02.r - d13.i, d02.i + d13.r};
+  }
+}
+
+struct FeArgs {
+  const float* wave;
+  const int* wave_len;
+  const float* window;        // [NFFT]
+  const float* mel_w;         // CSR weights
+  const int* mel_off;         // [n_mels + 1][2] = (first bin, offset)
+  float* logmel;              // [B][F][n_mels]
+  float* partial;             // [B][nwg][n_mels][2]
+  int* feat_len;
+  int n_samples, hop, n_mels, n_frames, nwg;
+  float preemph;
+};
+
+__global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int span = (FPW - 1) * a.hop + NFFT;
+  float* const sig = reinterpret_cast<float*>(smem);                 // [span] pre-emphasised, reflect-padded
+  Cx* const tw256 = reinterpret_cast<Cx*>(sig + round_up(span, 4));  // W_256^j
+  Cx* const tw512 = tw256 + NC;                                      // W_512^k, k = 0..256
+  float* const win = reinterpret_cast<float*>(tw512 + NC + 2);       // [NFFT]
+  float* const fr = win + NFFT;                                      // per frame scratch
+  constexpr int YSZ = 16 * 17 * 2;                                   // floats: padded transpose tile
+  constexpr int ZSZ = NC * 2;
+  constexpr int FSZ = YSZ + ZSZ;
+  float* const red = fr + FPW * FSZ;                                 // [FPW][n_mels] log-mel staging
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * FPW;
+  const float* x = a.wave + (size_t)b * a.n_samples;
+  const int T = a.n_samples;
+
+  // ---- tables + signal staging ------------------------------------------------------------------------
+  for (int j = tid; j < NC; j += 256) {
+    float s, c;
+    sincospif(-2.0f * (float)j / (float)NC, &s, &c);
+    tw256[j] = Cx{c, s};
+  }
+  for (int k = tid; k <= NC; k += 256) {
+    float s, c;
+    sincospif(-2.0f * (float)k / (float)NFFT, &s, &c);
+    tw512[k] = Cx{c, s};
+  }
+  for (int j = tid; j < NFFT; j += 256) win[j] = a.window[j];
+  const int k0 = f0 * a.hop - NFFT / 2;
+  for (int e = tid; e < span; e += 256) {
+    int k = k0 + e;
+    k = k < 0 ? -k : k;
+    k = k >= T ? 2 * (T - 1) - k : k;
+    k = k < 0 ? 0 : (k >= T ? T - 1 : k);          // frames entirely beyond the clip (never valid)
+    const float cur = x[k];
+    const float prev = k > 0 ? x[k - 1] : 0.f;
+    sig[e] = k > 0 ? cur - a.preemph * prev : cur;
+  }
+  __syncthreads();
+
+  // ---- 256-point complex FFT per frame: 16 lanes per frame ---------------------------------------------
+  const int fl = tid >> 4;          // frame in workgroup
+  const int i = tid & 15;
+  float* const Y = fr + fl * FSZ;
+  float* const Z = Y + YSZ;
+  {
+    Cx v[16];
+    const float* s = sig + fl * a.hop;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int j = 32 * n1 + 2 * i;
+      const f32x2 sv = *reinterpret_cast<const f32x2*>(s + j);
+      const f32x2 wv = *reinterpret_cast<const f32x2*>(win + j);
+      v[n1] = Cx{sv[0] * wv[0], sv[1] * wv[1]};
+    }
+    fft16(v);                                    // over n1 -> index k1
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const Cx t = cmul(v[k1], tw256[(i * k1) & (NC - 1)]);
+      *reinterpret_cast<f32x2*>(Y + (k1 * 17 + i) * 2) = f32x2{t.r, t.i};
+    }
+  }
+  __syncthreads();
+  {
+    Cx v[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) {
+      const f32x2 t = *reinterpret_cast<const f32x2*>(Y + (i * 17 + n2) * 2);
+      v[n2] = Cx{t[0], t[1]};
+    }
+    fft16(v);                                    // over n2 -> k2; bin = i + 16 k2
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<f32x2*>(Z + (i + 16 * k2) * 2) = f32x2{v[k2].r, v[k2].i};
+  }
+  __syncthreads();
+  // ---- real-FFT split + power spectrum, bins k = i + 16 j (and bin 256 on lane 0) -> P (aliases Y) ------
+  float* const P = Y;
+  {
+    float pw[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {
+      const int k = i + 16 * j;
+      if (j < 16 || i == 0) {
+        const f32x2 zk = *reinterpret_cast<const f32x2*>(Z + ((k & (NC - 1)) * 2));
+        const f32x2 zn = *reinterpret_cast<const f32x2*>(Z + (((NC - k) & (NC - 1)) * 2));
+        const Cx w = tw512[k];                    // (cos, -sin)
+        const float ar = zk[0] + zn[0], ai = zk[1] - zn[1];
+        const float dr = zk[0] - zn[0], di = zk[1] + zn[1];
+        // X = 0.5 * (A - i W D)
+        const float xr = 0.5f * (ar + w.r * di + w.i * dr);
+        const float xi = 0.5f * (ai - w.r * dr + w.i * di);
+        pw[j] = xr * xr + xi * xi;
+      }
+    }
+    __syncthreads();                              // all lanes of the frame are done reading Y/Z rows
+#pragma unroll
+    for (int j = 0; j < 17; ++j)
+      if (j < 16 || i == 0) P[i + 16 * j] = pw[j];
+  }
+  __syncthreads();
+  // ---- sparse mel filters + log -------------------------------------------------------------------------
+  const int f = f0 + fl;
+  for (int m = i; m < a.n_mels; m += 16) {
+    const int first = a.mel_off[2 * m], off = a.mel_off[2 * m + 1];
+    const int cnt = a.mel_off[2 * m + 3] - off;
+    float acc = 0.f;
+    for (int j = 0; j < cnt; ++j) acc = fmaf(a.mel_w[off + j], P[first + j], acc);
+    const float lm = logf(acc + LOG_FLOOR);
+    red[fl * a.n_mels + m] = lm;
+    if (f < a.n_frames) a.logmel[((size_t)b * a.n_frames + f) * a.n_mels + m] = lm;
+  }
+  __syncthreads();
+  // ---- partial statistics over the valid frames of this workgroup -----------------------------------------
+  const int flen = a.wave_len[b] / a.hop + 1;      // floor(len / hop) + 1  (transform.py:182-184)
+  if (tid == 0 && blockIdx.x == 0) a.feat_len[b] = flen;
+  for (int m = tid; m < a.n_mels; m += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < FPW; ++q) {
+      if (f0 + q < flen && f0 + q < a.n_frames) {
+        const float v = red[q * a.n_mels + m];
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+    }
+    float* dst = a.partial + (((size_t)b * a.nwg + blockIdx.x) * a.n_mels + m) * 2;
+    dst[0] = s1;
+    dst[1] = s2;
+  }
+}
+
+struct NormArgs {
+  const float* logmel;        // [B][F][n_mels]
+  const float* partial;       // [B][nwg][n_mels][2]
+  const int* feat_len;
+  unsigned short* out;        // [B][n_mels][pitch]
+  int n_mels, n_frames, nwg, pitch;
+};
+
+constexpr int NTF = 64;            // frames per normalize workgroup
+
+__global__ __launch_bounds__(256) void normalize_kernel(const NormArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const mean = reinterpret_cast<float*>(smem);           // [n_mels]
+  float* const rstd = mean + a.n_mels;                          // [n_mels]
+  float* const tile = rstd + a.n_mels;                          // [NTF][n_mels + 1]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * NTF;
+  const int flen = a.feat_len[b] < a.n_frames ? a.feat_len[b] : a.n_frames;
+
+  for (int m = tid; m < a.n_mels; m += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    const float* p = a.partial + ((size_t)b * a.nwg * a.n_mels + m) * 2;
+    for (int w = 0; w < a.nwg; ++w) {
+      s1 += (double)p[(size_t)w * a.n_mels * 2];
+      s2 += (double)p[(size_t)w * a.n_mels * 2 + 1];
+    }
+    const double n = (double)flen;
+    const double mu = s1 / n;
+    // quirk A1: padded frames contribute mu^2 each to the variance numerator
+    double var = (s2 - n * mu * mu + (double)(a.n_frames - flen) * mu * mu) / n;
+    var = var < 0.0 ? 0.0 : var;
+    mean[m] = (float)mu;
+    rstd[m] = (float)(1.0 / (sqrt(var) + 1e-5));
+  }
+  const int ld = a.n_mels + 1;
+  for (int idx = tid; idx < NTF * a.n_mels; idx += 256) {
+    const int q = idx / a.n_mels, m = idx - q * a.n_mels;
+    const int f = f0 + q;
+    tile[q * ld + m] = f < a.n_frames ? a.logmel[((size_t)b * a.n_frames + f) * a.n_mels + m] : 0.f;
+  }
+  __syncthreads();
+  // each thread produces 8 consecutive frames of one mel row (16 B)
+  for (int idx = tid; idx < a.n_mels * (NTF / 8); idx += 256) {
+    const int m = idx / (NTF / 8), g = idx - m * (NTF / 8);
+    const float mu = mean[m], rs = rstd[m];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = f0 + g * 8 + j;
+      v[j] = f < flen ? (tile[(g * 8 + j) * ld + m] - mu) * rs : 0.f;
+    }
+    if (f0 + g * 8 < a.pitch)
+      *reinterpret_cast<u32x4*>(a.out + ((size_t)b * a.n_mels + m) * a.pitch + f0 + g * 8) =
+          u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  }
+}
+
+static inline int fe_nwg(const ts_frontend_desc* d) { return (d->n_frames + FPW - 1) / FPW; }
+static inline size_t fe_logmel_bytes(const ts_frontend_desc* d) {
+  return round_up((size_t)d->batch * d->n_frames * d->n_mels * sizeof(float), 256);
+}
+
+}  // namespace ts
+
+extern "C" int64_t ts_frontend_workspace_bytes(const ts_frontend_desc* d) {
+  if (!d || d->batch <= 0 || d->n_frames <= 0 || d->n_mels <= 0) return TS_EINVAL;
+  return (int64_t)(ts::fe_logmel_bytes(d) + (size_t)d->batch * ts::fe_nwg(d) * d->n_mels * 2 * sizeof(float));
+}
+
+extern "C" const float* ts_frontend_logmel_ptr(const ts_frontend_desc* d, const void* workspace) {
+  (void)d;
+  return static_cast<const float*>(workspace);
+}
+
+extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave, const int32_t* wave_len, void* features,
+                                   int32_t* feat_len, void* workspace, void* stream_) {
+  using namespace ts;
+  if (!d || !wave || !wave_len || !features || !feat_len || !workspace) return TS_EINVAL;
+  if (!d->window || !d->mel_weights || !d->mel_offsets) return TS_EINVAL;
+  if (d->batch <= 0 || d->n_samples <= NFFT / 2 || d->hop <= 0 || d->n_mels <= 0) return TS_EINVAL;
+  if (d->n_fft != NFFT) return TS_EUNSUPPORTED;                    // both model families use n_fft = 512
+  if (d->win_length > NFFT || d->win_length <= 0) return TS_EINVAL;  // transform.py:166-170
+  if (d->n_frames != d->n_samples / d->hop + 1) return TS_EINVAL;
+  if (d->pitch_out % 8 || d->pitch_out < d->n_frames) return TS_EINVAL;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int nwg = fe_nwg(d);
+
+  FeArgs a{};
+  a.wave = wave; a.wave_len = wave_len; a.window = d->window; a.mel_w = d->mel_weights; a.mel_off = d->mel_offsets;
+  a.logmel = static_cast<float*>(workspace);
+  a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + fe_logmel_bytes(d));
+  a.feat_len = feat_len;
+  a.n_samples = d->n_samples; a.hop = d->hop; a.n_mels = d->n_mels; a.n_frames = d->n_frames; a.nwg = nwg;
+  a.preemph = d->preemph;
+  const int span = (FPW - 1) * d->hop + NFFT;
+  const size_t lds1 = ((size_t)round_up(span, 4) + 2 * NC * 2 + 4 + NFFT + (size_t)FPW * (16 * 17 * 2 + NC * 2) +
+                       (size_t)FPW * d->n_mels) * sizeof(float);
+  if (lds1 > 160 * 1024) return TS_EUNSUPPORTED;
+  if (lds1 > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(stft_mel_kernel, dim3(nwg, d->batch), dim3(256), lds1, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+
+  NormArgs n{};
+  n.logmel = a.logmel; n.partial = a.partial; n.feat_len = feat_len; n.out = static_cast<unsigned short*>(features);
+  n.n_mels = d->n_mels; n.n_frames = d->n_frames; n.nwg = nwg; n.pitch = d->pitch_out;
+  const size_t lds2 = ((size_t)2 * d->n_mels + (size_t)NTF * (d->n_mels + 1)) * sizeof(float);
+  hipLaunchKernelGGL(normalize_kernel, dim3((d->pitch_out + NTF - 1) / NTF, d->batch), dim3(256), lds2, stream, n);
+  return hip_status(hipGetLastError());
+}

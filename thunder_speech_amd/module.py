@@ -1,0 +1,118 @@
+"""BaseCTCModule -- the plugin surface of the reference's src/thunder/module.py:25-189.
+
+Subclasses pytorch_lightning.LightningModule when Lightning is installed (it is not in this image), otherwise a
+plain nn.Module with the same methods, so `pl.Trainer.fit` keeps working where available."""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .ctc_loss import calculate_ctc
+from .text_processing.transform import BatchTextTransformer
+
+try:  # optional dependency of the reference
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - Lightning is absent in the build image
+    pl = None
+    _Base = nn.Module
+
+
+def greedy_decode(logits: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """argmax over classes + run-collapse on the GPU.  logits [B, V, T'] fp32 -> (ids [B, T'], collapsed [B, T'],
+    counts [B]) int32."""
+    if not logits.is_cuda:
+        raise RuntimeError("greedy_decode: GPU tensors required (no CPU fallback)")
+    b, v, t = logits.shape
+    lg = logits
+    if lg.dtype != torch.float32 or lg.stride(2) != 1 or lg.stride(0) != v * lg.stride(1):
+        lg = lg.to(torch.float32).contiguous()
+    ids = torch.empty(b, t, dtype=torch.int32, device=lg.device)
+    collapsed = torch.empty(b, t, dtype=torch.int32, device=lg.device)
+    counts = torch.empty(b, dtype=torch.int32, device=lg.device)
+    st = _lib.lib().ts_greedy_decode(lg.data_ptr(), b, v, t, lg.stride(1), ids.data_ptr(), collapsed.data_ptr(),
+                                     counts.data_ptr(), torch.cuda.current_stream(lg.device).cuda_stream)
+    _lib.check(st, "ts_greedy_decode")
+    return ids, collapsed, counts
+
+
+class BaseCTCModule(_Base):
+    def __init__(self, encoder: nn.Module, decoder: nn.Module, audio_transform: nn.Module,
+                 text_transform: BatchTextTransformer, optimizer_class=torch.optim.AdamW, optimizer_kwargs: Dict = None,
+                 lr_scheduler_class=None, lr_scheduler_kwargs: Dict = None, encoder_final_dimension: int = None):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.audio_transform = audio_transform
+        self.text_transform = text_transform
+        self.optimizer_class = optimizer_class
+        self.optimizer_kwargs = optimizer_kwargs or {}
+        self.lr_scheduler_class = lr_scheduler_class
+        self.lr_scheduler_kwargs = lr_scheduler_kwargs or {}
+        self.lr_scheduler_interval = self.lr_scheduler_kwargs.pop("interval", "step")
+        self.encoder_final_dimension = encoder_final_dimension
+        try:
+            from torchmetrics import CharErrorRate, WordErrorRate
+            self.validation_cer, self.validation_wer = CharErrorRate(), WordErrorRate()
+        except Exception:  # torchmetrics absent: validation metrics are SURVEY 8f rank 4 (out of scope)
+            self.validation_cer = self.validation_wer = None
+        self.example_input_array = (torch.randn((10, 16000)), torch.randint(100, 16000, (10,)))
+
+    def forward(self, x: Tensor, lengths: Tensor) -> Tuple[Tensor, Optional[Tensor]]:
+        """[batch, time] audio -> (logits [batch, vocab, time'] BEFORE softmax, output lengths)."""
+        features, feature_lengths = self.audio_transform(x, lengths)
+        encoded, out_lengths = self.encoder(features, feature_lengths)
+        return self.decoder(encoded), out_lengths
+
+    def predict(self, x: Tensor) -> List[str]:
+        """Greedy transcription; every clip is treated as full length (module.py:98)."""
+        audio_lengths = torch.full((x.shape[0],), x.shape[-1], dtype=torch.int32, device=x.device)
+        pred, _ = self(x, audio_lengths)
+        _, collapsed, counts = greedy_decode(pred)
+        return self.text_transform.decode_collapsed(collapsed, counts)
+
+    def training_step(self, batch, batch_idx: int) -> torch.Tensor:
+        audio, audio_lengths, texts = batch
+        y, y_lengths = self.text_transform.encode(texts, device=audio.device)
+        probabilities, prob_lengths = self(audio, audio_lengths)
+        loss = calculate_ctc(probabilities, y, prob_lengths, y_lengths, self.text_transform.vocab.blank_idx)
+        if pl is not None:
+            self.log("loss/train_loss", loss)
+        return loss
+
+    def validation_step(self, batch, batch_idx: int) -> torch.Tensor:
+        audio, audio_lengths, texts = batch
+        y, y_lengths = self.text_transform.encode(texts, device=audio.device)
+        probabilities, prob_lengths = self(audio, audio_lengths)
+        loss = calculate_ctc(probabilities, y, prob_lengths, y_lengths, self.text_transform.vocab.blank_idx)
+        if self.validation_cer is not None:
+            _, collapsed, counts = greedy_decode(probabilities)
+            decoded_preds = self.text_transform.decode_collapsed(collapsed, counts)
+            decoded_targets = self.text_transform.decode_prediction(y, remove_repeated=False)
+            self.validation_cer(decoded_preds, decoded_targets)
+            self.validation_wer(decoded_preds, decoded_targets)
+        if pl is not None:
+            self.log("loss/val_loss", loss)
+            if self.validation_cer is not None:
+                self.log("metrics/cer", self.validation_cer, on_epoch=True)
+                self.log("metrics/wer", self.validation_wer, on_epoch=True)
+        return loss
+
+    def _update_special_optimizer_arg(self, original_kwargs: Dict) -> Dict:
+        updated_kwargs = original_kwargs.copy()
+        total_steps_arg = updated_kwargs.pop("total_steps_arg", None)
+        if total_steps_arg:
+            updated_kwargs[total_steps_arg] = self.trainer.estimated_stepping_batches
+        return updated_kwargs
+
+    def configure_optimizers(self) -> Union[torch.optim.Optimizer, Dict[str, Any]]:
+        optim_kwargs = self._update_special_optimizer_arg(self.optimizer_kwargs)
+        optimizer = self.optimizer_class(filter(lambda p: p.requires_grad, self.parameters()), **optim_kwargs)
+        if not self.lr_scheduler_class:
+            return optimizer
+        scheduler_kwargs = self._update_special_optimizer_arg(self.lr_scheduler_kwargs)
+        lr_scheduler = self.lr_scheduler_class(optimizer, **scheduler_kwargs)
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": lr_scheduler, "interval": self.lr_scheduler_interval}}

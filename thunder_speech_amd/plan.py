@@ -147,22 +147,23 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
 
     dw_w: [Cin, 1, K] or None (pointwise only); pw_w: [Cout, Cin, 1] or [Cout, Cin]; bn = (weight, bias,
     running_mean, running_var) or None (scale 1, shift 0; `bias_extra` then carries a conv bias)."""
-    pw2 = pw_w.reshape(pw_w.shape[0], pw_w.shape[1]).float()
+    cpu = lambda t: t.detach().to(device="cpu", dtype=torch.float32)      # packing is host-side index arithmetic
+    pw2 = cpu(pw_w).reshape(pw_w.shape[0], pw_w.shape[1])
     cout, cin = pw2.shape
     if bn is not None:
-        scale, shift = fold_bn(*[t.float() for t in bn])
+        scale, shift = fold_bn(*[cpu(t) for t in bn])
     else:
         scale, shift = torch.ones(cout), torch.zeros(cout)
     if bias_extra is not None:
-        shift = shift + bias_extra.float() * scale
+        shift = shift + cpu(bias_extra) * scale
     wf = pw2 * scale[:, None]
     taps, nk = (None, 0)
     if dw_w is not None:
-        taps, nk = pack_dw_taps(dw_w.float(), stride, dilation, padding)
+        taps, nk = pack_dw_taps(cpu(dw_w), stride, dilation, padding)
     c_res, res_p = 0, None
     if res_w is not None:
-        r2 = res_w.reshape(res_w.shape[0], res_w.shape[1]).float()
-        rs, rsh = fold_bn(*[t.float() for t in res_bn])
+        r2 = cpu(res_w).reshape(res_w.shape[0], res_w.shape[1])
+        rs, rsh = fold_bn(*[cpu(t) for t in res_bn])
         res_p = pack_pw_frags(r2 * rs[:, None]).to(device)
         shift = shift + rsh
         c_res = r2.shape[1]

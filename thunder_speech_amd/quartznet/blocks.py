@@ -1,0 +1,280 @@
+"""QuartzNet encoder -- same module tree, constructor signatures and state-dict keys as the reference's
+src/thunder/quartznet/blocks.py, executed as fused HIP launches.
+
+Reference tree per block (quartznet/blocks.py:231-315): `mconv` = [dw MaskedConv1d, pw MaskedConv1d, Masked(BN),
+Masked(ReLU), Masked(Dropout)] x repeat (the last repeat stops after BN), `res` = [1x1 MaskedConv1d, Masked(BN)],
+`mout` = [Masked(ReLU), Masked(Dropout)].  Here each repeat is ONE launch of ts_tcs_subblock_fwd (mask ->
+depthwise -> mask -> pointwise -> folded BN -> ReLU), the residual branch and the block's final ReLU are
+fused into the last repeat's launch.
+"""
+from __future__ import annotations
+
+from enum import Enum
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn.common_types import _size_1_t
+
+from .. import plan as _plan
+from .. import tensors as _t
+from ..blocks import Masked, MultiSequential, _PackedCache, get_same_padding
+
+__all__ = ["InitMode", "init_weights", "MaskedConv1d", "QuartznetBlock", "stem", "body", "QuartznetEncoder"]
+
+
+class InitMode(str, Enum):
+    xavier_uniform = "xavier_uniform"
+    xavier_normal = "xavier_normal"
+    kaiming_uniform = "kaiming_uniform"
+    kaiming_normal = "kaiming_normal"
+
+
+def init_weights(m: nn.Module, mode: InitMode = InitMode.xavier_uniform):
+    """reference quartznet/blocks.py:59-90"""
+    if isinstance(m, MaskedConv1d):
+        init_weights(m.conv, mode)
+    if isinstance(m, (nn.Conv1d, nn.Linear)):
+        if mode == InitMode.xavier_uniform:
+            nn.init.xavier_uniform_(m.weight, gain=1.0)
+        elif mode == InitMode.xavier_normal:
+            nn.init.xavier_normal_(m.weight, gain=1.0)
+        elif mode == InitMode.kaiming_uniform:
+            nn.init.kaiming_uniform_(m.weight, nonlinearity="relu")
+        elif mode == InitMode.kaiming_normal:
+            nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+        else:
+            raise ValueError(f"Unknown Initialization mode: {mode}")
+    elif isinstance(m, nn.BatchNorm1d):
+        if m.track_running_stats:
+            m.running_mean.zero_()
+            m.running_var.fill_(1)
+            m.num_batches_tracked.zero_()
+        if m.affine:
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+def _conv_len(lengths: torch.Tensor, k: int, s: int, p: int, d: int) -> torch.Tensor:
+    return torch.div(lengths + 2 * p - d * (k - 1) - 1, s, rounding_mode="floor") + 1
+
+
+class MaskedConv1d(nn.Module):
+    """Parameter holder with the reference's attributes (quartznet/blocks.py:93-182).  Standalone forward is
+    supported for depthwise (groups == channels) and 1x1 convolutions through the fused kernel."""
+    __constants__ = ["use_mask", "padding", "dilation", "kernel_size", "stride"]
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: _size_1_t, stride: _size_1_t = 1,
+                 padding: _size_1_t = 0, dilation: _size_1_t = 1, groups: int = 1, bias: bool = False,
+                 use_mask: bool = True):
+        super().__init__()
+        self.use_mask = use_mask
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, groups=groups, bias=bias)
+        self.padding = self.conv.padding[0]
+        self.dilation = self.conv.dilation[0]
+        self.kernel_size = self.conv.kernel_size[0]
+        self.stride = self.conv.stride[0]
+        self._cache = _PackedCache()
+
+    def get_seq_len(self, lengths: torch.Tensor) -> torch.Tensor:
+        return _conv_len(lengths, self.kernel_size, self.stride, self.padding, self.dilation)
+
+    def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        _t.require_gpu(x, "MaskedConv1d")
+        conv = self.conv
+        depthwise = conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1
+        if not depthwise and not (conv.groups == 1 and self.kernel_size == 1):
+            raise NotImplementedError("MaskedConv1d: only depthwise and 1x1 convolutions have HIP kernels "
+                                      "(dense K>1 convs are not on the QuartzNet/Citrinet hot path)")
+        tensors = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+
+        def build():
+            c = conv.out_channels
+            if depthwise:
+                return _plan.make_tcs_layer(conv.weight.device, dw_w=conv.weight.detach(), pw_w=torch.eye(c), bn=None,
+                                            kernel=self.kernel_size, stride=self.stride, dilation=self.dilation,
+                                            padding=self.padding, relu=False,
+                                            bias_extra=None if conv.bias is None else conv.bias.detach())
+            return _plan.make_tcs_layer(conv.weight.device, dw_w=None, pw_w=conv.weight.detach(), bn=None, kernel=1,
+                                        stride=self.stride, dilation=1, padding=0, relu=False,
+                                        bias_extra=None if conv.bias is None else conv.bias.detach())
+        layer = self._cache.get(tensors, build)
+        xi = _t.pack(x)
+        b, _, t = xi.shape
+        li = _t.lengths_i32(lengths, xi.device) if self.use_mask else torch.full((b,), t, dtype=torch.int32, device=xi.device)
+        y, t_out = layer.run(_t.backing(xi), t, li)
+        return y[:, :, :t_out], self.get_seq_len(lengths)
+
+
+def _get_conv_bn_layer(in_channels: int, out_channels: int, kernel_size: _size_1_t = 11, separable: bool = False,
+                       **conv_kwargs):
+    """reference quartznet/blocks.py:185-224"""
+    if separable:
+        layers = [
+            MaskedConv1d(in_channels, in_channels, kernel_size, groups=in_channels, **conv_kwargs),
+            MaskedConv1d(in_channels, out_channels, kernel_size=1, stride=1, dilation=1, padding=0,
+                         bias=conv_kwargs.get("bias", False)),
+        ]
+    else:
+        layers = [MaskedConv1d(in_channels, out_channels, kernel_size, **conv_kwargs)]
+    layers.append(Masked(nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.1)))
+    return layers
+
+
+def _get_act_dropout_layer(drop_prob: float = 0.2):
+    return [Masked(nn.ReLU(True)), Masked(nn.Dropout(p=drop_prob))]
+
+
+def _bn_tensors(bn: nn.BatchNorm1d):
+    return [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+
+
+class _FusedBlockBase(nn.Module):
+    """Shared executor of QuartznetBlock / CitrinetBlock: compiles `mconv`/`res` into TcsLayers."""
+
+    separable: bool
+    repeat: int
+
+    def _sub_blocks(self):
+        """Yield (dw_conv | None, pw_or_dense_conv, bn) for every repeat."""
+        step = 5 if self.separable else 4
+        for r in range(self.repeat):
+            base = r * step
+            if self.separable:
+                yield self.mconv[base], self.mconv[base + 1], self.mconv[base + 2].layer[0]
+            else:
+                yield None, self.mconv[base], self.mconv[base + 1].layer[0]
+
+    def _params(self) -> List[torch.Tensor]:
+        out = []
+        for dw, pw, bn in self._sub_blocks():
+            if dw is not None:
+                out.append(dw.conv.weight)
+            out.append(pw.conv.weight)
+            out.extend(_bn_tensors(bn))
+        if self.res is not None:
+            out.append(self.res[0].conv.weight)
+            out.extend(_bn_tensors(self.res[1].layer[0]))
+        return out
+
+    def _compile(self) -> List[_plan.TcsLayer]:
+        layers = []
+        subs = list(self._sub_blocks())
+        device = subs[0][1].conv.weight.device
+        for r, (dw, pw, bn) in enumerate(subs):
+            last = r == len(subs) - 1
+            geom = dw if dw is not None else pw
+            if dw is None and geom.kernel_size != 1:
+                raise NotImplementedError("non-separable blocks with kernel_size > 1 have no HIP kernel "
+                                          "(the reference models only use kernel_size=1 there)")
+            kw = dict(dw_w=None if dw is None else dw.conv.weight, pw_w=pw.conv.weight, bn=_bn_tensors(bn),
+                      kernel=geom.kernel_size, stride=geom.stride, dilation=geom.dilation, padding=geom.padding,
+                      relu=True)
+            if last and self._has_se():
+                kw["relu"] = False          # SE gate + residual + ReLU follow in separate launches
+            elif last and self.res is not None:
+                rc = self.res[0]
+                kw.update(res_w=rc.conv.weight, res_bn=_bn_tensors(self.res[1].layer[0]), res_stride=rc.stride)
+            layers.append(_plan.make_tcs_layer(device, **kw))
+        return layers
+
+    def _has_se(self) -> bool:
+        return False
+
+    def _check_eval(self):
+        if self.training:
+            raise NotImplementedError(
+                f"{type(self).__name__}: training-mode forward (batch-stat BatchNorm, dropout, backward) has no HIP "
+                "kernels yet -- call .eval(); see DESIGN.md 'out of scope this round'.")
+
+    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor):
+        _t.require_gpu(x, type(self).__name__)
+        self._check_eval()
+        layers = self._cache.get(self._params(), self._compile)
+        was_internal = _t.is_internal(x)
+        xi = _t.pack(x)
+        t = xi.shape[2]
+        x0 = _t.backing(xi)
+        len_in = _t.lengths_i32(lengths, xi.device)
+        h, th, lh = x0, t, len_in
+        out_lengths = lengths
+        subs = list(self._sub_blocks())
+        for r, layer in enumerate(layers):
+            geom = subs[r][0] if subs[r][0] is not None else subs[r][1]
+            kw = {}
+            if layer.c_res:
+                kw = dict(x_res=x0, t_res=t, len_res=len_in)
+            h, th = layer.run(h, th, lh, **kw)
+            if geom.stride != 1 or 2 * geom.padding != geom.dilation * (geom.kernel_size - 1):
+                out_lengths = geom.get_seq_len(out_lengths)          # only length-changing convs cost host work
+                lh = _t.lengths_i32(out_lengths, xi.device)
+        return h, th, lh, out_lengths, x0, t, len_in, was_internal
+
+
+class QuartznetBlock(_FusedBlockBase):
+    def __init__(self, in_channels: int, out_channels: int, repeat: int = 5, kernel_size: _size_1_t = (11,),
+                 stride: _size_1_t = (1,), dilation: _size_1_t = (1,), dropout: float = 0.0, residual: bool = True,
+                 separable: bool = False):
+        """Same arguments as the reference QuartznetBlock (quartznet/blocks.py:231-315)."""
+        super().__init__()
+        padding_val = get_same_padding(kernel_size[0], stride[0], dilation[0])
+        inplanes_loop = in_channels
+        conv = []
+        for _ in range(repeat - 1):
+            conv.extend(_get_conv_bn_layer(inplanes_loop, out_channels, kernel_size=kernel_size, stride=stride,
+                                           dilation=dilation, padding=padding_val, separable=separable, bias=False))
+            conv.extend(_get_act_dropout_layer(drop_prob=dropout))
+            inplanes_loop = out_channels
+        conv.extend(_get_conv_bn_layer(inplanes_loop, out_channels, kernel_size=kernel_size, stride=stride,
+                                       dilation=dilation, padding=padding_val, separable=separable, bias=False))
+        self.mconv = MultiSequential(*conv)
+        if residual:
+            stride_residual = stride if stride[0] == 1 else stride[0] ** repeat      # A8
+            self.res = MultiSequential(*_get_conv_bn_layer(in_channels, out_channels, kernel_size=1,
+                                                           stride=stride_residual, bias=False))
+        else:
+            self.res = None
+        self.mout = MultiSequential(*_get_act_dropout_layer(drop_prob=dropout))
+        self.separable = separable
+        self.repeat = repeat
+        self._cache = _PackedCache()
+
+    def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        h, th, _, out_lengths, _, _, _, was_internal = self._run_fused(x, lengths)
+        y = h[:, :, :th]
+        return (y if was_internal else _t.unpack(y)), out_lengths
+
+
+class EncoderSequential(MultiSequential):
+    def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        _t.require_gpu(audio, "encoder")
+        return super().forward(_t.pack(audio), audio_lengths)
+
+
+def stem(feat_in: int) -> QuartznetBlock:
+    return QuartznetBlock(feat_in, 256, repeat=1, stride=(2,), kernel_size=(33,), residual=False, separable=True)
+
+
+def body(filters: List[int], kernel_size: List[int], repeat_blocks: int = 1, dropout: float = 0.0) -> List[QuartznetBlock]:
+    layers = []
+    f_in = 256
+    for f, k in zip(filters, kernel_size):
+        for _ in range(repeat_blocks):
+            layers.append(QuartznetBlock(f_in, f, kernel_size=(k,), separable=True, dropout=dropout))
+            f_in = f
+    layers.extend([
+        QuartznetBlock(f_in, 512, repeat=1, dilation=(2,), kernel_size=(87,), residual=False, separable=True,
+                       dropout=dropout),
+        QuartznetBlock(512, 1024, repeat=1, kernel_size=(1,), residual=False, separable=False, dropout=dropout),
+    ])
+    return layers
+
+
+def QuartznetEncoder(feat_in: int = 64, filters: List[int] = [256, 256, 512, 512, 512],
+                     kernel_sizes: List[int] = [33, 39, 51, 63, 75], repeat_blocks: int = 1,
+                     dropout: float = 0.0) -> nn.Module:
+    """QuartzNet 5x5 (repeat_blocks=1) / 15x5 (repeat_blocks=3), reference quartznet/blocks.py:413-434.
+    Returns a MultiSequential (same keys "0.mconv.0.conv.weight" ...) that packs a reference-layout input once
+    and keeps the activations in the internal bf16 layout through all blocks."""
+    return EncoderSequential(stem(feat_in), *body(filters, kernel_sizes, repeat_blocks, dropout))

@@ -1,0 +1,176 @@
+"""Mel-filterbank front end -- reference names and constructor signature of
+src/thunder/quartznet/transform.py, executed by the fused HIP front end (csrc/frontend.hip).
+
+`FilterbankFeatures(...)` returns a MultiSequential with the reference's four children (so
+`filterbank[1].stft_func`, the "1.window" / "2.layer.0.fb" buffers and `patch_stft` keep working) whose
+forward is ONE call of ts_mel_frontend_fwd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from .. import tensors as _t
+from ..blocks import Masked, MultiSequential
+
+__all__ = ["FeatureBatchNormalizer", "DitherAudio", "PreEmphasisFilter", "PowerSpectrum", "MelScale",
+           "FilterbankFeatures", "patch_stft", "melscale_fbanks"]
+
+
+def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> torch.Tensor:
+    """Slaney-scale, slaney-normalised triangular filterbank [n_freqs, n_mels] -- what the reference obtains from
+    torchaudio.functional.melscale_fbanks(norm="slaney", mel_scale="slaney") (transform.py:227-236)."""
+    def hz_to_mel(f):
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) / (math.log(6.4) / 27.0), f * 3.0 / 200.0)
+
+    def mel_to_hz(m):
+        return np.where(m >= 15.0, 1000.0 * np.exp((math.log(6.4) / 27.0) * (m - 15.0)), m * 200.0 / 3.0)
+
+    freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
+    pts = mel_to_hz(np.linspace(hz_to_mel(np.float64(f_min)), hz_to_mel(np.float64(f_max)), n_mels + 2))
+    width = np.diff(pts)
+    rel = pts[None, :] - freqs[:, None]
+    fb = np.clip(np.minimum(-rel[:, :-2] / width[:-1], rel[:, 2:] / width[1:]), 0.0, None)
+    fb *= (2.0 / (pts[2:] - pts[:-2]))[None, :]
+    return torch.from_numpy(fb.astype(np.float32))
+
+
+class _FusedOnly(nn.Module):
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(f"{type(self).__name__} runs only fused inside FilterbankFeatures "
+                                  "(one HIP kernel computes pre-emphasis, STFT, mel and log together)")
+
+
+class FeatureBatchNormalizer(_FusedOnly):
+    def __init__(self):
+        super().__init__()
+        self.div_guard = 1e-5
+
+
+class DitherAudio(_FusedOnly):
+    def __init__(self, dither: float = 1e-5):
+        super().__init__()
+        self.dither = dither
+
+
+class PreEmphasisFilter(_FusedOnly):
+    def __init__(self, preemph: float = 0.97):
+        super().__init__()
+        self.preemph = preemph
+
+
+class PowerSpectrum(_FusedOnly):
+    def __init__(self, n_window_size: int = 320, n_window_stride: int = 160, n_fft: Optional[int] = None):
+        super().__init__()
+        if n_window_size <= 0 or n_window_stride <= 0:
+            raise ValueError(f"{self} got an invalid value for either n_window_size or n_window_stride. "
+                             "Both must be positive ints.")
+        self.win_length = n_window_size
+        self.hop_length = n_window_stride
+        self.n_fft = n_fft or 2 ** math.ceil(math.log2(self.win_length))
+        self.register_buffer("window", torch.hann_window(self.win_length, periodic=False))
+        self.stft_func = torch.stft          # kept for patch_stft(); the HIP front end does not call it
+
+    def get_sequence_length(self, lengths: torch.Tensor) -> torch.Tensor:
+        return (torch.floor(lengths / self.hop_length) + 1).to(dtype=torch.long)
+
+
+class MelScale(_FusedOnly):
+    def __init__(self, sample_rate: int, n_fft: int, nfilt: int, log_scale: bool = True):
+        super().__init__()
+        fb = melscale_fbanks(int(1 + n_fft // 2), 0.0, sample_rate / 2, nfilt, sample_rate).transpose(0, 1).unsqueeze(0)
+        self.register_buffer("fb", fb.contiguous())
+        self.log_scale = log_scale
+
+
+class _FilterbankFeatures(MultiSequential):
+    """MultiSequential(Masked(Dither, PreEmphasis), PowerSpectrum, Masked(MelScale), FeatureBatchNormalizer)."""
+
+    def _tables(self, device):
+        ps, mel = self[1], self[2].layer[0]
+        key = (str(device), ps.window.data_ptr(), ps.window._version, mel.fb.data_ptr(), mel.fb._version)
+        if getattr(self, "_tab_key", None) != key:
+            win = torch.zeros(ps.n_fft, dtype=torch.float32)
+            left = (ps.n_fft - ps.win_length) // 2
+            win[left:left + ps.win_length] = ps.window.detach().float().cpu()
+            fb = mel.fb.detach().float().cpu()[0]                       # [n_mels, n_freqs]
+            weights, offsets = [], []
+            for m in range(fb.shape[0]):
+                nz = torch.nonzero(fb[m]).flatten()
+                first = int(nz[0]) if len(nz) else 0
+                last = int(nz[-1]) + 1 if len(nz) else 0
+                offsets.append((first, len(weights)))
+                weights.extend(fb[m, first:last].tolist())
+            offsets.append((0, len(weights)))
+            self._tab = (win.to(device), torch.tensor(weights, dtype=torch.float32).to(device),
+                         torch.tensor(offsets, dtype=torch.int32).to(device), len(weights))
+            self._tab_key = key
+        return self._tab
+
+    def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        _t.require_gpu(audio, "FilterbankFeatures")
+        if self.training and self[0].layer[0].dither > 0:
+            raise NotImplementedError("FilterbankFeatures: training-mode dither has no HIP kernel yet; call .eval()")
+        if len(self) > 4:
+            raise NotImplementedError("SpecAugment / SpecCutout (training-only, SURVEY 8f rank 3) are not implemented")
+        ps, mel = self[1], self[2].layer[0]
+        if not mel.log_scale:
+            raise NotImplementedError("MelScale(log_scale=False)")
+        x = audio.to(torch.float32).contiguous()
+        b, n = x.shape
+        win, mw, moff, nnz = self._tables(x.device)
+        d = _lib.FrontendDesc()
+        d.batch, d.n_samples, d.n_fft, d.hop, d.win_length = b, n, ps.n_fft, ps.hop_length, ps.win_length
+        d.n_mels = mel.fb.shape[1]
+        d.preemph = float(self[0].layer[1].preemph)
+        d.n_frames = n // ps.hop_length + 1
+        d.pitch_out = _lib.time_pitch(d.n_frames)
+        d.window, d.mel_weights, d.mel_offsets, d.mel_nnz = win.data_ptr(), mw.data_ptr(), moff.data_ptr(), nnz
+        L = _lib.lib()
+        ws_bytes = L.ts_frontend_workspace_bytes(C.byref(d))
+        if ws_bytes < 0:
+            _lib.check(int(ws_bytes), "ts_frontend_workspace_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        feats = torch.empty(b, d.n_mels, d.pitch_out, dtype=torch.bfloat16, device=x.device)
+        flen = torch.empty(b, dtype=torch.int32, device=x.device)
+        wl = _t.lengths_i32(audio_lengths, x.device)
+        st = L.ts_mel_frontend_fwd(C.byref(d), x.data_ptr(), wl.data_ptr(), feats.data_ptr(), flen.data_ptr(),
+                                   ws.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(st, "ts_mel_frontend_fwd")
+        self._last_logmel = ws[: b * d.n_frames * d.n_mels * 4].view(torch.float32).view(b, d.n_frames, d.n_mels)
+        return feats[:, :, :d.n_frames], ps.get_sequence_length(audio_lengths)
+
+    def last_logmel(self) -> torch.Tensor:
+        """Parity hook: un-normalised log-mel [B, frames, n_mels] of the last forward (kernel-1 output)."""
+        return self._last_logmel
+
+
+def FilterbankFeatures(sample_rate: int = 16000, n_window_size: int = 320, n_window_stride: int = 160, n_fft: int = 512,
+                       preemph: float = 0.97, nfilt: int = 64, dither: float = 1e-5, num_cutout_masks: int = 0,
+                       num_time_masks: int = 0, num_freq_masks: int = 0, mask_time_width: int = 50,
+                       mask_freq_width: int = 20) -> nn.Module:
+    """Same signature as the reference (quartznet/transform.py:258-271)."""
+    if num_cutout_masks > 0 and (num_freq_masks + num_time_masks > 0):
+        raise ValueError("Cutout and SpecAugment can't be used at the same time.")
+    if num_cutout_masks > 0 or num_freq_masks + num_time_masks > 0:
+        raise NotImplementedError("SpecAugment / SpecCutout are training-only augmentations outside this round's "
+                                  "scope (SURVEY 8f rank 3); construct with the default 0 masks")
+    return _FilterbankFeatures(
+        Masked(DitherAudio(dither=dither), PreEmphasisFilter(preemph=preemph)),
+        PowerSpectrum(n_window_size=n_window_size, n_window_stride=n_window_stride, n_fft=n_fft),
+        Masked(MelScale(sample_rate=sample_rate, n_fft=n_fft, nfilt=nfilt)),
+        FeatureBatchNormalizer(),
+    )
+
+
+def patch_stft(filterbank: nn.Module) -> nn.Module:
+    """Reference hook for FFT-less export targets (transform.py:324-336).  The HIP front end has its own FFT, so
+    this only records the request."""
+    filterbank[1].stft_func = "convolution_stft"
+    return filterbank
