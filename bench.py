@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: QuartzNet15x5 inference, batch 64 x 15 s of 16 kHz audio per GPU, bf16 (BASELINE.json
+configs[1]).  One "step" = mel front end -> 78 fused TCS launches -> decoder -> argmax + run-collapse, inputs
+resident in HBM, replayed from a hipGraph.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Inference shards by clip (independent units, no collective on the data path):
+every rank runs its own 64-clip batch, scaling is "weak".  `roofline` is for the dominant kernel family
+(ts::tcs_kernel, all 78 launches of a step): algorithmic bytes (ideal fusion) / HIP-event time of the
+encoder segment.  `cpu_baseline` times the CPU oracle (a port of the reference path, fp32 torch-CPU ops) on a
+bounded sample of the same workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
+
+
+def build_model(device, seed=0):
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.utils import variance_preserving_init_
+    module = build_synthetic_quartznet(repeat_blocks=3)
+    variance_preserving_init_(module.encoder, module.decoder, seed=seed)
+    return module.to(device).eval()
+
+
+def encoder_layers(module):
+    layers = []
+    for blk in module.encoder:
+        layers.extend(blk._cache.get(blk._params(), blk._compile))
+    return layers
+
+
+def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16):
+    """Oracle (port of the reference path) on the host cores, bounded sample.  16 threads is where torch-CPU
+    peaks for this model on the GPU box's 256-core host (8: 117, 16: 167, 32: 104, 64: 73 audio-s/s measured);
+    more threads only add synchronisation overhead, so `cores` reports the threads actually used."""
+    from oracle import frontend as ofe
+    from oracle import tcs as otcs
+    from oracle import decode as odec
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
+    arch = otcs.quartznet_arch(repeat_blocks=3)
+    sd = {k: v.detach().cpu() for k, v in module.encoder.state_dict().items()}
+    dsd = {k: v.detach().cpu() for k, v in module.decoder.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    wav = 0.1 * torch.randn(clips, 16000 * seconds, generator=g)
+    lengths = torch.full((clips,), 16000 * seconds)
+
+    def run():
+        with torch.no_grad():
+            feats, fl = ofe.filterbank_features(wav, lengths)
+            enc, _ = otcs.encoder_forward(arch, sd, feats, fl)
+            logits = otcs.conv1d_decoder_forward(dsd, enc)
+            ids = logits.argmax(1).numpy()
+            return [odec.collapse_repeats(r) for r in ids]
+    run()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": clips * seconds / dt, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"QuartzNet15x5 fp32 oracle, {clips}x{seconds} s clips, {iters} timed passes after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seconds", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly from Python instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (this benchmark has no CPU path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from thunder_speech_amd.module import greedy_decode
+    from thunder_speech_amd.parallel import max_over_ranks
+    from thunder_speech_amd.utils import tcs_algorithmic_bytes
+    module = build_model(device)
+    B, S = args.batch, args.seconds
+    g = torch.Generator().manual_seed(1234 + rank)
+    wav = (0.1 * torch.randn(B, 16000 * S, generator=g)).to(device)
+    lengths = torch.full((B,), 16000 * S, dtype=torch.int32, device=device)
+
+    def step():
+        logits, _ = module(wav, lengths)
+        return greedy_decode(logits)
+
+    def encoder_only(feats, fl):
+        return module.encoder(feats, fl)
+
+    with torch.no_grad():
+        for _ in range(2):          # eager warm-up: packs weights, sizes the allocator, sets kernel attributes
+            out = step()
+        torch.cuda.synchronize()
+        feats, fl = module.audio_transform(wav, lengths)
+        side = torch.cuda.Stream(device)
+        if args.no_graph:
+            run_step = step
+            run_enc = lambda: encoder_only(feats, fl)
+        else:
+            g_step, g_enc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g_step, stream=side):
+                    out = step()
+                with torch.cuda.graph(g_enc, stream=side):
+                    enc_out = encoder_only(feats, fl)
+            run_step, run_enc = g_step.replay, g_enc.replay
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+
+        for _ in range(args.warmup):
+            run_step()
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        torch.cuda.synchronize(); barrier()
+        dt = time.perf_counter() - t0
+        dt = max_over_ranks(dt, device)
+
+        # dominant kernel family: the fused TCS launches of the encoder, timed with HIP events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        run_enc(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            run_enc()
+        e1.record(); torch.cuda.synchronize()
+        enc_ms = e0.elapsed_time(e1) / args.steps
+
+    layers = encoder_layers(module)
+    n_frames = 16000 * S // 160 + 1
+    alg_bytes, alg_flops, _ = tcs_algorithmic_bytes(layers, B, n_frames)
+    n_launch = len(layers)
+    achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
+    value = world * B * S * args.steps / dt
+    result = {
+        "metric": "audio-seconds/s (16 kHz) QuartzNet15x5 inference",
+        "value": value, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"QuartzNet15x5 inference, batch {B}x{S} s per GPU, 16 kHz synthetic clips "
+                               "(BASELINE.json configs[1]); step = mel front end + 78 fused TCS launches + decoder + "
+                               "greedy decode (argmax + collapse), hipGraph replay" if not args.no_graph else
+                               f"QuartzNet15x5 inference, batch {B}x{S} s per GPU (eager launches)",
+                   "batch_per_gpu": B, "clip_seconds": S, "random_init": True},
+        "roofline": {"bound": "hbm", "kernel": "ts::tcs_kernel (all fused TCS launches of one step)",
+                     "launches_per_step": n_launch,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes / n_launch, "avg_launch_us": enc_ms * 1e3 / n_launch,
+                     "encoder_ms": enc_ms, "mfma_tflops": alg_flops / (enc_ms * 1e-3) / 1e12,
+                     "mfma_frac_of_dense_bf16_peak": alg_flops / (enc_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(module)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

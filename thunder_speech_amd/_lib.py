@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
         raise RuntimeError(
             f"thunder_speech_amd: HIP extension {path} is missing. Build it with "
             "`python -m thunder_speech_amd.build` (needs hipcc / ROCm); there is no CPU fallback.")
+    import torch  # noqa: F401  -- must initialise its bundled HIP runtime BEFORE our code object is loaded
     L = C.CDLL(path)
     missing = [s for s in EXPORTED_SYMBOLS if not hasattr(L, s)]
     if missing:

@@ -171,9 +171,11 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
   a.lmax = 2 * s_max + 1; a.blank = blank;
   const size_t lds = ((size_t)2 * (a.lmax + 2) + a.lmax + n_classes) * sizeof(float);
   if (lds > 64 * 1024) return TS_EUNSUPPORTED;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(ctc_kernel, dim3(batch), dim3(64), lds, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, stream, nll, target_len, batch, s_max, loss);
   return hip_status(hipGetLastError());
 }

@@ -59,6 +59,7 @@ extern "C" int ts_greedy_decode(const float* logits, int32_t batch, int32_t n_cl
                                 int32_t* ids, int32_t* collapsed, int32_t* counts, void* stream) {
   if (!logits || !ids || !collapsed || !counts) return TS_EINVAL;
   if (batch <= 0 || n_classes <= 0 || n_frames <= 0 || pitch < n_frames) return TS_EINVAL;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(ts::greedy_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, logits, n_classes, n_frames,
                      pitch, ids, collapsed, counts);
   return ts::hip_status(hipGetLastError());

@@ -310,6 +310,7 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (e != hipSuccess) return (int)e;
   }
+  (void)hipGetLastError();
   hipLaunchKernelGGL(stft_mel_kernel, dim3(nwg, d->batch), dim3(256), lds1, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -318,6 +319,7 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   n.logmel = a.logmel; n.partial = a.partial; n.feat_len = feat_len; n.out = static_cast<unsigned short*>(features);
   n.n_mels = d->n_mels; n.n_frames = d->n_frames; n.nwg = nwg; n.pitch = d->pitch_out;
   const size_t lds2 = ((size_t)2 * d->n_mels + (size_t)NTF * (d->n_mels + 1)) * sizeof(float);
+  (void)hipGetLastError();
   hipLaunchKernelGGL(normalize_kernel, dim3((d->pitch_out + NTF - 1) / NTF, d->batch), dim3(256), lds2, stream, n);
   return hip_status(hipGetLastError());
 }

@@ -37,6 +37,7 @@ extern "C" int ts_pack_activation(const float* src, int32_t batch, int32_t chann
                                   void* stream) {
   if (!src || !dst || batch <= 0 || channels <= 0 || t <= 0 || pitch < t || pitch % 8) return TS_EINVAL;
   const long long n = (long long)batch * channels * (pitch / 8);
+  (void)hipGetLastError();
   hipLaunchKernelGGL(ts::pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                      (unsigned short*)dst, batch * channels, t, pitch);
   return ts::hip_status(hipGetLastError());
@@ -46,6 +47,7 @@ extern "C" int ts_unpack_activation(const void* src, int32_t batch, int32_t chan
                                     void* stream) {
   if (!src || !dst || batch <= 0 || channels <= 0 || t <= 0 || pitch < t) return TS_EINVAL;
   const long long n = (long long)batch * channels * t;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(ts::unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned short*)src, dst, batch * channels, t, pitch);
   return ts::hip_status(hipGetLastError());

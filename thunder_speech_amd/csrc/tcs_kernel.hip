@@ -424,6 +424,7 @@ static int launch(const TcsArgs& a, int batch, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  (void)hipGetLastError();
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
   return hip_status(hipGetLastError());
 }

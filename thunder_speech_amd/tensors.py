@@ -68,4 +68,12 @@ def lengths_i32(lengths: torch.Tensor, device) -> torch.Tensor:
     """Reference lengths may be float or int (A5); the kernels take floor()ed int32 on the device."""
     if lengths.dtype == torch.int32 and lengths.device == torch.device(device) and lengths.is_contiguous():
         return lengths
-    return lengths.to(device=device, dtype=torch.int64).to(torch.int32).contiguous()
+    cached = getattr(lengths, "_ts_i32", None)
+    if cached is not None and cached[0] == lengths._version and cached[1].device == torch.device(device):
+        return cached[1]
+    out = lengths.to(device=device, dtype=torch.int64).to(torch.int32).contiguous()
+    try:
+        lengths._ts_i32 = (lengths._version, out)     # the same tensor object flows through the length-preserving blocks
+    except Exception:
+        pass
+    return out

@@ -1,0 +1,65 @@
+"""Small host-side helpers: synthetic weights for benchmarks / smoke tests and workload accounting."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+from torch import nn
+
+
+def variance_preserving_init_(encoder: nn.Module, decoder: nn.Module = None, seed: int = 0) -> None:
+    """Random weights whose activations stay O(1) through an arbitrarily deep QuartzNet/Citrinet stack, so that
+    benchmarks run on realistic magnitudes (all-zero or vanishing activations let the chip clock higher and
+    would flatter the numbers).  depthwise ~ N(0, 1/K), pointwise ~ N(0, 2/Cin) (one ReLU per sub-block),
+    residual and main branch each scaled by 1/sqrt(2); BatchNorm: affine ~ (1 +- 0.1, +-0.1) and perturbed
+    running statistics so that BN folding is exercised.  No pretrained weights exist offline."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in encoder.named_parameters():
+            if name.endswith("conv.weight"):
+                cout, cin_g, k = p.shape
+                if cin_g == 1 and k >= 1 and cout > 1 and ".mconv." in name and _is_depthwise(encoder, name):
+                    std = math.sqrt(1.0 / k)
+                else:
+                    std = math.sqrt(2.0 / (cin_g * k))
+                    if ".res." in name:
+                        std = math.sqrt(1.0 / (cin_g * k))
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+        for name, m in encoder.named_modules():
+            if isinstance(m, nn.BatchNorm1d):
+                c = m.num_features
+                m.weight.copy_((1.0 + 0.1 * torch.randn(c, generator=g)) / math.sqrt(2.0))
+                m.bias.copy_(0.1 * torch.randn(c, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(c, generator=g))
+                m.running_var.copy_(0.8 + 0.4 * torch.rand(c, generator=g))
+        if decoder is not None:
+            for p in decoder.parameters():
+                if p.dim() >= 2:
+                    p.copy_(torch.randn(p.shape, generator=g) * (2.0 / math.sqrt(p.shape[1])))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+
+
+def _is_depthwise(encoder: nn.Module, param_name: str) -> bool:
+    mod = encoder
+    for part in param_name.split(".")[:-1]:
+        mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+    return isinstance(mod, nn.Conv1d) and mod.groups == mod.in_channels and mod.groups > 1
+
+
+def tcs_algorithmic_bytes(layers, batch: int, t_in: int) -> Tuple[int, int, List[Dict]]:
+    """Ideal-fusion HBM bytes and FLOPs of a list of fused TcsLayer launches: each launch reads its
+    input once (bf16), reads the residual input once, writes its output once; weights are L2-resident."""
+    total_b, total_f, rows = 0, 0, []
+    t = t_in
+    for layer in layers:
+        t_out = layer.out_size(t)
+        by = 2 * batch * (layer.c_in * t + layer.c_out * t_out + layer.c_res * t_out)
+        macs = batch * t_out * (layer.c_in * layer.c_out + layer.c_res * layer.c_out
+                                + (layer.c_in * layer.kernel if layer.depthwise else 0))
+        rows.append(dict(c_in=layer.c_in, c_out=layer.c_out, k=layer.kernel, bytes=by, flops=2 * macs, t_out=t_out))
+        total_b += by
+        total_f += 2 * macs
+        t = t_out
+    return total_b, total_f, rows
