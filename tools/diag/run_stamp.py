@@ -28,5 +28,5 @@ for s in range(n):
 c = d[0]
 print("consumer wave 0:")
 for s in range(n):
-    print(f"  stage {s}: wait-barrier {int(c[2+2*s])-int(c[1+2*s]):6d}  (barrier passed @{int(c[2+2*s])-base})   pw {int(c[1+2*(s+1)] if s+1<n else c[40])-int(c[2+2*s]):6d}")
-print(f"  epilogue: lds+issue stores {int(c[41])-int(c[40])}, store drain {int(c[42])-int(c[41])}, end@{int(c[42])-base}")
+    print(f"  stage {s}: wait-barrier {int(c[2+2*s])-int(c[1+2*s]):6d}  (barrier passed @{int(c[2+2*s])-base})   pw {int(c[1+2*(s+1)] if s+1<n else c[60])-int(c[2+2*s]):6d}")
+print(f"  epilogue {int(c[61])-int(c[60])}, end@{int(c[61])-base}")
