@@ -9,8 +9,9 @@
  * argument error, or a positive hipError_t value when a HIP call failed.  Nothing here allocates,
  * frees or synchronises, so every call can be captured into a hipGraph.
  *
- * Activation layout ("NCT-p"): [B][C][Tp] bf16, time contiguous, Tp = ts_time_pitch(T) (multiple of
- * 128); the reference's own [B, C, T] layout with a padded pitch.  Columns >= T are scratch.
+ * Activation layout ("NCT-p"): [B][C][Tp] bf16, time contiguous, Tp = ts_time_pitch(T) = round_up(T + 384, 128);
+ * the reference's own [B, C, T] layout with a padded pitch.  Columns >= T are scratch (or zero, see
+ * TS_TCS_IN_TAILZERO).
  */
 #ifndef THUNDER_SPEECH_AMD_H
 #define THUNDER_SPEECH_AMD_H
@@ -25,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 1
+#define TS_ABI_VERSION 2
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -56,11 +57,22 @@ typedef struct ts_tcs_desc {
   int32_t pitch_res, t_res, res_stride;
   /* prepacked parameters (see thunder_speech_amd/plan.py for the packers) */
   int32_t dw_ksteps;            /* NK: number of 4-sample k-steps in `dw_taps` (multiple of 3) */
+  int32_t flags;                /* TS_TCS_* bits below */
   const void* dw_taps;          /* bf16 [c_in_pad64][4][4*NK]   shifted Toeplitz rows of the depthwise taps */
   const void* pw_w;             /* bf16 [c_out_pad32/32][c_in_pad64/16][64][8]  MFMA B-fragments of W*bn_scale */
   const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */
 } ts_tcs_desc;
+
+/* ts_tcs_desc.flags
+ * TS_TCS_IN_TAILZERO : x (and x_res) satisfy the tail-zero invariant -- every row is 0 from its length to the pitch,
+ *   pitch >= ts_time_pitch(T) (which includes the slack the tiles over-read), and >= TS_GUARD_BYTES of zeros sit
+ *   before the first and after the last row of the buffer.  Lets the kernel skip every mask and bounds check.
+ * TS_TCS_OUT_ZERO_TAIL : store 0 for frames >= the output length, so that y satisfies the invariant for the next
+ *   launch (the reference leaves relu(bias) there, quirk A2; use 0 only for outputs the caller never exposes). */
+#define TS_TCS_IN_TAILZERO 1
+#define TS_TCS_OUT_ZERO_TAIL 2
+#define TS_GUARD_BYTES 1024
 
 /* x: bf16 [B][c_in][pitch_in]; len_in: int32 [B] valid frames of x (frames >= len are treated as 0,
  * quirk A2); x_res / len_res likewise for the residual input (may be NULL when c_res == 0);
@@ -119,8 +131,9 @@ int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes, int32_t n
 /* ------------------------------------------------------------------------------------------------
  * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].
  * ---------------------------------------------------------------------------------------------- */
-int ts_pack_activation(const float* src, int32_t batch, int32_t channels, int32_t t, void* dst_bf16, int32_t pitch,
-                       void* stream);
+/* len (may be NULL): int32 [B]; frames >= len[b] are written as 0 so that dst satisfies the tail-zero invariant. */
+int ts_pack_activation(const float* src, const int32_t* len, int32_t batch, int32_t channels, int32_t t, void* dst_bf16,
+                       int32_t pitch, void* stream);
 int ts_unpack_activation(const void* src_bf16, int32_t batch, int32_t channels, int32_t t, int32_t pitch,
                          float* dst, void* stream);
 

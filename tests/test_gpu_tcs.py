@@ -78,6 +78,55 @@ def test_pointwise_only_block_matches_oracle(cin, cout, t, lens):
     _run_case(cin, cout, 1, 1, 1, t, lens, False, separable=False)
 
 
+def _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, residual, seed=0):
+    """Same comparison through the mask-free kernels: tail-zero inputs (arena, guards) and zeroed output tails."""
+    from thunder_speech_amd import plan, tensors as TS
+    spec = otcs.BlockSpec(cin, cout, repeat=1, kernel=k, stride=stride, dilation=dil, residual=residual)
+    sd = {key[2:]: v for key, v in otcs.synth_encoder_state([spec], seed=seed).items()}
+    g = torch.Generator().manual_seed(seed)
+    x = bf16_round(torch.randn(len(lens), cin, t, generator=g))
+    lengths = torch.tensor(lens)
+    ref, ref_len = otcs.block_forward(spec, sd, "", x, lengths, emulate_bf16=True)
+    pad = same_padding(k, stride, dil)
+    bn = [sd["mconv.2.layer.0." + n] for n in ("weight", "bias", "running_mean", "running_var")]
+    kw = dict(dw_w=sd["mconv.0.conv.weight"], pw_w=sd["mconv.1.conv.weight"], bn=bn, kernel=k, stride=stride,
+              dilation=dil, padding=pad, relu=True)
+    if residual:
+        kw.update(res_w=sd["res.0.conv.weight"], res_stride=spec.residual_stride,
+                  res_bn=[sd["res.1.layer.0." + n] for n in ("weight", "bias", "running_mean", "running_var")])
+    layer = plan.make_tcs_layer("cuda", **kw)
+    li = lengths.to(torch.int32).cuda()
+    xi = TS.pack(x.cuda(), li, slot=("t", seed))
+    assert TS.is_tail_zero(xi)
+    xb = TS.backing(xi)
+    t_out = layer.out_size(t)
+    out = TS.arena(("to", seed), len(lens), cout, t_out, "cuda")
+    out.fill_(3.0)                                     # stale data from an earlier use must be overwritten
+    y, _ = layer.run(xb, t, li, x_res=xb if residual else None, t_res=t, len_res=li if residual else None, out=out,
+                     in_tail_zero=True, zero_tail=True)
+    torch.cuda.synchronize()
+    got = y[:, :, :t_out].float().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    for b, n in enumerate(ref_len.tolist()):
+        n = int(n)
+        assert float((got[b, :, :n] - ref[b, :, :n]).abs().max()) <= 0.012 * scale
+        assert float(got[b, :, n:].abs().max()) == 0.0 if n < t_out else True      # tail-zero invariant on the output
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,dil,t,lens,res", [
+    (256, 256, 33, 1, 1, 751, [751, 600, 13], True),
+    (256, 256, 39, 1, 1, 300, [300, 299], False),
+    (256, 512, 51, 1, 1, 300, [300, 211], True),
+    (512, 512, 75, 1, 1, 200, [200, 1], True),
+    (512, 512, 63, 1, 1, 751, [751, 640], False),
+    (64, 256, 33, 2, 1, 1501, [1501, 1000], False),
+    (512, 512, 87, 1, 2, 260, [260, 129], False),
+    (64, 64, 5, 1, 1, 128, [128, 100], False),
+])
+def test_tail_zero_fast_kernels_match_oracle(cin, cout, k, stride, dil, t, lens, res):
+    _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, res)
+
+
 def test_padding_region_never_leaks():
     """Frames >= length and the pitch padding are poisoned in the input; outputs must not change."""
     got1, _ = _run_case(64, 64, 33, 1, 1, 200, [200, 120], True, seed=3)

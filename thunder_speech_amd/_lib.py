@@ -12,6 +12,10 @@ from typing import Optional
 from .build import lib_path
 
 _lib: Optional[C.CDLL] = None
+ABI_VERSION = 2
+TCS_IN_TAILZERO = 1
+TCS_OUT_ZERO_TAIL = 2
+GUARD_BYTES = 1024
 
 EXPORTED_SYMBOLS = [
     "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd",
@@ -29,7 +33,7 @@ class TcsDesc(C.Structure):
         ("kernel", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32), ("padding", C.c_int32),
         ("depthwise", C.c_int32), ("relu", C.c_int32), ("out_fp32", C.c_int32),
         ("c_res", C.c_int32), ("pitch_res", C.c_int32), ("t_res", C.c_int32), ("res_stride", C.c_int32),
-        ("dw_ksteps", C.c_int32),
+        ("dw_ksteps", C.c_int32), ("flags", C.c_int32),
         ("dw_taps", C.c_void_p), ("pw_w", C.c_void_p), ("res_w", C.c_void_p), ("bias", C.c_void_p),
     ]
 
@@ -81,11 +85,11 @@ def lib() -> C.CDLL:
     L.ts_ctc_workspace_bytes.restype = i64
     L.ts_ctc_loss.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.ts_ctc_loss.restype = C.c_int
-    L.ts_pack_activation.argtypes = [vp, i32, i32, i32, vp, i32, vp]
+    L.ts_pack_activation.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
     L.ts_pack_activation.restype = C.c_int
     L.ts_unpack_activation.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     L.ts_unpack_activation.restype = C.c_int
-    if L.ts_abi_version() != 1:
+    if L.ts_abi_version() != ABI_VERSION:
         raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")
     _lib = L
     return L
@@ -103,4 +107,4 @@ def check(status: int, what: str) -> None:
 
 def time_pitch(t: int) -> int:
     """Python mirror of ts_time_pitch (kept in sync by tests/test_capi.py)."""
-    return ((max(int(t), 1) + 127) // 128) * 128
+    return ((max(int(t), 1) + 384 + 127) // 128) * 128

@@ -67,6 +67,7 @@ struct TcsArgs {
   int kt_main, kt_res;         // k-steps (16 channels) in the packed weights = c_pad64 / 16
   int taps_lds;                // 1: taps of the stage are cached in LDS
   int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
+  int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
 #ifdef TS_STAMP
   long long* dbg;              // diagnostic build only: s_memtime stamps of one workgroup
 #endif
@@ -111,7 +112,7 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {
 #define STAMP(slot) do { } while (0)
 #endif
 
-template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS>
+template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS, bool TZ, int XJ>
 __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
   constexpr int MT = TT / 32;     // 32-frame MFMA row tiles
   constexpr int M = TT / 16;      // 4-frame steps per lane run (4 runs per channel)
@@ -150,9 +151,134 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
     const char* const xrow = xs_w + ((size_t)(cw - pv * 16) * a.xpitch + a.woff + q * RUN * STRIDE) * 2;
     const bool chan_full = (a.c_in % KC) == 0;
 
-    u32x4 X[2][XMAX];
+    u32x4 X[2][TZ ? (XJ > 0 ? XJ : 1) : XMAX];
     u32x2 T[NKMAX];
     u32x4 I[2][IDJ];
+
+    if constexpr (TZ) {
+      // ---------------------------------------------------------------------------------------------------
+      // Tail-zero input (every row is 0 from its length to the pitch, pitch has slack, buffer has guards):
+      // no masks, no predicates, no bounds checks -- negative frames read the previous row's zero tail.
+      // The stage stream is flat over (tile, source, chunk); loads run one stage ahead ACROSS tile boundaries.
+      // ---------------------------------------------------------------------------------------------------
+      struct Cursor { int tile, s; };                       // s: stage inside the tile (main chunks, then residual chunks)
+      auto advance = [&](Cursor c) { ++c.s; if (c.s == n_stage) { c.s = 0; c.tile += tile_step; } return c; };
+      auto tile_b = [&](int tile) { return (tile / a.n_tt) / a.n_z; };
+      auto tile_t0 = [&](int tile) { return (tile % a.n_tt) * TT; };
+      const size_t row8 = (size_t)8 * a.pitch_in;
+      const size_t lane_x = (size_t)(pv * 16 + r8) * a.pitch_in + sub * 8;          // DW staging, element offset of row r8
+      const size_t lane_t = ((size_t)(cw * 4 + q) * nk) * 4;
+      const size_t lane_r = (size_t)(pv * 16 + r8) * a.pitch_res + sub * 8;         // residual / identity staging
+      const size_t row8r = (size_t)8 * a.pitch_res;
+
+      auto issue = [&](Cursor c) {
+        if (c.tile >= a.n_tiles) return;
+        const int b = tile_b(c.tile), t0 = tile_t0(c.tile);
+        if (DW && c.s < n_main) {
+          const unsigned short* src = a.x + ((size_t)(b * a.c_in + c.s * KC) * a.pitch_in + (t0 * STRIDE - a.padl8)) + lane_x;
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) X[rr][j] = *reinterpret_cast<const u32x4*>(src + rr * row8 + j * 64);
+          if constexpr (TLDS) {
+            const unsigned short* tp = a.taps + (size_t)c.s * KC * 4 * nk * 4 + lane_t;
+#pragma unroll
+            for (int p = 0; p < NKMAX / NKP; ++p)
+              if (p < a.npass) {
+#pragma unroll
+                for (int k = 0; k < NKP; ++k) T[p * NKP + k] = *reinterpret_cast<const u32x2*>(tp + (p * NKP + k) * 4);
+              }
+          }
+        } else {
+          const bool main = !DW && c.s < n_main;
+          const unsigned short* base = main ? a.x : a.xres;
+          const int ctot = main ? a.c_in : a.c_res;
+          const size_t pitch = main ? (size_t)a.pitch_in : (size_t)a.pitch_res;
+          const int chunk = main ? c.s : c.s - n_main;
+          const unsigned short* src = base + ((size_t)(b * ctot + chunk * KC + pv * 16 + r8) * pitch + t0 + sub * 8);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < IDJ; ++j) I[rr][j] = *reinterpret_cast<const u32x4*>(src + rr * 8 * pitch + j * 64);
+        }
+      };
+
+      unsigned gs = 0;
+      Cursor cur{(int)blockIdx.x, 0};
+      issue(cur);
+      while (cur.tile < a.n_tiles) {
+        char* const dst = dwt + (gs & 1) * Tile::BYTES;
+        const Cursor nxt = advance(cur);
+        if (DW && cur.s < n_main) {
+          // staged registers -> wave-private LDS rows
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            char* const dstb = rr ? xw1 : xw0;
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+              u32x2* d2 = reinterpret_cast<u32x2*>(dstb + j * 128);
+              d2[0] = u32x2{X[rr][j][0], X[rr][j][1]};
+              d2[1] = u32x2{X[rr][j][2], X[rr][j][3]};
+            }
+          }
+          if constexpr (TLDS) {
+#pragma unroll
+            for (int p = 0; p < NKMAX / NKP; ++p)
+              if (p < a.npass) {
+#pragma unroll
+                for (int k = 0; k < NKP; ++k) *reinterpret_cast<u32x2*>(tl_w + ((p * NKP + k) * 64 + lane) * 8) = T[p * NKP + k];
+              }
+          }
+          issue(nxt);
+          // depthwise FIR, LDS reads of pass p+1 issued before the MFMAs of pass p
+          f32x4 d[M];
+#pragma unroll
+          for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const unsigned short* tp = a.taps + (size_t)cur.s * KC * 4 * nk * 4 + lane_t;
+          s16x4 A0[NKP], A1[NKP], P0[NPP], P1[NPP];
+          auto load_pass = [&](int pass, s16x4 (&A)[NKP], s16x4 (&P)[NPP]) {
+#pragma unroll
+            for (int k = 0; k < NKP; ++k) {
+              if constexpr (TLDS) A[k] = *reinterpret_cast<const s16x4*>(tl_w + ((pass * NKP + k) * 64 + lane) * 8);
+              else A[k] = *reinterpret_cast<const s16x4*>(tp + (pass * NKP + k) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NPP; ++u) P[u] = *reinterpret_cast<const s16x4*>(xrow + (pass * NKP + u) * 8);
+          };
+          auto mfma_pass = [&](const s16x4 (&A)[NKP], const s16x4 (&P)[NPP]) {
+#pragma unroll
+            for (int k = 0; k < NKP; ++k)
+#pragma unroll
+              for (int m = 0; m < M; ++m)
+                d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A[k], P[m * STRIDE + k], d[m], 0, 0, 0);
+          };
+          load_pass(0, A0, P0);
+          for (int pass = 0; pass < a.npass; pass += 2) {
+            if (pass + 1 < a.npass) load_pass(pass + 1, A1, P1);
+            mfma_pass(A0, P0);
+            if (pass + 1 < a.npass) {
+              if (pass + 2 < a.npass) load_pass(pass + 2, A0, P0);
+              mfma_pass(A1, P1);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < M; ++m)
+            *reinterpret_cast<u32x2*>(dst + Tile::addr(cw, q * RUN + 4 * m)) =
+                u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < IDJ; ++j)
+              *reinterpret_cast<u32x4*>(dst + Tile::addr(pv * 16 + r8 + 8 * rr, (sub + 8 * j) * 8)) = I[rr][j];
+          issue(nxt);
+        }
+        stage_barrier();
+        cur = nxt;
+        ++gs;
+      }
+      return;
+    }
 
     unsigned gs = 0;                             // global stage counter of this workgroup (selects the dwt buffer)
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
@@ -368,13 +494,17 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
     const int t0 = tt * TT;
     const int cot0 = (z * 4 + wave) * NT;          // first 32-channel output tile of this wave
 
+    // the accumulators start at the (BN-folded) bias of the lane's output channel: no add in the epilogue
     f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j) {
+      const int col = (cot0 + j) * 32 + (lane & 31);
+      const float bv = a.bias[col < a.c_out ? col : 0];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
 
     // weight-fragment ring, RING k-steps deep: k-step gk = 4 * stage + ks.  Loads are branch-free (indices
     // clamped to valid memory; a clamped fragment is never used, or feeds a tile that is never stored) so the
@@ -432,14 +562,13 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       for (int nt = 0; nt < NT; ++nt) {
         const int co = (cot0 + nt) * 32 + (lane & 31);
         if (co < a.c_out) {
-          const float bv = a.bias[co];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               const int t = t0 + 32 * mt + 8 * rg + 4 * h;
-              float v0 = acc[mt][nt][4 * rg + 0] + bv, v1 = acc[mt][nt][4 * rg + 1] + bv;
-              float v2 = acc[mt][nt][4 * rg + 2] + bv, v3 = acc[mt][nt][4 * rg + 3] + bv;
+              float v0 = acc[mt][nt][4 * rg + 0], v1 = acc[mt][nt][4 * rg + 1];
+              float v2 = acc[mt][nt][4 * rg + 2], v3 = acc[mt][nt][4 * rg + 3];
               if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
               if (t < a.pitch_out)
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + (size_t)(b * a.c_out + co) * a.pitch_out + t) =
@@ -453,19 +582,34 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       // 32-channel output tile so that the global stores are whole 16-B-per-lane row segments (the accumulator
       // layout gives 8 B per lane in 64 different rows per instruction, which is TA-issue-bound).
       unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
+      // ReLU as a packed signed-16-bit max against `floor`: 0 clamps negative bf16 to +0, 0x8000 is a no-op
+      const unsigned floor2 = a.relu ? 0u : 0x80008000u;
+      // frames >= the output length are stored as 0 when the caller asks for the tail-zero invariant
+      int len_out = 0x7fffffff;
+      if (a.zero_tail) {
+        len_out = a.len_in[b];
+        if (DW) len_out = conv_len(len_out, a.kernel, STRIDE, a.padding, a.dilation);
+        else if (STRIDE > 1) len_out = conv_len(len_out, 1, STRIDE, 0, 1);
+      }
+      const bool partial = t0 + TT > len_out;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int cob = (cot0 + nt) * 32;
-        const int col = cob + (lane & 31);
-        const float bv = a.bias[col < a.c_out ? col : 0];
         char* const row = et + (size_t)(lane & 31) * EP + 8 * h;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            unsigned lo = pack_bf16(acc[mt][nt][4 * rg + 0] + bv, acc[mt][nt][4 * rg + 1] + bv);
-            unsigned hi = pack_bf16(acc[mt][nt][4 * rg + 2] + bv, acc[mt][nt][4 * rg + 3] + bv);
-            if (a.relu) { lo = relu_bf16x2(lo); hi = relu_bf16x2(hi); }
+            float v0 = acc[mt][nt][4 * rg + 0], v1 = acc[mt][nt][4 * rg + 1];
+            float v2 = acc[mt][nt][4 * rg + 2], v3 = acc[mt][nt][4 * rg + 3];
+            if (partial) {
+              const int t = t0 + 32 * mt + 8 * rg + 4 * h;
+              v0 = t + 0 < len_out ? v0 : 0.f; v1 = t + 1 < len_out ? v1 : 0.f;
+              v2 = t + 2 < len_out ? v2 : 0.f; v3 = t + 3 < len_out ? v3 : 0.f;
+            }
+            const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
+            const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(v0, v1)), f2));
+            const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(v2, v3)), f2));
             *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
           }
         }
@@ -485,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
   }
 }
 
-template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS = false>
+template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS = false, bool TZ = false, int XJ = 0>
 static int launch(TcsArgs& a, hipStream_t stream) {
   constexpr int CO_WG = 4 * NT * 32;
   a.n_tt = (a.t_out + TT - 1) / TT;
@@ -494,7 +638,7 @@ static int launch(TcsArgs& a, hipStream_t stream) {
   size_t lds = (size_t)2 * KC * TT * 2 + (size_t)4 * 32 * (TT * 2 + 16);
   if (DW) lds += (size_t)KC * a.xpitch * 2 + (a.taps_lds ? (size_t)4 * a.npass * NKP * 512 : 0);
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = tcs_kernel<TT, NT, STRIDE, DW, OUT_F32, TLDS>;
+  auto kern = tcs_kernel<TT, NT, STRIDE, DW, OUT_F32, TLDS, TZ, XJ>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -514,7 +658,7 @@ static int launch(TcsArgs& a, hipStream_t stream) {
 
 }  // namespace ts
 
-extern "C" int ts_time_pitch(int T) { return ts::round_up(T < 1 ? 1 : T, 128); }
+extern "C" int ts_time_pitch(int T) { return ts::round_up((T < 1 ? 1 : T) + 384, 128); }
 
 extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const int32_t* len_in, const void* x_res,
                                    const int32_t* len_res, void* y, void* stream_) {
@@ -554,8 +698,15 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   a.kt_main = round_up(d->c_in, KC) / 16;
   a.kt_res = round_up(d->c_res > 0 ? d->c_res : 1, KC) / 16;
 
+  a.zero_tail = (d->flags & TS_TCS_OUT_ZERO_TAIL) ? 1 : 0;
   const bool wide = round_up(d->c_out, 32) > 256;   // 512-channel tiles for the wide layers
   const int TT = wide ? 64 : 128;
+  const int n_tt = (d->t_out + TT - 1) / TT;
+  // tail-zero fast kernels: rows are 0 from their length to the pitch, the pitch has slack for the tile
+  // overreach and the buffer has zero guards, so the producers need no mask, predicate or bounds check
+  // (they also skip the re-masking of the depthwise output, which is only invisible when the output tail is zeroed)
+  bool tz = (d->flags & TS_TCS_IN_TAILZERO) && (d->flags & TS_TCS_OUT_ZERO_TAIL) && !d->out_fp32 && d->c_in % KC == 0 &&
+            (d->c_res == 0 || (d->c_res % KC == 0 && a.res_stride == 1 && d->pitch_res >= n_tt * TT));
   if (d->depthwise) {
     a.npass = d->dw_ksteps / NKP;
     a.taps_lds = d->dw_ksteps <= NKMAX;
@@ -567,6 +718,16 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     a.xe = round_up(a.xuse, 64);
     if (a.xe > 64 * XMAX) return TS_EUNSUPPORTED;
     a.xpitch = a.xe + 4;                              // row pitch == 8 (mod 16) bytes: conflict-free window reads
+    const int xj = a.xe / 64;
+    tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
+    if (tz) {
+#define TS_TZ(TT_, NT_, S_, TL_, XJ_) \
+      if (TT == TT_ && d->stride == S_ && a.taps_lds == TL_ && xj == XJ_) return launch<TT_, NT_, S_, true, false, TL_, true, XJ_>(a, stream);
+      TS_TZ(128, 2, 1, true, 3) TS_TZ(128, 2, 1, true, 4)
+      TS_TZ(64, 4, 1, true, 2) TS_TZ(64, 4, 1, true, 3) TS_TZ(64, 4, 1, false, 4)
+      TS_TZ(128, 2, 2, true, 5) TS_TZ(64, 4, 2, true, 3)
+#undef TS_TZ
+    }
     if (a.taps_lds) {
       if (d->stride == 1)
         return wide ? launch<64, 4, 1, true, false, true>(a, stream) : launch<128, 2, 1, true, false, true>(a, stream);
@@ -581,8 +742,11 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     if (d->stride != 1) return TS_EUNSUPPORTED;
     return launch<128, 2, 1, false, true>(a, stream);
   }
-  if (d->stride == 1)
+  if (d->stride == 1) {
+    if (tz && d->pitch_in >= n_tt * TT)
+      return wide ? launch<64, 4, 1, false, false, false, true, 0>(a, stream) : launch<128, 2, 1, false, false, false, true, 0>(a, stream);
     return wide ? launch<64, 4, 1, false, false>(a, stream) : launch<128, 2, 1, false, false>(a, stream);
+  }
   if (d->stride == 2)
     return wide ? launch<64, 4, 2, false, false>(a, stream) : launch<128, 2, 2, false, false>(a, stream);
   return TS_EUNSUPPORTED;

@@ -106,8 +106,11 @@ class TcsLayer:
         return conv_out_size(t_in, self.kernel, self.stride, self.padding, self.dilation)
 
     def run(self, x: torch.Tensor, t_in: int, len_in: torch.Tensor, x_res: Optional[torch.Tensor] = None,
-            t_res: int = 0, len_res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-        """x: bf16 [B, c_in, pitch]; len_in int32 [B].  Returns (y [B, c_out, pitch_out], t_out)."""
+            t_res: int = 0, len_res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            in_tail_zero: bool = False, zero_tail: bool = False):
+        """x: bf16 [B, c_in, pitch]; len_in int32 [B].  Returns (y [B, c_out, pitch_out], t_out).
+        in_tail_zero: x (and x_res) satisfy the tail-zero invariant (tensors.py) -> mask-free kernels;
+        zero_tail: store 0 for frames >= the output length so that y satisfies it too."""
         if not x.is_cuda:
             raise RuntimeError("thunder_speech_amd kernels run on the GPU only (no CPU fallback)")
         L = _lib.lib()
@@ -128,6 +131,7 @@ class TcsLayer:
             d.pitch_res, d.t_res = x_res.shape[2], t_res
             d.res_w = self.res_w.data_ptr()
         d.dw_ksteps = self.nk
+        d.flags = (_lib.TCS_IN_TAILZERO if in_tail_zero else 0) | (_lib.TCS_OUT_ZERO_TAIL if zero_tail else 0)
         d.dw_taps = self.taps.data_ptr() if self.taps is not None else None
         d.pw_w = self.pw.data_ptr()
         d.bias = self.bias.data_ptr()

@@ -188,28 +188,45 @@ class _FusedBlockBase(nn.Module):
                 f"{type(self).__name__}: training-mode forward (batch-stat BatchNorm, dropout, backward) has no HIP "
                 "kernels yet -- call .eval(); see DESIGN.md 'out of scope this round'.")
 
-    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor):
+    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=0):
+        """Run the block's launches.  `internal=True` (set by the encoder for every block but the last): the block
+        output is never shown to the caller, so it is written into a library-owned arena buffer with frames >=
+        length zeroed (tail-zero invariant) and the next block runs mask-free.  The last sub-block of a
+        caller-visible block keeps the reference's values beyond the length (quirk A2) in a fresh buffer."""
         _t.require_gpu(x, type(self).__name__)
         self._check_eval()
         layers = self._cache.get(self._params(), self._compile)
         was_internal = _t.is_internal(x)
-        xi = _t.pack(x)
-        t = xi.shape[2]
+        xi = x if was_internal else _t.pack(x, lengths, slot=("blk", id(self)))
+        x0_tz = h_tz = _t.is_tail_zero(xi)
+        b, _, t = xi.shape
         x0 = _t.backing(xi)
         len_in = _t.lengths_i32(lengths, xi.device)
         h, th, lh = x0, t, len_in
         out_lengths = lengths
         subs = list(self._sub_blocks())
+        n = len(layers)
         for r, layer in enumerate(layers):
             geom = subs[r][0] if subs[r][0] is not None else subs[r][1]
-            kw = {}
+            last = r == n - 1
+            keep_tail = last and not internal          # caller-visible: reference values beyond the length
+            t_out = layer.out_size(th)
+            if keep_tail:
+                out = _t.alloc(b, layer.c_out, t_out, xi.device)
+            else:
+                out = _t.arena(("enc", slot, r % 2), b, layer.c_out, t_out, xi.device)
+            kw = dict(out=out, in_tail_zero=h_tz and (x0_tz or not layer.c_res), zero_tail=not keep_tail)
             if layer.c_res:
-                kw = dict(x_res=x0, t_res=t, len_res=len_in)
+                kw.update(x_res=x0, t_res=t, len_res=len_in)
             h, th = layer.run(h, th, lh, **kw)
+            h_tz = not keep_tail                         # arena buffer + zeroed tail -> invariant holds for the next launch
             if geom.stride != 1 or 2 * geom.padding != geom.dilation * (geom.kernel_size - 1):
                 out_lengths = geom.get_seq_len(out_lengths)          # only length-changing convs cost host work
                 lh = _t.lengths_i32(out_lengths, xi.device)
-        return h, th, lh, out_lengths, x0, t, len_in, was_internal
+        y = h[:, :, :th]
+        if internal:
+            _t.tag_tail_zero(y)
+        return y, out_lengths, was_internal
 
 
 class QuartznetBlock(_FusedBlockBase):
@@ -241,15 +258,25 @@ class QuartznetBlock(_FusedBlockBase):
         self._cache = _PackedCache()
 
     def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        h, th, _, out_lengths, _, _, _, was_internal = self._run_fused(x, lengths)
-        y = h[:, :, :th]
+        y, out_lengths, was_internal = self._run_fused(x, lengths)
         return (y if was_internal else _t.unpack(y)), out_lengths
 
 
 class EncoderSequential(MultiSequential):
+    """MultiSequential of fused blocks.  Packs a reference-layout input once (zeroing frames >= length), runs every
+    block but the last as `internal` (arena buffers, tail-zero outputs, mask-free kernels) and lets the last block
+    produce the caller-visible output with the reference's values beyond the length (quirk A2)."""
+
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "encoder")
-        return super().forward(_t.pack(audio), audio_lengths)
+        x = audio if _t.is_internal(audio) else _t.pack(audio, audio_lengths, slot=("enc", id(self)))
+        blocks = list(self.children())
+        for i, blk in enumerate(blocks):
+            if isinstance(blk, _FusedBlockBase):
+                x, audio_lengths, _ = blk._run_fused(x, audio_lengths, internal=i < len(blocks) - 1, slot=i % 2)
+            else:
+                x, audio_lengths = blk(x, audio_lengths)
+        return x, audio_lengths
 
 
 def stem(feat_in: int) -> QuartznetBlock:

@@ -137,14 +137,14 @@ class _FilterbankFeatures(MultiSequential):
         if ws_bytes < 0:
             _lib.check(int(ws_bytes), "ts_frontend_workspace_bytes")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-        feats = torch.empty(b, d.n_mels, d.pitch_out, dtype=torch.bfloat16, device=x.device)
+        feats = _t.arena(("feat", id(self)), b, d.n_mels, d.n_frames, x.device)   # normalize_kernel zeroes frames >= length up to the pitch
         flen = torch.empty(b, dtype=torch.int32, device=x.device)
         wl = _t.lengths_i32(audio_lengths, x.device)
         st = L.ts_mel_frontend_fwd(C.byref(d), x.data_ptr(), wl.data_ptr(), feats.data_ptr(), flen.data_ptr(),
                                    ws.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(st, "ts_mel_frontend_fwd")
         self._last_logmel = ws[: b * d.n_frames * d.n_mels * 4].view(torch.float32).view(b, d.n_frames, d.n_mels)
-        return feats[:, :, :d.n_frames], ps.get_sequence_length(audio_lengths)
+        return _t.tag_tail_zero(feats[:, :, :d.n_frames]), ps.get_sequence_length(audio_lengths)
 
     def last_logmel(self) -> torch.Tensor:
         """Parity hook: un-normalised log-mel [B, frames, n_mels] of the last forward (kernel-1 output)."""

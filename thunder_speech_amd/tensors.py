@@ -1,19 +1,27 @@
 """Activation containers at the Python boundary.
 
-Internal activations are bf16 [B, C, pitch] buffers (time contiguous, pitch = multiple of 128, see
+Internal activations are bf16 [B, C, pitch] buffers (time contiguous, pitch = ts_time_pitch(T), see
 include/thunder_speech_amd.h).  They travel between modules as ordinary torch views `buf[:, :, :T]`, so the
 reference's `(Tensor[B, C, T], lengths) -> (Tensor, lengths)` convention (blocks.py:94-115) is kept and a
 chain of blocks never copies; a plain fp32 [B, C, T] tensor (reference layout) is accepted anywhere and
 packed on entry.
+
+Tail-zero invariant.  Buffers handed out by `arena()` are zero-initialised ONCE, carry TS_GUARD_BYTES of zeros on
+both sides, and every kernel that writes into them stores 0 for frames >= the clip's length.  A view produced that
+way is tagged `_ts_tz = True`; launches whose inputs are all tagged run the mask-free fast kernels
+(TS_TCS_IN_TAILZERO).  Arena buffers are owned by the library and REUSED by later calls with the same shape --
+tensors the caller keeps (encoder output, logits) are therefore always freshly allocated instead.
 """
 from __future__ import annotations
 
-import ctypes as C
-from typing import Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
 from . import _lib
+
+_ARENA: Dict[Tuple, torch.Tensor] = {}
+_GUARD = _lib.GUARD_BYTES // 2          # elements (bf16)
 
 
 def require_gpu(x: torch.Tensor, what: str) -> None:
@@ -28,6 +36,15 @@ def is_internal(x: torch.Tensor) -> bool:
             and x.stride(1) >= x.shape[2] and x.stride(0) == x.shape[1] * x.stride(1) and x.data_ptr() % 16 == 0)
 
 
+def is_tail_zero(x: torch.Tensor) -> bool:
+    return bool(getattr(x, "_ts_tz", False)) and x.stride(1) >= _lib.time_pitch(x.shape[2])
+
+
+def tag_tail_zero(x: torch.Tensor) -> torch.Tensor:
+    x._ts_tz = True
+    return x
+
+
 def backing(x: torch.Tensor) -> torch.Tensor:
     """The full [B, C, pitch] buffer behind an internal view."""
     b, c, _ = x.shape
@@ -35,21 +52,40 @@ def backing(x: torch.Tensor) -> torch.Tensor:
 
 
 def alloc(b: int, c: int, t: int, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """Fresh (caller-owned) buffer; contents undefined."""
     return torch.empty(b, c, _lib.time_pitch(t), device=device, dtype=dtype)
 
 
-def pack(x: torch.Tensor) -> torch.Tensor:
-    """fp32/any [B, C, T] (reference layout) -> internal bf16 view [B, C, T]."""
+def arena(slot, b: int, c: int, t: int, device) -> torch.Tensor:
+    """Library-owned, zero-initialised, guarded bf16 buffer [B, C, pitch] for (slot, shape); reused across calls."""
+    pitch = _lib.time_pitch(t)
+    key = (slot, b, c, pitch, str(device))
+    flat = _ARENA.get(key)
+    if flat is None:
+        flat = torch.zeros(b * c * pitch + 2 * _GUARD, dtype=torch.bfloat16, device=device)
+        _ARENA[key] = flat
+    return flat[_GUARD: _GUARD + b * c * pitch].view(b, c, pitch)
+
+
+def release_arena() -> None:
+    _ARENA.clear()
+
+
+def pack(x: torch.Tensor, lengths: Optional[torch.Tensor] = None, slot="pack") -> torch.Tensor:
+    """fp32/any [B, C, T] (reference layout) -> internal bf16 view [B, C, T].  With `lengths` the frames >= length are
+    zeroed and the result satisfies the tail-zero invariant (it then lives in the arena)."""
     require_gpu(x, "pack")
     if is_internal(x):
         return x
     b, c, t = x.shape
     src = x.to(torch.float32).contiguous()
-    buf = alloc(b, c, t, x.device)
-    st = _lib.lib().ts_pack_activation(src.data_ptr(), b, c, t, buf.data_ptr(), buf.shape[2],
-                                       torch.cuda.current_stream(x.device).cuda_stream)
+    li = lengths_i32(lengths, x.device) if lengths is not None else None
+    buf = arena((slot, "in"), b, c, t, x.device) if li is not None else alloc(b, c, t, x.device)
+    st = _lib.lib().ts_pack_activation(src.data_ptr(), li.data_ptr() if li is not None else None, b, c, t,
+                                       buf.data_ptr(), buf.shape[2], torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(st, "ts_pack_activation")
-    return buf[:, :, :t]
+    out = buf[:, :, :t]
+    return tag_tail_zero(out) if li is not None else out
 
 
 def unpack(x: torch.Tensor) -> torch.Tensor:

@@ -15,21 +15,23 @@ def layer(cin, cout, k, res, stride=1, dil=1, separable=True):
         kw.update(res_w=torch.randn(cout, res, 1, generator=g) * 0.05, res_bn=bn, res_stride=1)
     return plan.make_tcs_layer("cuda", **kw)
 
-def bench(name, L, B, T, iters=20):
-    x = (torch.randn(B, L.c_in, _lib.time_pitch(T), device="cuda")).to(torch.bfloat16)
-    xr = (torch.randn(B, L.c_res, _lib.time_pitch(T // L.stride + 1), device="cuda")).to(torch.bfloat16) if L.c_res else None
+def bench(name, L, B, T, iters=20, tz=True):
+    from thunder_speech_amd import tensors as TS
     li = torch.full((B,), T, dtype=torch.int32, device="cuda")
     t_out = L.out_size(T)
     lr = torch.full((B,), t_out, dtype=torch.int32, device="cuda")
-    out, _ = L.run(x, T, li, xr, t_out, lr)
-    for _ in range(3): L.run(x, T, li, xr, t_out, lr, out=out)
+    x = TS.backing(TS.pack(torch.randn(B, L.c_in, T, device="cuda"), li, slot="bx"))          # tail-zero arena buffers
+    xr = TS.backing(TS.pack(torch.randn(B, L.c_res, t_out, device="cuda"), lr, slot="br")) if L.c_res else None
+    out = TS.arena("bo", B, L.c_out, t_out, "cuda")
+    run = lambda: L.run(x, T, li, xr, t_out, lr, out=out, in_tail_zero=tz, zero_tail=tz)
+    for _ in range(3): run()
     torch.cuda.synchronize()
     # capture the launches in a graph so that host (Python/ctypes) launch overhead is not measured
     gr = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         with torch.cuda.graph(gr, stream=side):
-            for _ in range(iters): L.run(x, T, li, xr, t_out, lr, out=out)
+            for _ in range(iters): run()
     gr.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -11,10 +11,12 @@ from thunder_speech_amd import _lib
 cin, cout, k = [int(v) for v in sys.argv[1:4]]
 L = layer(cin, cout, k, 0, separable=k > 1)
 Bn, T = 64, 751
-x = torch.randn(Bn, cin, _lib.time_pitch(T), device="cuda").to(torch.bfloat16)
+from thunder_speech_amd import tensors as TS
 li = torch.full((Bn,), T, dtype=torch.int32, device="cuda")
+x = TS.backing(TS.pack(torch.randn(Bn, cin, T, device="cuda"), li, slot="bx"))
+out = TS.arena("bo", Bn, cout, T, "cuda")
 for _ in range(3):
-    L.run(x, T, li)
+    L.run(x, T, li, out=out, in_tail_zero=True, zero_tail=True)
 torch.cuda.synchronize()
 d = dbg.cpu().view(8, 64)
 n = (cin + 63) // 64
