@@ -112,7 +112,7 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {
 #define STAMP(slot) do { } while (0)
 #endif
 
-template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS, bool TZ, int XJ>
+template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS, bool TZ, int XJ, int NPASS>
 __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
   constexpr int MT = TT / 32;     // 32-frame MFMA row tiles
   constexpr int M = TT / 16;      // 4-frame steps per lane run (4 runs per channel)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
     const bool chan_full = (a.c_in % KC) == 0;
 
     u32x4 X[2][TZ ? (XJ > 0 ? XJ : 1) : XMAX];
-    u32x2 T[NKMAX];
+    u32x2 T[TZ ? (NPASS > 0 ? NPASS * NKP : 1) : NKMAX];
     u32x4 I[2][IDJ];
 
     if constexpr (TZ) {
@@ -161,121 +161,140 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       // no masks, no predicates, no bounds checks -- negative frames read the previous row's zero tail.
       // The stage stream is flat over (tile, source, chunk); loads run one stage ahead ACROSS tile boundaries.
       // ---------------------------------------------------------------------------------------------------
-      struct Cursor { int tile, s; };                       // s: stage inside the tile (main chunks, then residual chunks)
-      auto advance = [&](Cursor c) { ++c.s; if (c.s == n_stage) { c.s = 0; c.tile += tile_step; } return c; };
-      auto tile_b = [&](int tile) { return (tile / a.n_tt) / a.n_z; };
-      auto tile_t0 = [&](int tile) { return (tile % a.n_tt) * TT; };
+      // Two independent prefetch streams, each with ONE issue site inside the loops (a register set that is written
+      // from several places costs a v_mov per register per stage to reconcile):
+      //   DW stream: X/T registers <- (tile, chunk) of the next depthwise stage, possibly of the NEXT tile
+      //   ID stream: I registers   <- next identity stage (residual chunk, or the main chunk of a pointwise-only layer)
       const size_t row8 = (size_t)8 * a.pitch_in;
       const size_t lane_x = (size_t)(pv * 16 + r8) * a.pitch_in + sub * 8;          // DW staging, element offset of row r8
       const size_t lane_t = ((size_t)(cw * 4 + q) * nk) * 4;
-      const size_t lane_r = (size_t)(pv * 16 + r8) * a.pitch_res + sub * 8;         // residual / identity staging
-      const size_t row8r = (size_t)8 * a.pitch_res;
+      const size_t chunk_x = (size_t)KC * a.pitch_in;
+      const size_t chunk_t = (size_t)KC * 4 * nk * 4;
+      const int n_id = DW ? n_res : n_stage;                                          // identity stages per tile
+      const size_t lane_i_main = (size_t)(pv * 16 + r8) * a.pitch_in + sub * 8;
+      const size_t lane_i_res = (size_t)(pv * 16 + r8) * a.pitch_res + sub * 8;
 
-      auto issue = [&](Cursor c) {
-        if (c.tile >= a.n_tiles) return;
-        const int b = tile_b(c.tile), t0 = tile_t0(c.tile);
-        if (DW && c.s < n_main) {
-          const unsigned short* src = a.x + ((size_t)(b * a.c_in + c.s * KC) * a.pitch_in + (t0 * STRIDE - a.padl8)) + lane_x;
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int j = 0; j < XJ; ++j) X[rr][j] = *reinterpret_cast<const u32x4*>(src + rr * row8 + j * 64);
-          if constexpr (TLDS) {
-            const unsigned short* tp = a.taps + (size_t)c.s * KC * 4 * nk * 4 + lane_t;
-#pragma unroll
-            for (int p = 0; p < NKMAX / NKP; ++p)
-              if (p < a.npass) {
-#pragma unroll
-                for (int k = 0; k < NKP; ++k) T[p * NKP + k] = *reinterpret_cast<const u32x2*>(tp + (p * NKP + k) * 4);
-              }
-          }
-        } else {
-          const bool main = !DW && c.s < n_main;
-          const unsigned short* base = main ? a.x : a.xres;
-          const int ctot = main ? a.c_in : a.c_res;
-          const size_t pitch = main ? (size_t)a.pitch_in : (size_t)a.pitch_res;
-          const int chunk = main ? c.s : c.s - n_main;
-          const unsigned short* src = base + ((size_t)(b * ctot + chunk * KC + pv * 16 + r8) * pitch + t0 + sub * 8);
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int j = 0; j < IDJ; ++j) I[rr][j] = *reinterpret_cast<const u32x4*>(src + rr * 8 * pitch + j * 64);
+      auto tile_origin = [&](int tile, int& b, int& t0) { b = (tile / a.n_tt) / a.n_z; t0 = (tile % a.n_tt) * TT; };
+
+      // ---- DW stream state: next stage to issue
+      int dw_tile = blockIdx.x, dw_chunk = 0;
+      const unsigned short* dw_src = nullptr;            // element pointer of (dw_tile, dw_chunk), lane part excluded
+      auto dw_seek = [&]() {                             // called when dw_tile changes
+        if (dw_tile < a.n_tiles) {
+          int b, t0; tile_origin(dw_tile, b, t0);
+          dw_src = a.x + ((size_t)b * a.c_in * a.pitch_in + (t0 * STRIDE - a.padl8));
         }
+      };
+      auto dw_issue = [&]() {
+        if (dw_tile >= a.n_tiles) return;
+        const unsigned short* src = dw_src + lane_x;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int j = 0; j < XJ; ++j) X[rr][j] = *reinterpret_cast<const u32x4*>(src + rr * row8 + j * 64);
+        if (++dw_chunk == n_main) { dw_chunk = 0; dw_tile += tile_step; dw_seek(); }
+        else dw_src += chunk_x;
+      };
+      // ---- ID stream state
+      int id_tile = blockIdx.x, id_s = 0;                // id_s: identity stage inside the tile
+      int id_b = 0, id_t0 = 0;
+      auto id_issue = [&]() {
+        if (id_tile >= a.n_tiles || n_id == 0) return;
+        if (id_s == 0) tile_origin(id_tile, id_b, id_t0);
+        const bool main = !DW && id_s < n_main;
+        const int chunk = main ? id_s : (DW ? id_s : id_s - n_main);
+        const unsigned short* src = main
+            ? a.x + ((size_t)(id_b * a.c_in + chunk * KC) * a.pitch_in + id_t0) + lane_i_main
+            : a.xres + ((size_t)(id_b * a.c_res + chunk * KC) * a.pitch_res + id_t0) + lane_i_res;
+        const size_t pitch8 = (size_t)8 * (main ? a.pitch_in : a.pitch_res);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int j = 0; j < IDJ; ++j) I[rr][j] = *reinterpret_cast<const u32x4*>(src + rr * pitch8 + j * 64);
+        if (++id_s == n_id) { id_s = 0; id_tile += tile_step; }
+      };
+      auto write_id = [&](char* dst) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int j = 0; j < IDJ; ++j)
+            *reinterpret_cast<u32x4*>(dst + Tile::addr(pv * 16 + r8 + 8 * rr, (sub + 8 * j) * 8)) = I[rr][j];
       };
 
       unsigned gs = 0;
-      Cursor cur{(int)blockIdx.x, 0};
-      issue(cur);
-      while (cur.tile < a.n_tiles) {
-        char* const dst = dwt + (gs & 1) * Tile::BYTES;
-        const Cursor nxt = advance(cur);
-        if (DW && cur.s < n_main) {
-          // staged registers -> wave-private LDS rows
+      if constexpr (DW) { dw_seek(); dw_issue(); }
+      id_issue();
+      for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
+        if constexpr (DW) {
+          for (int s = 0; s < n_main; ++s, ++gs) {
+            char* const dst = dwt + (gs & 1) * Tile::BYTES;
+            STAMP(1 + 5 * s);
+            // taps of THIS stage straight into registers (NPASS is compile-time, so they are statically indexed
+            // MFMA operands): they arrive from L2 while the staging writes below run -- no LDS round trip
+            const unsigned short* tp = a.taps + (size_t)s * chunk_t + lane_t;
+            if constexpr (TLDS) {
 #pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
-            char* const dstb = rr ? xw1 : xw0;
-#pragma unroll
-            for (int j = 0; j < XJ; ++j) {
-              u32x2* d2 = reinterpret_cast<u32x2*>(dstb + j * 128);
-              d2[0] = u32x2{X[rr][j][0], X[rr][j][1]};
-              d2[1] = u32x2{X[rr][j][2], X[rr][j][3]};
+              for (int k = 0; k < NPASS * NKP; ++k) T[k] = *reinterpret_cast<const u32x2*>(tp + k * 4);
             }
-          }
-          if constexpr (TLDS) {
+            // staged registers -> wave-private LDS rows
 #pragma unroll
-            for (int p = 0; p < NKMAX / NKP; ++p)
-              if (p < a.npass) {
+            for (int rr = 0; rr < 2; ++rr) {
+              char* const dstb = rr ? xw1 : xw0;
 #pragma unroll
-                for (int k = 0; k < NKP; ++k) *reinterpret_cast<u32x2*>(tl_w + ((p * NKP + k) * 64 + lane) * 8) = T[p * NKP + k];
+              for (int j = 0; j < XJ; ++j) {
+                u32x2* d2 = reinterpret_cast<u32x2*>(dstb + j * 128);
+                d2[0] = u32x2{X[rr][j][0], X[rr][j][1]};
+                d2[1] = u32x2{X[rr][j][2], X[rr][j][3]};
               }
-          }
-          issue(nxt);
-          // depthwise FIR, LDS reads of pass p+1 issued before the MFMAs of pass p
-          f32x4 d[M];
+            }
+            STAMP(2 + 5 * s);
+            dw_issue();                                   // next depthwise stage (may belong to the next tile)
+            STAMP(3 + 5 * s);
+            // depthwise FIR, LDS reads of pass p+1 issued before the MFMAs of pass p
+            f32x4 d[M];
 #pragma unroll
-          for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const unsigned short* tp = a.taps + (size_t)cur.s * KC * 4 * nk * 4 + lane_t;
-          s16x4 A0[NKP], A1[NKP], P0[NPP], P1[NPP];
-          auto load_pass = [&](int pass, s16x4 (&A)[NKP], s16x4 (&P)[NPP]) {
+            for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s16x4 A0[NKP], A1[NKP], P0[NPP], P1[NPP];
+            auto load_pass = [&](int pass, s16x4 (&A)[NKP], s16x4 (&P)[NPP]) {
 #pragma unroll
-            for (int k = 0; k < NKP; ++k) {
-              if constexpr (TLDS) A[k] = *reinterpret_cast<const s16x4*>(tl_w + ((pass * NKP + k) * 64 + lane) * 8);
-              else A[k] = *reinterpret_cast<const s16x4*>(tp + (pass * NKP + k) * 4);
+              for (int k = 0; k < NKP; ++k) {
+                if constexpr (TLDS) A[k] = __builtin_bit_cast(s16x4, T[pass * NKP + k]);
+                else A[k] = *reinterpret_cast<const s16x4*>(tp + (pass * NKP + k) * 4);
+              }
+#pragma unroll
+              for (int u = 0; u < NPP; ++u) P[u] = *reinterpret_cast<const s16x4*>(xrow + (pass * NKP + u) * 8);
+            };
+            auto mfma_pass = [&](const s16x4 (&A)[NKP], const s16x4 (&P)[NPP]) {
+#pragma unroll
+              for (int k = 0; k < NKP; ++k)
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+                  d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A[k], P[m * STRIDE + k], d[m], 0, 0, 0);
+            };
+            load_pass(0, A0, P0);
+#pragma unroll
+            for (int pass = 0; pass < NPASS; pass += 2) {
+              if (pass + 1 < NPASS) load_pass(pass + 1, A1, P1);
+              mfma_pass(A0, P0);
+              if (pass + 1 < NPASS) {
+                if (pass + 2 < NPASS) load_pass(pass + 2, A0, P0);
+                mfma_pass(A1, P1);
+              }
             }
 #pragma unroll
-            for (int u = 0; u < NPP; ++u) P[u] = *reinterpret_cast<const s16x4*>(xrow + (pass * NKP + u) * 8);
-          };
-          auto mfma_pass = [&](const s16x4 (&A)[NKP], const s16x4 (&P)[NPP]) {
-#pragma unroll
-            for (int k = 0; k < NKP; ++k)
-#pragma unroll
-              for (int m = 0; m < M; ++m)
-                d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(A[k], P[m * STRIDE + k], d[m], 0, 0, 0);
-          };
-          load_pass(0, A0, P0);
-          for (int pass = 0; pass < a.npass; pass += 2) {
-            if (pass + 1 < a.npass) load_pass(pass + 1, A1, P1);
-            mfma_pass(A0, P0);
-            if (pass + 1 < a.npass) {
-              if (pass + 2 < a.npass) load_pass(pass + 2, A0, P0);
-              mfma_pass(A1, P1);
-            }
+            for (int m = 0; m < M; ++m)
+              *reinterpret_cast<u32x2*>(dst + Tile::addr(cw, q * RUN + 4 * m)) =
+                  u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+            STAMP(4 + 5 * s);
+            stage_barrier();
+            STAMP(5 + 5 * s);
           }
-#pragma unroll
-          for (int m = 0; m < M; ++m)
-            *reinterpret_cast<u32x2*>(dst + Tile::addr(cw, q * RUN + 4 * m)) =
-                u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int j = 0; j < IDJ; ++j)
-              *reinterpret_cast<u32x4*>(dst + Tile::addr(pv * 16 + r8 + 8 * rr, (sub + 8 * j) * 8)) = I[rr][j];
-          issue(nxt);
         }
-        stage_barrier();
-        cur = nxt;
-        ++gs;
+        for (int s = 0; s < n_id; ++s, ++gs) {
+          write_id(dwt + (gs & 1) * Tile::BYTES);
+          id_issue();
+          stage_barrier();
+        }
       }
       return;
     }
@@ -535,9 +554,9 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       stage_barrier();
       STAMP(2 + 2 * s);
       const char* src = dwt + (gs & 1) * Tile::BYTES;
-#pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) {
-        s16x8 af[MT];
+      // A fragments of k-step ks+1 are read (transposed) from LDS before the MFMAs of k-step ks are issued
+      s16x8 afA[MT], afB[MT];
+      auto read_a = [&](int ks, s16x8 (&af)[MT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -546,13 +565,27 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
               (TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * Tile::ROWB + 4 * Tile::ROWB));
           af[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+      };
+      auto mfma_ks = [&](int ks, const s16x8 (&af)[MT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
         load_w(4 * s + ks + RING, ring[ks % RING]);
-      }
+      };
+      read_a(0, afA);
+      read_a(1, afB);
+      mfma_ks(0, afA);
+      STAMP(20 + 4 * s);
+      read_a(2, afA);
+      mfma_ks(1, afB);
+      STAMP(21 + 4 * s);
+      read_a(3, afB);
+      mfma_ks(2, afA);
+      STAMP(22 + 4 * s);
+      mfma_ks(3, afB);
+      STAMP(23 + 4 * s);
     }
 
     STAMP(60);
@@ -592,25 +625,37 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
         else if (STRIDE > 1) len_out = conv_len(len_out, 1, STRIDE, 0, 1);
       }
       const bool partial = t0 + TT > len_out;
+      // the accumulators were last written by MFMAs: let them settle before inline-asm readers (no auto wait states)
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int cob = (cot0 + nt) * 32;
         char* const row = et + (size_t)(lane & 31) * EP + 8 * h;
+        const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
+        if (!partial) {                           // wave-uniform: the common tile has no frame beyond the length
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+          for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            float v0 = acc[mt][nt][4 * rg + 0], v1 = acc[mt][nt][4 * rg + 1];
-            float v2 = acc[mt][nt][4 * rg + 2], v3 = acc[mt][nt][4 * rg + 3];
-            if (partial) {
-              const int t = t0 + 32 * mt + 8 * rg + 4 * h;
-              v0 = t + 0 < len_out ? v0 : 0.f; v1 = t + 1 < len_out ? v1 : 0.f;
-              v2 = t + 2 < len_out ? v2 : 0.f; v3 = t + 3 < len_out ? v3 : 0.f;
+            for (int rg = 0; rg < 4; ++rg) {
+              const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(
+                  __builtin_bit_cast(s16x2, pack_bf16_settled(acc[mt][nt][4 * rg + 0], acc[mt][nt][4 * rg + 1])), f2));
+              const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(
+                  __builtin_bit_cast(s16x2, pack_bf16_settled(acc[mt][nt][4 * rg + 2], acc[mt][nt][4 * rg + 3])), f2));
+              *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
             }
-            const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
-            const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(v0, v1)), f2));
-            const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(v2, v3)), f2));
-            *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
+          }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int t = t0 + 32 * mt + 8 * rg + 4 * h;
+              const float v0 = t + 0 < len_out ? acc[mt][nt][4 * rg + 0] : 0.f, v1 = t + 1 < len_out ? acc[mt][nt][4 * rg + 1] : 0.f;
+              const float v2 = t + 2 < len_out ? acc[mt][nt][4 * rg + 2] : 0.f, v3 = t + 3 < len_out ? acc[mt][nt][4 * rg + 3] : 0.f;
+              const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16_settled(v0, v1)), f2));
+              const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16_settled(v2, v3)), f2));
+              *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
+            }
           }
         }
         // wave-private tile: LDS operations of one wave are processed in order, no barrier needed
@@ -629,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
   }
 }
 
-template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS = false, bool TZ = false, int XJ = 0>
+template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS = false, bool TZ = false, int XJ = 0, int NPASS = 0>
 static int launch(TcsArgs& a, hipStream_t stream) {
   constexpr int CO_WG = 4 * NT * 32;
   a.n_tt = (a.t_out + TT - 1) / TT;
@@ -638,7 +683,7 @@ static int launch(TcsArgs& a, hipStream_t stream) {
   size_t lds = (size_t)2 * KC * TT * 2 + (size_t)4 * 32 * (TT * 2 + 16);
   if (DW) lds += (size_t)KC * a.xpitch * 2 + (a.taps_lds ? (size_t)4 * a.npass * NKP * 512 : 0);
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = tcs_kernel<TT, NT, STRIDE, DW, OUT_F32, TLDS, TZ, XJ>;
+  auto kern = tcs_kernel<TT, NT, STRIDE, DW, OUT_F32, TLDS, TZ, XJ, NPASS>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -721,11 +766,15 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     const int xj = a.xe / 64;
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
     if (tz) {
-#define TS_TZ(TT_, NT_, S_, TL_, XJ_) \
-      if (TT == TT_ && d->stride == S_ && a.taps_lds == TL_ && xj == XJ_) return launch<TT_, NT_, S_, true, false, TL_, true, XJ_>(a, stream);
-      TS_TZ(128, 2, 1, true, 3) TS_TZ(128, 2, 1, true, 4)
-      TS_TZ(64, 4, 1, true, 2) TS_TZ(64, 4, 1, true, 3) TS_TZ(64, 4, 1, false, 4)
-      TS_TZ(128, 2, 2, true, 5) TS_TZ(64, 4, 2, true, 3)
+      // straight-line instantiations (staged row groups XJ and depthwise passes NPASS are compile-time) for the
+      // geometries of the reference models; anything else takes the generic kernel below
+#define TS_TZ(TT_, NT_, S_, TL_, XJ_, NP_) \
+      if (TT == TT_ && d->stride == S_ && a.taps_lds == TL_ && xj == XJ_ && a.npass == NP_) \
+        return launch<TT_, NT_, S_, true, false, TL_, true, XJ_, NP_>(a, stream);
+      TS_TZ(128, 2, 1, true, 3, 3) TS_TZ(128, 2, 1, true, 3, 4) TS_TZ(128, 2, 1, true, 3, 2) TS_TZ(128, 2, 1, true, 3, 1)
+      TS_TZ(64, 4, 1, true, 2, 5) TS_TZ(64, 4, 1, true, 3, 6) TS_TZ(64, 4, 1, true, 3, 7) TS_TZ(64, 4, 1, true, 2, 3)
+      TS_TZ(64, 4, 1, false, 4, 15)
+      TS_TZ(128, 2, 2, true, 5, 4)
 #undef TS_TZ
     }
     if (a.taps_lds) {

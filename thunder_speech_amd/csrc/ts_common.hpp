@@ -19,10 +19,18 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 #define TS_LDS __attribute__((address_space(3)))
 
-// float pair -> packed bf16 pair (round-to-nearest-even; lowers to v_cvt_pk_bf16_f32 on gfx950)
+// float pair -> packed bf16 pair (round-to-nearest-even).  Compiler-scheduled form: safe right after an MFMA (hipcc pads
+// the MFMA -> VALU hazard), but it lowers to two single conversions plus a v_perm_b32.
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(unsigned, v);
+}
+// ONE v_cvt_pk_bf16_f32.  hipcc inserts no wait states for inline asm, so the operands must NOT be the result of an
+// MFMA issued within the last ~20 cycles (cdna_hip_programming.md 5.7 item 2); used by the epilogues only.
+__device__ __forceinline__ unsigned pack_bf16_settled(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }

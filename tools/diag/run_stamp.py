@@ -32,3 +32,8 @@ print("consumer wave 0:")
 for s in range(n):
     print(f"  stage {s}: wait-barrier {int(c[2+2*s])-int(c[1+2*s]):6d}  (barrier passed @{int(c[2+2*s])-base})   pw {int(c[1+2*(s+1)] if s+1<n else c[60])-int(c[2+2*s]):6d}")
 print(f"  epilogue {int(c[61])-int(c[60])}, end@{int(c[61])-base}")
+
+print("consumer wave 0 k-step stamps (cycles after barrier): ")
+for s_ in range(min(n, 8)):
+    t0_ = int(c[2 + 2 * s_])
+    print("  stage", s_, [int(c[20 + 4 * s_ + i]) - t0_ for i in range(4)])
