@@ -58,7 +58,8 @@ typedef struct ts_tcs_desc {
   /* prepacked parameters (see thunder_speech_amd/plan.py for the packers) */
   int32_t dw_ksteps;            /* NK: number of 4-sample k-steps in `dw_taps` (multiple of 3) */
   int32_t flags;                /* TS_TCS_* bits below */
-  const void* dw_taps;          /* bf16 [c_in_pad64][4][4*NK]   shifted Toeplitz rows of the depthwise taps */
+  const void* dw_taps;          /* bf16 [c_in_pad64/64][4 waves][NK][64 lanes][4]  shifted Toeplitz rows of the depthwise taps,
+                                   lane = 4*(channel % 16) + row (plan.tap_fragments) */
   const void* pw_w;             /* bf16 [c_out_pad32/32][c_in_pad64/16][64][8]  MFMA B-fragments of W*bn_scale */
   const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */

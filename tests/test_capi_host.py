@@ -96,6 +96,16 @@ def test_pack_dw_taps_is_the_toeplitz_of_the_conv(k, stride, dil):
     assert torch.all(taps[3:] == 0)
 
 
+def test_tap_fragments_layout():
+    from thunder_speech_amd import plan
+    taps = torch.arange(128 * 4 * 12, dtype=torch.float32).reshape(128, 4, 12)
+    fr = plan.tap_fragments(taps)
+    assert fr.shape == (2, 4, 3, 64, 4)
+    for (chunk, wave, k, lane) in [(0, 0, 0, 0), (1, 3, 2, 63), (0, 2, 1, 37), (1, 0, 0, 5)]:
+        ch, row = chunk * 64 + wave * 16 + lane // 4, lane % 4
+        assert torch.equal(fr[chunk, wave, k, lane], taps[ch, row, 4 * k: 4 * k + 4])
+
+
 def test_state_dict_keys_match_reference_layout():
     """Same keys/shapes as the reference module tree (pinned through the oracle's synthetic state dict, which the
     golden generator loaded strict=True into the real reference QuartznetEncoder)."""

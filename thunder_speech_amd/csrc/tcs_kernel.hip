@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       //   ID stream: I registers   <- next identity stage (residual chunk, or the main chunk of a pointwise-only layer)
       const size_t row8 = (size_t)8 * a.pitch_in;
       const size_t lane_x = (size_t)(pv * 16 + r8) * a.pitch_in + sub * 8;          // DW staging, element offset of row r8
-      const size_t lane_t = ((size_t)(cw * 4 + q) * nk) * 4;
+      const size_t lane_t = ((size_t)pv * nk * 64 + lane) * 4;                       // tap fragments: [chunk][wave][k][lane][4]
       const size_t chunk_x = (size_t)KC * a.pitch_in;
       const size_t chunk_t = (size_t)KC * 4 * nk * 4;
       const int n_id = DW ? n_res : n_stage;                                          // identity stages per tile
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
             const unsigned short* tp = a.taps + (size_t)s * chunk_t + lane_t;
             if constexpr (TLDS) {
 #pragma unroll
-              for (int k = 0; k < NPASS * NKP; ++k) T[k] = *reinterpret_cast<const u32x2*>(tp + k * 4);
+              for (int k = 0; k < NPASS * NKP; ++k) T[k] = *reinterpret_cast<const u32x2*>(tp + k * 256);
             }
             // staged registers -> wave-private LDS rows
 #pragma unroll
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
 #pragma unroll
               for (int k = 0; k < NKP; ++k) {
                 if constexpr (TLDS) A[k] = __builtin_bit_cast(s16x4, T[pass * NKP + k]);
-                else A[k] = *reinterpret_cast<const s16x4*>(tp + (pass * NKP + k) * 4);
+                else A[k] = *reinterpret_cast<const s16x4*>(tp + (pass * NKP + k) * 256);
               }
 #pragma unroll
               for (int u = 0; u < NPP; ++u) P[u] = *reinterpret_cast<const s16x4*>(xrow + (pass * NKP + u) * 8);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
         const unsigned short* const xg0 = a.x + ((size_t)(b * a.c_in + pv * 16 + r8) * a.pitch_in + tin0 + sub * 8);
         const size_t row8 = (size_t)8 * a.pitch_in;
         const size_t chunk_stride = (size_t)KC * a.pitch_in;
-        const unsigned short* const tg0 = a.taps + ((size_t)(cw * 4 + q) * nk) * 4;
+        const unsigned short* const tg0 = a.taps + ((size_t)pv * nk * 64 + lane) * 4;   // [chunk][wave][k][lane][4]
         const size_t tap_chunk = (size_t)KC * 4 * nk * 4;
 
         // `fast` is wave-uniform: only the small predicate / mask pieces are duplicated, the depthwise body is shared
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
           for (int p = 0; p < NKMAX / NKP; ++p)
             if (p < a.npass) {
 #pragma unroll
-              for (int k = 0; k < NKP; ++k) T[p * NKP + k] = *reinterpret_cast<const u32x2*>(tp + (p * NKP + k) * 4);
+              for (int k = 0; k < NKP; ++k) T[p * NKP + k] = *reinterpret_cast<const u32x2*>(tp + (p * NKP + k) * 256);
             }
         };
         auto write_t = [&]() {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
               // TLDS is a template parameter on purpose: a runtime select between an LDS and a global pointer
               // compiles to flat_load + s_waitcnt vmcnt(0) lgkmcnt(0), which drains every prefetch in flight
               if constexpr (TLDS) A[k] = *reinterpret_cast<const s16x4*>(tl_w + ((pass * NKP + k) * 64 + lane) * 8);
-              else A[k] = *reinterpret_cast<const s16x4*>(tp + (pass * NKP + k) * 4);
+              else A[k] = *reinterpret_cast<const s16x4*>(tp + (pass * NKP + k) * 256);
             }
             s16x4 P[NPP];
 #pragma unroll
@@ -503,7 +503,6 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
   constexpr int LPR = TT / 8;                     // epilogue: lanes per output row (16 B each)
   constexpr int RPI = 64 / LPR;                   // rows per wave-instruction
   const int rsub = lane / LPR, csub = lane % LPR;
-  const int gk_last = 4 * n_stage - 1;
 
   unsigned gs = 0;
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
@@ -525,28 +524,37 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
     }
 
-    // weight-fragment ring, RING k-steps deep: k-step gk = 4 * stage + ks.  Loads are branch-free (indices
-    // clamped to valid memory; a clamped fragment is never used, or feeds a tile that is never stored) so the
-    // compiler can count them with partial vmcnt waits.
+    // weight-fragment ring, RING k-steps deep.  One running pointer per 32-channel output tile walks the fragment
+    // stream (1 KiB per k-step) of the main weights, switches to the residual weights after 4 * n_main k-steps and
+    // stops advancing at the end (the surplus loads re-read the last fragment and are never used).  Tiles beyond
+    // c_out are clamped to the last valid tile; their results are never stored.  Branch-free loads, so the compiler
+    // counts them with partial vmcnt waits.
     constexpr int RING = RING_BYTES / NT;          // k-steps ahead (4 for NT = 2, 2 for NT = 4)
     s16x8 ring[RING][NT];
-    auto load_w = [&](int gk, s16x8 (&slot)[NT]) {
-      gk = gk > gk_last ? gk_last : gk;
-      const int sg = gk >> 2, ks = gk & 3;
-      const bool main = sg < n_main;
-      const unsigned short* wfr = main ? a.pw_w : a.res_w;
-      const int kt = main ? a.kt_main : a.kt_res;
-      const int kidx = (main ? sg : sg - n_main) * 4 + ks;
+    const unsigned short* wptr[NT];
+    int cotc[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        int cot = cot0 + nt;
-        cot = cot < n_cot ? cot : n_cot - 1;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(wfr + ((size_t)(cot * kt + kidx) * 64 + lane) * 8);
-        slot[nt] = __builtin_bit_cast(s16x8, v);
+    for (int nt = 0; nt < NT; ++nt) {
+      cotc[nt] = cot0 + nt < n_cot ? cot0 + nt : n_cot - 1;
+      wptr[nt] = a.pw_w + ((size_t)cotc[nt] * a.kt_main * 64 + lane) * 8;
+    }
+    int gk_next = 0;                               // k-step the pointers refer to
+    const int gk_main = 4 * n_main, gk_end = 4 * n_stage;
+    auto load_w = [&](s16x8 (&slot)[NT]) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        slot[nt] = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(wptr[nt]));
+      ++gk_next;
+      if (gk_next == gk_main && gk_main < gk_end) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wptr[nt] = a.res_w + ((size_t)cotc[nt] * a.kt_res * 64 + lane) * 8;
+      } else if (gk_next < gk_end) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wptr[nt] += 64 * 8;
       }
     };
 #pragma unroll
-    for (int r = 0; r < RING; ++r) load_w(r, ring[r]);
+    for (int r = 0; r < RING; ++r) load_w(ring[r]);
 
     STAMP(0);
     for (int s = 0; s < n_stage; ++s, ++gs) {
@@ -572,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
-        load_w(4 * s + ks + RING, ring[ks % RING]);
+        load_w(ring[ks % RING]);
       };
       read_a(0, afA);
       read_a(1, afB);

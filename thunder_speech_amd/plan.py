@@ -59,6 +59,16 @@ def pack_dw_taps(w: torch.Tensor, stride: int, dilation: int, padding: int) -> T
     return out.to(torch.bfloat16).contiguous(), nk
 
 
+def tap_fragments(taps: torch.Tensor) -> torch.Tensor:
+    """[C_pad64, 4, 4*NK] Toeplitz rows -> the order the producer waves load them in:
+    [chunk(64 ch)][wave(16 ch)][k-step][lane = 4*(ch % 16) + row][4 samples], so that one wave-instruction reads
+    512 contiguous bytes (the row-major order gives 64 different cache lines per instruction)."""
+    cp, _, n4 = taps.shape
+    nk = n4 // 4
+    t = taps.view(cp // KC, 4, 16, 4, nk, 4)            # [chunk][wave][ch][row][k][4]
+    return t.permute(0, 1, 4, 2, 3, 5).contiguous().view(cp // KC, 4, nk, 64, 4)
+
+
 def pack_pw_frags(wf: torch.Tensor) -> torch.Tensor:
     """wf: [Cout, Cin] (already multiplied by the BN scale) -> bf16 [Cout_pad32/32, Cin_pad64/16, 64, 8].
 
@@ -172,6 +182,6 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
         shift = shift + rsh
         c_res = r2.shape[1]
     return TcsLayer(c_in=cin, c_out=cout, kernel=kernel, stride=stride, dilation=dilation, padding=padding,
-                    depthwise=dw_w is not None, relu=relu, taps=None if taps is None else taps.to(device), nk=nk,
+                    depthwise=dw_w is not None, relu=relu, taps=None if taps is None else tap_fragments(taps).to(device), nk=nk,
                     pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
                     res_stride=res_stride, out_fp32=out_fp32)
