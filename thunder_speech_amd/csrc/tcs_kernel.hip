@@ -682,6 +682,298 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
   }
 }
 
+// ======================================================================================================
+// Wide-layer kernel (c_out > 256, tail-zero input, stride 1, depthwise taps in registers).
+//
+// The role-split kernel above streams the pointwise weights at 4096 / TT bytes per clock per CU; with the
+// 64-frame tiles its 4 accumulator waves can afford for 512 output channels that is the whole L1 rate.  Here all
+// 8 waves hold accumulators (128 frames x 512 channels = the fp32 capacity of half the register file), so the
+// weight stream halves, and every wave alternates between the two jobs:
+//   depthwise phase: wave w runs the FIR of channels [8w, 8w+8) of the stage for all 128 frames
+//                    (16 MFMA blocks = 8 channels x 2 half-tiles) and writes dwt[stage & 1];
+//   one s_barrier;
+//   pointwise phase: wave w accumulates its 128 x 64 output tile from dwt (transposed LDS reads) and its weight ring.
+// With two dwt buffers one barrier per stage is enough: a wave can only reach the depthwise phase of stage s+2
+// (which overwrites dwt[s & 1]) after barrier s+1, which every wave passes only after its pointwise phase s.
+// ======================================================================================================
+template <int NPASS, int XJ>
+__global__ __launch_bounds__(512, 2) void tcs_wide_kernel(const TcsArgs a) {
+  constexpr int TT = 128, NT = 2, MT = 4, STRIDE = 1;
+  constexpr int M = 4, RUN = 16;                  // per half-tile: 4 runs of 16 frames, 4 steps of 4
+  constexpr int NPP = (M - 1) * STRIDE + NKP;
+  constexpr int EP = TT * 2 + 16;
+  using Tile = DwTile<TT>;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const dwt = smem;                                   // [2][KC][TT]
+  char* const epi = smem + 2 * Tile::BYTES;                 // [8 waves][32][EP]
+  char* const xs = epi + 8 * 32 * EP;                       // [8 waves][8][xpitch]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_main = a.c_in / KC;
+  const int n_res = a.c_res / KC;
+  const int tile_step = gridDim.x;
+  const int nk = NPASS * NKP;
+
+  // ---- depthwise-role lane geometry
+  const int r8 = lane >> 3, sub = lane & 7;        // staging: row r8 of the wave's 8 channels, 16-B groups sub + 8j
+  const int cl = (lane >> 2) & 7;                  // MFMA block -> channel 8*wave + cl ...
+  const int hh = lane >> 5;                        // ... and half-tile
+  const int q = lane & 3;
+  char* const xs_w = xs + (size_t)wave * 8 * a.xpitch * 2;
+  char* const xw = xs_w + ((size_t)r8 * a.xpitch + sub * 8) * 2;
+  const char* const xrow = xs_w + ((size_t)cl * a.xpitch + a.woff + (hh * 64 + q * RUN) * STRIDE) * 2;
+  const int cw = wave * 8 + cl;                    // channel inside the stage
+  const size_t lane_x = (size_t)(wave * 8 + r8) * a.pitch_in + sub * 8;
+  // tap fragments are packed for 16-channel groups: [chunk][group][k][lane16x4][4]
+  const size_t lane_t = (((size_t)(wave >> 1) * nk) * 64 + (wave & 1) * 32 + cl * 4 + q) * 4;
+  const size_t chunk_x = (size_t)KC * a.pitch_in;
+  const size_t chunk_t = (size_t)KC * 4 * nk * 4;
+  const size_t lane_i = (size_t)(wave * 8 + r8) * a.pitch_res + sub * 8;
+
+  // ---- pointwise-role lane geometry
+  const int n_cot = (a.c_out + 31) >> 5;
+  const int h = lane >> 5;
+  const int gq = (lane >> 4) & 1;
+  const int q4 = (lane >> 2) & 3;
+  const int p4 = lane & 3;
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = Tile::addr(8 * h + q4, 32 * mt + 16 * gq + 4 * p4);
+  char* const et = epi + (size_t)wave * 32 * EP;
+  constexpr int LPR = TT / 8, RPI = 64 / LPR;
+  const int rsub = lane / LPR, csub = lane % LPR;
+  const unsigned floor2 = a.relu ? 0u : 0x80008000u;
+
+  auto tile_origin = [&](int tile, int& b, int& t0) { b = (tile / a.n_tt) / a.n_z; t0 = (tile % a.n_tt) * TT; };
+
+  // ---- prefetch streams (one issue site each)
+  u32x4 X[XJ];
+  u32x4 I[2];
+  u32x2 T[NPASS * NKP];
+  int dw_tile = blockIdx.x, dw_chunk = 0;
+  const unsigned short* dw_src = nullptr;
+  auto dw_seek = [&]() {
+    if (dw_tile < a.n_tiles) {
+      int b, t0; tile_origin(dw_tile, b, t0);
+      dw_src = a.x + ((size_t)b * a.c_in * a.pitch_in + (t0 * STRIDE - a.padl8));
+    }
+  };
+  auto dw_issue = [&]() {
+    if (dw_tile >= a.n_tiles) return;
+    const unsigned short* src = dw_src + lane_x;
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) X[j] = *reinterpret_cast<const u32x4*>(src + j * 64);
+    if (++dw_chunk == n_main) { dw_chunk = 0; dw_tile += tile_step; dw_seek(); }
+    else dw_src += chunk_x;
+  };
+  int id_tile = blockIdx.x, id_s = 0, id_b = 0, id_t0 = 0;
+  auto id_issue = [&]() {
+    if (id_tile >= a.n_tiles || n_res == 0) return;
+    if (id_s == 0) tile_origin(id_tile, id_b, id_t0);
+    const unsigned short* src = a.xres + ((size_t)(id_b * a.c_res + id_s * KC) * a.pitch_res + id_t0) + lane_i;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) I[j] = *reinterpret_cast<const u32x4*>(src + j * 64);
+    if (++id_s == n_res) { id_s = 0; id_tile += tile_step; }
+  };
+
+  unsigned gs = 0;
+  dw_seek();
+  dw_issue();
+  id_issue();
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
+    int b, t0;
+    tile_origin(tile, b, t0);
+    const int z = (tile / a.n_tt) % a.n_z;
+    const int cot0 = (z * 8 + wave) * NT;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = (cot0 + j) * 32 + (lane & 31);
+      const float bv = a.bias[col < a.c_out ? col : 0];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
+    constexpr int RING = 2;                        // the ring is live across the depthwise phase: keep it short
+    s16x8 ring[RING][NT];
+    const unsigned short* wptr[NT];
+    int cotc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      cotc[nt] = cot0 + nt < n_cot ? cot0 + nt : n_cot - 1;
+      wptr[nt] = a.pw_w + ((size_t)cotc[nt] * a.kt_main * 64 + lane) * 8;
+    }
+    int gk_next = 0;
+    const int gk_main = 4 * n_main, gk_end = 4 * (n_main + n_res);
+    auto load_w = [&](s16x8 (&slot)[NT]) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) slot[nt] = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(wptr[nt]));
+      ++gk_next;
+      if (gk_next == gk_main && gk_main < gk_end) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wptr[nt] = a.res_w + ((size_t)cotc[nt] * a.kt_res * 64 + lane) * 8;
+      } else if (gk_next < gk_end) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wptr[nt] += 64 * 8;
+      }
+    };
+#pragma unroll
+    for (int r = 0; r < RING; ++r) load_w(ring[r]);
+
+    auto pointwise = [&](const char* src) {
+      s16x8 afA[MT], afB[MT];
+      auto read_a = [&](int ks, s16x8 (&af)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * Tile::ROWB));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * Tile::ROWB + 4 * Tile::ROWB));
+          af[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      };
+      auto mfma_ks = [&](int ks, const s16x8 (&af)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
+        load_w(ring[ks % RING]);
+      };
+      read_a(0, afA);
+      read_a(1, afB);
+      mfma_ks(0, afA);
+      read_a(2, afA);
+      mfma_ks(1, afB);
+      read_a(3, afB);
+      mfma_ks(2, afA);
+      mfma_ks(3, afB);
+    };
+
+    for (int s = 0; s < n_main; ++s, ++gs) {
+      char* const dst = dwt + (gs & 1) * Tile::BYTES;
+      STAMP(1 + 5 * s);
+      // taps of this stage (statically indexed MFMA operands), then staged rows -> wave-private LDS
+      const unsigned short* tp = a.taps + (size_t)s * chunk_t + lane_t;
+#pragma unroll
+      for (int k = 0; k < NPASS * NKP; ++k) T[k] = *reinterpret_cast<const u32x2*>(tp + k * 256);
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) {
+        u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 128);
+        d2[0] = u32x2{X[j][0], X[j][1]};
+        d2[1] = u32x2{X[j][2], X[j][3]};
+      }
+      STAMP(2 + 5 * s);
+      dw_issue();
+      f32x4 d[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s16x4 P0[NPP];
+      auto load_win = [&](int pass, s16x4 (&P)[NPP]) {
+#pragma unroll
+        for (int u = 0; u < NPP; ++u) P[u] = *reinterpret_cast<const s16x4*>(xrow + (pass * NKP + u) * 8);
+      };
+      auto mfma_pass = [&](int pass, const s16x4 (&P)[NPP]) {
+#pragma unroll
+        for (int k = 0; k < NKP; ++k)
+#pragma unroll
+          for (int m = 0; m < M; ++m)
+            d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[pass * NKP + k]), P[m * STRIDE + k], d[m], 0, 0, 0);
+      };
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        load_win(pass, P0);
+        mfma_pass(pass, P0);
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        *reinterpret_cast<u32x2*>(dst + Tile::addr(cw, hh * 64 + q * RUN + 4 * m)) =
+            u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+      STAMP(3 + 5 * s);
+      stage_barrier();
+      STAMP(4 + 5 * s);
+      pointwise(dst);
+      STAMP(5 + 5 * s);
+    }
+    for (int s = 0; s < n_res; ++s, ++gs) {
+      char* const dst = dwt + (gs & 1) * Tile::BYTES;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<u32x4*>(dst + Tile::addr(wave * 8 + r8, (sub + 8 * j) * 8)) = I[j];
+      id_issue();
+      stage_barrier();
+      pointwise(dst);
+    }
+
+    // ---- epilogue: bf16 pack + ReLU on packed pairs, transposed through a wave-private LDS tile
+    unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
+    int len_out = 0x7fffffff;
+    if (a.zero_tail) len_out = conv_len(a.len_in[b], a.kernel, STRIDE, a.padding, a.dilation);
+    const bool partial = t0 + TT > len_out;
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cob = (cot0 + nt) * 32;
+      char* const row = et + (size_t)(lane & 31) * EP + 8 * h;
+      const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float v0 = acc[mt][nt][4 * rg + 0], v1 = acc[mt][nt][4 * rg + 1];
+          float v2 = acc[mt][nt][4 * rg + 2], v3 = acc[mt][nt][4 * rg + 3];
+          if (partial) {
+            const int t = t0 + 32 * mt + 8 * rg + 4 * h;
+            v0 = t + 0 < len_out ? v0 : 0.f; v1 = t + 1 < len_out ? v1 : 0.f;
+            v2 = t + 2 < len_out ? v2 : 0.f; v3 = t + 3 < len_out ? v3 : 0.f;
+          }
+          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16_settled(v0, v1)), f2));
+          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16_settled(v2, v3)), f2));
+          *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
+        }
+      }
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rl = r0 + rsub;
+        const int co = cob + rl;
+        const int t = t0 + csub * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(et + (size_t)rl * EP + csub * 16);
+        if (co < a.c_out && t < a.pitch_out)
+          *reinterpret_cast<u32x4*>(yb + (size_t)(b * a.c_out + co) * a.pitch_out + t) = v;
+      }
+    }
+  }
+}
+
+template <int NPASS, int XJ>
+static int launch_wide(TcsArgs& a, hipStream_t stream) {
+  constexpr int TT = 128, CO_WG = 512;
+  a.n_tt = (a.t_out + TT - 1) / TT;
+  a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
+  a.n_tiles = a.batch * a.n_tt * a.n_z;
+  const size_t lds = (size_t)2 * KC * TT * 2 + (size_t)8 * 32 * (TT * 2 + 16) + (size_t)KC * a.xpitch * 2;
+  if (lds > 160 * 1024) return TS_EUNSUPPORTED;
+  auto kern = tcs_wide_kernel<NPASS, XJ>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  return hip_status(hipGetLastError());
+}
+
 template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS = false, bool TZ = false, int XJ = 0, int NPASS = 0>
 static int launch(TcsArgs& a, hipStream_t stream) {
   constexpr int CO_WG = 4 * NT * 32;
@@ -773,6 +1065,21 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     a.xpitch = a.xe + 4;                              // row pitch == 8 (mod 16) bytes: conflict-free window reads
     const int xj = a.xe / 64;
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
+    if (tz && wide && d->stride == 1 && a.taps_lds && getenv("TS_NO_WIDE") == nullptr) {
+      // all-waves-accumulate kernel for the wide layers (128-frame tiles): its own window geometry
+      TcsArgs w = a;
+      const int n_tt128 = (d->t_out + 127) / 128;
+      w.xuse = w.woff + (64 + 48) * 1 + 4 * (3 + d->dw_ksteps);
+      w.xe = round_up(w.xuse, 64);
+      w.xpitch = w.xe + 4;
+      const bool fits = (n_tt128 - 1) * 128 - w.padl8 + w.xe <= d->pitch_in && (d->c_res == 0 || d->pitch_res >= n_tt128 * 128) &&
+                        d->pitch_out >= n_tt128 * 128;
+      if (fits) {
+#define TS_WIDE(NP_, XJ_) if (w.npass == NP_ && w.xe == 64 * XJ_) return launch_wide<NP_, XJ_>(w, stream);
+        TS_WIDE(3, 3) TS_WIDE(4, 3) TS_WIDE(5, 3) TS_WIDE(6, 4) TS_WIDE(7, 4)
+#undef TS_WIDE
+      }
+    }
     if (tz) {
       // straight-line instantiations (staged row groups XJ and depthwise passes NPASS are compile-time) for the
       // geometries of the reference models; anything else takes the generic kernel below
