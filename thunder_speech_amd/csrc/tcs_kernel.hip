@@ -68,6 +68,7 @@ struct TcsArgs {
   int taps_lds;                // 1: taps of the stage are cached in LDS
   int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
   int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
+  int privb;                   // pipelined kernel: bytes of a wave's private LDS region
 #ifdef TS_STAMP
   long long* dbg;              // diagnostic build only: s_memtime stamps of one workgroup
 #endif
@@ -110,6 +111,11 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {
 #define STAMP(slot) do { if (a.dbg && blockIdx.x == 7 && tile == 7 && lane == 0 && (slot) < 64) a.dbg[wave * 64 + (slot)] = clock64(); } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#endif
+#ifdef TS_STAMP
+#define PSTAMP(slot) do { if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) < 64) a.dbg[wave * 64 + (slot)] = clock64(); } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
 #endif
 
 template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS, bool TZ, int XJ, int NPASS>
@@ -683,57 +689,112 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
 }
 
 // ======================================================================================================
-// Wide-layer kernel (c_out > 256, tail-zero input, stride 1, depthwise taps in registers).
+// Pipelined all-waves kernel (tail-zero input, stride 1, depthwise taps in registers): the kernel the QuartzNet /
+// Citrinet body layers run on.
 //
-// The role-split kernel above streams the pointwise weights at 4096 / TT bytes per clock per CU; with the
-// 64-frame tiles its 4 accumulator waves can afford for 512 output channels that is the whole L1 rate.  Here all
-// 8 waves hold accumulators (128 frames x 512 channels = the fp32 capacity of half the register file), so the
-// weight stream halves, and every wave alternates between the two jobs:
-//   depthwise phase: wave w runs the FIR of channels [8w, 8w+8) of the stage for all 128 frames
-//                    (16 MFMA blocks = 8 channels x 2 half-tiles) and writes dwt[stage & 1];
-//   one s_barrier;
-//   pointwise phase: wave w accumulates its 128 x 64 output tile from dwt (transposed LDS reads) and its weight ring.
-// With two dwt buffers one barrier per stage is enough: a wave can only reach the depthwise phase of stage s+2
-// (which overwrites dwt[s & 1]) after barrier s+1, which every wave passes only after its pointwise phase s.
+// All 8 waves hold accumulators and every wave does both jobs, software-pipelined one stage apart: while a wave
+// accumulates stage g of the pointwise GEMM out of dwt[g & 1] (v_mfma_f32_32x32x16_bf16), the SAME instruction stream
+// runs the depthwise FIR of stage g+1 (v_mfma_f32_4x4x4_16b_bf16) into dwt[(g+1) & 1], so the matrix pipe always has
+// independent work while LDS reads of the other job are in flight.  One s_barrier per stage.
+//   wave grid WM x WN (time x output channels), wave tile = 32*MT frames x 64 channels:
+//     WM = 1: tile 96 frames x 512 channels   (c_out > 256)
+//     WM = 2: tile 192 frames x 256 channels  (c_out <= 256)
+//   96-frame granules: 751 frames (15 s of audio after the stride-2 stem) = 8 x 96 = 4 x 192 with 2 % waste, and
+//   64 clips give 512 / 256 tiles = exactly 2 / 1 per CU.
+//   depthwise of a stage: wave w runs channels [8w, 8w+8) for all TT frames: 16 MFMA blocks = 8 channels x 2 segments,
+//   4 lane runs of TT/8 frames per segment, M = TT/32 steps of 4 frames per run; the lane's input window slides through
+//   registers (3 new 8-byte LDS reads per pass of 3 k-steps).
+// Prefetch streams, each with one issue site per loop body: X (input rows, one stage ahead -> wave-private LDS rows),
+// T (tap fragments of the next depthwise stage, loaded when the current one is done), I (identity rows of the residual
+// stages), W (weight fragments, 2-deep ring).
 // ======================================================================================================
-template <int NPASS, int XJ>
-__global__ __launch_bounds__(512, 2) void tcs_wide_kernel(const TcsArgs a) {
-  constexpr int TT = 128, NT = 2, MT = 4, STRIDE = 1;
-  constexpr int M = 4, RUN = 16;                  // per half-tile: 4 runs of 16 frames, 4 steps of 4
-  constexpr int NPP = (M - 1) * STRIDE + NKP;
-  constexpr int EP = TT * 2 + 16;
-  using Tile = DwTile<TT>;
+// position of a tile in the (clip, output-channel split, time tile) grid, advanced by the grid stride without divisions
+struct TilePos {
+  int b, z, tt;
+  int sb, sz, st;       // the stride, decomposed the same way
+  __device__ __forceinline__ void init(int tile, int step, int n_tt, int n_z) {
+    tt = tile % n_tt; z = (tile / n_tt) % n_z; b = (tile / n_tt) / n_z;
+    st = step % n_tt; sz = (step / n_tt) % n_z; sb = (step / n_tt) / n_z;
+  }
+  // branch-free conditional advance (scalar selects)
+  __device__ __forceinline__ void advance_if(bool go, int n_tt, int n_z) {
+    tt += go ? st : 0;
+    const int c1 = tt >= n_tt ? 1 : 0;
+    tt -= c1 ? n_tt : 0;
+    z += (go ? sz : 0) + c1;
+    const int c2 = z >= n_z ? 1 : 0;
+    z -= c2 ? n_z : 0;
+    b += (go ? sb : 0) + c2;
+  }
+  __device__ __forceinline__ void advance(int n_tt, int n_z) {
+    tt += st;
+    const int c1 = tt >= n_tt ? 1 : 0;
+    tt -= c1 ? n_tt : 0;
+    z += sz + c1;
+    const int c2 = z >= n_z ? 1 : 0;
+    z -= c2 ? n_z : 0;
+    b += sb + c2;
+  }
+};
+
+template <int NPASS, int XJ, int MT, int WM>
+__global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
+  constexpr int WN = 8 / WM, NT = 2;
+  constexpr int FW = 32 * MT;                     // frames of a wave tile
+  constexpr int TT = FW * WM;
+  constexpr int M = TT / 32, RUN = TT / 8, SEG = TT / 2;
+  constexpr int NK = NPASS * NKP;
+  constexpr int NP = NK + M - 1;                  // 4-sample window groups a lane reads per stage
+  constexpr int ROWB = TT <= 128 ? 256 : 512;     // dwt row pitch: 16 / 32 swizzled 16-byte chunks
+  constexpr int TILEB = KC * ROWB;
+  constexpr int EP = FW * 2 + 16;
+  constexpr int IDJ = (TT + 63) / 64;
+  static_assert(RUN % 4 == 0, "lane runs are whole 4-frame steps");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const dwt = smem;                                   // [2][KC][TT]
-  char* const epi = smem + 2 * Tile::BYTES;                 // [8 waves][32][EP]
-  char* const xs = epi + 8 * 32 * EP;                       // [8 waves][8][xpitch]
-
+  char* const dwt = smem;                                   // [2][KC][ROWB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* const priv = smem + 2 * TILEB + (size_t)wave * a.privb;   // staged input rows / epilogue tile (never live together)
   const int n_main = a.c_in / KC;
   const int n_res = a.c_res / KC;
+  const int n_stage = n_main + n_res;
   const int tile_step = gridDim.x;
-  const int nk = NPASS * NKP;
+  auto taddr = [](int c, int t) { return c * ROWB + ((((t >> 3) ^ ((c & 3) * 5))) << 4) + ((t & 7) << 1); };
 
-  // ---- depthwise-role lane geometry
+  // All global reads are raw buffer loads: descriptor + 32-bit lane offset (loop-invariant VGPR) + 32-bit scalar offset
+  // that carries the whole stream position.  No 64-bit address registers, no VALU pointer math, one s_add per advance.
+  constexpr int RSRC_FLAGS = 0x00020000;          // gfx9 raw buffer: 32-bit data format
+  auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
+  const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(a.x) - TS_GUARD_BYTES);   // offsets may reach into the front guard
+  const __amdgpu_buffer_rsrc_t rt = rsrc(a.taps);
+  const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
+  const __amdgpu_buffer_rsrc_t rwm = rsrc(a.pw_w);
+  const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? a.res_w : a.pw_w);
+  auto ld16 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); };
+  auto ld8 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); };
+
+  // ---- depthwise-job lane geometry
   const int r8 = lane >> 3, sub = lane & 7;        // staging: row r8 of the wave's 8 channels, 16-B groups sub + 8j
   const int cl = (lane >> 2) & 7;                  // MFMA block -> channel 8*wave + cl ...
-  const int hh = lane >> 5;                        // ... and half-tile
+  const int hh = lane >> 5;                        // ... and segment
   const int q = lane & 3;
-  char* const xs_w = xs + (size_t)wave * 8 * a.xpitch * 2;
-  char* const xw = xs_w + ((size_t)r8 * a.xpitch + sub * 8) * 2;
-  const char* const xrow = xs_w + ((size_t)cl * a.xpitch + a.woff + (hh * 64 + q * RUN) * STRIDE) * 2;
-  const int cw = wave * 8 + cl;                    // channel inside the stage
-  const size_t lane_x = (size_t)(wave * 8 + r8) * a.pitch_in + sub * 8;
-  // tap fragments are packed for 16-channel groups: [chunk][group][k][lane16x4][4]
-  const size_t lane_t = (((size_t)(wave >> 1) * nk) * 64 + (wave & 1) * 32 + cl * 4 + q) * 4;
-  const size_t chunk_x = (size_t)KC * a.pitch_in;
-  const size_t chunk_t = (size_t)KC * 4 * nk * 4;
-  const size_t lane_i = (size_t)(wave * 8 + r8) * a.pitch_res + sub * 8;
+  char* const xw = priv + ((size_t)r8 * a.xpitch + sub * 8) * 2;
+  const char* const xrow = priv + ((size_t)cl * a.xpitch + a.woff + hh * SEG + q * RUN) * 2;
+  int dw_out[M];                                   // 8-byte slots of the lane's 4-frame steps in the swizzled tile
+#pragma unroll
+  for (int m = 0; m < M; ++m) dw_out[m] = taddr(wave * 8 + cl, hh * SEG + q * RUN + 4 * m);
+  const int lane_x = ((wave * 8 + r8) * a.pitch_in + sub * 8) * 2;
+  const int lane_t = ((((wave >> 1) * NK) * 64 + (wave & 1) * 32 + cl * 4 + q) * 4) * 2;   // [chunk][16-ch group][k][lane][4]
+  const int lane_i = ((wave * 8 + r8) * a.pitch_res + sub * 8) * 2;
+  const int id_out = taddr(wave * 8 + r8, sub * 8);
+  const int chunk_x = KC * a.pitch_in * 2;           // bytes
+  const int chunk_t = KC * 4 * NK * 4 * 2;
+  const int chunk_i = KC * a.pitch_res * 2;
 
-  // ---- pointwise-role lane geometry
+  // ---- pointwise-job lane geometry
+  const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
   const int n_cot = (a.c_out + 31) >> 5;
   const int h = lane >> 5;
   const int gq = (lane >> 4) & 1;
@@ -741,185 +802,274 @@ __global__ __launch_bounds__(512, 2) void tcs_wide_kernel(const TcsArgs a) {
   const int p4 = lane & 3;
   int abase[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abase[mt] = Tile::addr(8 * h + q4, 32 * mt + 16 * gq + 4 * p4);
-  char* const et = epi + (size_t)wave * 32 * EP;
-  constexpr int LPR = TT / 8, RPI = 64 / LPR;
-  const int rsub = lane / LPR, csub = lane % LPR;
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = taddr(8 * h + q4, wm * FW + 32 * mt + 16 * gq + 4 * p4);
+  const int rsub = lane >> 4, csub = lane & 15;    // epilogue read-back: 4 rows per instruction, 16-byte column csub
   const unsigned floor2 = a.relu ? 0u : 0x80008000u;
+  const int lane_w = lane * 16;
 
-  auto tile_origin = [&](int tile, int& b, int& t0) { b = (tile / a.n_tt) / a.n_z; t0 = (tile % a.n_tt) * TT; };
-
-  // ---- prefetch streams (one issue site each)
+  // ---- X / T stream: next depthwise stage (runs on across tile boundaries; parks on its last tile at the end)
   u32x4 X[XJ];
-  u32x4 I[2];
-  u32x2 T[NPASS * NKP];
+  u32x2 T[NK];
+  TilePos dwp;
+  dwp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
   int dw_tile = blockIdx.x, dw_chunk = 0;
-  const unsigned short* dw_src = nullptr;
-  auto dw_seek = [&]() {
-    if (dw_tile < a.n_tiles) {
-      int b, t0; tile_origin(dw_tile, b, t0);
-      dw_src = a.x + ((size_t)b * a.c_in * a.pitch_in + (t0 * STRIDE - a.padl8));
+  auto x_origin = [&](const TilePos& p) { return (p.b * a.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
+  int x_soff = x_origin(dwp);
+  int t_soff = 0;
+  auto dw_issue = [&]() {            // X <- rows of the next depthwise stage; t_soff <- its tap fragments
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) X[j] = ld16(rx, lane_x + j * 128, x_soff);
+    t_soff = dw_chunk * chunk_t;
+    const bool wrap = dw_chunk + 1 == n_main;
+    const bool adv = wrap && dw_tile + tile_step < a.n_tiles;
+    dw_chunk = wrap ? 0 : dw_chunk + 1;
+    dw_tile += adv ? tile_step : 0;
+    dwp.advance_if(adv, a.n_tt, a.n_z);
+    x_soff = wrap ? x_origin(dwp) : x_soff + chunk_x;
+  };
+  // taps are fetched in three groups of passes so that at most two groups are live: group 0 of the NEXT stage when the
+  // current depthwise is done, groups 1 / 2 of the current stage while the groups before them run
+  constexpr int P1 = (NPASS + 2) / 3, P2 = (2 * NPASS + 2) / 3;
+  auto tap_issue = [&](int p0, int p1) {
+#pragma unroll
+    for (int k = p0 * NKP; k < p1 * NKP; ++k) T[k] = ld8(rt, lane_t + ((k * 512) & 4095), t_soff + ((k * 512) & ~4095));
+  };
+  // ---- I stream: next identity (residual) stage
+  u32x4 I[IDJ];
+  TilePos idp;
+  idp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+  int id_tile = blockIdx.x, id_s = 0;
+  auto i_origin = [&](const TilePos& p) { return (p.b * a.c_res * a.pitch_res + p.tt * TT) * 2; };
+  int i_soff = i_origin(idp);
+  auto id_issue = [&]() {
+#pragma unroll
+    for (int j = 0; j < IDJ; ++j) I[j] = ld16(ri, lane_i + j * 128, i_soff);
+    const bool wrap = id_s + 1 == n_res;
+    const bool adv = wrap && id_tile + tile_step < a.n_tiles;
+    id_s = wrap ? 0 : id_s + 1;
+    id_tile += adv ? tile_step : 0;
+    idp.advance_if(adv, a.n_tt, a.n_z);
+    i_soff = wrap ? i_origin(idp) : i_soff + chunk_i;
+  };
+  // ---- W stream: weight fragments of the current (wc) and the next (wn) stage of this wave's output-channel tiles
+  s16x8 ring[2][NT];
+  TilePos wp;
+  wp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+  int w_tile = blockIdx.x, w_s = 0;
+  bool wc_res = false, wn_res = false;
+  int wc_soff[NT], wn_soff[NT];
+  auto w_seek = [&]() {              // wn <- fragments of stage w_s of tile position wp
+    wn_res = w_s >= n_main;
+    const int idx = wn_res ? w_s - n_main : w_s;
+    const int kt = wn_res ? a.kt_res : a.kt_main;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cot = (wp.z * WN + wn) * NT + nt;
+      wn_soff[nt] = ((cot < n_cot ? cot : n_cot - 1) * kt + idx * 4) * 1024;
     }
   };
-  auto dw_issue = [&]() {
-    if (dw_tile >= a.n_tiles) return;
-    const unsigned short* src = dw_src + lane_x;
+  auto w_advance = [&]() {           // wc <- wn; wn <- the stage after it
+    wc_res = wn_res;
 #pragma unroll
-    for (int j = 0; j < XJ; ++j) X[j] = *reinterpret_cast<const u32x4*>(src + j * 64);
-    if (++dw_chunk == n_main) { dw_chunk = 0; dw_tile += tile_step; dw_seek(); }
-    else dw_src += chunk_x;
+    for (int nt = 0; nt < NT; ++nt) wc_soff[nt] = wn_soff[nt];
+    const bool wrap = w_s + 1 == n_stage;
+    const bool adv = wrap && w_tile + tile_step < a.n_tiles;
+    w_s = wrap ? 0 : w_s + 1;
+    w_tile += adv ? tile_step : 0;
+    wp.advance_if(adv, a.n_tt, a.n_z);
+    w_seek();
   };
-  int id_tile = blockIdx.x, id_s = 0, id_b = 0, id_t0 = 0;
-  auto id_issue = [&]() {
-    if (id_tile >= a.n_tiles || n_res == 0) return;
-    if (id_s == 0) tile_origin(id_tile, id_b, id_t0);
-    const unsigned short* src = a.xres + ((size_t)(id_b * a.c_res + id_s * KC) * a.pitch_res + id_t0) + lane_i;
+  auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) I[j] = *reinterpret_cast<const u32x4*>(src + j * 64);
-    if (++id_s == n_res) { id_s = 0; id_tile += tile_step; }
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool res = next ? wn_res : wc_res;
+      const int soff = (next ? wn_soff[nt] : wc_soff[nt]) + ks * 1024;
+      slot[nt] = __builtin_bit_cast(s16x8, res ? ld16(rwr, lane_w, soff) : ld16(rwm, lane_w, soff));
+    }
   };
 
+  // ---- depthwise job pieces
+  s16x4 P[NP];
+  f32x4 d[M];
+  auto xs_write = [&]() {
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 128);
+      d2[0] = u32x2{X[j][0], X[j][1]};
+      d2[1] = u32x2{X[j][2], X[j][3]};
+    }
+  };
+  auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
+  auto dw_begin = [&]() {
+#pragma unroll
+    for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < M + NKP - 1; ++u) win_load(u);
+  };
+  auto dw_pass = [&](int p) {
+    if (p + 1 < NPASS) {
+#pragma unroll
+      for (int u = 0; u < NKP; ++u) win_load((p + 1) * NKP + M - 1 + u);
+    }
+#pragma unroll
+    for (int k = 0; k < NKP; ++k)
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + k]), P[p * NKP + k + m], d[m], 0, 0, 0);
+  };
+  auto dw_store = [&](char* dst) {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+  };
+
+  // ---- pointwise job pieces
+  f32x16 acc[MT][NT];
+  float bnext[NT];
+  auto bias_fetch = [&](const TilePos& p) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = ((p.z * WN + wn) * NT + nt) * 32 + (lane & 31);
+      bnext[nt] = a.bias[col < a.c_out ? col : 0];
+    }
+  };
+  s16x8 af[MT], afB[MT];            // afB: second buffer of the residual stages (no depthwise to hide the read behind)
+  auto read_a = [&](const char* src, int ks, s16x8 (&f)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB + 4 * ROWB));
+      f[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  // k-step ks of the current stage; its ring slot is refilled with k-step ks+2 (of the next stage for ks >= 2)
+  auto mfma_ks = [&](int ks, const s16x8 (&f)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks & 1][nt], acc[mt][nt], 0, 0, 0);
+    load_w(ring[ks & 1], ks >= 2, (ks + 2) & 3);
+  };
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  // pointwise stage gs  ||  depthwise of the next main stage (of the next tile after the last stage of a tile).
+  // SB pins the interleaving: left alone, the scheduler hoists every LDS read to the top of the block and spills.
   unsigned gs = 0;
-  dw_seek();
-  dw_issue();
-  id_issue();
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
-    int b, t0;
-    tile_origin(tile, b, t0);
-    const int z = (tile / a.n_tt) % a.n_z;
-    const int cot0 = (z * 8 + wave) * NT;
-
-    f32x16 acc[MT][NT];
+  auto body_main = [&]() {
+    const char* const src = dwt + (gs & 1) * TILEB;
+    char* const dst = dwt + ((gs + 1) & 1) * TILEB;
+    PSTAMP(4 * gs);
+    xs_write();
+    read_a(src, 0, af);
+    dw_begin();
+    tap_issue(P1, P2);
+    SB();
+    mfma_ks(0, af);
+    SB();
+    read_a(src, 1, af);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = (cot0 + j) * 32 + (lane & 31);
-      const float bv = a.bias[col < a.c_out ? col : 0];
+    for (int p = 0; p < P1; ++p) { dw_pass(p); SB(); }
+    tap_issue(P2, NPASS);
+    mfma_ks(1, af);
+    SB();
+    read_a(src, 2, af);
+#pragma unroll
+    for (int p = P1; p < P2; ++p) { dw_pass(p); SB(); }
+    dw_issue();
+    mfma_ks(2, af);
+    SB();
+    read_a(src, 3, af);
+#pragma unroll
+    for (int p = P2; p < NPASS; ++p) { dw_pass(p); SB(); }
+    mfma_ks(3, af);
+    SB();
+    dw_store(dst);
+    tap_issue(0, P1);
+    w_advance();
+    PSTAMP(4 * gs + 1);
+    stage_barrier();
+    PSTAMP(4 * gs + 2);
+    ++gs;
+  };
+  // pointwise stage gs  ||  copy of the next residual stage's block-input rows
+  auto body_res = [&]() {
+    const char* const src = dwt + (gs & 1) * TILEB;
+    char* const dst = dwt + ((gs + 1) & 1) * TILEB;
+#pragma unroll
+    for (int j = 0; j < IDJ; ++j) *reinterpret_cast<u32x4*>(dst + (id_out ^ (j << 7))) = I[j];
+    PSTAMP(4 * gs);
+    id_issue();
+    read_a(src, 0, af);
+    read_a(src, 1, afB);
+    SB();
+    mfma_ks(0, af);
+    read_a(src, 2, af);
+    SB();
+    mfma_ks(1, afB);
+    read_a(src, 3, afB);
+    SB();
+    mfma_ks(2, af);
+    SB();
+    mfma_ks(3, afB);
+    w_advance();
+    PSTAMP(4 * gs + 1);
+    stage_barrier();
+    PSTAMP(4 * gs + 2);
+    ++gs;
+  };
+
+  // ---- prologue: depthwise of the first stage alone
+  TilePos pos;
+  pos.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+  dw_issue();
+  tap_issue(0, NPASS);
+  if (n_res) id_issue();
+  w_seek();
+  w_advance();
+  load_w(ring[0], false, 0);
+  load_w(ring[1], false, 1);
+  bias_fetch(pos);
+  {
+    xs_write();
+    dw_begin();
+    dw_issue();
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) dw_pass(p);
+    dw_store(dwt);
+    tap_issue(0, P1);
+    stage_barrier();
+  }
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
+    const int b = pos.b, t0 = pos.tt * TT;
+    const int cot0 = (pos.z * WN + wn) * NT;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
-    }
-    constexpr int RING = 2;                        // the ring is live across the depthwise phase: keep it short
-    s16x8 ring[RING][NT];
-    const unsigned short* wptr[NT];
-    int cotc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      cotc[nt] = cot0 + nt < n_cot ? cot0 + nt : n_cot - 1;
-      wptr[nt] = a.pw_w + ((size_t)cotc[nt] * a.kt_main * 64 + lane) * 8;
-    }
-    int gk_next = 0;
-    const int gk_main = 4 * n_main, gk_end = 4 * (n_main + n_res);
-    auto load_w = [&](s16x8 (&slot)[NT]) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) slot[nt] = __builtin_bit_cast(s16x8, *reinterpret_cast<const u32x4*>(wptr[nt]));
-      ++gk_next;
-      if (gk_next == gk_main && gk_main < gk_end) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wptr[nt] = a.res_w + ((size_t)cotc[nt] * a.kt_res * 64 + lane) * 8;
-      } else if (gk_next < gk_end) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wptr[nt] += 64 * 8;
-      }
-    };
-#pragma unroll
-    for (int r = 0; r < RING; ++r) load_w(ring[r]);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
 
-    auto pointwise = [&](const char* src) {
-      s16x8 afA[MT], afB[MT];
-      auto read_a = [&](int ks, s16x8 (&af)[MT]) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * Tile::ROWB));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * Tile::ROWB + 4 * Tile::ROWB));
-          af[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      };
-      auto mfma_ks = [&](int ks, const s16x8 (&af)[MT]) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
-        load_w(ring[ks % RING]);
-      };
-      read_a(0, afA);
-      read_a(1, afB);
-      mfma_ks(0, afA);
-      read_a(2, afA);
-      mfma_ks(1, afB);
-      read_a(3, afB);
-      mfma_ks(2, afA);
-      mfma_ks(3, afB);
-    };
+    for (int s = 0; s + 1 < n_main; ++s) body_main();
+    for (int s = 0; s < n_res; ++s) body_res();
+    body_main();
+    PSTAMP(4 * (gs - 1) + 3);
 
-    for (int s = 0; s < n_main; ++s, ++gs) {
-      char* const dst = dwt + (gs & 1) * Tile::BYTES;
-      STAMP(1 + 5 * s);
-      // taps of this stage (statically indexed MFMA operands), then staged rows -> wave-private LDS
-      const unsigned short* tp = a.taps + (size_t)s * chunk_t + lane_t;
-#pragma unroll
-      for (int k = 0; k < NPASS * NKP; ++k) T[k] = *reinterpret_cast<const u32x2*>(tp + k * 256);
-#pragma unroll
-      for (int j = 0; j < XJ; ++j) {
-        u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 128);
-        d2[0] = u32x2{X[j][0], X[j][1]};
-        d2[1] = u32x2{X[j][2], X[j][3]};
-      }
-      STAMP(2 + 5 * s);
-      dw_issue();
-      f32x4 d[M];
-#pragma unroll
-      for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s16x4 P0[NPP];
-      auto load_win = [&](int pass, s16x4 (&P)[NPP]) {
-#pragma unroll
-        for (int u = 0; u < NPP; ++u) P[u] = *reinterpret_cast<const s16x4*>(xrow + (pass * NKP + u) * 8);
-      };
-      auto mfma_pass = [&](int pass, const s16x4 (&P)[NPP]) {
-#pragma unroll
-        for (int k = 0; k < NKP; ++k)
-#pragma unroll
-          for (int m = 0; m < M; ++m)
-            d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[pass * NKP + k]), P[m * STRIDE + k], d[m], 0, 0, 0);
-      };
-#pragma unroll
-      for (int pass = 0; pass < NPASS; ++pass) {
-        load_win(pass, P0);
-        mfma_pass(pass, P0);
-      }
-#pragma unroll
-      for (int m = 0; m < M; ++m)
-        *reinterpret_cast<u32x2*>(dst + Tile::addr(cw, hh * 64 + q * RUN + 4 * m)) =
-            u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
-      STAMP(3 + 5 * s);
-      stage_barrier();
-      STAMP(4 + 5 * s);
-      pointwise(dst);
-      STAMP(5 + 5 * s);
-    }
-    for (int s = 0; s < n_res; ++s, ++gs) {
-      char* const dst = dwt + (gs & 1) * Tile::BYTES;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        *reinterpret_cast<u32x4*>(dst + Tile::addr(wave * 8 + r8, (sub + 8 * j) * 8)) = I[j];
-      id_issue();
-      stage_barrier();
-      pointwise(dst);
-    }
-
-    // ---- epilogue: bf16 pack + ReLU on packed pairs, transposed through a wave-private LDS tile
+    // ---- epilogue: bias of the next tile first, then bf16 pack + ReLU on packed pairs, transposed through the
+    //      wave-private LDS region
+    pos.advance_if(tile + tile_step < a.n_tiles, a.n_tt, a.n_z);
+    bias_fetch(pos);
     unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
     int len_out = 0x7fffffff;
-    if (a.zero_tail) len_out = conv_len(a.len_in[b], a.kernel, STRIDE, a.padding, a.dilation);
-    const bool partial = t0 + TT > len_out;
+    if (a.zero_tail) len_out = conv_len(a.len_in[b], a.kernel, 1, a.padding, a.dilation);
+    const int tw = t0 + wm * FW;
+    const bool partial = tw + FW > len_out;
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cob = (cot0 + nt) * 32;
-      char* const row = et + (size_t)(lane & 31) * EP + 8 * h;
+      char* const row = priv + (size_t)(lane & 31) * EP + 8 * h;
       const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -928,7 +1078,7 @@ __global__ __launch_bounds__(512, 2) void tcs_wide_kernel(const TcsArgs a) {
           float v0 = acc[mt][nt][4 * rg + 0], v1 = acc[mt][nt][4 * rg + 1];
           float v2 = acc[mt][nt][4 * rg + 2], v3 = acc[mt][nt][4 * rg + 3];
           if (partial) {
-            const int t = t0 + 32 * mt + 8 * rg + 4 * h;
+            const int t = tw + 32 * mt + 8 * rg + 4 * h;
             v0 = t + 0 < len_out ? v0 : 0.f; v1 = t + 1 < len_out ? v1 : 0.f;
             v2 = t + 2 < len_out ? v2 : 0.f; v3 = t + 3 < len_out ? v3 : 0.f;
           }
@@ -937,37 +1087,46 @@ __global__ __launch_bounds__(512, 2) void tcs_wide_kernel(const TcsArgs a) {
           *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
         }
       }
+      if (csub < FW / 8) {
 #pragma unroll
-      for (int r0 = 0; r0 < 32; r0 += RPI) {
-        const int rl = r0 + rsub;
-        const int co = cob + rl;
-        const int t = t0 + csub * 8;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(et + (size_t)rl * EP + csub * 16);
-        if (co < a.c_out && t < a.pitch_out)
-          *reinterpret_cast<u32x4*>(yb + (size_t)(b * a.c_out + co) * a.pitch_out + t) = v;
+        for (int r0 = 0; r0 < 32; r0 += 4) {
+          const int rl = r0 + rsub;
+          const int co = cob + rl;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(priv + (size_t)rl * EP + csub * 16);
+          if (co < a.c_out)
+            *reinterpret_cast<u32x4*>(yb + (size_t)(b * a.c_out + co) * a.pitch_out + tw + csub * 8) = v;
+        }
       }
     }
   }
+#undef SB
 }
 
-template <int NPASS, int XJ>
-static int launch_wide(TcsArgs& a, hipStream_t stream) {
-  constexpr int TT = 128, CO_WG = 512;
+static int cu_count() {
+  static int n_cu = 0;
+  if (n_cu) return n_cu;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    return n_cu = prop.multiProcessorCount;
+  return n_cu = 256;
+}
+
+template <int NPASS, int XJ, int MT, int WM>
+static int launch_pipe(TcsArgs& a, hipStream_t stream) {
+  constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);
+  constexpr int ROWB = TT <= 128 ? 256 : 512;
   a.n_tt = (a.t_out + TT - 1) / TT;
   a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
   a.n_tiles = a.batch * a.n_tt * a.n_z;
-  const size_t lds = (size_t)2 * KC * TT * 2 + (size_t)8 * 32 * (TT * 2 + 16) + (size_t)KC * a.xpitch * 2;
+  const int xs_b = 8 * a.xpitch * 2, ep_b = 32 * (FW * 2 + 16);
+  a.privb = round_up(xs_b > ep_b ? xs_b : ep_b, 16);
+  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * a.privb;
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = tcs_wide_kernel<NPASS, XJ>;
+  auto kern = tcs_pipe_kernel<NPASS, XJ, MT, WM>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = cu_count();
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
   (void)hipGetLastError();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
@@ -988,13 +1147,7 @@ static int launch(TcsArgs& a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = cu_count();
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;      // persistent: one workgroup per CU
   (void)hipGetLastError();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
@@ -1065,19 +1218,21 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     a.xpitch = a.xe + 4;                              // row pitch == 8 (mod 16) bytes: conflict-free window reads
     const int xj = a.xe / 64;
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
-    if (tz && wide && d->stride == 1 && a.taps_lds && getenv("TS_NO_WIDE") == nullptr) {
-      // all-waves-accumulate kernel for the wide layers (128-frame tiles): its own window geometry
+    if (tz && d->stride == 1 && a.npass <= 7 && getenv("TS_NO_PIPE") == nullptr) {
+      // pipelined all-waves kernel: 96-frame granules, its own window geometry
       TcsArgs w = a;
-      const int n_tt128 = (d->t_out + 127) / 128;
-      w.xuse = w.woff + (64 + 48) * 1 + 4 * (3 + d->dw_ksteps);
+      const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;
+      const int TTp = 96 * WM;
+      const int n_ttp = (d->t_out + TTp - 1) / TTp;
+      w.xuse = w.woff + TTp + 4 * d->dw_ksteps;
       w.xe = round_up(w.xuse, 64);
       w.xpitch = w.xe + 4;
-      const bool fits = (n_tt128 - 1) * 128 - w.padl8 + w.xe <= d->pitch_in && (d->c_res == 0 || d->pitch_res >= n_tt128 * 128) &&
-                        d->pitch_out >= n_tt128 * 128;
+      const bool fits = (n_ttp - 1) * TTp - w.padl8 + w.xe <= d->pitch_in && d->pitch_out >= n_ttp * TTp &&
+                        (d->c_res == 0 || d->pitch_res >= (n_ttp - 1) * TTp + round_up(TTp, 64));
       if (fits) {
-#define TS_WIDE(NP_, XJ_) if (w.npass == NP_ && w.xe == 64 * XJ_) return launch_wide<NP_, XJ_>(w, stream);
-        TS_WIDE(3, 3) TS_WIDE(4, 3) TS_WIDE(5, 3) TS_WIDE(6, 4) TS_WIDE(7, 4)
-#undef TS_WIDE
+#define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) return launch_pipe<NP_, XJ_, 3, WM_>(w, stream);
+        TS_PIPE(3, 4, 2) TS_PIPE(4, 4, 2) TS_PIPE(5, 3, 1) TS_PIPE(6, 3, 1) TS_PIPE(7, 3, 1)
+#undef TS_PIPE
       }
     }
     if (tz) {
