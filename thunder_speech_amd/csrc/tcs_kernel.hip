@@ -40,6 +40,12 @@ constexpr int KC = 64;         // input channels per stage
 constexpr int NKP = 3;         // depthwise k-steps (of 4 samples) per pass
 constexpr int XMAX = 5;        // staged row length <= 64 * XMAX elements
 constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
+#ifndef TS_PIPE_RING
+#define TS_PIPE_RING 2
+#endif
+#ifndef TS_WIN_DIST
+#define TS_WIN_DIST 1
+#endif
 constexpr int RING_BYTES = 8;   // weight-fragment prefetch depth: RING_BYTES KiB per wave in flight
 
 struct TcsArgs {
@@ -113,7 +119,7 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {
 #define STAMP(slot) do { } while (0)
 #endif
 #ifdef TS_STAMP
-#define PSTAMP(slot) do { if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) < 64) a.dbg[wave * 64 + (slot)] = clock64(); } while (0)
+#define PSTAMP(slot) do { if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) < 128) a.dbg[wave * 128 + (slot)] = clock64(); } while (0)
 #else
 #define PSTAMP(slot) do { } while (0)
 #endif
@@ -708,6 +714,60 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
 // T (tap fragments of the next depthwise stage, loaded when the current one is done), I (identity rows of the residual
 // stages), W (weight fragments, 2-deep ring).
 // ======================================================================================================
+// compile-time loop: f(std::integral_constant<int, I>) for I in [A, B)
+template <int A, int B, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (A < B) {
+    f(std::integral_constant<int, A>{});
+    static_for<A + 1, B>(f);
+  }
+}
+// at most N vector-memory operations outstanding (N is clamped to the 6-bit counter)
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  constexpr int n = N < 63 ? N : 63;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15) | ((n >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
+
+// Tap DMA bookkeeping of the pipelined kernel.  The hardware retires vector-memory operations in order, so "the DMA of
+// quad q has landed" == "at most (operations issued after it) are still outstanding".  A main body issues, in program
+// order (the sched barriers pin it):
+//   [taps of passes < dist read] ks0: NT | passes [0, p1) | ks1: NT | passes [p1, p2) | ks2: NT | passes [p2, npass) | rows: XJ | ks3: NT
+// and at the end of pass i one DMA per tap quad whose last k-step that pass consumed (ascending quad order); the taps of
+// pass i + dist are read at the start of pass i.  wait_count() walks that list.  Residual bodies and epilogues between
+// two main bodies only add operations, which makes the waits stricter, never weaker.
+struct TapSched {
+  int npass, p1, p2, xj, nt, nk, nkq, dist;
+  constexpr int last_pass(int q) const { return ((4 * q + 3 < nk ? 4 * q + 3 : nk - 1)) / 3; }
+  // walk one body: position (operations issued before it) of the DMA of quad `q` (want_dma) or of the read point of the
+  // taps of pass `q` (!want_dma); q == -1 returns the operations per body
+  constexpr int walk(bool want_dma, int q) const {
+    int n = 0;
+    if (!want_dma && q >= 0 && q < dist) return 0;          // read in dw_begin, ahead of ks0
+    n += nt;                                                  // ks0
+    for (int i = 0; i < npass; ++i) {
+      if (i == p1) n += nt;                                   // ks1
+      if (i == p2) n += nt;                                   // ks2
+      if (!want_dma && q == i + dist) return n;
+      for (int r = 0; r < nkq; ++r)
+        if (last_pass(r) == i) {
+          if (want_dma && r == q) return n;
+          ++n;
+        }
+    }
+    if (p1 >= npass) n += nt;
+    if (p2 >= npass) n += nt;
+    return n + xj + nt;                                       // rows, ks3
+  }
+  // counter value that guarantees the taps of pass `for_pass` have landed when they are read
+  constexpr int wait_count(int for_pass) const {
+    int kmax = 3 * for_pass + 2;
+    if (kmax > nk - 1) kmax = nk - 1;
+    return (walk(true, -1) - 1 - walk(true, kmax / 4)) + walk(false, for_pass);
+  }
+};
+
 // position of a tile in the (clip, output-channel split, time tile) grid, advanced by the grid stride without divisions
 struct TilePos {
   int b, z, tt;
@@ -747,8 +807,10 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
   constexpr int NP = NK + M - 1;                  // 4-sample window groups a lane reads per stage
   constexpr int ROWB = TT <= 128 ? 256 : 512;     // dwt row pitch: 16 / 32 swizzled 16-byte chunks
   constexpr int TILEB = KC * ROWB;
-  constexpr int EP = FW * 2 + 16;
+  constexpr int EP = FW * 2 + 24;                 // epilogue tile row pitch: 8 x odd bytes -> the 8-byte MFMA-layout writes of a half-wave hit 64 distinct banks
+  static_assert((EP / 8) % 2 == 1, "");
   constexpr int IDJ = (TT + 63) / 64;
+  constexpr int NKQ = (NK + 3) / 4;               // tap fragments travel global -> LDS in quads of 4 k-steps (1 KiB per wave)
   static_assert(RUN % 4 == 0, "lane runs are whole 4-frame steps");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -757,6 +819,7 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* const priv = smem + 2 * TILEB + (size_t)wave * a.privb;   // staged input rows / epilogue tile (never live together)
+  char* const tapl = priv + a.privb - NKQ * 1024;                 // this wave's tap fragments of the running depthwise stage
   const int n_main = a.c_in / KC;
   const int n_res = a.c_res / KC;
   const int n_stage = n_main + n_res;
@@ -768,7 +831,8 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
   constexpr int RSRC_FLAGS = 0x00020000;          // gfx9 raw buffer: 32-bit data format
   auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
   const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(a.x) - TS_GUARD_BYTES);   // offsets may reach into the front guard
-  const __amdgpu_buffer_rsrc_t rt = rsrc(a.taps);
+  // exact bound: the last quad of a stage over-reads up to 3 k-steps, out-of-range lanes must return 0 instead of faulting
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.taps), 0, n_main * (KC * 4 * NK * 4 * 2), RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
   const __amdgpu_buffer_rsrc_t rwm = rsrc(a.pw_w);
   const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? a.res_w : a.pw_w);
@@ -786,7 +850,10 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
 #pragma unroll
   for (int m = 0; m < M; ++m) dw_out[m] = taddr(wave * 8 + cl, hh * SEG + q * RUN + 4 * m);
   const int lane_x = ((wave * 8 + r8) * a.pitch_in + sub * 8) * 2;
-  const int lane_t = ((((wave >> 1) * NK) * 64 + (wave & 1) * 32 + cl * 4 + q) * 4) * 2;   // [chunk][16-ch group][k][lane][4]
+  // tap fragments [chunk][16-ch group][k][64 lanes][4]: this wave owns lanes [32 (wave & 1), +32) of group wave >> 1.
+  // DMA lane L fetches 16 bytes of k-step 4j + (L >> 4); in LDS the fragment of (k, lane t) lands at k * 256 + t * 8.
+  const int lane_t = (wave >> 1) * NK * 512 + (lane >> 4) * 512 + (wave & 1) * 256 + (lane & 15) * 16;
+  const char* const trow = tapl + (cl * 4 + q) * 8;
   const int lane_i = ((wave * 8 + r8) * a.pitch_res + sub * 8) * 2;
   const int id_out = taddr(wave * 8 + r8, sub * 8);
   const int chunk_x = KC * a.pitch_in * 2;           // bytes
@@ -809,31 +876,30 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
 
   // ---- X / T stream: next depthwise stage (runs on across tile boundaries; parks on its last tile at the end)
   u32x4 X[XJ];
-  u32x2 T[NK];
   TilePos dwp;
   dwp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
   int dw_tile = blockIdx.x, dw_chunk = 0;
   auto x_origin = [&](const TilePos& p) { return (p.b * a.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
   int x_soff = x_origin(dwp);
-  int t_soff = 0;
-  auto dw_issue = [&]() {            // X <- rows of the next depthwise stage; t_soff <- its tap fragments
+  auto dw_issue = [&]() {            // X <- rows of the next depthwise stage
 #pragma unroll
     for (int j = 0; j < XJ; ++j) X[j] = ld16(rx, lane_x + j * 128, x_soff);
-    t_soff = dw_chunk * chunk_t;
-    const bool wrap = dw_chunk + 1 == n_main;
-    const bool adv = wrap && dw_tile + tile_step < a.n_tiles;
-    dw_chunk = wrap ? 0 : dw_chunk + 1;
-    dw_tile += adv ? tile_step : 0;
-    dwp.advance_if(adv, a.n_tt, a.n_z);
-    x_soff = wrap ? x_origin(dwp) : x_soff + chunk_x;
+    if (++dw_chunk == n_main) {      // once per tile: next tile (or park on this one)
+      dw_chunk = 0;
+      if (dw_tile + tile_step < a.n_tiles) { dw_tile += tile_step; dwp.advance(a.n_tt, a.n_z); }
+      x_soff = x_origin(dwp);
+    } else {
+      x_soff += chunk_x;
+    }
   };
-  // taps are fetched in three groups of passes so that at most two groups are live: group 0 of the NEXT stage when the
-  // current depthwise is done, groups 1 / 2 of the current stage while the groups before them run
+  // ---- T stream: tap fragments of the NEXT depthwise stage, DMA'd quad by quad into the slots the running stage has
+  //      finished with (buffer_load ... lds: no VGPR round trip, 1/4 of the vector-memory instructions of register taps)
   constexpr int P1 = (NPASS + 2) / 3, P2 = (2 * NPASS + 2) / 3;
-  auto tap_issue = [&](int p0, int p1) {
-#pragma unroll
-    for (int k = p0 * NKP; k < p1 * NKP; ++k) T[k] = ld8(rt, lane_t + ((k * 512) & 4095), t_soff + ((k * 512) & ~4095));
+  int t_next = (n_main > 1 ? 1 : 0) * chunk_t;      // scalar byte offset of the next stage's fragments
+  auto tap_dma = [&](int jq, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (TS_LDS void*)(tapl + jq * 1024), 16, lane_t, soff + jq * 2048, 0, 0);
   };
+  auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
   // ---- I stream: next identity (residual) stage
   u32x4 I[IDJ];
   TilePos idp;
@@ -844,53 +910,60 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
   auto id_issue = [&]() {
 #pragma unroll
     for (int j = 0; j < IDJ; ++j) I[j] = ld16(ri, lane_i + j * 128, i_soff);
-    const bool wrap = id_s + 1 == n_res;
-    const bool adv = wrap && id_tile + tile_step < a.n_tiles;
-    id_s = wrap ? 0 : id_s + 1;
-    id_tile += adv ? tile_step : 0;
-    idp.advance_if(adv, a.n_tt, a.n_z);
-    i_soff = wrap ? i_origin(idp) : i_soff + chunk_i;
+    if (++id_s == n_res) {
+      id_s = 0;
+      if (id_tile + tile_step < a.n_tiles) { id_tile += tile_step; idp.advance(a.n_tt, a.n_z); }
+      i_soff = i_origin(idp);
+    } else {
+      i_soff += chunk_i;
+    }
   };
   // ---- W stream: weight fragments of the current (wc) and the next (wn) stage of this wave's output-channel tiles
-  s16x8 ring[2][NT];
+  constexpr int RING = TS_PIPE_RING;              // 4: every weight fragment is requested a whole stage before its MFMA
+  s16x8 ring[RING][NT];
   TilePos wp;
   wp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
   int w_tile = blockIdx.x, w_s = 0;
-  bool wc_res = false, wn_res = false;
+  __amdgpu_buffer_rsrc_t rwc = rwm, rwn = rwm;
   int wc_soff[NT], wn_soff[NT];
-  auto w_seek = [&]() {              // wn <- fragments of stage w_s of tile position wp
-    wn_res = w_s >= n_main;
-    const int idx = wn_res ? w_s - n_main : w_s;
-    const int kt = wn_res ? a.kt_res : a.kt_main;
+  auto w_seek = [&](bool res) {      // wn <- first main / first residual stage of tile position wp
+    rwn = res ? rwr : rwm;
+    const int kt = res ? a.kt_res : a.kt_main;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cot = (wp.z * WN + wn) * NT + nt;
-      wn_soff[nt] = ((cot < n_cot ? cot : n_cot - 1) * kt + idx * 4) * 1024;
+      wn_soff[nt] = (cot < n_cot ? cot : n_cot - 1) * kt * 1024;
     }
   };
   auto w_advance = [&]() {           // wc <- wn; wn <- the stage after it
-    wc_res = wn_res;
+    rwc = rwn;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wc_soff[nt] = wn_soff[nt];
-    const bool wrap = w_s + 1 == n_stage;
-    const bool adv = wrap && w_tile + tile_step < a.n_tiles;
-    w_s = wrap ? 0 : w_s + 1;
-    w_tile += adv ? tile_step : 0;
-    wp.advance_if(adv, a.n_tt, a.n_z);
-    w_seek();
+    ++w_s;
+    if (w_s == n_stage) {            // once per tile
+      w_s = 0;
+      if (w_tile + tile_step < a.n_tiles) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
+      w_seek(false);
+    } else if (w_s == n_main) {
+      w_seek(true);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wn_soff[nt] += 4096;
+    }
   };
   auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const bool res = next ? wn_res : wc_res;
-      const int soff = (next ? wn_soff[nt] : wc_soff[nt]) + ks * 1024;
-      slot[nt] = __builtin_bit_cast(s16x8, res ? ld16(rwr, lane_w, soff) : ld16(rwm, lane_w, soff));
-    }
+    for (int nt = 0; nt < NT; ++nt)
+      slot[nt] = __builtin_bit_cast(s16x8, next ? ld16(rwn, lane_w + ks * 1024, wn_soff[nt]) : ld16(rwc, lane_w + ks * 1024, wc_soff[nt]));
   };
 
+  unsigned gs = 0;                 // stages done by this workgroup (dwt buffer parity)
   // ---- depthwise job pieces
   s16x4 P[NP];
+  u32x2 T[NK];
   f32x4 d[M];
+  constexpr TapSched TS{NPASS, (NPASS + 2) / 3, (2 * NPASS + 2) / 3, XJ, NT, NK, NKQ, TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS};
+  auto tap_drain = [&]() { vm_wait<NT>(); };   // every tap DMA of the previous stage was issued before the NT weight loads of its last k-step
   auto xs_write = [&]() {
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
@@ -900,22 +973,37 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
     }
   };
   auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
+  auto tap_load = [&](int kk) { T[kk] = *reinterpret_cast<const u32x2*>(trow + kk * 256); };
+  // operand prefetch distance in passes: an LDS round trip with all 8 waves reading costs about 3 passes of MFMA time
+  constexpr int WD = TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS;
   auto dw_begin = [&]() {
 #pragma unroll
     for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < M + NKP - 1; ++u) win_load(u);
-  };
-  auto dw_pass = [&](int p) {
-    if (p + 1 < NPASS) {
+    for (int u = 0; u < M - 1 + NKP * WD; ++u) win_load(u);
+    vm_wait<TS.wait_count(WD - 1)>();
 #pragma unroll
-      for (int u = 0; u < NKP; ++u) win_load((p + 1) * NKP + M - 1 + u);
+    for (int kk = 0; kk < NKP * WD; ++kk) tap_load(kk);
+  };
+  auto dw_pass = [&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    if constexpr (p + WD < NPASS) {
+#pragma unroll
+      for (int u = 0; u < NKP; ++u) win_load((p + WD) * NKP + M - 1 + u);
+      vm_wait<TS.wait_count(p + WD)>();
+#pragma unroll
+      for (int u = 0; u < NKP; ++u) tap_load((p + WD) * NKP + u);
     }
 #pragma unroll
-    for (int k = 0; k < NKP; ++k)
+    for (int kk = 0; kk < NKP; ++kk)
 #pragma unroll
       for (int m = 0; m < M; ++m)
-        d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + k]), P[p * NKP + k + m], d[m], 0, 0, 0);
+        d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m], d[m], 0, 0, 0);
+    // quads whose last k-step this pass consumed are refilled with the next stage's fragments (the MFMAs above could
+    // only issue once their tap reads had returned, so the slots are no longer being read)
+#pragma unroll
+    for (int jq = 0; jq < NKQ; ++jq)
+      if (TS.last_pass(jq) == p) tap_dma(jq, t_next);
   };
   auto dw_store = [&](char* dst) {
 #pragma unroll
@@ -942,51 +1030,65 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
       f[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
   };
-  // k-step ks of the current stage; its ring slot is refilled with k-step ks+2 (of the next stage for ks >= 2)
+  // k-step ks of the current stage; its ring slot is refilled with the k-step RING further on (of the next stage when
+  // that is past this one's four)
   auto mfma_ks = [&](int ks, const s16x8 (&f)[MT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks & 1][nt], acc[mt][nt], 0, 0, 0);
-    load_w(ring[ks & 1], ks >= 2, (ks + 2) & 3);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
+    load_w(ring[ks % RING], ks + RING >= 4, (ks + RING) & 3);
   };
 
+#ifdef TS_NO_SB
+#define SB() do { } while (0)
+#else
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#endif
   // pointwise stage gs  ||  depthwise of the next main stage (of the next tile after the last stage of a tile).
   // SB pins the interleaving: left alone, the scheduler hoists every LDS read to the top of the block and spills.
-  unsigned gs = 0;
+  // Two jobs per stage, interleaved in one instruction stream: pointwise GEMM of stage gs out of dwt[gs & 1] and the
+  // depthwise FIR of the next main stage (of the next tile after the last stage of a tile) into the other buffer.
+  // SB pins the order: left alone, the scheduler hoists every LDS read to the top of the block and spills.
   auto body_main = [&]() {
     const char* const src = dwt + (gs & 1) * TILEB;
     char* const dst = dwt + ((gs + 1) & 1) * TILEB;
+    constexpr int P1 = (NPASS + 2) / 3, P2 = (2 * NPASS + 2) / 3;
     PSTAMP(4 * gs);
-    xs_write();
-    read_a(src, 0, af);
-    dw_begin();
-    tap_issue(P1, P2);
+#if !defined(TS_EXP) || !(TS_EXP & 1)     // diagnostic builds: TS_EXP & 1 drops the depthwise job, & 2 the pointwise job
+#define DWJ(x) x
+#else
+#define DWJ(x)
+#endif
+#if !defined(TS_EXP) || !(TS_EXP & 2)
+#define PWJ(x) x
+#else
+#define PWJ(x)
+#endif
+    DWJ(xs_write();)
+    PWJ(read_a(src, 0, af);)
+    DWJ(dw_begin();)
     SB();
-    mfma_ks(0, af);
+    PWJ(mfma_ks(0, af);)
     SB();
-    read_a(src, 1, af);
-#pragma unroll
-    for (int p = 0; p < P1; ++p) { dw_pass(p); SB(); }
-    tap_issue(P2, NPASS);
-    mfma_ks(1, af);
+    PWJ(read_a(src, 1, af);)
+    static_for<0, P1>([&](auto pc) { DWJ(dw_pass(pc);) SB(); });
+    PWJ(mfma_ks(1, af);)
     SB();
-    read_a(src, 2, af);
-#pragma unroll
-    for (int p = P1; p < P2; ++p) { dw_pass(p); SB(); }
-    dw_issue();
-    mfma_ks(2, af);
+    PWJ(read_a(src, 2, af);)
+    static_for<P1, P2>([&](auto pc) { DWJ(dw_pass(pc);) SB(); });
+    PWJ(mfma_ks(2, af);)
     SB();
-    read_a(src, 3, af);
-#pragma unroll
-    for (int p = P2; p < NPASS; ++p) { dw_pass(p); SB(); }
-    mfma_ks(3, af);
+    PWJ(read_a(src, 3, af);)
+    static_for<P2, NPASS>([&](auto pc) { DWJ(dw_pass(pc);) SB(); });
+    DWJ(dw_issue();)
+    PWJ(mfma_ks(3, af);)
     SB();
-    dw_store(dst);
-    tap_issue(0, P1);
+    DWJ(dw_store(dst); tap_advance();)
     w_advance();
+#undef DWJ
+#undef PWJ
     PSTAMP(4 * gs + 1);
     stage_barrier();
     PSTAMP(4 * gs + 2);
@@ -1023,27 +1125,30 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
   TilePos pos;
   pos.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
   dw_issue();
-  tap_issue(0, NPASS);
+#pragma unroll
+  for (int jq = 0; jq < NKQ; ++jq) tap_dma(jq, 0);
   if (n_res) id_issue();
-  w_seek();
+  w_seek(false);
   w_advance();
-  load_w(ring[0], false, 0);
-  load_w(ring[1], false, 1);
+#pragma unroll
+  for (int r = 0; r < RING; ++r) load_w(ring[r], false, r);
   bias_fetch(pos);
   {
+    vm_wait<0>();                                  // first rows and taps are in
     xs_write();
     dw_begin();
     dw_issue();
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) dw_pass(p);
+    static_for<0, NPASS>([&](auto pc) { dw_pass(pc); SB(); });
     dw_store(dwt);
-    tap_issue(0, P1);
+    tap_advance();
+    vm_wait<0>();                                  // the in-body waits count on a full body's worth of operations behind each DMA
     stage_barrier();
   }
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
     const int b = pos.b, t0 = pos.tt * TT;
     const int cot0 = (pos.z * WN + wn) * NT;
+    const int len_b = a.zero_tail ? a.len_in[b] : 0;        // fetched now, used by the epilogue
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1057,15 +1162,20 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
     PSTAMP(4 * (gs - 1) + 3);
 
     // ---- epilogue: bias of the next tile first, then bf16 pack + ReLU on packed pairs, transposed through the
-    //      wave-private LDS region
+    //      wave-private LDS region.  The tap DMAs are drained first: after the stores below, a counter wait would also
+    //      have to wait for the stores.
+    tap_drain();
     pos.advance_if(tile + tile_step < a.n_tiles, a.n_tt, a.n_z);
     bias_fetch(pos);
     unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
     int len_out = 0x7fffffff;
-    if (a.zero_tail) len_out = conv_len(a.len_in[b], a.kernel, 1, a.padding, a.dilation);
+    if (a.zero_tail) len_out = conv_len(len_b, a.kernel, 1, a.padding, a.dilation);
     const int tw = t0 + wm * FW;
     const bool partial = tw + FW > len_out;
+    u32x4 keep = u32x4{~0u, ~0u, ~0u, ~0u};                 // tail zeroing is applied to the 16-byte vectors on their way out
+    if (partial) keep = keep_first(keep, len_out - (tw + csub * 8));
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    if (tile == (int)blockIdx.x) PSTAMP(100);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cob = (cot0 + nt) * 32;
@@ -1075,28 +1185,30 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          float v0 = acc[mt][nt][4 * rg + 0], v1 = acc[mt][nt][4 * rg + 1];
-          float v2 = acc[mt][nt][4 * rg + 2], v3 = acc[mt][nt][4 * rg + 3];
-          if (partial) {
-            const int t = tw + 32 * mt + 8 * rg + 4 * h;
-            v0 = t + 0 < len_out ? v0 : 0.f; v1 = t + 1 < len_out ? v1 : 0.f;
-            v2 = t + 2 < len_out ? v2 : 0.f; v3 = t + 3 < len_out ? v3 : 0.f;
-          }
-          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16_settled(v0, v1)), f2));
-          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16_settled(v2, v3)), f2));
+          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+              pack_bf16_settled(acc[mt][nt][4 * rg + 0], acc[mt][nt][4 * rg + 1])), f2));
+          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+              pack_bf16_settled(acc[mt][nt][4 * rg + 2], acc[mt][nt][4 * rg + 3])), f2));
           *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
         }
       }
+      if (tile == (int)blockIdx.x) PSTAMP(101 + 2 * nt);
       if (csub < FW / 8) {
+        unsigned short* const yrow = yb + (size_t)(b * a.c_out + cob + rsub) * a.pitch_out + tw + csub * 8;
+        const char* const prow = priv + (size_t)rsub * EP + csub * 16;
+        u32x4 v[8];                                           // all reads first: one LDS round trip per output-channel tile
 #pragma unroll
-        for (int r0 = 0; r0 < 32; r0 += 4) {
-          const int rl = r0 + rsub;
-          const int co = cob + rl;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(priv + (size_t)rl * EP + csub * 16);
-          if (co < a.c_out)
-            *reinterpret_cast<u32x4*>(yb + (size_t)(b * a.c_out + co) * a.pitch_out + tw + csub * 8) = v;
+        for (int i = 0; i < 8; ++i) {
+          const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * i * EP);   // rows are only 8-byte aligned
+          v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (partial) v[i] &= keep;
+          if (cob + 4 * i + rsub < a.c_out) *reinterpret_cast<u32x4*>(yrow + (size_t)(4 * i) * a.pitch_out) = v[i];
         }
       }
+      if (tile == (int)blockIdx.x) PSTAMP(102 + 2 * nt);
     }
   }
 #undef SB
@@ -1119,8 +1231,8 @@ static int launch_pipe(TcsArgs& a, hipStream_t stream) {
   a.n_tt = (a.t_out + TT - 1) / TT;
   a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
   a.n_tiles = a.batch * a.n_tt * a.n_z;
-  const int xs_b = 8 * a.xpitch * 2, ep_b = 32 * (FW * 2 + 16);
-  a.privb = round_up(xs_b > ep_b ? xs_b : ep_b, 16);
+  const int xs_b = 8 * a.xpitch * 2, ep_b = 32 * (FW * 2 + 24);
+  a.privb = round_up(xs_b > ep_b ? xs_b : ep_b, 16) + (NPASS * NKP + 3) / 4 * 1024;
   const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * a.privb;
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
   auto kern = tcs_pipe_kernel<NPASS, XJ, MT, WM>;

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 from thunder_speech_amd import build as B
 shutil.copy(os.path.join(ROOT, "tools", "diag", os.environ.get("TS_STAMP_LIB", "libstamp.so")), B.lib_path())
-dbg = torch.zeros(8 * 64, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(8 * 128, dtype=torch.int64, device="cuda")
 os.environ["TS_DBG_PTR"] = str(dbg.data_ptr())
 from tools.bench_tcs import layer
 from thunder_speech_amd import _lib, tensors as TS
@@ -18,7 +18,7 @@ out = TS.arena("bo", Bn, cout, T, "cuda")
 for _ in range(3):
     L.run(x, T, li, out=out, in_tail_zero=True, zero_tail=True)
 torch.cuda.synchronize()
-d = dbg.cpu().view(8, 64)
+d = dbg.cpu().view(8, 128)
 n = cin // 64
 for w in (0, 5):
     p = d[w]; base = int(p[0])
@@ -30,3 +30,12 @@ for w in (0, 5):
         if a[3]:
             line += f"  | epilogue+init {nxt - a[3]:5d}" if nxt else "  | epilogue"
         print(line)
+for w in (0, 5):
+    p = d[w]
+    e0 = int(p[4 * (n - 1) + 3])
+    print(f"wave {w} epilogue of tile 0: start->len/partial {int(p[100])-e0}, nt0 pack {int(p[101])-int(p[100])}, nt0 store {int(p[102])-int(p[101])}, "
+          f"nt1 pack {int(p[103])-int(p[102])}, nt1 store {int(p[104])-int(p[103])}, ->next stage begin {int(p[4*n])-int(p[104])}")
+for w in (0, 5):
+    p = d[w]
+    t = [int(p[110 + i]) for i in range(8)]
+    print(f"wave {w} stage 2 pass starts (rel. body begin {int(p[8])}):", [x - int(p[8]) for x in t if x], "body end", int(p[9]) - int(p[8]))
