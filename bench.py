@@ -9,7 +9,7 @@ resident in HBM, replayed from a hipGraph.
 
 Prints ONE JSON line on rank 0.  Inference shards by clip (independent units, no collective on the data path):
 every rank runs its own 64-clip batch, scaling is "weak".  `roofline` is for the dominant kernel family
-(ts::tcs_kernel, all 78 launches of a step): algorithmic bytes (ideal fusion, SURVEY 8d) / HIP-event time of the
+(ts::tcs_pipe_kernel / ts::tcs_kernel, all 78 launches of a step): algorithmic bytes (ideal fusion, SURVEY 8d) / HIP-event time of the
 encoder segment.  `cpu_baseline` times the CPU oracle (a port of the reference path, fp32 torch-CPU ops) on a
 bounded sample of the same workload on this box's host cores.
 """
@@ -28,6 +28,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
+
+
+def pmc_traffic(batch, seconds):
+    """HBM-side bytes per TCS launch from the PMC passes of this same workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 correction applied; tools/prof_bench.sh writes profiles/*_traffic.json).  Counters cannot be read
+    from inside the timed process, so this is the committed measurement; None for any other workload."""
+    if (batch, seconds) != (64, 15):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
 
 
 def build_model(device, seed=0):
@@ -177,10 +191,10 @@ def main():
                                "greedy decode (argmax + collapse), hipGraph replay" if not args.no_graph else
                                f"QuartzNet15x5 inference, batch {B}x{S} s per GPU (eager launches)",
                    "batch_per_gpu": B, "clip_seconds": S, "random_init": True},
-        "roofline": {"bound": "hbm", "kernel": "ts::tcs_kernel (all fused TCS launches of one step)",
+        "roofline": {"bound": "hbm", "kernel": "ts::tcs_pipe_kernel / ts::tcs_kernel (all fused TCS launches of one step)",
                      "launches_per_step": n_launch,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None,
+                     "traffic": pmc_traffic(B, S),
                      "algorithmic_bytes_per_launch": alg_bytes / n_launch, "avg_launch_us": enc_ms * 1e3 / n_launch,
                      "encoder_ms": enc_ms, "mfma_tflops": alg_flops / (enc_ms * 1e-3) / 1e12,
                      "mfma_frac_of_dense_bf16_peak": alg_flops / (enc_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF},
