@@ -82,6 +82,26 @@ int ts_tcs_subblock_fwd(const ts_tcs_desc* desc, const void* x, const int32_t* l
                         const int32_t* len_res, void* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Squeeze-excite of the Citrinet blocks (eval): replaces SqueezeExcite.forward (citrinet/blocks.py:70-83: AdaptiveAvgPool1d
+ * over ALL frames incl. padding -> Linear -> ReLU -> Linear -> sigmoid -> x * g) and the block tail
+ * `out = relu(se(mconv(x)) + res(x))` (citrinet/blocks.py:186-196).
+ *   y: bf16 [B][C][pitch] main-branch output of the block's last sub-block launch (no ReLU), tail zeroed
+ *      (TS_TCS_OUT_ZERO_TAIL); len: int32 [B] valid frames of y; tail_y: f32 [C] the value the reference holds beyond the
+ *      length (= the folded BN shift, ts_tcs_desc.bias: a masked input makes the conv output 0 there).
+ *   ts_se_gate_fwd : pool_ws f32 [B][C] (workspace, receives the means), gate f32 [B][C];
+ *                    w1 f32 [hidden][C], w2 f32 [C][hidden] (nn.Linear layout, no bias).
+ *   ts_se_apply_fwd: out = act( gate * y + r ), r: bf16 [B][C][pitch_r] residual branch (pointwise launch, tail zeroed) or
+ *                    NULL, tail_r its constant beyond the length; zero_tail = 1 stores 0 for frames >= len (internal
+ *                    blocks), 0 stores the reference's values there (caller-visible output).
+ * ---------------------------------------------------------------------------------------------- */
+int ts_se_gate_fwd(const void* y, const int32_t* len, const float* tail_y, int32_t batch, int32_t channels, int32_t t,
+                   int32_t pitch, int32_t hidden, const float* w1, const float* w2, float* pool_ws, float* gate,
+                   void* stream);
+int ts_se_apply_fwd(const void* y, const void* r, const float* gate, const int32_t* len, const float* tail_y,
+                    const float* tail_r, int32_t batch, int32_t channels, int32_t t, int32_t pitch_y, int32_t pitch_r,
+                    int32_t pitch_out, int32_t relu, int32_t zero_tail, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Mel-filterbank front end (eval mode): pre-emphasis -> reflect-padded STFT power -> slaney mel ->
  * log -> per-(clip, mel) masked normalisation, replaces FilterbankFeatures.forward
  * (quartznet/transform.py:136-144, :186-208, :243-255, :77-92 -> blocks.py:136-149).

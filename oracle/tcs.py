@@ -217,6 +217,8 @@ def block_forward(spec: BlockSpec, sd: Dict[str, torch.Tensor], prefix: str, x: 
             wf = bf16_round(rw * scale[:, None, None])
             res, _ = masked_conv(x, lengths, wf, spec.residual_stride, 0, 1, 1)
             res = res + shift[None, :, None]
+            if spec.has_se:
+                res = bf16_round(res)             # HIP path: the residual branch of an SE block is its own launch, stored bf16
         else:
             res, _ = masked_conv(x, lengths, rw, spec.residual_stride, 0, 1, 1)
             res = batch_norm(res, sd, rbn, training, new_stats)

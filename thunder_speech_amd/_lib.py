@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd",
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss",
-    "ts_pack_activation", "ts_unpack_activation",
+    "ts_pack_activation", "ts_unpack_activation", "ts_se_gate_fwd", "ts_se_apply_fwd",
 ]
 
 
@@ -89,6 +89,10 @@ def lib() -> C.CDLL:
     L.ts_pack_activation.restype = C.c_int
     L.ts_unpack_activation.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     L.ts_unpack_activation.restype = C.c_int
+    L.ts_se_gate_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.ts_se_gate_fwd.restype = C.c_int
+    L.ts_se_apply_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ts_se_apply_fwd.restype = C.c_int
     if L.ts_abi_version() != ABI_VERSION:
         raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")
     _lib = L

@@ -2,10 +2,10 @@
 src/thunder/citrinet/blocks.py (SqueezeExcite :48-83, CitrinetBlock :86-197, stem :200-216, body :219-255,
 CitrinetEncoder :258-278).
 
-The sub-block kernel already covers Citrinet's geometry (stride only on the last repeat, residual stride = stride).
-The squeeze-excite launch sequence (pool over ALL frames incl. padding -- quirk A3 --, gate MLP, gate * x + residual,
-ReLU) is SURVEY section 8 config C3 and is the next row to be built; until then `CitrinetBlock.forward` fails loudly
-rather than running anything that is not a HIP kernel.
+Launch sequence of a block (eval): R fused sub-block launches (the last one without ReLU or residual) -> squeeze-excite
+gate (`ts_se_gate_fwd`: pool over ALL frames incl. padding -- quirk A3 --, two bias-free linears, sigmoid) -> the residual
+1x1 conv + BN as a pointwise launch -> `ts_se_apply_fwd`: relu(gate * y + res).  All of it runs in HIP; there is no
+fallback.
 """
 from __future__ import annotations
 
@@ -15,8 +15,9 @@ import torch
 from torch import nn
 from torch.nn.common_types import _size_1_t
 
+from .. import _lib, plan as _plan, tensors as _t
 from ..blocks import Masked, MultiSequential, _PackedCache, get_same_padding
-from ..quartznet.blocks import EncoderSequential, _FusedBlockBase, _get_act_dropout_layer, _get_conv_bn_layer
+from ..quartznet.blocks import EncoderSequential, _FusedBlockBase, _bn_tensors, _get_act_dropout_layer, _get_conv_bn_layer
 
 __all__ = ["SqueezeExcite", "CitrinetBlock", "stem", "body", "CitrinetEncoder"]
 
@@ -32,7 +33,42 @@ class SqueezeExcite(nn.Module):
         )
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("SqueezeExcite: HIP kernels for the Citrinet SE path are not built yet (DESIGN.md §7)")
+        """x: [batch, channels, time] -> x * sigmoid(fc(mean_t x)); the mean runs over every frame (quirk A3)."""
+        _t.require_gpu(x, "SqueezeExcite")
+        b, c, t = x.shape
+        dev = x.device
+        full = torch.full((b,), t, dtype=torch.int32, device=dev)
+        xi = _t.backing(x) if _t.is_internal(x) else _t.backing(_t.pack(x, full, slot=("se", id(self))))
+        zeros = torch.zeros(c, dtype=torch.float32, device=dev)
+        gate = se_gate(self, xi, full, zeros, t)
+        out = _t.alloc(b, c, t, dev)
+        se_apply(xi, None, gate, full, zeros, None, t, out, relu=False, zero_tail=False)
+        y = out[:, :, :t]
+        return y if _t.is_internal(x) else _t.unpack(y)
+
+
+def se_gate(se: SqueezeExcite, y: torch.Tensor, len_i32: torch.Tensor, tail_y: torch.Tensor, t: int) -> torch.Tensor:
+    """y: bf16 [B, C, pitch] backing buffer with zeroed tails -> gate f32 [B, C] (ts_se_gate_fwd)."""
+    b, c, pitch = y.shape
+    w1 = se.fc[0].weight.detach().to(device=y.device, dtype=torch.float32).contiguous()
+    w2 = se.fc[2].weight.detach().to(device=y.device, dtype=torch.float32).contiguous()
+    pool = torch.empty(b, c, dtype=torch.float32, device=y.device)
+    gate = torch.empty(b, c, dtype=torch.float32, device=y.device)
+    st = _lib.lib().ts_se_gate_fwd(y.data_ptr(), len_i32.data_ptr(), tail_y.data_ptr(), b, c, t, pitch, w1.shape[0],
+                                   w1.data_ptr(), w2.data_ptr(), pool.data_ptr(), gate.data_ptr(),
+                                   torch.cuda.current_stream(y.device).cuda_stream)
+    _lib.check(st, "ts_se_gate_fwd")
+    return gate
+
+
+def se_apply(y, r, gate, len_i32, tail_y, tail_r, t: int, out, relu: bool, zero_tail: bool) -> None:
+    """out = act(gate * y + r) through ts_se_apply_fwd; y / r / out are [B, C, pitch] backing buffers."""
+    b, c, _ = y.shape
+    st = _lib.lib().ts_se_apply_fwd(y.data_ptr(), None if r is None else r.data_ptr(), gate.data_ptr(), len_i32.data_ptr(),
+                                    tail_y.data_ptr(), None if r is None else tail_r.data_ptr(), b, c, t, y.shape[2],
+                                    0 if r is None else r.shape[2], out.shape[2], int(relu), int(zero_tail),
+                                    out.data_ptr(), torch.cuda.current_stream(y.device).cuda_stream)
+    _lib.check(st, "ts_se_apply_fwd")
 
 
 class CitrinetBlock(_FusedBlockBase):
@@ -67,9 +103,64 @@ class CitrinetBlock(_FusedBlockBase):
     def _has_se(self) -> bool:
         return True
 
+    def _params(self) -> List[torch.Tensor]:
+        se = self.mconv[len(self.mconv) - 1].layer[0]
+        return super()._params() + [se.fc[0].weight, se.fc[2].weight]
+
+    def _compile(self):
+        layers = super()._compile()          # the last sub-block comes without ReLU / residual (see _has_se)
+        if self.res is not None:
+            rc = self.res[0]
+            layers.append(_plan.make_tcs_layer(rc.conv.weight.device, dw_w=None, pw_w=rc.conv.weight,
+                                               bn=_bn_tensors(self.res[1].layer[0]), kernel=1, stride=rc.stride, dilation=1,
+                                               padding=0, relu=False))
+        return layers
+
+    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=0):
+        """Same contract as _FusedBlockBase._run_fused; the tail of the block is the SE launch sequence."""
+        _t.require_gpu(x, type(self).__name__)
+        self._check_eval()
+        layers = self._cache.get(self._params(), self._compile)
+        convs = layers[:self.repeat]
+        res_layer = layers[self.repeat] if self.res is not None else None
+        was_internal = _t.is_internal(x)
+        xi = x if was_internal else _t.pack(x, lengths, slot=("blk", id(self)))
+        x0_tz = _t.is_tail_zero(xi)
+        b, _, t = xi.shape
+        x0 = _t.backing(xi)
+        dev = xi.device
+        len_in = _t.lengths_i32(lengths, dev)
+        h, th, lh, h_tz = x0, t, len_in, x0_tz
+        out_lengths = lengths
+        subs = list(self._sub_blocks())
+        for r, layer in enumerate(convs):
+            geom = subs[r][0] if subs[r][0] is not None else subs[r][1]
+            out = _t.arena(("enc", slot, r % 2), b, layer.c_out, layer.out_size(th), dev)
+            h, th = layer.run(h, th, lh, out=out, in_tail_zero=h_tz, zero_tail=True)
+            h_tz = True
+            if geom.stride != 1 or 2 * geom.padding != geom.dilation * (geom.kernel_size - 1):
+                out_lengths = geom.get_seq_len(out_lengths)
+                lh = _t.lengths_i32(out_lengths, dev)
+        c_out = convs[-1].c_out
+        se = self.mconv[len(self.mconv) - 1].layer[0]
+        tail_y = convs[-1].bias[:c_out]
+        gate = se_gate(se, h, lh, tail_y, th)
+        r_buf = tail_r = None
+        if res_layer is not None:
+            r_buf = _t.arena(("enc", slot, "res"), b, c_out, th, dev)
+            r_buf, t_res = res_layer.run(x0, t, len_in, out=r_buf, in_tail_zero=x0_tz, zero_tail=True)
+            assert t_res == th
+            tail_r = res_layer.bias[:c_out]
+        out = _t.arena(("enc", slot, "out"), b, c_out, th, dev) if internal else _t.alloc(b, c_out, th, dev)
+        se_apply(h, r_buf, gate, lh, tail_y, tail_r, th, out, relu=True, zero_tail=internal)
+        y = out[:, :, :th]
+        if internal:
+            _t.tag_tail_zero(y)
+        return y, out_lengths, was_internal
+
     def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        raise NotImplementedError("CitrinetBlock: the squeeze-excite HIP launch sequence is not built yet "
-                                  "(SURVEY section 8 config C3, DESIGN.md §7); no fallback is provided")
+        y, out_lengths, was_internal = self._run_fused(x, lengths)
+        return (y if was_internal else _t.unpack(y)), out_lengths
 
 
 def stem(feat_in: int) -> CitrinetBlock:
