@@ -88,7 +88,7 @@ int ts_tcs_subblock_fwd(const ts_tcs_desc* desc, const void* x, const int32_t* l
  *   y: bf16 [B][C][pitch] main-branch output of the block's last sub-block launch (no ReLU), tail zeroed
  *      (TS_TCS_OUT_ZERO_TAIL); len: int32 [B] valid frames of y; tail_y: f32 [C] the value the reference holds beyond the
  *      length (= the folded BN shift, ts_tcs_desc.bias: a masked input makes the conv output 0 there).
- *   ts_se_gate_fwd : pool_ws f32 [B][C] (workspace, receives the means), gate f32 [B][C];
+ *   ts_se_gate_fwd : pool_ws f32 [B][C + hidden] (workspace: the means, then the hidden activations), gate f32 [B][C];
  *                    w1 f32 [hidden][C], w2 f32 [C][hidden] (nn.Linear layout, no bias).
  *   ts_se_apply_fwd: out = act( gate * y + r ), r: bf16 [B][C][pitch_r] residual branch (pointwise launch, tail zeroed) or
  *                    NULL, tail_r its constant beyond the length; zero_tail = 1 stores 0 for frames >= len (internal

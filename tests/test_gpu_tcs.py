@@ -122,6 +122,10 @@ def _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, residual, seed=0):
     (64, 256, 33, 2, 1, 1501, [1501, 1000], False),
     (512, 512, 87, 1, 2, 260, [260, 129], False),
     (64, 64, 5, 1, 1, 128, [128, 100], False),
+    (320, 384, 11, 1, 1, 251, [251, 97], False),        # Citrinet kernel sizes: 2 / 3 / 4 passes, 96-frame tiles
+    (384, 640, 25, 1, 1, 200, [200, 155], False),
+    (128, 1024, 39, 1, 1, 150, [150, 64], False),       # two output-channel splits per tile
+    (128, 128, 17, 1, 1, 400, [400, 201], False),       # 192-frame tiles, 2 passes
 ])
 def test_tail_zero_fast_kernels_match_oracle(cin, cout, k, stride, dil, t, lens, res):
     _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, res)

@@ -52,7 +52,7 @@ def se_gate(se: SqueezeExcite, y: torch.Tensor, len_i32: torch.Tensor, tail_y: t
     b, c, pitch = y.shape
     w1 = se.fc[0].weight.detach().to(device=y.device, dtype=torch.float32).contiguous()
     w2 = se.fc[2].weight.detach().to(device=y.device, dtype=torch.float32).contiguous()
-    pool = torch.empty(b, c, dtype=torch.float32, device=y.device)
+    pool = torch.empty(b * (c + w1.shape[0]), dtype=torch.float32, device=y.device)      # means + hidden activations
     gate = torch.empty(b, c, dtype=torch.float32, device=y.device)
     st = _lib.lib().ts_se_gate_fwd(y.data_ptr(), len_i32.data_ptr(), tail_y.data_ptr(), b, c, t, pitch, w1.shape[0],
                                    w1.data_ptr(), w2.data_ptr(), pool.data_ptr(), gate.data_ptr(),

@@ -33,33 +33,22 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const unsigned short* __re
   if (lane == 0) pool[row] = (s + (float)(t - l) * tail_y[c]) / (float)t;
 }
 
-// one workgroup per clip: hidden = relu(W1 pool), gate = sigmoid(W2 hidden); a wave per output, lanes over the contraction
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
-                                                       const float* __restrict__ w2, float* __restrict__ gate, int channels,
-                                                       int hidden) {
-  extern __shared__ float sm[];          // [channels] pooled means, then [hidden]
-  float* const p = sm;
-  float* const h = sm + channels;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < channels; i += 256) p[i] = pool[(size_t)b * channels + i];
-  __syncthreads();
-  for (int j = wave; j < hidden; j += 4) {
-    const float* w = w1 + (size_t)j * channels;
-    float s = 0.f;
-    for (int i = lane; i < channels; i += 64) s += w[i] * p[i];
+// out[b, j] = act( sum_i w[j, i] * in[b, i] ): one wave per output, lanes over the contraction (coalesced weight rows);
+// ACT 0: ReLU (first linear), 1: sigmoid (second linear).  Grid: (ceil(n_out / 4), batch).
+template <int ACT>
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                     float* __restrict__ out, int n_in, int n_out) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (j >= n_out) return;
+  const float* x = in + (size_t)b * n_in;
+  const float* wr = w + (size_t)j * n_in;
+  float s = 0.f;
+  for (int i = lane; i < n_in; i += 64) s += wr[i] * x[i];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) h[j] = s > 0.f ? s : 0.f;
-  }
-  __syncthreads();
-  for (int c = wave; c < channels; c += 4) {
-    const float* w = w2 + (size_t)c * hidden;
-    float s = 0.f;
-    for (int i = lane; i < hidden; i += 64) s += w[i] * h[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) gate[(size_t)b * channels + c] = 1.f / (1.f + __expf(-s));
-  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[(size_t)b * n_out + j] = ACT == 0 ? (s > 0.f ? s : 0.f) : 1.f / (1.f + __expf(-s));
 }
 
 // one thread per 8 frames (16 B)
@@ -110,14 +99,14 @@ extern "C" int ts_se_gate_fwd(const void* y, const int32_t* len, const float* ta
                               void* stream_) {
   if (!y || !len || !tail_y || !w1 || !w2 || !pool_ws || !gate) return TS_EINVAL;
   if (batch <= 0 || channels <= 0 || hidden <= 0 || t <= 0 || pitch < t || pitch % 8) return TS_EINVAL;
-  if ((size_t)(channels + hidden) * sizeof(float) > 64 * 1024) return TS_EUNSUPPORTED;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int rows = batch * channels;
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::se_pool_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, static_cast<const unsigned short*>(y), len,
                      tail_y, pool_ws, rows, channels, t, pitch);
-  hipLaunchKernelGGL(ts::se_gate_kernel, dim3(batch), dim3(256), (channels + hidden) * sizeof(float), stream, pool_ws, w1, w2,
-                     gate, channels, hidden);
+  float* const hid = pool_ws + (size_t)batch * channels;           // workspace: [B][C] means, then [B][hidden]
+  hipLaunchKernelGGL(ts::se_fc_kernel<0>, dim3((hidden + 3) / 4, batch), dim3(256), 0, stream, pool_ws, w1, hid, channels, hidden);
+  hipLaunchKernelGGL(ts::se_fc_kernel<1>, dim3((channels + 3) / 4, batch), dim3(256), 0, stream, hid, w2, gate, hidden, channels);
   return ts::hip_status(hipGetLastError());
 }
 

@@ -1343,7 +1343,8 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
                         (d->c_res == 0 || d->pitch_res >= (n_ttp - 1) * TTp + round_up(TTp, 64));
       if (fits) {
 #define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) return launch_pipe<NP_, XJ_, 3, WM_>(w, stream);
-        TS_PIPE(3, 4, 2) TS_PIPE(4, 4, 2) TS_PIPE(5, 3, 1) TS_PIPE(6, 3, 1) TS_PIPE(7, 3, 1)
+        TS_PIPE(3, 4, 2) TS_PIPE(4, 4, 2) TS_PIPE(5, 3, 1) TS_PIPE(6, 3, 1) TS_PIPE(7, 3, 1)      /* QuartzNet: K 33..75 */
+        TS_PIPE(2, 2, 1) TS_PIPE(3, 3, 1) TS_PIPE(4, 3, 1) TS_PIPE(2, 4, 2)                         /* Citrinet: K 11..41 */
 #undef TS_PIPE
       }
     }

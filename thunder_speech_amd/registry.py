@@ -39,6 +39,9 @@ def _register_builtin():
     register_checkpoint_enum(QuartznetCheckpoint, load_quartznet_checkpoint)
     register_checkpoint("QuartzNet5x5_synthetic", lambda **kw: build_synthetic_quartznet(repeat_blocks=1, **kw))
     register_checkpoint("QuartzNet15x5_synthetic", lambda **kw: build_synthetic_quartznet(repeat_blocks=3, **kw))
+    from .citrinet.compatibility import CitrinetCheckpoint, load_citrinet_checkpoint, build_synthetic_citrinet
+    register_checkpoint_enum(CitrinetCheckpoint, load_citrinet_checkpoint)
+    register_checkpoint("Citrinet1024_synthetic", lambda **kw: build_synthetic_citrinet(**kw))
 
 
 _register_builtin()
