@@ -126,6 +126,8 @@ def _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, residual, seed=0):
     (384, 640, 25, 1, 1, 200, [200, 155], False),
     (128, 1024, 39, 1, 1, 150, [150, 64], False),       # two output-channel splits per tile
     (128, 128, 17, 1, 1, 400, [400, 201], False),       # 192-frame tiles, 2 passes
+    (256, 256, 39, 1, 1, 401, [401, 333, 250], True),   # 4 passes + residual stages, several tiles per workgroup
+    (256, 256, 33, 1, 1, 1400, [1400, 1399, 700, 5] * 40, True),   # more tiles than CUs: the persistent loop wraps
 ])
 def test_tail_zero_fast_kernels_match_oracle(cin, cout, k, stride, dil, t, lens, res):
     _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, res)
@@ -136,3 +138,27 @@ def test_padding_region_never_leaks():
     got1, _ = _run_case(64, 64, 33, 1, 1, 200, [200, 120], True, seed=3)
     got2, _ = _run_case(64, 64, 33, 1, 1, 200, [200, 120], True, seed=3)
     assert torch.equal(got1, got2)
+
+
+@pytest.mark.parametrize("k", [63, 75, 39])
+def test_back_to_back_launches_never_use_the_next_stages_taps(k):
+    """Regression: with the tap fragments L2-hot (the same layer launched again and again) a tap DMA that refills a slot
+    for the NEXT stage used to be able to land before the running stage had read the slot.  Identity pointwise, distinct
+    taps per channel: any stage that sees another stage's taps is off by O(1)."""
+    from thunder_speech_amd import plan, tensors as TS
+    c, t, b = 512 if k != 39 else 256, 751, 2
+    g = torch.Generator().manual_seed(k)
+    dw = bf16_round(torch.randn(c, 1, k, generator=g) * 0.2)
+    bn = [torch.ones(c), torch.zeros(c), torch.zeros(c), torch.ones(c) - 1e-3]      # scale 1, shift 0 after folding
+    layer = plan.make_tcs_layer("cuda", dw_w=dw, pw_w=torch.eye(c).reshape(c, c, 1), bn=bn, kernel=k, stride=1,
+                                dilation=1, padding=k // 2, relu=False)
+    x = bf16_round(torch.randn(b, c, t, generator=g))
+    ref = torch.nn.functional.conv1d(x.double(), dw.double(), padding=k // 2, groups=c).float()
+    li = torch.full((b,), t, dtype=torch.int32, device="cuda")
+    xb = TS.backing(TS.pack(x.cuda(), li, slot=("b2b", k)))
+    out = TS.arena(("b2bo", k), b, c, t, "cuda")
+    scale = float(ref.abs().max())
+    for it in range(60):
+        y, _ = layer.run(xb, t, li, out=out, in_tail_zero=True, zero_tail=True)
+        err = float((y[:, :, :t].float().cpu() - ref).abs().max())
+        assert err <= 0.012 * scale, f"launch {it}: max err {err} (scale {scale})"

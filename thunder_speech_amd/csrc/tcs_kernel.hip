@@ -832,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
   auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
   const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(a.x) - TS_GUARD_BYTES);   // offsets may reach into the front guard
   // exact bound: the last quad of a stage over-reads up to 3 k-steps, out-of-range lanes must return 0 instead of faulting
-  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.taps), 0, n_main * (KC * 4 * NK * 4 * 2), RSRC_FLAGS);
+  const i32x4 rt = raw_rsrc(a.taps, (unsigned)n_main * (KC * 4 * NK * 4 * 2));
   const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
   const __amdgpu_buffer_rsrc_t rwm = rsrc(a.pw_w);
   const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? a.res_w : a.pw_w);
@@ -896,8 +896,8 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
   //      finished with (buffer_load ... lds: no VGPR round trip, 1/4 of the vector-memory instructions of register taps)
   constexpr int P1 = (NPASS + 2) / 3, P2 = (2 * NPASS + 2) / 3;
   int t_next = (n_main > 1 ? 1 : 0) * chunk_t;      // scalar byte offset of the next stage's fragments
-  auto tap_dma = [&](int jq, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (TS_LDS void*)(tapl + jq * 1024), 16, lane_t, soff + jq * 2048, 0, 0);
+  auto tap_dma = [&](int jq, int soff, float after = 0.f) {
+    lds_dma16(rt, tapl + jq * 1024, lane_t, soff + jq * 2048, after);
   };
   auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
   // ---- I stream: next identity (residual) stage
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
     // only issue once their tap reads had returned, so the slots are no longer being read)
 #pragma unroll
     for (int jq = 0; jq < NKQ; ++jq)
-      if (TS.last_pass(jq) == p) tap_dma(jq, t_next);
+      if (TS.last_pass(jq) == p) tap_dma(jq, t_next, d[M - 1][3]);      // behind the pass's last MFMA
   };
   auto dw_store = [&](char* dst) {
 #pragma unroll
@@ -1245,6 +1245,397 @@ static int launch_pipe(TcsArgs& a, hipStream_t stream) {
   return hip_status(hipGetLastError());
 }
 
+// ======================================================================================================
+// Split kernel: 12 waves = 8 consumer waves (pointwise GEMM, accumulators) + 4 producer waves (depthwise FIR).
+//
+// In the pipelined kernel above the two jobs share an instruction stream and measurably do not overlap (skeleton +
+// pointwise + depthwise times add up).  Here they are different waves: every SIMD runs two consumer waves and one
+// producer wave, so the LDS-heavy depthwise stream issues while the consumers sit in their MFMA bursts.  Three waves
+// per SIMD leave 168 VGPRs each: enough for the 96 accumulators + ring + A fragments of a consumer, and for the
+// 16-channel windows of a producer.
+//   producer p (wave 8 + p): channels [16p, 16p + 16) of the stage, 16 MFMA blocks = 16 channels, 4 lane runs of TT/4
+//     frames, M = TT/16 steps per run (each tap fragment read feeds M MFMAs: 6 or 12, against 3 or 6 above);
+//     rows global -> registers (a stage ahead) -> wave-private LDS rows; taps global -> LDS by DMA, 2 k-steps per KiB.
+//   consumer w: output tile 96 frames x 64 channels, exactly the pointwise job of the pipelined kernel.
+//   iteration i: producers write stage i into dwt[i & 1], consumers read stage i-1 out of dwt[(i-1) & 1]; one barrier.
+//   The epilogue runs after the barrier that ends the last stage of a tile, so the producers work through it.
+// ======================================================================================================
+// Tap pairs of a producer: pair h holds k-steps 2h and 2h+1 and is free for the next stage's fragments once the pass that
+// consumes its last k-step has issued its MFMAs.
+struct ProdSched {
+  int npass, xp, nk, nkh, dist;
+  constexpr int last_pass(int h) const { return ((2 * h + 1 < nk ? 2 * h + 1 : nk - 1)) / 3; }
+};
+
+template <int NPASS, int XJ, int MT, int WM>
+__global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
+  constexpr int WN = 8 / WM, NT = 2;
+  constexpr int FW = 32 * MT;
+  constexpr int TT = FW * WM;
+  constexpr int M = TT / 16, RUN = TT / 4;        // producer: 4 runs of RUN frames per channel, M steps of 4 frames
+  constexpr int NK = NPASS * NKP;
+  constexpr int NP = NK + M - 1;
+  constexpr int ROWB = TT <= 128 ? 256 : 512;
+  constexpr int TILEB = KC * ROWB;
+  constexpr int EP = FW * 2 + 24;
+  constexpr int XP = 2 * XJ;                      // 16 rows x 128*XJ bytes per wave, 1 KiB per instruction
+  constexpr int IDP = (2 * TT + 63) / 64;         // identity rows: 16 rows x 2*TT bytes
+  constexpr int NKH = (NK + 1) / 2;               // tap fragments travel in pairs of k-steps (1 KiB per wave)
+  constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
+  constexpr int ER = WM == 2 ? 16 : 32;           // output-channel rows of a consumer's epilogue tile
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const dwt = smem;                                             // [2][KC][ROWB]
+  char* const cons0 = smem + 2 * TILEB;                               // [8][32][EP] epilogue tiles
+  char* const prod0 = cons0 + 8 * ER * EP;                            // [4][XSB + NKH KiB]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_main = a.c_in / KC;
+  const int n_res = a.c_res / KC;
+  const int n_stage = n_main + n_res;
+  const int tile_step = gridDim.x;
+  auto taddr = [](int c, int t) { return c * ROWB + ((((t >> 3) ^ ((c & 3) * 5))) << 4) + ((t & 7) << 1); };
+  constexpr int RSRC_FLAGS = 0x00020000;
+  auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
+  auto ld16 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); };
+  unsigned gs = 0;
+
+  if (wave >= 8) {
+    // ================================= PRODUCER =======================================================
+    const int pw = wave - 8;
+    char* const xs = prod0 + (size_t)pw * (XSB + NKH * 1024);
+    char* const tapl = xs + XSB;
+    const int xpitch = 64 * XJ + 4;
+    const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(a.x) - TS_GUARD_BYTES);
+    const i32x4 rt = raw_rsrc(a.taps, (unsigned)n_main * (KC * 4 * NK * 4 * 2));
+    const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
+    const int row = lane >> 2, sub = lane & 3;     // staging: row of the wave's 16 channels, 16-byte group sub + 4j
+    const int q = lane & 3;                        // depthwise: channel = row, time run q
+    char* const xw = xs + ((size_t)row * xpitch + sub * 8) * 2;
+    const char* const xrow = xs + ((size_t)row * xpitch + a.woff + q * RUN) * 2;
+    const char* const trow = tapl + lane * 8;      // fragment of (k, lane) at k * 512 + lane * 8
+    int dw_out[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) dw_out[m] = taddr(pw * 16 + row, q * RUN + 4 * m);
+    const int lane_x = ((pw * 16 + row) * a.pitch_in + sub * 8) * 2;
+    const int lane_t = pw * NK * 512 + lane * 16;  // [chunk][16-ch group][k][64 lanes][4]: a pair of k-steps is 1 KiB contiguous
+    const int lane_i = ((pw * 16 + row) * a.pitch_res + sub * 8) * 2;
+    const int id_out = taddr(pw * 16 + row, sub * 8);
+    const int chunk_x = KC * a.pitch_in * 2;
+    const int chunk_t = KC * 4 * NK * 4 * 2;
+    const int chunk_i = KC * a.pitch_res * 2;
+
+    u32x4 X[XP];
+    TilePos dwp;
+    dwp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+    int dw_tile = blockIdx.x, dw_chunk = 0;
+    auto x_origin = [&](const TilePos& p) { return (p.b * a.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
+    int x_soff = x_origin(dwp);
+    auto dw_issue = [&]() {
+#pragma unroll
+      for (int j = 0; j < XP; ++j) X[j] = ld16(rx, lane_x + j * 64, x_soff);
+      if (++dw_chunk == n_main) {
+        dw_chunk = 0;
+        if (dw_tile + tile_step < a.n_tiles) { dw_tile += tile_step; dwp.advance(a.n_tt, a.n_z); }
+        x_soff = x_origin(dwp);
+      } else {
+        x_soff += chunk_x;
+      }
+    };
+    int t_next = (n_main > 1 ? 1 : 0) * chunk_t;
+    auto tap_dma = [&](int h, int soff, float after = 0.f) {
+      lds_dma16(rt, tapl + h * 1024, lane_t, soff + h * 1024, after);
+    };
+    auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
+    u32x4 I[IDP];
+    TilePos idp;
+    idp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+    int id_tile = blockIdx.x, id_s = 0;
+    auto i_origin = [&](const TilePos& p) { return (p.b * a.c_res * a.pitch_res + p.tt * TT) * 2; };
+    int i_soff = i_origin(idp);
+    auto id_issue = [&]() {
+#pragma unroll
+      for (int j = 0; j < IDP; ++j) I[j] = ld16(ri, lane_i + j * 64, i_soff);
+      if (++id_s == n_res) {
+        id_s = 0;
+        if (id_tile + tile_step < a.n_tiles) { id_tile += tile_step; idp.advance(a.n_tt, a.n_z); }
+        i_soff = i_origin(idp);
+      } else {
+        i_soff += chunk_i;
+      }
+    };
+
+    s16x4 P[NP];
+    u32x2 T[NK];
+    f32x4 d[M];
+    constexpr int WD = TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS;
+    constexpr ProdSched PS{NPASS, XP, NK, NKH, WD};   // which pass frees which tap pair
+    auto xs_write = [&]() {
+#pragma unroll
+      for (int j = 0; j < XP; ++j) {
+        u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 64);
+        d2[0] = u32x2{X[j][0], X[j][1]};
+        d2[1] = u32x2{X[j][2], X[j][3]};
+      }
+    };
+    auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
+    auto tap_load = [&](int kk) { T[kk] = *reinterpret_cast<const u32x2*>(trow + kk * 512); };
+    auto dw_begin = [&]() {
+#pragma unroll
+      for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < M - 1 + NKP * WD; ++u) win_load(u);
+#pragma unroll
+      for (int kk = 0; kk < NKP * WD; ++kk) tap_load(kk);
+    };
+    auto dw_pass = [&](auto pc) {
+      constexpr int p = decltype(pc)::value;
+      if constexpr (p + WD < NPASS) {
+#pragma unroll
+        for (int u = 0; u < NKP; ++u) win_load((p + WD) * NKP + M - 1 + u);
+#pragma unroll
+        for (int u = 0; u < NKP; ++u) tap_load((p + WD) * NKP + u);
+      }
+#pragma unroll
+      for (int kk = 0; kk < NKP; ++kk)
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+          d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m], d[m], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < NKH; ++h)
+        if (PS.last_pass(h) == p) tap_dma(h, t_next, d[M - 1][3]);   // behind the pass's last MFMA
+    };
+
+    // prologue: rows and taps of the first stage
+    dw_issue();
+#pragma unroll
+    for (int h = 0; h < NKH; ++h) tap_dma(h, 0);
+    if (n_res) id_issue();
+    vm_wait<0>();
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
+      for (int s = 0; s < n_main; ++s, ++gs) {
+        char* const dst = dwt + (gs & 1) * TILEB;
+        // Everything this wave has in flight is a stage old except the last tap DMAs: drain it all.  (Measured: DMA-to-LDS
+        // loads and register loads retire out of order with respect to each other, so a counted vmcnt cannot separate them;
+        // hipcc's own waits for the row loads assume in-order retirement and are not enough once DMAs are in the queue.)
+        vm_wait<0>();
+        xs_write();
+        dw_begin();
+        dw_issue();
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+          *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+        tap_advance();
+        stage_barrier();
+      }
+      for (int s = 0; s < n_res; ++s, ++gs) {
+        char* const dst = dwt + (gs & 1) * TILEB;
+        vm_wait<0>();
+#pragma unroll
+        for (int j = 0; j < IDP; ++j) *reinterpret_cast<u32x4*>(dst + (id_out ^ (j << 6))) = I[j];
+        id_issue();
+        stage_barrier();
+      }
+    }
+    vm_wait<0>();                                    // no tap DMA may still be heading for this workgroup's LDS when it is released
+    stage_barrier();                                 // pairs with the consumers' last stage
+    return;
+  }
+
+  // ================================= CONSUMER =========================================================
+  char* const priv = cons0 + (size_t)wave * ER * EP;
+  const __amdgpu_buffer_rsrc_t rwm = rsrc(a.pw_w);
+  const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? a.res_w : a.pw_w);
+  const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
+  const int n_cot = (a.c_out + 31) >> 5;
+  const int h = lane >> 5;
+  const int gq = (lane >> 4) & 1;
+  const int q4 = (lane >> 2) & 3;
+  const int p4 = lane & 3;
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = taddr(8 * h + q4, wm * FW + 32 * mt + 16 * gq + 4 * p4);
+  const int rsub = lane >> 4, csub = lane & 15;
+  const unsigned floor2 = a.relu ? 0u : 0x80008000u;
+  const int lane_w = lane * 16;
+
+  s16x8 ring[2][NT];
+  TilePos wp;
+  wp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+  int w_tile = blockIdx.x, w_s = 0;
+  __amdgpu_buffer_rsrc_t rwc = rwm, rwn = rwm;
+  int wc_soff[NT], wn_soff[NT];
+  auto w_seek = [&](bool res) {
+    rwn = res ? rwr : rwm;
+    const int kt = res ? a.kt_res : a.kt_main;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cot = (wp.z * WN + wn) * NT + nt;
+      wn_soff[nt] = (cot < n_cot ? cot : n_cot - 1) * kt * 1024;
+    }
+  };
+  auto w_advance = [&]() {
+    rwc = rwn;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wc_soff[nt] = wn_soff[nt];
+    ++w_s;
+    if (w_s == n_stage) {
+      w_s = 0;
+      if (w_tile + tile_step < a.n_tiles) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
+      w_seek(false);
+    } else if (w_s == n_main) {
+      w_seek(true);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wn_soff[nt] += 4096;
+    }
+  };
+  auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      slot[nt] = __builtin_bit_cast(s16x8, next ? ld16(rwn, lane_w + ks * 1024, wn_soff[nt]) : ld16(rwc, lane_w + ks * 1024, wc_soff[nt]));
+  };
+  f32x16 acc[MT][NT];
+  float bnext[NT];
+  auto bias_fetch = [&](const TilePos& p) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = ((p.z * WN + wn) * NT + nt) * 32 + (lane & 31);
+      bnext[nt] = a.bias[col < a.c_out ? col : 0];
+    }
+  };
+  s16x8 af[MT], afB[MT];
+  auto read_a = [&](const char* src, int ks, s16x8 (&f)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB + 4 * ROWB));
+      f[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  auto mfma_ks = [&](int ks, const s16x8 (&f)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks & 1][nt], acc[mt][nt], 0, 0, 0);
+    load_w(ring[ks & 1], ks >= 2, (ks + 2) & 3);
+  };
+
+  TilePos pos;
+  pos.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+  w_seek(false);
+  w_advance();
+  load_w(ring[0], false, 0);
+  load_w(ring[1], false, 1);
+  bias_fetch(pos);
+  stage_barrier();                                   // stage 0 is in dwt[0]
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
+    const int b = pos.b, t0 = pos.tt * TT;
+    const int cot0 = (pos.z * WN + wn) * NT;
+    const int len_b = a.zero_tail ? a.len_in[b] : 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
+    for (int s = 0; s < n_stage; ++s, ++gs) {
+      const char* const src = dwt + (gs & 1) * TILEB;
+      read_a(src, 0, af);
+      read_a(src, 1, afB);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(0, af);
+      read_a(src, 2, af);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(1, afB);
+      read_a(src, 3, afB);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(2, af);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(3, afB);
+      w_advance();
+      stage_barrier();
+    }
+    // ---- epilogue (the producers are already on the next tile)
+    pos.advance_if(tile + tile_step < a.n_tiles, a.n_tt, a.n_z);
+    bias_fetch(pos);
+    unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
+    int len_out = 0x7fffffff;
+    if (a.zero_tail) len_out = conv_len(len_b, a.kernel, 1, a.padding, a.dilation);
+    const int tw = t0 + wm * FW;
+    const bool partial = tw + FW > len_out;
+    u32x4 keep = u32x4{~0u, ~0u, ~0u, ~0u};
+    if (partial) keep = keep_first(keep, len_out - (tw + csub * 8));
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cob = (cot0 + nt) * 32;
+      const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
+      u32x2 pk[MT * 4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+              pack_bf16_settled(acc[mt][nt][4 * rg + 0], acc[mt][nt][4 * rg + 1])), f2));
+          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+              pack_bf16_settled(acc[mt][nt][4 * rg + 2], acc[mt][nt][4 * rg + 3])), f2));
+          pk[mt * 4 + rg] = u32x2{lo, hi};
+        }
+      // the LDS tile holds ER output-channel rows at a time (all 32, or 16 when the 192-frame dwt buffers leave less room)
+#pragma unroll
+      for (int half = 0; half < 32 / ER; ++half) {
+        if (((lane & 31) / ER) == half) {
+          char* const row = priv + (size_t)(lane & (ER - 1)) * EP + 8 * h;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = pk[mt * 4 + rg];
+        }
+        if (csub < FW / 8) {
+          unsigned short* const yrow = yb + (size_t)(b * a.c_out + cob + half * ER + rsub) * a.pitch_out + tw + csub * 8;
+          const char* const prow = priv + (size_t)rsub * EP + csub * 16;
+          u32x4 v[ER / 4];
+#pragma unroll
+          for (int i = 0; i < ER / 4; ++i) {
+            const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * i * EP);
+            v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
+          }
+#pragma unroll
+          for (int i = 0; i < ER / 4; ++i) {
+            if (partial) v[i] &= keep;
+            if (cob + half * ER + 4 * i + rsub < a.c_out) *reinterpret_cast<u32x4*>(yrow + (size_t)(4 * i) * a.pitch_out) = v[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NPASS, int XJ, int MT, int WM>
+static int launch_split(TcsArgs& a, hipStream_t stream) {
+  constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);
+  constexpr int ROWB = TT <= 128 ? 256 : 512;
+  constexpr int NKH = (NPASS * NKP + 1) / 2;
+  a.n_tt = (a.t_out + TT - 1) / TT;
+  a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
+  a.n_tiles = a.batch * a.n_tt * a.n_z;
+  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * (WM == 2 ? 16 : 32) * (FW * 2 + 24) + (size_t)4 * (16 * (64 * XJ + 4) * 2 + NKH * 1024);
+  if (lds > 160 * 1024) return TS_EUNSUPPORTED;
+  auto kern = tcs_split_kernel<NPASS, XJ, MT, WM>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int n_cu = cu_count();
+  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, a);
+  return hip_status(hipGetLastError());
+}
+
 template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS = false, bool TZ = false, int XJ = 0, int NPASS = 0>
 static int launch(TcsArgs& a, hipStream_t stream) {
   constexpr int CO_WG = 4 * NT * 32;
@@ -1342,7 +1733,9 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       const bool fits = (n_ttp - 1) * TTp - w.padl8 + w.xe <= d->pitch_in && d->pitch_out >= n_ttp * TTp &&
                         (d->c_res == 0 || d->pitch_res >= (n_ttp - 1) * TTp + round_up(TTp, 64));
       if (fits) {
-#define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) return launch_pipe<NP_, XJ_, 3, WM_>(w, stream);
+        static const bool use_split = getenv("TS_NO_SPLIT") == nullptr;      // diagnostic switch: the single-stream pipelined kernel
+#define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) \
+          return use_split ? launch_split<NP_, XJ_, 3, WM_>(w, stream) : launch_pipe<NP_, XJ_, 3, WM_>(w, stream);
         TS_PIPE(3, 4, 2) TS_PIPE(4, 4, 2) TS_PIPE(5, 3, 1) TS_PIPE(6, 3, 1) TS_PIPE(7, 3, 1)      /* QuartzNet: K 33..75 */
         TS_PIPE(2, 2, 1) TS_PIPE(3, 3, 1) TS_PIPE(4, 3, 1) TS_PIPE(2, 4, 2)                         /* Citrinet: K 11..41 */
 #undef TS_PIPE

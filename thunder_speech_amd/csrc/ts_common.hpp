@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 #define TS_LDS __attribute__((address_space(3)))
 
@@ -45,6 +46,24 @@ __device__ __forceinline__ u32x4 keep_first(u32x4 v, int nv) {
     v[j] &= m;
   }
   return v;
+}
+
+// Raw buffer descriptor (gfx9 layout) over [p, p + bytes): base, stride 0, num_records, 32-bit data format.
+__device__ __forceinline__ i32x4 raw_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  return i32x4{(int)(a & 0xffffffffu), (int)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+// Global -> LDS DMA of 16 bytes per lane (1 KiB per wave): lane L's 16 bytes at buffer offset voff + soff land at LDS byte
+// address lds_dst + 16 L.  `after` is a register the DMA must be ordered behind: it is not read, it only pins the
+// instruction below its producer.  hipcc orders the DMA against other MEMORY operations only, so without it the DMA
+// that refills a tap slot floats above the MFMAs that consume the slot's old contents -- whose LDS reads may still be in
+// flight -- and with an L2-hot source it lands first (measured: the taps of the last pass came from the next stage in
+// 1-5 % of the waves).  Behind the last MFMA of the pass every read of the slot has returned.
+// hipcc neither counts this operation in its vmcnt model nor orders LDS reads behind it: callers wait with vm_wait<>.
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, const void* lds_dst, int voff, int soff, float after = 0.f) {
+  const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(TS_LDS const char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(addr), "v"(voff), "s"(rsrc), "s"(soff), "v"(after) : "memory");
 }
 
 __host__ __device__ constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
