@@ -150,6 +150,20 @@ int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes, int32_t n
                 int32_t blank, float* nll, float* loss, float* grad, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fine-tuning with a frozen encoder (the first phase of FinetuneCTCModule + FinetuneEncoderDecoder, finetune.py:19-88,
+ * callbacks.py: the encoder stays frozen until `unfreeze_encoder_at_epoch`): backward of the 1x1 decoder
+ * (blocks.py:199-216) and the optimizer step.
+ *   ts_decoder_bwd: grad_logits f32 [B][V][pitch_g] (dL/dlogits, e.g. from ts_ctc_loss), x bf16 [B][C][pitch_x] (encoder
+ *     output, NCT-p) -> d_weight f32 [V][C], d_bias f32 [V] (both overwritten).
+ *   ts_adamw_step : torch.optim.AdamW on a flat f32 buffer of n elements (decoupled weight decay, bias correction with
+ *     `step` >= 1, amsgrad off): p *= 1 - lr*wd; m,v updated; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ * ---------------------------------------------------------------------------------------------- */
+int ts_decoder_bwd(const float* grad_logits, const void* x, int32_t batch, int32_t n_classes, int32_t channels, int32_t t,
+                   int32_t pitch_g, int32_t pitch_x, float* d_weight, float* d_bias, void* stream);
+int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].
  * ---------------------------------------------------------------------------------------------- */
 /* len (may be NULL): int32 [B]; frames >= len[b] are written as 0 so that dst satisfies the tail-zero invariant. */

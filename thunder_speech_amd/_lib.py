@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss",
     "ts_pack_activation", "ts_unpack_activation", "ts_se_gate_fwd", "ts_se_apply_fwd",
+    "ts_decoder_bwd", "ts_adamw_step",
 ]
 
 
@@ -93,6 +94,11 @@ def lib() -> C.CDLL:
     L.ts_se_gate_fwd.restype = C.c_int
     L.ts_se_apply_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ts_se_apply_fwd.restype = C.c_int
+    L.ts_decoder_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.ts_decoder_bwd.restype = C.c_int
+    f32 = C.c_float
+    L.ts_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
+    L.ts_adamw_step.restype = C.c_int
     if L.ts_abi_version() != ABI_VERSION:
         raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")
     _lib = L

@@ -92,18 +92,54 @@ class _Conv1dDecoder(nn.Conv1d):
         super().__init__(in_channels, num_classes, kernel_size=1, bias=True)
         self._cache = _PackedCache()
 
+    def _build(self, pack_on_device: bool):
+        return _plan.make_tcs_layer(self.weight.device, dw_w=None, pw_w=self.weight.detach(), bn=None, kernel=1, stride=1,
+                                    dilation=1, padding=0, relu=False, bias_extra=self.bias.detach(), out_fp32=True,
+                                    pack_on_device=pack_on_device)
+
     def _layer(self):
-        return self._cache.get([self.weight, self.bias], lambda: _plan.make_tcs_layer(
-            self.weight.device, dw_w=None, pw_w=self.weight.detach(), bn=None, kernel=1, stride=1, dilation=1,
-            padding=0, relu=False, bias_extra=self.bias.detach(), out_fp32=True))
+        return self._cache.get([self.weight, self.bias], lambda: self._build(False))
 
     def forward(self, x: Tensor) -> Tensor:
         _t.require_gpu(x, "conv1d_decoder")
         xi = _t.pack(x)
         b, _, t = xi.shape
+        if torch.is_grad_enabled() and (self.weight.requires_grad or self.bias.requires_grad):
+            if x.requires_grad:
+                raise NotImplementedError("conv1d_decoder: gradient w.r.t. the encoder output is not built (the encoder "
+                                          "backward kernels are the next step of SURVEY 8 config C4); freeze the encoder")
+            return _DecoderFunction.apply(self.weight, self.bias, self, _t.backing(xi), t)
         full = torch.full((b,), t, dtype=torch.int32, device=xi.device)   # the decoder conv is not masked
         y, t_out = self._layer().run(_t.backing(xi), t, full)
         return y[:, :, :t_out]
+
+
+class _DecoderFunction(torch.autograd.Function):
+    """Trainable 1x1 decoder over a frozen encoder: forward = the fused pointwise kernel (weights packed on the device,
+    they change every step), backward = ts_decoder_bwd (dW, db)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, module, xb, t):
+        b = xb.shape[0]
+        full = torch.full((b,), t, dtype=torch.int32, device=xb.device)
+        y, t_out = module._build(True).run(xb, t, full)
+        ctx.save_for_backward(xb)
+        ctx.t, ctx.shape = t, weight.shape
+        return y[:, :, :t_out]
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        from . import _lib
+        (xb,) = ctx.saved_tensors
+        g = grad_logits.to(torch.float32).contiguous()
+        b, v, t = g.shape
+        c = xb.shape[1]
+        dw = torch.empty(v, c, dtype=torch.float32, device=g.device)
+        db = torch.empty(v, dtype=torch.float32, device=g.device)
+        st = _lib.lib().ts_decoder_bwd(g.data_ptr(), xb.data_ptr(), b, v, c, t, g.stride(1), xb.stride(1), dw.data_ptr(),
+                                       db.data_ptr(), torch.cuda.current_stream(g.device).cuda_stream)
+        _lib.check(st, "ts_decoder_bwd")
+        return dw.view(ctx.shape), db, None, None, None
 
 
 def conv1d_decoder(decoder_input_channels: int, num_classes: int) -> nn.Module:

@@ -1,0 +1,109 @@
+// Fine-tuning with a frozen encoder (the first phase of the reference's FinetuneCTCModule recipe: callbacks.py freezes
+// the encoder until `unfreeze_encoder_at_epoch`): the trainable part of the step is the 1x1 decoder.
+//   ts_decoder_bwd : dW[v, c] = sum_{b,t} g[b, v, t] * x[b, c, t],  db[v] = sum_{b,t} g[b, v, t]
+//                    (backward of conv1d_decoder, reference blocks.py:199-216; g = dL/dlogits from ts_ctc_loss)
+//   ts_adamw_step  : torch.optim.AdamW update (decoupled weight decay), one launch per flat parameter buffer
+#include "ts_common.hpp"
+
+namespace ts {
+
+constexpr int WG_C = 64;      // input channels per workgroup
+constexpr int WG_T = 128;     // frames per LDS tile
+constexpr int WG_V = 32;      // classes per pass
+
+// grid: (ceil(C / 64), ceil(B / clips_per_wg)); 256 threads: thread = (c = tid & 63, vg = tid >> 6 -> classes vg*8 .. +8)
+__global__ __launch_bounds__(256) void decoder_wgrad_kernel(const float* __restrict__ g, const unsigned short* __restrict__ x,
+                                                            float* __restrict__ dw, float* __restrict__ db, int batch, int n_cls,
+                                                            int channels, int t, int pitch_g, int pitch_x, int clips_per_wg) {
+  __shared__ float gs[WG_V][WG_T + 1];
+  __shared__ float xs[WG_C][WG_T + 1];
+  const int tid = threadIdx.x;
+  const int c_l = tid & 63, vg = tid >> 6;
+  const int c0 = blockIdx.x * WG_C;
+  const int b0 = blockIdx.y * clips_per_wg;
+  const int b1 = b0 + clips_per_wg < batch ? b0 + clips_per_wg : batch;
+  for (int v0 = 0; v0 < n_cls; v0 += WG_V) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    for (int b = b0; b < b1; ++b) {
+      for (int t0 = 0; t0 < t; t0 += WG_T) {
+        __syncthreads();
+        // stage g[b, v0 .. v0+32, t0 .. t0+128) and x[b, c0 .. c0+64, t0 .. t0+128): time-contiguous, coalesced
+        for (int i = tid; i < WG_V * WG_T; i += 256) {
+          const int v = i / WG_T, tt = i % WG_T;
+          gs[v][tt] = (v0 + v < n_cls && t0 + tt < t) ? g[((size_t)b * n_cls + v0 + v) * pitch_g + t0 + tt] : 0.f;
+        }
+        for (int i = tid; i < WG_C * WG_T; i += 256) {
+          const int c = i / WG_T, tt = i % WG_T;
+          xs[c][tt] = (c0 + c < channels && t0 + tt < t) ? bf16_to_f32(x[((size_t)b * channels + c0 + c) * pitch_x + t0 + tt]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int tt = 0; tt < WG_T; ++tt) {
+          const float xv = xs[c_l][tt];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += gs[vg * 8 + i][tt] * xv;
+        }
+        if (blockIdx.x == 0 && tid < WG_V) {
+          float s = 0.f;
+          for (int tt = 0; tt < WG_T; ++tt) s += gs[tid][tt];
+          bsum += s;
+        }
+      }
+    }
+    if (c0 + c_l < channels) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int v = v0 + vg * 8 + i;
+        if (v < n_cls) atomicAdd(dw + (size_t)v * channels + c0 + c_l, acc[i]);
+      }
+    }
+    if (blockIdx.x == 0 && tid < WG_V && v0 + tid < n_cls) atomicAdd(db + v0 + tid, bsum);
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float beta1, float beta2,
+                                                    float eps, float weight_decay, float bias_c1, float bias_c2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float pi = p[i] * (1.f - lr * weight_decay);
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  pi -= (lr / bias_c1) * mi / (sqrtf(vi) / sqrtf(bias_c2) + eps);
+  p[i] = pi;
+}
+
+}  // namespace ts
+
+extern "C" int ts_decoder_bwd(const float* grad_logits, const void* x, int32_t batch, int32_t n_classes, int32_t channels,
+                              int32_t t, int32_t pitch_g, int32_t pitch_x, float* d_weight, float* d_bias, void* stream_) {
+  if (!grad_logits || !x || !d_weight || !d_bias) return TS_EINVAL;
+  if (batch <= 0 || n_classes <= 0 || channels <= 0 || t <= 0 || pitch_g < t || pitch_x < t) return TS_EINVAL;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipError_t e = hipMemsetAsync(d_weight, 0, sizeof(float) * (size_t)n_classes * channels, stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(d_bias, 0, sizeof(float) * (size_t)n_classes, stream);
+  if (e != hipSuccess) return (int)e;
+  const int clips_per_wg = 4;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::decoder_wgrad_kernel, dim3((channels + ts::WG_C - 1) / ts::WG_C, (batch + clips_per_wg - 1) / clips_per_wg),
+                     dim3(256), 0, stream, grad_logits, static_cast<const unsigned short*>(x), d_weight, d_bias, batch, n_classes,
+                     channels, t, pitch_g, pitch_x, clips_per_wg);
+  return ts::hip_status(hipGetLastError());
+}
+
+extern "C" int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, void* stream_) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return TS_EINVAL;
+  const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), param,
+                     grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, weight_decay, c1, c2);
+  return ts::hip_status(hipGetLastError());
+}

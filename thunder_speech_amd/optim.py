@@ -1,0 +1,43 @@
+"""Optimizer step on the GPU: FusedAdamW = torch.optim.AdamW (decoupled weight decay, bias correction, amsgrad off) with
+the update done by ts_adamw_step (csrc/train.hip) instead of a chain of ATen elementwise ops.  Pass it as
+`optimizer_class=FusedAdamW` to BaseCTCModule / FinetuneCTCModule; the reference's default stays torch.optim.AdamW."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("FusedAdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdamW: contiguous fp32 GPU parameters only (no CPU fallback)")
+                g = p.grad.to(torch.float32).contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                rc = L.ts_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                     p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                     float(group["weight_decay"]), int(st["step"]),
+                                     torch.cuda.current_stream(p.device).cuda_stream)
+                _lib.check(rc, "ts_adamw_step")
+        return loss

@@ -156,18 +156,22 @@ class TcsLayer:
 def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, bn: Sequence[torch.Tensor],
                    kernel: int, stride: int, dilation: int, padding: int, relu: bool,
                    res_w: Optional[torch.Tensor] = None, res_bn: Optional[Sequence[torch.Tensor]] = None,
-                   res_stride: int = 1, bias_extra: Optional[torch.Tensor] = None, out_fp32: bool = False) -> TcsLayer:
+                   res_stride: int = 1, bias_extra: Optional[torch.Tensor] = None, out_fp32: bool = False,
+                   pack_on_device: bool = False) -> TcsLayer:
     """Build a fused layer from reference-layout fp32 tensors.
 
     dw_w: [Cin, 1, K] or None (pointwise only); pw_w: [Cout, Cin, 1] or [Cout, Cin]; bn = (weight, bias,
     running_mean, running_var) or None (scale 1, shift 0; `bias_extra` then carries a conv bias)."""
-    cpu = lambda t: t.detach().to(device="cpu", dtype=torch.float32)      # packing is host-side index arithmetic
+    # packing is index arithmetic: on the host by default (once per set of weights); `pack_on_device` keeps it on the GPU
+    # for weights that change every step (the decoder while fine-tuning) -- no host round trip, no synchronisation
+    cpu = (lambda t: t.detach().to(dtype=torch.float32)) if pack_on_device else \
+          (lambda t: t.detach().to(device="cpu", dtype=torch.float32))
     pw2 = cpu(pw_w).reshape(pw_w.shape[0], pw_w.shape[1])
     cout, cin = pw2.shape
     if bn is not None:
         scale, shift = fold_bn(*[cpu(t) for t in bn])
     else:
-        scale, shift = torch.ones(cout), torch.zeros(cout)
+        scale, shift = torch.ones(cout, device=pw2.device), torch.zeros(cout, device=pw2.device)
     if bias_extra is not None:
         shift = shift + cpu(bias_extra) * scale
     wf = pw2 * scale[:, None]
