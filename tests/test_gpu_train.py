@@ -16,7 +16,8 @@ def _module(seed=0):
     sd = otcs.synth_encoder_state(arch, seed=seed, calibrate=True)
     dsd = otcs.synth_decoder_state(1024, 29, seed=seed + 1)
     m = build_synthetic_quartznet(repeat_blocks=1, encoder_state=sd, decoder_state=dsd).cuda()
-    m.encoder.eval()
+    m.train()                              # Lightning puts the module in train mode ...
+    m.encoder.eval()                       # ... and FinetuneEncoderDecoder freezes the encoder (eval mode, no grads)
     for p in m.encoder.parameters():
         p.requires_grad_(False)
     return m, arch, sd, dsd

@@ -104,7 +104,7 @@ class _Conv1dDecoder(nn.Conv1d):
         _t.require_gpu(x, "conv1d_decoder")
         xi = _t.pack(x)
         b, _, t = xi.shape
-        if torch.is_grad_enabled() and (self.weight.requires_grad or self.bias.requires_grad):
+        if self.training and torch.is_grad_enabled() and (self.weight.requires_grad or self.bias.requires_grad):
             if x.requires_grad:
                 raise NotImplementedError("conv1d_decoder: gradient w.r.t. the encoder output is not built (the encoder "
                                           "backward kernels are the next step of SURVEY 8 config C4); freeze the encoder")

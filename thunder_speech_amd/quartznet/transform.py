@@ -115,14 +115,18 @@ class _FilterbankFeatures(MultiSequential):
 
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "FilterbankFeatures")
-        if self.training and self[0].layer[0].dither > 0:
-            raise NotImplementedError("FilterbankFeatures: training-mode dither has no HIP kernel yet; call .eval()")
+        dither = float(self[0].layer[0].dither) if self.training else 0.0
         if len(self) > 4:
             raise NotImplementedError("SpecAugment / SpecCutout (training-only, SURVEY 8f rank 3) are not implemented")
         ps, mel = self[1], self[2].layer[0]
         if not mel.log_scale:
             raise NotImplementedError("MelScale(log_scale=False)")
         x = audio.to(torch.float32).contiguous()
+        if dither > 0:
+            # DitherAudio (transform.py:109-118): x + dither * randn_like(x), training only.  Drawn from torch's generator on
+            # purpose: the same seed gives the same noise as the reference; 1e-5-scale noise is below bf16 resolution of the
+            # features, so the kernels downstream are unaffected by where it is generated.
+            x = x + dither * torch.randn_like(x)
         b, n = x.shape
         win, mw, moff, nnz = self._tables(x.device)
         d = _lib.FrontendDesc()

@@ -32,6 +32,7 @@ def main():
     m = build_synthetic_quartznet(repeat_blocks=3)
     variance_preserving_init_(m.encoder, m.decoder, seed=0)
     m = m.to(dev)
+    m.train()
     m.encoder.eval()
     for p in m.encoder.parameters():
         p.requires_grad_(False)
