@@ -69,7 +69,7 @@ struct FeArgs {
   float* logmel;              // [B][F][n_mels]
   float* partial;             // [B][nwg][n_mels][2]
   int* feat_len;
-  int n_samples, hop, n_mels, n_frames, nwg;
+  int n_samples, hop, n_mels, n_frames, nwg, mel_nnz;
   float preemph;
 };
 
@@ -81,10 +81,12 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   Cx* const tw512 = tw256 + NC;                                      // W_512^k, k = 0..256
   float* const win = reinterpret_cast<float*>(tw512 + NC + 2);       // [NFFT]
   float* const fr = win + NFFT;                                      // per frame scratch
-  constexpr int YSZ = 16 * 17 * 2;                                   // floats: padded transpose tile
-  constexpr int ZSZ = NC * 2;
-  constexpr int FSZ = YSZ + ZSZ;
+  constexpr int YSZ = 16 * 17 * 2;                                   // floats: padded transpose tile; Z and P reuse it
+  constexpr int FSZ = YSZ;
+  static_assert(NC * 2 <= YSZ, "the spectrum of a frame fits the transpose tile it replaces");
   float* const red = fr + FPW * FSZ;                                 // [FPW][n_mels] log-mel staging
+  float* const melw = red + FPW * a.n_mels;                          // [mel_nnz] CSR weights
+  int* const melo = reinterpret_cast<int*>(melw + a.mel_nnz);        // [n_mels + 1][2]
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -104,6 +106,8 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
     tw512[k] = Cx{c, s};
   }
   for (int j = tid; j < NFFT; j += 256) win[j] = a.window[j];
+  for (int j = tid; j < a.mel_nnz; j += 256) melw[j] = a.mel_w[j];
+  for (int j = tid; j < (a.n_mels + 1) * 2; j += 256) melo[j] = a.mel_off[j];
   const int k0 = f0 * a.hop - NFFT / 2;
   for (int e = tid; e < span; e += 256) {
     int k = k0 + e;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   const int fl = tid >> 4;          // frame in workgroup
   const int i = tid & 15;
   float* const Y = fr + fl * FSZ;
-  float* const Z = Y + YSZ;
+  float* const Z = Y;                 // written only after every lane of the workgroup has read its Y row
   {
     Cx v[16];
     const float* s = sig + fl * a.hop;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
       const f32x2 t = *reinterpret_cast<const f32x2*>(Y + (i * 17 + n2) * 2);
       v[n2] = Cx{t[0], t[1]};
     }
+    __syncthreads();
     fft16(v);                                    // over n2 -> k2; bin = i + 16 k2
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<f32x2*>(Z + (i + 16 * k2) * 2) = f32x2{v[k2].r, v[k2].i};
@@ -179,10 +184,10 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   // ---- sparse mel filters + log -------------------------------------------------------------------------
   const int f = f0 + fl;
   for (int m = i; m < a.n_mels; m += 16) {
-    const int first = a.mel_off[2 * m], off = a.mel_off[2 * m + 1];
-    const int cnt = a.mel_off[2 * m + 3] - off;
+    const int first = melo[2 * m], off = melo[2 * m + 1];
+    const int cnt = melo[2 * m + 3] - off;
     float acc = 0.f;
-    for (int j = 0; j < cnt; ++j) acc = fmaf(a.mel_w[off + j], P[first + j], acc);
+    for (int j = 0; j < cnt; ++j) acc = fmaf(melw[off + j], P[first + j], acc);
     const float lm = logf(acc + LOG_FLOOR);
     red[fl * a.n_mels + m] = lm;
     if (f < a.n_frames) a.logmel[((size_t)b * a.n_frames + f) * a.n_mels + m] = lm;
@@ -301,9 +306,11 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   a.feat_len = feat_len;
   a.n_samples = d->n_samples; a.hop = d->hop; a.n_mels = d->n_mels; a.n_frames = d->n_frames; a.nwg = nwg;
   a.preemph = d->preemph;
+  a.mel_nnz = d->mel_nnz;
   const int span = (FPW - 1) * d->hop + NFFT;
-  const size_t lds1 = ((size_t)round_up(span, 4) + 2 * NC * 2 + 4 + NFFT + (size_t)FPW * (16 * 17 * 2 + NC * 2) +
-                       (size_t)FPW * d->n_mels) * sizeof(float);
+  if (d->mel_nnz < 0) return TS_EINVAL;
+  const size_t lds1 = ((size_t)round_up(span, 4) + 2 * NC * 2 + 4 + NFFT + (size_t)FPW * (16 * 17 * 2) +
+                       (size_t)FPW * d->n_mels + (size_t)d->mel_nnz + (size_t)(d->n_mels + 1) * 2) * sizeof(float);
   if (lds1 > 160 * 1024) return TS_EUNSUPPORTED;
   if (lds1 > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_kernel),

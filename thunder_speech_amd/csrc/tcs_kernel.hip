@@ -1419,6 +1419,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         // Everything this wave has in flight is a stage old except the last tap DMAs: drain it all.  (Measured: DMA-to-LDS
         // loads and register loads retire out of order with respect to each other, so a counted vmcnt cannot separate them;
         // hipcc's own waits for the row loads assume in-order retirement and are not enough once DMAs are in the queue.)
+#if !defined(TS_EXP) || !(TS_EXP & 1)          // diagnostic builds: TS_EXP & 1 drops the producers' work, & 2 the consumers'
         vm_wait<0>();
         xs_write();
         dw_begin();
@@ -1429,6 +1430,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         for (int m = 0; m < M; ++m)
           *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
         tap_advance();
+#endif
         stage_barrier();
       }
       for (int s = 0; s < n_res; ++s, ++gs) {
@@ -1545,6 +1547,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
     for (int s = 0; s < n_stage; ++s, ++gs) {
       const char* const src = dwt + (gs & 1) * TILEB;
+#if !defined(TS_EXP) || !(TS_EXP & 2)
       read_a(src, 0, af);
       read_a(src, 1, afB);
       __builtin_amdgcn_sched_barrier(0);
@@ -1557,6 +1560,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       mfma_ks(2, af);
       __builtin_amdgcn_sched_barrier(0);
       mfma_ks(3, afB);
+#endif
       w_advance();
       stage_barrier();
     }
