@@ -44,58 +44,52 @@ class QuartznetCheckpoint(str, Enum):
 ENGLISH_LABELS = [" "] + [chr(ord("a") + i) for i in range(26)] + ["'"]
 
 
-def load_components_from_quartznet_config(config: Union[str, Path, Dict]) -> Tuple[nn.Module, nn.Module, BatchTextTransformer]:
-    """NeMo model_config.yaml -> (encoder, audio_transform, text_transform) (compatibility.py:71-124)."""
+def _section(conf: Dict, name: str) -> Dict:
+    """NeMo wrote `encoder: {params: {...}}` in the QuartzNet-era configs and `encoder: {...}` later; accept both."""
+    sec = conf[name]
+    return sec["params"] if isinstance(sec, dict) and "params" in sec else sec
+
+
+def load_components_from_quartznet_config(config: Union[str, Path, Dict], augment_params: Optional[dict] = None
+                                          ) -> Tuple[nn.Module, nn.Module, BatchTextTransformer]:
+    """NeMo model_config.yaml -> (encoder, audio_transform, text_transform) (compatibility.py:71-124): the body blocks are
+    the `jasper` entries between the stem and the two heads, one QuartznetBlock per entry."""
     import yaml
+    params = dict(augment_params or {})
     if not isinstance(config, dict):
         with open(config, "r") as f:
             config = yaml.safe_load(f)
-    enc_cfg = config["encoder"]
-    body_cfg = enc_cfg["jasper"][1:-2]                       # first = stem, last two = dilated + 1x1 heads
-    filters = [c["filters"] for c in body_cfg]
-    kernel_sizes = [c["kernel"][0] for c in body_cfg]
-    # consecutive identical (filters, kernel) entries are the repeated blocks
-    uniq, repeat = [], 1
-    for fk in zip(filters, kernel_sizes):
-        if not uniq or uniq[-1] != fk:
-            uniq.append(fk)
-    repeat = max(1, len(body_cfg) // max(1, len(uniq)))
-    encoder = QuartznetEncoder(feat_in=enc_cfg["feat_in"], filters=[u[0] for u in uniq],
-                               kernel_sizes=[u[1] for u in uniq], repeat_blocks=repeat)
-    pre = config["preprocessor"]
+    body_cfg = _section(config, "encoder")["jasper"][1:-2]
+    # the reference passes one (filters, kernel) pair per body entry with repeat_blocks = 1: a 15x5 config lists its
+    # 15 blocks explicitly, which gives the same module tree / state-dict keys as filters x 5 with repeat_blocks = 3
+    encoder = QuartznetEncoder(filters=[c["filters"] for c in body_cfg], kernel_sizes=[c["kernel"][0] for c in body_cfg],
+                               dropout=params.pop("dropout", 0.0))
+    pre = _section(config, "preprocessor")
     sr = pre["sample_rate"]
     audio_transform = FilterbankFeatures(sample_rate=sr, n_window_size=int(pre["window_size"] * sr),
                                          n_window_stride=int(pre["window_stride"] * sr), n_fft=pre["n_fft"],
-                                         preemph=0.97, nfilt=pre["features"], dither=pre.get("dither", 1e-5))
-    text_transform = BatchTextTransformer(tokens=list(config["labels"]))
+                                         nfilt=pre["features"], dither=pre["dither"], **params)
+    labels = config["labels"] if "labels" in config else _section(config, "decoder")["vocabulary"]
+    text_transform = BatchTextTransformer(tokens=list(labels))
     return encoder, audio_transform, text_transform
 
 
 def fix_encoder_name(key: str) -> str:
-    """NeMo state-dict key -> this module tree (compatibility.py:137-144)."""
-    return (key.replace("encoder.encoder.", "").replace("encoder.", "")
-            .replace(".conv.weight", ".conv.weight").replace("mconv.", "mconv.")
-            .replace(".res.0.", ".res.").replace("bn.", "layer.0."))
+    """NeMo state-dict key -> this module tree (compatibility.py:137-144): drop the `encoder.` prefixes and the
+    dense-residual list index, and put BatchNorm entries behind the `Masked` wrapper's `layer.0`."""
+    key = key.replace("encoder.", "").replace(".res.0", ".res")
+    if ".conv" not in key:
+        parts = key.split(".")
+        key = ".".join(parts[:3] + ["layer", "0"] + parts[3:])
+    return key
 
 
 def load_quartznet_weights(encoder: nn.Module, decoder: nn.Module, weights_path: str):
+    """model_weights.ckpt of a .nemo archive -> encoder / decoder (strict)."""
     sd = torch.load(weights_path, map_location="cpu")
-    enc = {}
-    for k, v in sd.items():
-        if not k.startswith("encoder."):
-            continue
-        nk = k[len("encoder.encoder."):] if k.startswith("encoder.encoder.") else k[len("encoder."):]
-        # NeMo: "<blk>.mconv.<i>.conv.weight" (convs) / "<blk>.mconv.<i>.weight" (BN) / "<blk>.res.0.<j>..."
-        parts = nk.split(".")
-        if "res" in parts:
-            r = parts.index("res")
-            parts = parts[:r + 1] + parts[r + 2:]            # drop the dense-residual list index
-        if parts[-2] != "conv" and parts[-1] in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
-            parts = parts[:-1] + ["layer", "0", parts[-1]]
-        enc[".".join(parts)] = v
-    encoder.load_state_dict(enc, strict=True)
-    dec = {"weight": sd["decoder.decoder_layers.0.weight"], "bias": sd["decoder.decoder_layers.0.bias"]}
-    decoder.load_state_dict(dec, strict=True)
+    encoder.load_state_dict({fix_encoder_name(k): v for k, v in sd.items() if "encoder" in k}, strict=True)
+    decoder.load_state_dict({k.replace("decoder.decoder_layers.0.", ""): v for k, v in sd.items() if "decoder" in k},
+                            strict=True)
 
 
 def load_quartznet_checkpoint(checkpoint: Union[str, QuartznetCheckpoint], save_folder: Optional[str] = None,
