@@ -1407,10 +1407,12 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         if (PS.last_pass(h) == p) tap_dma(h, t_next, d[M - 1][3]);   // behind the pass's last MFMA
     };
 
-    // prologue: rows and taps of the first stage
-    dw_issue();
+    // prologue: rows and taps of the first stage (a pointwise-only layer has identity stages only: n_main == 0)
+    if (n_main) {
+      dw_issue();
 #pragma unroll
-    for (int h = 0; h < NKH; ++h) tap_dma(h, 0);
+      for (int h = 0; h < NKH; ++h) tap_dma(h, 0);
+    }
     if (n_res) id_issue();
     vm_wait<0>();
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
@@ -1487,7 +1489,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     if (w_s == n_stage) {
       w_s = 0;
       if (w_tile + tile_step < a.n_tiles) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
-      w_seek(false);
+      w_seek(n_main == 0);
     } else if (w_s == n_main) {
       w_seek(true);
     } else {
@@ -1529,7 +1531,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 
   TilePos pos;
   pos.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-  w_seek(false);
+  w_seek(n_main == 0);
   w_advance();
   load_w(ring[0], false, 0);
   load_w(ring[1], false, 1);
@@ -1772,6 +1774,17 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     return launch<128, 2, 1, false, true>(a, stream);
   }
   if (d->stride == 1) {
+    if (tz && d->c_res == 0 && getenv("TS_NO_SPLIT") == nullptr) {
+      // pointwise only: the split kernel with identity stages only (the layer's input plays the residual input's role)
+      TcsArgs w = a;
+      const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;
+      const int TTp = 96 * WM;
+      const int n_ttp = (d->t_out + TTp - 1) / TTp;
+      w.c_res = d->c_in; w.c_in = 0; w.xres = a.x; w.res_w = a.pw_w; w.kt_res = a.kt_main; w.pitch_res = d->pitch_in;
+      w.len_res = a.len_in; w.woff = 0; w.padl8 = 0;
+      if (d->pitch_in >= (n_ttp - 1) * TTp + round_up(TTp, 64) && d->pitch_out >= n_ttp * TTp)
+        return WM == 2 ? launch_split<2, 4, 3, 2>(w, stream) : launch_split<2, 2, 3, 1>(w, stream);
+    }
     if (tz && d->pitch_in >= n_tt * TT)
       return wide ? launch<64, 4, 1, false, false, false, true, 0>(a, stream) : launch<128, 2, 1, false, false, false, true, 0>(a, stream);
     return wide ? launch<64, 4, 1, false, false>(a, stream) : launch<128, 2, 1, false, false>(a, stream);
