@@ -164,6 +164,17 @@ int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * wav2vec2 waveform normalisation, replaces Wav2Vec2Preprocess.forward (huggingface/transform.py:34-55 -> normalize_tensor,
+ * blocks.py:118-153).  wave / out f32 [B][n_samples]; wave_len int32 [B] (may be NULL when mask_input = 0).
+ * mask_input = 0: (x - mean) / sqrt(var_unbiased + div_guard); mask_input = 1: masked mean, sigma whose numerator runs over
+ * ALL samples of the zero-masked input, (x - mean) / (sigma + div_guard), zero beyond the length.
+ * workspace: ts_w2v_workspace_bytes(batch) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ts_w2v_workspace_bytes(int32_t batch);
+int ts_w2v_preprocess(const float* wave, const int32_t* wave_len, int32_t batch, int32_t n_samples, int32_t mask_input,
+                      float div_guard, float* out, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].
  * ---------------------------------------------------------------------------------------------- */
 /* len (may be NULL): int32 [B]; frames >= len[b] are written as 0 so that dst satisfies the tail-zero invariant. */

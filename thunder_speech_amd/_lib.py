@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss",
     "ts_pack_activation", "ts_unpack_activation", "ts_se_gate_fwd", "ts_se_apply_fwd",
-    "ts_decoder_bwd", "ts_adamw_step",
+    "ts_decoder_bwd", "ts_adamw_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
 ]
 
 
@@ -99,6 +99,10 @@ def lib() -> C.CDLL:
     f32 = C.c_float
     L.ts_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
     L.ts_adamw_step.restype = C.c_int
+    L.ts_w2v_workspace_bytes.argtypes = [i32]
+    L.ts_w2v_workspace_bytes.restype = i64
+    L.ts_w2v_preprocess.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp]
+    L.ts_w2v_preprocess.restype = C.c_int
     if L.ts_abi_version() != ABI_VERSION:
         raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")
     _lib = L

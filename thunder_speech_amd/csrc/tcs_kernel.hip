@@ -40,6 +40,9 @@ constexpr int KC = 64;         // input channels per stage
 constexpr int NKP = 3;         // depthwise k-steps (of 4 samples) per pass
 constexpr int XMAX = 5;        // staged row length <= 64 * XMAX elements
 constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
+#ifndef TS_SPLIT_RING
+#define TS_SPLIT_RING 2
+#endif
 #ifndef TS_PIPE_RING
 #define TS_PIPE_RING 2
 #endif
@@ -1466,7 +1469,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   const unsigned floor2 = a.relu ? 0u : 0x80008000u;
   const int lane_w = lane * 16;
 
-  s16x8 ring[2][NT];
+  constexpr int RING = TS_SPLIT_RING;             // weight-fragment ring depth in k-steps (4 = a whole stage ahead)
+  s16x8 ring[RING][NT];
   TilePos wp;
   wp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
   int w_tile = blockIdx.x, w_s = 0;
@@ -1525,16 +1529,16 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks & 1][nt], acc[mt][nt], 0, 0, 0);
-    load_w(ring[ks & 1], ks >= 2, (ks + 2) & 3);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
+    load_w(ring[ks % RING], ks + RING >= 4, (ks + RING) & 3);
   };
 
   TilePos pos;
   pos.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
   w_seek(n_main == 0);
   w_advance();
-  load_w(ring[0], false, 0);
-  load_w(ring[1], false, 1);
+#pragma unroll
+  for (int r = 0; r < RING; ++r) load_w(ring[r], false, r);
   bias_fetch(pos);
   stage_barrier();                                   // stage 0 is in dwt[0]
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
@@ -1549,7 +1553,21 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
     for (int s = 0; s < n_stage; ++s, ++gs) {
       const char* const src = dwt + (gs & 1) * TILEB;
-#if !defined(TS_EXP) || !(TS_EXP & 2)
+#if defined(TS_EXP) && (TS_EXP & 4)          // timing experiment only (reads the next tile before it is complete)
+      if (s == 0) { read_a(src, 0, af); read_a(src, 1, afB); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(0, af);
+      read_a(src, 2, af);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(1, afB);
+      read_a(src, 3, afB);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(2, af);
+      read_a(dwt + ((gs + 1) & 1) * TILEB, 0, af);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ks(3, afB);
+      read_a(dwt + ((gs + 1) & 1) * TILEB, 1, afB);
+#elif !defined(TS_EXP) || !(TS_EXP & 2)
       read_a(src, 0, af);
       read_a(src, 1, afB);
       __builtin_amdgcn_sched_barrier(0);
