@@ -122,3 +122,31 @@ def test_cpu_tensors_fail_loudly():
     module, *_ = _build(1)
     with pytest.raises(RuntimeError, match="no CPU"):
         module.cpu().predict(torch.zeros(1, 16000))
+
+
+def test_hipgraph_replays_are_bit_identical_to_eager():
+    """The bench replays the whole step from a hipGraph back to back: every replay must reproduce the eager logits
+    bit for bit (no launch-order or cache-state dependence anywhere in the inference path)."""
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.utils import variance_preserving_init_
+    module = build_synthetic_quartznet(repeat_blocks=3)
+    variance_preserving_init_(module.encoder, module.decoder, seed=4)
+    module = module.cuda().eval()
+    g = torch.Generator().manual_seed(8)
+    wav = (0.1 * torch.randn(8, 16000 * 6, generator=g)).cuda()
+    lengths = torch.tensor([96000, 96000, 90000, 80000, 64000, 50000, 33000, 16000], dtype=torch.int32).cuda()
+    with torch.no_grad():
+        for _ in range(2):
+            eager, eager_len = module(wav, lengths)
+        eager = eager.clone()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                out, out_len = module(wav, lengths)
+        for it in range(25):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager), f"replay {it}: max diff {float((out - eager).abs().max())}"
+    assert torch.equal(out_len, eager_len)
