@@ -164,6 +164,34 @@ int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training-mode encoder ops (fine-tuning with the encoder unfrozen), first unfused version: fp32 activations in the
+ * reference layout [B][C][T] (contiguous), one entry point per reference op and direction.  Lengths are int32 [B].
+ *   depthwise MaskedConv1d (quartznet/blocks.py:169-182, groups = C): x masked by len_in; y masked by len_out when given
+ *   1x1 MaskedConv1d: plain GEMMs (rocBLAS) on inputs the caller has masked with ts_train_mask_time
+ *   BatchNorm1d in train mode (quartznet/blocks.py:222, statistics over all B*T frames incl. padding -- quirk A4 --,
+ *     biased variance, eps) with optional fused ReLU; mean_rstd f32 [C][2] is saved for the backward
+ *   residual add + ReLU (quartznet/blocks.py:332-337)
+ * Workspaces: pwconv_bwd B*c_out*c_in floats; bn_fwd 2*C doubles; bn_bwd 2*C doubles + 2*B*C*T floats.
+ * ---------------------------------------------------------------------------------------------- */
+int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* y, int32_t batch,
+                        int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride, int32_t dilation,
+                        int32_t padding, void* stream);
+int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const float* w, float* dx, float* dw, int32_t batch,
+                        int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride, int32_t dilation,
+                        int32_t padding, void* stream);
+int ts_train_mask_time(const float* x, const int32_t* len, float* y, int32_t batch, int32_t channels, int32_t t, void* stream);
+int ts_train_pwconv_fwd(const float* u, const float* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t, void* stream);
+int ts_train_pwconv_bwd(const float* dv, const float* u, const float* w, float* du, float* dw, float* workspace, int32_t batch,
+                        int32_t c_in, int32_t c_out, int32_t t, void* stream);
+int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace, int32_t batch,
+                    int32_t channels, int32_t t, float eps, int32_t relu, void* stream);
+int ts_train_bn_bwd(const float* dy, const float* y, const float* v, const float* gamma, const float* mean_rstd, float* dv,
+                    float* dgamma, float* dbeta, void* workspace, int32_t batch, int32_t channels, int32_t t, int32_t relu,
+                    void* stream);
+int ts_train_add_relu_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
+int ts_train_relu_bwd(const float* dout, const float* out, float* din, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * wav2vec2 waveform normalisation, replaces Wav2Vec2Preprocess.forward (huggingface/transform.py:34-55 -> normalize_tensor,
  * blocks.py:118-153).  wave / out f32 [B][n_samples]; wave_len int32 [B] (may be NULL when mask_input = 0).
  * mask_input = 0: (x - mean) / sqrt(var_unbiased + div_guard); mask_input = 1: masked mean, sigma whose numerator runs over

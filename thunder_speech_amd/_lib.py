@@ -23,6 +23,8 @@ EXPORTED_SYMBOLS = [
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss",
     "ts_pack_activation", "ts_unpack_activation", "ts_se_gate_fwd", "ts_se_apply_fwd",
     "ts_decoder_bwd", "ts_adamw_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
+    "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd",
+    "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
 ]
 
 
@@ -103,6 +105,18 @@ def lib() -> C.CDLL:
     L.ts_w2v_workspace_bytes.restype = i64
     L.ts_w2v_preprocess.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp]
     L.ts_w2v_preprocess.restype = C.c_int
+    L.ts_train_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
+    L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
+    L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    L.ts_train_pwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.ts_train_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
+    L.ts_train_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.ts_train_add_relu_fwd.argtypes = [vp, vp, vp, i64, vp]
+    L.ts_train_relu_bwd.argtypes = [vp, vp, vp, i64, vp]
+    for fn in ("ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd",
+               "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd"):
+        getattr(L, fn).restype = C.c_int
     if L.ts_abi_version() != ABI_VERSION:
         raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")
     _lib = L

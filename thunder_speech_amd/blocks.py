@@ -102,12 +102,14 @@ class _Conv1dDecoder(nn.Conv1d):
 
     def forward(self, x: Tensor) -> Tensor:
         _t.require_gpu(x, "conv1d_decoder")
-        xi = _t.pack(x)
+        xi = x if (x.requires_grad and self.training) else _t.pack(x)
         b, _, t = xi.shape
         if self.training and torch.is_grad_enabled() and (self.weight.requires_grad or self.bias.requires_grad):
             if x.requires_grad:
-                raise NotImplementedError("conv1d_decoder: gradient w.r.t. the encoder output is not built (the encoder "
-                                          "backward kernels are the next step of SURVEY 8 config C4); freeze the encoder")
+                # encoder unfrozen: fp32 training ops all the way (GEMM forward / backward in train_ops.PointwiseConv);
+                # the bias add on the [B, V, T] logits is the one broadcast left to autograd
+                from .train_ops import PointwiseConv
+                return PointwiseConv.apply(x, self.weight) + self.bias.view(1, -1, 1)
             return _DecoderFunction.apply(self.weight, self.bias, self, _t.backing(xi), t)
         full = torch.full((b,), t, dtype=torch.int32, device=xi.device)   # the decoder conv is not masked
         y, t_out = self._layer().run(_t.backing(xi), t, full)

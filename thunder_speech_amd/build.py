@@ -54,7 +54,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+    # rocBLAS: the plain GEMMs of the training-mode pointwise convolutions (csrc/train_enc.hip); everything else is ours
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrocblas"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

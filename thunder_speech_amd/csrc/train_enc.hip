@@ -1,0 +1,308 @@
+// Training-mode encoder kernels (fine-tuning phase 2: encoder unfrozen).  First, unfused version:
+// fp32 activations in the reference layout [B][C][T] (contiguous), one launch per reference op, so that every op's
+// forward AND backward can be checked against the oracle's autograd.  The pointwise convolutions and their two backward
+// products are plain GEMMs and go to rocBLAS (the only library calls in this repo); everything else is hand-written.
+//   masked depthwise conv fwd / bwd-data / bwd-weight   quartznet/blocks.py:169-182 (MaskedConv1d, groups = C)
+//   masked 1x1 conv fwd / bwd-data / bwd-weight          same class, kernel_size = 1            (rocBLAS sgemm)
+//   BatchNorm1d(train) [+ ReLU] fwd / bwd                quartznet/blocks.py:222 (eps 1e-3), statistics over ALL B*T frames (A4)
+//   residual add + ReLU fwd / bwd                        quartznet/blocks.py:332-337
+#include "ts_common.hpp"
+
+#include <rocblas/rocblas.h>
+
+namespace ts {
+
+__device__ __forceinline__ int clamp_len(const int* len, int b, int t) {
+  if (!len) return t;
+  const int l = len[b];
+  return l < 0 ? 0 : (l > t ? t : l);
+}
+
+// y[b,c,t] = sum_k w[c,k] * xm[b,c,t*s + k*d - p],  xm = x zeroed from len_in[b] on;  y zeroed from len_out[b] on when given
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const int* __restrict__ len_in,
+                                                     const int* __restrict__ len_out, const float* __restrict__ w,
+                                                     float* __restrict__ y, int batch, int ch, int t_in, int t_out, int k, int s,
+                                                     int d, int p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)batch * ch * t_out) return;
+  const int t = (int)(idx % t_out);
+  const int c = (int)((idx / t_out) % ch), b = (int)(idx / ((long long)t_out * ch));
+  const int li = clamp_len(len_in, b, t_in);
+  const float* xr = x + ((size_t)b * ch + c) * t_in;
+  const float* wr = w + (size_t)c * k;
+  float acc = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const int i = t * s + j * d - p;
+    if (i >= 0 && i < li) acc = fmaf(wr[j], xr[i], acc);
+  }
+  if (len_out && t >= clamp_len(len_out, b, t_out)) acc = 0.f;
+  y[idx] = acc;
+}
+
+// dx[b,c,i] = (i < len_in) ? sum_k w[c,k] * dy[b,c,(i + p - k*d)/s] : 0    (terms with a non-integer or out-of-range index drop out)
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const int* __restrict__ len_in,
+                                                          const float* __restrict__ w, float* __restrict__ dx, int batch, int ch,
+                                                          int t_in, int t_out, int k, int s, int d, int p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)batch * ch * t_in) return;
+  const int i = (int)(idx % t_in);
+  const int c = (int)((idx / t_in) % ch), b = (int)(idx / ((long long)t_in * ch));
+  float acc = 0.f;
+  if (i < clamp_len(len_in, b, t_in)) {
+    const float* gr = dy + ((size_t)b * ch + c) * t_out;
+    const float* wr = w + (size_t)c * k;
+    for (int j = 0; j < k; ++j) {
+      const int n = i + p - j * d;
+      if (n >= 0 && n % s == 0 && n / s < t_out) acc = fmaf(wr[j], gr[n / s], acc);
+    }
+  }
+  dx[idx] = acc;
+}
+
+// dw[c,j] = sum_{b,t} dy[b,c,t] * xm[b,c,t*s + j*d - p]; one workgroup per (channel, tap)
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const int* __restrict__ len_in, float* __restrict__ dw, int batch,
+                                                            int ch, int t_in, int t_out, int k, int s, int d, int p) {
+  __shared__ double red[256];
+  const int c = blockIdx.x, j = blockIdx.y;
+  double acc = 0.0;
+  for (int b = 0; b < batch; ++b) {
+    const int li = clamp_len(len_in, b, t_in);
+    const float* gr = dy + ((size_t)b * ch + c) * t_out;
+    const float* xr = x + ((size_t)b * ch + c) * t_in;
+    for (int t = threadIdx.x; t < t_out; t += 256) {
+      const int i = t * s + j * d - p;
+      if (i >= 0 && i < li) acc += (double)gr[t] * (double)xr[i];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dw[(size_t)c * k + j] = (float)red[0];
+}
+
+// y = x with frames >= len[b] zeroed (the re-masking in front of every MaskedConv1d, and of gradients on the way back)
+__global__ __launch_bounds__(256) void mask_time_kernel(const float* __restrict__ x, const int* __restrict__ len, float* __restrict__ y,
+                                                        int batch, int ch, int t) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)batch * ch * t) return;
+  const int tt = (int)(idx % t), b = (int)(idx / ((long long)t * ch));
+  y[idx] = tt < clamp_len(len, b, t) ? x[idx] : 0.f;
+}
+
+// per-channel sums over all B*T frames: out[c] = (sum a, sum a*b) (b may alias a); fp64 accumulation
+__global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict__ a, const float* __restrict__ bsrc,
+                                                        double* __restrict__ out, int batch, int ch, int t) {
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < batch; ++b) {
+    const float* pa = a + ((size_t)b * ch + c) * t;
+    const float* pb = bsrc + ((size_t)b * ch + c) * t;
+    for (int i = threadIdx.x; i < t; i += 256) {
+      const double va = pa[i];
+      s1 += va;
+      s2 += va * (double)pb[i];
+    }
+  }
+  r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[2 * c] = r1[0]; out[2 * c + 1] = r2[0]; }
+}
+
+// BatchNorm(train) forward: stats[c] = (sum v, sum v^2) -> mean, rstd (biased variance, eps), y = gamma*(v-mean)*rstd + beta [ReLU]
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v, const double* __restrict__ sums,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, float* __restrict__ mean_rstd, int batch, int ch, int t,
+                                                     float eps, int relu) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)batch * ch * t) return;
+  const int c = (int)((idx / t) % ch);
+  const double n = (double)batch * t;
+  const double mu = sums[2 * c] / n;
+  double var = sums[2 * c + 1] / n - mu * mu;
+  var = var < 0.0 ? 0.0 : var;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (idx % t == 0 && idx / ((long long)t * ch) == 0) { mean_rstd[2 * c] = (float)mu; mean_rstd[2 * c + 1] = rstd; }
+  float o = gamma[c] * (v[idx] - (float)mu) * rstd + beta[c];
+  if (relu) o = o > 0.f ? o : 0.f;
+  y[idx] = o;
+}
+
+// g = dy * (y > 0) when relu; used twice: first to reduce (sum g, sum g*xhat), then to apply
+// dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat))
+__global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ v, const float* __restrict__ mean_rstd,
+                                                          float* __restrict__ g, float* __restrict__ xhat, int batch, int ch, int t,
+                                                          int relu) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)batch * ch * t) return;
+  const int c = (int)((idx / t) % ch);
+  g[idx] = (relu && !(y[idx] > 0.f)) ? 0.f : dy[idx];
+  xhat[idx] = (v[idx] - mean_rstd[2 * c]) * mean_rstd[2 * c + 1];
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
+                                                           const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_rstd, float* __restrict__ dv,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int batch, int ch,
+                                                           int t) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)batch * ch * t) return;
+  const int c = (int)((idx / t) % ch);
+  const double n = (double)batch * t;
+  const float mg = (float)(sums[2 * c] / n), mgx = (float)(sums[2 * c + 1] / n);
+  if (idx % t == 0 && idx / ((long long)t * ch) == 0) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
+  dv[idx] = gamma[c] * mean_rstd[2 * c + 1] * (g[idx] - mg - xhat[idx] * mgx);
+}
+
+// out = relu(a + b); backward: da = db = dout * (out > 0)
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                                                           long long n) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const float s = a[idx] + (b ? b[idx] : 0.f);
+  o[idx] = s > 0.f ? s : 0.f;
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, float* __restrict__ din,
+                                                       long long n) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  din[idx] = out[idx] > 0.f ? dout[idx] : 0.f;
+}
+
+// sum of `parts` partial [rows] vectors (the per-clip dW of the pointwise backward)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, float* __restrict__ out, long long rows, int n_parts) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows) return;
+  float s = 0.f;
+  for (int i = 0; i < n_parts; ++i) s += parts[(size_t)i * rows + idx];
+  out[idx] = s;
+}
+
+static rocblas_handle g_handle = nullptr;
+static int blas(hipStream_t stream, rocblas_handle* h) {
+  if (!g_handle && rocblas_create_handle(&g_handle) != rocblas_status_success) return TS_EUNSUPPORTED;
+  if (rocblas_set_stream(g_handle, stream) != rocblas_status_success) return TS_EUNSUPPORTED;
+  *h = g_handle;
+  return TS_OK;
+}
+static inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace ts
+
+using namespace ts;
+#define TS_STREAM hipStream_t stream = reinterpret_cast<hipStream_t>(stream_); (void)hipGetLastError()
+
+extern "C" int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* y, int32_t batch,
+                                   int32_t ch, int32_t t_in, int32_t t_out, int32_t k, int32_t stride, int32_t dil, int32_t pad,
+                                   void* stream_) {
+  if (!x || !w || !y || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0 || stride <= 0 || dil <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(blocks((long long)batch * ch * t_out)), dim3(256), 0, stream, x, len_in, len_out, w, y, batch,
+                     ch, t_in, t_out, k, stride, dil, pad);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const float* w, float* dx, float* dw,
+                                   int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k, int32_t stride, int32_t dil,
+                                   int32_t pad, void* stream_) {
+  if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(blocks((long long)batch * ch * t_in)), dim3(256), 0, stream, dy, len_in, w, dx, batch, ch,
+                     t_in, t_out, k, stride, dil, pad);
+  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(ch, k), dim3(256), 0, stream, dy, x, len_in, dw, batch, ch, t_in, t_out, k, stride, dil, pad);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_mask_time(const float* x, const int32_t* len, float* y, int32_t batch, int32_t ch, int32_t t, void* stream_) {
+  if (!x || !len || !y || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(mask_time_kernel, dim3(blocks((long long)batch * ch * t)), dim3(256), 0, stream, x, len, y, batch, ch, t);
+  return hip_status(hipGetLastError());
+}
+
+// v[b] = W . u[b]   (W [c_out][c_in] row-major, u [B][c_in][t], v [B][c_out][t]); u is expected masked by the caller
+extern "C" int ts_train_pwconv_fwd(const float* u, const float* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t,
+                                   void* stream_) {
+  if (!u || !w || !v || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0) return TS_EINVAL;
+  TS_STREAM;
+  rocblas_handle h;
+  if (int e = blas(stream, &h)) return e;
+  const float one = 1.f, zero = 0.f;
+  // row-major [c][t] == column-major [t][c]:  V(t x c_out) = U(t x c_in) . Wc(c_in x c_out)
+  const rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, t, c_out, c_in, &one, u, t,
+                                                          (rocblas_stride)c_in * t, w, c_in, 0, &zero, v, t, (rocblas_stride)c_out * t, batch);
+  return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
+}
+
+// du[b] = W^T . dv[b];  dW = sum_b dv[b] . u[b]^T  (workspace: batch * c_out * c_in floats)
+extern "C" int ts_train_pwconv_bwd(const float* dv, const float* u, const float* w, float* du, float* dw, float* workspace, int32_t batch,
+                                   int32_t c_in, int32_t c_out, int32_t t, void* stream_) {
+  if (!dv || !u || !w || !du || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0) return TS_EINVAL;
+  TS_STREAM;
+  rocblas_handle h;
+  if (int e = blas(stream, &h)) return e;
+  const float one = 1.f, zero = 0.f;
+  // dU(t x c_in) = dV(t x c_out) . Wc^T(c_out x c_in)
+  rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, t, c_in, c_out, &one, dv, t,
+                                                    (rocblas_stride)c_out * t, w, c_in, 0, &zero, du, t, (rocblas_stride)c_in * t, batch);
+  if (st != rocblas_status_success) return TS_EUNSUPPORTED;
+  // per clip: dWc_b(c_in x c_out) = U^T(c_in x t) . dV(t x c_out)
+  st = rocblas_sgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, c_in, c_out, t, &one, u, t,
+                                     (rocblas_stride)c_in * t, dv, t, (rocblas_stride)c_out * t, &zero, workspace, c_in,
+                                     (rocblas_stride)c_in * c_out, batch);
+  if (st != rocblas_status_success) return TS_EUNSUPPORTED;
+  const long long rows = (long long)c_in * c_out;
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(blocks(rows)), dim3(256), 0, stream, workspace, dw, rows, batch);
+  return hip_status(hipGetLastError());
+}
+
+// workspace: c * 2 doubles.  mean_rstd f32 [c][2] is saved for the backward.
+extern "C" int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace,
+                               int32_t batch, int32_t ch, int32_t t, float eps, int32_t relu, void* stream_) {
+  if (!v || !gamma || !beta || !y || !mean_rstd || !workspace || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
+  TS_STREAM;
+  double* sums = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(chan_sums_kernel, dim3(ch), dim3(256), 0, stream, v, v, sums, batch, ch, t);
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3(blocks((long long)batch * ch * t)), dim3(256), 0, stream, v, sums, gamma, beta, y, mean_rstd, batch,
+                     ch, t, eps, relu);
+  return hip_status(hipGetLastError());
+}
+
+// workspace: c * 2 doubles + 2 * batch*ch*t floats (g, xhat)
+extern "C" int ts_train_bn_bwd(const float* dy, const float* y, const float* v, const float* gamma, const float* mean_rstd, float* dv,
+                               float* dgamma, float* dbeta, void* workspace, int32_t batch, int32_t ch, int32_t t, int32_t relu,
+                               void* stream_) {
+  if (!dy || !y || !v || !gamma || !mean_rstd || !dv || !dgamma || !dbeta || !workspace || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
+  TS_STREAM;
+  const long long n = (long long)batch * ch * t;
+  double* sums = static_cast<double*>(workspace);
+  float* g = reinterpret_cast<float*>(sums + 2 * (size_t)ch);
+  float* xhat = g + n;
+  hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(blocks(n)), dim3(256), 0, stream, dy, y, v, mean_rstd, g, xhat, batch, ch, t, relu);
+  hipLaunchKernelGGL(chan_sums_kernel, dim3(ch), dim3(256), 0, stream, g, xhat, sums, batch, ch, t);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(n)), dim3(256), 0, stream, g, xhat, sums, gamma, mean_rstd, dv, dgamma, dbeta, batch, ch, t);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_add_relu_fwd(const float* a, const float* b, float* out, int64_t n, void* stream_) {
+  if (!a || !out || n <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(add_relu_fwd_kernel, dim3(blocks(n)), dim3(256), 0, stream, a, b, out, (long long)n);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_relu_bwd(const float* dout, const float* out, float* din, int64_t n, void* stream_) {
+  if (!dout || !out || !din || n <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks(n)), dim3(256), 0, stream, dout, out, din, (long long)n);
+  return hip_status(hipGetLastError());
+}

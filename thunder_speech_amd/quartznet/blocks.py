@@ -184,9 +184,40 @@ class _FusedBlockBase(nn.Module):
 
     def _check_eval(self):
         if self.training:
-            raise NotImplementedError(
-                f"{type(self).__name__}: training-mode forward (batch-stat BatchNorm, dropout, backward) has no HIP "
-                "kernels yet -- call .eval(); see DESIGN.md 'out of scope this round'.")
+            raise NotImplementedError(f"{type(self).__name__}: this path is the inference launch sequence; call .eval()")
+
+    def _forward_train(self, x: torch.Tensor, lengths: torch.Tensor):
+        """Training-mode forward (batch-statistics BatchNorm, autograd through every op): the reference's op sequence
+        (quartznet/blocks.py:317-338), one HIP launch per op and direction (train_ops.py), fp32 [B, C, T] activations."""
+        from .. import train_ops as T
+        _t.require_gpu(x, type(self).__name__)
+        if self._has_se():
+            raise NotImplementedError("training-mode squeeze-excite (Citrinet) is not built")
+        for m in self.modules():
+            if isinstance(m, nn.Dropout) and m.p > 0:
+                raise NotImplementedError("training-mode dropout > 0 has no HIP kernel (the reference encoders default to 0.0)")
+        x = _t.unpack(x) if _t.is_internal(x) else x.to(torch.float32)
+        dev = x.device
+        len_in = _t.lengths_i32(lengths, dev)
+        h, lh, out_lengths = x, len_in, lengths
+        subs = list(self._sub_blocks())
+        for r, (dw, pw, bn) in enumerate(subs):
+            last = r == len(subs) - 1
+            if dw is not None:
+                h = T.DepthwiseConv.apply(h, dw.conv.weight, lh, dw.kernel_size, dw.stride, dw.dilation, dw.padding)
+                out_lengths = dw.get_seq_len(out_lengths)
+                lh = _t.lengths_i32(out_lengths, dev)
+            if pw.kernel_size != 1 or pw.stride != 1:
+                raise NotImplementedError("training mode: dense convs other than 1x1 / stride 1 have no HIP kernel")
+            h = T.PointwiseConv.apply(T.MaskTime.apply(h, lh), pw.conv.weight)
+            h = T.batch_norm_train(bn, h, relu=not last)
+        r_out = None
+        if self.res is not None:
+            rc, rbn = self.res[0], self.res[1].layer[0]
+            if rc.stride != 1:
+                raise NotImplementedError("training mode: strided residual convs have no HIP kernel")
+            r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(T.MaskTime.apply(x, len_in), rc.conv.weight), relu=False)
+        return T.AddRelu.apply(h, r_out), out_lengths
 
     def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=0):
         """Run the block's launches.  `internal=True` (set by the encoder for every block but the last): the block
@@ -258,6 +289,8 @@ class QuartznetBlock(_FusedBlockBase):
         self._cache = _PackedCache()
 
     def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.training:
+            return self._forward_train(x, lengths)
         y, out_lengths, was_internal = self._run_fused(x, lengths)
         return (y if was_internal else _t.unpack(y)), out_lengths
 
@@ -269,6 +302,11 @@ class EncoderSequential(MultiSequential):
 
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "encoder")
+        if self.training:                       # training mode: plain chain of the blocks' training forwards (fp32, autograd)
+            x = audio
+            for blk in self.children():
+                x, audio_lengths = blk(x, audio_lengths)
+            return x, audio_lengths
         x = audio if _t.is_internal(audio) else _t.pack(audio, audio_lengths, slot=("enc", id(self)))
         blocks = list(self.children())
         for i, blk in enumerate(blocks):

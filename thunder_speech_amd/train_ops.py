@@ -1,0 +1,171 @@
+"""Training-mode encoder ops (fine-tuning with the encoder unfrozen): one torch.autograd.Function per reference op, each
+forward AND backward a call into csrc/train_enc.hip (fp32 activations, reference layout [B, C, T]).  PyTorch only chains the
+Functions; no ATen compute op touches an activation."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _s(t: Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _f32(t: Tensor) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("thunder_speech_amd training ops run on the GPU only (no CPU fallback)")
+    return t.to(torch.float32).contiguous()
+
+
+class DepthwiseConv(torch.autograd.Function):
+    """MaskedConv1d with groups = C: y = conv(mask(x, len_in)); backward masks dx the same way."""
+
+    @staticmethod
+    def forward(ctx, x, w, len_in, k, stride, dil, pad):
+        x, w2 = _f32(x), _f32(w).view(w.shape[0], -1)
+        b, c, t_in = x.shape
+        t_out = (t_in + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        y = torch.empty(b, c, t_out, dtype=torch.float32, device=x.device)
+        st = _lib.lib().ts_train_dwconv_fwd(x.data_ptr(), len_in.data_ptr(), None, w2.data_ptr(), y.data_ptr(), b, c, t_in, t_out, k,
+                                            stride, dil, pad, _s(x))
+        _lib.check(st, "ts_train_dwconv_fwd")
+        ctx.save_for_backward(x, w2, len_in)
+        ctx.geom = (k, stride, dil, pad, t_out, w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2, len_in = ctx.saved_tensors
+        k, stride, dil, pad, t_out, wshape = ctx.geom
+        dy = _f32(dy)
+        b, c, t_in = x.shape
+        dx, dw = torch.empty_like(x), torch.empty_like(w2)
+        st = _lib.lib().ts_train_dwconv_bwd(dy.data_ptr(), x.data_ptr(), len_in.data_ptr(), w2.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                            b, c, t_in, t_out, k, stride, dil, pad, _s(x))
+        _lib.check(st, "ts_train_dwconv_bwd")
+        return dx, dw.view(wshape), None, None, None, None, None
+
+
+class MaskTime(torch.autograd.Function):
+    """Zero the frames >= length (the re-masking in front of every MaskedConv1d); the gradient is masked the same way."""
+
+    @staticmethod
+    def forward(ctx, x, lens):
+        x = _f32(x)
+        b, c, t = x.shape
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ts_train_mask_time(x.data_ptr(), lens.data_ptr(), y.data_ptr(), b, c, t, _s(x)), "ts_train_mask_time")
+        ctx.save_for_backward(lens)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lens,) = ctx.saved_tensors
+        dy = _f32(dy)
+        b, c, t = dy.shape
+        dx = torch.empty_like(dy)
+        _lib.check(_lib.lib().ts_train_mask_time(dy.data_ptr(), lens.data_ptr(), dx.data_ptr(), b, c, t, _s(dy)), "ts_train_mask_time")
+        return dx, None
+
+
+class PointwiseConv(torch.autograd.Function):
+    """1x1 conv without bias on an already masked input: v[b] = W . u[b] (rocBLAS), du = W^T dv, dW = sum_b dv u^T."""
+
+    @staticmethod
+    def forward(ctx, u, w):
+        u, w2 = _f32(u), _f32(w).view(w.shape[0], -1)
+        b, c_in, t = u.shape
+        c_out = w2.shape[0]
+        v = torch.empty(b, c_out, t, dtype=torch.float32, device=u.device)
+        _lib.check(_lib.lib().ts_train_pwconv_fwd(u.data_ptr(), w2.data_ptr(), v.data_ptr(), b, c_in, c_out, t, _s(u)), "ts_train_pwconv_fwd")
+        ctx.save_for_backward(u, w2)
+        ctx.wshape = w.shape
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        u, w2 = ctx.saved_tensors
+        dv = _f32(dv)
+        b, c_in, t = u.shape
+        c_out = w2.shape[0]
+        du, dw = torch.empty_like(u), torch.empty_like(w2)
+        ws = torch.empty(b * c_out * c_in, dtype=torch.float32, device=u.device)
+        st = _lib.lib().ts_train_pwconv_bwd(dv.data_ptr(), u.data_ptr(), w2.data_ptr(), du.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in,
+                                            c_out, t, _s(u))
+        _lib.check(st, "ts_train_pwconv_bwd")
+        return du, dw.view(ctx.wshape)
+
+
+class BatchNormTrain(torch.autograd.Function):
+    """BatchNorm1d in train mode (+ optional ReLU): statistics over all B*T frames (quirk A4).  Returns y and leaves the
+    batch mean / biased variance in `stats_out` ([2, C]) for the running-statistics update."""
+
+    @staticmethod
+    def forward(ctx, v, gamma, beta, eps, relu, stats_out):
+        v, g, be = _f32(v), _f32(gamma), _f32(beta)
+        b, c, t = v.shape
+        y = torch.empty_like(v)
+        mr = torch.empty(c, 2, dtype=torch.float32, device=v.device)
+        ws = torch.empty(2 * c, dtype=torch.float64, device=v.device)
+        st = _lib.lib().ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c, t,
+                                        float(eps), int(relu), _s(v))
+        _lib.check(st, "ts_train_bn_fwd")
+        if stats_out is not None:
+            stats_out[0].copy_(mr[:, 0])
+            stats_out[1].copy_(1.0 / (mr[:, 1] * mr[:, 1]) - eps)
+        ctx.save_for_backward(v, y, g, mr)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, y, g, mr = ctx.saved_tensors
+        dy = _f32(dy)
+        b, c, t = v.shape
+        dv = torch.empty_like(v)
+        dg, db = torch.empty(c, dtype=torch.float32, device=v.device), torch.empty(c, dtype=torch.float32, device=v.device)
+        ws = torch.empty(2 * c * 8 + 2 * v.numel() * 4, dtype=torch.uint8, device=v.device)
+        st = _lib.lib().ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(),
+                                        db.data_ptr(), ws.data_ptr(), b, c, t, int(ctx.relu), _s(v))
+        _lib.check(st, "ts_train_bn_bwd")
+        return dv, dg, db, None, None, None
+
+
+class AddRelu(torch.autograd.Function):
+    """out = relu(a + b) (b may be None)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _f32(a)
+        bb = _f32(b) if b is not None else None
+        out = torch.empty_like(a)
+        st = _lib.lib().ts_train_add_relu_fwd(a.data_ptr(), bb.data_ptr() if bb is not None else None, out.data_ptr(), a.numel(), _s(a))
+        _lib.check(st, "ts_train_add_relu_fwd")
+        ctx.save_for_backward(out)
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = _f32(dout)
+        din = torch.empty_like(out)
+        _lib.check(_lib.lib().ts_train_relu_bwd(dout.data_ptr(), out.data_ptr(), din.data_ptr(), out.numel(), _s(out)), "ts_train_relu_bwd")
+        return din, (din if ctx.has_b else None)
+
+
+def batch_norm_train(bn: torch.nn.BatchNorm1d, v: Tensor, relu: bool) -> Tensor:
+    """BatchNorm1d(train) through the kernels + the module's running-statistics update (momentum, unbiased variance)."""
+    c = v.shape[1]
+    stats = torch.empty(2, c, dtype=torch.float32, device=v.device) if bn.track_running_stats else None
+    y = BatchNormTrain.apply(v, bn.weight, bn.bias, bn.eps, relu, stats)
+    if stats is not None:
+        with torch.no_grad():
+            n = v.shape[0] * v.shape[2]
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1 - m).add_(stats[0], alpha=m)
+            bn.running_var.mul_(1 - m).add_(stats[1] * (n / max(n - 1, 1)), alpha=m)
+            bn.num_batches_tracked += 1
+    return y
