@@ -18,70 +18,121 @@ __device__ __forceinline__ int clamp_len(const int* len, int b, int t) {
   return l < 0 ? 0 : (l > t ? t : l);
 }
 
-// y[b,c,t] = sum_k w[c,k] * xm[b,c,t*s + k*d - p],  xm = x zeroed from len_in[b] on;  y zeroed from len_out[b] on when given
+constexpr int DW_TILE = 1024;      // output frames per workgroup (forward) / input frames per workgroup (backward-data)
+constexpr int DW_KMAX = 128;       // taps cached in LDS
+
+// y[b,c,t] = sum_k w[c,k] * xm[b,c,t*s + k*d - p],  xm = x zeroed from len_in[b] on;  y zeroed from len_out[b] on when given.
+// One workgroup = one (clip, channel) row segment of DW_TILE outputs: the input span and the taps are staged in LDS once.
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const int* __restrict__ len_in,
                                                      const int* __restrict__ len_out, const float* __restrict__ w,
                                                      float* __restrict__ y, int batch, int ch, int t_in, int t_out, int k, int s,
                                                      int d, int p) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)batch * ch * t_out) return;
-  const int t = (int)(idx % t_out);
-  const int c = (int)((idx / t_out) % ch), b = (int)(idx / ((long long)t_out * ch));
+  extern __shared__ float sm[];
+  float* const ws = sm;                 // [k]
+  float* const xs = sm + DW_KMAX;       // [span]
+  const int row = blockIdx.y, b = row / ch, c = row % ch;
+  const int t0 = blockIdx.x * DW_TILE;
+  const int nt = t_out - t0 < DW_TILE ? t_out - t0 : DW_TILE;
+  const int i0 = t0 * s - p;
+  const int span = (nt - 1) * s + (k - 1) * d + 1;
   const int li = clamp_len(len_in, b, t_in);
-  const float* xr = x + ((size_t)b * ch + c) * t_in;
-  const float* wr = w + (size_t)c * k;
-  float acc = 0.f;
-  for (int j = 0; j < k; ++j) {
-    const int i = t * s + j * d - p;
-    if (i >= 0 && i < li) acc = fmaf(wr[j], xr[i], acc);
+  const float* xr = x + (size_t)row * t_in;
+  for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
+  for (int e = threadIdx.x; e < span; e += 256) {
+    const int i = i0 + e;
+    xs[e] = (i >= 0 && i < li) ? xr[i] : 0.f;
   }
-  if (len_out && t >= clamp_len(len_out, b, t_out)) acc = 0.f;
-  y[idx] = acc;
+  __syncthreads();
+  const int lo = len_out ? clamp_len(len_out, b, t_out) : t_out;
+  for (int tt = threadIdx.x; tt < nt; tt += 256) {
+    float acc = 0.f;
+    const float* xp = xs + tt * s;
+    for (int j = 0; j < k; ++j) acc = fmaf(ws[j], xp[j * d], acc);
+    y[(size_t)row * t_out + t0 + tt] = t0 + tt < lo ? acc : 0.f;
+  }
 }
 
 // dx[b,c,i] = (i < len_in) ? sum_k w[c,k] * dy[b,c,(i + p - k*d)/s] : 0    (terms with a non-integer or out-of-range index drop out)
+// One workgroup = DW_TILE input frames of one row; the dy span that can reach them is staged in LDS.
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const int* __restrict__ len_in,
                                                           const float* __restrict__ w, float* __restrict__ dx, int batch, int ch,
                                                           int t_in, int t_out, int k, int s, int d, int p) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)batch * ch * t_in) return;
-  const int i = (int)(idx % t_in);
-  const int c = (int)((idx / t_in) % ch), b = (int)(idx / ((long long)t_in * ch));
-  float acc = 0.f;
-  if (i < clamp_len(len_in, b, t_in)) {
-    const float* gr = dy + ((size_t)b * ch + c) * t_out;
-    const float* wr = w + (size_t)c * k;
-    for (int j = 0; j < k; ++j) {
-      const int n = i + p - j * d;
-      if (n >= 0 && n % s == 0 && n / s < t_out) acc = fmaf(wr[j], gr[n / s], acc);
+  extern __shared__ float sm[];
+  float* const ws = sm;
+  float* const gs = sm + DW_KMAX;
+  const int row = blockIdx.y, b = row / ch, c = row % ch;
+  const int i0 = blockIdx.x * DW_TILE;
+  const int ni = t_in - i0 < DW_TILE ? t_in - i0 : DW_TILE;
+  // n = i + p - j*d ranges over [i0 + p - (k-1)d, i0 + ni - 1 + p]; output frames n / s
+  const int n_lo = i0 + p - (k - 1) * d, n_hi = i0 + ni - 1 + p;
+  const int g0 = n_lo <= 0 ? 0 : (n_lo + s - 1) / s;
+  const int g1 = n_hi < 0 ? -1 : (n_hi / s < t_out - 1 ? n_hi / s : t_out - 1);
+  const float* gr = dy + (size_t)row * t_out;
+  for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
+  for (int e = threadIdx.x; e <= g1 - g0; e += 256) gs[e] = gr[g0 + e];
+  __syncthreads();
+  const int li = clamp_len(len_in, b, t_in);
+  for (int ii = threadIdx.x; ii < ni; ii += 256) {
+    const int i = i0 + ii;
+    float acc = 0.f;
+    if (i < li) {
+      if (s == 1) {                                  // every body layer: no divisions in the tap loop
+        for (int j = 0; j < k; ++j) {
+          const int q = i + p - j * d;
+          if (q >= g0 && q <= g1) acc = fmaf(ws[j], gs[q - g0], acc);
+        }
+      } else {
+        for (int j = 0; j < k; ++j) {
+          const int n = i + p - j * d;
+          if (n >= 0 && n % s == 0) {
+            const int q = n / s;
+            if (q >= g0 && q <= g1) acc = fmaf(ws[j], gs[q - g0], acc);
+          }
+        }
+      }
     }
+    dx[(size_t)row * t_in + i] = acc;
   }
-  dx[idx] = acc;
 }
 
-// dw[c,j] = sum_{b,t} dy[b,c,t] * xm[b,c,t*s + j*d - p]; one workgroup per (channel, tap)
+// dw[c,j] = sum_{b,t} dy[b,c,t] * xm[b,c,t*s + j*d - p].  One workgroup per channel: each clip's dy and x rows go through
+// LDS once, thread (tap j, slice q) accumulates its share of the frames, the slices are reduced at the end.
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const int* __restrict__ len_in, float* __restrict__ dw, int batch,
                                                             int ch, int t_in, int t_out, int k, int s, int d, int p) {
-  __shared__ double red[256];
-  const int c = blockIdx.x, j = blockIdx.y;
+  extern __shared__ float sm[];
+  float* const gs = sm;                       // [t_out]
+  float* const xs = sm + t_out;               // [t_in]
+  double* const red = reinterpret_cast<double*>(sm + round_up(t_out + t_in, 2));   // [256]
+  const int c = blockIdx.x;
+  const int kp = k <= 32 ? 32 : (k <= 64 ? 64 : 128);
+  const int j = threadIdx.x % kp, q = threadIdx.x / kp, nq = 256 / kp;
   double acc = 0.0;
-  for (int b = 0; b < batch; ++b) {
+  const int per = (batch + gridDim.y - 1) / gridDim.y;
+  const int b_lo = blockIdx.y * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
+  for (int b = b_lo; b < b_hi; ++b) {
     const int li = clamp_len(len_in, b, t_in);
-    const float* gr = dy + ((size_t)b * ch + c) * t_out;
-    const float* xr = x + ((size_t)b * ch + c) * t_in;
-    for (int t = threadIdx.x; t < t_out; t += 256) {
-      const int i = t * s + j * d - p;
-      if (i >= 0 && i < li) acc += (double)gr[t] * (double)xr[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < t_out; e += 256) gs[e] = dy[((size_t)b * ch + c) * t_out + e];
+    for (int e = threadIdx.x; e < t_in; e += 256) xs[e] = e < li ? x[((size_t)b * ch + c) * t_in + e] : 0.f;
+    __syncthreads();
+    if (j < k) {
+      float part = 0.f;
+      for (int t = q; t < t_out; t += nq) {
+        const int i = t * s + j * d - p;
+        if (i >= 0 && i < t_in) part = fmaf(gs[t], xs[i], part);
+      }
+      acc += (double)part;
     }
   }
+  __syncthreads();
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  if (q == 0 && j < k) {
+    double tot = 0.0;
+    for (int r = 0; r < nq; ++r) tot += red[r * kp + j];
+    atomicAdd(dw + (size_t)c * k + j, (float)tot);       // dw is zeroed by the launcher; clips are split over blockIdx.y
   }
-  if (threadIdx.x == 0) dw[(size_t)c * k + j] = (float)red[0];
 }
 
 // y = x with frames >= len[b] zeroed (the re-masking in front of every MaskedConv1d, and of gradients on the way back)
@@ -206,8 +257,11 @@ extern "C" int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const 
                                    void* stream_) {
   if (!x || !w || !y || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0 || stride <= 0 || dil <= 0) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(blocks((long long)batch * ch * t_out)), dim3(256), 0, stream, x, len_in, len_out, w, y, batch,
-                     ch, t_in, t_out, k, stride, dil, pad);
+  if (k > DW_KMAX) return TS_EUNSUPPORTED;
+  const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1) * sizeof(float);
+  if (lds > 64 * 1024) return TS_EUNSUPPORTED;
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3((t_out + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds, stream, x, len_in, len_out, w, y,
+                     batch, ch, t_in, t_out, k, stride, dil, pad);
   return hip_status(hipGetLastError());
 }
 
@@ -216,9 +270,15 @@ extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_
                                    int32_t pad, void* stream_) {
   if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3(blocks((long long)batch * ch * t_in)), dim3(256), 0, stream, dy, len_in, w, dx, batch, ch,
-                     t_in, t_out, k, stride, dil, pad);
-  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(ch, k), dim3(256), 0, stream, dy, x, len_in, dw, batch, ch, t_in, t_out, k, stride, dil, pad);
+  if (k > DW_KMAX) return TS_EUNSUPPORTED;
+  const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2) * sizeof(float);
+  const size_t lds_w = (size_t)round_up(t_out + t_in, 2) * sizeof(float) + 256 * sizeof(double);
+  if (lds_d > 64 * 1024 || lds_w > 64 * 1024) return TS_EUNSUPPORTED;
+  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3((t_in + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds_d, stream, dy, len_in, w, dx,
+                     batch, ch, t_in, t_out, k, stride, dil, pad);
+  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)ch * k, stream) != hipSuccess) return TS_EUNSUPPORTED;
+  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(ch, batch < 8 ? batch : 8), dim3(256), lds_w, stream, dy, x, len_in, dw, batch, ch, t_in,
+                     t_out, k, stride, dil, pad);
   return hip_status(hipGetLastError());
 }
 

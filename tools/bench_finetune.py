@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0, help="default: 32 per rank")
     ap.add_argument("--seconds", type=int, default=10)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--unfreeze", action="store_true", help="phase 2: encoder trainable (training-mode kernels, full backward)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -33,9 +34,10 @@ def main():
     variance_preserving_init_(m.encoder, m.decoder, seed=0)
     m = m.to(dev)
     m.train()
-    m.encoder.eval()
-    for p in m.encoder.parameters():
-        p.requires_grad_(False)
+    if not args.unfreeze:
+        m.encoder.eval()
+        for p in m.encoder.parameters():
+            p.requires_grad_(False)
     trainable = [p for p in m.parameters() if p.requires_grad]
     opt = FusedAdamW(trainable, lr=1e-3)
     B = (args.global_batch // world) if args.global_batch else 32
@@ -61,7 +63,7 @@ def main():
     torch.cuda.synchronize()
     dt = max_over_ranks((time.perf_counter() - t0) / args.steps, dev)
     if rank == 0:
-        print(f"C4 phase 1 (frozen encoder), {world} GPU(s), local batch {B} x {args.seconds} s: {dt * 1e3:.2f} ms/step, "
+        print(f"C4 phase {2 if args.unfreeze else 1} ({'encoder unfrozen' if args.unfreeze else 'frozen encoder'}), {world} GPU(s), local batch {B} x {args.seconds} s: {dt * 1e3:.2f} ms/step, "
               f"{1 / dt:.1f} step/s, {world * B * args.seconds / dt:,.0f} audio-s/s, loss {float(loss.detach()):.3f}")
     if world > 1:
         dist.destroy_process_group()
