@@ -6,18 +6,16 @@
 // Replaces the reference's per-sub-block ATen chain (quartznet/blocks.py:166-182 masked_fill + conv1d
 // (groups=C) + masked_fill + conv1d(k=1), :222 batch_norm, :332-337 residual add + relu).
 //
-// Design (see DESIGN.md "TCS kernel"):
+// Three kernels live in this file, newest last (DESIGN.md section 3.1 has the measurements behind each step):
+//   tcs_kernel        first design and generic fallback: 4 producer + 4 consumer waves, 64/128-frame tiles, masked
+//                     producers for caller tensors; still runs the stride-2 stem, the dilated layer and the fp32 decoder.
+//   tcs_pipe_kernel   all 8 waves accumulate, 96/192-frame tiles, both jobs software-pipelined in one instruction stream,
+//                     raw buffer loads, tap fragments by DMA into LDS.  Kept behind TS_NO_SPLIT=1.
+//   tcs_split_kernel  12 waves = 8 pointwise consumers + 4 depthwise producers on the same tiles: the default for every
+//                     depthwise / pointwise-only layer with tail-zero tensors.
+// Common to all of them:
 //  * layout NCT-p: bf16 [B][C][Tp], time contiguous.  A tile = TT output frames x CO_WG output channels of one
-//    clip; the input channels are walked in stages of 64.
-//  * PERSISTENT workgroups (one per CU) stride over the tiles; the stage stream runs on across tile
-//    boundaries, so the first loads of the next tile and the epilogue of the previous one overlap.
-//  * 8 waves with fixed roles.  Waves 4-7 are PRODUCERS: each stages 16 input channels of the stage
-//    (global -> registers, one stage ahead -> wave-private LDS rows), runs the depthwise FIR and writes the
-//    bf16 result tile dwt[stage & 1].  Waves 0-3 are CONSUMERS: they hold the fp32 accumulators and, one
-//    stage behind the producers, run the pointwise GEMM out of dwt.  One s_barrier per stage.
-//  * a lone wave issues a VALU instruction only every ~8 cycles on this chip, so the steady state is kept
-//    almost VALU-free: interior tiles (no length mask, no tensor edge) take a fast path without predicates,
-//    all LDS addresses are loop-invariant, the epilogue works on packed pairs.
+//    clip; the input channels are walked in stages of 64; PERSISTENT workgroups (one per CU) stride over the tiles.
 //  * depthwise FIR on the matrix cores: v_mfma_f32_4x4x4_16b_bf16 computes 16 independent 4x4x4
 //    products per instruction -- one block per channel.  For channel c the A block is a 4x4 slice of the
 //    Toeplitz matrix of its taps (rows = 4 consecutive output frames; pre-shifted per row on the host),
@@ -25,10 +23,10 @@
 //    input window in registers.  4.1x the fp32-VALU FMA rate measured on MI355X (240 vs 58 TMAC/s).
 //  * the depthwise result is stored [ci][t] (XOR-swizzled 16-B chunks) and consumed as the A operand of
 //    v_mfma_f32_32x32x16_bf16 through ds_read_b64_tr_b16 (hardware transpose read); the B operand
-//    (BN-folded pointwise weights) is pre-packed per lane on the host and streamed from L2 through a
-//    4-deep register ring.
-//  * residual 1x1 conv = extra stages over the block input whose "depthwise" is a masked copy,
-//    accumulating into the same registers; bias + ReLU + bf16 pack in the epilogue.
+//    (BN-folded pointwise weights) is pre-packed per lane on the host and streamed from L2 through a register ring.
+//  * residual 1x1 conv = extra stages over the block input whose "depthwise" is a copy, accumulating into the same
+//    registers; bias = initial accumulator value; ReLU + bf16 pack in the epilogue.
+//  * a lone wave issues an instruction only every ~8 cycles on this chip, so the steady state is kept almost VALU-free.
 #include "ts_common.hpp"
 
 #include <cstdlib>
