@@ -191,7 +191,7 @@ def main():
                                "greedy decode (argmax + collapse), hipGraph replay" if not args.no_graph else
                                f"QuartzNet15x5 inference, batch {B}x{S} s per GPU (eager launches)",
                    "batch_per_gpu": B, "clip_seconds": S, "random_init": True},
-        "roofline": {"bound": "hbm", "kernel": "ts::tcs_pipe_kernel / ts::tcs_kernel (all fused TCS launches of one step)",
+        "roofline": {"bound": "hbm", "kernel": "ts::tcs_split_kernel / ts::tcs_kernel (all fused TCS launches of one step)",
                      "launches_per_step": n_launch,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(B, S),

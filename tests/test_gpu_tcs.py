@@ -162,3 +162,27 @@ def test_back_to_back_launches_never_use_the_next_stages_taps(k):
         y, _ = layer.run(xb, t, li, out=out, in_tail_zero=True, zero_tail=True)
         err = float((y[:, :, :t].float().cpu() - ref).abs().max())
         assert err <= 0.012 * scale, f"launch {it}: max err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("cin,cout,t,lens", [(512, 1024, 751, [751, 400, 9]), (128, 256, 300, [300, 150])])
+def test_pointwise_only_tail_zero_input_keeps_reference_values_beyond_length(cin, cout, t, lens):
+    """The encoder's last block is caller-visible: its output is NOT tail-zeroed (quirk A2: predict() decodes all frames),
+    but its input is -- the mask-free kernel must still reproduce the reference on every frame."""
+    from thunder_speech_amd import plan, tensors as TS
+    spec = otcs.BlockSpec(cin, cout, repeat=1, kernel=1, stride=1, dilation=1, residual=False, separable=False)
+    sd = {key[2:]: v for key, v in otcs.synth_encoder_state([spec], seed=5).items()}
+    g = torch.Generator().manual_seed(5)
+    x = bf16_round(torch.randn(len(lens), cin, t, generator=g))
+    lengths = torch.tensor(lens)
+    ref, _ = otcs.block_forward(spec, sd, "", x, lengths, emulate_bf16=True)
+    bn = [sd["mconv.1.layer.0." + n] for n in ("weight", "bias", "running_mean", "running_var")]
+    layer = plan.make_tcs_layer("cuda", dw_w=None, pw_w=sd["mconv.0.conv.weight"], bn=bn, kernel=1, stride=1, dilation=1,
+                                padding=0, relu=True)
+    li = lengths.to(torch.int32).cuda()
+    xb = TS.backing(TS.pack(x.cuda(), li, slot=("pwtz", cin)))
+    y, t_out = layer.run(xb, t, li, in_tail_zero=True, zero_tail=False)
+    torch.cuda.synchronize()
+    got = y[:, :, :t_out].float().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= 0.012 * scale
+    assert float(got[1, :, lens[1]:].abs().max()) > 0          # relu(shift) beyond the length, as in the reference

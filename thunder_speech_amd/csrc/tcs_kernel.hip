@@ -75,6 +75,7 @@ struct TcsArgs {
   int taps_lds;                // 1: taps of the stage are cached in LDS
   int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
   int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
+  int xcd;                     // split kernel: 1 = XCD-contiguous tile order (grid is a multiple of 8)
   int privb;                   // pipelined kernel: bytes of a wave's private LDS region
 #ifdef TS_STAMP
   long long* dbg;              // diagnostic build only: s_memtime stamps of one workgroup
@@ -1295,7 +1296,16 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   const int n_main = a.c_in / KC;
   const int n_res = a.c_res / KC;
   const int n_stage = n_main + n_res;
-  const int tile_step = gridDim.x;
+  // XCD-aware tile order: workgroup i runs on XCD i % 8, and each XCD has its own L2.  Give every XCD one
+  // contiguous range of tiles so that the input halos neighbouring time tiles share are fetched into ONE L2.
+  int tile0 = blockIdx.x, tile_step = gridDim.x, tile_end = a.n_tiles;
+  if (a.xcd) {
+    const int per = (a.n_tiles + 7) >> 3, xcd = blockIdx.x & 7;
+    tile0 = xcd * per + (blockIdx.x >> 3);
+    tile_step = gridDim.x >> 3;
+    tile_end = min(a.n_tiles, (xcd + 1) * per);
+    if (tile0 >= tile_end) return;
+  }
   auto taddr = [](int c, int t) { return c * ROWB + ((((t >> 3) ^ ((c & 3) * 5))) << 4) + ((t & 7) << 1); };
   constexpr int RSRC_FLAGS = 0x00020000;
   auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
@@ -1329,8 +1339,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 
     u32x4 X[XP];
     TilePos dwp;
-    dwp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-    int dw_tile = blockIdx.x, dw_chunk = 0;
+    dwp.init(tile0, tile_step, a.n_tt, a.n_z);
+    int dw_tile = tile0, dw_chunk = 0;
     auto x_origin = [&](const TilePos& p) { return (p.b * a.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
     int x_soff = x_origin(dwp);
     auto dw_issue = [&]() {
@@ -1338,7 +1348,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       for (int j = 0; j < XP; ++j) X[j] = ld16(rx, lane_x + j * 64, x_soff);
       if (++dw_chunk == n_main) {
         dw_chunk = 0;
-        if (dw_tile + tile_step < a.n_tiles) { dw_tile += tile_step; dwp.advance(a.n_tt, a.n_z); }
+        if (dw_tile + tile_step < tile_end) { dw_tile += tile_step; dwp.advance(a.n_tt, a.n_z); }
         x_soff = x_origin(dwp);
       } else {
         x_soff += chunk_x;
@@ -1349,18 +1359,18 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       lds_dma16(rt, tapl + h * 1024, lane_t, soff + h * 1024, after);
     };
     auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
-    u32x4 I[IDP];
+    u32x4 I[IDP], I2[IDP];                          // identity rows in flight: one stage ahead (two when n_res is even)
     TilePos idp;
-    idp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-    int id_tile = blockIdx.x, id_s = 0;
+    idp.init(tile0, tile_step, a.n_tt, a.n_z);
+    int id_tile = tile0, id_s = 0;
     auto i_origin = [&](const TilePos& p) { return (p.b * a.c_res * a.pitch_res + p.tt * TT) * 2; };
     int i_soff = i_origin(idp);
-    auto id_issue = [&]() {
+    auto id_issue = [&](u32x4 (&I)[IDP]) {
 #pragma unroll
       for (int j = 0; j < IDP; ++j) I[j] = ld16(ri, lane_i + j * 64, i_soff);
       if (++id_s == n_res) {
         id_s = 0;
-        if (id_tile + tile_step < a.n_tiles) { id_tile += tile_step; idp.advance(a.n_tt, a.n_z); }
+        if (id_tile + tile_step < tile_end) { id_tile += tile_step; idp.advance(a.n_tt, a.n_z); }
         i_soff = i_origin(idp);
       } else {
         i_soff += chunk_i;
@@ -1414,9 +1424,22 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #pragma unroll
       for (int h = 0; h < NKH; ++h) tap_dma(h, 0);
     }
-    if (n_res) id_issue();
+    // Identity rows are fetched TWO stages ahead when the stage count is even (register sets alternate, statically):
+    // an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
+    const bool id2 = WM == 1 && n_res && !(n_res & 1);      // (the 192-frame tiles have no registers to spare for a second set)
+    if (n_res) id_issue(I);
+    if (id2) id_issue(I2);
     vm_wait<0>();
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
+    auto id_stage = [&](u32x4 (&R)[IDP], bool drain) {
+      char* const dst = dwt + (gs & 1) * TILEB;
+      if (drain) vm_wait<0>(); else vm_wait<IDP>();
+#pragma unroll
+      for (int j = 0; j < IDP; ++j) *reinterpret_cast<u32x4*>(dst + (id_out ^ (j << 6))) = R[j];
+      id_issue(R);
+      stage_barrier();
+      ++gs;
+    };
+    for (int tile = tile0; tile < tile_end; tile += tile_step) {
       for (int s = 0; s < n_main; ++s, ++gs) {
         char* const dst = dwt + (gs & 1) * TILEB;
         // Everything this wave has in flight is a stage old except the last tap DMAs: drain it all.  (Measured: DMA-to-LDS
@@ -1436,13 +1459,15 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #endif
         stage_barrier();
       }
-      for (int s = 0; s < n_res; ++s, ++gs) {
-        char* const dst = dwt + (gs & 1) * TILEB;
-        vm_wait<0>();
-#pragma unroll
-        for (int j = 0; j < IDP; ++j) *reinterpret_cast<u32x4*>(dst + (id_out ^ (j << 6))) = I[j];
-        id_issue();
-        stage_barrier();
+      if (id2) {
+        // a tile that had depthwise stages drains once (tap DMAs and row loads are in the queue: counted waits cannot
+        // separate them); after that only identity loads are in flight and they retire in order
+        for (int s = 0; s < n_res; s += 2) {
+          id_stage(I, s == 0 && n_main != 0);
+          id_stage(I2, false);
+        }
+      } else {
+        for (int s = 0; s < n_res; ++s) id_stage(I, true);
       }
     }
     vm_wait<0>();                                    // no tap DMA may still be heading for this workgroup's LDS when it is released
@@ -1470,8 +1495,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   constexpr int RING = TS_SPLIT_RING;             // weight-fragment ring depth in k-steps (4 = a whole stage ahead)
   s16x8 ring[RING][NT];
   TilePos wp;
-  wp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-  int w_tile = blockIdx.x, w_s = 0;
+  wp.init(tile0, tile_step, a.n_tt, a.n_z);
+  int w_tile = tile0, w_s = 0;
   __amdgpu_buffer_rsrc_t rwc = rwm, rwn = rwm;
   int wc_soff[NT], wn_soff[NT];
   auto w_seek = [&](bool res) {
@@ -1490,7 +1515,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     ++w_s;
     if (w_s == n_stage) {
       w_s = 0;
-      if (w_tile + tile_step < a.n_tiles) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
+      if (w_tile + tile_step < tile_end) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
       w_seek(n_main == 0);
     } else if (w_s == n_main) {
       w_seek(true);
@@ -1532,14 +1557,14 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   };
 
   TilePos pos;
-  pos.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
+  pos.init(tile0, tile_step, a.n_tt, a.n_z);
   w_seek(n_main == 0);
   w_advance();
 #pragma unroll
   for (int r = 0; r < RING; ++r) load_w(ring[r], false, r);
   bias_fetch(pos);
   stage_barrier();                                   // stage 0 is in dwt[0]
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
+  for (int tile = tile0; tile < tile_end; tile += tile_step) {
     const int b = pos.b, t0 = pos.tt * TT;
     const int cot0 = (pos.z * WN + wn) * NT;
     const int len_b = a.zero_tail ? a.len_in[b] : 0;
@@ -1583,7 +1608,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       stage_barrier();
     }
     // ---- epilogue (the producers are already on the next tile)
-    pos.advance_if(tile + tile_step < a.n_tiles, a.n_tt, a.n_z);
+    pos.advance_if(tile + tile_step < tile_end, a.n_tt, a.n_z);
     bias_fetch(pos);
     unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
     int len_out = 0x7fffffff;
@@ -1653,6 +1678,8 @@ static int launch_split(TcsArgs& a, hipStream_t stream) {
   if (e != hipSuccess) return (int)e;
   const int n_cu = cu_count();
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+  static const bool no_xcd = getenv("TS_NO_XCD") != nullptr;
+  a.xcd = (grid % 8 == 0 && !no_xcd) ? 1 : 0;
   (void)hipGetLastError();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, a);
   return hip_status(hipGetLastError());
@@ -1790,7 +1817,10 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     return launch<128, 2, 1, false, true>(a, stream);
   }
   if (d->stride == 1) {
-    if (tz && d->c_res == 0 && getenv("TS_NO_SPLIT") == nullptr) {
+    // without a depthwise stage a tail-zero input needs no mask whether or not the output tail is zeroed: frames >= length
+    // come out as relu(shift), which is what the reference computes from its masked input (quirk A2)
+    const bool tz_in = (d->flags & TS_TCS_IN_TAILZERO) && d->c_in % KC == 0;
+    if (tz_in && d->c_res == 0 && getenv("TS_NO_SPLIT") == nullptr) {
       // pointwise only: the split kernel with identity stages only (the layer's input plays the residual input's role)
       TcsArgs w = a;
       const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;
