@@ -70,9 +70,14 @@ typedef struct ts_tcs_desc {
  *   pitch >= ts_time_pitch(T) (which includes the slack the tiles over-read), and >= TS_GUARD_BYTES of zeros sit
  *   before the first and after the last row of the buffer.  Lets the kernel skip every mask and bounds check.
  * TS_TCS_OUT_ZERO_TAIL : store 0 for frames >= the output length, so that y satisfies the invariant for the next
- *   launch (the reference leaves relu(bias) there, quirk A2; use 0 only for outputs the caller never exposes). */
+ *   launch (the reference leaves relu(bias) there, quirk A2; use 0 only for outputs the caller never exposes).
+ * TS_TCS_TAPS_PHASE : dilation-2 layers only (stride 1, even padding, both flags above set): dw_taps / dw_ksteps are packed
+ *   for the phase-split form -- the even and the odd frames of a row are filtered as two dilation-1 sequences -- i.e. as
+ *   for (kernel, stride 1, dilation 1, padding / 2).  TS_EUNSUPPORTED when the geometry has no phase-split kernel: launch
+ *   again with the plain dilation-2 fragments. */
 #define TS_TCS_IN_TAILZERO 1
 #define TS_TCS_OUT_ZERO_TAIL 2
+#define TS_TCS_TAPS_PHASE 4
 #define TS_GUARD_BYTES 1024
 
 /* x: bf16 [B][c_in][pitch_in]; len_in: int32 [B] valid frames of x (frames >= len are treated as 0,

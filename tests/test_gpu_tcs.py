@@ -120,7 +120,9 @@ def _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, residual, seed=0):
     (512, 512, 75, 1, 1, 200, [200, 1], True),
     (512, 512, 63, 1, 1, 751, [751, 640], False),
     (64, 256, 33, 2, 1, 1501, [1501, 1000], False),
-    (512, 512, 87, 1, 2, 260, [260, 129], False),
+    (512, 512, 87, 1, 2, 260, [260, 129], False),      # dilation 2: phase-split kernel (even / odd frames)
+    (512, 512, 87, 1, 2, 751, [751, 750, 377, 2], False),
+    (64, 512, 87, 1, 2, 97, [97, 96, 1], False),
     (64, 64, 5, 1, 1, 128, [128, 100], False),
     (320, 384, 11, 1, 1, 251, [251, 97], False),        # Citrinet kernel sizes: 2 / 3 / 4 passes, 96-frame tiles
     (384, 640, 25, 1, 1, 200, [200, 155], False),
@@ -140,20 +142,22 @@ def test_padding_region_never_leaks():
     assert torch.equal(got1, got2)
 
 
-@pytest.mark.parametrize("k", [63, 75, 39])
+@pytest.mark.parametrize("k", [63, 75, 39, 87])
 def test_back_to_back_launches_never_use_the_next_stages_taps(k):
     """Regression: with the tap fragments L2-hot (the same layer launched again and again) a tap DMA that refills a slot
     for the NEXT stage used to be able to land before the running stage had read the slot.  Identity pointwise, distinct
     taps per channel: any stage that sees another stage's taps is off by O(1)."""
     from thunder_speech_amd import plan, tensors as TS
     c, t, b = 512 if k != 39 else 256, 751, 2
+    dil = 2 if k == 87 else 1                          # K87 is QuartzNet's dilation-2 layer (phase-split kernel)
+    pad = dil * (k - 1) // 2
     g = torch.Generator().manual_seed(k)
     dw = bf16_round(torch.randn(c, 1, k, generator=g) * 0.2)
     bn = [torch.ones(c), torch.zeros(c), torch.zeros(c), torch.ones(c) - 1e-3]      # scale 1, shift 0 after folding
     layer = plan.make_tcs_layer("cuda", dw_w=dw, pw_w=torch.eye(c).reshape(c, c, 1), bn=bn, kernel=k, stride=1,
-                                dilation=1, padding=k // 2, relu=False)
+                                dilation=dil, padding=pad, relu=False)
     x = bf16_round(torch.randn(b, c, t, generator=g))
-    ref = torch.nn.functional.conv1d(x.double(), dw.double(), padding=k // 2, groups=c).float()
+    ref = torch.nn.functional.conv1d(x.double(), dw.double(), padding=pad, dilation=dil, groups=c).float()
     li = torch.full((b,), t, dtype=torch.int32, device="cuda")
     xb = TS.backing(TS.pack(x.cuda(), li, slot=("b2b", k)))
     out = TS.arena(("b2bo", k), b, c, t, "cuda")

@@ -15,6 +15,8 @@ _lib: Optional[C.CDLL] = None
 ABI_VERSION = 2
 TCS_IN_TAILZERO = 1
 TCS_OUT_ZERO_TAIL = 2
+TCS_TAPS_PHASE = 4
+TS_EUNSUPPORTED = -2
 GUARD_BYTES = 1024
 
 EXPORTED_SYMBOLS = [

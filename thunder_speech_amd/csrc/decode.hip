@@ -6,23 +6,33 @@
 
 namespace ts {
 
-// one workgroup per clip; frames are processed in chunks of 256 with a running output offset
-__global__ __launch_bounds__(256) void greedy_kernel(const float* __restrict__ logits, int n_classes, int n_frames, int pitch,
+// one workgroup per clip; frames are processed in chunks of 1024 (one chunk covers a 20 s clip at the encoder's frame
+// rate, so the class loop's loads are all in flight at once) with a running output offset
+constexpr int GTH = 1024, GW = GTH / 64;
+__global__ __launch_bounds__(GTH) void greedy_kernel(const float* __restrict__ logits, int n_classes, int n_frames, int pitch,
                                                      int* __restrict__ ids, int* __restrict__ collapsed,
                                                      int* __restrict__ counts) {
-  __shared__ int wave_sum[4];
+  __shared__ int wave_sum[GW];
   __shared__ int carry_s;
   __shared__ int last_id_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* base = logits + (size_t)b * n_classes * pitch;
   if (tid == 0) { carry_s = 0; last_id_s = -1; }
   __syncthreads();
-  for (int t0 = 0; t0 < n_frames; t0 += 256) {
+  for (int t0 = 0; t0 < n_frames; t0 += GTH) {
     const int t = t0 + tid;
     int best = 0;
     if (t < n_frames) {
       float bv = base[t];
-      for (int v = 1; v < n_classes; ++v) {          // coalesced over t; lowest index wins ties
+      int v = 1;
+      for (; v + 8 <= n_classes; v += 8) {           // coalesced over t; lowest index wins ties; 8 loads in flight
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = base[(size_t)(v + j) * pitch + t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (x[j] > bv) { bv = x[j]; best = v + j; }
+      }
+      for (; v < n_classes; ++v) {
         const float x = base[(size_t)v * pitch + t];
         if (x > bv) { bv = x; best = v; }
       }
@@ -30,7 +40,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(const float* __restrict__ l
     }
     // previous frame's id: neighbour lane, or the last id of the previous chunk
     int prev = __shfl_up(best, 1);
-    __shared__ int edge[4];
+    __shared__ int edge[GW];
     if (lane == 63) edge[wave] = best;
     __syncthreads();
     if (lane == 0) prev = wave == 0 ? last_id_s : edge[wave - 1];
@@ -44,9 +54,9 @@ __global__ __launch_bounds__(256) void greedy_kernel(const float* __restrict__ l
     for (int w = 0; w < wave; ++w) off += wave_sum[w];
     if (keep) collapsed[(size_t)b * n_frames + off + before] = best;
     __syncthreads();
-    if (tid == 255) {
+    if (tid == GTH - 1) {
       carry_s = off + before + keep;
-      last_id_s = (t0 + 255 < n_frames) ? best : last_id_s;
+      last_id_s = (t0 + GTH - 1 < n_frames) ? best : last_id_s;
     }
     __syncthreads();
   }
@@ -60,7 +70,7 @@ extern "C" int ts_greedy_decode(const float* logits, int32_t batch, int32_t n_cl
   if (!logits || !ids || !collapsed || !counts) return TS_EINVAL;
   if (batch <= 0 || n_classes <= 0 || n_frames <= 0 || pitch < n_frames) return TS_EINVAL;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ts::greedy_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, logits, n_classes, n_frames,
+  hipLaunchKernelGGL(ts::greedy_kernel, dim3(batch), dim3(ts::GTH), 0, (hipStream_t)stream, logits, n_classes, n_frames,
                      pitch, ids, collapsed, counts);
   return ts::hip_status(hipGetLastError());
 }

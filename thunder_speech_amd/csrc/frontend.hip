@@ -231,12 +231,27 @@ __global__ __launch_bounds__(256) void normalize_kernel(const NormArgs a) {
   const int f0 = blockIdx.x * NTF;
   const int flen = a.feat_len[b] < a.n_frames ? a.feat_len[b] : a.n_frames;
 
-  for (int m = tid; m < a.n_mels; m += 256) {
+  // statistics: 4 interleaved slices of the per-workgroup partial sums per mel row (all 256 threads busy), combined in a
+  // fixed order -> deterministic; the slice sums borrow the transpose tile before it is filled
+  constexpr int NSL = 4;
+  double* const slice = reinterpret_cast<double*>(tile);        // [NSL][n_mels][2]
+  for (int idx = tid; idx < NSL * a.n_mels; idx += 256) {
+    const int sl = idx / a.n_mels, m = idx - sl * a.n_mels;
     double s1 = 0.0, s2 = 0.0;
     const float* p = a.partial + ((size_t)b * a.nwg * a.n_mels + m) * 2;
-    for (int w = 0; w < a.nwg; ++w) {
+    for (int w = sl; w < a.nwg; w += NSL) {
       s1 += (double)p[(size_t)w * a.n_mels * 2];
       s2 += (double)p[(size_t)w * a.n_mels * 2 + 1];
+    }
+    slice[idx * 2] = s1;
+    slice[idx * 2 + 1] = s2;
+  }
+  __syncthreads();
+  for (int m = tid; m < a.n_mels; m += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int sl = 0; sl < NSL; ++sl) {
+      s1 += slice[(sl * a.n_mels + m) * 2];
+      s2 += slice[(sl * a.n_mels + m) * 2 + 1];
     }
     const double n = (double)flen;
     const double mu = s1 / n;
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(const NormArgs a) {
     mean[m] = (float)mu;
     rstd[m] = (float)(1.0 / (sqrt(var) + 1e-5));
   }
+  __syncthreads();
   const int ld = a.n_mels + 1;
   for (int idx = tid; idx < NTF * a.n_mels; idx += 256) {
     const int q = idx / a.n_mels, m = idx - q * a.n_mels;

@@ -1269,7 +1269,11 @@ struct ProdSched {
   constexpr int last_pass(int h) const { return ((2 * h + 1 < nk ? 2 * h + 1 : nk - 1)) / 3; }
 };
 
-template <int NPASS, int XJ, int MT, int WM>
+// DIL == 2 (dilation-2 layers, K87 of QuartzNet): the even and the odd frames of a row are two independent dilation-1
+// sequences (y[2s+p] = sum_u w[u] x[2(s+u)+p - pad], pad even).  The producers stage each row as [even | odd] halves,
+// lane runs 0,1 filter the even half and 2,3 the odd half with dilation-1 tap fragments (no zero-stuffed Toeplitz rows:
+// 24 k-steps instead of 45), and lane pairs re-interleave their results on the way into the dw tile.
+template <int NPASS, int XJ, int MT, int WM, int DIL = 1>
 __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   constexpr int WN = 8 / WM, NT = 2;
   constexpr int FW = 32 * MT;
@@ -1284,7 +1288,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   constexpr int IDP = (2 * TT + 63) / 64;         // identity rows: 16 rows x 2*TT bytes
   constexpr int NKH = (NK + 1) / 2;               // tap fragments travel in pairs of k-steps (1 KiB per wave)
   constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
-  constexpr int ER = WM == 2 ? 16 : 32;           // output-channel rows of a consumer's epilogue tile
+  constexpr int ER = (WM == 2 || DIL == 2) ? 16 : 32;   // output-channel rows of a consumer's epilogue tile
+  constexpr int PHW = 32 * XJ;                    // DIL == 2: frames of a staged half row
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const dwt = smem;                                             // [2][KC][ROWB]
@@ -1323,12 +1328,14 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
     const int row = lane >> 2, sub = lane & 3;     // staging: row of the wave's 16 channels, 16-byte group sub + 4j
     const int q = lane & 3;                        // depthwise: channel = row, time run q
-    char* const xw = xs + ((size_t)row * xpitch + sub * 8) * 2;
-    const char* const xrow = xs + ((size_t)row * xpitch + a.woff + q * RUN) * 2;
+    char* const xw = xs + ((size_t)row * xpitch + sub * (DIL == 2 ? 4 : 8)) * 2;
+    const char* const xrow = DIL == 2 ? xs + ((size_t)row * xpitch + (q >> 1) * PHW + a.woff + (q & 1) * RUN) * 2
+                                      : xs + ((size_t)row * xpitch + a.woff + q * RUN) * 2;
     const char* const trow = tapl + lane * 8;      // fragment of (k, lane) at k * 512 + lane * 8
     int dw_out[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) dw_out[m] = taddr(pw * 16 + row, q * RUN + 4 * m);
+    for (int m = 0; m < M; ++m)
+      dw_out[m] = DIL == 2 ? taddr(pw * 16 + row, (q & 1) * 2 * RUN + 8 * m + 4 * (q >> 1)) : taddr(pw * 16 + row, q * RUN + 4 * m);
     const int lane_x = ((pw * 16 + row) * a.pitch_in + sub * 8) * 2;
     const int lane_t = pw * NK * 512 + lane * 16;  // [chunk][16-ch group][k][64 lanes][4]: a pair of k-steps is 1 KiB contiguous
     const int lane_i = ((pw * 16 + row) * a.pitch_res + sub * 8) * 2;
@@ -1385,9 +1392,16 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     auto xs_write = [&]() {
 #pragma unroll
       for (int j = 0; j < XP; ++j) {
-        u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 64);
-        d2[0] = u32x2{X[j][0], X[j][1]};
-        d2[1] = u32x2{X[j][2], X[j][3]};
+        if constexpr (DIL == 2) {     // 8 frames -> 4 even + 4 odd (the staged span starts on an even frame)
+          *reinterpret_cast<u32x2*>(xw + j * 32) = u32x2{__builtin_amdgcn_perm(X[j][1], X[j][0], 0x05040100u),
+                                                         __builtin_amdgcn_perm(X[j][3], X[j][2], 0x05040100u)};
+          *reinterpret_cast<u32x2*>(xw + j * 32 + PHW * 2) = u32x2{__builtin_amdgcn_perm(X[j][1], X[j][0], 0x07060302u),
+                                                                   __builtin_amdgcn_perm(X[j][3], X[j][2], 0x07060302u)};
+        } else {
+          u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 64);
+          d2[0] = u32x2{X[j][0], X[j][1]};
+          d2[1] = u32x2{X[j][2], X[j][3]};
+        }
       }
     };
     auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
@@ -1453,8 +1467,20 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-          *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+        for (int m = 0; m < M; ++m) {
+          const unsigned m0 = pack_bf16(d[m][0], d[m][1]), m1 = pack_bf16(d[m][2], d[m][3]);
+          if constexpr (DIL == 2) {
+            // lanes q and q ^ 2 hold the even and the odd frames of the same 8-frame group: the even lane stores frames
+            // 0..3 (e0 o0 e1 o1), the odd lane frames 4..7 (e2 o2 e3 o3)
+            const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m0, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+            const unsigned t1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m1, 0x4E, 0xf, 0xf, true);
+            const bool odd = (q >> 1) != 0;
+            const unsigned ev = odd ? t1 : m0, od = odd ? m1 : t0;
+            *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{__builtin_amdgcn_perm(od, ev, 0x05040100u), __builtin_amdgcn_perm(od, ev, 0x07060302u)};
+          } else {
+            *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{m0, m1};
+          }
+        }
         tap_advance();
 #endif
         stage_barrier();
@@ -1663,7 +1689,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   }
 }
 
-template <int NPASS, int XJ, int MT, int WM>
+template <int NPASS, int XJ, int MT, int WM, int DIL = 1>
 static int launch_split(TcsArgs& a, hipStream_t stream) {
   constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);
   constexpr int ROWB = TT <= 128 ? 256 : 512;
@@ -1671,9 +1697,9 @@ static int launch_split(TcsArgs& a, hipStream_t stream) {
   a.n_tt = (a.t_out + TT - 1) / TT;
   a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
   a.n_tiles = a.batch * a.n_tt * a.n_z;
-  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * (WM == 2 ? 16 : 32) * (FW * 2 + 24) + (size_t)4 * (16 * (64 * XJ + 4) * 2 + NKH * 1024);
+  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) + (size_t)4 * (16 * (64 * XJ + 4) * 2 + NKH * 1024);
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = tcs_split_kernel<NPASS, XJ, MT, WM>;
+  auto kern = tcs_split_kernel<NPASS, XJ, MT, WM, DIL>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int n_cu = cu_count();
@@ -1759,6 +1785,20 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
             (d->c_res == 0 || (d->c_res % KC == 0 && a.res_stride == 1 && d->pitch_res >= n_tt * TT));
   if (d->depthwise) {
     a.npass = d->dw_ksteps / NKP;
+    if (d->flags & TS_TCS_TAPS_PHASE) {
+      // dilation 2 as two interleaved dilation-1 sequences; dw_taps are packed for (K, stride 1, dilation 1, padding / 2)
+      const bool ok = (d->flags & TS_TCS_IN_TAILZERO) && (d->flags & TS_TCS_OUT_ZERO_TAIL) && d->stride == 1 && d->dilation == 2 &&
+                      d->padding % 2 == 0 && d->c_in % KC == 0 && d->c_res == 0 && round_up(d->c_out, 32) > 256 &&
+                      getenv("TS_NO_SPLIT") == nullptr;
+      if (!ok) return TS_EUNSUPPORTED;
+      TcsArgs w = a;
+      w.padl8 = 2 * round_up(d->padding / 2, 4);      // frames staged before the tile: even, so staged parity == frame parity
+      w.woff = 0;
+      const int n_ttp = (d->t_out + 95) / 96;
+      const bool fits = a.npass == 8 && 24 + 4 * (5 + d->dw_ksteps) <= 160 && (n_ttp - 1) * 96 - w.padl8 + 320 <= d->pitch_in &&
+                        d->pitch_in - d->t_in >= w.padl8 && d->pitch_out >= n_ttp * 96;
+      return fits ? launch_split<8, 5, 3, 1, 2>(w, stream) : TS_EUNSUPPORTED;
+    }
     a.taps_lds = d->dw_ksteps <= NKMAX;
     const int padl4 = round_up(d->padding, 4);
     a.padl8 = round_up(padl4, 8);

@@ -111,6 +111,8 @@ class TcsLayer:
     res_w: Optional[torch.Tensor] = None
     res_stride: int = 1
     out_fp32: bool = False
+    taps_phase: Optional[torch.Tensor] = None      # dilation 2: the same taps packed for the phase-split kernel
+    nk_phase: int = 0
 
     def out_size(self, t_in: int) -> int:
         return conv_out_size(t_in, self.kernel, self.stride, self.padding, self.dilation)
@@ -146,9 +148,19 @@ class TcsLayer:
         d.pw_w = self.pw.data_ptr()
         d.bias = self.bias.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        st = L.ts_tcs_subblock_fwd(C.byref(d), x.data_ptr(), len_in.data_ptr(),
-                                   x_res.data_ptr() if self.c_res else None,
-                                   len_res.data_ptr() if self.c_res else None, out.data_ptr(), stream)
+        args = (x.data_ptr(), len_in.data_ptr(), x_res.data_ptr() if self.c_res else None,
+                len_res.data_ptr() if self.c_res else None, out.data_ptr(), stream)
+        if self.taps_phase is not None and in_tail_zero and zero_tail:
+            # dilation 2: offer the phase-split fragments first; the library declines geometries it has no such kernel for
+            d.flags |= _lib.TCS_TAPS_PHASE
+            d.dw_taps, d.dw_ksteps = self.taps_phase.data_ptr(), self.nk_phase
+            st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
+            if st != _lib.TS_EUNSUPPORTED:
+                _lib.check(st, "ts_tcs_subblock_fwd")
+                return out, t_out
+            d.flags &= ~_lib.TCS_TAPS_PHASE
+            d.dw_taps, d.dw_ksteps = self.taps.data_ptr(), self.nk
+        st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
         _lib.check(st, "ts_tcs_subblock_fwd")
         return out, t_out
 
@@ -178,6 +190,10 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
     taps, nk = (None, 0)
     if dw_w is not None:
         taps, nk = pack_dw_taps(cpu(dw_w), stride, dilation, padding)
+    taps_phase, nk_phase = None, 0
+    if dw_w is not None and stride == 1 and dilation == 2 and padding % 2 == 0 and res_w is None:
+        taps_phase, nk_phase = pack_dw_taps(cpu(dw_w), 1, 1, padding // 2)
+        taps_phase = tap_fragments(taps_phase).to(device)
     c_res, res_p = 0, None
     if res_w is not None:
         r2 = cpu(res_w).reshape(res_w.shape[0], res_w.shape[1])
@@ -188,4 +204,4 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
     return TcsLayer(c_in=cin, c_out=cout, kernel=kernel, stride=stride, dilation=dilation, padding=padding,
                     depthwise=dw_w is not None, relu=relu, taps=None if taps is None else tap_fragments(taps).to(device), nk=nk,
                     pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
-                    res_stride=res_stride, out_fp32=out_fp32)
+                    res_stride=res_stride, out_fp32=out_fp32, taps_phase=taps_phase, nk_phase=nk_phase)
