@@ -11,6 +11,9 @@
 // as a 256-point complex FFT of z[n] = x[2n] + i x[2n+1] by the four-step method (16 x 16): each lane runs
 // a 16-point FFT in registers, the 16 lanes of a frame exchange through a padded LDS transpose, second
 // 16-point FFT, then the real-FFT split, |X|^2, sparse triangular mel filters (CSR) and log.
+// Workgroups are persistent (3 per CU: 52 KB of LDS each): tables are built once, the samples of the next frame group
+// travel global -> registers while the current group is transformed.  The kernel is latency / barrier bound, not
+// VALU bound (packed fp32 math changed nothing; a third resident workgroup per CU did: 121 -> 99 us).
 // Kernel 2 (normalize_kernel): reduces the per-workgroup partial sums in fp64, normalises, masks frames
 // >= length, transposes [frame][mel] -> [mel][frame] through LDS and stores bf16 rows.
 #include "ts_common.hpp"
@@ -23,26 +26,30 @@ constexpr int NC = NFFT / 2;       // complex FFT length
 constexpr float LOG_FLOOR = 5.9604644775390625e-08f;   // 2^-24
 
 struct Cx { float r, i; };
-__device__ __forceinline__ Cx cmul(Cx a, Cx b) { return Cx{a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
+// Complex values live in two-float vectors so that hipcc emits the packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: one instruction per complex add, two per complex multiply) -- the kernel is VALU-issue bound.
+using C2 = f32x2;
+__device__ __forceinline__ C2 cmul(C2 a, C2 w) { return C2{a[0], a[0]} * w + C2{a[1], a[1]} * C2{-w[1], w[0]}; }
+__device__ __forceinline__ C2 mul_mi(C2 a) { return C2{a[1], -a[0]}; }     // a * (-i)
+__device__ __forceinline__ C2 mul_pi(C2 a) { return C2{-a[1], a[0]}; }     // a * (+i)
 
 // 16-point forward DFT in registers (decimation 4 x 4), natural-order in and out.
-__device__ __forceinline__ void fft16(Cx (&a)[16]) {
-  Cx b[16];
+__device__ __forceinline__ void fft16(C2 (&a)[16]) {
+  C2 b[16];
   // stage 1: 4-point DFTs over n1 for each n2 (input index 4 n1 + n2), result index [n2][k1]
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2) {
-    const Cx x0 = a[n2], x1 = a[4 + n2], x2 = a[8 + n2], x3 = a[12 + n2];
-    const Cx s02{x0.r + x2.r, x0.i + x2.i}, d02{x0.r - x2.r, x0.i - x2.i};
-    const Cx s13{x1.r + x3.r, x1.i + x3.i}, d13{x1.r - x3.r, x1.i - x3.i};
-    b[n2 * 4 + 0] = Cx{s02.r + s13.r, s02.i + s13.i};
-    b[n2 * 4 + 1] = Cx{d02.r + d13.i, d02.i - d13.r};     // x0 - i x1 - x2 + i x3
-    b[n2 * 4 + 2] = Cx{s02.r - s13.r, s02.i - s13.i};
-    b[n2 * 4 + 3] = Cx{d02.r - d13.i, d02.i + d13.r};     // x0 + i x1 - x2 - i x3
+    const C2 s02 = a[n2] + a[8 + n2], d02 = a[n2] - a[8 + n2];
+    const C2 s13 = a[4 + n2] + a[12 + n2], d13 = a[4 + n2] - a[12 + n2];
+    b[n2 * 4 + 0] = s02 + s13;
+    b[n2 * 4 + 1] = d02 + mul_mi(d13);             // x0 - i x1 - x2 + i x3
+    b[n2 * 4 + 2] = s02 - s13;
+    b[n2 * 4 + 3] = d02 + mul_pi(d13);             // x0 + i x1 - x2 - i x3
   }
   // twiddles W16^(n2 k1)
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
-  const Cx w[10] = {Cx{1.f, 0.f}, Cx{C1, -S1}, Cx{R2, -R2}, Cx{S1, -C1}, Cx{0.f, -1.f},
-                    Cx{-S1, -C1}, Cx{-R2, -R2}, Cx{-C1, -S1}, Cx{-1.f, 0.f}, Cx{-C1, S1}};
+  const C2 w[10] = {C2{1.f, 0.f}, C2{C1, -S1}, C2{R2, -R2}, C2{S1, -C1}, C2{0.f, -1.f},
+                    C2{-S1, -C1}, C2{-R2, -R2}, C2{-C1, -S1}, C2{-1.f, 0.f}, C2{-C1, S1}};
 #pragma unroll
   for (int n2 = 1; n2 < 4; ++n2)
 #pragma unroll
@@ -50,13 +57,12 @@ __device__ __forceinline__ void fft16(Cx (&a)[16]) {
   // stage 2: 4-point DFTs over n2 for each k1, output index k1 + 4 k2
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) {
-    const Cx x0 = b[k1], x1 = b[4 + k1], x2 = b[8 + k1], x3 = b[12 + k1];
-    const Cx s02{x0.r + x2.r, x0.i + x2.i}, d02{x0.r - x2.r, x0.i - x2.i};
-    const Cx s13{x1.r + x3.r, x1.i + x3.i}, d13{x1.r - x3.r, x1.i - x3.i};
-    a[k1 + 0] = Cx{s02.r + s13.r, s02.i + s13.i};
-    a[k1 + 4] = Cx{d02.r + d13.i, d02.i - d13.r};
-    a[k1 + 8] = Cx{s02.r - s13.r, s02.i - s13.i};
-    a[k1 + 12] = Cx{d02.r - d13.i, d02.i + d13.r};
+    const C2 s02 = b[k1] + b[8 + k1], d02 = b[k1] - b[8 + k1];
+    const C2 s13 = b[4 + k1] + b[12 + k1], d13 = b[4 + k1] - b[12 + k1];
+    a[k1 + 0] = s02 + s13;
+    a[k1 + 4] = d02 + mul_mi(d13);
+    a[k1 + 8] = s02 - s13;
+    a[k1 + 12] = d02 + mul_pi(d13);
   }
 }
 
@@ -69,7 +75,7 @@ struct FeArgs {
   float* logmel;              // [B][F][n_mels]
   float* partial;             // [B][nwg][n_mels][2]
   int* feat_len;
-  int n_samples, hop, n_mels, n_frames, nwg, mel_nnz;
+  int n_samples, hop, n_mels, n_frames, nwg, mel_nnz, batch;
   float preemph;
 };
 
@@ -78,47 +84,73 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   const int span = (FPW - 1) * a.hop + NFFT;
   float* const sig = reinterpret_cast<float*>(smem);                 // [span] pre-emphasised, reflect-padded
   Cx* const tw256 = reinterpret_cast<Cx*>(sig + round_up(span, 4));  // W_256^j
-  Cx* const tw512 = tw256 + NC;                                      // W_512^k, k = 0..256
-  float* const win = reinterpret_cast<float*>(tw512 + NC + 2);       // [NFFT]
+  float* const win = reinterpret_cast<float*>(tw256 + NC);           // [NFFT]
   float* const fr = win + NFFT;                                      // per frame scratch
   constexpr int YSZ = 16 * 17 * 2;                                   // floats: padded transpose tile; Z and P reuse it
   constexpr int FSZ = YSZ;
   static_assert(NC * 2 <= YSZ, "the spectrum of a frame fits the transpose tile it replaces");
-  float* const red = fr + FPW * FSZ;                                 // [FPW][n_mels] log-mel staging
-  float* const melw = red + FPW * a.n_mels;                          // [mel_nnz] CSR weights
+  constexpr int RED0 = 288;                                          // log-mel staging of a frame: floats [288, 288 + n_mels) of its
+                                                                     // tile, above the 257 power-spectrum bins (n_mels <= 256)
+  float* const melw = fr + FPW * FSZ;                                // [mel_nnz] CSR weights
   int* const melo = reinterpret_cast<int*>(melw + a.mel_nnz);        // [n_mels + 1][2]
 
   const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int f0 = blockIdx.x * FPW;
-  const float* x = a.wave + (size_t)b * a.n_samples;
   const int T = a.n_samples;
 
-  // ---- tables + signal staging ------------------------------------------------------------------------
+  // ---- tables: once per (persistent) workgroup -------------------------------------------------------------
   for (int j = tid; j < NC; j += 256) {
     float s, c;
     sincospif(-2.0f * (float)j / (float)NC, &s, &c);
     tw256[j] = Cx{c, s};
   }
-  for (int k = tid; k <= NC; k += 256) {
-    float s, c;
-    sincospif(-2.0f * (float)k / (float)NFFT, &s, &c);
-    tw512[k] = Cx{c, s};
-  }
   for (int j = tid; j < NFFT; j += 256) win[j] = a.window[j];
   for (int j = tid; j < a.mel_nnz; j += 256) melw[j] = a.mel_w[j];
   for (int j = tid; j < (a.n_mels + 1) * 2; j += 256) melo[j] = a.mel_off[j];
-  const int k0 = f0 * a.hop - NFFT / 2;
-  for (int e = tid; e < span; e += 256) {
-    int k = k0 + e;
-    k = k < 0 ? -k : k;
-    k = k >= T ? 2 * (T - 1) - k : k;
-    k = k < 0 ? 0 : (k >= T ? T - 1 : k);          // frames entirely beyond the clip (never valid)
-    const float cur = x[k];
-    const float prev = k > 0 ? x[k - 1] : 0.f;
-    sig[e] = k > 0 ? cur - a.preemph * prev : cur;
-  }
+
+  // ---- signal staging, one frame group ahead: the samples of group g + grid travel global -> registers while group g
+  // is transformed, and go into `sig` as soon as the first FFT stage of g has read it ------------------------------
+  constexpr int NL = 12;                             // staged samples per thread held in registers (span <= 3072)
+  const bool pre = span <= 256 * NL;
+  float cur[NL], prv[NL];
+  auto fetch = [&](int g) {
+    const float* x = a.wave + (size_t)(g / a.nwg) * a.n_samples;
+    const int k0 = (g % a.nwg) * FPW * a.hop - NFFT / 2;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int k = k0 + tid + 256 * j;
+      k = k < 0 ? -k : k;
+      k = k >= T ? 2 * (T - 1) - k : k;
+      k = k < 0 ? 0 : (k >= T ? T - 1 : k);          // frames entirely beyond the clip (never valid)
+      cur[j] = x[k];
+      prv[j] = k > 0 ? x[k - 1] : 0.f;               // sample 0 is not pre-emphasised
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      if (tid + 256 * j < span) sig[tid + 256 * j] = cur[j] - a.preemph * prv[j];
+  };
+  auto stage_direct = [&](int g) {                   // long hops: no register prefetch
+    const float* x = a.wave + (size_t)(g / a.nwg) * a.n_samples;
+    const int k0 = (g % a.nwg) * FPW * a.hop - NFFT / 2;
+    for (int e = tid; e < span; e += 256) {
+      int k = k0 + e;
+      k = k < 0 ? -k : k;
+      k = k >= T ? 2 * (T - 1) - k : k;
+      k = k < 0 ? 0 : (k >= T ? T - 1 : k);
+      sig[e] = k > 0 ? x[k] - a.preemph * x[k - 1] : x[k];
+    }
+  };
+  const int n_groups = a.nwg * a.batch;
+  int g = blockIdx.x;
+  if (pre) { fetch(g); commit(); } else { stage_direct(g); }
   __syncthreads();
+
+  for (; g < n_groups; g += gridDim.x) {
+  const int b = g / a.nwg, grp = g - b * a.nwg;
+  const int f0 = grp * FPW;
+  const int gn = g + gridDim.x;
+  if (pre && gn < n_groups) fetch(gn);
 
   // ---- 256-point complex FFT per frame: 16 lanes per frame ---------------------------------------------
   const int fl = tid >> 4;          // frame in workgroup
@@ -126,52 +158,49 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   float* const Y = fr + fl * FSZ;
   float* const Z = Y;                 // written only after every lane of the workgroup has read its Y row
   {
-    Cx v[16];
+    C2 v[16];
     const float* s = sig + fl * a.hop;
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       const int j = 32 * n1 + 2 * i;
-      const f32x2 sv = *reinterpret_cast<const f32x2*>(s + j);
-      const f32x2 wv = *reinterpret_cast<const f32x2*>(win + j);
-      v[n1] = Cx{sv[0] * wv[0], sv[1] * wv[1]};
+      v[n1] = *reinterpret_cast<const f32x2*>(s + j) * *reinterpret_cast<const f32x2*>(win + j);
     }
     fft16(v);                                    // over n1 -> index k1
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-      const Cx t = cmul(v[k1], tw256[(i * k1) & (NC - 1)]);
-      *reinterpret_cast<f32x2*>(Y + (k1 * 17 + i) * 2) = f32x2{t.r, t.i};
-    }
+    for (int k1 = 0; k1 < 16; ++k1)
+      *reinterpret_cast<f32x2*>(Y + (k1 * 17 + i) * 2) = cmul(v[k1], *reinterpret_cast<const f32x2*>(&tw256[(i * k1) & (NC - 1)]));
   }
   __syncthreads();
+  if (pre && gn < n_groups) commit();                // every lane has read its samples of group g
   {
-    Cx v[16];
+    C2 v[16];
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) {
-      const f32x2 t = *reinterpret_cast<const f32x2*>(Y + (i * 17 + n2) * 2);
-      v[n2] = Cx{t[0], t[1]};
-    }
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = *reinterpret_cast<const f32x2*>(Y + (i * 17 + n2) * 2);
     __syncthreads();
     fft16(v);                                    // over n2 -> k2; bin = i + 16 k2
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<f32x2*>(Z + (i + 16 * k2) * 2) = f32x2{v[k2].r, v[k2].i};
+    for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<f32x2*>(Z + (i + 16 * k2) * 2) = v[k2];
   }
   __syncthreads();
   // ---- real-FFT split + power spectrum, bins k = i + 16 j (and bin 256 on lane 0) -> P (aliases Y) ------
   float* const P = Y;
   {
     float pw[17];
+    const f32x2 w_odd = (i & 1) ? f32x2{0.99992470183914454f, -0.012271538285719925f} : f32x2{1.f, 0.f};   // W_512^1
 #pragma unroll
     for (int j = 0; j < 17; ++j) {
       const int k = i + 16 * j;
       if (j < 16 || i == 0) {
         const f32x2 zk = *reinterpret_cast<const f32x2*>(Z + ((k & (NC - 1)) * 2));
         const f32x2 zn = *reinterpret_cast<const f32x2*>(Z + (((NC - k) & (NC - 1)) * 2));
-        const Cx w = tw512[k];                    // (cos, -sin)
-        const float ar = zk[0] + zn[0], ai = zk[1] - zn[1];
-        const float dr = zk[0] - zn[0], di = zk[1] + zn[1];
-        // X = 0.5 * (A - i W D)
-        const float xr = 0.5f * (ar + w.r * di + w.i * dr);
-        const float xi = 0.5f * (ai - w.r * dr + w.i * di);
+        // W_512^k = W_256^(k >> 1) * W_512^(k & 1); k = i + 16 j has the parity of the lane
+        const f32x2 w = cmul(*reinterpret_cast<const f32x2*>(&tw256[(k >> 1) & (NC - 1)]), w_odd);
+        const f32x2 znc = f32x2{zn[0], -zn[1]};                          // conj(z[N - k])
+        const f32x2 A = zk + znc, D = zk - znc;                          // A = (ar, ai), D = (dr, di)
+        // X = 0.5 * (A - i W D):  -i (W D) = (Im(WD), -Re(WD))
+        const f32x2 wd = cmul(D, w);
+        const f32x2 X = 0.5f * (A + f32x2{wd[1], -wd[0]});
+        const float xr = X[0], xi = X[1];
         pw[j] = xr * xr + xi * xi;
       }
     }
@@ -189,25 +218,28 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
     float acc = 0.f;
     for (int j = 0; j < cnt; ++j) acc = fmaf(melw[off + j], P[first + j], acc);
     const float lm = logf(acc + LOG_FLOOR);
-    red[fl * a.n_mels + m] = lm;
+    fr[fl * FSZ + RED0 + m] = lm;
     if (f < a.n_frames) a.logmel[((size_t)b * a.n_frames + f) * a.n_mels + m] = lm;
   }
   __syncthreads();
   // ---- partial statistics over the valid frames of this workgroup -----------------------------------------
   const int flen = a.wave_len[b] / a.hop + 1;      // floor(len / hop) + 1  (transform.py:182-184)
-  if (tid == 0 && blockIdx.x == 0) a.feat_len[b] = flen;
+  if (tid == 0 && grp == 0) a.feat_len[b] = flen;
   for (int m = tid; m < a.n_mels; m += 256) {
     float s1 = 0.f, s2 = 0.f;
     for (int q = 0; q < FPW; ++q) {
       if (f0 + q < flen && f0 + q < a.n_frames) {
-        const float v = red[q * a.n_mels + m];
+        const float v = fr[q * FSZ + RED0 + m];
         s1 += v;
         s2 = fmaf(v, v, s2);
       }
     }
-    float* dst = a.partial + (((size_t)b * a.nwg + blockIdx.x) * a.n_mels + m) * 2;
+    float* dst = a.partial + (((size_t)b * a.nwg + grp) * a.n_mels + m) * 2;
     dst[0] = s1;
     dst[1] = s2;
+  }
+  if (!pre && gn < n_groups) stage_direct(gn);
+  __syncthreads();                                   // `red` / P are free again, the next group's samples are in place
   }
 }
 
@@ -323,10 +355,12 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   a.n_samples = d->n_samples; a.hop = d->hop; a.n_mels = d->n_mels; a.n_frames = d->n_frames; a.nwg = nwg;
   a.preemph = d->preemph;
   a.mel_nnz = d->mel_nnz;
+  a.batch = d->batch;
   const int span = (FPW - 1) * d->hop + NFFT;
   if (d->mel_nnz < 0) return TS_EINVAL;
-  const size_t lds1 = ((size_t)round_up(span, 4) + 2 * NC * 2 + 4 + NFFT + (size_t)FPW * (16 * 17 * 2) +
-                       (size_t)FPW * d->n_mels + (size_t)d->mel_nnz + (size_t)(d->n_mels + 1) * 2) * sizeof(float);
+  if (d->n_mels > 256) return TS_EUNSUPPORTED;                     // the log-mel staging sits in the upper half of a frame tile
+  const size_t lds1 = ((size_t)round_up(span, 4) + NC * 2 + NFFT + (size_t)FPW * (16 * 17 * 2) +
+                       (size_t)d->mel_nnz + (size_t)(d->n_mels + 1) * 2) * sizeof(float);
   if (lds1 > 160 * 1024) return TS_EUNSUPPORTED;
   if (lds1 > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_kernel),
@@ -334,7 +368,11 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
     if (e != hipSuccess) return (int)e;
   }
   (void)hipGetLastError();
-  hipLaunchKernelGGL(stft_mel_kernel, dim3(nwg, d->batch), dim3(256), lds1, stream, a);
+  // persistent workgroups: as many as fit at once (LDS-limited), each walks frame groups g, g + grid, ...
+  const int per_cu = (int)((160 * 1024) / lds1) < 1 ? 1 : (int)((160 * 1024) / lds1);
+  const int n_groups = nwg * d->batch;
+  const int grid = n_groups < cu_count() * per_cu ? n_groups : cu_count() * per_cu;
+  hipLaunchKernelGGL(stft_mel_kernel, dim3(grid), dim3(256), lds1, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
 

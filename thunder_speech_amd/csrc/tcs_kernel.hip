@@ -1216,16 +1216,6 @@ __global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
 #undef SB
 }
 
-static int cu_count() {
-  static int n_cu = 0;
-  if (n_cu) return n_cu;
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    return n_cu = prop.multiProcessorCount;
-  return n_cu = 256;
-}
-
 template <int NPASS, int XJ, int MT, int WM>
 static int launch_pipe(TcsArgs& a, hipStream_t stream) {
   constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);

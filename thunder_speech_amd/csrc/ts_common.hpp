@@ -70,4 +70,15 @@ __host__ __device__ constexpr int round_up(int x, int m) { return (x + m - 1) / 
 
 inline int hip_status(hipError_t e) { return e == hipSuccess ? TS_OK : (int)e; }
 
+// compute units of the current device (one process per GPU: looked up once)
+inline int cu_count() {
+  static int n_cu = 0;
+  if (n_cu) return n_cu;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    return n_cu = prop.multiProcessorCount;
+  return n_cu = 256;
+}
+
 }  // namespace ts
