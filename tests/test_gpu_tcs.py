@@ -130,6 +130,8 @@ def _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, residual, seed=0):
     (128, 128, 17, 1, 1, 400, [400, 201], False),       # 192-frame tiles, 2 passes
     (256, 256, 39, 1, 1, 401, [401, 333, 250], True),   # 4 passes + residual stages, several tiles per workgroup
     (256, 256, 33, 1, 1, 1400, [1400, 1399, 700, 5] * 40, True),   # more tiles than CUs: the persistent loop wraps
+    (512, 512, 51, 1, 1, 570, [570, 569, 300] * 14 + [33], True),  # 258 tiles: ragged last XCD range of the tile order
+    (320, 512, 25, 1, 1, 300, [300, 150, 7], True),                # 5 residual stages (odd): one-ahead identity rows
 ])
 def test_tail_zero_fast_kernels_match_oracle(cin, cout, k, stride, dil, t, lens, res):
     _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, res)

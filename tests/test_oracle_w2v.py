@@ -1,0 +1,43 @@
+"""The wav2vec2 oracle against the fixture produced by the real transformers model (tests/golden/make_golden_w2v.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import w2v as ow
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_fixture():
+    z = np.load(os.path.join(HERE, "golden", "w2v_tiny.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    c = {k[4:]: z[k] for k in z.files if k.startswith("cfg/")}
+    cfg = ow.W2VConfig(conv_dim=tuple(int(v) for v in c["conv_dim"]), conv_kernel=tuple(int(v) for v in c["conv_kernel"]),
+                       conv_stride=tuple(int(v) for v in c["conv_stride"]), hidden_size=int(c["hidden_size"]),
+                       num_hidden_layers=int(c["num_hidden_layers"]), num_attention_heads=int(c["num_attention_heads"]),
+                       intermediate_size=int(c["intermediate_size"]), num_conv_pos_embeddings=int(c["num_conv_pos_embeddings"]),
+                       num_conv_pos_embedding_groups=int(c["num_conv_pos_embedding_groups"]))
+    return z, sd, cfg
+
+
+def test_feature_extractor_matches_transformers():
+    z, sd, cfg = load_fixture()
+    feat = ow.feature_extractor(cfg, sd, torch.from_numpy(z["x"]))
+    np.testing.assert_allclose(feat.numpy(), z["feat"], atol=2e-5, rtol=1e-5)
+
+
+def test_forward_matches_transformers_unmasked():
+    z, sd, cfg = load_fixture()
+    out, key_len = ow.forward(cfg, sd, torch.from_numpy(z["x"]))
+    assert key_len is None
+    np.testing.assert_allclose(out.numpy(), z["out"], atol=5e-5, rtol=1e-5)
+
+
+def test_forward_matches_transformers_masked_and_lengths():
+    z, sd, cfg = load_fixture()
+    x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
+    xm = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
+    out, key_len = ow.forward(cfg, sd, xm, lengths)
+    np.testing.assert_array_equal(key_len.numpy(), z["out_lengths"])
+    np.testing.assert_allclose(out.numpy(), z["out_masked"], atol=5e-5, rtol=1e-5)
