@@ -1,0 +1,88 @@
+"""GPU parity: wav2vec2 encoder (csrc/w2v_enc.hip through the C ABI) vs the oracle and the transformers-generated fixture.
+fp32 activations, fp32 rocBLAS GEMMs: tolerances are fp32 summation-order noise."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import w2v as ow
+from test_oracle_w2v import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _hf_cfg(cfg: ow.W2VConfig):
+    return SimpleNamespace(conv_dim=cfg.conv_dim, conv_kernel=cfg.conv_kernel, conv_stride=cfg.conv_stride,
+                           hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                           num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                           num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+                           num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups, layer_norm_eps=cfg.layer_norm_eps,
+                           feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False, hidden_act="gelu",
+                           feat_extract_activation="gelu")
+
+
+def _plan():
+    from thunder_speech_amd.huggingface.encoder import Wav2Vec2Plan
+    z, sd, cfg = load_fixture()
+    return z, sd, cfg, Wav2Vec2Plan(_hf_cfg(cfg), sd, "cuda")
+
+
+def test_feature_extractor_matches_transformers_fixture():
+    z, sd, cfg, plan = _plan()
+    feat = plan.feature_extractor(torch.from_numpy(z["x"]).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(feat.cpu().numpy(), z["feat"], atol=1e-4, rtol=1e-4)
+
+
+def test_forward_matches_transformers_fixture_unmasked():
+    z, sd, cfg, plan = _plan()
+    out = plan.forward(torch.from_numpy(z["x"]).cuda(), None)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), z["out"], atol=5e-4, rtol=1e-4)
+
+
+def test_forward_matches_transformers_fixture_masked():
+    z, sd, cfg, plan = _plan()
+    x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
+    xm = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
+    out = plan.forward(xm.cuda(), lengths.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), z["out_masked"], atol=5e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n,lens", [(4000, [4000, 3999, 1500]), (16000, [16000, 9000])])
+def test_other_lengths_match_the_oracle(n, lens):
+    """Ragged clip lengths and frame counts that are not multiples of anything."""
+    z, sd, cfg, plan = _plan()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(len(lens), n, generator=g)
+    lengths = torch.tensor(lens)
+    xm = x * (torch.arange(n)[None, :] < lengths[:, None])
+    ref, key_len = ow.forward(cfg, sd, xm, lengths)
+    out = plan.forward(xm.cuda(), lengths.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=5e-4, rtol=1e-4)
+
+
+def test_adapter_has_the_reference_interface():
+    """`_HuggingFaceEncoderAdapt` contract (huggingface/compatibility.py:23-42) on a real transformers module."""
+    transformers = pytest.importorskip("transformers")
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    z, sd, cfg = load_fixture()
+    hf_cfg = transformers.Wav2Vec2Config(
+        hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+        intermediate_size=cfg.intermediate_size, feat_extract_norm="group", do_stable_layer_norm=False, vocab_size=32,
+        conv_dim=tuple(cfg.conv_dim), conv_kernel=tuple(cfg.conv_kernel), conv_stride=tuple(cfg.conv_stride),
+        num_conv_pos_embeddings=cfg.num_conv_pos_embeddings, num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups)
+    model = transformers.Wav2Vec2Model(hf_cfg).eval()
+    model.load_state_dict(sd)
+    enc = HuggingFaceEncoderAdapt(model.cuda(), mask_input=False).eval()
+    assert "original_encoder.encoder.layers.0.attention.q_proj.weight" in enc.state_dict()
+    x = torch.from_numpy(z["x"]).cuda()
+    lengths = torch.from_numpy(z["lengths"]).cuda()
+    with torch.no_grad():
+        out, out_len = enc(x, lengths)
+    assert out.shape == (2, cfg.hidden_size, z["out"].shape[1])
+    np.testing.assert_array_equal(out_len.cpu().numpy(), z["out_lengths"])
+    np.testing.assert_allclose(out.transpose(-1, -2).cpu().numpy(), z["out"], atol=5e-4, rtol=1e-4)

@@ -1,0 +1,79 @@
+"""load_huggingface_checkpoint on a checkpoint directory written offline by transformers' own save_pretrained (random
+weights): module structure / vocabulary on the CPU, logits and transcripts on the GPU against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+transformers = pytest.importorskip("transformers")
+
+VOCAB = ["<pad>", "<s>", "</s>", "<unk>", "|"] + list("abcdefghijklmnopqrstuvwxyz'")
+CFG = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, feat_extract_norm="group",
+           do_stable_layer_norm=False, vocab_size=len(VOCAB), conv_dim=(32,) * 7, conv_kernel=(10, 3, 3, 3, 3, 2, 2),
+           conv_stride=(5, 2, 2, 2, 2, 2, 2), num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, pad_token_id=0)
+
+
+@pytest.fixture(scope="module")
+def checkpoint_dir(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("w2v_ckpt"))
+    torch.manual_seed(3)
+    model = transformers.Wav2Vec2ForCTC(transformers.Wav2Vec2Config(**CFG)).eval()
+    model.save_pretrained(d)
+    with open(os.path.join(d, "vocab.json"), "w") as f:
+        json.dump({t: i for i, t in enumerate(VOCAB)}, f)
+    transformers.Wav2Vec2CTCTokenizer(os.path.join(d, "vocab.json")).save_pretrained(d)
+    transformers.Wav2Vec2FeatureExtractor(return_attention_mask=False).save_pretrained(d)
+    return d
+
+
+def test_loader_builds_the_reference_module_layout(checkpoint_dir):
+    from thunder_speech_amd.huggingface.compatibility import load_huggingface_checkpoint
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    from thunder_speech_amd.huggingface.transform import Wav2Vec2Preprocess
+    m = load_huggingface_checkpoint(checkpoint_dir)
+    assert not m.training and isinstance(m.encoder, HuggingFaceEncoderAdapt) and isinstance(m.audio_transform, Wav2Vec2Preprocess)
+    assert m.encoder.mask_input is False and m.audio_transform.mask_input is False
+    assert m.encoder_final_dimension == 64
+    keys = m.state_dict().keys()
+    assert "encoder.original_encoder.feature_extractor.conv_layers.0.conv.weight" in keys
+    assert "decoder.2.weight" in keys and m.state_dict()["decoder.2.weight"].shape == (len(VOCAB), 64)
+    # "|" is shown as a space; the CTC blank is the tokenizer's pad token
+    assert m.text_transform.vocab.itos[4] == " " and m.text_transform.vocab.blank_token == "<pad>"
+    assert m.text_transform.num_tokens == len(VOCAB)
+    # the conv feature encoder is frozen, as in the reference
+    assert not any(p.requires_grad for p in m.encoder.original_encoder.feature_extractor.parameters())
+
+
+def test_unsupported_configurations_fail_loudly():
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    cfg = transformers.Wav2Vec2Config(**{**CFG, "feat_extract_norm": "layer", "do_stable_layer_norm": True})
+    with pytest.raises(NotImplementedError):
+        HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(cfg))
+
+
+@pytest.mark.gpu
+def test_logits_and_transcripts_match_the_oracle(checkpoint_dir):
+    from oracle import w2v as ow
+    from thunder_speech_amd.huggingface.compatibility import load_huggingface_checkpoint
+    m = load_huggingface_checkpoint(checkpoint_dir)
+    sd = {k: v.clone() for k, v in m.encoder.original_encoder.state_dict().items()}
+    dec_w, dec_b = m.decoder[2].weight.detach().clone(), m.decoder[2].bias.detach().clone()
+    m = m.cuda()
+    g = torch.Generator().manual_seed(11)
+    x = 0.1 * torch.randn(3, 12000, generator=g)
+    lengths = torch.tensor([12000, 12000, 12000])
+    with torch.no_grad():
+        logits, out_len = m(x.cuda(), lengths.cuda())
+        texts = m.predict(x.cuda())
+    cfg = ow.W2VConfig(**{k: CFG[k] for k in ("conv_dim", "conv_kernel", "conv_stride", "hidden_size", "num_hidden_layers",
+                                               "num_attention_heads", "intermediate_size", "num_conv_pos_embeddings",
+                                               "num_conv_pos_embedding_groups")})
+    xn = (x - x.mean(dim=1, keepdim=True)) / torch.sqrt(x.var(dim=1, keepdim=True) + 1e-7)      # Wav2Vec2Preprocess, mask_input=False
+    h, _ = ow.forward(cfg, sd, xn)
+    ref = (h @ dec_w.T + dec_b).transpose(1, 2)
+    assert logits.shape == ref.shape and out_len.tolist() == [37, 37, 37]
+    # the decoder kernel keeps its input in bf16 (as for QuartzNet): ~3 significant digits on the logits
+    assert float((logits.float().cpu() - ref).abs().max()) <= 0.02 * max(1.0, float(ref.abs().max()))
+    assert len(texts) == 3 and all(isinstance(t, str) for t in texts)

@@ -27,6 +27,9 @@ EXPORTED_SYMBOLS = [
     "ts_decoder_bwd", "ts_adamw_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd",
     "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
+    "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
+    "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_attention_workspace_bytes",
+    "ts_w2v_attention_fwd",
 ]
 
 
@@ -107,6 +110,22 @@ def lib() -> C.CDLL:
     L.ts_w2v_workspace_bytes.restype = i64
     L.ts_w2v_preprocess.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp]
     L.ts_w2v_preprocess.restype = C.c_int
+    L.ts_w2v_conv0_workspace_bytes.argtypes = [i32, i64, i32, i32, i32]
+    L.ts_w2v_conv0_workspace_bytes.restype = i64
+    L.ts_w2v_conv0_fwd.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
+    L.ts_w2v_conv_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp]
+    L.ts_w2v_linear_fwd.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, i32, vp]
+    L.ts_w2v_layernorm_fwd.argtypes = [vp, vp, vp, vp, f32, i64, i32, vp, vp]
+    L.ts_w2v_mask_rows.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.ts_w2v_posconv_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.ts_w2v_posconv_workspace_bytes.restype = i64
+    L.ts_w2v_posconv_fwd.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.ts_w2v_attention_workspace_bytes.argtypes = [i32, i32, i32]
+    L.ts_w2v_attention_workspace_bytes.restype = i64
+    L.ts_w2v_attention_fwd.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    for fn in ("ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd", "ts_w2v_mask_rows",
+               "ts_w2v_posconv_fwd", "ts_w2v_attention_fwd"):
+        getattr(L, fn).restype = C.c_int
     L.ts_train_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
     L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
     L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, vp]

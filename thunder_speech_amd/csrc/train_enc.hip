@@ -8,7 +8,7 @@
 //   residual add + ReLU fwd / bwd                        quartznet/blocks.py:332-337
 #include "ts_common.hpp"
 
-#include <rocblas/rocblas.h>
+#include "ts_blas.hpp"
 
 namespace ts {
 
@@ -238,13 +238,6 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
   out[idx] = s;
 }
 
-static rocblas_handle g_handle = nullptr;
-static int blas(hipStream_t stream, rocblas_handle* h) {
-  if (!g_handle && rocblas_create_handle(&g_handle) != rocblas_status_success) return TS_EUNSUPPORTED;
-  if (rocblas_set_stream(g_handle, stream) != rocblas_status_success) return TS_EUNSUPPORTED;
-  *h = g_handle;
-  return TS_OK;
-}
 static inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace ts

@@ -1,0 +1,364 @@
+// wav2vec2 encoder, first (unfused, fp32) version: what the reference gets from transformers.Wav2Vec2Model through
+// _HuggingFaceEncoderAdapt.forward (huggingface/compatibility.py:31-42) for group-norm / post-LN checkpoints
+// (facebook/wav2vec2-base-960h, -large-960h).  Activations are TIME-MAJOR fp32 [B][T][C]; the reference's final
+// transpose(-1, -2) is a view on the host side.
+//
+//   ts_w2v_conv0_fwd      conv(1 -> C, k, s) + GroupNorm(C groups: per (clip, channel) over time) + GELU, three launches:
+//                         partial sums (conv recomputed, never stored un-normalised), fp64 finalize, apply
+//   ts_w2v_conv_fwd       strided conv C -> C as one GEMM per tap (rows s*t + j of the time-major input are a strided
+//                         matrix) accumulating in place, + GELU
+//   ts_w2v_linear_fwd     y = act(x W^T + b [+ res])
+//   ts_w2v_layernorm_fwd  y = LN(x [+ res])
+//   ts_w2v_posconv_fwd    y = x + gelu(grouped conv(x) + b): one batched GEMM per tap over a zero-padded copy
+//   ts_w2v_attention_fwd  softmax(q k^T * scale [keys >= len masked]) v per (clip, head)
+// The GEMMs are plain library calls (rocBLAS sgemm_strided_batched); everything else is hand-written here.  This version
+// exists for parity and coverage of config C5; MFMA attention / fused bf16 kernels are the follow-up.
+#include "ts_blas.hpp"
+
+namespace ts {
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv0 + GroupNorm + GELU
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int C0_FR = 256;          // frames per workgroup
+constexpr int C0_KMAX = 16;
+
+struct Conv0Args {
+  const float* wave;                // [B][n]
+  const float* w;                   // [C][k]
+  const float* gamma;
+  const float* beta;
+  float* partial;                   // [B][chunks][C][2]
+  float* stats;                     // [B][C][2] = (scale, shift)
+  float* y;                         // [B][T0][C]
+  long long n;
+  int t0, c, k, s, chunks;
+  float eps;
+};
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void w2v_conv0_kernel(const Conv0Args a) {
+  extern __shared__ float sig[];                               // (C0_FR - 1) * s + k samples
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int f0 = chunk * C0_FR;
+  const int nf = a.t0 - f0 < C0_FR ? a.t0 - f0 : C0_FR;
+  const int span = (nf - 1) * a.s + a.k;
+  const float* x = a.wave + (size_t)b * a.n + (size_t)f0 * a.s;
+  for (int i = threadIdx.x; i < span; i += 256) sig[i] = x[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.c; c += 256) {
+    float w[C0_KMAX];
+#pragma unroll
+    for (int j = 0; j < C0_KMAX; ++j) w[j] = j < a.k ? a.w[(size_t)c * a.k + j] : 0.f;
+    if constexpr (APPLY) {
+      const float scale = a.stats[((size_t)b * a.c + c) * 2], shift = a.stats[((size_t)b * a.c + c) * 2 + 1];
+      float* out = a.y + ((size_t)b * a.t0 + f0) * a.c + c;
+      for (int f = 0; f < nf; ++f) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_KMAX; ++j) if (j < a.k) v = fmaf(w[j], sig[f * a.s + j], v);
+        out[(size_t)f * a.c] = gelu_erf(fmaf(v, scale, shift));
+      }
+    } else {
+      float s1 = 0.f, s2 = 0.f;
+      for (int f = 0; f < nf; ++f) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_KMAX; ++j) if (j < a.k) v = fmaf(w[j], sig[f * a.s + j], v);
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+      float* p = a.partial + (((size_t)b * a.chunks + chunk) * a.c + c) * 2;
+      p[0] = s1;
+      p[1] = s2;
+    }
+  }
+}
+
+// mean / biased variance over time per (clip, channel) in fp64 -> (scale, shift) of the affine normalisation
+__global__ __launch_bounds__(256) void w2v_conv0_finalize_kernel(const Conv0Args a) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int ch = 0; ch < a.chunks; ++ch) {
+    const float* p = a.partial + (((size_t)b * a.chunks + ch) * a.c + c) * 2;
+    s1 += (double)p[0];
+    s2 += (double)p[1];
+  }
+  const double mu = s1 / a.t0;
+  double var = s2 / a.t0 - mu * mu;
+  var = var < 0.0 ? 0.0 : var;
+  const double rs = 1.0 / sqrt(var + (double)a.eps);
+  const double g = a.gamma[c];
+  a.stats[((size_t)b * a.c + c) * 2] = (float)(rs * g);
+  a.stats[((size_t)b * a.c + c) * 2 + 1] = (float)((double)a.beta[c] - mu * rs * g);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// elementwise epilogues
+// ---------------------------------------------------------------------------------------------------------------------
+// y[r][c] = act(y[r][c] + bias[c]) (+ res[r][c]); ld = row pitch of y and res; n % 4 == 0 path is vectorised
+__global__ __launch_bounds__(256) void w2v_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                           const float* __restrict__ res, long long rows, int n, long long ld,
+                                                           long long ld_res, int act) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = n >> 2;
+  if (idx >= rows * n4) return;
+  const long long r = idx / n4;
+  const int c = (int)(idx - r * n4) * 4;
+  float4 v = *reinterpret_cast<float4*>(y + r * ld + c);
+  if (bias) {
+    const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+  }
+  if (act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+  if (res) {
+    const float4 rr = *reinterpret_cast<const float4*>(res + r * ld_res + c);
+    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+  }
+  *reinterpret_cast<float4*>(y + r * ld + c) = v;
+}
+
+// one wavefront per row: y = LN(x (+ res)) * w + b
+__global__ __launch_bounds__(256) void w2v_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ y, long long rows, int c, float eps) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * c;
+  const float* rr = res ? res + row * c : nullptr;
+  float s = 0.f;
+  for (int i = lane; i < c; i += 64) s += xr[i] + (rr ? rr[i] : 0.f);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / c;
+  float q = 0.f;
+  for (int i = lane; i < c; i += 64) {
+    const float d = xr[i] + (rr ? rr[i] : 0.f) - mu;
+    q = fmaf(d, d, q);
+  }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rs = rsqrtf(q / c + eps);
+  float* yr = y + row * c;
+  for (int i = lane; i < c; i += 64) yr[i] = (xr[i] + (rr ? rr[i] : 0.f) - mu) * rs * w[i] + b[i];
+}
+
+// rows >= len[b] of a [B][T][C] tensor become 0 (hidden_states[~attention_mask] = 0)
+__global__ __launch_bounds__(256) void w2v_mask_rows_kernel(float* __restrict__ x, const int* __restrict__ len, int t, int c) {
+  const int b = blockIdx.y;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = len[b] < 0 ? 0 : (len[b] < t ? len[b] : t);
+  const long long total = (long long)(t - n) * c;
+  if (idx < total) x[((size_t)b * t + n) * c + idx] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// positional conv: zero-padded copy in, bias + GELU + residual out
+// ---------------------------------------------------------------------------------------------------------------------
+// xp: [B][T + k][C] with k/2 zero rows before and k - k/2 after each clip
+__global__ __launch_bounds__(256) void w2v_pad_rows_kernel(const float* __restrict__ x, float* __restrict__ xp, int t, int c, int k) {
+  const int b = blockIdx.y;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)(t + k) * c;
+  if (idx >= total) return;
+  const long long r = idx / c;
+  const int col = (int)(idx - r * c);
+  const long long src = r - k / 2;
+  xp[(size_t)b * total + idx] = (src >= 0 && src < t) ? x[((size_t)b * t + src) * c + col] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void w2v_posconv_finish_kernel(const float* __restrict__ x, const float* __restrict__ yp,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int t,
+                                                                 int c, int k) {
+  const int b = blockIdx.y;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)t * c) return;
+  const int col = (int)(idx % c);
+  // conv output frame r of clip b was accumulated at padded row b (T + k) + r
+  const float v = yp[(size_t)b * (t + k) * c + idx] + bias[col];
+  y[(size_t)b * t * c + idx] = x[(size_t)b * t * c + idx] + gelu_erf(v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention softmax: one wavefront per (clip, head, query) row of scores [B][H][T][T], in place
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void w2v_softmax_kernel(float* __restrict__ s, const int* __restrict__ key_len, int heads, int t,
+                                                          float scale) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long long rows = (long long)gridDim.y * heads * t;
+  (void)rows;
+  const int b = blockIdx.y;
+  if (row >= (long long)heads * t) return;
+  float* p = s + ((size_t)b * heads * t + row) * t;
+  const int n = key_len ? (key_len[b] < t ? (key_len[b] < 0 ? 0 : key_len[b]) : t) : t;
+  // the reference adds finfo.min to the masked keys: with at least one valid key they get probability exactly 0; with
+  // none (len = 0) every key is "equally masked" and the softmax is uniform over all T keys
+  const int lim = n > 0 ? n : t;
+  float m = -3.0e38f;
+  for (int i = lane; i < lim; i += 64) m = fmaxf(m, p[i] * scale);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float z = 0.f;
+  for (int i = lane; i < lim; i += 64) z += __expf(p[i] * scale - m);
+  for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+  const float rz = 1.f / z;
+  for (int i = lane; i < t; i += 64) p[i] = i < lim ? __expf(p[i] * scale - m) * rz : 0.f;
+}
+
+static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+// row-major y[M][N] (ldc) = alpha x[M][K] (lda) W[N][K]^T (ldw) + beta y, batched with element strides
+static int gemm_nt(rocblas_handle h, long long m, int n, int k, const float* x, long long lda, long long sx, const float* w,
+                   long long ldw, long long sw, float* y, long long ldc, long long sy, float beta, int batch) {
+  const float one = 1.f;
+  const rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, (rocblas_int)m, k,
+                                                          &one, w, (rocblas_int)ldw, sw, x, (rocblas_int)lda, sx, &beta, y,
+                                                          (rocblas_int)ldc, sy, batch);
+  return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
+}
+
+}  // namespace ts
+
+using namespace ts;
+#define TS_STREAM hipStream_t stream = reinterpret_cast<hipStream_t>(stream_); (void)hipGetLastError()
+
+static inline int conv_frames(long long n, int k, int s) { return n < k ? 0 : (int)((n - k) / s + 1); }
+
+extern "C" int64_t ts_w2v_conv0_workspace_bytes(int32_t batch, int64_t n_samples, int32_t c, int32_t kernel, int32_t stride) {
+  if (batch <= 0 || c <= 0 || kernel <= 0 || stride <= 0 || n_samples < kernel) return TS_EINVAL;
+  const int t0 = conv_frames(n_samples, kernel, stride);
+  const int chunks = (t0 + C0_FR - 1) / C0_FR;
+  return (int64_t)batch * chunks * c * 2 * sizeof(float) + (int64_t)batch * c * 2 * sizeof(float);
+}
+
+extern "C" int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const float* w, const float* gn_w,
+                                const float* gn_b, int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* workspace,
+                                void* stream_) {
+  if (!wave || !w || !gn_w || !gn_b || !y || !workspace || batch <= 0 || c <= 0 || stride <= 0 || n_samples < kernel) return TS_EINVAL;
+  if (kernel <= 0 || kernel > C0_KMAX) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  Conv0Args a{};
+  a.wave = wave; a.w = w; a.gamma = gn_w; a.beta = gn_b; a.y = y; a.n = n_samples; a.c = c; a.k = kernel; a.s = stride; a.eps = eps;
+  a.t0 = conv_frames(n_samples, kernel, stride);
+  a.chunks = (a.t0 + C0_FR - 1) / C0_FR;
+  a.partial = static_cast<float*>(workspace);
+  a.stats = a.partial + (size_t)batch * a.chunks * c * 2;
+  const size_t lds = ((size_t)(C0_FR - 1) * stride + kernel) * sizeof(float);
+  if (lds > 64 * 1024) return TS_EUNSUPPORTED;
+  hipLaunchKernelGGL(w2v_conv0_kernel<false>, dim3(a.chunks, batch), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(w2v_conv0_finalize_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(w2v_conv0_kernel<true>, dim3(a.chunks, batch), dim3(256), lds, stream, a);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_conv_fwd(const float* x, int32_t batch, int32_t t_in, int32_t c_in, const float* w_taps, int32_t c_out,
+                               int32_t kernel, int32_t stride, float* y, void* stream_) {
+  if (!x || !w_taps || !y || batch <= 0 || c_in <= 0 || c_out <= 0 || kernel <= 0 || stride <= 0 || t_in < kernel) return TS_EINVAL;
+  if (c_out % 4) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  rocblas_handle h;
+  if (int st = blas(stream, &h)) return st;
+  const int t_out = conv_frames(t_in, kernel, stride);
+  for (int j = 0; j < kernel; ++j) {
+    // rows stride*t + j of clip b: a [t_out x c_in] matrix with row pitch stride * c_in
+    if (int st = gemm_nt(h, t_out, c_out, c_in, x + (size_t)j * c_in, (long long)stride * c_in, (long long)t_in * c_in,
+                         w_taps + (size_t)j * c_out * c_in, c_in, 0, y, c_out, (long long)t_out * c_out, j ? 1.f : 0.f, batch))
+      return st;
+  }
+  const long long rows = (long long)batch * t_out;
+  hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (c_out / 4))), dim3(256), 0, stream, y, (const float*)nullptr,
+                     (const float*)nullptr, rows, c_out, (long long)c_out, 0LL, 1);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_linear_fwd(const float* x, int64_t lda, const float* w, const float* bias, const float* res, int64_t ld_res,
+                                 float* y, int64_t ldc, int64_t rows, int32_t n, int32_t k, int32_t act, void* stream_) {
+  if (!x || !w || !y || rows <= 0 || n <= 0 || k <= 0 || lda < k || ldc < n || (res && ld_res < n)) return TS_EINVAL;
+  if (n % 4 || ldc % 4 || (res && ld_res % 4) || act < 0 || act > 1) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  rocblas_handle h;
+  if (int st = blas(stream, &h)) return st;
+  if (int st = gemm_nt(h, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, 0.f, 1)) return st;
+  if (bias || res || act)
+    hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (n / 4))), dim3(256), 0, stream, y, bias, res, (long long)rows, n,
+                       (long long)ldc, (long long)ld_res, act);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float eps, int64_t rows,
+                                    int32_t c, float* y, void* stream_) {
+  if (!x || !w || !b || !y || rows <= 0 || c <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(w2v_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, w, b, y, (long long)rows, c, eps);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_mask_rows(float* x, int32_t batch, int32_t t, int32_t c, const int32_t* len, void* stream_) {
+  if (!x || !len || batch <= 0 || t <= 0 || c <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(w2v_mask_rows_kernel, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, len, t, c);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int64_t ts_w2v_posconv_workspace_bytes(int32_t batch, int32_t t, int32_t c, int32_t kernel) {
+  if (batch <= 0 || t <= 0 || c <= 0 || kernel <= 0) return TS_EINVAL;
+  return (int64_t)2 * batch * (t + kernel) * c * sizeof(float);
+}
+
+extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const float* w_taps, const float* bias,
+                                  int32_t kernel, int32_t groups, float* y, void* workspace, void* stream_) {
+  if (!x || !w_taps || !bias || !y || !workspace || batch <= 0 || t <= 0 || c <= 0 || kernel <= 0 || groups <= 0 || c % groups) return TS_EINVAL;
+  TS_STREAM;
+  rocblas_handle h;
+  if (int st = blas(stream, &h)) return st;
+  const int cg = c / groups;
+  const long long prow = (long long)t + kernel;                       // padded rows per clip
+  float* xp = static_cast<float*>(workspace);
+  float* yp = xp + (size_t)batch * prow * c;
+  hipLaunchKernelGGL(w2v_pad_rows_kernel, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x, xp, t, c, kernel);
+  // all clips at once: output row r (over the padded row space) = sum_j xp[r + j] W_j^T, per group; rows between clips are waste
+  const long long m = (long long)batch * prow - kernel;
+  for (int j = 0; j < kernel; ++j) {
+    if (int st = gemm_nt(h, m, cg, cg, xp + (size_t)j * c, c, cg, w_taps + (size_t)j * groups * cg * cg, cg, (long long)cg * cg, yp, c, cg,
+                         j ? 1.f : 0.f, groups))
+      return st;
+  }
+  hipLaunchKernelGGL(w2v_posconv_finish_kernel, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, yp, bias, y, t, c, kernel);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int64_t ts_w2v_attention_workspace_bytes(int32_t batch, int32_t t, int32_t heads) {
+  if (batch <= 0 || t <= 0 || heads <= 0) return TS_EINVAL;
+  return (int64_t)batch * heads * t * t * sizeof(float);
+}
+
+extern "C" int ts_w2v_attention_fwd(const float* qkv, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len,
+                                    float* ctx, void* workspace, void* stream_) {
+  if (!qkv || !ctx || !workspace || batch <= 0 || t <= 0 || c <= 0 || heads <= 0 || c % heads) return TS_EINVAL;
+  TS_STREAM;
+  rocblas_handle h;
+  if (int st = blas(stream, &h)) return st;
+  const int hd = c / heads;
+  float* s = static_cast<float*>(workspace);
+  const float one = 1.f, zero = 0.f;
+  for (int b = 0; b < batch; ++b) {
+    const float* q = qkv + (size_t)b * t * 3 * c;
+    // scores[query][key] = q . k : batched over the heads (head h = columns [h hd, (h+1) hd) of each third of a qkv row)
+    if (int st = gemm_nt(h, t, t, hd, q, 3LL * c, hd, q + c, 3LL * c, hd, s + (size_t)b * heads * t * t, t, (long long)t * t, 0.f, heads))
+      return st;
+  }
+  hipLaunchKernelGGL(w2v_softmax_kernel, dim3((unsigned)(((long long)heads * t + 3) / 4), batch), dim3(256), 0, stream, s, key_len, heads, t,
+                     1.f / sqrtf((float)hd));
+  for (int b = 0; b < batch; ++b) {
+    const float* v = qkv + (size_t)b * t * 3 * c + 2 * c;
+    // ctx[query][d] = sum_key p[query][key] v[key][d]   (column-major view: ctx^T = v^T p^T, no transposes)
+    const rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, hd, t, t, &one, v, 3 * c, hd,
+                                                            s + (size_t)b * heads * t * t, t, (rocblas_stride)t * t, &zero,
+                                                            ctx + (size_t)b * t * c, c, hd, heads);
+    if (st != rocblas_status_success) return TS_EUNSUPPORTED;
+  }
+  return hip_status(hipGetLastError());
+}

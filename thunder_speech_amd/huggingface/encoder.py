@@ -1,0 +1,193 @@
+"""wav2vec2 encoder on the HIP kernels of csrc/w2v_enc.hip.
+
+The reference hands the whole encoder to transformers (`_HuggingFaceEncoderAdapt.forward`,
+src/thunder/huggingface/compatibility.py:31-42: `self.original_encoder(audio, attention_mask=...)`, then
+`last_hidden_state.transpose(-1, -2)` and `_get_feat_extract_output_lengths`).  Here the transformers module only OWNS the
+weights (same attribute name `original_encoder`, same state-dict keys, so checkpoints and fine-tuning code see no
+difference); the arithmetic runs in `Wav2Vec2Plan`, which keeps packed fp32 device copies of the weights and issues one C-ABI
+call per stage.  Group-norm / post-LN configurations only (wav2vec2-base-960h, -large-960h); no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import _lib, tensors as _t
+from ..blocks import _PackedCache
+
+__all__ = ["Wav2Vec2Plan", "HuggingFaceEncoderAdapt", "feat_extract_output_lengths"]
+
+
+def feat_extract_output_lengths(conv_kernel, conv_stride, lengths: torch.Tensor) -> torch.Tensor:
+    """transformers' `_get_feat_extract_output_lengths`: floor((len - k) / s) + 1 per conv layer (integer tensor in, out)."""
+    out = lengths
+    for k, s in zip(conv_kernel, conv_stride):
+        out = torch.div(out - k, s, rounding_mode="floor") + 1
+    return out
+
+
+def _check_config(cfg) -> None:
+    bad = []
+    if getattr(cfg, "feat_extract_norm", "group") != "group":
+        bad.append(f"feat_extract_norm={cfg.feat_extract_norm!r}")
+    if getattr(cfg, "do_stable_layer_norm", False):
+        bad.append("do_stable_layer_norm=True")
+    if getattr(cfg, "conv_bias", False):
+        bad.append("conv_bias=True")
+    if getattr(cfg, "hidden_act", "gelu") != "gelu" or getattr(cfg, "feat_extract_activation", "gelu") != "gelu":
+        bad.append("activation != gelu")
+    if getattr(cfg, "position_embeddings_type", None) not in (None, "absolute") and hasattr(cfg, "position_embeddings_type"):
+        bad.append(f"position_embeddings_type={cfg.position_embeddings_type!r}")
+    if bad:
+        raise NotImplementedError("wav2vec2 HIP path: group-norm / post-LN wav2vec2 configurations only; got " + ", ".join(bad))
+
+
+class Wav2Vec2Plan:
+    """Packed weights + launch sequence for one set of encoder weights (HF state-dict keys, see oracle/w2v.py)."""
+
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device):
+        _check_config(cfg)
+        f = lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+        self.device = torch.device(device)
+        self.kernels = [int(k) for k in cfg.conv_kernel]
+        self.strides = [int(s) for s in cfg.conv_stride]
+        self.dims = [int(c) for c in cfg.conv_dim]
+        self.hidden = int(cfg.hidden_size)
+        self.heads = int(cfg.num_attention_heads)
+        self.n_layers = int(cfg.num_hidden_layers)
+        self.kpos = int(cfg.num_conv_pos_embeddings)
+        self.groups = int(cfg.num_conv_pos_embedding_groups)
+        self.eps = float(cfg.layer_norm_eps)
+        self.w0 = f("feature_extractor.conv_layers.0.conv.weight").reshape(self.dims[0], self.kernels[0]).contiguous()
+        self.gn_w = f("feature_extractor.conv_layers.0.layer_norm.weight")
+        self.gn_b = f("feature_extractor.conv_layers.0.layer_norm.bias")
+        # [c_out][c_in][k] -> tap-major [k][c_out][c_in]: one GEMM per tap
+        self.conv_w = [f(f"feature_extractor.conv_layers.{i}.conv.weight").permute(2, 0, 1).contiguous()
+                       for i in range(1, len(self.kernels))]
+        self.fp_ln = (f("feature_projection.layer_norm.weight"), f("feature_projection.layer_norm.bias"))
+        self.fp_w, self.fp_b = f("feature_projection.projection.weight"), f("feature_projection.projection.bias")
+        # weight_norm(dim=2): w[:, :, j] = g[j] v[:, :, j] / ||v[:, :, j]||
+        p = "encoder.pos_conv_embed.conv."
+        if p + "parametrizations.weight.original0" in sd:
+            g, v = f(p + "parametrizations.weight.original0"), f(p + "parametrizations.weight.original1")
+        else:
+            g, v = f(p + "weight_g"), f(p + "weight_v")
+        w_eff = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()                    # [C][C/g][k]
+        cg = self.hidden // self.groups
+        self.pos_w = w_eff.view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2).contiguous()     # [k][g][out][in]
+        self.pos_b = f(p + "bias")
+        self.enc_ln = (f("encoder.layer_norm.weight"), f("encoder.layer_norm.bias"))
+        self.layers = []
+        for i in range(self.n_layers):
+            q = f"encoder.layers.{i}."
+            self.layers.append(dict(
+                wqkv=torch.cat([f(q + f"attention.{n}_proj.weight") for n in "qkv"], 0).contiguous(),
+                bqkv=torch.cat([f(q + f"attention.{n}_proj.bias") for n in "qkv"], 0).contiguous(),
+                wo=f(q + "attention.out_proj.weight"), bo=f(q + "attention.out_proj.bias"),
+                ln1=(f(q + "layer_norm.weight"), f(q + "layer_norm.bias")),
+                w1=f(q + "feed_forward.intermediate_dense.weight"), b1=f(q + "feed_forward.intermediate_dense.bias"),
+                w2=f(q + "feed_forward.output_dense.weight"), b2=f(q + "feed_forward.output_dense.bias"),
+                ln2=(f(q + "final_layer_norm.weight"), f(q + "final_layer_norm.bias"))))
+
+    # ---- launch helpers -------------------------------------------------------------------------------------------
+    def _buf(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def _linear(self, L, stream, x, w, bias, act=0, res=None):
+        rows, k = x.shape[0] * x.shape[1], x.shape[2]
+        n = w.shape[0]
+        y = self._buf(x.shape[0], x.shape[1], n)
+        st = L.ts_w2v_linear_fwd(x.data_ptr(), k, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 res.data_ptr() if res is not None else None, n, y.data_ptr(), n, rows, n, k, act, stream)
+        _lib.check(st, "ts_w2v_linear_fwd")
+        return y
+
+    def _ln(self, L, stream, x, wb, res=None):
+        y = torch.empty_like(x)
+        st = L.ts_w2v_layernorm_fwd(x.data_ptr(), res.data_ptr() if res is not None else None, wb[0].data_ptr(), wb[1].data_ptr(),
+                                    self.eps, x.shape[0] * x.shape[1], x.shape[2], y.data_ptr(), stream)
+        _lib.check(st, "ts_w2v_layernorm_fwd")
+        return y
+
+    def feature_extractor(self, audio: torch.Tensor) -> torch.Tensor:
+        """[B, n] fp32 -> [B, T', C_last] (time-major)."""
+        L = _lib.lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        b, n = audio.shape
+        k0, s0, c0 = self.kernels[0], self.strides[0], self.dims[0]
+        if n < k0:
+            raise RuntimeError(f"wav2vec2: input of {n} samples is shorter than the first conv kernel ({k0})")
+        t = (n - k0) // s0 + 1
+        ws = self._buf(L.ts_w2v_conv0_workspace_bytes(b, n, c0, k0, s0), dtype=torch.uint8)
+        h = self._buf(b, t, c0)
+        _lib.check(L.ts_w2v_conv0_fwd(audio.data_ptr(), b, n, self.w0.data_ptr(), self.gn_w.data_ptr(), self.gn_b.data_ptr(), c0, k0,
+                                      s0, 1e-5, h.data_ptr(), ws.data_ptr(), stream), "ts_w2v_conv0_fwd")
+        for i, w in enumerate(self.conv_w, start=1):
+            k, s = self.kernels[i], self.strides[i]
+            t_out = (t - k) // s + 1
+            if t_out < 1:
+                raise RuntimeError("wav2vec2: input too short for the conv feature extractor")
+            y = self._buf(b, t_out, self.dims[i])
+            _lib.check(L.ts_w2v_conv_fwd(h.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self.dims[i], k, s, y.data_ptr(), stream),
+                       "ts_w2v_conv_fwd")
+            h, t = y, t_out
+        return h
+
+    def forward(self, audio: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+        """audio [B, n] fp32 on the GPU; lengths = samples per clip when the model was trained with an attention mask
+        (`mask_input`), else None.  Returns last_hidden_state [B, T', C] (time-major)."""
+        L = _lib.lib()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        feats = self.feature_extractor(audio)
+        b, t, _ = feats.shape
+        c = self.hidden
+        h = self._linear(L, stream, self._ln(L, stream, feats, self.fp_ln), self.fp_w, self.fp_b)
+        key_len = None
+        if lengths is not None:
+            key_len = feat_extract_output_lengths(self.kernels, self.strides, lengths.to(self.device).long()).to(torch.int32).contiguous()
+            _lib.check(L.ts_w2v_mask_rows(h.data_ptr(), b, t, c, key_len.data_ptr(), stream), "ts_w2v_mask_rows")
+        ws = self._buf(L.ts_w2v_posconv_workspace_bytes(b, t, c, self.kpos), dtype=torch.uint8)
+        hp = torch.empty_like(h)
+        _lib.check(L.ts_w2v_posconv_fwd(h.data_ptr(), b, t, c, self.pos_w.data_ptr(), self.pos_b.data_ptr(), self.kpos, self.groups,
+                                        hp.data_ptr(), ws.data_ptr(), stream), "ts_w2v_posconv_fwd")
+        del ws
+        h = self._ln(L, stream, hp, self.enc_ln)
+        att_ws = self._buf(L.ts_w2v_attention_workspace_bytes(b, t, self.heads), dtype=torch.uint8)
+        for lw in self.layers:
+            qkv = self._linear(L, stream, h, lw["wqkv"], lw["bqkv"])
+            ctx = self._buf(b, t, c)
+            _lib.check(L.ts_w2v_attention_fwd(qkv.data_ptr(), b, t, c, self.heads, key_len.data_ptr() if key_len is not None else None,
+                                              ctx.data_ptr(), att_ws.data_ptr(), stream), "ts_w2v_attention_fwd")
+            h = self._ln(L, stream, self._linear(L, stream, ctx, lw["wo"], lw["bo"]), lw["ln1"], res=h)
+            ff = self._linear(L, stream, self._linear(L, stream, h, lw["w1"], lw["b1"], act=1), lw["w2"], lw["b2"])
+            h = self._ln(L, stream, ff, lw["ln2"], res=h)
+        return h
+
+
+class HuggingFaceEncoderAdapt(nn.Module):
+    """Same constructor, attributes and return convention as the reference's `_HuggingFaceEncoderAdapt`
+    (huggingface/compatibility.py:23-42): `(audio [B, n], lengths) -> (features [B, C, T'], lengths')`."""
+
+    def __init__(self, encoder, mask_input: bool = False):
+        super().__init__()
+        self.original_encoder = encoder
+        if hasattr(self.original_encoder, "freeze_feature_encoder"):
+            self.original_encoder.freeze_feature_encoder()
+        self.mask_input = mask_input
+        self._cache = _PackedCache()
+        _check_config(encoder.config)
+
+    def _plan(self, device) -> Wav2Vec2Plan:
+        params = list(self.original_encoder.parameters())
+        return self._cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, self.original_encoder.state_dict(), device))
+
+    def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        _t.require_gpu(audio, "wav2vec2 encoder")
+        if self.training:
+            raise NotImplementedError("wav2vec2 HIP path: inference only (no backward kernels yet); call .eval()")
+        x = audio.to(torch.float32).contiguous()
+        h = self._plan(x.device).forward(x, audio_lengths if self.mask_input else None)
+        cfg = self.original_encoder.config
+        return h.transpose(-1, -2), feat_extract_output_lengths(cfg.conv_kernel, cfg.conv_stride, audio_lengths)
