@@ -213,35 +213,39 @@ int ts_w2v_preprocess(const float* wave, const int32_t* wave_len, int32_t batch,
  * group-norm / post-LN checkpoints (wav2vec2-base-960h, -large-960h).  One entry point per stage of that forward pass;
  * all activations f32, TIME-MAJOR [B][T][C] (the reference's final transpose(-1, -2) is a view).  GEMMs are rocBLAS calls.
  * ---------------------------------------------------------------------------------------------- */
+/* `precision` (all GEMM-carrying entry points): 0 = f32 operands; 1 = bf16 operands (x / w / qkv pointers are bf16), f32
+ * accumulation and f32 results.  `y_bf16` (may be NULL): a dense bf16 copy of the result for the next GEMM, written by the
+ * same launch -- there is no separate cast pass. */
 /* conv layer 0: Conv1d(1, c, kernel, stride, bias=False) -> GroupNorm(c groups, eps) -> GELU.
- * wave f32 [B][n_samples]; w f32 [c][kernel]; y f32 [B][(n_samples - kernel) / stride + 1][c]. */
+ * wave f32 [B][n_samples]; w f32 [c][kernel]; y f32 (may be NULL if y_bf16 is given) [B][(n_samples - kernel) / stride + 1][c]. */
 int64_t ts_w2v_conv0_workspace_bytes(int32_t batch, int64_t n_samples, int32_t c, int32_t kernel, int32_t stride);
 int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const float* w, const float* gn_w, const float* gn_b,
-                     int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* workspace, void* stream);
+                     int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* y_bf16, void* workspace, void* stream);
 /* conv layers 1..6: Conv1d(c_in, c_out, kernel, stride, bias=False) -> GELU.  x [B][t_in][c_in];
- * w_taps f32 [kernel][c_out][c_in] (tap-major repack of the reference's [c_out][c_in][kernel]); y [B][t_out][c_out]. */
-int ts_w2v_conv_fwd(const float* x, int32_t batch, int32_t t_in, int32_t c_in, const float* w_taps, int32_t c_out, int32_t kernel,
-                    int32_t stride, float* y, void* stream);
-/* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W f32 [n][k]; bias / res may be NULL; act 0 = none, 1 = GELU (erf).
+ * w_taps [kernel][c_out][c_in] (tap-major repack of the reference's [c_out][c_in][kernel]); y f32 [B][t_out][c_out]. */
+int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, int32_t c_out, int32_t kernel,
+                    int32_t stride, int32_t precision, float* y, void* y_bf16, void* stream);
+/* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act 0 = none, 1 = GELU (erf).
  * lda / ldc / ld_res: row pitches in elements. */
-int ts_w2v_linear_fwd(const float* x, int64_t lda, const float* w, const float* bias, const float* res, int64_t ld_res, float* y,
-                      int64_t ldc, int64_t rows, int32_t n, int32_t k, int32_t act, void* stream);
+int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res, float* y,
+                      int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision, void* stream);
 /* y = LayerNorm(x + res) * w + b over the last dimension (res may be NULL); x, res, y f32 [rows][c]. */
 int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float eps, int64_t rows, int32_t c,
-                         float* y, void* stream);
+                         float* y, void* y_bf16, void* stream);
 /* hidden_states[~attention_mask] = 0: rows >= len[b] of x [B][t][c] become 0. */
 int ts_w2v_mask_rows(float* x, int32_t batch, int32_t t, int32_t c, const int32_t* len, void* stream);
 /* positional conv embedding: y = x + gelu(Conv1d(c, c, kernel, padding = kernel / 2, groups)(x) + bias), last frame of an
- * even kernel dropped (Wav2Vec2SamePadLayer).  w_taps f32 [kernel][groups][c/groups (out)][c/groups (in)], weight-norm
+ * even kernel dropped (Wav2Vec2SamePadLayer).  x, y f32; w_taps [kernel][groups][c/groups (out)][c/groups (in)], weight-norm
  * already applied. */
 int64_t ts_w2v_posconv_workspace_bytes(int32_t batch, int32_t t, int32_t c, int32_t kernel);
-int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const float* w_taps, const float* bias, int32_t kernel,
-                       int32_t groups, float* y, void* workspace, void* stream);
-/* self-attention core: qkv f32 [B][t][3c] (q | k | v, heads are contiguous column blocks), softmax(q k^T / sqrt(c / heads)) v
- * -> ctx f32 [B][t][c].  key_len int32 [B] or NULL: keys >= key_len[b] get probability 0 (the reference's additive mask). */
-int64_t ts_w2v_attention_workspace_bytes(int32_t batch, int32_t t, int32_t heads);
-int ts_w2v_attention_fwd(const float* qkv, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len, float* ctx,
-                         void* workspace, void* stream);
+int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias, int32_t kernel,
+                       int32_t groups, int32_t precision, float* y, void* y_bf16, void* workspace, void* stream);
+/* self-attention core: qkv [B][t][3c] (q | k | v, heads are contiguous column blocks), softmax(q k^T / sqrt(c / heads)) v
+ * -> ctx [B][t][c]; qkv and ctx are f32 (precision 0) or bf16 (precision 1), scores and softmax f32.
+ * key_len int32 [B] or NULL: keys >= key_len[b] get probability 0 (the reference's additive mask). */
+int64_t ts_w2v_attention_workspace_bytes(int32_t batch, int32_t t, int32_t heads, int32_t precision);
+int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len,
+                         int32_t precision, void* ctx, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].

@@ -22,10 +22,22 @@ def _hf_cfg(cfg: ow.W2VConfig):
                            feat_extract_activation="gelu")
 
 
-def _plan():
+def _plan(precision="fp32"):
     from thunder_speech_amd.huggingface.encoder import Wav2Vec2Plan
     z, sd, cfg = load_fixture()
-    return z, sd, cfg, Wav2Vec2Plan(_hf_cfg(cfg), sd, "cuda")
+    return z, sd, cfg, Wav2Vec2Plan(_hf_cfg(cfg), sd, "cuda", precision=precision)
+
+
+def test_bf16_operand_mode_stays_within_bf16_tolerance_of_the_fp32_reference():
+    """precision="bf16": GEMM operands rounded to bf16 (8 mantissa bits), fp32 accumulation and normalisations.  The
+    outputs are LayerNorm-ed (unit scale): a few 1e-2 absolute is what operand rounding through 2 layers gives."""
+    z, sd, cfg, plan = _plan("bf16")
+    x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
+    out = plan.forward(x.cuda(), None).cpu().numpy()
+    assert np.abs(out - z["out"]).max() <= 0.06 and np.sqrt(np.mean((out - z["out"]) ** 2)) <= 0.01
+    xm = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
+    outm = plan.forward(xm.cuda(), lengths.cuda()).cpu().numpy()
+    assert np.abs(outm - z["out_masked"]).max() <= 0.06 and np.sqrt(np.mean((outm - z["out_masked"]) ** 2)) <= 0.01
 
 
 def test_feature_extractor_matches_transformers_fixture():
@@ -77,7 +89,7 @@ def test_adapter_has_the_reference_interface():
         num_conv_pos_embeddings=cfg.num_conv_pos_embeddings, num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups)
     model = transformers.Wav2Vec2Model(hf_cfg).eval()
     model.load_state_dict(sd)
-    enc = HuggingFaceEncoderAdapt(model.cuda(), mask_input=False).eval()
+    enc = HuggingFaceEncoderAdapt(model.cuda(), mask_input=False, precision="fp32").eval()
     assert "original_encoder.encoder.layers.0.attention.q_proj.weight" in enc.state_dict()
     x = torch.from_numpy(z["x"]).cuda()
     lengths = torch.from_numpy(z["lengths"]).cuda()

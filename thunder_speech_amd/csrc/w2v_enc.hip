@@ -11,8 +11,10 @@
 //   ts_w2v_layernorm_fwd  y = LN(x [+ res])
 //   ts_w2v_posconv_fwd    y = x + gelu(grouped conv(x) + b): one batched GEMM per tap over a zero-padded copy
 //   ts_w2v_attention_fwd  softmax(q k^T * scale [keys >= len masked]) v per (clip, head)
-// The GEMMs are plain library calls (rocBLAS sgemm_strided_batched); everything else is hand-written here.  This version
-// exists for parity and coverage of config C5; MFMA attention / fused bf16 kernels are the follow-up.
+// The GEMMs are plain library calls (rocBLAS gemm_strided_batched_ex); everything else is hand-written here.
+// precision 0: fp32 GEMMs (tight parity with the fp32 reference).  precision 1: the GEMM operands are bf16 (MFMA rate),
+// accumulation, residual stream, normalisations and softmax stay fp32; every producer writes the bf16 copy its consumer
+// needs next to (or instead of) the fp32 result, so no separate cast pass exists.  Fused MFMA attention is the follow-up.
 #include "ts_blas.hpp"
 
 namespace ts {
@@ -32,7 +34,8 @@ struct Conv0Args {
   const float* beta;
   float* partial;                   // [B][chunks][C][2]
   float* stats;                     // [B][C][2] = (scale, shift)
-  float* y;                         // [B][T0][C]
+  float* y;                         // [B][T0][C] (may be null when only the bf16 copy is wanted)
+  unsigned short* y16;              // optional bf16 copy
   long long n;
   int t0, c, k, s, chunks;
   float eps;
@@ -54,12 +57,14 @@ __global__ __launch_bounds__(256) void w2v_conv0_kernel(const Conv0Args a) {
     for (int j = 0; j < C0_KMAX; ++j) w[j] = j < a.k ? a.w[(size_t)c * a.k + j] : 0.f;
     if constexpr (APPLY) {
       const float scale = a.stats[((size_t)b * a.c + c) * 2], shift = a.stats[((size_t)b * a.c + c) * 2 + 1];
-      float* out = a.y + ((size_t)b * a.t0 + f0) * a.c + c;
+      const size_t o0 = ((size_t)b * a.t0 + f0) * a.c + c;
       for (int f = 0; f < nf; ++f) {
         float v = 0.f;
 #pragma unroll
         for (int j = 0; j < C0_KMAX; ++j) if (j < a.k) v = fmaf(w[j], sig[f * a.s + j], v);
-        out[(size_t)f * a.c] = gelu_erf(fmaf(v, scale, shift));
+        v = gelu_erf(fmaf(v, scale, shift));
+        if (a.y) a.y[o0 + (size_t)f * a.c] = v;
+        if (a.y16) a.y16[o0 + (size_t)f * a.c] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
       }
     } else {
       float s1 = 0.f, s2 = 0.f;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void w2v_conv0_finalize_kernel(const Conv0Args
 // y[r][c] = act(y[r][c] + bias[c]) (+ res[r][c]); ld = row pitch of y and res; n % 4 == 0 path is vectorised
 __global__ __launch_bounds__(256) void w2v_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                            const float* __restrict__ res, long long rows, int n, long long ld,
-                                                           long long ld_res, int act) {
+                                                           long long ld_res, int act, unsigned short* __restrict__ y16) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int n4 = n >> 2;
   if (idx >= rows * n4) return;
@@ -120,12 +125,14 @@ __global__ __launch_bounds__(256) void w2v_bias_act_kernel(float* __restrict__ y
     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
   }
   *reinterpret_cast<float4*>(y + r * ld + c) = v;
+  if (y16) *reinterpret_cast<uint2*>(y16 + r * n + c) = uint2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};     // dense [rows][n]
 }
 
 // one wavefront per row: y = LN(x (+ res)) * w + b
 __global__ __launch_bounds__(256) void w2v_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            float* __restrict__ y, long long rows, int c, float eps) {
+                                                            float* __restrict__ y, long long rows, int c, float eps,
+                                                            unsigned short* __restrict__ y16) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -143,7 +150,11 @@ __global__ __launch_bounds__(256) void w2v_layernorm_kernel(const float* __restr
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   const float rs = rsqrtf(q / c + eps);
   float* yr = y + row * c;
-  for (int i = lane; i < c; i += 64) yr[i] = (xr[i] + (rr ? rr[i] : 0.f) - mu) * rs * w[i] + b[i];
+  for (int i = lane; i < c; i += 64) {
+    const float v = (xr[i] + (rr ? rr[i] : 0.f) - mu) * rs * w[i] + b[i];
+    yr[i] = v;
+    if (y16) y16[row * c + i] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
+  }
 }
 
 // rows >= len[b] of a [B][T][C] tensor become 0 (hidden_states[~attention_mask] = 0)
@@ -159,7 +170,8 @@ __global__ __launch_bounds__(256) void w2v_mask_rows_kernel(float* __restrict__ 
 // positional conv: zero-padded copy in, bias + GELU + residual out
 // ---------------------------------------------------------------------------------------------------------------------
 // xp: [B][T + k][C] with k/2 zero rows before and k - k/2 after each clip
-__global__ __launch_bounds__(256) void w2v_pad_rows_kernel(const float* __restrict__ x, float* __restrict__ xp, int t, int c, int k) {
+template <typename T>
+__global__ __launch_bounds__(256) void w2v_pad_rows_kernel(const float* __restrict__ x, T* __restrict__ xp, int t, int c, int k) {
   const int b = blockIdx.y;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)(t + k) * c;
@@ -167,7 +179,9 @@ __global__ __launch_bounds__(256) void w2v_pad_rows_kernel(const float* __restri
   const long long r = idx / c;
   const int col = (int)(idx - r * c);
   const long long src = r - k / 2;
-  xp[(size_t)b * total + idx] = (src >= 0 && src < t) ? x[((size_t)b * t + src) * c + col] : 0.f;
+  const float v = (src >= 0 && src < t) ? x[((size_t)b * t + src) * c + col] : 0.f;
+  if constexpr (sizeof(T) == 2) xp[(size_t)b * total + idx] = (T)(pack_bf16(v, 0.f) & 0xffffu);
+  else xp[(size_t)b * total + idx] = v;
 }
 
 __global__ __launch_bounds__(256) void w2v_posconv_finish_kernel(const float* __restrict__ x, const float* __restrict__ yp,
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(256) void w2v_posconv_finish_kernel(const float* __
 // attention softmax: one wavefront per (clip, head, query) row of scores [B][H][T][T], in place
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void w2v_softmax_kernel(float* __restrict__ s, const int* __restrict__ key_len, int heads, int t,
-                                                          float scale) {
+                                                          float scale, unsigned short* __restrict__ p16) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const long long rows = (long long)gridDim.y * heads * t;
@@ -205,18 +219,27 @@ __global__ __launch_bounds__(256) void w2v_softmax_kernel(float* __restrict__ s,
   for (int i = lane; i < lim; i += 64) z += __expf(p[i] * scale - m);
   for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
   const float rz = 1.f / z;
-  for (int i = lane; i < t; i += 64) p[i] = i < lim ? __expf(p[i] * scale - m) * rz : 0.f;
+  unsigned short* q = p16 ? p16 + ((size_t)b * heads * t + row) * t : nullptr;
+  for (int i = lane; i < t; i += 64) {
+    const float v = i < lim ? __expf(p[i] * scale - m) * rz : 0.f;
+    if (q) q[i] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
+    else p[i] = v;
+  }
 }
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
-// row-major y[M][N] (ldc) = alpha x[M][K] (lda) W[N][K]^T (ldw) + beta y, batched with element strides
-static int gemm_nt(rocblas_handle h, long long m, int n, int k, const float* x, long long lda, long long sx, const float* w,
-                   long long ldw, long long sw, float* y, long long ldc, long long sy, float beta, int batch) {
+// row-major y[M][N] (ldc) = x[M][K] (lda) W[N][K]^T (ldw) + beta y, batched with element strides.  bf16 = x and W are bf16;
+// y is f32 (or bf16 when y16 is set), accumulation f32 either way.
+static int gemm_nt(rocblas_handle h, bool bf16, long long m, int n, int k, const void* x, long long lda, long long sx, const void* w,
+                   long long ldw, long long sw, void* y, long long ldc, long long sy, float beta, int batch, bool y16 = false) {
   const float one = 1.f;
-  const rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, n, (rocblas_int)m, k,
-                                                          &one, w, (rocblas_int)ldw, sw, x, (rocblas_int)lda, sx, &beta, y,
-                                                          (rocblas_int)ldc, sy, batch);
+  const rocblas_datatype in = bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
+  const rocblas_datatype out = y16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
+  const rocblas_status st = rocblas_gemm_strided_batched_ex(h, rocblas_operation_transpose, rocblas_operation_none, n, (rocblas_int)m, k,
+                                                            &one, w, in, (rocblas_int)ldw, sw, x, in, (rocblas_int)lda, sx, &beta, y, out,
+                                                            (rocblas_int)ldc, sy, y, out, (rocblas_int)ldc, sy, batch,
+                                                            rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
   return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
 }
 
@@ -235,13 +258,14 @@ extern "C" int64_t ts_w2v_conv0_workspace_bytes(int32_t batch, int64_t n_samples
 }
 
 extern "C" int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const float* w, const float* gn_w,
-                                const float* gn_b, int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* workspace,
-                                void* stream_) {
-  if (!wave || !w || !gn_w || !gn_b || !y || !workspace || batch <= 0 || c <= 0 || stride <= 0 || n_samples < kernel) return TS_EINVAL;
+                                const float* gn_b, int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* y_bf16,
+                                void* workspace, void* stream_) {
+  if (!wave || !w || !gn_w || !gn_b || (!y && !y_bf16) || !workspace || batch <= 0 || c <= 0 || stride <= 0 || n_samples < kernel) return TS_EINVAL;
   if (kernel <= 0 || kernel > C0_KMAX) return TS_EUNSUPPORTED;
   TS_STREAM;
   Conv0Args a{};
-  a.wave = wave; a.w = w; a.gamma = gn_w; a.beta = gn_b; a.y = y; a.n = n_samples; a.c = c; a.k = kernel; a.s = stride; a.eps = eps;
+  a.wave = wave; a.w = w; a.gamma = gn_w; a.beta = gn_b; a.y = y; a.y16 = static_cast<unsigned short*>(y_bf16);
+  a.n = n_samples; a.c = c; a.k = kernel; a.s = stride; a.eps = eps;
   a.t0 = conv_frames(n_samples, kernel, stride);
   a.chunks = (a.t0 + C0_FR - 1) / C0_FR;
   a.partial = static_cast<float*>(workspace);
@@ -254,45 +278,49 @@ extern "C" int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samp
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_w2v_conv_fwd(const float* x, int32_t batch, int32_t t_in, int32_t c_in, const float* w_taps, int32_t c_out,
-                               int32_t kernel, int32_t stride, float* y, void* stream_) {
+extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, int32_t c_out,
+                               int32_t kernel, int32_t stride, int32_t precision, float* y, void* y_bf16, void* stream_) {
   if (!x || !w_taps || !y || batch <= 0 || c_in <= 0 || c_out <= 0 || kernel <= 0 || stride <= 0 || t_in < kernel) return TS_EINVAL;
-  if (c_out % 4) return TS_EUNSUPPORTED;
+  if (c_out % 4 || precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
   const int t_out = conv_frames(t_in, kernel, stride);
+  const size_t es = precision ? 2 : 4;
   for (int j = 0; j < kernel; ++j) {
     // rows stride*t + j of clip b: a [t_out x c_in] matrix with row pitch stride * c_in
-    if (int st = gemm_nt(h, t_out, c_out, c_in, x + (size_t)j * c_in, (long long)stride * c_in, (long long)t_in * c_in,
-                         w_taps + (size_t)j * c_out * c_in, c_in, 0, y, c_out, (long long)t_out * c_out, j ? 1.f : 0.f, batch))
+    if (int st = gemm_nt(h, precision != 0, t_out, c_out, c_in, static_cast<const char*>(x) + (size_t)j * c_in * es, (long long)stride * c_in,
+                         (long long)t_in * c_in, static_cast<const char*>(w_taps) + (size_t)j * c_out * c_in * es, c_in, 0, y, c_out,
+                         (long long)t_out * c_out, j ? 1.f : 0.f, batch))
       return st;
   }
   const long long rows = (long long)batch * t_out;
   hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (c_out / 4))), dim3(256), 0, stream, y, (const float*)nullptr,
-                     (const float*)nullptr, rows, c_out, (long long)c_out, 0LL, 1);
+                     (const float*)nullptr, rows, c_out, (long long)c_out, 0LL, 1, static_cast<unsigned short*>(y_bf16));
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_w2v_linear_fwd(const float* x, int64_t lda, const float* w, const float* bias, const float* res, int64_t ld_res,
-                                 float* y, int64_t ldc, int64_t rows, int32_t n, int32_t k, int32_t act, void* stream_) {
+extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res,
+                                 float* y, int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision,
+                                 void* stream_) {
   if (!x || !w || !y || rows <= 0 || n <= 0 || k <= 0 || lda < k || ldc < n || (res && ld_res < n)) return TS_EINVAL;
-  if (n % 4 || ldc % 4 || (res && ld_res % 4) || act < 0 || act > 1) return TS_EUNSUPPORTED;
+  if (n % 4 || ldc % 4 || (res && ld_res % 4) || act < 0 || act > 1 || precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
-  if (int st = gemm_nt(h, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, 0.f, 1)) return st;
-  if (bias || res || act)
+  if (int st = gemm_nt(h, precision != 0, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, 0.f, 1)) return st;
+  if (bias || res || act || y_bf16)
     hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (n / 4))), dim3(256), 0, stream, y, bias, res, (long long)rows, n,
-                       (long long)ldc, (long long)ld_res, act);
+                       (long long)ldc, (long long)ld_res, act, static_cast<unsigned short*>(y_bf16));
   return hip_status(hipGetLastError());
 }
 
 extern "C" int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float eps, int64_t rows,
-                                    int32_t c, float* y, void* stream_) {
+                                    int32_t c, float* y, void* y_bf16, void* stream_) {
   if (!x || !w || !b || !y || rows <= 0 || c <= 0) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(w2v_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, w, b, y, (long long)rows, c, eps);
+  hipLaunchKernelGGL(w2v_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, w, b, y, (long long)rows, c, eps,
+                     static_cast<unsigned short*>(y_bf16));
   return hip_status(hipGetLastError());
 }
 
@@ -308,21 +336,29 @@ extern "C" int64_t ts_w2v_posconv_workspace_bytes(int32_t batch, int32_t t, int3
   return (int64_t)2 * batch * (t + kernel) * c * sizeof(float);
 }
 
-extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const float* w_taps, const float* bias,
-                                  int32_t kernel, int32_t groups, float* y, void* workspace, void* stream_) {
+extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias,
+                                  int32_t kernel, int32_t groups, int32_t precision, float* y, void* y_bf16, void* workspace,
+                                  void* stream_) {
   if (!x || !w_taps || !bias || !y || !workspace || batch <= 0 || t <= 0 || c <= 0 || kernel <= 0 || groups <= 0 || c % groups) return TS_EINVAL;
+  if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
+  (void)y_bf16;
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
   const int cg = c / groups;
   const long long prow = (long long)t + kernel;                       // padded rows per clip
-  float* xp = static_cast<float*>(workspace);
-  float* yp = xp + (size_t)batch * prow * c;
-  hipLaunchKernelGGL(w2v_pad_rows_kernel, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x, xp, t, c, kernel);
+  // workspace: yp f32 [B (t+k)][c] first, then the padded copy (f32 or bf16)
+  float* yp = static_cast<float*>(workspace);
+  char* xp = reinterpret_cast<char*>(yp + (size_t)batch * prow * c);
+  const size_t es = precision ? 2 : 4;
+  if (precision) hipLaunchKernelGGL(w2v_pad_rows_kernel<unsigned short>, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x,
+                                    reinterpret_cast<unsigned short*>(xp), t, c, kernel);
+  else hipLaunchKernelGGL(w2v_pad_rows_kernel<float>, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x, reinterpret_cast<float*>(xp), t, c, kernel);
   // all clips at once: output row r (over the padded row space) = sum_j xp[r + j] W_j^T, per group; rows between clips are waste
   const long long m = (long long)batch * prow - kernel;
   for (int j = 0; j < kernel; ++j) {
-    if (int st = gemm_nt(h, m, cg, cg, xp + (size_t)j * c, c, cg, w_taps + (size_t)j * groups * cg * cg, cg, (long long)cg * cg, yp, c, cg,
+    if (int st = gemm_nt(h, precision != 0, m, cg, cg, xp + (size_t)j * c * es, c, cg,
+                         static_cast<const char*>(w_taps) + (size_t)j * groups * cg * cg * es, cg, (long long)cg * cg, yp, c, cg,
                          j ? 1.f : 0.f, groups))
       return st;
   }
@@ -330,34 +366,42 @@ extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int3
   return hip_status(hipGetLastError());
 }
 
-extern "C" int64_t ts_w2v_attention_workspace_bytes(int32_t batch, int32_t t, int32_t heads) {
+extern "C" int64_t ts_w2v_attention_workspace_bytes(int32_t batch, int32_t t, int32_t heads, int32_t precision) {
   if (batch <= 0 || t <= 0 || heads <= 0) return TS_EINVAL;
-  return (int64_t)batch * heads * t * t * sizeof(float);
+  return (int64_t)batch * heads * t * t * (sizeof(float) + (precision ? 2 : 0));
 }
 
-extern "C" int ts_w2v_attention_fwd(const float* qkv, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len,
-                                    float* ctx, void* workspace, void* stream_) {
+extern "C" int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len,
+                                    int32_t precision, void* ctx, void* workspace, void* stream_) {
   if (!qkv || !ctx || !workspace || batch <= 0 || t <= 0 || c <= 0 || heads <= 0 || c % heads) return TS_EINVAL;
+  if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
   const int hd = c / heads;
+  const bool bf = precision != 0;
+  const size_t es = bf ? 2 : 4;
   float* s = static_cast<float*>(workspace);
-  const float one = 1.f, zero = 0.f;
+  unsigned short* p16 = bf ? reinterpret_cast<unsigned short*>(s + (size_t)batch * heads * t * t) : nullptr;
   for (int b = 0; b < batch; ++b) {
-    const float* q = qkv + (size_t)b * t * 3 * c;
+    const char* q = static_cast<const char*>(qkv) + (size_t)b * t * 3 * c * es;
     // scores[query][key] = q . k : batched over the heads (head h = columns [h hd, (h+1) hd) of each third of a qkv row)
-    if (int st = gemm_nt(h, t, t, hd, q, 3LL * c, hd, q + c, 3LL * c, hd, s + (size_t)b * heads * t * t, t, (long long)t * t, 0.f, heads))
+    if (int st = gemm_nt(h, bf, t, t, hd, q, 3LL * c, hd, q + (size_t)c * es, 3LL * c, hd, s + (size_t)b * heads * t * t, t,
+                         (long long)t * t, 0.f, heads))
       return st;
   }
   hipLaunchKernelGGL(w2v_softmax_kernel, dim3((unsigned)(((long long)heads * t + 3) / 4), batch), dim3(256), 0, stream, s, key_len, heads, t,
-                     1.f / sqrtf((float)hd));
+                     1.f / sqrtf((float)hd), p16);
+  const float one = 1.f, zero = 0.f;
+  const rocblas_datatype dt = bf ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
   for (int b = 0; b < batch; ++b) {
-    const float* v = qkv + (size_t)b * t * 3 * c + 2 * c;
-    // ctx[query][d] = sum_key p[query][key] v[key][d]   (column-major view: ctx^T = v^T p^T, no transposes)
-    const rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, hd, t, t, &one, v, 3 * c, hd,
-                                                            s + (size_t)b * heads * t * t, t, (rocblas_stride)t * t, &zero,
-                                                            ctx + (size_t)b * t * c, c, hd, heads);
+    const char* v = static_cast<const char*>(qkv) + ((size_t)b * t * 3 * c + 2 * c) * es;
+    const void* p = bf ? static_cast<const void*>(p16 + (size_t)b * heads * t * t) : static_cast<const void*>(s + (size_t)b * heads * t * t);
+    void* out = static_cast<char*>(ctx) + (size_t)b * t * c * es;
+    // ctx[query][d] = sum_key p[query][key] v[key][d]   (column-major view: ctx^T = v^T p^T, no transposes); bf16 in -> bf16 out
+    const rocblas_status st = rocblas_gemm_strided_batched_ex(h, rocblas_operation_none, rocblas_operation_none, hd, t, t, &one, v, dt, 3 * c, hd,
+                                                              p, dt, t, (rocblas_stride)t * t, &zero, out, dt, c, hd, out, dt, c, hd, heads,
+                                                              rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
     if (st != rocblas_status_success) return TS_EUNSUPPORTED;
   }
   return hip_status(hipGetLastError());

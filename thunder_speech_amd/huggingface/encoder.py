@@ -45,11 +45,17 @@ def _check_config(cfg) -> None:
 
 
 class Wav2Vec2Plan:
-    """Packed weights + launch sequence for one set of encoder weights (HF state-dict keys, see oracle/w2v.py)."""
+    """Packed weights + launch sequence for one set of encoder weights (HF state-dict keys, see oracle/w2v.py).
+    precision "fp32": every GEMM in fp32; "bf16": GEMM operands in bf16 (fp32 accumulation, fp32 residual stream /
+    normalisations / softmax) -- each launch also writes the bf16 copy its consumer multiplies with."""
 
-    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device):
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device, precision: str = "bf16"):
         _check_config(cfg)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.prec = 1 if precision == "bf16" else 0
         f = lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+        gw = (lambda t: t.to(torch.bfloat16).contiguous()) if self.prec else (lambda t: t.contiguous())     # GEMM operand
         self.device = torch.device(device)
         self.kernels = [int(k) for k in cfg.conv_kernel]
         self.strides = [int(s) for s in cfg.conv_stride]
@@ -64,10 +70,10 @@ class Wav2Vec2Plan:
         self.gn_w = f("feature_extractor.conv_layers.0.layer_norm.weight")
         self.gn_b = f("feature_extractor.conv_layers.0.layer_norm.bias")
         # [c_out][c_in][k] -> tap-major [k][c_out][c_in]: one GEMM per tap
-        self.conv_w = [f(f"feature_extractor.conv_layers.{i}.conv.weight").permute(2, 0, 1).contiguous()
+        self.conv_w = [gw(f(f"feature_extractor.conv_layers.{i}.conv.weight").permute(2, 0, 1))
                        for i in range(1, len(self.kernels))]
         self.fp_ln = (f("feature_projection.layer_norm.weight"), f("feature_projection.layer_norm.bias"))
-        self.fp_w, self.fp_b = f("feature_projection.projection.weight"), f("feature_projection.projection.bias")
+        self.fp_w, self.fp_b = gw(f("feature_projection.projection.weight")), f("feature_projection.projection.bias")
         # weight_norm(dim=2): w[:, :, j] = g[j] v[:, :, j] / ||v[:, :, j]||
         p = "encoder.pos_conv_embed.conv."
         if p + "parametrizations.weight.original0" in sd:
@@ -76,43 +82,53 @@ class Wav2Vec2Plan:
             g, v = f(p + "weight_g"), f(p + "weight_v")
         w_eff = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()                    # [C][C/g][k]
         cg = self.hidden // self.groups
-        self.pos_w = w_eff.view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2).contiguous()     # [k][g][out][in]
+        self.pos_w = gw(w_eff.view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2))   # [k][g][out][in]
         self.pos_b = f(p + "bias")
         self.enc_ln = (f("encoder.layer_norm.weight"), f("encoder.layer_norm.bias"))
         self.layers = []
         for i in range(self.n_layers):
             q = f"encoder.layers.{i}."
             self.layers.append(dict(
-                wqkv=torch.cat([f(q + f"attention.{n}_proj.weight") for n in "qkv"], 0).contiguous(),
+                wqkv=gw(torch.cat([f(q + f"attention.{n}_proj.weight") for n in "qkv"], 0)),
                 bqkv=torch.cat([f(q + f"attention.{n}_proj.bias") for n in "qkv"], 0).contiguous(),
-                wo=f(q + "attention.out_proj.weight"), bo=f(q + "attention.out_proj.bias"),
+                wo=gw(f(q + "attention.out_proj.weight")), bo=f(q + "attention.out_proj.bias"),
                 ln1=(f(q + "layer_norm.weight"), f(q + "layer_norm.bias")),
-                w1=f(q + "feed_forward.intermediate_dense.weight"), b1=f(q + "feed_forward.intermediate_dense.bias"),
-                w2=f(q + "feed_forward.output_dense.weight"), b2=f(q + "feed_forward.output_dense.bias"),
+                w1=gw(f(q + "feed_forward.intermediate_dense.weight")), b1=f(q + "feed_forward.intermediate_dense.bias"),
+                w2=gw(f(q + "feed_forward.output_dense.weight")), b2=f(q + "feed_forward.output_dense.bias"),
                 ln2=(f(q + "final_layer_norm.weight"), f(q + "final_layer_norm.bias"))))
 
-    # ---- launch helpers -------------------------------------------------------------------------------------------
+    # ---- launch helpers: every helper returns (fp32 result, GEMM operand for the next stage) ------------------------
     def _buf(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
-    def _linear(self, L, stream, x, w, bias, act=0, res=None):
-        rows, k = x.shape[0] * x.shape[1], x.shape[2]
-        n = w.shape[0]
-        y = self._buf(x.shape[0], x.shape[1], n)
-        st = L.ts_w2v_linear_fwd(x.data_ptr(), k, w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                 res.data_ptr() if res is not None else None, n, y.data_ptr(), n, rows, n, k, act, stream)
-        _lib.check(st, "ts_w2v_linear_fwd")
-        return y
+    def _op(self, *shape):
+        """Buffer for the GEMM-operand copy of a result (None in fp32 mode: the fp32 result is the operand)."""
+        return self._buf(*shape, dtype=torch.bfloat16) if self.prec else None
 
-    def _ln(self, L, stream, x, wb, res=None):
+    @staticmethod
+    def _ptr(t):
+        return t.data_ptr() if t is not None else None
+
+    def _linear(self, L, stream, x_op, w, bias, act=0, want_op=False):
+        b, t, k = x_op.shape
+        n = w.shape[0]
+        y = self._buf(b, t, n)
+        y_op = self._op(b, t, n) if want_op else None
+        st = L.ts_w2v_linear_fwd(x_op.data_ptr(), k, w.data_ptr(), self._ptr(bias), None, n, y.data_ptr(), n, self._ptr(y_op),
+                                 b * t, n, k, act, self.prec, stream)
+        _lib.check(st, "ts_w2v_linear_fwd")
+        return y, (y_op if self.prec else y)
+
+    def _ln(self, L, stream, x, wb, res=None, want_op=True):
         y = torch.empty_like(x)
-        st = L.ts_w2v_layernorm_fwd(x.data_ptr(), res.data_ptr() if res is not None else None, wb[0].data_ptr(), wb[1].data_ptr(),
-                                    self.eps, x.shape[0] * x.shape[1], x.shape[2], y.data_ptr(), stream)
+        y_op = self._op(*x.shape) if want_op else None
+        st = L.ts_w2v_layernorm_fwd(x.data_ptr(), self._ptr(res), wb[0].data_ptr(), wb[1].data_ptr(), self.eps,
+                                    x.shape[0] * x.shape[1], x.shape[2], y.data_ptr(), self._ptr(y_op), stream)
         _lib.check(st, "ts_w2v_layernorm_fwd")
-        return y
+        return y, (y_op if self.prec else y)
 
     def feature_extractor(self, audio: torch.Tensor) -> torch.Tensor:
-        """[B, n] fp32 -> [B, T', C_last] (time-major)."""
+        """[B, n] fp32 -> [B, T', C_last] fp32 (time-major)."""
         L = _lib.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         b, n = audio.shape
@@ -121,29 +137,36 @@ class Wav2Vec2Plan:
             raise RuntimeError(f"wav2vec2: input of {n} samples is shorter than the first conv kernel ({k0})")
         t = (n - k0) // s0 + 1
         ws = self._buf(L.ts_w2v_conv0_workspace_bytes(b, n, c0, k0, s0), dtype=torch.uint8)
-        h = self._buf(b, t, c0)
+        last = len(self.kernels) == 1
+        h = self._buf(b, t, c0) if (not self.prec or last) else None       # bf16 mode: the next conv only reads the bf16 copy
+        h_op = self._op(b, t, c0)
         _lib.check(L.ts_w2v_conv0_fwd(audio.data_ptr(), b, n, self.w0.data_ptr(), self.gn_w.data_ptr(), self.gn_b.data_ptr(), c0, k0,
-                                      s0, 1e-5, h.data_ptr(), ws.data_ptr(), stream), "ts_w2v_conv0_fwd")
+                                      s0, 1e-5, self._ptr(h), self._ptr(h_op), ws.data_ptr(), stream), "ts_w2v_conv0_fwd")
+        x_op = h_op if self.prec else h
         for i, w in enumerate(self.conv_w, start=1):
             k, s = self.kernels[i], self.strides[i]
             t_out = (t - k) // s + 1
             if t_out < 1:
                 raise RuntimeError("wav2vec2: input too short for the conv feature extractor")
+            last = i == len(self.kernels) - 1
             y = self._buf(b, t_out, self.dims[i])
-            _lib.check(L.ts_w2v_conv_fwd(h.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self.dims[i], k, s, y.data_ptr(), stream),
-                       "ts_w2v_conv_fwd")
+            y_op = None if last else self._op(b, t_out, self.dims[i])
+            _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self.dims[i], k, s, self.prec,
+                                         y.data_ptr(), self._ptr(y_op), stream), "ts_w2v_conv_fwd")
             h, t = y, t_out
+            x_op = y_op if self.prec else y
         return h
 
     def forward(self, audio: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
         """audio [B, n] fp32 on the GPU; lengths = samples per clip when the model was trained with an attention mask
-        (`mask_input`), else None.  Returns last_hidden_state [B, T', C] (time-major)."""
+        (`mask_input`), else None.  Returns last_hidden_state [B, T', C] fp32 (time-major)."""
         L = _lib.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         feats = self.feature_extractor(audio)
         b, t, _ = feats.shape
         c = self.hidden
-        h = self._linear(L, stream, self._ln(L, stream, feats, self.fp_ln), self.fp_w, self.fp_b)
+        _, ln_op = self._ln(L, stream, feats, self.fp_ln)
+        h, _ = self._linear(L, stream, ln_op, self.fp_w, self.fp_b)
         key_len = None
         if lengths is not None:
             key_len = feat_extract_output_lengths(self.kernels, self.strides, lengths.to(self.device).long()).to(torch.int32).contiguous()
@@ -151,18 +174,20 @@ class Wav2Vec2Plan:
         ws = self._buf(L.ts_w2v_posconv_workspace_bytes(b, t, c, self.kpos), dtype=torch.uint8)
         hp = torch.empty_like(h)
         _lib.check(L.ts_w2v_posconv_fwd(h.data_ptr(), b, t, c, self.pos_w.data_ptr(), self.pos_b.data_ptr(), self.kpos, self.groups,
-                                        hp.data_ptr(), ws.data_ptr(), stream), "ts_w2v_posconv_fwd")
+                                        self.prec, hp.data_ptr(), None, ws.data_ptr(), stream), "ts_w2v_posconv_fwd")
         del ws
-        h = self._ln(L, stream, hp, self.enc_ln)
-        att_ws = self._buf(L.ts_w2v_attention_workspace_bytes(b, t, self.heads), dtype=torch.uint8)
+        h, h_op = self._ln(L, stream, hp, self.enc_ln)
+        att_ws = self._buf(L.ts_w2v_attention_workspace_bytes(b, t, self.heads, self.prec), dtype=torch.uint8)
         for lw in self.layers:
-            qkv = self._linear(L, stream, h, lw["wqkv"], lw["bqkv"])
-            ctx = self._buf(b, t, c)
-            _lib.check(L.ts_w2v_attention_fwd(qkv.data_ptr(), b, t, c, self.heads, key_len.data_ptr() if key_len is not None else None,
-                                              ctx.data_ptr(), att_ws.data_ptr(), stream), "ts_w2v_attention_fwd")
-            h = self._ln(L, stream, self._linear(L, stream, ctx, lw["wo"], lw["bo"]), lw["ln1"], res=h)
-            ff = self._linear(L, stream, self._linear(L, stream, h, lw["w1"], lw["b1"], act=1), lw["w2"], lw["b2"])
-            h = self._ln(L, stream, ff, lw["ln2"], res=h)
+            _, qkv_op = self._linear(L, stream, h_op, lw["wqkv"], lw["bqkv"], want_op=True)
+            ctx_op = self._buf(b, t, c, dtype=torch.bfloat16 if self.prec else torch.float32)
+            _lib.check(L.ts_w2v_attention_fwd(qkv_op.data_ptr(), b, t, c, self.heads, self._ptr(key_len), self.prec, ctx_op.data_ptr(),
+                                              att_ws.data_ptr(), stream), "ts_w2v_attention_fwd")
+            o, _ = self._linear(L, stream, ctx_op, lw["wo"], lw["bo"])
+            h, h_op = self._ln(L, stream, o, lw["ln1"], res=h)
+            _, f1_op = self._linear(L, stream, h_op, lw["w1"], lw["b1"], act=1, want_op=True)
+            f2, _ = self._linear(L, stream, f1_op, lw["w2"], lw["b2"])
+            h, h_op = self._ln(L, stream, f2, lw["ln2"], res=h)
         return h
 
 
@@ -170,8 +195,9 @@ class HuggingFaceEncoderAdapt(nn.Module):
     """Same constructor, attributes and return convention as the reference's `_HuggingFaceEncoderAdapt`
     (huggingface/compatibility.py:23-42): `(audio [B, n], lengths) -> (features [B, C, T'], lengths')`."""
 
-    def __init__(self, encoder, mask_input: bool = False):
+    def __init__(self, encoder, mask_input: bool = False, precision: str = "bf16"):
         super().__init__()
+        self.precision = precision
         self.original_encoder = encoder
         if hasattr(self.original_encoder, "freeze_feature_encoder"):
             self.original_encoder.freeze_feature_encoder()
@@ -181,7 +207,7 @@ class HuggingFaceEncoderAdapt(nn.Module):
 
     def _plan(self, device) -> Wav2Vec2Plan:
         params = list(self.original_encoder.parameters())
-        return self._cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, self.original_encoder.state_dict(), device))
+        return self._cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, self.original_encoder.state_dict(), device, self.precision))
 
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "wav2vec2 encoder")
