@@ -98,3 +98,34 @@ def test_adapter_has_the_reference_interface():
     assert out.shape == (2, cfg.hidden_size, z["out"].shape[1])
     np.testing.assert_array_equal(out_len.cpu().numpy(), z["out_lengths"])
     np.testing.assert_allclose(out.transpose(-1, -2).cpu().numpy(), z["out"], atol=5e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("b,t,heads,lens", [(2, 200, 2, None), (3, 333, 3, [333, 100, 1]), (1, 999, 4, None), (2, 64, 1, [64, 33])])
+def test_fused_attention_matches_softmax_qk_v(b, t, heads, lens):
+    """ts_w2v_attention_fwd, precision 1, head_dim 64 (the fused MFMA kernel): against fp32 attention on the same bf16 inputs."""
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    c = 64 * heads
+    g = torch.Generator().manual_seed(t)
+    qkv = (torch.randn(b, t, 3 * c, generator=g) * 1.5).to(torch.bfloat16)
+    qf = qkv.float()
+    q, k, v = [z.view(b, t, heads, 64).transpose(1, 2) for z in qf.split(c, dim=-1)]
+    scores = (q @ k.transpose(-1, -2)) / 8.0
+    key_len = None
+    if lens is not None:
+        key_len = torch.tensor(lens, dtype=torch.int32)
+        pad = torch.arange(t)[None, :] >= key_len[:, None]
+        scores = scores.masked_fill(pad[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(scores, -1) @ v).transpose(1, 2).reshape(b, t, c)
+    dq = qkv.cuda()
+    ctx = torch.zeros(b, t, c, dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty(L.ts_w2v_attention_workspace_bytes(b, t, heads, 1), dtype=torch.uint8, device="cuda")
+    kl = key_len.cuda() if key_len is not None else None
+    st = L.ts_w2v_attention_fwd(dq.data_ptr(), b, t, c, heads, kl.data_ptr() if kl is not None else None, 1, ctx.data_ptr(),
+                                ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    got = ctx.float().cpu()
+    # bf16 probabilities and a bf16 result: 2-3 significant digits
+    assert float((got - ref).abs().max()) <= 0.03 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).pow(2).mean().sqrt()) <= 0.006 * max(1.0, float(ref.abs().max()))

@@ -227,6 +227,134 @@ __global__ __launch_bounds__(256) void w2v_softmax_kernel(float* __restrict__ s,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused attention (precision 1, head_dim 64): softmax(q k^T * scale) v without materialising the [T][T] scores.
+//   workgroup = 128 queries of one (clip, head), 4 waves x 32 queries; K / V tiles of 64 keys staged in LDS for all 4 waves.
+//   Per 32-key sub-tile and wave, v_mfma_f32_32x32x16_bf16 throughout:
+//     S^T[key][query] = K Q^T   -- transposed on purpose: a lane then owns ONE query column and 16 of the 32 keys, so the
+//                                  row maximum / sum of the online softmax are in-lane plus one exchange with lane ^ 32;
+//     O^T[d][query] += V^T P^T  -- A = V^T read out of the [key][d] tile with ds_read_b64_tr_b16, B = P^T straight from
+//                                  the accumulator registers of the first product: the K rows are loaded in the order
+//                                  (bits 2 and 3 of the row index swapped) that makes accumulator register i of lane half h
+//                                  hold key 16 (i / 8) + 8 h + i % 8, which is exactly the B-operand slot order.
+//   Probabilities are rounded to bf16 for the second product (as in the unfused path), everything else is fp32.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FA_KT = 64;          // keys per staged tile
+constexpr int FA_PITCH = 144;      // bytes per staged row: 64 bf16 + 16 (rows 36 banks apart: conflict-free b128 / tr reads)
+constexpr int FA_QW = 128;         // queries per workgroup
+
+struct FaArgs {
+  const unsigned short* qkv;       // [B][T][3C] bf16
+  unsigned short* ctx;             // [B][T][C] bf16
+  const int* key_len;
+  int t, c;
+  float scale_log2e;
+};
+
+__global__ __launch_bounds__(256) void w2v_flash_attn_kernel(const FaArgs a) {
+  __shared__ __attribute__((aligned(16))) char ks_[FA_KT * FA_PITCH];
+  __shared__ __attribute__((aligned(16))) char vs_[FA_KT * FA_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * FA_QW + wave * 32;
+  const size_t rowp = (size_t)3 * a.c;
+  const unsigned short* base = a.qkv + (size_t)b * a.t * rowp + (size_t)head * 64;
+  int lim = a.t;
+  if (a.key_len) {
+    const int n = a.key_len[b] < a.t ? a.key_len[b] : a.t;
+    lim = n > 0 ? n : a.t;                       // no valid key: the reference's softmax degenerates to all keys
+  }
+  const int half = lane >> 5, n32 = lane & 31;
+  // B operand of the first product: Q^T, lane = (query n32, k-half): 8 consecutive d per k-step
+  s16x8 qf[4];
+  {
+    const int qrow = q0 + n32 < a.t ? q0 + n32 : a.t - 1;
+    const uint4* qp = reinterpret_cast<const uint4*>(base + (size_t)qrow * rowp + 8 * half);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(s16x8, qp[2 * ks]);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[mt][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int pm = (n32 & ~12) | ((n32 & 4) << 1) | ((n32 & 8) >> 1);          // K row order: bits 2 and 3 swapped
+  const int q4 = (lane >> 2) & 3, gq = (lane >> 4) & 1, p4 = lane & 3;
+  const int v_off = (8 * half + q4) * FA_PITCH + (16 * gq + 4 * p4) * 2;     // transposing read of the V tile
+
+  for (int k0 = 0; k0 < lim; k0 += FA_KT) {
+    __syncthreads();                                                          // the previous tile has been consumed
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int chunk = tid + 256 * rep, r = chunk >> 3, cc = chunk & 7;
+      const int key = k0 + r < a.t ? k0 + r : a.t - 1;
+      const unsigned short* src = base + (size_t)key * rowp + cc * 8;
+      *reinterpret_cast<uint4*>(ks_ + r * FA_PITCH + cc * 16) = *reinterpret_cast<const uint4*>(src + a.c);
+      *reinterpret_cast<uint4*>(vs_ + r * FA_PITCH + cc * 16) = *reinterpret_cast<const uint4*>(src + 2 * a.c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (k0 + sub * 32 >= lim) break;                                        // uniform: nothing but masked keys
+      f32x16 s;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = 0.f;
+      const char* kr = ks_ + (sub * 32 + pm) * FA_PITCH + half * 16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const s16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
+      // accumulator register i <-> key k0 + 32 sub + 16 (i / 8) + 8 half + i % 8
+      const int kbase = k0 + sub * 32 + 8 * half;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kbase + 16 * (i >> 3) + (i & 7);
+        s[i] = key < lim ? s[i] * a.scale_log2e : -INFINITY;
+        mx = fmaxf(mx, s[i]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);                                   // finite: the sub-tile has at least one valid key
+      const float alpha = exp2f(m_run - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = exp2f(s[i] - m_new); rs += s[i]; }
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[mt][i] *= alpha;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const unsigned p01 = pack_bf16(s[8 * ks2 + 0], s[8 * ks2 + 1]), p23 = pack_bf16(s[8 * ks2 + 2], s[8 * ks2 + 3]);
+        const unsigned p45 = pack_bf16(s[8 * ks2 + 4], s[8 * ks2 + 5]), p67 = pack_bf16(s[8 * ks2 + 6], s[8 * ks2 + 7]);
+        const s16x8 pb = __builtin_bit_cast(s16x8, uint4{p01, p23, p45, p67});
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const char* va = vs_ + (sub * 32 + 16 * ks2) * FA_PITCH + v_off + 64 * mt;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)va));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)va + 4 * FA_PITCH));
+          const s16x8 vf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l;
+  const int query = q0 + n32;
+  if (query < a.t) {
+    unsigned short* dst = a.ctx + ((size_t)b * a.t + query) * a.c + (size_t)head * 64 + 4 * half;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)       // accumulator registers 4g .. 4g+3 <-> d = 32 mt + 8 g + 4 half + 0..3
+        *reinterpret_cast<uint2*>(dst + 32 * mt + 8 * g) =
+            uint2{pack_bf16(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv), pack_bf16(o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv)};
+  }
+}
+
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 // row-major y[M][N] (ldc) = x[M][K] (lda) W[N][K]^T (ldw) + beta y, batched with element strides.  bf16 = x and W are bf16;
@@ -380,6 +508,14 @@ extern "C" int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, i
   if (int st = blas(stream, &h)) return st;
   const int hd = c / heads;
   const bool bf = precision != 0;
+  static const bool no_fused = getenv("TS_W2V_NO_FUSED_ATTN") != nullptr;     // diagnostic: the GEMM + softmax + GEMM path
+  if (bf && hd == 64 && c % 8 == 0 && !no_fused) {
+    FaArgs f{};
+    f.qkv = static_cast<const unsigned short*>(qkv); f.ctx = static_cast<unsigned short*>(ctx); f.key_len = key_len;
+    f.t = t; f.c = c; f.scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
+    hipLaunchKernelGGL(w2v_flash_attn_kernel, dim3((t + FA_QW - 1) / FA_QW, heads, batch), dim3(256), 0, stream, f);
+    return hip_status(hipGetLastError());
+  }
   const size_t es = bf ? 2 : 4;
   float* s = static_cast<float*>(workspace);
   unsigned short* p16 = bf ? reinterpret_cast<unsigned short*>(s + (size_t)batch * heads * t * t) : nullptr;
