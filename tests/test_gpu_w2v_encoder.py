@@ -129,3 +129,29 @@ def test_fused_attention_matches_softmax_qk_v(b, t, heads, lens):
     # bf16 probabilities and a bf16 result: 2-3 significant digits
     assert float((got - ref).abs().max()) <= 0.03 * max(1.0, float(ref.abs().max()))
     assert float((got - ref).pow(2).mean().sqrt()) <= 0.006 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("b,t,groups,k", [(2, 300, 2, 128), (1, 999, 3, 128), (3, 77, 1, 16), (2, 130, 2, 7)])
+def test_posconv_mfma_kernel_matches_conv1d(b, t, groups, k):
+    """ts_w2v_posconv_fwd, precision 1, 64 channels per group (the implicit-GEMM MFMA kernel) against F.conv1d on the same
+    bf16-rounded operands: y = x + gelu(conv(x) + bias), 'same' padding k // 2, last frame of an even kernel dropped."""
+    import torch.nn.functional as F
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    c, cg = 64 * groups, 64
+    g = torch.Generator().manual_seed(t + k)
+    x = torch.randn(b, t, c, generator=g)
+    w = torch.randn(c, cg, k, generator=g) * (1.0 / (cg * k) ** 0.5)
+    bias = torch.randn(c, generator=g) * 0.1
+    xr, wr = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    conv = F.conv1d(xr.transpose(1, 2), wr, bias, padding=k // 2, groups=groups)[:, :, :t]
+    ref = x + F.gelu(conv).transpose(1, 2)
+    w_taps = w.view(groups, cg, cg, k).permute(3, 0, 1, 2).contiguous().to(torch.bfloat16).cuda()
+    xd, bd = x.cuda(), bias.cuda()
+    y = torch.empty_like(xd)
+    ws = torch.empty(L.ts_w2v_posconv_workspace_bytes(b, t, c, k), dtype=torch.uint8, device="cuda")
+    st = L.ts_w2v_posconv_fwd(xd.data_ptr(), b, t, c, w_taps.data_ptr(), bd.data_ptr(), k, groups, 1, y.data_ptr(), None, ws.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert float((y.cpu() - ref).abs().max()) <= 2e-3

@@ -355,6 +355,81 @@ __global__ __launch_bounds__(256) void w2v_flash_attn_kernel(const FaArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Positional conv as an implicit GEMM on the matrix cores (precision 1, 64 channels per group: wav2vec2-large).
+//   workgroup = 128 frames x 64 output channels of one (clip, group); the 128 + k - 1 input rows it needs are staged ONCE in
+//   LDS and tap j simply reads rows j .. j + 127 of that window (no im2col, no per-tap restaging);
+//   waves 2 x 2: 64 frames x 32 channels each, v_mfma_f32_32x32x16_bf16, A = window rows (ds_read_b128), B = tap weights
+//   [co][ci] straight from L2, prefetched one tap ahead.  Epilogue: + bias, GELU, + x (fp32 residual), coalesced along channels.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PC_TT = 128;         // frames per workgroup
+constexpr int PC_PITCH = 144;      // bytes per staged row (64 bf16 + 16)
+
+struct PcArgs {
+  const unsigned short* xp;        // [B][T + k][C] bf16, k/2 zero rows in front of each clip
+  const unsigned short* w;         // [k][G][64 co][64 ci] bf16
+  const float* bias;
+  const float* x;                  // [B][T][C] fp32 (residual)
+  float* y;
+  int t, c, k, groups;
+};
+
+__global__ __launch_bounds__(256) void w2v_posconv_mfma_kernel(const PcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char win[];                  // [PC_TT + k - 1][PC_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, g = blockIdx.y, t0 = blockIdx.x * PC_TT;
+  const int rows = PC_TT + a.k - 1;
+  const int prow = a.t + a.k;
+  const unsigned short* src = a.xp + ((size_t)b * prow + t0) * a.c + (size_t)g * 64;
+  for (int chunk = tid; chunk < rows * 8; chunk += 256) {
+    const int r = chunk >> 3, cc = chunk & 7;
+    uint4 v = uint4{0u, 0u, 0u, 0u};
+    if (t0 + r < prow) v = *reinterpret_cast<const uint4*>(src + (size_t)r * a.c + cc * 8);
+    *reinterpret_cast<uint4*>(win + r * PC_PITCH + cc * 16) = v;
+  }
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;                                    // 64 frames x 32 channels per wave
+  const int half = lane >> 5, n32 = lane & 31;
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+  const char* arow = win + (wm * 64 + n32) * PC_PITCH + half * 16;            // A: row = frame, 8 consecutive ci per k-step
+  const uint4* wp = reinterpret_cast<const uint4*>(a.w + ((size_t)g * 64 + wn * 32 + n32) * 64 + 8 * half);
+  const size_t tap_stride = (size_t)a.groups * 64 * 64 / 8;                   // uint4 units
+  uint4 bf[4], bn[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) bf[ks] = wp[2 * ks];
+  for (int j = 0; j < a.k; ++j) {
+    if (j + 1 < a.k) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bn[ks] = wp[(size_t)(j + 1) * tap_stride + 2 * ks];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const s16x8 af = *reinterpret_cast<const s16x8*>(arow + (j + 32 * mt) * PC_PITCH + ks * 32);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(s16x8, bf[ks]), acc[mt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bf[ks] = bn[ks];
+  }
+  const int co = g * 64 + wn * 32 + n32;
+  const float bv = a.bias[co];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = t0 + wm * 64 + 32 * mt + 8 * (i >> 2) + 4 * half + (i & 3);
+      if (t < a.t) {
+        const size_t o = ((size_t)b * a.t + t) * a.c + co;
+        a.y[o] = a.x[o] + gelu_erf(acc[mt][i] + bv);
+      }
+    }
+}
+
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 // row-major y[M][N] (ldc) = x[M][K] (lda) W[N][K]^T (ldw) + beta y, batched with element strides.  bf16 = x and W are bf16;
@@ -482,6 +557,15 @@ extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int3
   if (precision) hipLaunchKernelGGL(w2v_pad_rows_kernel<unsigned short>, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x,
                                     reinterpret_cast<unsigned short*>(xp), t, c, kernel);
   else hipLaunchKernelGGL(w2v_pad_rows_kernel<float>, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x, reinterpret_cast<float*>(xp), t, c, kernel);
+  static const bool no_mfma = getenv("TS_W2V_NO_POSCONV_MFMA") != nullptr;    // diagnostic: the per-tap GEMM path
+  const size_t win_lds = (size_t)(PC_TT + kernel - 1) * PC_PITCH;
+  if (precision && cg == 64 && win_lds <= 64 * 1024 && !no_mfma) {
+    PcArgs pa{};
+    pa.xp = reinterpret_cast<const unsigned short*>(xp); pa.w = static_cast<const unsigned short*>(w_taps); pa.bias = bias; pa.x = x; pa.y = y;
+    pa.t = t; pa.c = c; pa.k = kernel; pa.groups = groups;
+    hipLaunchKernelGGL(w2v_posconv_mfma_kernel, dim3((t + PC_TT - 1) / PC_TT, groups, batch), dim3(256), win_lds, stream, pa);
+    return hip_status(hipGetLastError());
+  }
   // all clips at once: output row r (over the padded row space) = sum_j xp[r + j] W_j^T, per group; rows between clips are waste
   const long long m = (long long)batch * prow - kernel;
   for (int j = 0; j < kernel; ++j) {
