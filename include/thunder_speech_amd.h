@@ -225,13 +225,14 @@ int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const 
  * w_taps [kernel][c_out][c_in] (tap-major repack of the reference's [c_out][c_in][kernel]); y f32 [B][t_out][c_out]. */
 int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, int32_t c_out, int32_t kernel,
                     int32_t stride, int32_t precision, float* y, void* y_bf16, void* stream);
-/* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act 0 = none, 1 = GELU (erf).
- * lda / ldc / ld_res: row pitches in elements. */
+/* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act bit 0: GELU (erf), bit 1:
+ * only y_bf16 is wanted (y is then scratch space for the f32 GEMM result).  lda / ldc / ld_res: row pitches in elements. */
 int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res, float* y,
                       int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision, void* stream);
-/* y = LayerNorm(x + res) * w + b over the last dimension (res may be NULL); x, res, y f32 [rows][c]. */
-int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float eps, int64_t rows, int32_t c,
-                         float* y, void* y_bf16, void* stream);
+/* y = LayerNorm(x + xbias + res) * w + b over the last dimension; x, res (may be NULL), y f32 [rows][c]; xbias f32 [c] or NULL:
+ * the bias of the linear layer that produced x, applied here instead of in a pass of its own. */
+int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* xbias, const float* w, const float* b, float eps, int64_t rows,
+                         int32_t c, float* y, void* y_bf16, void* stream);
 /* hidden_states[~attention_mask] = 0: rows >= len[b] of x [B][t][c] become 0. */
 int ts_w2v_mask_rows(float* x, int32_t batch, int32_t t, int32_t c, const int32_t* len, void* stream);
 /* positional conv embedding: y = x + gelu(Conv1d(c, c, kernel, padding = kernel / 2, groups)(x) + bias), last frame of an

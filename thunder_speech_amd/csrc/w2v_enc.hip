@@ -119,41 +119,63 @@ __global__ __launch_bounds__(256) void w2v_bias_act_kernel(float* __restrict__ y
     const float4 bb = *reinterpret_cast<const float4*>(bias + c);
     v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
   }
-  if (act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+  if (act & 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
   if (res) {
     const float4 rr = *reinterpret_cast<const float4*>(res + r * ld_res + c);
     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
   }
-  *reinterpret_cast<float4*>(y + r * ld + c) = v;
+  if (!(act & 2)) *reinterpret_cast<float4*>(y + r * ld + c) = v;      // act & 2: y is scratch, only the bf16 copy is wanted
   if (y16) *reinterpret_cast<uint2*>(y16 + r * n + c) = uint2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};     // dense [rows][n]
 }
 
-// one wavefront per row: y = LN(x (+ res)) * w + b
+// one wavefront per row: y = LN(x (+ xbias) (+ res)) * w + b.  NV float4 per lane hold the row (c <= 256 NV, c % 4 == 0):
+// one read of the inputs, fp32 statistics in registers (mean, then centred sum of squares), one write of each output.
+template <int NV>
 __global__ __launch_bounds__(256) void w2v_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            float* __restrict__ y, long long rows, int c, float eps,
-                                                            unsigned short* __restrict__ y16) {
+                                                            const float* __restrict__ xbias, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y, long long rows, int c,
+                                                            float eps, unsigned short* __restrict__ y16) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + row * c;
   const float* rr = res ? res + row * c : nullptr;
+  float4 v[NV];
   float s = 0.f;
-  for (int i = lane; i < c; i += 64) s += xr[i] + (rr ? rr[i] : 0.f);
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    const int i = (it * 64 + lane) * 4;
+    v[it] = float4{0.f, 0.f, 0.f, 0.f};
+    if (i < c) {
+      v[it] = *reinterpret_cast<const float4*>(xr + i);
+      if (rr) { const float4 r4 = *reinterpret_cast<const float4*>(rr + i); v[it].x += r4.x; v[it].y += r4.y; v[it].z += r4.z; v[it].w += r4.w; }
+      if (xbias) { const float4 b4 = *reinterpret_cast<const float4*>(xbias + i); v[it].x += b4.x; v[it].y += b4.y; v[it].z += b4.z; v[it].w += b4.w; }
+      s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+    }
+  }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float mu = s / c;
   float q = 0.f;
-  for (int i = lane; i < c; i += 64) {
-    const float d = xr[i] + (rr ? rr[i] : 0.f) - mu;
-    q = fmaf(d, d, q);
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    const int i = (it * 64 + lane) * 4;
+    if (i < c) {
+      const float d0 = v[it].x - mu, d1 = v[it].y - mu, d2 = v[it].z - mu, d3 = v[it].w - mu;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
   }
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   const float rs = rsqrtf(q / c + eps);
-  float* yr = y + row * c;
-  for (int i = lane; i < c; i += 64) {
-    const float v = (xr[i] + (rr ? rr[i] : 0.f) - mu) * rs * w[i] + b[i];
-    yr[i] = v;
-    if (y16) y16[row * c + i] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
+#pragma unroll
+  for (int it = 0; it < NV; ++it) {
+    const int i = (it * 64 + lane) * 4;
+    if (i < c) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + i), b4 = *reinterpret_cast<const float4*>(b + i);
+      const float4 o4 = float4{(v[it].x - mu) * rs * w4.x + b4.x, (v[it].y - mu) * rs * w4.y + b4.y, (v[it].z - mu) * rs * w4.z + b4.z,
+                               (v[it].w - mu) * rs * w4.w + b4.w};
+      *reinterpret_cast<float4*>(y + row * c + i) = o4;
+      if (y16) *reinterpret_cast<uint2*>(y16 + row * c + i) = uint2{pack_bf16(o4.x, o4.y), pack_bf16(o4.z, o4.w)};
+    }
   }
 }
 
@@ -507,7 +529,8 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
                                  float* y, int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision,
                                  void* stream_) {
   if (!x || !w || !y || rows <= 0 || n <= 0 || k <= 0 || lda < k || ldc < n || (res && ld_res < n)) return TS_EINVAL;
-  if (n % 4 || ldc % 4 || (res && ld_res % 4) || act < 0 || act > 1 || precision < 0 || precision > 1) return TS_EUNSUPPORTED;
+  if (n % 4 || ldc % 4 || (res && ld_res % 4) || act < 0 || act > 3 || precision < 0 || precision > 1) return TS_EUNSUPPORTED;
+  if ((act & 2) && !y_bf16) return TS_EINVAL;
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
@@ -518,12 +541,16 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float eps, int64_t rows,
-                                    int32_t c, float* y, void* y_bf16, void* stream_) {
+extern "C" int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* xbias, const float* w, const float* b, float eps,
+                                    int64_t rows, int32_t c, float* y, void* y_bf16, void* stream_) {
   if (!x || !w || !b || !y || rows <= 0 || c <= 0) return TS_EINVAL;
+  if (c % 4 || c > 4096) return TS_EUNSUPPORTED;
   TS_STREAM;
-  hipLaunchKernelGGL(w2v_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, w, b, y, (long long)rows, c, eps,
-                     static_cast<unsigned short*>(y_bf16));
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  unsigned short* y16 = static_cast<unsigned short*>(y_bf16);
+#define TS_LN(NV_) hipLaunchKernelGGL(w2v_layernorm_kernel<NV_>, grid, dim3(256), 0, stream, x, res, xbias, w, b, y, (long long)rows, c, eps, y16)
+  if (c <= 512) TS_LN(2); else if (c <= 1024) TS_LN(4); else if (c <= 2048) TS_LN(8); else TS_LN(16);
+#undef TS_LN
   return hip_status(hipGetLastError());
 }
 

@@ -110,19 +110,20 @@ class Wav2Vec2Plan:
         return t.data_ptr() if t is not None else None
 
     def _linear(self, L, stream, x_op, w, bias, act=0, want_op=False):
+        """want_op: the consumer is another GEMM -- in bf16 mode only the bf16 copy is kept (the fp32 buffer is scratch)."""
         b, t, k = x_op.shape
         n = w.shape[0]
         y = self._buf(b, t, n)
         y_op = self._op(b, t, n) if want_op else None
         st = L.ts_w2v_linear_fwd(x_op.data_ptr(), k, w.data_ptr(), self._ptr(bias), None, n, y.data_ptr(), n, self._ptr(y_op),
-                                 b * t, n, k, act, self.prec, stream)
+                                 b * t, n, k, act | (2 if y_op is not None else 0), self.prec, stream)
         _lib.check(st, "ts_w2v_linear_fwd")
         return y, (y_op if self.prec else y)
 
-    def _ln(self, L, stream, x, wb, res=None, want_op=True):
+    def _ln(self, L, stream, x, wb, res=None, xbias=None, want_op=True):
         y = torch.empty_like(x)
         y_op = self._op(*x.shape) if want_op else None
-        st = L.ts_w2v_layernorm_fwd(x.data_ptr(), self._ptr(res), wb[0].data_ptr(), wb[1].data_ptr(), self.eps,
+        st = L.ts_w2v_layernorm_fwd(x.data_ptr(), self._ptr(res), self._ptr(xbias), wb[0].data_ptr(), wb[1].data_ptr(), self.eps,
                                     x.shape[0] * x.shape[1], x.shape[2], y.data_ptr(), self._ptr(y_op), stream)
         _lib.check(st, "ts_w2v_layernorm_fwd")
         return y, (y_op if self.prec else y)
@@ -183,11 +184,11 @@ class Wav2Vec2Plan:
             ctx_op = self._buf(b, t, c, dtype=torch.bfloat16 if self.prec else torch.float32)
             _lib.check(L.ts_w2v_attention_fwd(qkv_op.data_ptr(), b, t, c, self.heads, self._ptr(key_len), self.prec, ctx_op.data_ptr(),
                                               att_ws.data_ptr(), stream), "ts_w2v_attention_fwd")
-            o, _ = self._linear(L, stream, ctx_op, lw["wo"], lw["bo"])
-            h, h_op = self._ln(L, stream, o, lw["ln1"], res=h)
+            o, _ = self._linear(L, stream, ctx_op, lw["wo"], None)            # the bias rides in the LayerNorm launch
+            h, h_op = self._ln(L, stream, o, lw["ln1"], res=h, xbias=lw["bo"])
             _, f1_op = self._linear(L, stream, h_op, lw["w1"], lw["b1"], act=1, want_op=True)
-            f2, _ = self._linear(L, stream, f1_op, lw["w2"], lw["b2"])
-            h, h_op = self._ln(L, stream, f2, lw["ln2"], res=h)
+            f2, _ = self._linear(L, stream, f1_op, lw["w2"], None)
+            h, h_op = self._ln(L, stream, f2, lw["ln2"], res=h, xbias=lw["b2"])
         return h
 
 
