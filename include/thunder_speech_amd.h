@@ -222,7 +222,8 @@ int64_t ts_w2v_conv0_workspace_bytes(int32_t batch, int64_t n_samples, int32_t c
 int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const float* w, const float* gn_w, const float* gn_b,
                      int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* y_bf16, void* workspace, void* stream);
 /* conv layers 1..6: Conv1d(c_in, c_out, kernel, stride, bias=False) -> GELU.  x [B][t_in][c_in];
- * w_taps [kernel][c_out][c_in] (tap-major repack of the reference's [c_out][c_in][kernel]); y f32 [B][t_out][c_out]. */
+ * w_taps [c_out][kernel][c_in] (the reference's [c_out][c_in][kernel] with the last two axes swapped); y f32 [B][t_out][c_out]
+ * (GEMM accumulator; when y_bf16 is given only the bf16 copy holds the result). */
 int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, int32_t c_out, int32_t kernel,
                     int32_t stride, int32_t precision, float* y, void* y_bf16, void* stream);
 /* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act bit 0: GELU (erf), bit 1:

@@ -19,7 +19,16 @@
 
 namespace ts {
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 GELU noise; a third of the instructions of ocml's erff:
+// the conv0 and epilogue kernels are bound by exactly this)
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float r = 1.f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // conv0 + GroupNorm + GELU
@@ -512,16 +521,20 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
   if (int st = blas(stream, &h)) return st;
   const int t_out = conv_frames(t_in, kernel, stride);
   const size_t es = precision ? 2 : 4;
-  for (int j = 0; j < kernel; ++j) {
-    // rows stride*t + j of clip b: a [t_out x c_in] matrix with row pitch stride * c_in
-    if (int st = gemm_nt(h, precision != 0, t_out, c_out, c_in, static_cast<const char*>(x) + (size_t)j * c_in * es, (long long)stride * c_in,
-                         (long long)t_in * c_in, static_cast<const char*>(w_taps) + (size_t)j * c_out * c_in * es, c_in, 0, y, c_out,
-                         (long long)t_out * c_out, j ? 1.f : 0.f, batch))
+  // Output frame t reads input rows stride*t .. stride*t + kernel - 1, which are CONTIGUOUS in the time-major layout: with a
+  // row pitch of stride * c_in the first `stride` taps are one [t_out x stride*c_in] matrix, so taps go `stride` at a time
+  // (k = 3, s = 2: taps {0, 1} in one GEMM with K = 2 c_in, tap 2 in a second one accumulating; k = 2, s = 2: one GEMM).
+  for (int j = 0; j < kernel; j += stride) {
+    const int nt = kernel - j < stride ? kernel - j : stride;
+    if (int st = gemm_nt(h, precision != 0, t_out, c_out, nt * c_in, static_cast<const char*>(x) + (size_t)j * c_in * es,
+                         (long long)stride * c_in, (long long)t_in * c_in, static_cast<const char*>(w_taps) + (size_t)j * c_in * es,
+                         (long long)kernel * c_in, 0, y, c_out, (long long)t_out * c_out, j ? 1.f : 0.f, batch))
       return st;
   }
   const long long rows = (long long)batch * t_out;
+  // with a bf16 copy requested the f32 buffer is only the GEMM accumulator: it is not written back after the GELU
   hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (c_out / 4))), dim3(256), 0, stream, y, (const float*)nullptr,
-                     (const float*)nullptr, rows, c_out, (long long)c_out, 0LL, 1, static_cast<unsigned short*>(y_bf16));
+                     (const float*)nullptr, rows, c_out, (long long)c_out, 0LL, y_bf16 ? 3 : 1, static_cast<unsigned short*>(y_bf16));
   return hip_status(hipGetLastError());
 }
 

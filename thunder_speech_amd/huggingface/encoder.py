@@ -69,8 +69,8 @@ class Wav2Vec2Plan:
         self.w0 = f("feature_extractor.conv_layers.0.conv.weight").reshape(self.dims[0], self.kernels[0]).contiguous()
         self.gn_w = f("feature_extractor.conv_layers.0.layer_norm.weight")
         self.gn_b = f("feature_extractor.conv_layers.0.layer_norm.bias")
-        # [c_out][c_in][k] -> tap-major [k][c_out][c_in]: one GEMM per tap
-        self.conv_w = [gw(f(f"feature_extractor.conv_layers.{i}.conv.weight").permute(2, 0, 1))
+        # [c_out][c_in][k] -> [c_out][k][c_in]: consecutive taps are consecutive K columns of one GEMM
+        self.conv_w = [gw(f(f"feature_extractor.conv_layers.{i}.conv.weight").permute(0, 2, 1))
                        for i in range(1, len(self.kernels))]
         self.fp_ln = (f("feature_projection.layer_norm.weight"), f("feature_projection.layer_norm.bias"))
         self.fp_w, self.fp_b = gw(f("feature_projection.projection.weight")), f("feature_projection.projection.bias")
