@@ -45,11 +45,13 @@ def main():
     ap.add_argument("--base", action="store_true")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--check", action="store_true", help="time the CPU oracle on clip 0 (16 threads) and compare the HIP output with it")
     a = ap.parse_args()
     from thunder_speech_amd.huggingface.encoder import Wav2Vec2Plan
     from thunder_speech_amd.huggingface.transform import Wav2Vec2Preprocess
     cfg = config(a.base, a.layers)
-    plan = Wav2Vec2Plan(cfg, random_state(cfg), "cuda", precision=a.precision)
+    sd = random_state(cfg)
+    plan = Wav2Vec2Plan(cfg, sd, "cuda", precision=a.precision)
     pre = Wav2Vec2Preprocess()
     x = (0.1 * torch.randn(a.batch, 16000 * a.seconds)).cuda()
     lengths = torch.full((a.batch,), 16000 * a.seconds, dtype=torch.int32, device="cuda")
@@ -77,6 +79,26 @@ def main():
           f"frames {t}; feature extractor {fe_ms:.1f} ms; {(flops_fe+flops_tr+flops_pos)/dt/1e12:.1f} TFLOP/s "
           f"(fe {flops_fe/1e12:.2f} + transformer {flops_tr/1e12:.2f} + pos-conv {flops_pos/1e12:.2f} TFLOP per step); "
           f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+    if a.check:
+        check_against_oracle(cfg, sd, x[:1].cpu(), out[:1].float().cpu(), a.seconds)
+
+
+def check_against_oracle(cfg, sd, x0, out0, seconds):
+    """CPU oracle (oracle/w2v.py, the restated transformers forward) on ONE clip: parity at full length + the CPU baseline."""
+    from oracle import w2v as ow
+    torch.set_num_threads(16)
+    ocfg = ow.W2VConfig(conv_dim=cfg.conv_dim, conv_kernel=cfg.conv_kernel, conv_stride=cfg.conv_stride, hidden_size=cfg.hidden_size,
+                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                        intermediate_size=cfg.intermediate_size, num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+                        num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups)
+    xn = (x0 - x0.mean(dim=1, keepdim=True)) / torch.sqrt(x0.var(dim=1, keepdim=True) + 1e-7)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref, _ = ow.forward(ocfg, sd, xn)
+        dt = time.perf_counter() - t0
+    err = (out0 - ref).abs()
+    print(f"CPU oracle (fp32, 16 threads), 1x{seconds}s clip: {dt:.2f} s -> {seconds/dt:.1f} audio-s/s; HIP vs oracle on that clip: "
+          f"max |err| {float(err.max()):.4f}, rms {float(err.pow(2).mean().sqrt()):.5f} (outputs are LayerNorm-ed, unit scale)")
 
 
 if __name__ == "__main__":
