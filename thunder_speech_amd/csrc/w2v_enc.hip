@@ -282,7 +282,7 @@ struct FaArgs {
   float scale_log2e;
 };
 
-__global__ __launch_bounds__(256) void w2v_flash_attn_kernel(const FaArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void w2v_flash_attn_kernel(const FaArgs a) {
   __shared__ __attribute__((aligned(16))) char ks_[FA_KT * FA_PITCH];
   __shared__ __attribute__((aligned(16))) char vs_[FA_KT * FA_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -314,6 +314,8 @@ __global__ __launch_bounds__(256) void w2v_flash_attn_kernel(const FaArgs a) {
   const int q4 = (lane >> 2) & 3, gq = (lane >> 4) & 1, p4 = lane & 3;
   const int v_off = (8 * half + q4) * FA_PITCH + (16 * gq + 4 * p4) * 2;     // transposing read of the V tile
 
+  // (A register-prefetched, double-buffered variant of this loop was measured SLOWER: 176 VGPRs halve the occupancy, and this
+  // kernel is bound by the softmax VALU work -- exp2 runs at quarter rate -- which only other resident waves can hide.)
   for (int k0 = 0; k0 < lim; k0 += FA_KT) {
     __syncthreads();                                                          // the previous tile has been consumed
 #pragma unroll
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(256) void w2v_flash_attn_kernel(const FaArgs a) {
       *reinterpret_cast<uint4*>(vs_ + r * FA_PITCH + cc * 16) = *reinterpret_cast<const uint4*>(src + 2 * a.c);
     }
     __syncthreads();
+    const bool full = k0 + FA_KT <= lim;                                      // no masked key in this tile (uniform)
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       if (k0 + sub * 32 >= lim) break;                                        // uniform: nothing but masked keys
@@ -336,26 +339,29 @@ __global__ __launch_bounds__(256) void w2v_flash_attn_kernel(const FaArgs a) {
       for (int ks = 0; ks < 4; ++ks)
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const s16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
       // accumulator register i <-> key k0 + 32 sub + 16 (i / 8) + 8 half + i % 8
-      const int kbase = k0 + sub * 32 + 8 * half;
-      float mx = -INFINITY;
+      if (!full) {
+        const int kbase = k0 + sub * 32 + 8 * half;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kbase + 16 * (i >> 3) + (i & 7);
-        s[i] = key < lim ? s[i] * a.scale_log2e : -INFINITY;
-        mx = fmaxf(mx, s[i]);
+        for (int i = 0; i < 16; ++i)
+          if (kbase + 16 * (i >> 3) + (i & 7) >= lim) s[i] = -INFINITY;
       }
+      float mx = s[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);                                   // finite: the sub-tile has at least one valid key
+      const float m_new = fmaxf(m_run, mx * a.scale_log2e);                   // scale > 0: max commutes with it; finite (>= 1 valid key)
       const float alpha = exp2f(m_run - m_new);
       float rs = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = exp2f(s[i] - m_new); rs += s[i]; }
+      for (int i = 0; i < 16; ++i) { s[i] = exp2f(fmaf(s[i], a.scale_log2e, -m_new)); rs += s[i]; }
       l_run = l_run * alpha + rs;
       m_run = m_new;
+      if (__any(alpha != 1.f)) {                                              // after the first tiles the running maximum rarely moves
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[mt][i] *= alpha;
+          for (int i = 0; i < 16; ++i) o[mt][i] *= alpha;
+      }
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
         const unsigned p01 = pack_bf16(s[8 * ks2 + 0], s[8 * ks2 + 1]), p23 = pack_bf16(s[8 * ks2 + 2], s[8 * ks2 + 3]);
