@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--base", action="store_true")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--graph", action="store_true", help="replay the forward pass from a hipGraph (no host launch overhead)")
     ap.add_argument("--check", action="store_true", help="time the CPU oracle on clip 0 (16 threads) and compare the HIP output with it")
     a = ap.parse_args()
     from thunder_speech_amd.huggingface.encoder import Wav2Vec2Plan
@@ -61,10 +62,20 @@ def main():
         return plan.forward(xn, None)
 
     with torch.no_grad():
-        out = step(); torch.cuda.synchronize()
+        out = step(); out = step(); torch.cuda.synchronize()
+        run = step
+        if a.graph:
+            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    gout = step()
+            def run():
+                g.replay()
+                return gout
+            run(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            out = step()
+            out = run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
