@@ -1671,6 +1671,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #pragma unroll
           for (int i = 0; i < ER / 4; ++i) {
             if (partial) v[i] &= keep;
+#if defined(TS_EXP) && (TS_EXP & 8)            // timing experiment: the epilogue without its global stores
+            if (a.c_out < 0)
+#endif
             if (cob + half * ER + 4 * i + rsub < a.c_out) *reinterpret_cast<u32x4*>(yrow + (size_t)(4 * i) * a.pitch_out) = v[i];
           }
         }
