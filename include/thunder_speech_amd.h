@@ -216,24 +216,25 @@ int ts_w2v_preprocess(const float* wave, const int32_t* wave_len, int32_t batch,
 /* `precision` (all GEMM-carrying entry points): 0 = f32 operands; 1 = bf16 operands (x / w / qkv pointers are bf16), f32
  * accumulation and f32 results.  `y_bf16` (may be NULL): a dense bf16 copy of the result for the next GEMM, written by the
  * same launch -- there is no separate cast pass. */
-/* conv layer 0: Conv1d(1, c, kernel, stride, bias=False) -> GroupNorm(c groups, eps) -> GELU.
+/* conv layer 0.  feat_extract_norm = "group": Conv1d(1, c, kernel, stride, bias=False) -> GroupNorm(c groups, eps) -> GELU.
+ * gn_w == NULL ("layer" family): y = Conv1d(...) + gn_b (the conv bias, may be NULL), no normalisation, no activation.
  * wave f32 [B][n_samples]; w f32 [c][kernel]; y f32 (may be NULL if y_bf16 is given) [B][(n_samples - kernel) / stride + 1][c]. */
 int64_t ts_w2v_conv0_workspace_bytes(int32_t batch, int64_t n_samples, int32_t c, int32_t kernel, int32_t stride);
 int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const float* w, const float* gn_w, const float* gn_b,
                      int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* y_bf16, void* workspace, void* stream);
-/* conv layers 1..6: Conv1d(c_in, c_out, kernel, stride, bias=False) -> GELU.  x [B][t_in][c_in];
+/* conv layers 1..6: act(Conv1d(c_in, c_out, kernel, stride) + bias); bias f32 [c_out] or NULL; act 0 = none, 1 = GELU.  x [B][t_in][c_in];
  * w_taps [c_out][kernel][c_in] (the reference's [c_out][c_in][kernel] with the last two axes swapped); y f32 [B][t_out][c_out]
  * (GEMM accumulator; when y_bf16 is given only the bf16 copy holds the result). */
-int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, int32_t c_out, int32_t kernel,
-                    int32_t stride, int32_t precision, float* y, void* y_bf16, void* stream);
+int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, const float* bias, int32_t c_out,
+                    int32_t kernel, int32_t stride, int32_t act, int32_t precision, float* y, void* y_bf16, void* stream);
 /* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act bit 0: GELU (erf), bit 1:
  * only y_bf16 is wanted (y is then scratch space for the f32 GEMM result).  lda / ldc / ld_res: row pitches in elements. */
 int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res, float* y,
                       int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision, void* stream);
-/* y = LayerNorm(x + xbias + res) * w + b over the last dimension; x, res (may be NULL), y f32 [rows][c]; xbias f32 [c] or NULL:
- * the bias of the linear layer that produced x, applied here instead of in a pass of its own. */
+/* y = act(LayerNorm(x + xbias + res) * w + b) over the last dimension; x, res (may be NULL), y f32 [rows][c]; xbias f32 [c] or
+ * NULL: the bias of the linear layer that produced x, applied here instead of in a pass of its own; act 0 = none, 1 = GELU. */
 int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* xbias, const float* w, const float* b, float eps, int64_t rows,
-                         int32_t c, float* y, void* y_bf16, void* stream);
+                         int32_t c, int32_t act, float* y, void* y_bf16, void* stream);
 /* hidden_states[~attention_mask] = 0: rows >= len[b] of x [B][t][c] become 0. */
 int ts_w2v_mask_rows(float* x, int32_t batch, int32_t t, int32_t c, const int32_t* len, void* stream);
 /* positional conv embedding: y = x + gelu(Conv1d(c, c, kernel, padding = kernel / 2, groups)(x) + bias), last frame of an

@@ -9,9 +9,12 @@ CFG = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermedi
            conv_stride=(5, 2, 2, 2, 2, 2, 2), num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
 
 
-def main():
+LAYER = dict(CFG, feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)
+
+
+def main(cfg=CFG, name="w2v_tiny.npz"):
     torch.manual_seed(0)
-    model = Wav2Vec2Model(Wav2Vec2Config(**CFG)).eval()
+    model = Wav2Vec2Model(Wav2Vec2Config(**cfg)).eval()
     with torch.no_grad():                      # make the norms / biases non-trivial
         for k, v in model.state_dict().items():
             if k.endswith("layer_norm.weight"):
@@ -30,11 +33,14 @@ def main():
     arrays = {"sd/" + k: v.numpy() for k, v in model.state_dict().items()}
     arrays.update(x=x.numpy(), lengths=lengths.numpy(), out=out.numpy(), out_masked=out_masked.numpy(), feat=feat.numpy(),
                   out_lengths=model._get_feat_extract_output_lengths(lengths).numpy())
-    for k, v in CFG.items():
-        if isinstance(v, (int, tuple)) and not isinstance(v, bool):
+    for k, v in cfg.items():
+        if isinstance(v, (int, tuple, bool)):
             arrays["cfg/" + k] = np.asarray(v)
-    np.savez_compressed(__file__.replace("make_golden_w2v.py", "w2v_tiny.npz"), **arrays)
+        elif isinstance(v, str):
+            arrays["cfgs/" + k] = np.asarray(v)
+    np.savez_compressed(__file__.replace("make_golden_w2v.py", name), **arrays)
 
 
 if __name__ == "__main__":
     main()
+    main(LAYER, "w2v_tiny_layer.npz")

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import w2v as ow
-from test_oracle_w2v import load_fixture
+from test_oracle_w2v import FIXTURES, load_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -18,20 +18,21 @@ def _hf_cfg(cfg: ow.W2VConfig):
                            num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
                            num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
                            num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups, layer_norm_eps=cfg.layer_norm_eps,
-                           feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False, hidden_act="gelu",
-                           feat_extract_activation="gelu")
+                           feat_extract_norm=cfg.feat_extract_norm, do_stable_layer_norm=cfg.do_stable_layer_norm,
+                           conv_bias=cfg.conv_bias, hidden_act="gelu", feat_extract_activation="gelu")
 
 
-def _plan(precision="fp32"):
+def _plan(precision="fp32", name="w2v_tiny.npz"):
     from thunder_speech_amd.huggingface.encoder import Wav2Vec2Plan
-    z, sd, cfg = load_fixture()
+    z, sd, cfg = load_fixture(name)
     return z, sd, cfg, Wav2Vec2Plan(_hf_cfg(cfg), sd, "cuda", precision=precision)
 
 
-def test_bf16_operand_mode_stays_within_bf16_tolerance_of_the_fp32_reference():
+@pytest.mark.parametrize("name", FIXTURES)
+def test_bf16_operand_mode_stays_within_bf16_tolerance_of_the_fp32_reference(name):
     """precision="bf16": GEMM operands rounded to bf16 (8 mantissa bits), fp32 accumulation and normalisations.  The
     outputs are LayerNorm-ed (unit scale): a few 1e-2 absolute is what operand rounding through 2 layers gives."""
-    z, sd, cfg, plan = _plan("bf16")
+    z, sd, cfg, plan = _plan("bf16", name)
     x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
     out = plan.forward(x.cuda(), None).cpu().numpy()
     assert np.abs(out - z["out"]).max() <= 0.06 and np.sqrt(np.mean((out - z["out"]) ** 2)) <= 0.01
@@ -40,22 +41,25 @@ def test_bf16_operand_mode_stays_within_bf16_tolerance_of_the_fp32_reference():
     assert np.abs(outm - z["out_masked"]).max() <= 0.06 and np.sqrt(np.mean((outm - z["out_masked"]) ** 2)) <= 0.01
 
 
-def test_feature_extractor_matches_transformers_fixture():
-    z, sd, cfg, plan = _plan()
+@pytest.mark.parametrize("name", FIXTURES)
+def test_feature_extractor_matches_transformers_fixture(name):
+    z, sd, cfg, plan = _plan(name=name)
     feat = plan.feature_extractor(torch.from_numpy(z["x"]).cuda())
     torch.cuda.synchronize()
     np.testing.assert_allclose(feat.cpu().numpy(), z["feat"], atol=1e-4, rtol=1e-4)
 
 
-def test_forward_matches_transformers_fixture_unmasked():
-    z, sd, cfg, plan = _plan()
+@pytest.mark.parametrize("name", FIXTURES)
+def test_forward_matches_transformers_fixture_unmasked(name):
+    z, sd, cfg, plan = _plan(name=name)
     out = plan.forward(torch.from_numpy(z["x"]).cuda(), None)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), z["out"], atol=5e-4, rtol=1e-4)
 
 
-def test_forward_matches_transformers_fixture_masked():
-    z, sd, cfg, plan = _plan()
+@pytest.mark.parametrize("name", FIXTURES)
+def test_forward_matches_transformers_fixture_masked(name):
+    z, sd, cfg, plan = _plan(name=name)
     x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
     xm = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
     out = plan.forward(xm.cuda(), lengths.cuda())
@@ -63,10 +67,11 @@ def test_forward_matches_transformers_fixture_masked():
     np.testing.assert_allclose(out.cpu().numpy(), z["out_masked"], atol=5e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("name", FIXTURES)
 @pytest.mark.parametrize("n,lens", [(4000, [4000, 3999, 1500]), (16000, [16000, 9000])])
-def test_other_lengths_match_the_oracle(n, lens):
+def test_other_lengths_match_the_oracle(n, lens, name):
     """Ragged clip lengths and frame counts that are not multiples of anything."""
-    z, sd, cfg, plan = _plan()
+    z, sd, cfg, plan = _plan(name=name)
     g = torch.Generator().manual_seed(n)
     x = torch.randn(len(lens), n, generator=g)
     lengths = torch.tensor(lens)

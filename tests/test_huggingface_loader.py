@@ -48,9 +48,13 @@ def test_loader_builds_the_reference_module_layout(checkpoint_dir):
 
 def test_unsupported_configurations_fail_loudly():
     from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
-    cfg = transformers.Wav2Vec2Config(**{**CFG, "feat_extract_norm": "layer", "do_stable_layer_norm": True})
+    cfg = transformers.Wav2Vec2Config(**{**CFG, "add_adapter": True})
     with pytest.raises(NotImplementedError):
         HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(cfg))
+    enc = HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(**CFG)))
+    enc.train()
+    with pytest.raises((NotImplementedError, RuntimeError)):        # training mode has no HIP path; CPU tensors have none at all
+        enc(torch.zeros(1, 4000), torch.tensor([4000]))
 
 
 @pytest.mark.gpu

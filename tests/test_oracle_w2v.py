@@ -9,33 +9,44 @@ from oracle import w2v as ow
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def load_fixture():
-    z = np.load(os.path.join(HERE, "golden", "w2v_tiny.npz"))
+FIXTURES = ["w2v_tiny.npz", "w2v_tiny_layer.npz"]          # group-norm / post-LN and layer-norm / stable-LN families
+
+
+def load_fixture(name="w2v_tiny.npz"):
+    z = np.load(os.path.join(HERE, "golden", name))
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
     c = {k[4:]: z[k] for k in z.files if k.startswith("cfg/")}
     cfg = ow.W2VConfig(conv_dim=tuple(int(v) for v in c["conv_dim"]), conv_kernel=tuple(int(v) for v in c["conv_kernel"]),
                        conv_stride=tuple(int(v) for v in c["conv_stride"]), hidden_size=int(c["hidden_size"]),
                        num_hidden_layers=int(c["num_hidden_layers"]), num_attention_heads=int(c["num_attention_heads"]),
                        intermediate_size=int(c["intermediate_size"]), num_conv_pos_embeddings=int(c["num_conv_pos_embeddings"]),
-                       num_conv_pos_embedding_groups=int(c["num_conv_pos_embedding_groups"]))
+                       num_conv_pos_embedding_groups=int(c["num_conv_pos_embedding_groups"]),
+                       feat_extract_norm=str(z["cfgs/feat_extract_norm"]) if "cfgs/feat_extract_norm" in z.files else "group",
+                       do_stable_layer_norm=bool(c.get("do_stable_layer_norm", False)), conv_bias=bool(c.get("conv_bias", False)))
     return z, sd, cfg
 
 
-def test_feature_extractor_matches_transformers():
-    z, sd, cfg = load_fixture()
+import pytest
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_feature_extractor_matches_transformers(name):
+    z, sd, cfg = load_fixture(name)
     feat = ow.feature_extractor(cfg, sd, torch.from_numpy(z["x"]))
     np.testing.assert_allclose(feat.numpy(), z["feat"], atol=2e-5, rtol=1e-5)
 
 
-def test_forward_matches_transformers_unmasked():
-    z, sd, cfg = load_fixture()
+@pytest.mark.parametrize("name", FIXTURES)
+def test_forward_matches_transformers_unmasked(name):
+    z, sd, cfg = load_fixture(name)
     out, key_len = ow.forward(cfg, sd, torch.from_numpy(z["x"]))
     assert key_len is None
     np.testing.assert_allclose(out.numpy(), z["out"], atol=5e-5, rtol=1e-5)
 
 
-def test_forward_matches_transformers_masked_and_lengths():
-    z, sd, cfg = load_fixture()
+@pytest.mark.parametrize("name", FIXTURES)
+def test_forward_matches_transformers_masked_and_lengths(name):
+    z, sd, cfg = load_fixture(name)
     x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
     xm = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
     out, key_len = ow.forward(cfg, sd, xm, lengths)

@@ -113,9 +113,9 @@ def lib() -> C.CDLL:
     L.ts_w2v_conv0_workspace_bytes.argtypes = [i32, i64, i32, i32, i32]
     L.ts_w2v_conv0_workspace_bytes.restype = i64
     L.ts_w2v_conv0_fwd.argtypes = [vp, i32, i64, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
-    L.ts_w2v_conv_fwd.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.ts_w2v_conv_fwd.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.ts_w2v_linear_fwd.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
-    L.ts_w2v_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, f32, i64, i32, vp, vp, vp]
+    L.ts_w2v_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, f32, i64, i32, i32, vp, vp, vp]
     L.ts_w2v_mask_rows.argtypes = [vp, i32, i32, i32, vp, vp]
     L.ts_w2v_posconv_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.ts_w2v_posconv_workspace_bytes.restype = i64

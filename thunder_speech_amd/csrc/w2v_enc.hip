@@ -47,6 +47,7 @@ struct Conv0Args {
   unsigned short* y16;              // optional bf16 copy
   long long n;
   int t0, c, k, s, chunks;
+  int plain;                        // 1: y = conv + beta (bias), no normalisation, no activation (layer-norm family)
   float eps;
 };
 
@@ -65,13 +66,15 @@ __global__ __launch_bounds__(256) void w2v_conv0_kernel(const Conv0Args a) {
 #pragma unroll
     for (int j = 0; j < C0_KMAX; ++j) w[j] = j < a.k ? a.w[(size_t)c * a.k + j] : 0.f;
     if constexpr (APPLY) {
-      const float scale = a.stats[((size_t)b * a.c + c) * 2], shift = a.stats[((size_t)b * a.c + c) * 2 + 1];
+      const float scale = a.plain ? 1.f : a.stats[((size_t)b * a.c + c) * 2];
+      const float shift = a.plain ? (a.beta ? a.beta[c] : 0.f) : a.stats[((size_t)b * a.c + c) * 2 + 1];
       const size_t o0 = ((size_t)b * a.t0 + f0) * a.c + c;
       for (int f = 0; f < nf; ++f) {
         float v = 0.f;
 #pragma unroll
         for (int j = 0; j < C0_KMAX; ++j) if (j < a.k) v = fmaf(w[j], sig[f * a.s + j], v);
-        v = gelu_erf(fmaf(v, scale, shift));
+        v = fmaf(v, scale, shift);
+        if (!a.plain) v = gelu_erf(v);
         if (a.y) a.y[o0 + (size_t)f * a.c] = v;
         if (a.y16) a.y16[o0 + (size_t)f * a.c] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
       }
@@ -143,7 +146,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void w2v_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ xbias, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y, long long rows, int c,
-                                                            float eps, unsigned short* __restrict__ y16) {
+                                                            float eps, unsigned short* __restrict__ y16, int act) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -180,8 +183,9 @@ __global__ __launch_bounds__(256) void w2v_layernorm_kernel(const float* __restr
     const int i = (it * 64 + lane) * 4;
     if (i < c) {
       const float4 w4 = *reinterpret_cast<const float4*>(w + i), b4 = *reinterpret_cast<const float4*>(b + i);
-      const float4 o4 = float4{(v[it].x - mu) * rs * w4.x + b4.x, (v[it].y - mu) * rs * w4.y + b4.y, (v[it].z - mu) * rs * w4.z + b4.z,
-                               (v[it].w - mu) * rs * w4.w + b4.w};
+      float4 o4 = float4{(v[it].x - mu) * rs * w4.x + b4.x, (v[it].y - mu) * rs * w4.y + b4.y, (v[it].z - mu) * rs * w4.z + b4.z,
+                         (v[it].w - mu) * rs * w4.w + b4.w};
+      if (act) o4 = float4{gelu_erf(o4.x), gelu_erf(o4.y), gelu_erf(o4.z), gelu_erf(o4.w)};
       *reinterpret_cast<float4*>(y + row * c + i) = o4;
       if (y16) *reinterpret_cast<uint2*>(y16 + row * c + i) = uint2{pack_bf16(o4.x, o4.y), pack_bf16(o4.z, o4.w)};
     }
@@ -500,7 +504,7 @@ extern "C" int64_t ts_w2v_conv0_workspace_bytes(int32_t batch, int64_t n_samples
 extern "C" int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const float* w, const float* gn_w,
                                 const float* gn_b, int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* y_bf16,
                                 void* workspace, void* stream_) {
-  if (!wave || !w || !gn_w || !gn_b || (!y && !y_bf16) || !workspace || batch <= 0 || c <= 0 || stride <= 0 || n_samples < kernel) return TS_EINVAL;
+  if (!wave || !w || (gn_w && !gn_b) || (!y && !y_bf16) || !workspace || batch <= 0 || c <= 0 || stride <= 0 || n_samples < kernel) return TS_EINVAL;
   if (kernel <= 0 || kernel > C0_KMAX) return TS_EUNSUPPORTED;
   TS_STREAM;
   Conv0Args a{};
@@ -512,16 +516,20 @@ extern "C" int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samp
   a.stats = a.partial + (size_t)batch * a.chunks * c * 2;
   const size_t lds = ((size_t)(C0_FR - 1) * stride + kernel) * sizeof(float);
   if (lds > 64 * 1024) return TS_EUNSUPPORTED;
-  hipLaunchKernelGGL(w2v_conv0_kernel<false>, dim3(a.chunks, batch), dim3(256), lds, stream, a);
-  hipLaunchKernelGGL(w2v_conv0_finalize_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, a);
+  a.plain = gn_w ? 0 : 1;
+  if (!a.plain) {
+    hipLaunchKernelGGL(w2v_conv0_kernel<false>, dim3(a.chunks, batch), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(w2v_conv0_finalize_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, a);
+  }
   hipLaunchKernelGGL(w2v_conv0_kernel<true>, dim3(a.chunks, batch), dim3(256), lds, stream, a);
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, int32_t c_out,
-                               int32_t kernel, int32_t stride, int32_t precision, float* y, void* y_bf16, void* stream_) {
+extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, const float* bias,
+                               int32_t c_out, int32_t kernel, int32_t stride, int32_t act, int32_t precision, float* y, void* y_bf16,
+                               void* stream_) {
   if (!x || !w_taps || !y || batch <= 0 || c_in <= 0 || c_out <= 0 || kernel <= 0 || stride <= 0 || t_in < kernel) return TS_EINVAL;
-  if (c_out % 4 || precision < 0 || precision > 1) return TS_EUNSUPPORTED;
+  if (c_out % 4 || precision < 0 || precision > 1 || act < 0 || act > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
@@ -538,9 +546,10 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
       return st;
   }
   const long long rows = (long long)batch * t_out;
-  // with a bf16 copy requested the f32 buffer is only the GEMM accumulator: it is not written back after the GELU
-  hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (c_out / 4))), dim3(256), 0, stream, y, (const float*)nullptr,
-                     (const float*)nullptr, rows, c_out, (long long)c_out, 0LL, y_bf16 ? 3 : 1, static_cast<unsigned short*>(y_bf16));
+  // with a bf16 copy requested the f32 buffer is only the GEMM accumulator: it is not written back after the epilogue
+  if (bias || act || y_bf16)
+    hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (c_out / 4))), dim3(256), 0, stream, y, bias, (const float*)nullptr, rows,
+                       c_out, (long long)c_out, 0LL, act | (y_bf16 ? 2 : 0), static_cast<unsigned short*>(y_bf16));
   return hip_status(hipGetLastError());
 }
 
@@ -561,13 +570,13 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
 }
 
 extern "C" int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* xbias, const float* w, const float* b, float eps,
-                                    int64_t rows, int32_t c, float* y, void* y_bf16, void* stream_) {
+                                    int64_t rows, int32_t c, int32_t act, float* y, void* y_bf16, void* stream_) {
   if (!x || !w || !b || !y || rows <= 0 || c <= 0) return TS_EINVAL;
   if (c % 4 || c > 4096) return TS_EUNSUPPORTED;
   TS_STREAM;
   const dim3 grid((unsigned)((rows + 3) / 4));
   unsigned short* y16 = static_cast<unsigned short*>(y_bf16);
-#define TS_LN(NV_) hipLaunchKernelGGL(w2v_layernorm_kernel<NV_>, grid, dim3(256), 0, stream, x, res, xbias, w, b, y, (long long)rows, c, eps, y16)
+#define TS_LN(NV_) hipLaunchKernelGGL(w2v_layernorm_kernel<NV_>, grid, dim3(256), 0, stream, x, res, xbias, w, b, y, (long long)rows, c, eps, y16, act)
   if (c <= 512) TS_LN(2); else if (c <= 1024) TS_LN(4); else if (c <= 2048) TS_LN(8); else TS_LN(16);
 #undef TS_LN
   return hip_status(hipGetLastError());

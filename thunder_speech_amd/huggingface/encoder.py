@@ -30,18 +30,16 @@ def feat_extract_output_lengths(conv_kernel, conv_stride, lengths: torch.Tensor)
 
 def _check_config(cfg) -> None:
     bad = []
-    if getattr(cfg, "feat_extract_norm", "group") != "group":
+    if getattr(cfg, "feat_extract_norm", "group") not in ("group", "layer"):
         bad.append(f"feat_extract_norm={cfg.feat_extract_norm!r}")
-    if getattr(cfg, "do_stable_layer_norm", False):
-        bad.append("do_stable_layer_norm=True")
-    if getattr(cfg, "conv_bias", False):
-        bad.append("conv_bias=True")
+    if getattr(cfg, "add_adapter", False):
+        bad.append("add_adapter=True")
     if getattr(cfg, "hidden_act", "gelu") != "gelu" or getattr(cfg, "feat_extract_activation", "gelu") != "gelu":
         bad.append("activation != gelu")
     if getattr(cfg, "position_embeddings_type", None) not in (None, "absolute") and hasattr(cfg, "position_embeddings_type"):
         bad.append(f"position_embeddings_type={cfg.position_embeddings_type!r}")
     if bad:
-        raise NotImplementedError("wav2vec2 HIP path: group-norm / post-LN wav2vec2 configurations only; got " + ", ".join(bad))
+        raise NotImplementedError("wav2vec2 HIP path: unsupported configuration: " + ", ".join(bad))
 
 
 class Wav2Vec2Plan:
@@ -66,8 +64,15 @@ class Wav2Vec2Plan:
         self.kpos = int(cfg.num_conv_pos_embeddings)
         self.groups = int(cfg.num_conv_pos_embedding_groups)
         self.eps = float(cfg.layer_norm_eps)
+        self.layer_norm_convs = getattr(cfg, "feat_extract_norm", "group") == "layer"      # lv60 / xlsr family
+        self.stable_ln = bool(getattr(cfg, "do_stable_layer_norm", False))
+        opt = lambda k: f(k) if k in sd else None
+        self.conv_b = [opt(f"feature_extractor.conv_layers.{i}.conv.bias") if getattr(cfg, "conv_bias", False) else None
+                       for i in range(len(self.kernels))]
+        self.conv_ln = [(f(f"feature_extractor.conv_layers.{i}.layer_norm.weight"), f(f"feature_extractor.conv_layers.{i}.layer_norm.bias"))
+                        for i in range(len(self.kernels))] if self.layer_norm_convs else None
         self.w0 = f("feature_extractor.conv_layers.0.conv.weight").reshape(self.dims[0], self.kernels[0]).contiguous()
-        self.gn_w = f("feature_extractor.conv_layers.0.layer_norm.weight")
+        self.gn_w = f("feature_extractor.conv_layers.0.layer_norm.weight")       # GroupNorm affine ("group" family)
         self.gn_b = f("feature_extractor.conv_layers.0.layer_norm.bias")
         # [c_out][c_in][k] -> [c_out][k][c_in]: consecutive taps are consecutive K columns of one GEMM
         self.conv_w = [gw(f(f"feature_extractor.conv_layers.{i}.conv.weight").permute(0, 2, 1))
@@ -109,22 +114,23 @@ class Wav2Vec2Plan:
     def _ptr(t):
         return t.data_ptr() if t is not None else None
 
-    def _linear(self, L, stream, x_op, w, bias, act=0, want_op=False):
+    def _linear(self, L, stream, x_op, w, bias, act=0, want_op=False, res=None):
         """want_op: the consumer is another GEMM -- in bf16 mode only the bf16 copy is kept (the fp32 buffer is scratch)."""
         b, t, k = x_op.shape
         n = w.shape[0]
         y = self._buf(b, t, n)
         y_op = self._op(b, t, n) if want_op else None
-        st = L.ts_w2v_linear_fwd(x_op.data_ptr(), k, w.data_ptr(), self._ptr(bias), None, n, y.data_ptr(), n, self._ptr(y_op),
+        st = L.ts_w2v_linear_fwd(x_op.data_ptr(), k, w.data_ptr(), self._ptr(bias), self._ptr(res), n, y.data_ptr(), n, self._ptr(y_op),
                                  b * t, n, k, act | (2 if y_op is not None else 0), self.prec, stream)
         _lib.check(st, "ts_w2v_linear_fwd")
         return y, (y_op if self.prec else y)
 
-    def _ln(self, L, stream, x, wb, res=None, xbias=None, want_op=True):
+    def _ln(self, L, stream, x, wb, res=None, xbias=None, want_op=True, act=0, eps=None):
         y = torch.empty_like(x)
         y_op = self._op(*x.shape) if want_op else None
-        st = L.ts_w2v_layernorm_fwd(x.data_ptr(), self._ptr(res), self._ptr(xbias), wb[0].data_ptr(), wb[1].data_ptr(), self.eps,
-                                    x.shape[0] * x.shape[1], x.shape[2], y.data_ptr(), self._ptr(y_op), stream)
+        st = L.ts_w2v_layernorm_fwd(x.data_ptr(), self._ptr(res), self._ptr(xbias), wb[0].data_ptr(), wb[1].data_ptr(),
+                                    self.eps if eps is None else eps, x.shape[0] * x.shape[1], x.shape[2], act, y.data_ptr(),
+                                    self._ptr(y_op), stream)
         _lib.check(st, "ts_w2v_layernorm_fwd")
         return y, (y_op if self.prec else y)
 
@@ -138,7 +144,25 @@ class Wav2Vec2Plan:
             raise RuntimeError(f"wav2vec2: input of {n} samples is shorter than the first conv kernel ({k0})")
         t = (n - k0) // s0 + 1
         ws = self._buf(L.ts_w2v_conv0_workspace_bytes(b, n, c0, k0, s0), dtype=torch.uint8)
-        last = len(self.kernels) == 1
+        n_conv = len(self.kernels)
+        if self.layer_norm_convs:
+            # every layer: conv (+ bias) -> LayerNorm over the channels -> GELU; the conv output stays fp32 for the LayerNorm
+            h = self._buf(b, t, c0)
+            _lib.check(L.ts_w2v_conv0_fwd(audio.data_ptr(), b, n, self.w0.data_ptr(), None, self._ptr(self.conv_b[0]), c0, k0, s0, 1e-5,
+                                          h.data_ptr(), None, ws.data_ptr(), stream), "ts_w2v_conv0_fwd")
+            h, x_op = self._ln(L, stream, h, self.conv_ln[0], act=1, eps=1e-5, want_op=n_conv > 1)
+            for i, w in enumerate(self.conv_w, start=1):
+                k, s = self.kernels[i], self.strides[i]
+                t_out = (t - k) // s + 1
+                if t_out < 1:
+                    raise RuntimeError("wav2vec2: input too short for the conv feature extractor")
+                y = self._buf(b, t_out, self.dims[i])
+                _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self._ptr(self.conv_b[i]), self.dims[i],
+                                             k, s, 0, self.prec, y.data_ptr(), None, stream), "ts_w2v_conv_fwd")
+                h, x_op = self._ln(L, stream, y, self.conv_ln[i], act=1, eps=1e-5, want_op=i < n_conv - 1)
+                t = t_out
+            return h
+        last = n_conv == 1
         h = self._buf(b, t, c0) if (not self.prec or last) else None       # bf16 mode: the next conv only reads the bf16 copy
         h_op = self._op(b, t, c0)
         _lib.check(L.ts_w2v_conv0_fwd(audio.data_ptr(), b, n, self.w0.data_ptr(), self.gn_w.data_ptr(), self.gn_b.data_ptr(), c0, k0,
@@ -149,11 +173,11 @@ class Wav2Vec2Plan:
             t_out = (t - k) // s + 1
             if t_out < 1:
                 raise RuntimeError("wav2vec2: input too short for the conv feature extractor")
-            last = i == len(self.kernels) - 1
+            last = i == n_conv - 1
             y = self._buf(b, t_out, self.dims[i])
             y_op = None if last else self._op(b, t_out, self.dims[i])
-            _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self.dims[i], k, s, self.prec,
-                                         y.data_ptr(), self._ptr(y_op), stream), "ts_w2v_conv_fwd")
+            _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self._ptr(self.conv_b[i]), self.dims[i], k, s,
+                                         1, self.prec, y.data_ptr(), self._ptr(y_op), stream), "ts_w2v_conv_fwd")
             h, t = y, t_out
             x_op = y_op if self.prec else y
         return h
@@ -177,14 +201,30 @@ class Wav2Vec2Plan:
         _lib.check(L.ts_w2v_posconv_fwd(h.data_ptr(), b, t, c, self.pos_w.data_ptr(), self.pos_b.data_ptr(), self.kpos, self.groups,
                                         self.prec, hp.data_ptr(), None, ws.data_ptr(), stream), "ts_w2v_posconv_fwd")
         del ws
-        h, h_op = self._ln(L, stream, hp, self.enc_ln)
         att_ws = self._buf(L.ts_w2v_attention_workspace_bytes(b, t, self.heads, self.prec), dtype=torch.uint8)
-        for lw in self.layers:
-            _, qkv_op = self._linear(L, stream, h_op, lw["wqkv"], lw["bqkv"], want_op=True)
+
+        def attention(x_op):
+            _, qkv_op = self._linear(L, stream, x_op, lw["wqkv"], lw["bqkv"], want_op=True)
             ctx_op = self._buf(b, t, c, dtype=torch.bfloat16 if self.prec else torch.float32)
             _lib.check(L.ts_w2v_attention_fwd(qkv_op.data_ptr(), b, t, c, self.heads, self._ptr(key_len), self.prec, ctx_op.data_ptr(),
                                               att_ws.data_ptr(), stream), "ts_w2v_attention_fwd")
-            o, _ = self._linear(L, stream, ctx_op, lw["wo"], None)            # the bias rides in the LayerNorm launch
+            return ctx_op
+
+        if self.stable_ln:
+            # pre-LN family: h += attn(LN(h)); h += ffn(LN(h)); one LayerNorm after the last layer
+            h = hp
+            for lw in self.layers:
+                _, x_op = self._ln(L, stream, h, lw["ln1"])
+                h, _ = self._linear(L, stream, attention(x_op), lw["wo"], lw["bo"], res=h)
+                _, x_op = self._ln(L, stream, h, lw["ln2"])
+                _, f1_op = self._linear(L, stream, x_op, lw["w1"], lw["b1"], act=1, want_op=True)
+                h, _ = self._linear(L, stream, f1_op, lw["w2"], lw["b2"], res=h)
+            h, _ = self._ln(L, stream, h, self.enc_ln, want_op=False)
+            return h
+        # post-LN family: LayerNorm before the layers, after each residual add inside them
+        h, h_op = self._ln(L, stream, hp, self.enc_ln)
+        for lw in self.layers:
+            o, _ = self._linear(L, stream, attention(h_op), lw["wo"], None)       # the bias rides in the LayerNorm launch
             h, h_op = self._ln(L, stream, o, lw["ln1"], res=h, xbias=lw["bo"])
             _, f1_op = self._linear(L, stream, h_op, lw["w1"], lw["b1"], act=1, want_op=True)
             f2, _ = self._linear(L, stream, f1_op, lw["w2"], None)
