@@ -38,12 +38,30 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
   const int li = clamp_len(len_in, b, t_in);
   const float* xr = x + (size_t)row * t_in;
   for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
-  for (int e = threadIdx.x; e < span; e += 256) {
+  for (int e = threadIdx.x; e < span + 6; e += 256) {       // + 6: overreach of the 4-output sliding window (zeros)
     const int i = i0 + e;
-    xs[e] = (i >= 0 && i < li) ? xr[i] : 0.f;
+    xs[e] = (e < span && i >= 0 && i < li) ? xr[i] : 0.f;
   }
   __syncthreads();
   const int lo = len_out ? clamp_len(len_out, b, t_out) : t_out;
+  if (s == 1 && d == 1) {
+    // every body layer: 4 consecutive outputs per thread, the input window slides through registers -- per tap one LDS read
+    // of the weight (broadcast) and one of the next sample feed 4 FMAs (the one-output form needs 2 reads per FMA)
+    for (int t4 = threadIdx.x * 4; t4 < nt; t4 += 1024) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float* xp = xs + t4;                          // xs holds (nt - 1) + k samples; reads beyond are discarded below
+      float w0 = xp[0], w1 = xp[1], w2 = xp[2];
+      for (int j = 0; j < k; ++j) {
+        const float wj = ws[j], w3 = xp[j + 3];
+        a0 = fmaf(wj, w0, a0); a1 = fmaf(wj, w1, a1); a2 = fmaf(wj, w2, a2); a3 = fmaf(wj, w3, a3);
+        w0 = w1; w1 = w2; w2 = w3;
+      }
+      const float out[4] = {a0, a1, a2, a3};
+      for (int m = 0; m < 4; ++m)
+        if (t4 + m < nt) y[(size_t)row * t_out + t0 + t4 + m] = t0 + t4 + m < lo ? out[m] : 0.f;
+    }
+    return;
+  }
   for (int tt = threadIdx.x; tt < nt; tt += 256) {
     float acc = 0.f;
     const float* xp = xs + tt * s;
@@ -69,9 +87,33 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
   const int g1 = n_hi < 0 ? -1 : (n_hi / s < t_out - 1 ? n_hi / s : t_out - 1);
   const float* gr = dy + (size_t)row * t_out;
   for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
+  const int li = clamp_len(len_in, b, t_in);
+  if (s == 1 && d == 1) {
+    // every body layer: gs2[e] = dy[n_lo + e] with zeros outside the row, dx[i0 + ii] = sum_j w[j] gs2[ii + k - 1 - j];
+    // 4 consecutive outputs per thread, the window slides DOWN one sample per tap (2 LDS reads per 4 FMAs, no bounds checks)
+    const int n2 = ni + k - 1 + 6;
+    for (int e = threadIdx.x; e < n2; e += 256) {
+      const int n = n_lo + e - 3;                           // 3 zero samples of slack below the window
+      gs[e] = (n >= 0 && n < t_out) ? gr[n] : 0.f;
+    }
+    __syncthreads();
+    for (int i4 = threadIdx.x * 4; i4 < ni; i4 += 1024) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float* gp = gs + 3 + i4 + k - 1;                // sample of output i4, tap 0
+      float w0 = gp[0], w1 = gp[1], w2 = gp[2], w3 = gp[3];
+      for (int j = 0; j < k; ++j) {
+        const float wj = ws[j];
+        a0 = fmaf(wj, w0, a0); a1 = fmaf(wj, w1, a1); a2 = fmaf(wj, w2, a2); a3 = fmaf(wj, w3, a3);
+        w3 = w2; w2 = w1; w1 = w0; w0 = gp[-1 - j];
+      }
+      const float out[4] = {a0, a1, a2, a3};
+      for (int m = 0; m < 4; ++m)
+        if (i4 + m < ni) dx[(size_t)row * t_in + i0 + i4 + m] = i0 + i4 + m < li ? out[m] : 0.f;
+    }
+    return;
+  }
   for (int e = threadIdx.x; e <= g1 - g0; e += 256) gs[e] = gr[g0 + e];
   __syncthreads();
-  const int li = clamp_len(len_in, b, t_in);
   for (int ii = threadIdx.x; ii < ni; ii += 256) {
     const int i = i0 + ii;
     float acc = 0.f;
@@ -95,42 +137,72 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
   }
 }
 
-// dw[c,j] = sum_{b,t} dy[b,c,t] * xm[b,c,t*s + j*d - p].  One workgroup per channel: each clip's dy and x rows go through
-// LDS once, thread (tap j, slice q) accumulates its share of the frames, the slices are reduced at the end.
+// dw[c,j] = sum_{b,t} dy[b,c,t] * xm[b,c,t*s + j*d - p].  One workgroup per (channel, clip group): each clip's dy and x rows
+// go through LDS once.  Thread = (group of 4 taps, contiguous slice of the frames); for stride 1 / dilation 1 (every layer but
+// the stem and the dilated one) it slides a 4-sample x window through registers: per frame 2 LDS reads feed 4 FMAs (the
+// one-tap-per-thread form needs 8).  fp32 partials per clip, fp64 across clips and slices.
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const int* __restrict__ len_in, float* __restrict__ dw, int batch,
                                                             int ch, int t_in, int t_out, int k, int s, int d, int p) {
   extern __shared__ float sm[];
   float* const gs = sm;                       // [t_out]
-  float* const xs = sm + t_out;               // [t_in]
-  double* const red = reinterpret_cast<double*>(sm + round_up(t_out + t_in, 2));   // [256]
+  float* const xs = sm + t_out + 4;           // [-p .. t_in + 3]: zero margins, so the sliding window needs no bounds checks
+  const int xoff = p + 4;                     // xs index of input frame 0
+  const int xlen = t_in + 2 * p + 8;
+  double* const red = reinterpret_cast<double*>(sm + round_up(t_out + 4 + xlen, 2));   // [256][4]
   const int c = blockIdx.x;
-  const int kp = k <= 32 ? 32 : (k <= 64 ? 64 : 128);
-  const int j = threadIdx.x % kp, q = threadIdx.x / kp, nq = 256 / kp;
-  double acc = 0.0;
+  const int ng = (k + 3) / 4;                 // tap groups
+  const int nq = 256 / ng;                    // frame slices
+  const int g = threadIdx.x % ng, q = threadIdx.x / ng;
+  const bool active = q < nq;
+  const int per_q = (t_out + nq - 1) / nq;
+  const int t_lo = q * per_q, t_hi = t_lo + per_q < t_out ? t_lo + per_q : t_out;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
   const int per = (batch + gridDim.y - 1) / gridDim.y;
   const int b_lo = blockIdx.y * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
   for (int b = b_lo; b < b_hi; ++b) {
     const int li = clamp_len(len_in, b, t_in);
     __syncthreads();
     for (int e = threadIdx.x; e < t_out; e += 256) gs[e] = dy[((size_t)b * ch + c) * t_out + e];
-    for (int e = threadIdx.x; e < t_in; e += 256) xs[e] = e < li ? x[((size_t)b * ch + c) * t_in + e] : 0.f;
+    for (int e = threadIdx.x; e < xlen; e += 256) {
+      const int i = e - xoff;
+      xs[e] = (i >= 0 && i < li) ? x[((size_t)b * ch + c) * t_in + i] : 0.f;
+    }
     __syncthreads();
-    if (j < k) {
-      float part = 0.f;
-      for (int t = q; t < t_out; t += nq) {
-        const int i = t * s + j * d - p;
-        if (i >= 0 && i < t_in) part = fmaf(gs[t], xs[i], part);
+    if (active) {
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+      if (s == 1 && d == 1) {
+        // taps 4g .. 4g+3 of frame t read x[t + 4g - p + 0..3]: a window that moves by one sample per frame
+        const float* xw = xs + xoff + 4 * g - p;
+        float w0 = xw[t_lo], w1 = xw[t_lo + 1], w2 = xw[t_lo + 2];
+        for (int t = t_lo; t < t_hi; ++t) {
+          const float w3 = xw[t + 3], gv = gs[t];
+          part[0] = fmaf(gv, w0, part[0]); part[1] = fmaf(gv, w1, part[1]);
+          part[2] = fmaf(gv, w2, part[2]); part[3] = fmaf(gv, w3, part[3]);
+          w0 = w1; w1 = w2; w2 = w3;
+        }
+      } else {
+        for (int t = t_lo; t < t_hi; ++t) {
+          const float gv = gs[t];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int i = t * s + (4 * g + jj) * d - p;
+            if (4 * g + jj < k && i >= 0 && i < t_in) part[jj] = fmaf(gv, xs[xoff + i], part[jj]);
+          }
+        }
       }
-      acc += (double)part;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[jj] += (double)part[jj];
     }
   }
   __syncthreads();
-  red[threadIdx.x] = acc;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) red[threadIdx.x * 4 + jj] = active ? acc[jj] : 0.0;
   __syncthreads();
-  if (q == 0 && j < k) {
+  if (threadIdx.x < k) {
+    const int j = threadIdx.x, gj = j >> 2, jj = j & 3;
     double tot = 0.0;
-    for (int r = 0; r < nq; ++r) tot += red[r * kp + j];
+    for (int r = 0; r < nq; ++r) tot += red[(r * ng + gj) * 4 + jj];
     atomicAdd(dw + (size_t)c * k + j, (float)tot);       // dw is zeroed by the launcher; clips are split over blockIdx.y
   }
 }
@@ -251,7 +323,7 @@ extern "C" int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const 
   if (!x || !w || !y || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0 || stride <= 0 || dil <= 0) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
-  const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1) * sizeof(float);
+  const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 8) * sizeof(float);
   if (lds > 64 * 1024) return TS_EUNSUPPORTED;
   hipLaunchKernelGGL(dw_fwd_kernel, dim3((t_out + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds, stream, x, len_in, len_out, w, y,
                      batch, ch, t_in, t_out, k, stride, dil, pad);
@@ -264,8 +336,9 @@ extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_
   if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
-  const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2) * sizeof(float);
-  const size_t lds_w = (size_t)round_up(t_out + t_in, 2) * sizeof(float) + 256 * sizeof(double);
+  const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 8) * sizeof(float);
+  const size_t lds_w = (size_t)round_up(t_out + 4 + t_in + 2 * pad + 8, 2) * sizeof(float) + 256 * 4 * sizeof(double);
+  if (k > 256) return TS_EUNSUPPORTED;
   if (lds_d > 64 * 1024 || lds_w > 64 * 1024) return TS_EUNSUPPORTED;
   hipLaunchKernelGGL(dw_bwd_data_kernel, dim3((t_in + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds_d, stream, dy, len_in, w, dx,
                      batch, ch, t_in, t_out, k, stride, dil, pad);

@@ -205,8 +205,9 @@ class _FusedBlockBase(nn.Module):
             last = r == len(subs) - 1
             if dw is not None:
                 h = T.DepthwiseConv.apply(h, dw.conv.weight, lh, dw.kernel_size, dw.stride, dw.dilation, dw.padding)
-                out_lengths = dw.get_seq_len(out_lengths)
-                lh = _t.lengths_i32(out_lengths, dev)
+                if dw.stride != 1 or 2 * dw.padding != dw.dilation * (dw.kernel_size - 1):
+                    out_lengths = dw.get_seq_len(out_lengths)      # only length-changing convs cost host work / tiny launches
+                    lh = _t.lengths_i32(out_lengths, dev)
             if pw.kernel_size != 1 or pw.stride != 1:
                 raise NotImplementedError("training mode: dense convs other than 1x1 / stride 1 have no HIP kernel")
             h = T.PointwiseConv.apply(T.MaskTime.apply(h, lh), pw.conv.weight)
