@@ -181,9 +181,11 @@ int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* y, int32_t batch,
                         int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride, int32_t dilation,
                         int32_t padding, void* stream);
-int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const float* w, float* dx, float* dw, int32_t batch,
-                        int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride, int32_t dilation,
-                        int32_t padding, void* stream);
+/* len_out (may be NULL) in both directions: the forward zeroes y from len_out[b] on -- the re-masking the next MaskedConv1d applies
+ * (quartznet/blocks.py:169-171) -- and the backward treats dy as zero there; no separate masking pass is needed then. */
+int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* dx,
+                        float* dw, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride,
+                        int32_t dilation, int32_t padding, void* stream);
 int ts_train_mask_time(const float* x, const int32_t* len, float* y, int32_t batch, int32_t channels, int32_t t, void* stream);
 int ts_train_pwconv_fwd(const float* u, const float* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t, void* stream);
 int ts_train_pwconv_bwd(const float* dv, const float* u, const float* w, float* du, float* dw, float* workspace, int32_t batch,

@@ -127,7 +127,7 @@ def lib() -> C.CDLL:
                "ts_w2v_posconv_fwd", "ts_w2v_attention_fwd"):
         getattr(L, fn).restype = C.c_int
     L.ts_train_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
-    L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
+    L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
     L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     L.ts_train_pwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]

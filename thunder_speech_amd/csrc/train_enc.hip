@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
 // dx[b,c,i] = (i < len_in) ? sum_k w[c,k] * dy[b,c,(i + p - k*d)/s] : 0    (terms with a non-integer or out-of-range index drop out)
 // One workgroup = DW_TILE input frames of one row; the dy span that can reach them is staged in LDS.
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const int* __restrict__ len_in,
-                                                          const float* __restrict__ w, float* __restrict__ dx, int batch, int ch,
-                                                          int t_in, int t_out, int k, int s, int d, int p) {
+                                                          const int* __restrict__ len_out, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int batch, int ch, int t_in, int t_out, int k, int s,
+                                                          int d, int p) {
   extern __shared__ float sm[];
   float* const ws = sm;
   float* const gs = sm + DW_KMAX;
@@ -88,13 +89,14 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
   const float* gr = dy + (size_t)row * t_out;
   for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
   const int li = clamp_len(len_in, b, t_in);
+  const int lo = len_out ? clamp_len(len_out, b, t_out) : t_out;     // the forward zeroed y from here on: so is its gradient
   if (s == 1 && d == 1) {
     // every body layer: gs2[e] = dy[n_lo + e] with zeros outside the row, dx[i0 + ii] = sum_j w[j] gs2[ii + k - 1 - j];
     // 4 consecutive outputs per thread, the window slides DOWN one sample per tap (2 LDS reads per 4 FMAs, no bounds checks)
     const int n2 = ni + k - 1 + 6;
     for (int e = threadIdx.x; e < n2; e += 256) {
       const int n = n_lo + e - 3;                           // 3 zero samples of slack below the window
-      gs[e] = (n >= 0 && n < t_out) ? gr[n] : 0.f;
+      gs[e] = (n >= 0 && n < lo) ? gr[n] : 0.f;
     }
     __syncthreads();
     for (int i4 = threadIdx.x * 4; i4 < ni; i4 += 1024) {
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
     }
     return;
   }
-  for (int e = threadIdx.x; e <= g1 - g0; e += 256) gs[e] = gr[g0 + e];
+  for (int e = threadIdx.x; e <= g1 - g0; e += 256) gs[e] = g0 + e < lo ? gr[g0 + e] : 0.f;
   __syncthreads();
   for (int ii = threadIdx.x; ii < ni; ii += 256) {
     const int i = i0 + ii;
@@ -142,8 +144,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
 // the stem and the dilated one) it slides a 4-sample x window through registers: per frame 2 LDS reads feed 4 FMAs (the
 // one-tap-per-thread form needs 8).  fp32 partials per clip, fp64 across clips and slices.
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const int* __restrict__ len_in, float* __restrict__ dw, int batch,
-                                                            int ch, int t_in, int t_out, int k, int s, int d, int p) {
+                                                            const int* __restrict__ len_in, const int* __restrict__ len_out,
+                                                            float* __restrict__ dw, int batch, int ch, int t_in, int t_out, int k, int s,
+                                                            int d, int p) {
   extern __shared__ float sm[];
   float* const gs = sm;                       // [t_out]
   float* const xs = sm + t_out + 4;           // [-p .. t_in + 3]: zero margins, so the sliding window needs no bounds checks
@@ -163,7 +166,8 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
   for (int b = b_lo; b < b_hi; ++b) {
     const int li = clamp_len(len_in, b, t_in);
     __syncthreads();
-    for (int e = threadIdx.x; e < t_out; e += 256) gs[e] = dy[((size_t)b * ch + c) * t_out + e];
+    const int lo = len_out ? clamp_len(len_out, b, t_out) : t_out;
+    for (int e = threadIdx.x; e < t_out; e += 256) gs[e] = e < lo ? dy[((size_t)b * ch + c) * t_out + e] : 0.f;
     for (int e = threadIdx.x; e < xlen; e += 256) {
       const int i = e - xoff;
       xs[e] = (i >= 0 && i < li) ? x[((size_t)b * ch + c) * t_in + i] : 0.f;
@@ -330,9 +334,9 @@ extern "C" int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const 
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const float* w, float* dx, float* dw,
-                                   int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k, int32_t stride, int32_t dil,
-                                   int32_t pad, void* stream_) {
+extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const int32_t* len_out, const float* w,
+                                   float* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
+                                   int32_t stride, int32_t dil, int32_t pad, void* stream_) {
   if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
@@ -340,11 +344,11 @@ extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_
   const size_t lds_w = (size_t)round_up(t_out + 4 + t_in + 2 * pad + 8, 2) * sizeof(float) + 256 * 4 * sizeof(double);
   if (k > 256) return TS_EUNSUPPORTED;
   if (lds_d > 64 * 1024 || lds_w > 64 * 1024) return TS_EUNSUPPORTED;
-  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3((t_in + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds_d, stream, dy, len_in, w, dx,
-                     batch, ch, t_in, t_out, k, stride, dil, pad);
+  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3((t_in + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds_d, stream, dy, len_in, len_out, w,
+                     dx, batch, ch, t_in, t_out, k, stride, dil, pad);
   if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)ch * k, stream) != hipSuccess) return TS_EUNSUPPORTED;
-  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(ch, batch < 8 ? batch : 8), dim3(256), lds_w, stream, dy, x, len_in, dw, batch, ch, t_in,
-                     t_out, k, stride, dil, pad);
+  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(ch, batch < 8 ? batch : 8), dim3(256), lds_w, stream, dy, x, len_in, len_out, dw, batch, ch,
+                     t_in, t_out, k, stride, dil, pad);
   return hip_status(hipGetLastError());
 }
 

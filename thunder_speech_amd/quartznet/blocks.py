@@ -203,14 +203,18 @@ class _FusedBlockBase(nn.Module):
         subs = list(self._sub_blocks())
         for r, (dw, pw, bn) in enumerate(subs):
             last = r == len(subs) - 1
+            if pw.kernel_size != 1 or pw.stride != 1:
+                raise NotImplementedError("training mode: dense convs other than 1x1 / stride 1 have no HIP kernel")
             if dw is not None:
-                h = T.DepthwiseConv.apply(h, dw.conv.weight, lh, dw.kernel_size, dw.stride, dw.dilation, dw.padding)
+                lh_in = lh
                 if dw.stride != 1 or 2 * dw.padding != dw.dilation * (dw.kernel_size - 1):
                     out_lengths = dw.get_seq_len(out_lengths)      # only length-changing convs cost host work / tiny launches
                     lh = _t.lengths_i32(out_lengths, dev)
-            if pw.kernel_size != 1 or pw.stride != 1:
-                raise NotImplementedError("training mode: dense convs other than 1x1 / stride 1 have no HIP kernel")
-            h = T.PointwiseConv.apply(T.MaskTime.apply(h, lh), pw.conv.weight)
+                # the depthwise launch writes its output already masked for the pointwise conv (and masks the gradient on the way back)
+                h = T.DepthwiseConv.apply(h, dw.conv.weight, lh_in, dw.kernel_size, dw.stride, dw.dilation, dw.padding, lh)
+            else:
+                h = T.MaskTime.apply(h, lh)
+            h = T.PointwiseConv.apply(h, pw.conv.weight)
             h = T.batch_norm_train(bn, h, relu=not last)
         r_out = None
         if self.res is not None:

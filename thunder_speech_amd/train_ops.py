@@ -20,18 +20,20 @@ def _f32(t: Tensor) -> Tensor:
 
 
 class DepthwiseConv(torch.autograd.Function):
-    """MaskedConv1d with groups = C: y = conv(mask(x, len_in)); backward masks dx the same way."""
+    """MaskedConv1d with groups = C: y = conv(mask(x, len_in)); backward masks dx the same way.  With `len_out` the output is
+    zeroed from len_out[b] on (the re-masking the following MaskedConv1d would apply) and so is the incoming gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, len_in, k, stride, dil, pad):
+    def forward(ctx, x, w, len_in, k, stride, dil, pad, len_out=None):
         x, w2 = _f32(x), _f32(w).view(w.shape[0], -1)
         b, c, t_in = x.shape
         t_out = (t_in + 2 * pad - dil * (k - 1) - 1) // stride + 1
         y = torch.empty(b, c, t_out, dtype=torch.float32, device=x.device)
-        st = _lib.lib().ts_train_dwconv_fwd(x.data_ptr(), len_in.data_ptr(), None, w2.data_ptr(), y.data_ptr(), b, c, t_in, t_out, k,
-                                            stride, dil, pad, _s(x))
+        st = _lib.lib().ts_train_dwconv_fwd(x.data_ptr(), len_in.data_ptr(), len_out.data_ptr() if len_out is not None else None,
+                                            w2.data_ptr(), y.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad, _s(x))
         _lib.check(st, "ts_train_dwconv_fwd")
         ctx.save_for_backward(x, w2, len_in)
+        ctx.len_out = len_out
         ctx.geom = (k, stride, dil, pad, t_out, w.shape)
         return y
 
@@ -42,10 +44,11 @@ class DepthwiseConv(torch.autograd.Function):
         dy = _f32(dy)
         b, c, t_in = x.shape
         dx, dw = torch.empty_like(x), torch.empty_like(w2)
-        st = _lib.lib().ts_train_dwconv_bwd(dy.data_ptr(), x.data_ptr(), len_in.data_ptr(), w2.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                            b, c, t_in, t_out, k, stride, dil, pad, _s(x))
+        lo = ctx.len_out
+        st = _lib.lib().ts_train_dwconv_bwd(dy.data_ptr(), x.data_ptr(), len_in.data_ptr(), lo.data_ptr() if lo is not None else None,
+                                            w2.data_ptr(), dx.data_ptr(), dw.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad, _s(x))
         _lib.check(st, "ts_train_dwconv_bwd")
-        return dx, dw.view(wshape), None, None, None, None, None
+        return dx, dw.view(wshape), None, None, None, None, None, None
 
 
 class MaskTime(torch.autograd.Function):
