@@ -176,7 +176,7 @@ int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *   BatchNorm1d in train mode (quartznet/blocks.py:222, statistics over all B*T frames incl. padding -- quirk A4 --,
  *     biased variance, eps) with optional fused ReLU; mean_rstd f32 [C][2] is saved for the backward
  *   residual add + ReLU (quartznet/blocks.py:332-337)
- * Workspaces: pwconv_bwd B*c_out*c_in floats; bn_fwd 2*C doubles; bn_bwd 2*C doubles + 2*B*C*T floats.
+ * Workspaces: pwconv_bwd B*c_out*c_in floats; bn_fwd and bn_bwd 16*C doubles each (8 clip-group partial sums).
  * ---------------------------------------------------------------------------------------------- */
 int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* y, int32_t batch,
                         int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride, int32_t dilation,

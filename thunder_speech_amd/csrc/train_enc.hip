@@ -220,19 +220,37 @@ __global__ __launch_bounds__(256) void mask_time_kernel(const float* __restrict_
   y[idx] = tt < clamp_len(len, b, t) ? x[idx] : 0.f;
 }
 
-// per-channel sums over all B*T frames: out[c] = (sum a, sum a*b) (b may alias a); fp64 accumulation
-__global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict__ a, const float* __restrict__ bsrc,
-                                                        double* __restrict__ out, int batch, int ch, int t) {
+// Per-channel sums over all B*T frames in BN_G clip groups (grid ch x BN_G): part[g][c] = (s1, s2), fp64 accumulation; the
+// consumers add the BN_G partials in a fixed order (deterministic, no atomics).
+//   MODE 0 (forward statistics):  s1 = sum v,  s2 = sum v^2
+//   MODE 1 (backward statistics): g = dy * (y > 0 if relu), xhat = (v - mean) * rstd:  s1 = sum g,  s2 = sum g * xhat
+//          -- g and xhat are recomputed here and in the apply kernel instead of being written out and read back twice
+constexpr int BN_G = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict__ a, const float* __restrict__ y, const float* __restrict__ v,
+                                                        const float* __restrict__ mean_rstd, double* __restrict__ part, int batch,
+                                                        int ch, int t, int relu) {
   __shared__ double r1[256], r2[256];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, grp = blockIdx.y;
+  const int per = (batch + BN_G - 1) / BN_G;
+  const int b_lo = grp * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
+  float mu = 0.f, rs = 0.f;
+  if (MODE == 1) { mu = mean_rstd[2 * c]; rs = mean_rstd[2 * c + 1]; }
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < batch; ++b) {
-    const float* pa = a + ((size_t)b * ch + c) * t;
-    const float* pb = bsrc + ((size_t)b * ch + c) * t;
+  for (int b = b_lo; b < b_hi; ++b) {
+    const size_t row = ((size_t)b * ch + c) * t;
     for (int i = threadIdx.x; i < t; i += 256) {
-      const double va = pa[i];
-      s1 += va;
-      s2 += va * (double)pb[i];
+      if (MODE == 0) {
+        const double va = a[row + i];
+        s1 += va;
+        s2 += va * va;
+      } else {
+        const float gv = (relu && !(y[row + i] > 0.f)) ? 0.f : a[row + i];
+        const float xh = (v[row + i] - mu) * rs;
+        s1 += (double)gv;
+        s2 += (double)gv * (double)xh;
+      }
     }
   }
   r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
@@ -241,11 +259,17 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict_
     if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[2 * c] = r1[0]; out[2 * c + 1] = r2[0]; }
+  if (threadIdx.x == 0) { part[((size_t)grp * ch + c) * 2] = r1[0]; part[((size_t)grp * ch + c) * 2 + 1] = r2[0]; }
+}
+
+__device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch, int c, double& s1, double& s2) {
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int g = 0; g < BN_G; ++g) { s1 += part[((size_t)g * ch + c) * 2]; s2 += part[((size_t)g * ch + c) * 2 + 1]; }
 }
 
 // BatchNorm(train) forward: stats[c] = (sum v, sum v^2) -> mean, rstd (biased variance, eps), y = gamma*(v-mean)*rstd + beta [ReLU]
-__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v, const double* __restrict__ sums,
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v, const double* __restrict__ part,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ mean_rstd, int batch, int ch, int t,
                                                      float eps, int relu) {
@@ -253,8 +277,10 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v
   if (idx >= (long long)batch * ch * t) return;
   const int c = (int)((idx / t) % ch);
   const double n = (double)batch * t;
-  const double mu = sums[2 * c] / n;
-  double var = sums[2 * c + 1] / n - mu * mu;
+  double s1, s2;
+  bn_total(part, ch, c, s1, s2);
+  const double mu = s1 / n;
+  double var = s2 / n - mu * mu;
   var = var < 0.0 ? 0.0 : var;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   if (idx % t == 0 && idx / ((long long)t * ch) == 0) { mean_rstd[2 * c] = (float)mu; mean_rstd[2 * c + 1] = rstd; }
@@ -263,31 +289,23 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v
   y[idx] = o;
 }
 
-// g = dy * (y > 0) when relu; used twice: first to reduce (sum g, sum g*xhat), then to apply
-// dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat))
-__global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                          const float* __restrict__ v, const float* __restrict__ mean_rstd,
-                                                          float* __restrict__ g, float* __restrict__ xhat, int batch, int ch, int t,
-                                                          int relu) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)batch * ch * t) return;
-  const int c = (int)((idx / t) % ch);
-  g[idx] = (relu && !(y[idx] > 0.f)) ? 0.f : dy[idx];
-  xhat[idx] = (v[idx] - mean_rstd[2 * c]) * mean_rstd[2 * c + 1];
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ xhat,
-                                                           const double* __restrict__ sums, const float* __restrict__ gamma,
-                                                           const float* __restrict__ mean_rstd, float* __restrict__ dv,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int batch, int ch,
-                                                           int t) {
+// dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (y > 0) when relu,  xhat = (v - mean) * rstd
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ v, const double* __restrict__ part,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                           float* __restrict__ dv, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int batch, int ch, int t, int relu) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)batch * ch * t) return;
   const int c = (int)((idx / t) % ch);
   const double n = (double)batch * t;
-  const float mg = (float)(sums[2 * c] / n), mgx = (float)(sums[2 * c + 1] / n);
-  if (idx % t == 0 && idx / ((long long)t * ch) == 0) { dbeta[c] = (float)sums[2 * c]; dgamma[c] = (float)sums[2 * c + 1]; }
-  dv[idx] = gamma[c] * mean_rstd[2 * c + 1] * (g[idx] - mg - xhat[idx] * mgx);
+  double s1, s2;
+  bn_total(part, ch, c, s1, s2);
+  const float mg = (float)(s1 / n), mgx = (float)(s2 / n);
+  if (idx % t == 0 && idx / ((long long)t * ch) == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  const float g = (relu && !(y[idx] > 0.f)) ? 0.f : dy[idx];
+  const float xhat = (v[idx] - mean_rstd[2 * c]) * mean_rstd[2 * c + 1];
+  dv[idx] = gamma[c] * mean_rstd[2 * c + 1] * (g - mg - xhat * mgx);
 }
 
 // out = relu(a + b); backward: da = db = dout * (out > 0)
@@ -395,13 +413,14 @@ extern "C" int ts_train_pwconv_bwd(const float* dv, const float* u, const float*
   return hip_status(hipGetLastError());
 }
 
-// workspace: c * 2 doubles.  mean_rstd f32 [c][2] is saved for the backward.
+// workspace: 16 * c doubles (8 clip-group partials of 2 sums).  mean_rstd f32 [c][2] is saved for the backward.
 extern "C" int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace,
                                int32_t batch, int32_t ch, int32_t t, float eps, int32_t relu, void* stream_) {
   if (!v || !gamma || !beta || !y || !mean_rstd || !workspace || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
   TS_STREAM;
   double* sums = static_cast<double*>(workspace);
-  hipLaunchKernelGGL(chan_sums_kernel, dim3(ch), dim3(256), 0, stream, v, v, sums, batch, ch, t);
+  hipLaunchKernelGGL(chan_sums_kernel<0>, dim3(ch, BN_G), dim3(256), 0, stream, v, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, sums, batch, ch, t, 0);
   hipLaunchKernelGGL(bn_fwd_kernel, dim3(blocks((long long)batch * ch * t)), dim3(256), 0, stream, v, sums, gamma, beta, y, mean_rstd, batch,
                      ch, t, eps, relu);
   return hip_status(hipGetLastError());
@@ -415,11 +434,9 @@ extern "C" int ts_train_bn_bwd(const float* dy, const float* y, const float* v, 
   TS_STREAM;
   const long long n = (long long)batch * ch * t;
   double* sums = static_cast<double*>(workspace);
-  float* g = reinterpret_cast<float*>(sums + 2 * (size_t)ch);
-  float* xhat = g + n;
-  hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(blocks(n)), dim3(256), 0, stream, dy, y, v, mean_rstd, g, xhat, batch, ch, t, relu);
-  hipLaunchKernelGGL(chan_sums_kernel, dim3(ch), dim3(256), 0, stream, g, xhat, sums, batch, ch, t);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(n)), dim3(256), 0, stream, g, xhat, sums, gamma, mean_rstd, dv, dgamma, dbeta, batch, ch, t);
+  hipLaunchKernelGGL(chan_sums_kernel<1>, dim3(ch, BN_G), dim3(256), 0, stream, dy, y, v, mean_rstd, sums, batch, ch, t, relu);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(n)), dim3(256), 0, stream, dy, y, v, sums, gamma, mean_rstd, dv, dgamma, dbeta, batch,
+                     ch, t, relu);
   return hip_status(hipGetLastError());
 }
 

@@ -111,7 +111,7 @@ class BatchNormTrain(torch.autograd.Function):
         b, c, t = v.shape
         y = torch.empty_like(v)
         mr = torch.empty(c, 2, dtype=torch.float32, device=v.device)
-        ws = torch.empty(2 * c, dtype=torch.float64, device=v.device)
+        ws = torch.empty(16 * c, dtype=torch.float64, device=v.device)
         st = _lib.lib().ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c, t,
                                         float(eps), int(relu), _s(v))
         _lib.check(st, "ts_train_bn_fwd")
@@ -129,7 +129,7 @@ class BatchNormTrain(torch.autograd.Function):
         b, c, t = v.shape
         dv = torch.empty_like(v)
         dg, db = torch.empty(c, dtype=torch.float32, device=v.device), torch.empty(c, dtype=torch.float32, device=v.device)
-        ws = torch.empty(2 * c * 8 + 2 * v.numel() * 4, dtype=torch.uint8, device=v.device)
+        ws = torch.empty(16 * c, dtype=torch.float64, device=v.device)
         st = _lib.lib().ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(),
                                         db.data_ptr(), ws.data_ptr(), b, c, t, int(ctx.relu), _s(v))
         _lib.check(st, "ts_train_bn_bwd")
