@@ -190,8 +190,11 @@ int ts_train_mask_time(const float* x, const int32_t* len, float* y, int32_t bat
 int ts_train_pwconv_fwd(const float* u, const float* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t, void* stream);
 int ts_train_pwconv_bwd(const float* dv, const float* u, const float* w, float* du, float* dw, float* workspace, int32_t batch,
                         int32_t c_in, int32_t c_out, int32_t t, void* stream);
+/* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
+ * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */
 int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace, int32_t batch,
-                    int32_t channels, int32_t t, float eps, int32_t relu, void* stream);
+                    int32_t channels, int32_t t, float eps, int32_t relu, float* running_mean, float* running_var, float momentum,
+                    int64_t* num_batches_tracked, void* stream);
 int ts_train_bn_bwd(const float* dy, const float* y, const float* v, const float* gamma, const float* mean_rstd, float* dv,
                     float* dgamma, float* dbeta, void* workspace, int32_t batch, int32_t channels, int32_t t, int32_t relu,
                     void* stream);

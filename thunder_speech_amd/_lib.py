@@ -131,7 +131,7 @@ def lib() -> C.CDLL:
     L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     L.ts_train_pwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    L.ts_train_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
+    L.ts_train_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, f32, vp, vp]
     L.ts_train_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.ts_train_add_relu_fwd.argtypes = [vp, vp, vp, i64, vp]
     L.ts_train_relu_bwd.argtypes = [vp, vp, vp, i64, vp]

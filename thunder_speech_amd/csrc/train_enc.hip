@@ -272,7 +272,9 @@ __device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v, const double* __restrict__ part,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ mean_rstd, int batch, int ch, int t,
-                                                     float eps, int relu) {
+                                                     float eps, int relu, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float momentum,
+                                                     long long* __restrict__ num_batches_tracked) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)batch * ch * t) return;
   const int c = (int)((idx / t) % ch);
@@ -283,7 +285,14 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v
   double var = s2 / n - mu * mu;
   var = var < 0.0 ? 0.0 : var;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  if (idx % t == 0 && idx / ((long long)t * ch) == 0) { mean_rstd[2 * c] = (float)mu; mean_rstd[2 * c + 1] = rstd; }
+  if (idx % t == 0 && idx / ((long long)t * ch) == 0) {           // one thread per channel
+    mean_rstd[2 * c] = (float)mu; mean_rstd[2 * c + 1] = rstd;
+    if (running_mean) {    // nn.BatchNorm1d's update: momentum blend of the batch mean and the UNBIASED batch variance
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+      if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    }
+  }
   float o = gamma[c] * (v[idx] - (float)mu) * rstd + beta[c];
   if (relu) o = o > 0.f ? o : 0.f;
   y[idx] = o;
@@ -415,14 +424,16 @@ extern "C" int ts_train_pwconv_bwd(const float* dv, const float* u, const float*
 
 // workspace: 16 * c doubles (8 clip-group partials of 2 sums).  mean_rstd f32 [c][2] is saved for the backward.
 extern "C" int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace,
-                               int32_t batch, int32_t ch, int32_t t, float eps, int32_t relu, void* stream_) {
+                               int32_t batch, int32_t ch, int32_t t, float eps, int32_t relu, float* running_mean, float* running_var,
+                               float momentum, int64_t* num_batches_tracked, void* stream_) {
   if (!v || !gamma || !beta || !y || !mean_rstd || !workspace || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TS_EINVAL;
   TS_STREAM;
   double* sums = static_cast<double*>(workspace);
   hipLaunchKernelGGL(chan_sums_kernel<0>, dim3(ch, BN_G), dim3(256), 0, stream, v, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, sums, batch, ch, t, 0);
   hipLaunchKernelGGL(bn_fwd_kernel, dim3(blocks((long long)batch * ch * t)), dim3(256), 0, stream, v, sums, gamma, beta, y, mean_rstd, batch,
-                     ch, t, eps, relu);
+                     ch, t, eps, relu, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   return hip_status(hipGetLastError());
 }
 

@@ -102,22 +102,22 @@ class PointwiseConv(torch.autograd.Function):
 
 
 class BatchNormTrain(torch.autograd.Function):
-    """BatchNorm1d in train mode (+ optional ReLU): statistics over all B*T frames (quirk A4).  Returns y and leaves the
-    batch mean / biased variance in `stats_out` ([2, C]) for the running-statistics update."""
+    """BatchNorm1d in train mode (+ optional ReLU): statistics over all B*T frames (quirk A4).  `running` = (running_mean,
+    running_var, momentum, num_batches_tracked) or None: the module's running statistics, updated by the same launch."""
 
     @staticmethod
-    def forward(ctx, v, gamma, beta, eps, relu, stats_out):
+    def forward(ctx, v, gamma, beta, eps, relu, running):
         v, g, be = _f32(v), _f32(gamma), _f32(beta)
         b, c, t = v.shape
         y = torch.empty_like(v)
         mr = torch.empty(c, 2, dtype=torch.float32, device=v.device)
         ws = torch.empty(16 * c, dtype=torch.float64, device=v.device)
+        rm, rv, mom, nbt = running if running is not None else (None, None, 0.0, None)
         st = _lib.lib().ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c, t,
-                                        float(eps), int(relu), _s(v))
+                                        float(eps), int(relu), rm.data_ptr() if rm is not None else None,
+                                        rv.data_ptr() if rv is not None else None, float(mom),
+                                        nbt.data_ptr() if nbt is not None else None, _s(v))
         _lib.check(st, "ts_train_bn_fwd")
-        if stats_out is not None:
-            stats_out[0].copy_(mr[:, 0])
-            stats_out[1].copy_(1.0 / (mr[:, 1] * mr[:, 1]) - eps)
         ctx.save_for_backward(v, y, g, mr)
         ctx.relu = relu
         return y
@@ -161,14 +161,11 @@ class AddRelu(torch.autograd.Function):
 
 def batch_norm_train(bn: torch.nn.BatchNorm1d, v: Tensor, relu: bool) -> Tensor:
     """BatchNorm1d(train) through the kernels + the module's running-statistics update (momentum, unbiased variance)."""
-    c = v.shape[1]
-    stats = torch.empty(2, c, dtype=torch.float32, device=v.device) if bn.track_running_stats else None
-    y = BatchNormTrain.apply(v, bn.weight, bn.bias, bn.eps, relu, stats)
-    if stats is not None:
-        with torch.no_grad():
-            n = v.shape[0] * v.shape[2]
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-            bn.running_mean.mul_(1 - m).add_(stats[0], alpha=m)
-            bn.running_var.mul_(1 - m).add_(stats[1] * (n / max(n - 1, 1)), alpha=m)
-            bn.num_batches_tracked += 1
-    return y
+    running = None
+    if bn.track_running_stats and bn.running_mean is not None:
+        if bn.running_mean.dtype != torch.float32 or bn.running_var.dtype != torch.float32 or not bn.running_mean.is_cuda:
+            raise RuntimeError("batch_norm_train: fp32 running statistics on the GPU only")
+        # momentum=None (cumulative average) needs the counter's value: one host read, the reference default is 0.1
+        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+        running = (bn.running_mean, bn.running_var, m, bn.num_batches_tracked)
+    return BatchNormTrain.apply(v, bn.weight, bn.bias, bn.eps, relu, running)
