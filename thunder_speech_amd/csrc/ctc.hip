@@ -1,7 +1,7 @@
-// CTC loss (forward + gradient w.r.t. the logits) for gfx950, one wavefront per utterance.
+// CTC loss (forward + gradient w.r.t. the logits) for gfx950, one 256-thread workgroup per utterance.
 // Replaces ctc_loss.py:36-47: permute -> log_softmax(dim=2) -> F.ctc_loss(blank, reduction="mean",
 // zero_infinity=True) and its autograd backward.  Graves et al. 2006: log-space alpha/beta recursions
-// over the blank-extended target (L = 2S+1 states spread over the 64 lanes, rows kept in LDS), then
+// over the blank-extended target (L = 2S+1 states spread over the 256 threads, rows kept in LDS), then
 //   dL/dlogit[b, v, t] = (softmax[b, v, t] - sum_{s: ext[s]=v} exp(alpha + beta - lp + nll)) * g_b,
 //   g_b = 1 / (B * max(S_b, 1)), zero for t >= input_len and for utterances whose loss is inf (A10).
 #include "ts_common.hpp"
@@ -28,7 +28,13 @@ struct CtcArgs {
   int batch, n_classes, n_frames, pitch, s_max, lmax, blank;
 };
 
-__global__ __launch_bounds__(64) void ctc_kernel(const CtcArgs a) {
+// The recursions are serial in t, so a step must stay short.  Measured: staging the emissions / alpha rows in LDS chunks does NOT
+// help (the gathers overlap with the log-sum-exp arithmetic of the step); what a backward step spent its time on was (a) the LDS
+// atomics of the occupancy sums -- every other state is the blank, ~S atomics on ONE address -- now a wavefront reduction, and
+// (b) the dense softmax term of the gradient (V exps and scattered stores per step), now one coalesced sweep after the loop.
+constexpr int CTC_NT = 256;     // threads per utterance: one state per thread up to S = 127, so a step is one pass, not L / 64
+
+__global__ __launch_bounds__(CTC_NT) void ctc_kernel(const CtcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L_MAX = a.lmax;
   float* const row0 = reinterpret_cast<float*>(smem);          // [lmax + 2] (two leading -inf guards)
@@ -46,9 +52,9 @@ __global__ __launch_bounds__(64) void ctc_kernel(const CtcArgs a) {
   float* const lse = a.lse + (size_t)b * a.n_frames;
   float* const alpha = a.alpha + (size_t)b * a.n_frames * L_MAX;
 
-  for (int s = lane; s < L; s += 64) ext[s] = (s & 1) ? a.targets[(size_t)b * a.s_max + (s >> 1)] : a.blank;
+  for (int s = lane; s < L; s += CTC_NT) ext[s] = (s & 1) ? a.targets[(size_t)b * a.s_max + (s >> 1)] : a.blank;
   // log-sum-exp per frame (coalesced over t)
-  for (int t = lane; t < T; t += 64) {
+  for (int t = lane; t < T; t += CTC_NT) {
     float m = NEG_INF;
     for (int v = 0; v < V; ++v) m = fmaxf(m, lg[(size_t)v * a.pitch + t]);
     float sum = 0.f;
@@ -67,18 +73,17 @@ __global__ __launch_bounds__(64) void ctc_kernel(const CtcArgs a) {
   if (T == 0) {
     feasible = (S == 0);
   } else {
-    for (int s = lane; s < L; s += 64) {
-      const float v = s < 2 ? lp(0, s) : NEG_INF;
-      prev[s] = v;
-      alpha[s] = v;
-    }
-    __syncthreads();
-    for (int t = 1; t < T; ++t) {
-      for (int s = lane; s < L; s += 64) {
-        const int e = ext[s];
-        const float a0 = prev[s], a1 = prev[s - 1];
-        const float a2 = (s >= 2 && e != a.blank && e != ext[s - 2]) ? prev[s - 2] : NEG_INF;
-        const float v = lse3(a0, a1, a2) + lp(t, s);
+    for (int t = 0; t < T; ++t) {
+      for (int s = lane; s < L; s += CTC_NT) {
+        float v;
+        if (t == 0) {
+          v = s < 2 ? lp(0, s) : NEG_INF;
+        } else {
+          const int e = ext[s];
+          const float a0 = prev[s], a1 = prev[s - 1];
+          const float a2 = (s >= 2 && e != a.blank && e != ext[s - 2]) ? prev[s - 2] : NEG_INF;
+          v = lse3(a0, a1, a2) + lp(t, s);
+        }
         cur[s] = v;
         alpha[(size_t)t * L_MAX + s] = v;
       }
@@ -99,37 +104,46 @@ __global__ __launch_bounds__(64) void ctc_kernel(const CtcArgs a) {
   const float scale = 1.f / ((float)a.batch * (float)(S > 0 ? S : 1));
   // frames >= T (and everything when infeasible): zero gradient
   for (int v = 0; v < V; ++v)
-    for (int t = (feasible ? T : 0) + lane; t < a.n_frames; t += 64) gb[(size_t)v * a.pitch + t] = 0.f;
+    for (int t = (feasible ? T : 0) + lane; t < a.n_frames; t += CTC_NT) gb[(size_t)v * a.pitch + t] = 0.f;
   if (!feasible || T == 0) return;
+  for (int v = lane; v < V; v += CTC_NT) occ[v] = 0.f;
   __syncthreads();
   // beta rows live in prev/cur with two trailing guards: use index s+1, s+2 < L checks instead
   for (int t = T - 1; t >= 0; --t) {
-    for (int s = lane; s < L; s += 64) {
+    float blank_w = 0.f;                                      // occupancy of the blank states handled by this lane
+    for (int s = lane; s < L; s += CTC_NT) {
+      const float e_lp = lp(t, s);
       float v;
       if (t == T - 1) {
-        v = (s >= L - 2) ? lp(t, s) : NEG_INF;
+        v = (s >= L - 2) ? e_lp : NEG_INF;
       } else {
         const int e = ext[s];
         const float b0 = prev[s];
         const float b1 = s + 1 < L ? prev[s + 1] : NEG_INF;
         const float b2 = (s + 2 < L && ext[s + 2] != a.blank && ext[s + 2] != e) ? prev[s + 2] : NEG_INF;
-        v = lse3(b0, b1, b2) + lp(t, s);
+        v = lse3(b0, b1, b2) + e_lp;
       }
       cur[s] = v;
+      // occupancy exp(alpha + beta - lp + nll): v already holds beta[t][s]
+      const float w = expf(alpha[(size_t)t * L_MAX + s] + v - e_lp + nll);
+      if (s & 1) atomicAdd(&occ[ext[s]], w);                  // a label: few states share a class
+      else blank_w += w;                                      // the blank: every other state -> reduce in registers
     }
-    for (int v = lane; v < V; v += 64) occ[v] = 0.f;
+    for (int o = 32; o > 0; o >>= 1) blank_w += __shfl_xor(blank_w, o);
+    if ((lane & 63) == 0) atomicAdd(&occ[a.blank], blank_w);       // one atomic per wavefront
     __syncthreads();
-    for (int s = lane; s < L; s += 64) {
-      const float w = expf(alpha[(size_t)t * L_MAX + s] + cur[s] - lp(t, s) + nll);
-      atomicAdd(&occ[ext[s]], w);
-    }
-    __syncthreads();
-    for (int v = lane; v < V; v += 64) {
-      const float p = expf(lg[(size_t)v * a.pitch + t] - lse[t]);
-      gb[(size_t)v * a.pitch + t] = (p - occ[v]) * scale;
+    for (int v = lane; v < V; v += CTC_NT) {
+      gb[(size_t)v * a.pitch + t] = -occ[v] * scale;          // the softmax term follows below
+      occ[v] = 0.f;
     }
     __syncthreads();
     float* tmp = prev; prev = cur; cur = tmp;
+  }
+  __syncthreads();
+  // dense part of the gradient, coalesced over t: + softmax * scale
+  for (int t = lane; t < T; t += CTC_NT) {
+    const float l = lse[t];
+    for (int v = 0; v < V; ++v) gb[(size_t)v * a.pitch + t] += expf(lg[(size_t)v * a.pitch + t] - l) * scale;
   }
 }
 
@@ -172,7 +186,7 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
   const size_t lds = ((size_t)2 * (a.lmax + 2) + a.lmax + n_classes) * sizeof(float);
   if (lds > 64 * 1024) return TS_EUNSUPPORTED;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ctc_kernel, dim3(batch), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL(ctc_kernel, dim3(batch), dim3(CTC_NT), lds, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   (void)hipGetLastError();
