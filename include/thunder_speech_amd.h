@@ -187,9 +187,13 @@ int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, 
                         float* dw, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride,
                         int32_t dilation, int32_t padding, void* stream);
 int ts_train_mask_time(const float* x, const int32_t* len, float* y, int32_t batch, int32_t channels, int32_t t, void* stream);
-int ts_train_pwconv_fwd(const float* u, const float* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t, void* stream);
-int ts_train_pwconv_bwd(const float* dv, const float* u, const float* w, float* du, float* dw, float* workspace, int32_t batch,
-                        int32_t c_in, int32_t c_out, int32_t t, void* stream);
+/* precision (pointwise convs): 0 = f32 GEMM operands; 1 = bf16 operands (u, w, dv are bf16 copies made by ts_train_cast_bf16),
+ * f32 accumulation and f32 results -- the opt-in mixed-precision mode of the fine-tuning step. */
+int ts_train_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+int ts_train_pwconv_fwd(const void* u, const void* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t, int32_t precision,
+                        void* stream);
+int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, float* du, float* dw, float* workspace, int32_t batch,
+                        int32_t c_in, int32_t c_out, int32_t t, int32_t precision, void* stream);
 /* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
  * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */
 int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace, int32_t batch,

@@ -91,3 +91,42 @@ def test_unfrozen_finetune_step_decreases_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("name", ["qn_res_k11", "qn_dense_k1"])
+def test_bf16_gemm_operands_stay_within_bf16_tolerance(golden, name):
+    """train_ops.set_gemm_precision("bf16"): the pointwise-conv GEMMs multiply bf16 copies (fp32 accumulation); outputs and
+    gradients stay within a few bf16 ulps (2^-8 relative per operand) of the fp32 reference path."""
+    from thunder_speech_amd import train_ops
+    g = golden("blocks.npz")
+    spec = otcs.BlockSpec(**CASES[name])
+    sd = sd_from_npz(g, f"{name}/sd/")
+    x, lengths = torch.from_numpy(g[f"{name}/x"]), torch.from_numpy(g[f"{name}/lengths"])
+    cot = torch.randn(g[f"{name}/y_train"].shape, generator=torch.Generator().manual_seed(1)).cuda()
+
+    def run():
+        blk = _block(spec, sd)
+        xg = x.clone().cuda().requires_grad_(True)
+        y, _ = blk(xg, lengths.cuda())
+        (y * cot).sum().backward()
+        return y.detach(), xg.grad, {k: p.grad for k, p in blk.named_parameters()}
+
+    y0, gx0, gp0 = run()
+    train_ops.set_gemm_precision("bf16")
+    try:
+        y1, gx1, gp1 = run()
+    finally:
+        train_ops.set_gemm_precision("fp32")
+    # operand rounding is 2^-9 relative per product; BatchNorm's backward subtracts means, so single gradient entries can move by
+    # several per cent of the largest entry while the gradient as a whole (rms) moves by about one per cent
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3)
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt()) / max(float(b.pow(2).mean().sqrt()), 1e-6)
+    # (on this tiny fixture -- 16-32 channels, BatchNorm statistics over a few hundred frames, ReLU gates that flip -- the
+    # noise grows towards the first layer: 0.5 % at the output and in the last repeat, 7-9 % rms in the first repeat's weights)
+    assert rel(y1, y0) <= 0.03 and rms(y1, y0) <= 0.01
+    assert rel(gx1, gx0) <= 0.25 and rms(gx1, gx0) <= 0.12
+    for k in gp0:
+        assert rel(gp1[k], gp0[k]) <= 0.3 and rms(gp1[k], gp0[k]) <= 0.15, k
+    last = [k for k in gp0 if k.startswith("res.") or k.startswith("mconv.%d." % (5 * (spec.repeat - 1) + (1 if spec.separable else 0)))]
+    assert last and all(rms(gp1[k], gp0[k]) <= 0.02 for k in last), last
+    assert not torch.equal(y1, y0)                      # the mode really changes the arithmetic

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "ts_pack_activation", "ts_unpack_activation", "ts_se_gate_fwd", "ts_se_apply_fwd",
     "ts_decoder_bwd", "ts_adamw_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd",
-    "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
+    "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
     "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_attention_workspace_bytes",
     "ts_w2v_attention_fwd",
@@ -129,8 +129,10 @@ def lib() -> C.CDLL:
     L.ts_train_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
     L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
     L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, vp]
-    L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
-    L.ts_train_pwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.ts_train_cast_bf16.argtypes = [vp, vp, i64, vp]
+    L.ts_train_cast_bf16.restype = C.c_int
+    L.ts_train_pwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ts_train_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, f32, vp, vp]
     L.ts_train_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.ts_train_add_relu_fwd.argtypes = [vp, vp, vp, i64, vp]

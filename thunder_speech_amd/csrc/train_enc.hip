@@ -386,36 +386,64 @@ extern "C" int ts_train_mask_time(const float* x, const int32_t* len, float* y, 
   return hip_status(hipGetLastError());
 }
 
-// v[b] = W . u[b]   (W [c_out][c_in] row-major, u [B][c_in][t], v [B][c_out][t]); u is expected masked by the caller
-extern "C" int ts_train_pwconv_fwd(const float* u, const float* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t,
-                                   void* stream_) {
+// fp32 -> bf16 (round to nearest even): the operand copies of the mixed-precision GEMMs
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    *reinterpret_cast<uint2*>(y + i) = uint2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+  } else {
+    for (long long j = i; j < n; ++j) y[j] = (unsigned short)(pack_bf16(x[j], 0.f) & 0xffffu);
+  }
+}
+
+static rocblas_status gemm_ex(rocblas_handle h, bool bf16, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const void* a,
+                              int lda, long long sa, const void* b, int ldb, long long sb, float* c, int ldc, long long sc, int batch) {
+  const float one = 1.f, zero = 0.f;
+  const rocblas_datatype in = bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
+  return rocblas_gemm_strided_batched_ex(h, ta, tb, m, n, k, &one, a, in, lda, sa, b, in, ldb, sb, &zero, c, rocblas_datatype_f32_r, ldc, sc, c,
+                                         rocblas_datatype_f32_r, ldc, sc, batch, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+}
+
+extern "C" int ts_train_cast_bf16(const float* x, void* y, int64_t n, void* stream_) {
+  if (!x || !y || n <= 0) return TS_EINVAL;
+  if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(y) % 8) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks((n + 3) / 4)), dim3(256), 0, stream, x, static_cast<unsigned short*>(y), (long long)n);
+  return hip_status(hipGetLastError());
+}
+
+// v[b] = W . u[b]   (W [c_out][c_in] row-major, u [B][c_in][t], v [B][c_out][t]); u is expected masked by the caller.
+// precision 0: f32 operands; 1: u and w are bf16 (ts_train_cast_bf16), f32 accumulation and result.
+extern "C" int ts_train_pwconv_fwd(const void* u, const void* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t,
+                                   int32_t precision, void* stream_) {
   if (!u || !w || !v || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0) return TS_EINVAL;
+  if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int e = blas(stream, &h)) return e;
-  const float one = 1.f, zero = 0.f;
   // row-major [c][t] == column-major [t][c]:  V(t x c_out) = U(t x c_in) . Wc(c_in x c_out)
-  const rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, t, c_out, c_in, &one, u, t,
-                                                          (rocblas_stride)c_in * t, w, c_in, 0, &zero, v, t, (rocblas_stride)c_out * t, batch);
+  const rocblas_status st = gemm_ex(h, precision != 0, rocblas_operation_none, rocblas_operation_none, t, c_out, c_in, u, t, (long long)c_in * t,
+                                    w, c_in, 0, v, t, (long long)c_out * t, batch);
   return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
 }
 
-// du[b] = W^T . dv[b];  dW = sum_b dv[b] . u[b]^T  (workspace: batch * c_out * c_in floats)
-extern "C" int ts_train_pwconv_bwd(const float* dv, const float* u, const float* w, float* du, float* dw, float* workspace, int32_t batch,
-                                   int32_t c_in, int32_t c_out, int32_t t, void* stream_) {
+// du[b] = W^T . dv[b];  dW = sum_b dv[b] . u[b]^T  (workspace: batch * c_out * c_in floats); precision 1: dv, u, w are bf16
+extern "C" int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, float* du, float* dw, float* workspace, int32_t batch,
+                                   int32_t c_in, int32_t c_out, int32_t t, int32_t precision, void* stream_) {
   if (!dv || !u || !w || !du || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0) return TS_EINVAL;
+  if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int e = blas(stream, &h)) return e;
-  const float one = 1.f, zero = 0.f;
+  const bool bf = precision != 0;
   // dU(t x c_in) = dV(t x c_out) . Wc^T(c_out x c_in)
-  rocblas_status st = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, t, c_in, c_out, &one, dv, t,
-                                                    (rocblas_stride)c_out * t, w, c_in, 0, &zero, du, t, (rocblas_stride)c_in * t, batch);
+  rocblas_status st = gemm_ex(h, bf, rocblas_operation_none, rocblas_operation_transpose, t, c_in, c_out, dv, t, (long long)c_out * t, w, c_in, 0,
+                              du, t, (long long)c_in * t, batch);
   if (st != rocblas_status_success) return TS_EUNSUPPORTED;
   // per clip: dWc_b(c_in x c_out) = U^T(c_in x t) . dV(t x c_out)
-  st = rocblas_sgemm_strided_batched(h, rocblas_operation_transpose, rocblas_operation_none, c_in, c_out, t, &one, u, t,
-                                     (rocblas_stride)c_in * t, dv, t, (rocblas_stride)c_out * t, &zero, workspace, c_in,
-                                     (rocblas_stride)c_in * c_out, batch);
+  st = gemm_ex(h, bf, rocblas_operation_transpose, rocblas_operation_none, c_in, c_out, t, u, t, (long long)c_in * t, dv, t, (long long)c_out * t,
+               workspace, c_in, (long long)c_in * c_out, batch);
   if (st != rocblas_status_success) return TS_EUNSUPPORTED;
   const long long rows = (long long)c_in * c_out;
   hipLaunchKernelGGL(sum_parts_kernel, dim3(blocks(rows)), dim3(256), 0, stream, workspace, dw, rows, batch);

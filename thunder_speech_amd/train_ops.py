@@ -9,6 +9,26 @@ from torch import Tensor
 from . import _lib
 
 
+# Operand precision of the pointwise-conv GEMMs (forward and both backward products): "fp32" (default: the reference's
+# arithmetic) or "bf16" (opt-in mixed precision: bf16 operands, fp32 accumulation / results / master weights, like Lightning's
+# precision="bf16-mixed" for the reference).  Set through `set_gemm_precision`.
+_GEMM_BF16 = False
+
+
+def set_gemm_precision(precision: str) -> None:
+    global _GEMM_BF16
+    if precision not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+    _GEMM_BF16 = precision == "bf16"
+
+
+def _bf16(t: Tensor) -> Tensor:
+    """bf16 operand copy of a contiguous fp32 tensor (ts_train_cast_bf16)."""
+    y = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    _lib.check(_lib.lib().ts_train_cast_bf16(t.data_ptr(), y.data_ptr(), t.numel(), _s(t)), "ts_train_cast_bf16")
+    return y
+
+
 def _s(t: Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -82,9 +102,13 @@ class PointwiseConv(torch.autograd.Function):
         b, c_in, t = u.shape
         c_out = w2.shape[0]
         v = torch.empty(b, c_out, t, dtype=torch.float32, device=u.device)
-        _lib.check(_lib.lib().ts_train_pwconv_fwd(u.data_ptr(), w2.data_ptr(), v.data_ptr(), b, c_in, c_out, t, _s(u)), "ts_train_pwconv_fwd")
+        prec = 1 if _GEMM_BF16 else 0
+        if prec:
+            u, w2 = _bf16(u), _bf16(w2)            # the bf16 copies are what the backward needs too: half the saved bytes
+        _lib.check(_lib.lib().ts_train_pwconv_fwd(u.data_ptr(), w2.data_ptr(), v.data_ptr(), b, c_in, c_out, t, prec, _s(v)),
+                   "ts_train_pwconv_fwd")
         ctx.save_for_backward(u, w2)
-        ctx.wshape = w.shape
+        ctx.wshape, ctx.prec = w.shape, prec
         return v
 
     @staticmethod
@@ -93,10 +117,13 @@ class PointwiseConv(torch.autograd.Function):
         dv = _f32(dv)
         b, c_in, t = u.shape
         c_out = w2.shape[0]
-        du, dw = torch.empty_like(u), torch.empty_like(w2)
+        du = torch.empty(u.shape, dtype=torch.float32, device=u.device)
+        dw = torch.empty(w2.shape, dtype=torch.float32, device=u.device)
         ws = torch.empty(b * c_out * c_in, dtype=torch.float32, device=u.device)
+        if ctx.prec:
+            dv = _bf16(dv)
         st = _lib.lib().ts_train_pwconv_bwd(dv.data_ptr(), u.data_ptr(), w2.data_ptr(), du.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in,
-                                            c_out, t, _s(u))
+                                            c_out, t, ctx.prec, _s(du))
         _lib.check(st, "ts_train_pwconv_bwd")
         return du, dw.view(ctx.wshape)
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--seconds", type=int, default=10)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--unfreeze", action="store_true", help="phase 2: encoder trainable (training-mode kernels, full backward)")
+    ap.add_argument("--gemm-bf16", action="store_true", help="phase 2: bf16 operands for the pointwise-conv GEMMs (opt-in mixed precision)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -34,6 +35,9 @@ def main():
     variance_preserving_init_(m.encoder, m.decoder, seed=0)
     m = m.to(dev)
     m.train()
+    if args.gemm_bf16:
+        from thunder_speech_amd import train_ops
+        train_ops.set_gemm_precision("bf16")
     if not args.unfreeze:
         m.encoder.eval()
         for p in m.encoder.parameters():
@@ -63,7 +67,7 @@ def main():
     torch.cuda.synchronize()
     dt = max_over_ranks((time.perf_counter() - t0) / args.steps, dev)
     if rank == 0:
-        print(f"C4 phase {2 if args.unfreeze else 1} ({'encoder unfrozen' if args.unfreeze else 'frozen encoder'}), {world} GPU(s), local batch {B} x {args.seconds} s: {dt * 1e3:.2f} ms/step, "
+        print(f"C4 phase {2 if args.unfreeze else 1} ({'encoder unfrozen' if args.unfreeze else 'frozen encoder'}{', bf16 GEMM operands' if args.gemm_bf16 else ''}), {world} GPU(s), local batch {B} x {args.seconds} s: {dt * 1e3:.2f} ms/step, "
               f"{1 / dt:.1f} step/s, {world * B * args.seconds / dt:,.0f} audio-s/s, loss {float(loss.detach()):.3f}")
     if world > 1:
         dist.destroy_process_group()
