@@ -160,3 +160,30 @@ def test_posconv_mfma_kernel_matches_conv1d(b, t, groups, k):
     assert st == 0
     torch.cuda.synchronize()
     assert float((y.cpu() - ref).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_fused_epilogue_linear_matches_unfused_path(act):
+    """ts_w2v_linear_fwd with bf16 operands and only the bf16 result wanted (library GEMM with the bias / bias+GELU epilogue
+    fused) against exact fp32 arithmetic on the same bf16 operands: the result is bf16, so agreement is to ~1 bf16 ulp --
+    that also bounds what the library's GELU may differ from the erf form by."""
+    import torch.nn.functional as F
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    rows, k, n = 999 * 2, 256, 512
+    g = torch.Generator().manual_seed(act)
+    x = torch.randn(rows, k, generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.bfloat16)
+    b = torch.randn(n, generator=g) * 0.5
+    ref = x.float() @ w.float().T + b
+    if act:
+        ref = F.gelu(ref)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y = torch.empty(rows, n, dtype=torch.float32, device="cuda")
+    y16 = torch.zeros(rows, n, dtype=torch.bfloat16, device="cuda")
+    st = L.ts_w2v_linear_fwd(xd.data_ptr(), k, wd.data_ptr(), bd.data_ptr(), None, n, y.data_ptr(), n, y16.data_ptr(), rows, n, k, act | 2, 1,
+                             torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    err = (y16.float().cpu() - ref).abs()
+    assert float(err.max()) <= 0.02 * max(1.0, float(ref.abs().max())) and float(err.mean()) <= 4e-3

@@ -55,8 +55,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    # rocBLAS: the plain GEMMs of the training-mode pointwise convolutions (csrc/train_enc.hip); everything else is ours
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrocblas"]
+    # rocBLAS / hipBLASLt: plain library GEMMs (training-mode pointwise convs, wav2vec2 linears incl. the fused bias / GELU
+    # epilogue); everything else is ours
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrocblas", "-lhipblaslt"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

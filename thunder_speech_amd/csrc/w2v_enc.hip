@@ -16,6 +16,9 @@
 // accumulation, residual stream, normalisations and softmax stay fp32; every producer writes the bf16 copy its consumer
 // needs next to (or instead of) the fp32 result, so no separate cast pass exists.  Fused MFMA attention is the follow-up.
 #include "ts_blas.hpp"
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <tuple>
 
 namespace ts {
 
@@ -487,6 +490,72 @@ static int gemm_nt(rocblas_handle h, bool bf16, long long m, int n, int k, const
   return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// hipBLASLt GEMM with a fused epilogue (bias, or bias + GELU) and a bf16 result: used when the consumer of a linear layer is
+// another GEMM, so neither the f32 product nor a separate bias / activation pass ever touches HBM.  Plans (descriptor, layouts,
+// heuristic algorithm) are cached per shape.  Any failure returns false and the caller takes the rocBLAS + epilogue-kernel path.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LtPlan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+  bool ok = false;
+};
+
+static bool lt_linear(hipStream_t stream, const void* x, long long lda, const void* w, const float* bias, void* y16, long long rows, int n,
+                      int k, bool gelu) {
+  static hipblasLtHandle_t handle = nullptr;
+  static void* workspace = nullptr;
+  static const size_t WS = (size_t)32 << 20;
+  static std::map<std::tuple<long long, int, int, long long, int>, LtPlan> plans;
+  static const bool disabled = getenv("TS_W2V_NO_HIPBLASLT") != nullptr;     // diagnostic: rocBLAS + epilogue kernel everywhere
+  if (disabled) return false;
+  if (!handle) {
+    if (hipblasLtCreate(&handle) != HIPBLAS_STATUS_SUCCESS) { handle = nullptr; return false; }
+    if (hipMalloc(&workspace, WS) != hipSuccess) { workspace = nullptr; }     // one-time scratch of the library's own
+  }
+  const auto key = std::make_tuple(rows, n, k, lda, gelu ? 1 : 0);
+  auto it = plans.find(key);
+  if (it == plans.end()) {
+    LtPlan p;
+    bool ok = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+    const int32_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+    const uint32_t epi = gelu ? HIPBLASLT_EPILOGUE_GELU_BIAS : HIPBLASLT_EPILOGUE_BIAS;
+    const int32_t bias_type = HIP_R_32F;
+    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type, sizeof(bias_type)) == HIPBLAS_STATUS_SUCCESS;
+    // column-major view: D^T [n x rows] = W(stored k x n, transposed) . X(stored k x rows)
+    ok = ok && hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, k, n, k) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, k, rows, lda) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && hipblasLtMatrixLayoutCreate(&p.d, HIP_R_16BF, n, rows, n) == HIPBLAS_STATUS_SUCCESS;
+    if (ok) {
+      // the bias pointer takes part in the heuristic query on some versions: set a placeholder now, the real one per call
+      ok = hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
+      hipblasLtMatmulPreference_t pref = nullptr;
+      ok = ok && hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
+      const uint64_t max_ws = workspace ? WS : 0;
+      ok = ok && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)) == HIPBLAS_STATUS_SUCCESS;
+      hipblasLtMatmulHeuristicResult_t res[1];
+      int found = 0;
+      ok = ok && hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS &&
+           found > 0 && res[0].state == HIPBLAS_STATUS_SUCCESS;
+      if (ok) { p.algo = res[0].algo; p.ws = res[0].workspaceSize; }
+      if (pref) hipblasLtMatmulPreferenceDestroy(pref);
+    }
+    p.ok = ok;
+    it = plans.emplace(key, p).first;
+  }
+  LtPlan& p = it->second;
+  if (!p.ok) return false;
+  if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
+  const float one = 1.f, zero = 0.f;
+  return hipblasLtMatmul(handle, p.desc, &one, w, p.a, x, p.b, &zero, y16, p.d, y16, p.d, &p.algo, workspace, p.ws, stream) ==
+         HIPBLAS_STATUS_SUCCESS;
+}
+
 }  // namespace ts
 
 using namespace ts;
@@ -562,6 +631,9 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
+  // bf16 operands, only the bf16 copy of the result wanted, a bias to add: one library GEMM with the epilogue fused
+  if (precision && (act & 2) && bias && !res && n % 8 == 0 && k % 8 == 0 && lt_linear(stream, x, lda, w, bias, y_bf16, rows, n, k, (act & 1) != 0))
+    return hip_status(hipGetLastError());
   if (int st = gemm_nt(h, precision != 0, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, 0.f, 1)) return st;
   if (bias || res || act || y_bf16)
     hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (n / 4))), dim3(256), 0, stream, y, bias, res, (long long)rows, n,
