@@ -515,13 +515,14 @@ static bool lt_linear(hipStream_t stream, const void* x, long long lda, const vo
     if (hipblasLtCreate(&handle) != HIPBLAS_STATUS_SUCCESS) { handle = nullptr; return false; }
     if (hipMalloc(&workspace, WS) != hipSuccess) { workspace = nullptr; }     // one-time scratch of the library's own
   }
-  const auto key = std::make_tuple(rows, n, k, lda, gelu ? 1 : 0);
+  const auto key = std::make_tuple(rows, n, k, lda, (gelu ? 1 : 0) | (bias ? 2 : 0));
   auto it = plans.find(key);
   if (it == plans.end()) {
     LtPlan p;
     bool ok = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
     const int32_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
-    const uint32_t epi = gelu ? HIPBLASLT_EPILOGUE_GELU_BIAS : HIPBLASLT_EPILOGUE_BIAS;
+    const uint32_t epi = bias ? (gelu ? HIPBLASLT_EPILOGUE_GELU_BIAS : HIPBLASLT_EPILOGUE_BIAS)
+                              : (gelu ? HIPBLASLT_EPILOGUE_GELU : HIPBLASLT_EPILOGUE_DEFAULT);
     const int32_t bias_type = HIP_R_32F;
     ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
     ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS;
@@ -533,7 +534,7 @@ static bool lt_linear(hipStream_t stream, const void* x, long long lda, const vo
     ok = ok && hipblasLtMatrixLayoutCreate(&p.d, HIP_R_16BF, n, rows, n) == HIPBLAS_STATUS_SUCCESS;
     if (ok) {
       // the bias pointer takes part in the heuristic query on some versions: set a placeholder now, the real one per call
-      ok = hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
+      if (bias) ok = hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
       hipblasLtMatmulPreference_t pref = nullptr;
       ok = ok && hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
       const uint64_t max_ws = workspace ? WS : 0;
@@ -550,7 +551,7 @@ static bool lt_linear(hipStream_t stream, const void* x, long long lda, const vo
   }
   LtPlan& p = it->second;
   if (!p.ok) return false;
-  if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
+  if (bias && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
   const float one = 1.f, zero = 0.f;
   return hipblasLtMatmul(handle, p.desc, &one, w, p.a, x, p.b, &zero, y16, p.d, y16, p.d, &p.algo, workspace, p.ws, stream) ==
          HIPBLAS_STATUS_SUCCESS;
@@ -604,6 +605,18 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
   if (int st = blas(stream, &h)) return st;
   const int t_out = conv_frames(t_in, kernel, stride);
   const size_t es = precision ? 2 : 4;
+  // bf16 operands and only the bf16 result wanted: ONE library GEMM per clip over all taps (K = kernel * c_in; the rows of the
+  // operand overlap when kernel > stride, which the GEMM kernels do not mind: they only ever use the row pitch) with the
+  // bias / GELU epilogue fused and a bf16 result -- no f32 accumulator in HBM, no epilogue pass.  Declined plans fall through.
+  static const bool overlap_ok = getenv("TS_W2V_NO_OVERLAP_GEMM") == nullptr;
+  if (precision && y_bf16 && overlap_ok && c_in % 8 == 0 && c_out % 8 == 0) {
+    bool ok = true;
+    for (int b = 0; b < batch && ok; ++b)
+      ok = lt_linear(stream, static_cast<const char*>(x) + (size_t)b * t_in * c_in * 2, (long long)stride * c_in, w_taps, bias,
+                     static_cast<char*>(y_bf16) + (size_t)b * t_out * c_out * 2, t_out, c_out, kernel * c_in, act != 0);
+    if (ok) return hip_status(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) return TS_EUNSUPPORTED;
+  }
   // Output frame t reads input rows stride*t .. stride*t + kernel - 1, which are CONTIGUOUS in the time-major layout: with a
   // row pitch of stride * c_in the first `stride` taps are one [t_out x stride*c_in] matrix, so taps go `stride` at a time
   // (k = 3, s = 2: taps {0, 1} in one GEMM with K = 2 c_in, tap 2 in a second one accumulating; k = 2, s = 2: one GEMM).
