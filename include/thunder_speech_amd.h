@@ -237,7 +237,8 @@ int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const 
 int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, const float* bias, int32_t c_out,
                     int32_t kernel, int32_t stride, int32_t act, int32_t precision, float* y, void* y_bf16, void* stream);
 /* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act bit 0: GELU (erf), bit 1:
- * only y_bf16 is wanted (y is then scratch space for the f32 GEMM result).  lda / ldc / ld_res: row pitches in elements. */
+ * only y_bf16 is wanted (y is then scratch space for the f32 GEMM result).  res == y (same pitch): the product is accumulated into y
+ * in place (the residual stream).  lda / ldc / ld_res: row pitches in elements. */
 int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res, float* y,
                       int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision, void* stream);
 /* y = act(LayerNorm(x + xbias + res) * w + b) over the last dimension; x, res (may be NULL), y f32 [rows][c]; xbias f32 [c] or

@@ -647,9 +647,12 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
   // bf16 operands, only the bf16 copy of the result wanted, a bias to add: one library GEMM with the epilogue fused
   if (precision && (act & 2) && bias && !res && n % 8 == 0 && k % 8 == 0 && lt_linear(stream, x, lda, w, bias, y_bf16, rows, n, k, (act & 1) != 0))
     return hip_status(hipGetLastError());
-  if (int st = gemm_nt(h, precision != 0, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, 0.f, 1)) return st;
-  if (bias || res || act || y_bf16)
-    hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (n / 4))), dim3(256), 0, stream, y, bias, res, (long long)rows, n,
+  // res == y: accumulate into the residual stream in place (beta = 1 inside the GEMM) -- no separate add, no second tensor to read
+  const bool inplace = res && static_cast<const void*>(res) == static_cast<const void*>(y) && ld_res == ldc;
+  if (int st = gemm_nt(h, precision != 0, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, inplace ? 1.f : 0.f, 1)) return st;
+  const float* res_e = inplace ? nullptr : res;
+  if (bias || res_e || act || y_bf16)
+    hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (n / 4))), dim3(256), 0, stream, y, bias, res_e, (long long)rows, n,
                        (long long)ldc, (long long)ld_res, act, static_cast<unsigned short*>(y_bf16));
   return hip_status(hipGetLastError());
 }

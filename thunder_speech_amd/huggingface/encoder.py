@@ -114,11 +114,13 @@ class Wav2Vec2Plan:
     def _ptr(t):
         return t.data_ptr() if t is not None else None
 
-    def _linear(self, L, stream, x_op, w, bias, act=0, want_op=False, res=None):
-        """want_op: the consumer is another GEMM -- in bf16 mode only the bf16 copy is kept (the fp32 buffer is scratch)."""
+    def _linear(self, L, stream, x_op, w, bias, act=0, want_op=False, res=None, into=None):
+        """want_op: the consumer is another GEMM -- in bf16 mode only the bf16 copy is kept (the fp32 buffer is scratch).
+        into: fp32 tensor the product is accumulated into in place (the residual stream; beta = 1 inside the GEMM)."""
         b, t, k = x_op.shape
         n = w.shape[0]
-        y = self._buf(b, t, n)
+        y = into if into is not None else self._buf(b, t, n)
+        res = into if into is not None else res
         y_op = self._op(b, t, n) if want_op else None
         st = L.ts_w2v_linear_fwd(x_op.data_ptr(), k, w.data_ptr(), self._ptr(bias), self._ptr(res), n, y.data_ptr(), n, self._ptr(y_op),
                                  b * t, n, k, act | (2 if y_op is not None else 0), self.prec, stream)
@@ -215,20 +217,21 @@ class Wav2Vec2Plan:
             h = hp
             for lw in self.layers:
                 _, x_op = self._ln(L, stream, h, lw["ln1"])
-                h, _ = self._linear(L, stream, attention(x_op), lw["wo"], lw["bo"], res=h)
+                self._linear(L, stream, attention(x_op), lw["wo"], lw["bo"], into=h)        # h += attn W^T (+ bias in the epilogue)
                 _, x_op = self._ln(L, stream, h, lw["ln2"])
                 _, f1_op = self._linear(L, stream, x_op, lw["w1"], lw["b1"], act=1, want_op=True)
-                h, _ = self._linear(L, stream, f1_op, lw["w2"], lw["b2"], res=h)
+                self._linear(L, stream, f1_op, lw["w2"], lw["b2"], into=h)
             h, _ = self._ln(L, stream, h, self.enc_ln, want_op=False)
             return h
         # post-LN family: LayerNorm before the layers, after each residual add inside them
         h, h_op = self._ln(L, stream, hp, self.enc_ln)
         for lw in self.layers:
-            o, _ = self._linear(L, stream, attention(h_op), lw["wo"], None)       # the bias rides in the LayerNorm launch
-            h, h_op = self._ln(L, stream, o, lw["ln1"], res=h, xbias=lw["bo"])
+            # the projections accumulate into the residual stream inside the GEMM; their biases ride in the LayerNorm launch
+            self._linear(L, stream, attention(h_op), lw["wo"], None, into=h)
+            h, h_op = self._ln(L, stream, h, lw["ln1"], xbias=lw["bo"])
             _, f1_op = self._linear(L, stream, h_op, lw["w1"], lw["b1"], act=1, want_op=True)
-            f2, _ = self._linear(L, stream, f1_op, lw["w2"], None)
-            h, h_op = self._ln(L, stream, f2, lw["ln2"], res=h, xbias=lw["b2"])
+            self._linear(L, stream, f1_op, lw["w2"], None, into=h)
+            h, h_op = self._ln(L, stream, h, lw["ln2"], xbias=lw["b2"])
         return h
 
 
