@@ -1342,6 +1342,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     int x_soff = x_origin(dwp);
     auto dw_issue = [&]() {
 #pragma unroll
+#if defined(TS_EXP) && (TS_EXP & 128)           // timing experiment: the input rows are fetched once (wrong results)
+      if (gs == 0)
+#endif
       for (int j = 0; j < XP; ++j) X[j] = ld16(rx, lane_x + j * 64, x_soff);
       if (++dw_chunk == n_main) {
         dw_chunk = 0;
@@ -1353,6 +1356,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     };
     int t_next = (n_main > 1 ? 1 : 0) * chunk_t;
     auto tap_dma = [&](int h, int soff, float after = 0.f) {
+#if defined(TS_EXP) && (TS_EXP & 64)            // timing experiment: taps fetched once, never refilled (wrong results)
+      if (gs != 0) return;
+#endif
       lds_dma16(rt, tapl + h * 1024, lane_t, soff + h * 1024, after);
     };
     auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
