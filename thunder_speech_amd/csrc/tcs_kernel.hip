@@ -1547,6 +1547,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     }
   };
   auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
+#if defined(TS_EXP) && (TS_EXP & 512)           // timing experiment: the weight fragments are never reloaded (wrong results)
+    if (gs != 0) return;
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       slot[nt] = __builtin_bit_cast(s16x8, next ? ld16(rwn, lane_w + ks * 1024, wn_soff[nt]) : ld16(rwc, lane_w + ks * 1024, wc_soff[nt]));
@@ -1562,6 +1565,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   };
   s16x8 af[MT], afB[MT];
   auto read_a = [&](const char* src, int ks, s16x8 (&f)[MT]) {
+#if defined(TS_EXP) && (TS_EXP & 256)           // timing experiment: the A fragments are read once (wrong results)
+    if (gs != 0) return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB));
