@@ -1456,12 +1456,18 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         // loads and register loads retire out of order with respect to each other, so a counted vmcnt cannot separate them;
         // hipcc's own waits for the row loads assume in-order retirement and are not enough once DMAs are in the queue.)
 #if !defined(TS_EXP) || !(TS_EXP & 1)          // diagnostic builds: TS_EXP & 1 drops the producers' work, & 2 the consumers'
+        PSTAMP(8 * gs);
         vm_wait<0>();
+        PSTAMP(8 * gs + 1);
         xs_write();
+        PSTAMP(8 * gs + 2);
         dw_begin();
         dw_issue();
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(8 * gs + 3);
         static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PSTAMP(8 * gs + 4);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           const unsigned m0 = pack_bf16(d[m][0], d[m][1]), m1 = pack_bf16(d[m][2], d[m][3]);
@@ -1478,8 +1484,10 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
           }
         }
         tap_advance();
+        PSTAMP(8 * gs + 5);
 #endif
         stage_barrier();
+        PSTAMP(8 * gs + 6);
       }
       if (id2) {
         // a tile that had depthwise stages drains once (tap DMAs and row loads are in the queue: counted waits cannot
@@ -1619,6 +1627,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       mfma_ks(3, afB);
       read_a(dwt + ((gs + 1) & 1) * TILEB, 1, afB);
 #elif !defined(TS_EXP) || !(TS_EXP & 2)
+      PSTAMP(8 * gs);
       read_a(src, 0, af);
       read_a(src, 1, afB);
       __builtin_amdgcn_sched_barrier(0);
@@ -1633,7 +1642,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       mfma_ks(3, afB);
 #endif
       w_advance();
+      PSTAMP(8 * gs + 1);
       stage_barrier();
+      PSTAMP(8 * gs + 2);
     }
     // ---- epilogue (the producers are already on the next tile)
     pos.advance_if(tile + tile_step < tile_end, a.n_tt, a.n_z);
