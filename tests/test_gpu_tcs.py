@@ -132,6 +132,8 @@ def _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, residual, seed=0):
     (256, 256, 33, 1, 1, 1400, [1400, 1399, 700, 5] * 40, True),   # more tiles than CUs: the persistent loop wraps
     (512, 512, 51, 1, 1, 570, [570, 569, 300] * 14 + [33], True),  # 258 tiles: ragged last XCD range of the tile order
     (320, 512, 25, 1, 1, 300, [300, 150, 7], True),                # 5 residual stages (odd): one-ahead identity rows
+    (320, 512, 25, 1, 1, 300, [300, 150, 7] * 43 + [299], True),   # ... and several tiles per workgroup: 5 + 5 stages per tile (row-buffer parity)
+    (512, 512, 63, 1, 1, 751, [751, 700] * 40, False),             # the headline shape with 640 tiles: rows fetched by the consumer waves across tiles
 ])
 def test_tail_zero_fast_kernels_match_oracle(cin, cout, k, stride, dil, t, lens, res):
     _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, res)
