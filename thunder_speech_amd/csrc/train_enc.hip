@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
   const int li = clamp_len(len_in, b, t_in);
   const float* xr = x + (size_t)row * t_in;
   for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
-  for (int e = threadIdx.x; e < span + 6; e += 256) {       // + 6: overreach of the 4-output sliding window (zeros)
+  for (int e = threadIdx.x; e < span + 14; e += 256) {      // + 14: overreach of the 8-output sliding window (zeros)
     const int i = i0 + e;
     xs[e] = (e < span && i >= 0 && i < li) ? xr[i] : 0.f;
   }
@@ -47,18 +47,23 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
   if (s == 1 && d == 1) {
     // every body layer: 4 consecutive outputs per thread, the input window slides through registers -- per tap one LDS read
     // of the weight (broadcast) and one of the next sample feed 4 FMAs (the one-output form needs 2 reads per FMA)
-    for (int t4 = threadIdx.x * 4; t4 < nt; t4 += 1024) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      const float* xp = xs + t4;                          // xs holds (nt - 1) + k samples; reads beyond are discarded below
-      float w0 = xp[0], w1 = xp[1], w2 = xp[2];
+    for (int t8 = threadIdx.x * 8; t8 < nt; t8 += 2048) {    // 8 outputs per thread: 2 LDS reads per 8 FMAs
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* xp = xs + t8;                          // xs holds (nt - 1) + k samples (+ zero slack); excess outputs are discarded
+      float w[8];
+#pragma unroll
+      for (int m = 0; m < 7; ++m) w[m] = xp[m];
       for (int j = 0; j < k; ++j) {
-        const float wj = ws[j], w3 = xp[j + 3];
-        a0 = fmaf(wj, w0, a0); a1 = fmaf(wj, w1, a1); a2 = fmaf(wj, w2, a2); a3 = fmaf(wj, w3, a3);
-        w0 = w1; w1 = w2; w2 = w3;
+        const float wj = ws[j];
+        w[7] = xp[j + 7];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = fmaf(wj, w[m], acc[m]);
+#pragma unroll
+        for (int m = 0; m < 7; ++m) w[m] = w[m + 1];
       }
-      const float out[4] = {a0, a1, a2, a3};
-      for (int m = 0; m < 4; ++m)
-        if (t4 + m < nt) y[(size_t)row * t_out + t0 + t4 + m] = t0 + t4 + m < lo ? out[m] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (t8 + m < nt) y[(size_t)row * t_out + t0 + t8 + m] = t0 + t8 + m < lo ? acc[m] : 0.f;
     }
     return;
   }
@@ -93,24 +98,29 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
   if (s == 1 && d == 1) {
     // every body layer: gs2[e] = dy[n_lo + e] with zeros outside the row, dx[i0 + ii] = sum_j w[j] gs2[ii + k - 1 - j];
     // 4 consecutive outputs per thread, the window slides DOWN one sample per tap (2 LDS reads per 4 FMAs, no bounds checks)
-    const int n2 = ni + k - 1 + 6;
+    const int n2 = ni + k - 1 + 14;
     for (int e = threadIdx.x; e < n2; e += 256) {
       const int n = n_lo + e - 3;                           // 3 zero samples of slack below the window
       gs[e] = (n >= 0 && n < lo) ? gr[n] : 0.f;
     }
     __syncthreads();
-    for (int i4 = threadIdx.x * 4; i4 < ni; i4 += 1024) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      const float* gp = gs + 3 + i4 + k - 1;                // sample of output i4, tap 0
-      float w0 = gp[0], w1 = gp[1], w2 = gp[2], w3 = gp[3];
+    for (int i8 = threadIdx.x * 8; i8 < ni; i8 += 2048) {   // 8 outputs per thread: 2 LDS reads per 8 FMAs
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* gp = gs + 3 + i8 + k - 1;                // sample of output i8, tap 0
+      float w[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) w[m] = gp[m];
       for (int j = 0; j < k; ++j) {
         const float wj = ws[j];
-        a0 = fmaf(wj, w0, a0); a1 = fmaf(wj, w1, a1); a2 = fmaf(wj, w2, a2); a3 = fmaf(wj, w3, a3);
-        w3 = w2; w2 = w1; w1 = w0; w0 = gp[-1 - j];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = fmaf(wj, w[m], acc[m]);
+#pragma unroll
+        for (int m = 7; m > 0; --m) w[m] = w[m - 1];
+        w[0] = gp[-1 - j];
       }
-      const float out[4] = {a0, a1, a2, a3};
-      for (int m = 0; m < 4; ++m)
-        if (i4 + m < ni) dx[(size_t)row * t_in + i0 + i4 + m] = i0 + i4 + m < li ? out[m] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        if (i8 + m < ni) dx[(size_t)row * t_in + i0 + i8 + m] = i0 + i8 + m < li ? acc[m] : 0.f;
     }
     return;
   }
@@ -149,18 +159,21 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
                                                             int d, int p) {
   extern __shared__ float sm[];
   float* const gs = sm;                       // [t_out]
-  float* const xs = sm + t_out + 4;           // [-p .. t_in + 3]: zero margins, so the sliding window needs no bounds checks
+  float* const xs = sm + t_out + 4;           // [-p .. t_in + 7]: zero margins, so the sliding window needs no bounds checks
   const int xoff = p + 4;                     // xs index of input frame 0
-  const int xlen = t_in + 2 * p + 8;
-  double* const red = reinterpret_cast<double*>(sm + round_up(t_out + 4 + xlen, 2));   // [256][4]
+  const int xlen = t_in + 2 * p + 16;
+  double* const red = reinterpret_cast<double*>(sm + round_up(t_out + 4 + xlen, 2));   // [256][TG]
   const int c = blockIdx.x;
-  const int ng = (k + 3) / 4;                 // tap groups
+  constexpr int TG = 8;                       // taps per thread
+  const int ng = (k + TG - 1) / TG;           // tap groups
   const int nq = 256 / ng;                    // frame slices
   const int g = threadIdx.x % ng, q = threadIdx.x / ng;
   const bool active = q < nq;
   const int per_q = (t_out + nq - 1) / nq;
   const int t_lo = q * per_q, t_hi = t_lo + per_q < t_out ? t_lo + per_q : t_out;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  double acc[TG];
+#pragma unroll
+  for (int jj = 0; jj < TG; ++jj) acc[jj] = 0.0;
   const int per = (batch + gridDim.y - 1) / gridDim.y;
   const int b_lo = blockIdx.y * per, b_hi = b_lo + per < batch ? b_lo + per : batch;
   for (int b = b_lo; b < b_hi; ++b) {
@@ -174,39 +187,45 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
     }
     __syncthreads();
     if (active) {
-      float part[4] = {0.f, 0.f, 0.f, 0.f};
+      float part[TG];
+#pragma unroll
+      for (int jj = 0; jj < TG; ++jj) part[jj] = 0.f;
       if (s == 1 && d == 1) {
-        // taps 4g .. 4g+3 of frame t read x[t + 4g - p + 0..3]: a window that moves by one sample per frame
-        const float* xw = xs + xoff + 4 * g - p;
-        float w0 = xw[t_lo], w1 = xw[t_lo + 1], w2 = xw[t_lo + 2];
+        // taps TG g .. TG g + TG-1 of frame t read x[t + TG g - p + 0..TG-1]: a window that moves by one sample per frame
+        const float* xw = xs + xoff + TG * g - p;
+        float w[TG];
+#pragma unroll
+        for (int jj = 0; jj < TG - 1; ++jj) w[jj] = xw[t_lo + jj];
         for (int t = t_lo; t < t_hi; ++t) {
-          const float w3 = xw[t + 3], gv = gs[t];
-          part[0] = fmaf(gv, w0, part[0]); part[1] = fmaf(gv, w1, part[1]);
-          part[2] = fmaf(gv, w2, part[2]); part[3] = fmaf(gv, w3, part[3]);
-          w0 = w1; w1 = w2; w2 = w3;
+          const float gv = gs[t];
+          w[TG - 1] = xw[t + TG - 1];
+#pragma unroll
+          for (int jj = 0; jj < TG; ++jj) part[jj] = fmaf(gv, w[jj], part[jj]);
+#pragma unroll
+          for (int jj = 0; jj < TG - 1; ++jj) w[jj] = w[jj + 1];
         }
       } else {
         for (int t = t_lo; t < t_hi; ++t) {
           const float gv = gs[t];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int i = t * s + (4 * g + jj) * d - p;
-            if (4 * g + jj < k && i >= 0 && i < t_in) part[jj] = fmaf(gv, xs[xoff + i], part[jj]);
+          for (int jj = 0; jj < TG; ++jj) {
+            const int i = t * s + (TG * g + jj) * d - p;
+            if (TG * g + jj < k && i >= 0 && i < t_in) part[jj] = fmaf(gv, xs[xoff + i], part[jj]);
           }
         }
       }
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[jj] += (double)part[jj];
+      for (int jj = 0; jj < TG; ++jj) acc[jj] += (double)part[jj];
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) red[threadIdx.x * 4 + jj] = active ? acc[jj] : 0.0;
+  for (int jj = 0; jj < TG; ++jj) red[threadIdx.x * TG + jj] = active ? acc[jj] : 0.0;
   __syncthreads();
   if (threadIdx.x < k) {
-    const int j = threadIdx.x, gj = j >> 2, jj = j & 3;
+    const int j = threadIdx.x, gj = j / TG, jj = j % TG;
     double tot = 0.0;
-    for (int r = 0; r < nq; ++r) tot += red[(r * ng + gj) * 4 + jj];
+    for (int r = 0; r < nq; ++r) tot += red[(r * ng + gj) * TG + jj];
     atomicAdd(dw + (size_t)c * k + j, (float)tot);       // dw is zeroed by the launcher; clips are split over blockIdx.y
   }
 }
@@ -354,7 +373,7 @@ extern "C" int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const 
   if (!x || !w || !y || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0 || stride <= 0 || dil <= 0) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
-  const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 8) * sizeof(float);
+  const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 16) * sizeof(float);
   if (lds > 64 * 1024) return TS_EUNSUPPORTED;
   hipLaunchKernelGGL(dw_fwd_kernel, dim3((t_out + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds, stream, x, len_in, len_out, w, y,
                      batch, ch, t_in, t_out, k, stride, dil, pad);
@@ -367,8 +386,8 @@ extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_
   if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
-  const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 8) * sizeof(float);
-  const size_t lds_w = (size_t)round_up(t_out + 4 + t_in + 2 * pad + 8, 2) * sizeof(float) + 256 * 4 * sizeof(double);
+  const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 16) * sizeof(float);
+  const size_t lds_w = (size_t)round_up(t_out + 4 + t_in + 2 * pad + 16, 2) * sizeof(float) + 256 * 8 * sizeof(double);
   if (k > 256) return TS_EUNSUPPORTED;
   if (lds_d > 64 * 1024 || lds_w > 64 * 1024) return TS_EUNSUPPORTED;
   hipLaunchKernelGGL(dw_bwd_data_kernel, dim3((t_in + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds_d, stream, dy, len_in, len_out, w,
