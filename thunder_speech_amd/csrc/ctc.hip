@@ -23,25 +23,29 @@ struct CtcArgs {
   const int* target_len;
   float* nll;               // [B]
   float* grad;              // [B][V][pitch] or null
-  float* lse;               // workspace [B][T]   log-sum-exp of each frame
+  float* lse;               // workspace [B][T]   log-sum-exp of each frame (alpha workgroup's copy)
   float* alpha;             // workspace [B][T][lmax]
+  float* lse2;              // workspace [B][T]   (beta workgroup's copy)
+  float* beta;              // workspace [B][T][lmax]
+  int* feasible;            // workspace [B]
   int batch, n_classes, n_frames, pitch, s_max, lmax, blank;
 };
 
-// The recursions are serial in t, so a step must stay short.  Measured: staging the emissions / alpha rows in LDS chunks does NOT
-// help (the gathers overlap with the log-sum-exp arithmetic of the step); what a backward step spent its time on was (a) the LDS
-// atomics of the occupancy sums -- every other state is the blank, ~S atomics on ONE address -- now a wavefront reduction, and
-// (b) the dense softmax term of the gradient (V exps and scattered stores per step), now one coalesced sweep after the loop.
-constexpr int CTC_NT = 256;     // threads per utterance: one state per thread up to S = 127, so a step is one pass, not L / 64
+constexpr int CTC_NT = 256;     // threads per utterance and direction: one state per thread up to S = 127
 
+// The recursions are serial in t (one step costs about 1.2 us whatever is prefetched or staged: it is the barrier + LDS
+// round trip + log-sum-exp chain), so the work is arranged to shorten the serial path instead: the alpha and the beta
+// recursion of an utterance run CONCURRENTLY in two workgroups (blockIdx.y), each storing its rows, and the gradient
+//   dL/dlogit[b, v, t] = (softmax - sum_{s: ext[s]=v} exp(alpha + beta - lp + nll)) * g_b
+// is a third, fully parallel kernel over (utterance, frame).
 __global__ __launch_bounds__(CTC_NT) void ctc_kernel(const CtcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L_MAX = a.lmax;
   float* const row0 = reinterpret_cast<float*>(smem);          // [lmax + 2] (two leading -inf guards)
   float* const row1 = row0 + L_MAX + 2;
   int* const ext = reinterpret_cast<int*>(row1 + L_MAX + 2);   // [lmax]
-  float* const occ = reinterpret_cast<float*>(ext + L_MAX);    // [n_classes]
   const int b = blockIdx.x, lane = threadIdx.x;
+  const bool backward = blockIdx.y != 0;
   const int V = a.n_classes;
   int T = a.input_len[b];
   T = T < 0 ? 0 : (T > a.n_frames ? a.n_frames : T);
@@ -49,8 +53,8 @@ __global__ __launch_bounds__(CTC_NT) void ctc_kernel(const CtcArgs a) {
   S = S < 0 ? 0 : (S > a.s_max ? a.s_max : S);
   const int L = 2 * S + 1;
   const float* lg = a.logits + (size_t)b * V * a.pitch;
-  float* const lse = a.lse + (size_t)b * a.n_frames;
-  float* const alpha = a.alpha + (size_t)b * a.n_frames * L_MAX;
+  float* const lse = (backward ? a.lse2 : a.lse) + (size_t)b * a.n_frames;        // each direction keeps its own copy
+  float* const rows = (backward ? a.beta : a.alpha) + (size_t)b * a.n_frames * L_MAX;
 
   for (int s = lane; s < L; s += CTC_NT) ext[s] = (s & 1) ? a.targets[(size_t)b * a.s_max + (s >> 1)] : a.blank;
   // log-sum-exp per frame (coalesced over t)
@@ -67,84 +71,103 @@ __global__ __launch_bounds__(CTC_NT) void ctc_kernel(const CtcArgs a) {
   float* cur = row1 + 2;
   auto lp = [&](int t, int s) { return lg[(size_t)ext[s] * a.pitch + t] - lse[t]; };
 
-  // ---- alpha ------------------------------------------------------------------------------------------
-  float nll = 0.f;
-  bool feasible = true;
-  if (T == 0) {
-    feasible = (S == 0);
-  } else {
-    for (int t = 0; t < T; ++t) {
-      for (int s = lane; s < L; s += CTC_NT) {
-        float v;
-        if (t == 0) {
-          v = s < 2 ? lp(0, s) : NEG_INF;
-        } else {
-          const int e = ext[s];
-          const float a0 = prev[s], a1 = prev[s - 1];
-          const float a2 = (s >= 2 && e != a.blank && e != ext[s - 2]) ? prev[s - 2] : NEG_INF;
-          v = lse3(a0, a1, a2) + lp(t, s);
+  if (!backward) {
+    // ---- alpha ----------------------------------------------------------------------------------------
+    float nll = 0.f;
+    bool feasible = true;
+    if (T == 0) {
+      feasible = (S == 0);
+    } else {
+      for (int t = 0; t < T; ++t) {
+        for (int s = lane; s < L; s += CTC_NT) {
+          float v;
+          if (t == 0) {
+            v = s < 2 ? lp(0, s) : NEG_INF;
+          } else {
+            const int e = ext[s];
+            const float a0 = prev[s], a1 = prev[s - 1];
+            const float a2 = (s >= 2 && e != a.blank && e != ext[s - 2]) ? prev[s - 2] : NEG_INF;
+            v = lse3(a0, a1, a2) + lp(t, s);
+          }
+          cur[s] = v;
+          rows[(size_t)t * L_MAX + s] = v;
         }
-        cur[s] = v;
-        alpha[(size_t)t * L_MAX + s] = v;
+        __syncthreads();
+        float* tmp = prev; prev = cur; cur = tmp;
       }
-      __syncthreads();
-      float* tmp = prev; prev = cur; cur = tmp;
+      const float l1 = prev[L - 1], l2 = L > 1 ? prev[L - 2] : NEG_INF;
+      const float ll = lse3(l1, l2, NEG_INF);
+      feasible = ll > NEG_INF;
+      nll = -ll;
     }
-    const float l1 = prev[L - 1], l2 = L > 1 ? prev[L - 2] : NEG_INF;
-    const float ll = lse3(l1, l2, NEG_INF);
-    feasible = ll > NEG_INF;
-    nll = -ll;
+    if (lane == 0) {
+      a.nll[b] = feasible ? nll : 0.f;               // zero_infinity=True
+      a.feasible[b] = feasible ? 1 : 0;
+    }
+    return;
   }
-  if (!feasible) nll = 0.f;                          // zero_infinity=True
-  if (lane == 0) a.nll[b] = nll;
-  if (!a.grad) return;
-
-  // ---- beta + gradient ---------------------------------------------------------------------------------
-  float* gb = a.grad + (size_t)b * V * a.pitch;
-  const float scale = 1.f / ((float)a.batch * (float)(S > 0 ? S : 1));
-  // frames >= T (and everything when infeasible): zero gradient
-  for (int v = 0; v < V; ++v)
-    for (int t = (feasible ? T : 0) + lane; t < a.n_frames; t += CTC_NT) gb[(size_t)v * a.pitch + t] = 0.f;
-  if (!feasible || T == 0) return;
-  for (int v = lane; v < V; v += CTC_NT) occ[v] = 0.f;
-  __syncthreads();
-  // beta rows live in prev/cur with two trailing guards: use index s+1, s+2 < L checks instead
+  // ---- beta (rows only: trailing guards are emulated with s + 1, s + 2 < L checks) -------------------------
   for (int t = T - 1; t >= 0; --t) {
-    float blank_w = 0.f;                                      // occupancy of the blank states handled by this lane
     for (int s = lane; s < L; s += CTC_NT) {
-      const float e_lp = lp(t, s);
       float v;
       if (t == T - 1) {
-        v = (s >= L - 2) ? e_lp : NEG_INF;
+        v = (s >= L - 2) ? lp(t, s) : NEG_INF;
       } else {
         const int e = ext[s];
         const float b0 = prev[s];
         const float b1 = s + 1 < L ? prev[s + 1] : NEG_INF;
         const float b2 = (s + 2 < L && ext[s + 2] != a.blank && ext[s + 2] != e) ? prev[s + 2] : NEG_INF;
-        v = lse3(b0, b1, b2) + e_lp;
+        v = lse3(b0, b1, b2) + lp(t, s);
       }
       cur[s] = v;
-      // occupancy exp(alpha + beta - lp + nll): v already holds beta[t][s]
-      const float w = expf(alpha[(size_t)t * L_MAX + s] + v - e_lp + nll);
-      if (s & 1) atomicAdd(&occ[ext[s]], w);                  // a label: few states share a class
-      else blank_w += w;                                      // the blank: every other state -> reduce in registers
-    }
-    for (int o = 32; o > 0; o >>= 1) blank_w += __shfl_xor(blank_w, o);
-    if ((lane & 63) == 0) atomicAdd(&occ[a.blank], blank_w);       // one atomic per wavefront
-    __syncthreads();
-    for (int v = lane; v < V; v += CTC_NT) {
-      gb[(size_t)v * a.pitch + t] = -occ[v] * scale;          // the softmax term follows below
-      occ[v] = 0.f;
+      rows[(size_t)t * L_MAX + s] = v;
     }
     __syncthreads();
     float* tmp = prev; prev = cur; cur = tmp;
   }
+}
+
+// gradient: one wavefront per (utterance, frame), 4 frames per workgroup
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const CtcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L_MAX = a.lmax, V = a.n_classes;
+  int* const ext = reinterpret_cast<int*>(smem);                         // [lmax]
+  float* const occ_all = reinterpret_cast<float*>(ext + L_MAX);          // [4][V]
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + wave;
+  int T = a.input_len[b];
+  T = T < 0 ? 0 : (T > a.n_frames ? a.n_frames : T);
+  int S = a.target_len[b];
+  S = S < 0 ? 0 : (S > a.s_max ? a.s_max : S);
+  const int L = 2 * S + 1;
+  for (int s = threadIdx.x; s < L; s += 256) ext[s] = (s & 1) ? a.targets[(size_t)b * a.s_max + (s >> 1)] : a.blank;
+  float* const occ = occ_all + wave * V;
+  for (int v = lane; v < V; v += 64) occ[v] = 0.f;
   __syncthreads();
-  // dense part of the gradient, coalesced over t: + softmax * scale
-  for (int t = lane; t < T; t += CTC_NT) {
-    const float l = lse[t];
-    for (int v = 0; v < V; ++v) gb[(size_t)v * a.pitch + t] += expf(lg[(size_t)v * a.pitch + t] - l) * scale;
+  if (t >= a.n_frames) return;
+  float* gb = a.grad + (size_t)b * V * a.pitch;
+  const float* lg = a.logits + (size_t)b * V * a.pitch;
+  if (t >= T || !a.feasible[b]) {                                        // frames >= T, and everything when the loss is inf
+    for (int v = lane; v < V; v += 64) gb[(size_t)v * a.pitch + t] = 0.f;
+    return;
   }
+  const float scale = 1.f / ((float)a.batch * (float)(S > 0 ? S : 1));
+  const float l = a.lse[(size_t)b * a.n_frames + t];
+  const float nll = a.nll[b];
+  const float* al = a.alpha + ((size_t)b * a.n_frames + t) * L_MAX;
+  const float* be = a.beta + ((size_t)b * a.n_frames + t) * L_MAX;
+  float blank_w = 0.f;
+  for (int s = lane; s < L; s += 64) {
+    const int e = ext[s];
+    const float w = expf(al[s] + be[s] - (lg[(size_t)e * a.pitch + t] - l) + nll);
+    if (s & 1) atomicAdd(&occ[e], w);                                    // a label: few states share a class
+    else blank_w += w;                                                   // the blank: every other state -> reduce in registers
+  }
+  for (int o = 32; o > 0; o >>= 1) blank_w += __shfl_xor(blank_w, o);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) atomicAdd(&occ[a.blank], blank_w);
+  __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): this wave's LDS atomics have landed
+  for (int v = lane; v < V; v += 64) gb[(size_t)v * a.pitch + t] = (expf(lg[(size_t)v * a.pitch + t] - l) - occ[v]) * scale;
 }
 
 __global__ void ctc_mean_kernel(const float* nll, const int* target_len, int batch, int s_max, float* loss) {
@@ -165,7 +188,7 @@ extern "C" int64_t ts_ctc_workspace_bytes(int32_t batch, int32_t n_classes, int3
   (void)n_classes;
   if (batch <= 0 || n_frames <= 0 || s_max < 0) return TS_EINVAL;
   const int64_t lmax = 2 * (int64_t)s_max + 1;
-  return (int64_t)batch * n_frames * sizeof(float) + (int64_t)batch * n_frames * lmax * sizeof(float);
+  return 2 * ((int64_t)batch * n_frames * sizeof(float) + (int64_t)batch * n_frames * lmax * sizeof(float)) + (int64_t)batch * sizeof(int);
 }
 
 extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes, int32_t n_frames, int32_t pitch,
@@ -181,14 +204,19 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
   a.nll = nll; a.grad = grad;
   a.lse = static_cast<float*>(workspace);
   a.alpha = a.lse + (size_t)batch * n_frames;
+  a.lse2 = a.alpha + (size_t)batch * n_frames * (2 * (size_t)s_max + 1);
+  a.beta = a.lse2 + (size_t)batch * n_frames;
+  a.feasible = reinterpret_cast<int*>(a.beta + (size_t)batch * n_frames * (2 * (size_t)s_max + 1));
   a.batch = batch; a.n_classes = n_classes; a.n_frames = n_frames; a.pitch = pitch; a.s_max = s_max;
   a.lmax = 2 * s_max + 1; a.blank = blank;
-  const size_t lds = ((size_t)2 * (a.lmax + 2) + a.lmax + n_classes) * sizeof(float);
-  if (lds > 64 * 1024) return TS_EUNSUPPORTED;
+  const size_t lds = ((size_t)2 * (a.lmax + 2) + a.lmax) * sizeof(float);
+  const size_t lds_g = ((size_t)a.lmax + 4 * (size_t)n_classes) * sizeof(float);
+  if (lds > 64 * 1024 || lds_g > 64 * 1024) return TS_EUNSUPPORTED;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ctc_kernel, dim3(batch), dim3(CTC_NT), lds, stream, a);
+  hipLaunchKernelGGL(ctc_kernel, dim3(batch, grad ? 2 : 1), dim3(CTC_NT), lds, stream, a);      // alpha || beta
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  if (grad) hipLaunchKernelGGL(ctc_grad_kernel, dim3((n_frames + 3) / 4, batch), dim3(256), lds_g, stream, a);
   (void)hipGetLastError();
   hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, stream, nll, target_len, batch, s_max, loss);
   return hip_status(hipGetLastError());
