@@ -287,53 +287,68 @@ __device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch
   for (int g = 0; g < BN_G; ++g) { s1 += part[((size_t)g * ch + c) * 2]; s2 += part[((size_t)g * ch + c) * 2 + 1]; }
 }
 
-// BatchNorm(train) forward: stats[c] = (sum v, sum v^2) -> mean, rstd (biased variance, eps), y = gamma*(v-mean)*rstd + beta [ReLU]
+// BatchNorm(train) forward: stats[c] = (sum v, sum v^2) -> mean, rstd (biased variance, eps), y = gamma*(v-mean)*rstd + beta [ReLU].
+// One workgroup per (clip, channel) row segment: the channel's statistics are reduced ONCE per workgroup (not per element) and the
+// row is streamed with no index arithmetic.
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v, const double* __restrict__ part,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ mean_rstd, int batch, int ch, int t,
                                                      float eps, int relu, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float momentum,
                                                      long long* __restrict__ num_batches_tracked) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)batch * ch * t) return;
-  const int c = (int)((idx / t) % ch);
-  const double n = (double)batch * t;
-  double s1, s2;
-  bn_total(part, ch, c, s1, s2);
-  const double mu = s1 / n;
-  double var = s2 / n - mu * mu;
-  var = var < 0.0 ? 0.0 : var;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  if (idx % t == 0 && idx / ((long long)t * ch) == 0) {           // one thread per channel
-    mean_rstd[2 * c] = (float)mu; mean_rstd[2 * c + 1] = rstd;
-    if (running_mean) {    // nn.BatchNorm1d's update: momentum blend of the batch mean and the UNBIASED batch variance
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
-      if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  __shared__ float sh[2];
+  const int row = blockIdx.x, c = row % ch;     // grid: x = (clip, channel) rows, y = 1024-frame chunks
+  if (threadIdx.x == 0) {
+    const double n = (double)batch * t;
+    double s1, s2;
+    bn_total(part, ch, c, s1, s2);
+    const double mu = s1 / n;
+    double var = s2 / n - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    sh[0] = (float)mu; sh[1] = rstd;
+    if (row < ch && blockIdx.y == 0) {                           // clip 0's workgroup of this channel publishes the statistics
+      mean_rstd[2 * c] = (float)mu; mean_rstd[2 * c + 1] = rstd;
+      if (running_mean) {    // nn.BatchNorm1d's update: momentum blend of the batch mean and the UNBIASED batch variance
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+      }
     }
   }
-  float o = gamma[c] * (v[idx] - (float)mu) * rstd + beta[c];
-  if (relu) o = o > 0.f ? o : 0.f;
-  y[idx] = o;
+  __syncthreads();
+  const float mu = sh[0], sc = gamma[c] * sh[1], be = beta[c];
+  const size_t base = (size_t)row * t;
+  for (int i = blockIdx.y * 1024 + threadIdx.x; i < t && i < (int)(blockIdx.y + 1) * 1024; i += 256) {
+    float o = sc * (v[base + i] - mu) + be;
+    if (relu) o = o > 0.f ? o : 0.f;
+    y[base + i] = o;
+  }
 }
 
-// dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (y > 0) when relu,  xhat = (v - mean) * rstd
+// dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (y > 0) when relu,  xhat = (v - mean) * rstd; same row-wise shape
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ v, const double* __restrict__ part,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                            float* __restrict__ dv, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int batch, int ch, int t, int relu) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)batch * ch * t) return;
-  const int c = (int)((idx / t) % ch);
-  const double n = (double)batch * t;
-  double s1, s2;
-  bn_total(part, ch, c, s1, s2);
-  const float mg = (float)(s1 / n), mgx = (float)(s2 / n);
-  if (idx % t == 0 && idx / ((long long)t * ch) == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
-  const float g = (relu && !(y[idx] > 0.f)) ? 0.f : dy[idx];
-  const float xhat = (v[idx] - mean_rstd[2 * c]) * mean_rstd[2 * c + 1];
-  dv[idx] = gamma[c] * mean_rstd[2 * c + 1] * (g - mg - xhat * mgx);
+  __shared__ float sh[2];
+  const int row = blockIdx.x, c = row % ch;     // grid: x = (clip, channel) rows, y = 1024-frame chunks
+  if (threadIdx.x == 0) {
+    const double n = (double)batch * t;
+    double s1, s2;
+    bn_total(part, ch, c, s1, s2);
+    sh[0] = (float)(s1 / n); sh[1] = (float)(s2 / n);
+    if (row < ch && blockIdx.y == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  }
+  __syncthreads();
+  const float mg = sh[0], mgx = sh[1], mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1], k = gamma[c] * rs;
+  const size_t base = (size_t)row * t;
+  for (int i = blockIdx.y * 1024 + threadIdx.x; i < t && i < (int)(blockIdx.y + 1) * 1024; i += 256) {
+    const float g = (relu && !(y[base + i] > 0.f)) ? 0.f : dy[base + i];
+    const float xhat = (v[base + i] - mu) * rs;
+    dv[base + i] = k * (g - mg - xhat * mgx);
+  }
 }
 
 // out = relu(a + b); backward: da = db = dout * (out > 0)
@@ -479,7 +494,7 @@ extern "C" int ts_train_bn_fwd(const float* v, const float* gamma, const float* 
   double* sums = static_cast<double*>(workspace);
   hipLaunchKernelGGL(chan_sums_kernel<0>, dim3(ch, BN_G), dim3(256), 0, stream, v, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, sums, batch, ch, t, 0);
-  hipLaunchKernelGGL(bn_fwd_kernel, dim3(blocks((long long)batch * ch * t)), dim3(256), 0, stream, v, sums, gamma, beta, y, mean_rstd, batch,
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3(batch * ch, (t + 1023) / 1024), dim3(256), 0, stream, v, sums, gamma, beta, y, mean_rstd, batch,
                      ch, t, eps, relu, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   return hip_status(hipGetLastError());
 }
@@ -493,7 +508,7 @@ extern "C" int ts_train_bn_bwd(const float* dy, const float* y, const float* v, 
   const long long n = (long long)batch * ch * t;
   double* sums = static_cast<double*>(workspace);
   hipLaunchKernelGGL(chan_sums_kernel<1>, dim3(ch, BN_G), dim3(256), 0, stream, dy, y, v, mean_rstd, sums, batch, ch, t, relu);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks(n)), dim3(256), 0, stream, dy, y, v, sums, gamma, mean_rstd, dv, dgamma, dbeta, batch,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(batch * ch, (t + 1023) / 1024), dim3(256), 0, stream, dy, y, v, sums, gamma, mean_rstd, dv, dgamma, dbeta, batch,
                      ch, t, relu);
   return hip_status(hipGetLastError());
 }
