@@ -167,6 +167,10 @@ int ts_decoder_bwd(const float* grad_logits, const void* x, int32_t batch, int32
                    int32_t pitch_g, int32_t pitch_x, float* d_weight, float* d_bias, void* stream);
 int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* The same update for all tensors of a parameter group in one launch.  table: device array of n_tensors entries of five 64-bit
+ * words (param, grad, exp_avg, exp_avg_sq pointers, element count); max_numel = the largest element count; one shared step. */
+int ts_adamw_multi_step(const void* table, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int32_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-mode encoder ops (fine-tuning with the encoder unfrozen), first unfused version: fp32 activations in the

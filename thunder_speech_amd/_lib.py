@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss",
     "ts_pack_activation", "ts_unpack_activation", "ts_se_gate_fwd", "ts_se_apply_fwd",
-    "ts_decoder_bwd", "ts_adamw_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
+    "ts_decoder_bwd", "ts_adamw_step", "ts_adamw_multi_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd",
     "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
     f32 = C.c_float
     L.ts_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
     L.ts_adamw_step.restype = C.c_int
+    L.ts_adamw_multi_step.argtypes = [vp, i32, i64, f32, f32, f32, f32, f32, i32, vp]
+    L.ts_adamw_multi_step.restype = C.c_int
     L.ts_w2v_workspace_bytes.argtypes = [i32]
     L.ts_w2v_workspace_bytes.restype = i64
     L.ts_w2v_preprocess.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp]

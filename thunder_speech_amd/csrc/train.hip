@@ -79,7 +79,48 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   p[i] = pi;
 }
 
+// all tensors of a parameter group in ONE launch: table[i] = (param, grad, exp_avg, exp_avg_sq, n) as 64-bit words; blockIdx.y is the
+// tensor, blockIdx.x its 1024-element block (blocks past a tensor's end leave at once)
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned long long* __restrict__ table, float lr, float beta1, float beta2,
+                                                          float eps, float weight_decay, float bias_c1, float bias_c2) {
+  const unsigned long long* e = table + (size_t)blockIdx.y * 5;
+  const long long n = (long long)e[4];
+  const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+  if ((long long)blockIdx.x * 1024 >= n) return;
+  float* p = reinterpret_cast<float*>(e[0]);
+  const float* g = reinterpret_cast<const float*>(e[1]);
+  float* m = reinterpret_cast<float*>(e[2]);
+  float* v = reinterpret_cast<float*>(e[3]);
+  const float step_size = lr / bias_c1, inv_sqrt_c2 = 1.f / sqrtf(bias_c2), decay = 1.f - lr * weight_decay;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long i = i0 + 256 * j;
+    if (i < n) {
+      const float gi = g[i];
+      float pi = p[i] * decay;
+      const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+      const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_c2 + eps);
+      p[i] = pi;
+    }
+  }
+}
+
 }  // namespace ts
+
+extern "C" int ts_adamw_multi_step(const void* table, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int32_t step, void* stream_) {
+  if (!table || n_tensors <= 0 || max_numel <= 0 || step <= 0) return TS_EINVAL;
+  if (n_tensors > 65535) return TS_EUNSUPPORTED;
+  const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::adamw_multi_kernel, dim3((unsigned)((max_numel + 1023) / 1024), n_tensors), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), static_cast<const unsigned long long*>(table), lr, beta1, beta2, eps,
+                     weight_decay, c1, c2);
+  return ts::hip_status(hipGetLastError());
+}
 
 extern "C" int ts_decoder_bwd(const float* grad_logits, const void* x, int32_t batch, int32_t n_classes, int32_t channels,
                               int32_t t, int32_t pitch_g, int32_t pitch_x, float* d_weight, float* d_bias, void* stream_) {

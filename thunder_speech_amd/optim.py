@@ -23,6 +23,7 @@ class FusedAdamW(torch.optim.Optimizer):
         L = _lib.lib()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            todo = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -35,6 +36,23 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                todo.append((p, g, st))
+            if not todo:
+                continue
+            dev = todo[0][0].device
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            steps = {st["step"] for _, _, st in todo}
+            if len(todo) >= 8 and len(steps) == 1 and all(p.device == dev for p, _, _ in todo):
+                # one launch for the whole group: a pointer table (rebuilt every step: gradients are fresh tensors) and one grid
+                rows = [[p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()] for p, g, st in todo]
+                # pinned + non_blocking: the upload is queued behind the step's kernels instead of making the host wait for them
+                # (the pinned-memory allocator does not recycle the block before the copy has run)
+                table = torch.tensor(rows, dtype=torch.int64, pin_memory=True).to(dev, non_blocking=True)
+                rc = L.ts_adamw_multi_step(table.data_ptr(), len(rows), max(r[4] for r in rows), float(group["lr"]), float(b1), float(b2),
+                                           float(group["eps"]), float(group["weight_decay"]), int(steps.pop()), stream)
+                _lib.check(rc, "ts_adamw_multi_step")
+                continue
+            for p, g, st in todo:
                 rc = L.ts_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                      p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                      float(group["weight_decay"]), int(st["step"]),
