@@ -25,3 +25,9 @@ for ev in prof.events():
         st = [s for s in (ev.stack or []) if "thunder_speech_amd" in s or "tools/" in s]
         c[(ev.name, st[0] if st else (str(ev.input_shapes)[:60] if ev.input_shapes else "?"))] += 1
 for k, v in c.most_common(25): print(v, k)
+m = Counter()
+for ev in prof.events():
+    if 'Memcpy' in ev.name or 'memcpy' in ev.name.lower() or 'copyBuffer' in ev.name:
+        m[ev.name] += 1
+print(m)
+print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=12, max_name_column_width=50))
