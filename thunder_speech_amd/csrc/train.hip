@@ -131,7 +131,7 @@ extern "C" int ts_decoder_bwd(const float* grad_logits, const void* x, int32_t b
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(d_bias, 0, sizeof(float) * (size_t)n_classes, stream);
   if (e != hipSuccess) return (int)e;
-  const int clips_per_wg = 4;
+  const int clips_per_wg = 1;      // 16 channel tiles x B clips: enough workgroups to fill the chip (4 clips per workgroup left half of it idle)
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::decoder_wgrad_kernel, dim3((channels + ts::WG_C - 1) / ts::WG_C, (batch + clips_per_wg - 1) / clips_per_wg),
                      dim3(256), 0, stream, grad_logits, static_cast<const unsigned short*>(x), d_weight, d_bias, batch, n_classes,
