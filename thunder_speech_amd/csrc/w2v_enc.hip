@@ -442,13 +442,15 @@ __global__ __launch_bounds__(256) void w2v_posconv_mfma_kernel(const PcArgs a) {
   const char* arow = win + (wm * 64 + n32) * PC_PITCH + half * 16;            // A: row = frame, 8 consecutive ci per k-step
   const uint4* wp = reinterpret_cast<const uint4*>(a.w + ((size_t)g * 64 + wn * 32 + n32) * 64 + 8 * half);
   const size_t tap_stride = (size_t)a.groups * 64 * 64 / 8;                   // uint4 units
-  uint4 bf[4], bn[4];
+  uint4 bf[4], bn[4], bnn[4];                    // weights of tap j, j + 1, j + 2: an L2 round trip is longer than one tap's MFMAs
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) bf[ks] = wp[2 * ks];
-  for (int j = 0; j < a.k; ++j) {
-    if (j + 1 < a.k) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bn[ks] = wp[(size_t)(j + 1) * tap_stride + 2 * ks];
+  for (int ks = 0; ks < 4; ++ks) bn[ks] = wp[(a.k > 1 ? tap_stride : 0) + 2 * ks];
+  for (int j = 0; j < a.k; ++j) {
+    if (j + 2 < a.k) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bnn[ks] = wp[(size_t)(j + 2) * tap_stride + 2 * ks];
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256) void w2v_posconv_mfma_kernel(const PcArgs a) {
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(s16x8, bf[ks]), acc[mt], 0, 0, 0);
       }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bf[ks] = bn[ks];
+    for (int ks = 0; ks < 4; ++ks) { bf[ks] = bn[ks]; bn[ks] = bnn[ks]; }
   }
   const int co = g * 64 + wn * 32 + n32;
   const float bv = a.bias[co];
