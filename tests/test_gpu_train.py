@@ -113,3 +113,36 @@ def test_finetune_loop_decreases_loss():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_graphed_frozen_encoder_gives_the_same_step():
+    """graph_frozen_encoder(): front end + frozen encoder replayed from a hipGraph -- the loss is bit-identical to the eager path
+    (same kernels, same order) and the decoder gradient equal up to its atomics' summation order, also on the second replay with
+    different audio."""
+    from oracle import tcs as otcs
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    arch = otcs.quartznet_arch(repeat_blocks=1)
+    m = build_synthetic_quartznet(repeat_blocks=1, encoder_state=otcs.synth_encoder_state(arch, seed=0, calibrate=True),
+                                  decoder_state=otcs.synth_decoder_state(1024, 29, seed=1)).cuda().train()
+    m.encoder.eval()
+    m.audio_transform.eval()                           # no dither: the two paths must see the same samples
+    for p in m.encoder.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    texts = ["abc", "hello", "data"]
+    lengths = torch.tensor([24000.0, 20000.0, 16000.0]).cuda()
+
+    def step(wav):
+        m.zero_grad()
+        loss = m.training_step((wav, lengths, texts), 0)
+        loss.backward()
+        return float(loss), m.decoder.weight.grad.clone()
+
+    wavs = [(0.1 * torch.randn(3, 24000, generator=g)).cuda() for _ in range(2)]
+    eager = [step(w) for w in wavs]
+    m.graph_frozen_encoder()
+    graphed = [step(w) for w in wavs]
+    for (l0, g0), (l1, g1) in zip(eager, graphed):
+        assert l0 == l1                                    # same kernels, same order: the logits and the loss are bit-identical
+        torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-6)      # the weight gradient is summed with atomics: order noise only
+    assert eager[0][0] != eager[1][0]

@@ -63,9 +63,22 @@ class BaseCTCModule(_Base):
 
     def forward(self, x: Tensor, lengths: Tensor) -> Tuple[Tensor, Optional[Tensor]]:
         """[batch, time] audio -> (logits [batch, vocab, time'] BEFORE softmax, output lengths)."""
+        graphed = getattr(self, "_frozen_graph", None)
+        if graphed is not None and x.is_cuda and not self.encoder.training and \
+                not any(p.requires_grad for p in self.encoder.parameters()):
+            encoded, out_lengths = graphed(x, lengths)             # front end + frozen encoder replayed from a hipGraph
+            return self.decoder(encoded), out_lengths
         features, feature_lengths = self.audio_transform(x, lengths)
         encoded, out_lengths = self.encoder(features, feature_lengths)
         return self.decoder(encoded), out_lengths
+
+    def graph_frozen_encoder(self, enable: bool = True) -> "BaseCTCModule":
+        """Opt-in (no reference counterpart): while the encoder is frozen and in eval mode -- the first phase of the reference's
+        fine-tuning recipe -- replay `audio_transform -> encoder` from a hipGraph (one per input shape) instead of launching its
+        ~80 kernels from Python every step.  The encoder output then lives in the graph's buffer until the next forward."""
+        from .utils import GraphedForward
+        self._frozen_graph = GraphedForward(lambda x, lengths: self.encoder(*self.audio_transform(x, lengths))) if enable else None
+        return self
 
     def predict(self, x: Tensor) -> List[str]:
         """Greedy transcription; every clip is treated as full length (module.py:98)."""

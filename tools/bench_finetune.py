@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--seconds", type=int, default=10)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--unfreeze", action="store_true", help="phase 2: encoder trainable (training-mode kernels, full backward)")
+    ap.add_argument("--graph-encoder", action="store_true", help="phase 1: replay front end + frozen encoder from a hipGraph")
     ap.add_argument("--gemm-bf16", action="store_true", help="phase 2: bf16 operands for the pointwise-conv GEMMs (opt-in mixed precision)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -42,6 +43,8 @@ def main():
         m.encoder.eval()
         for p in m.encoder.parameters():
             p.requires_grad_(False)
+    if args.graph_encoder and not args.unfreeze:
+        m.graph_frozen_encoder()
     trainable = [p for p in m.parameters() if p.requires_grad]
     opt = FusedAdamW(trainable, lr=1e-3)
     B = (args.global_batch // world) if args.global_batch else 32
