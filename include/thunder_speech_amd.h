@@ -96,15 +96,16 @@ int ts_tcs_subblock_fwd(const ts_tcs_desc* desc, const void* x, const int32_t* l
  *   ts_se_gate_fwd : pool_ws f32 [B][C + hidden] (workspace: the means, then the hidden activations), gate f32 [B][C];
  *                    w1 f32 [hidden][C], w2 f32 [C][hidden] (nn.Linear layout, no bias).
  *   ts_se_apply_fwd: out = act( gate * y + r ), r: bf16 [B][C][pitch_r] residual branch (pointwise launch, tail zeroed) or
- *                    NULL, tail_r its constant beyond the length; zero_tail = 1 stores 0 for frames >= len (internal
- *                    blocks), 0 stores the reference's values there (caller-visible output).
+ *                    NULL, tail_r its constant beyond the length; r_stride: out frame e reads r frame e * r_stride (a strided 1x1
+ *                    residual conv computed at the input's frame rate: a 1x1 conv commutes with subsampling); zero_tail = 1
+ *                    stores 0 for frames >= len (internal blocks), 0 stores the reference's values there (caller-visible output).
  * ---------------------------------------------------------------------------------------------- */
 int ts_se_gate_fwd(const void* y, const int32_t* len, const float* tail_y, int32_t batch, int32_t channels, int32_t t,
                    int32_t pitch, int32_t hidden, const float* w1, const float* w2, float* pool_ws, float* gate,
                    void* stream);
 int ts_se_apply_fwd(const void* y, const void* r, const float* gate, const int32_t* len, const float* tail_y,
                     const float* tail_r, int32_t batch, int32_t channels, int32_t t, int32_t pitch_y, int32_t pitch_r,
-                    int32_t pitch_out, int32_t relu, int32_t zero_tail, void* out, void* stream);
+                    int32_t r_stride, int32_t pitch_out, int32_t relu, int32_t zero_tail, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mel-filterbank front end (eval mode): pre-emphasis -> reflect-padded STFT power -> slaney mel ->

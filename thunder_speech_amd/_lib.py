@@ -99,7 +99,7 @@ def lib() -> C.CDLL:
     L.ts_unpack_activation.restype = C.c_int
     L.ts_se_gate_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.ts_se_gate_fwd.restype = C.c_int
-    L.ts_se_apply_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.ts_se_apply_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.ts_se_apply_fwd.restype = C.c_int
     L.ts_decoder_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.ts_decoder_bwd.restype = C.c_int

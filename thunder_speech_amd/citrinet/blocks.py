@@ -61,12 +61,12 @@ def se_gate(se: SqueezeExcite, y: torch.Tensor, len_i32: torch.Tensor, tail_y: t
     return gate
 
 
-def se_apply(y, r, gate, len_i32, tail_y, tail_r, t: int, out, relu: bool, zero_tail: bool) -> None:
-    """out = act(gate * y + r) through ts_se_apply_fwd; y / r / out are [B, C, pitch] backing buffers."""
+def se_apply(y, r, gate, len_i32, tail_y, tail_r, t: int, out, relu: bool, zero_tail: bool, r_stride: int = 1) -> None:
+    """out = act(gate * y + r[..., ::r_stride]) through ts_se_apply_fwd; y / r / out are [B, C, pitch] backing buffers."""
     b, c, _ = y.shape
     st = _lib.lib().ts_se_apply_fwd(y.data_ptr(), None if r is None else r.data_ptr(), gate.data_ptr(), len_i32.data_ptr(),
                                     tail_y.data_ptr(), None if r is None else tail_r.data_ptr(), b, c, t, y.shape[2],
-                                    0 if r is None else r.shape[2], out.shape[2], int(relu), int(zero_tail),
+                                    0 if r is None else r.shape[2], int(r_stride), out.shape[2], int(relu), int(zero_tail),
                                     out.data_ptr(), torch.cuda.current_stream(y.device).cuda_stream)
     _lib.check(st, "ts_se_apply_fwd")
 
@@ -111,8 +111,10 @@ class CitrinetBlock(_FusedBlockBase):
         layers = super()._compile()          # the last sub-block comes without ReLU / residual (see _has_se)
         if self.res is not None:
             rc = self.res[0]
+            # a strided 1x1 residual conv runs at the INPUT's frame rate on the fast pointwise kernel (a 1x1 conv commutes with
+            # subsampling); the SE-apply launch then reads every `stride`-th frame of it
             layers.append(_plan.make_tcs_layer(rc.conv.weight.device, dw_w=None, pw_w=rc.conv.weight,
-                                               bn=_bn_tensors(self.res[1].layer[0]), kernel=1, stride=rc.stride, dilation=1,
+                                               bn=_bn_tensors(self.res[1].layer[0]), kernel=1, stride=1, dilation=1,
                                                padding=0, relu=False))
         return layers
 
@@ -146,13 +148,15 @@ class CitrinetBlock(_FusedBlockBase):
         tail_y = convs[-1].bias[:c_out]
         gate = se_gate(se, h, lh, tail_y, th)
         r_buf = tail_r = None
+        r_stride = 1
         if res_layer is not None:
-            r_buf = _t.arena(("enc", slot, "res"), b, c_out, th, dev)
+            r_stride = self.res[0].stride
+            r_buf = _t.arena(("enc", slot, "res"), b, c_out, t, dev)
             r_buf, t_res = res_layer.run(x0, t, len_in, out=r_buf, in_tail_zero=x0_tz, zero_tail=True)
-            assert t_res == th
+            assert (t_res - 1) // r_stride + 1 == th
             tail_r = res_layer.bias[:c_out]
         out = _t.arena(("enc", slot, "out"), b, c_out, th, dev) if internal else _t.alloc(b, c_out, th, dev)
-        se_apply(h, r_buf, gate, lh, tail_y, tail_r, th, out, relu=True, zero_tail=internal)
+        se_apply(h, r_buf, gate, lh, tail_y, tail_r, th, out, relu=True, zero_tail=internal, r_stride=r_stride)
         y = out[:, :, :th]
         if internal:
             _t.tag_tail_zero(y)

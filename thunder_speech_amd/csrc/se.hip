@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const unsigned short* __r
                                                         const float* __restrict__ gate, const int* __restrict__ len,
                                                         const float* __restrict__ tail_y, const float* __restrict__ tail_r,
                                                         unsigned short* __restrict__ out, int rows, int channels, int t,
-                                                        int pitch_y, int pitch_r, int pitch_out, int relu, int zero_tail) {
+                                                        int pitch_y, int pitch_r, int pitch_out, int relu, int zero_tail, int r_stride) {
   const int groups = pitch_out >> 3;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)rows * groups) return;
@@ -71,7 +71,23 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const unsigned short* __r
     u32x4 yv = u32x4{0u, 0u, 0u, 0u}, rv = u32x4{0u, 0u, 0u, 0u};
     if (g < l) {                                     // rows are zero from their length on, pitches cover the over-read
       if (g + 8 <= pitch_y) yv = *reinterpret_cast<const u32x4*>(y + (size_t)row * pitch_y + g);
-      if (r && g + 8 <= pitch_r) rv = *reinterpret_cast<const u32x4*>(r + (size_t)row * pitch_r + g);
+      if (r) {
+        const unsigned short* rp = r + (size_t)row * pitch_r + (size_t)g * r_stride;
+        if (r_stride == 1) {
+          if (g + 8 <= pitch_r) rv = *reinterpret_cast<const u32x4*>(rp);
+        } else if (r_stride == 2 && 2 * g + 16 <= pitch_r) {
+          // the residual branch was computed at the input's frame rate (a 1x1 conv commutes with subsampling): take every other frame
+          const u32x4 a0 = *reinterpret_cast<const u32x4*>(rp), a1 = *reinterpret_cast<const u32x4*>(rp + 8);
+          rv = u32x4{__builtin_amdgcn_perm(a0[1], a0[0], 0x05040100u), __builtin_amdgcn_perm(a0[3], a0[2], 0x05040100u),
+                     __builtin_amdgcn_perm(a1[1], a1[0], 0x05040100u), __builtin_amdgcn_perm(a1[3], a1[2], 0x05040100u)};
+        } else {
+          unsigned short e8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e8[j] = (g + j) * r_stride < pitch_r ? rp[(size_t)j * r_stride] : (unsigned short)0;
+          rv = u32x4{(unsigned)e8[0] | ((unsigned)e8[1] << 16), (unsigned)e8[2] | ((unsigned)e8[3] << 16),
+                     (unsigned)e8[4] | ((unsigned)e8[5] << 16), (unsigned)e8[6] | ((unsigned)e8[7] << 16)};
+        }
+      }
     }
     float v[8];
 #pragma unroll
@@ -112,15 +128,16 @@ extern "C" int ts_se_gate_fwd(const void* y, const int32_t* len, const float* ta
 
 extern "C" int ts_se_apply_fwd(const void* y, const void* r, const float* gate, const int32_t* len, const float* tail_y,
                                const float* tail_r, int32_t batch, int32_t channels, int32_t t, int32_t pitch_y, int32_t pitch_r,
-                               int32_t pitch_out, int32_t relu, int32_t zero_tail, void* out, void* stream_) {
+                               int32_t r_stride, int32_t pitch_out, int32_t relu, int32_t zero_tail, void* out, void* stream_) {
   if (!y || !gate || !len || !tail_y || !out || (r && !tail_r)) return TS_EINVAL;
   if (batch <= 0 || channels <= 0 || t <= 0 || pitch_y < t || pitch_out < t || pitch_y % 8 || pitch_out % 8) return TS_EINVAL;
-  if (r && (pitch_r < t || pitch_r % 8)) return TS_EINVAL;
+  if (r && (r_stride < 1 || pitch_r < (t - 1) * r_stride + 1 || pitch_r % 8)) return TS_EINVAL;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const long long n = (long long)batch * channels * (pitch_out / 8);
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::se_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                      static_cast<const unsigned short*>(y), static_cast<const unsigned short*>(r), gate, len, tail_y, tail_r,
-                     static_cast<unsigned short*>(out), batch * channels, channels, t, pitch_y, pitch_r, pitch_out, relu, zero_tail);
+                     static_cast<unsigned short*>(out), batch * channels, channels, t, pitch_y, pitch_r, pitch_out, relu, zero_tail,
+                     r ? r_stride : 1);
   return ts::hip_status(hipGetLastError());
 }
