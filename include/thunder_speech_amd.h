@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 2
+#define TS_ABI_VERSION 3
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -123,6 +123,11 @@ typedef struct ts_frontend_desc {
   const float* mel_weights;      /* f32 packed non-zero filterbank weights */
   const int32_t* mel_offsets;    /* int32 [n_mels][2]: (first bin, offset into mel_weights); count = next offset - this */
   int32_t mel_nnz;
+  /* training-mode extras (all zero / NULL in eval mode) */
+  int32_t n_masks;               /* SpecAugment / SpecCutout rectangles applied after the normaliser (spec_augment.py:51-56, :96-101) */
+  const int32_t* masks;          /* int32 [n_masks][4] = (f0, f1, t0, t1): features[b][f0:f1][t0:t1] = 0 for every clip */
+  uint64_t dither_seed;          /* Philox key of the dither noise */
+  float dither;                  /* > 0: DitherAudio (quartznet/transform.py:109-118): x + dither * N(0, 1) before pre-emphasis */
 } ts_frontend_desc;
 
 /* Stage 1: logmel f32 [B][n_frames][n_mels] (frame-major scratch) + per-(b, mel) partial sums.
@@ -134,6 +139,26 @@ int ts_mel_frontend_fwd(const ts_frontend_desc* desc, const float* wave, const i
                         void* features, int32_t* feat_len, void* workspace, void* stream);
 /* Debug/parity hook: copy of the un-normalised log-mel [B][n_frames][n_mels] f32 left in workspace. */
 const float* ts_frontend_logmel_ptr(const ts_frontend_desc* desc, const void* workspace);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-time augmentation.  SpecAugment / SpecCutout (quartznet/spec_augment.py:23-102): a mask is a row
+ * (f0, f1, t0, t1) of an int32 device table, the same for every clip of the batch as in the reference.
+ *   ts_spec_masks_draw : fills the table on the device from a Philox stream, in the reference's order -- n_cutout rectangles
+ *     (frequency span, then a time span drawn with cut_FREQ_width: reference quirk, spec_augment.py:99-100), n_time time
+ *     masks, n_freq frequency masks; each span is value = u * width, min = u' * (size - value), [long(min), long(min) + long(value)).
+ *     (The Python mirror can instead fill the table from torch.rand(1) draws on the host, exactly as the reference does.)
+ *   ts_spec_mask_apply : features[b][f0:f1][t0:t1] = 0 on a bf16 [B][channels][pitch] tensor, in place.  ts_mel_frontend_fwd
+ *     applies the same table inside its normaliser when ts_frontend_desc.masks is set (no extra pass).
+ *   ts_dropout : y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) per element from (seed, element index) -- nn.Dropout in
+ *     train mode (quartznet/blocks.py:227-228, blocks.py:238); the backward pass is the same call on dy with the same seed.
+ *     x, y f32, 16-byte aligned, may alias.
+ * ---------------------------------------------------------------------------------------------- */
+int ts_spec_masks_draw(uint64_t seed, int32_t n_time, int32_t time_width, int32_t n_freq, int32_t freq_width, int32_t n_cutout,
+                       int32_t cut_time_width, int32_t cut_freq_width, int32_t n_mels, int32_t n_frames, int32_t* table,
+                       void* stream);
+int ts_spec_mask_apply(void* features, int32_t batch, int32_t channels, int32_t t, int32_t pitch, const int32_t* table,
+                       int32_t n_masks, void* stream);
+int ts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy CTC decode: argmax over classes then run-collapse (torch.unique_consecutive), replaces
@@ -209,6 +234,19 @@ int ts_train_bn_bwd(const float* dy, const float* y, const float* v, const float
                     void* stream);
 int ts_train_add_relu_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
 int ts_train_relu_bwd(const float* dout, const float* out, float* din, int64_t n, void* stream);
+/* strided 1x1 MaskedConv1d (residual branch of a strided block: quartznet/blocks.py:301-311, citrinet/blocks.py:156-165) =
+ * this mask + subsample pass followed by the pointwise GEMM.  backward = 0: y[b,c,j] = x[b,c,j*stride] if j*stride < len[b] else 0
+ * (x [B][C][t_in], y [B][C][t_out]); backward = 1: x is dy [B][C][t_out], y is dx [B][C][t_in], zero where the forward read nothing. */
+int ts_train_subsample_mask(const float* x, const int32_t* len, float* y, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out,
+                            int32_t stride, int32_t backward, void* stream);
+/* SqueezeExcite in train mode (citrinet/blocks.py:70-83), the passes over the [rows = B*C][t] activation:
+ *   ts_train_se_pool   mean[row] = mean_t x[row][t]           (AdaptiveAvgPool1d(1) over ALL frames, quirk A3)
+ *   ts_train_se_scale  y = x * gate[row] (+ add_mean[row] / t when add_mean != NULL: the pooled gradient, backward pass)
+ *   ts_train_se_rowdot out[row] = sum_t a[row][t] * b[row][t]  (d gate = sum_t dy * x)
+ * The [B, C] bottleneck in between (Linear -> ReLU -> Linear -> sigmoid) is a few tiny GEMMs on the caller's side. */
+int ts_train_se_pool(const float* x, float* mean, int64_t rows, int32_t t, void* stream);
+int ts_train_se_scale(const float* x, const float* gate, const float* add_mean, float* y, int64_t rows, int32_t t, void* stream);
+int ts_train_se_rowdot(const float* a, const float* b, float* out, int64_t rows, int32_t t, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * wav2vec2 waveform normalisation, replaces Wav2Vec2Preprocess.forward (huggingface/transform.py:34-55 -> normalize_tensor,
@@ -264,6 +302,31 @@ int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, cons
 int64_t ts_w2v_attention_workspace_bytes(int32_t batch, int32_t t, int32_t heads, int32_t precision);
 int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len,
                          int32_t precision, void* ctx, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The steps either side of the hot path, on the device.
+ *   ts_audio_prep  : AudioFileLoader.preprocess_audio (data/dataset.py:49-77): mono = mean over channels, minus its mean over
+ *     time, resampled by torchaudio's polyphase sinc kernel (torchaudio.functional.resample 0.12.0 defaults).  audio f32
+ *     [channels][t]; kernel f32 [new][kw] or NULL (no resampling; then t_out == t); orig / new = the two rates divided by
+ *     their gcd; width = the kernel's left padding; out f32 [t_out], t_out = ceil(new * t / orig);
+ *     workspace: ts_audio_prep_workspace_bytes(t) bytes.
+ *   ts_collate_pad : asr_collate's pad_sequence (data/dataloader_utils.py:17-33): clip_table = n_clips x {const float*, int64 len}
+ *     in device memory (already sorted by the caller), out f32 [n_clips][max_len], zero padded.
+ *   ts_edit_distance : Levenshtein distance of n_pairs (a, b) int32 symbol sequences given as concatenations + offsets
+ *     int32 [n_pairs + 1]: what torchmetrics' CharErrorRate / WordErrorRate sum in validation_step (module.py:153-156).
+ *   ts_encode_chars : BatchTextTransformer.encode for character vocabularies (text_processing/transform.py:65-92): code points
+ *     int32 (concatenated rows + offsets) -> ids by binary search in vocab_cp (sorted) / vocab_id, unknown -> unk_id,
+ *     start_id / end_id < 0 = none; out int64 [n_rows][s_max] padded with pad_id, lens int64 [n_rows].
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ts_audio_prep_workspace_bytes(int64_t t);
+int ts_audio_prep(const float* audio, int32_t channels, int64_t t, const float* kernel, int32_t orig, int32_t new_, int32_t kw,
+                  int32_t width, float* out, int64_t t_out, void* workspace, void* stream);
+int ts_collate_pad(const void* clip_table, int32_t n_clips, int64_t max_len, float* out, void* stream);
+int ts_edit_distance(const int32_t* a, const int32_t* a_off, const int32_t* b, const int32_t* b_off, int32_t n_pairs,
+                     int32_t max_a_len, int32_t* dist, void* stream);
+int ts_encode_chars(const int32_t* text, const int32_t* off, int32_t n_rows, const int32_t* vocab_cp, const int32_t* vocab_id,
+                    int32_t n_vocab, int32_t unk_id, int32_t start_id, int32_t end_id, int32_t pad_id, int32_t s_max,
+                    int64_t* out, int64_t* lens, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].

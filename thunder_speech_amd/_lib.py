@@ -12,7 +12,7 @@ from typing import Optional
 from .build import lib_path
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 TCS_IN_TAILZERO = 1
 TCS_OUT_ZERO_TAIL = 2
 TCS_TAPS_PHASE = 4
@@ -30,6 +30,9 @@ EXPORTED_SYMBOLS = [
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
     "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_attention_workspace_bytes",
     "ts_w2v_attention_fwd",
+    "ts_spec_masks_draw", "ts_spec_mask_apply", "ts_dropout",
+    "ts_audio_prep_workspace_bytes", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance", "ts_encode_chars",
+    "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot",
 ]
 
 
@@ -53,6 +56,7 @@ class FrontendDesc(C.Structure):
         ("win_length", C.c_int32), ("n_mels", C.c_int32), ("preemph", C.c_float), ("n_frames", C.c_int32),
         ("pitch_out", C.c_int32),
         ("window", C.c_void_p), ("mel_weights", C.c_void_p), ("mel_offsets", C.c_void_p), ("mel_nnz", C.c_int32),
+        ("n_masks", C.c_int32), ("masks", C.c_void_p), ("dither_seed", C.c_uint64), ("dither", C.c_float),
     ]
 
 
@@ -141,6 +145,25 @@ def lib() -> C.CDLL:
     L.ts_train_relu_bwd.argtypes = [vp, vp, vp, i64, vp]
     for fn in ("ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd",
                "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd"):
+        getattr(L, fn).restype = C.c_int
+    u64 = C.c_uint64
+    L.ts_spec_masks_draw.argtypes = [u64] + [i32] * 9 + [vp, vp]
+    L.ts_spec_mask_apply.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp]
+    L.ts_dropout.argtypes = [vp, vp, i64, f32, u64, vp]
+    L.ts_audio_prep_workspace_bytes.argtypes = [i64]
+    L.ts_audio_prep_workspace_bytes.restype = i64
+    L.ts_audio_prep.argtypes = [vp, i32, i64, vp, i32, i32, i32, i32, vp, i64, vp, vp]
+    L.ts_collate_pad.argtypes = [vp, i32, i64, vp, vp]
+    L.ts_edit_distance.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    L.ts_encode_chars.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    for fn in ("ts_spec_masks_draw", "ts_spec_mask_apply", "ts_dropout", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance",
+               "ts_encode_chars"):
+        getattr(L, fn).restype = C.c_int
+    L.ts_train_subsample_mask.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.ts_train_se_pool.argtypes = [vp, vp, i64, i32, vp]
+    L.ts_train_se_scale.argtypes = [vp, vp, vp, vp, i64, i32, vp]
+    L.ts_train_se_rowdot.argtypes = [vp, vp, vp, i64, i32, vp]
+    for fn in ("ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot"):
         getattr(L, fn).restype = C.c_int
     if L.ts_abi_version() != ABI_VERSION:
         raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")

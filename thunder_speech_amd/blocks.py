@@ -102,14 +102,16 @@ class _Conv1dDecoder(nn.Conv1d):
 
     def forward(self, x: Tensor) -> Tensor:
         _t.require_gpu(x, "conv1d_decoder")
-        xi = x if (x.requires_grad and self.training) else _t.pack(x)
+        grad_on = torch.is_grad_enabled()
+        if grad_on and x.requires_grad:
+            # the encoder is being trained (whether or not the decoder's own parameters are frozen): fp32 training ops all the
+            # way (GEMM forward / backward in train_ops.PointwiseConv); the bias add on the [B, V, T] logits is the one
+            # broadcast left to autograd
+            from .train_ops import PointwiseConv
+            return PointwiseConv.apply(x, self.weight) + self.bias.view(1, -1, 1)
+        xi = _t.pack(x)
         b, _, t = xi.shape
-        if self.training and torch.is_grad_enabled() and (self.weight.requires_grad or self.bias.requires_grad):
-            if x.requires_grad:
-                # encoder unfrozen: fp32 training ops all the way (GEMM forward / backward in train_ops.PointwiseConv);
-                # the bias add on the [B, V, T] logits is the one broadcast left to autograd
-                from .train_ops import PointwiseConv
-                return PointwiseConv.apply(x, self.weight) + self.bias.view(1, -1, 1)
+        if self.training and grad_on and (self.weight.requires_grad or self.bias.requires_grad):
             return _DecoderFunction.apply(self.weight, self.bias, self, _t.backing(xi), t)
         full = torch.full((b,), t, dtype=torch.int32, device=xi.device)   # the decoder conv is not masked
         y, t_out = self._layer().run(_t.backing(xi), t, full)
@@ -167,9 +169,16 @@ class _LinearDecoder(nn.Sequential):
 
     def forward(self, x: Tensor) -> Tensor:
         _t.require_gpu(x, "linear_decoder")
-        if self.training and self[1].p > 0:
-            raise NotImplementedError("linear_decoder: dropout in training mode has no HIP kernel yet")
         lin = self[2]
+        drop = self[1]
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad or lin.bias.requires_grad)
+        if needs_grad or (drop.training and drop.p > 0):
+            # training path (blocks.py:226-248: transpose -> dropout -> Linear -> transpose): dropout is elementwise and the
+            # Linear over the channel axis is a 1x1 conv on [B, C, T], so the two transposes cancel here as well
+            from . import train_ops as T
+            h = _t.unpack(x) if _t.is_internal(x) else x.to(torch.float32)
+            h = T.dropout(h, drop.p, drop.training)
+            return T.PointwiseConv.apply(h, lin.weight.unsqueeze(-1)) + lin.bias.view(1, -1, 1)
         layer = self._cache.get([lin.weight, lin.bias], lambda: _plan.make_tcs_layer(
             lin.weight.device, dw_w=None, pw_w=lin.weight.detach(), bn=None, kernel=1, stride=1, dilation=1,
             padding=0, relu=False, bias_extra=lin.bias.detach(), out_fp32=True))

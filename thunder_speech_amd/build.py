@@ -19,7 +19,10 @@ ARCH = "gfx950"
 
 
 def lib_path() -> str:
-    return os.path.join(PKG, LIB_NAME)
+    # TS_LIB_VARIANT selects a diagnostic build (tools/variants.py: same sources, extra -D flags) for A/B timing runs;
+    # unset (always, outside tools/) it is the product library
+    variant = os.environ.get("TS_LIB_VARIANT", "")
+    return os.path.join(PKG, LIB_NAME if not variant else LIB_NAME.replace(".so", f".{variant}.so"))
 
 
 def sources():
@@ -34,17 +37,22 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, only=None) -> str:
     out = lib_path()
     if not force and not needs_build():
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    variant = os.environ.get("TS_LIB_VARIANT", "")
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
     for src in sources():
-        obj = os.path.join(PKG, "build", os.path.basename(src) + ".o")
+        # a variant build recompiles only the sources named in `only` and links the product objects of the rest
+        own = not variant or only is None or os.path.basename(src) in only
+        obj = os.path.join(PKG, "build", os.path.basename(src) + (f".{variant}" if variant and own else "") + ".o")
         objs.append(obj)
+        if not own and os.path.exists(obj):
+            continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
                "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
                f'-DTS_BUILD_TARGET="{ARCH}"', "-c", src, "-o", obj]

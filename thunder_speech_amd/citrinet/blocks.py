@@ -163,6 +163,8 @@ class CitrinetBlock(_FusedBlockBase):
         return y, out_lengths, was_internal
 
     def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.training:
+            return self._forward_train(x, lengths)
         y, out_lengths, was_internal = self._run_fused(x, lengths)
         return (y if was_internal else _t.unpack(y)), out_lengths
 

@@ -82,7 +82,7 @@ def load_citrinet_checkpoint(checkpoint: Union[str, CitrinetCheckpoint], save_fo
         raise FileNotFoundError(f"{nemo_path} not found; this environment has no network access to download it")
     with tempfile.TemporaryDirectory() as tmp:
         with tarfile.open(nemo_path) as tar:
-            tar.extractall(tmp)
+            tar.extractall(tmp, filter="data")      # untrusted archive: no absolute paths, links out of tmp, devices
         root = Path(tmp)
         encoder, audio_transform, text_transform = load_components_from_citrinet_config(
             next(root.rglob("model_config.yaml")), next(root.rglob("tokenizer.model")), augment_params)

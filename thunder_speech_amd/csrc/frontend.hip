@@ -17,6 +17,7 @@
 // Kernel 2 (normalize_kernel): reduces the per-workgroup partial sums in fp64, normalises, masks frames
 // >= length, transposes [frame][mel] -> [mel][frame] through LDS and stores bf16 rows.
 #include "ts_common.hpp"
+#include "ts_philox.hpp"
 
 namespace ts {
 
@@ -77,7 +78,18 @@ struct FeArgs {
   int* feat_len;
   int n_samples, hop, n_mels, n_frames, nwg, mel_nnz, batch;
   float preemph;
+  float dither;               // > 0: DitherAudio (transform.py:109-118, training only): x + dither * N(0, 1)
+  unsigned long long seed;    // Philox key of the dither noise
 };
+
+// Dither noise of sample `k` of clip `b`: a pure function of (seed, b, k), so every frame group (and the reflect padding)
+// that touches the sample sees the same value -- exactly as if the noise had been added to the waveform up front.
+__device__ __forceinline__ float dither_noise(unsigned long long seed, int b, int k) {
+  const Philox4 r = philox(seed, PHILOX_DITHER, ((unsigned long long)(unsigned)b << 32) | (unsigned)(k >> 1));
+  float n0, n1;
+  normal2(r.v[0], r.v[1], n0, n1);
+  return (k & 1) ? n1 : n0;
+}
 
 __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,6 +135,10 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
       k = k < 0 ? 0 : (k >= T ? T - 1 : k);          // frames entirely beyond the clip (never valid)
       cur[j] = x[k];
       prv[j] = k > 0 ? x[k - 1] : 0.f;               // sample 0 is not pre-emphasised
+      if (a.dither > 0.f) {                          // wave-uniform branch; eval mode never takes it
+        cur[j] += a.dither * dither_noise(a.seed, g / a.nwg, k);
+        if (k > 0) prv[j] += a.dither * dither_noise(a.seed, g / a.nwg, k - 1);
+      }
     }
   };
   auto commit = [&]() {
@@ -138,7 +154,12 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
       k = k < 0 ? -k : k;
       k = k >= T ? 2 * (T - 1) - k : k;
       k = k < 0 ? 0 : (k >= T ? T - 1 : k);
-      sig[e] = k > 0 ? x[k] - a.preemph * x[k - 1] : x[k];
+      float xc = x[k], xp = k > 0 ? x[k - 1] : 0.f;
+      if (a.dither > 0.f) {
+        xc += a.dither * dither_noise(a.seed, g / a.nwg, k);
+        if (k > 0) xp += a.dither * dither_noise(a.seed, g / a.nwg, k - 1);
+      }
+      sig[e] = xc - a.preemph * xp;
     }
   };
   const int n_groups = a.nwg * a.batch;
@@ -249,6 +270,8 @@ struct NormArgs {
   const int* feat_len;
   unsigned short* out;        // [B][n_mels][pitch]
   int n_mels, n_frames, nwg, pitch;
+  const int* masks;           // SpecAugment / SpecCutout rectangles [n_masks][4] = (f0, f1, t0, t1), or NULL
+  int n_masks;
 };
 
 constexpr int NTF = 64;            // frames per normalize workgroup
@@ -311,6 +334,17 @@ __global__ __launch_bounds__(256) void normalize_kernel(const NormArgs a) {
       const int f = f0 + g * 8 + j;
       v[j] = f < flen ? (tile[(g * 8 + j) * ld + m] - mu) * rs : 0.f;
     }
+    // spec_augment.py:51-56, :96-101: masked_fill(mask, 0) after the normaliser -- applied on the way out
+    for (int r = 0; r < a.n_masks; ++r) {
+      const int mf0 = a.masks[4 * r], mf1 = a.masks[4 * r + 1], mt0 = a.masks[4 * r + 2], mt1 = a.masks[4 * r + 3];
+      if (m >= mf0 && m < mf1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int f = f0 + g * 8 + j;
+          if (f >= mt0 && f < mt1) v[j] = 0.f;
+        }
+      }
+    }
     if (f0 + g * 8 < a.pitch)
       *reinterpret_cast<u32x4*>(a.out + ((size_t)b * a.n_mels + m) * a.pitch + f0 + g * 8) =
           u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
@@ -354,6 +388,9 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   a.feat_len = feat_len;
   a.n_samples = d->n_samples; a.hop = d->hop; a.n_mels = d->n_mels; a.n_frames = d->n_frames; a.nwg = nwg;
   a.preemph = d->preemph;
+  a.dither = d->dither;
+  a.seed = d->dither_seed;
+  if (d->n_masks < 0 || (d->n_masks > 0 && !d->masks)) return TS_EINVAL;
   a.mel_nnz = d->mel_nnz;
   a.batch = d->batch;
   const int span = (FPW - 1) * d->hop + NFFT;
@@ -379,6 +416,7 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   NormArgs n{};
   n.logmel = a.logmel; n.partial = a.partial; n.feat_len = feat_len; n.out = static_cast<unsigned short*>(features);
   n.n_mels = d->n_mels; n.n_frames = d->n_frames; n.nwg = nwg; n.pitch = d->pitch_out;
+  n.masks = d->masks; n.n_masks = d->n_masks;
   const size_t lds2 = ((size_t)2 * d->n_mels + (size_t)NTF * (d->n_mels + 1)) * sizeof(float);
   (void)hipGetLastError();
   hipLaunchKernelGGL(normalize_kernel, dim3((d->pitch_out + NTF - 1) / NTF, d->batch), dim3(256), lds2, stream, n);

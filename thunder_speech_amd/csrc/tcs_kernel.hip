@@ -121,7 +121,9 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {
 #define STAMP(slot) do { } while (0)
 #endif
 #ifdef TS_STAMP
-#define PSTAMP(slot) do { if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) < 128) a.dbg[wave * 128 + (slot)] = clock64(); } while (0)
+#define PSTAMP(slot) do { if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) < 120) a.dbg[wave * 128 + (slot)] = clock64(); \
+    if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) == 0) { a.dbg[wave * 128 + 120] = __builtin_amdgcn_s_memrealtime(); a.dbg[wave * 128 + 121] = clock64(); } \
+    if (a.dbg && blockIdx.x == 7 && lane == 0) { a.dbg[wave * 128 + 122] = __builtin_amdgcn_s_memrealtime(); a.dbg[wave * 128 + 123] = clock64(); } } while (0)
 #else
 #define PSTAMP(slot) do { } while (0)
 #endif
@@ -1309,6 +1311,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 
   if (wave >= 8) {
     // ================================= PRODUCER =======================================================
+#ifdef TS_PROD_PRIO
+    __builtin_amdgcn_s_setprio(TS_PROD_PRIO);
+#endif
     const int pw = wave - 8;
     char* const xs = prod0 + (size_t)pw * (XSB + NKH * 1024);
     char* const tapl = xs + XSB;
@@ -1506,6 +1511,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   }
 
   // ================================= CONSUMER =========================================================
+#ifdef TS_CONS_HALF_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   char* const priv = cons0 + (size_t)wave * ER * EP;
   const __amdgpu_buffer_rsrc_t rwm = rsrc(a.pw_w);
   const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? a.res_w : a.pw_w);

@@ -8,6 +8,14 @@ import torch
 from . import _lib
 
 
+def _bump_versions(tensors) -> None:
+    """The kernels write through raw pointers, which torch cannot see: bump each tensor's version counter so that everything
+    keyed on `_version` (the packed / BN-folded inference weights in blocks._PackedCache, autograd's saved-tensor checks)
+    notices the update."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
@@ -51,6 +59,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 rc = L.ts_adamw_multi_step(table.data_ptr(), len(rows), max(r[4] for r in rows), float(group["lr"]), float(b1), float(b2),
                                            float(group["eps"]), float(group["weight_decay"]), int(steps.pop()), stream)
                 _lib.check(rc, "ts_adamw_multi_step")
+                _bump_versions(p for p, _, _ in todo)
                 continue
             for p, g, st in todo:
                 rc = L.ts_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
@@ -58,4 +67,5 @@ class FusedAdamW(torch.optim.Optimizer):
                                      float(group["weight_decay"]), int(st["step"]),
                                      torch.cuda.current_stream(p.device).cuda_stream)
                 _lib.check(rc, "ts_adamw_step")
+                _bump_versions([p])
         return loss

@@ -191,11 +191,10 @@ class _FusedBlockBase(nn.Module):
         (quartznet/blocks.py:317-338), one HIP launch per op and direction (train_ops.py), fp32 [B, C, T] activations."""
         from .. import train_ops as T
         _t.require_gpu(x, type(self).__name__)
-        if self._has_se():
-            raise NotImplementedError("training-mode squeeze-excite (Citrinet) is not built")
-        for m in self.modules():
-            if isinstance(m, nn.Dropout) and m.p > 0:
-                raise NotImplementedError("training-mode dropout > 0 has no HIP kernel (the reference encoders default to 0.0)")
+        # Dropout modules of the reference tree: after the ReLU of every repeat but the last (mconv), and after the block's
+        # final ReLU (mout) -- quartznet/blocks.py:227-228; each follows its own training flag like nn.Dropout does
+        drops = [m.layer[0] for m in self.mconv if isinstance(m, Masked) and isinstance(m.layer[0], nn.Dropout)]
+        out_drop = self.mout[1].layer[0]
         x = _t.unpack(x) if _t.is_internal(x) else x.to(torch.float32)
         dev = x.device
         len_in = _t.lengths_i32(lengths, dev)
@@ -216,13 +215,21 @@ class _FusedBlockBase(nn.Module):
                 h = T.MaskTime.apply(h, lh)
             h = T.PointwiseConv.apply(h, pw.conv.weight)
             h = T.batch_norm_train(bn, h, relu=not last)
+            if not last and r < len(drops):
+                h = T.dropout(h, drops[r].p, drops[r].training)
+        if self._has_se():
+            se = self.mconv[len(self.mconv) - 1].layer[0]          # citrinet/blocks.py:154: SE closes the main branch
+            h = T.SqueezeExciteTrain.apply(h, se.fc[0].weight, se.fc[2].weight)
         r_out = None
         if self.res is not None:
             rc, rbn = self.res[0], self.res[1].layer[0]
-            if rc.stride != 1:
-                raise NotImplementedError("training mode: strided residual convs have no HIP kernel")
-            r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(T.MaskTime.apply(x, len_in), rc.conv.weight), relu=False)
-        return T.AddRelu.apply(h, r_out), out_lengths
+            if rc.stride != 1:       # strided 1x1 MaskedConv1d: mask + subsample, then the pointwise GEMM
+                r_in = T.SubsampleMask.apply(x, len_in, rc.stride, (x.shape[2] - 1) // rc.stride + 1)
+            else:
+                r_in = T.MaskTime.apply(x, len_in)
+            r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(r_in, rc.conv.weight), relu=False)
+        out = T.AddRelu.apply(h, r_out)
+        return T.dropout(out, out_drop.p, out_drop.training), out_lengths
 
     def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=0):
         """Run the block's launches.  `internal=True` (set by the encoder for every block but the last): the block

@@ -30,6 +30,7 @@ class QuartznetCheckpoint(str, Enum):
     """Names of the NeMo checkpoints the reference knows (compatibility.py:45-58)."""
     QuartzNet5x5LS_En = "QuartzNet5x5LS-En"
     QuartzNet15x5Base_En = "QuartzNet15x5Base-En"
+    QuartzNet15x5Base_Zh = "QuartzNet15x5Base-Zh"
     QuartzNet15x5NR_En = "QuartzNet15x5NR-En"
     stt_ca_quartznet15x5 = "stt_ca_quartznet15x5"
     stt_de_quartznet15x5 = "stt_de_quartznet15x5"
@@ -38,6 +39,7 @@ class QuartznetCheckpoint(str, Enum):
     stt_it_quartznet15x5 = "stt_it_quartznet15x5"
     stt_pl_quartznet15x5 = "stt_pl_quartznet15x5"
     stt_ru_quartznet15x5 = "stt_ru_quartznet15x5"
+    stt_en_quartznet15x5 = "stt_en_quartznet15x5"
     stt_zh_quartznet15x5 = "stt_zh_quartznet15x5"
 
 
@@ -104,10 +106,10 @@ def load_quartznet_checkpoint(checkpoint: Union[str, QuartznetCheckpoint], save_
         raise FileNotFoundError(f"{nemo_path} not found; this environment has no network access to download it")
     with tempfile.TemporaryDirectory() as tmp:
         with tarfile.open(nemo_path) as tar:
-            tar.extractall(tmp)
+            tar.extractall(tmp, filter="data")      # untrusted archive: no absolute paths, links out of tmp, devices
         cfg = next(Path(tmp).rglob("model_config.yaml"))
         wts = next(Path(tmp).rglob("model_weights.ckpt"))
-        encoder, audio_transform, text_transform = load_components_from_quartznet_config(cfg)
+        encoder, audio_transform, text_transform = load_components_from_quartznet_config(cfg, augment_params)
         decoder = conv1d_decoder(1024, text_transform.num_tokens)
         load_quartznet_weights(encoder, decoder, str(wts))
     return BaseCTCModule(encoder=encoder, decoder=decoder, audio_transform=audio_transform,

@@ -16,8 +16,10 @@ import torch
 from torch import nn
 
 from .. import _lib
+from .. import rng as _rng
 from .. import tensors as _t
 from ..blocks import Masked, MultiSequential
+from .spec_augment import SpecAugment, SpecCutout
 
 __all__ = ["FeatureBatchNormalizer", "DitherAudio", "PreEmphasisFilter", "PowerSpectrum", "MelScale",
            "FilterbankFeatures", "patch_stft", "melscale_fbanks"]
@@ -115,18 +117,12 @@ class _FilterbankFeatures(MultiSequential):
 
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "FilterbankFeatures")
-        dither = float(self[0].layer[0].dither) if self.training else 0.0
-        if len(self) > 4:
-            raise NotImplementedError("SpecAugment / SpecCutout (training-only, SURVEY 8f rank 3) are not implemented")
+        # DitherAudio is a training-only step (transform.py:115); the augmentation modules follow their own training flag
+        dither = float(self[0].layer[0].dither) if self[0].layer[0].training else 0.0
         ps, mel = self[1], self[2].layer[0]
         if not mel.log_scale:
             raise NotImplementedError("MelScale(log_scale=False)")
         x = audio.to(torch.float32).contiguous()
-        if dither > 0:
-            # DitherAudio (transform.py:109-118): x + dither * randn_like(x), training only.  Drawn from torch's generator on
-            # purpose: the same seed gives the same noise as the reference; 1e-5-scale noise is below bf16 resolution of the
-            # features, so the kernels downstream are unaffected by where it is generated.
-            x = x + dither * torch.randn_like(x)
         b, n = x.shape
         win, mw, moff, nnz = self._tables(x.device)
         d = _lib.FrontendDesc()
@@ -136,6 +132,16 @@ class _FilterbankFeatures(MultiSequential):
         d.n_frames = n // ps.hop_length + 1
         d.pitch_out = _lib.time_pitch(d.n_frames)
         d.window, d.mel_weights, d.mel_offsets, d.mel_nnz = win.data_ptr(), mw.data_ptr(), moff.data_ptr(), nnz
+        if dither > 0:
+            # DitherAudio (transform.py:109-118): x + dither * N(0, 1), drawn inside the kernel's sample load from a Philox
+            # stream keyed by (seed, clip, sample): no noise tensor, no extra pass over the waveform
+            d.dither, d.dither_seed = dither, _rng.next_seed()
+        tables = [m.layer[0].draw(d.n_mels, d.n_frames, x.device) for m in list(self)[4:] if m.layer[0].training]
+        tables = [t for t in tables if t is not None]
+        if tables:
+            # SpecCutout / SpecAugment (transform.py:299-320): the rectangles are zeroed by the normaliser as it writes the features
+            table = tables[0] if len(tables) == 1 else torch.cat(tables)
+            d.masks, d.n_masks = table.data_ptr(), table.shape[0]
         L = _lib.lib()
         ws_bytes = L.ts_frontend_workspace_bytes(C.byref(d))
         if ws_bytes < 0:
@@ -162,15 +168,18 @@ def FilterbankFeatures(sample_rate: int = 16000, n_window_size: int = 320, n_win
     """Same signature as the reference (quartznet/transform.py:258-271)."""
     if num_cutout_masks > 0 and (num_freq_masks + num_time_masks > 0):
         raise ValueError("Cutout and SpecAugment can't be used at the same time.")
-    if num_cutout_masks > 0 or num_freq_masks + num_time_masks > 0:
-        raise NotImplementedError("SpecAugment / SpecCutout are training-only augmentations outside this round's "
-                                  "scope (SURVEY 8f rank 3); construct with the default 0 masks")
-    return _FilterbankFeatures(
+    modules = [
         Masked(DitherAudio(dither=dither), PreEmphasisFilter(preemph=preemph)),
         PowerSpectrum(n_window_size=n_window_size, n_window_stride=n_window_stride, n_fft=n_fft),
         Masked(MelScale(sample_rate=sample_rate, n_fft=n_fft, nfilt=nfilt)),
         FeatureBatchNormalizer(),
-    )
+    ]
+    if num_cutout_masks > 0:
+        modules.append(Masked(SpecCutout(rect_masks=num_cutout_masks, time_width=mask_time_width, freq_width=mask_freq_width)))
+    if num_freq_masks + num_time_masks > 0:
+        modules.append(Masked(SpecAugment(time_masks=num_time_masks, freq_masks=num_freq_masks, time_width=mask_time_width,
+                                          freq_width=mask_freq_width)))
+    return _FilterbankFeatures(*modules)
 
 
 def patch_stft(filterbank: nn.Module) -> nn.Module:

@@ -104,10 +104,15 @@ def lengths_i32(lengths: torch.Tensor, device) -> torch.Tensor:
     """Reference lengths may be float or int (A5); the kernels take floor()ed int32 on the device."""
     if lengths.dtype == torch.int32 and lengths.device == torch.device(device) and lengths.is_contiguous():
         return lengths
+    # while a hipGraph is being captured the conversion must be RECORDED (a replay refreshes `lengths` in place and the
+    # kernels have to see the new values), so the cache is neither read nor written
+    capturing = lengths.is_cuda and torch.cuda.is_current_stream_capturing()
     cached = getattr(lengths, "_ts_i32", None)
-    if cached is not None and cached[0] == lengths._version and cached[1].device == torch.device(device):
+    if not capturing and cached is not None and cached[0] == lengths._version and cached[1].device == torch.device(device):
         return cached[1]
     out = lengths.to(device=device, dtype=torch.int64).to(torch.int32).contiguous()
+    if capturing:
+        return out
     try:
         lengths._ts_i32 = (lengths._version, out)     # the same tensor object flows through the length-preserving blocks
     except Exception:

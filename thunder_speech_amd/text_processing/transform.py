@@ -30,7 +30,43 @@ class BatchTextTransformer(nn.Module):
         else:
             self.tokenizer = char_tokenizer
 
+    def _encode_on_device(self, items: List[str], device: torch.device):
+        """Character vocabularies: the strings are uploaded once as code points and ts_encode_chars (csrc/metrics.hip) looks the
+        ids up, adds the start / end tokens and pads -- instead of one torch.tensor + pad_sequence slice per utterance."""
+        import numpy as np
+        from .. import _lib
+        v = self.vocab
+        tab = getattr(self, "_cp_table", None)
+        if tab is None or tab[0] != str(device):
+            single = sorted((ord(t), i) for i, t in enumerate(v.itos) if len(t) == 1)
+            cp = torch.tensor([c for c, _ in single], dtype=torch.int32, device=device)
+            ids = torch.tensor([i for _, i in single], dtype=torch.int32, device=device)
+            known = {chr(c) for c, _ in single}
+            tab = self._cp_table = (str(device), cp, ids, known)
+        _, cp, ids, known = tab
+        if v.unknown_token is None:                       # numericalize drops out-of-vocabulary tokens (vocab.py:95-96)
+            items = ["".join(ch for ch in s if ch in known) for s in items]
+        rows = [np.frombuffer(s.encode("utf-32-le"), dtype="<u4").astype(np.int32) for s in items]
+        off = np.zeros(len(rows) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([r.size for r in rows])
+        flat = np.concatenate(rows + [np.zeros(1, np.int32)])
+        extra = (v.start_token is not None) + (v.end_token is not None)
+        s_max = max(int(max(r.size for r in rows)) + extra, 1)
+        d = torch.from_numpy(np.concatenate([flat, off])).pin_memory().to(device, non_blocking=True)
+        out = torch.empty(len(rows), s_max, dtype=torch.int64, device=device)
+        lens = torch.empty(len(rows), dtype=torch.int64, device=device)
+        st = _lib.lib().ts_encode_chars(d.data_ptr(), d[flat.size:].data_ptr(), len(rows), cp.data_ptr(), ids.data_ptr(), cp.numel(),
+                                        v._unk_idx, v.stoi[v.start_token] if v.start_token is not None else -1,
+                                        v.stoi[v.end_token] if v.end_token is not None else -1, v.pad_idx, s_max, out.data_ptr(),
+                                        lens.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(st, "ts_encode_chars")
+        return out, lens
+
     def encode(self, items: List[str], return_length: bool = True, device=None) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        dev = torch.device(device) if device is not None else None
+        if dev is not None and dev.type == "cuda" and self.tokenizer is char_tokenizer and len(items) > 0:
+            batched, lengths = self._encode_on_device(items, dev)
+            return (batched, lengths) if return_length else batched
         encoded = [self.vocab.numericalize(self.vocab.add_special_tokens(self.tokenizer(x))) for x in items]
         batched = pad_sequence(encoded, batch_first=True, padding_value=self.vocab.pad_idx).to(device=device)
         if return_length:

@@ -186,6 +186,95 @@ class AddRelu(torch.autograd.Function):
         return din, (din if ctx.has_b else None)
 
 
+class Dropout(torch.autograd.Function):
+    """nn.Dropout in train mode: y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) drawn per element from a Philox stream
+    (csrc/augment.hip).  Nothing is saved: the backward pass re-draws the mask from the same seed."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ts_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed), _s(x)), "ts_dropout")
+        ctx.p, ctx.seed = float(p), int(seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32(dy)
+        dx = torch.empty_like(dy)
+        _lib.check(_lib.lib().ts_dropout(dy.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, ctx.seed, _s(dy)), "ts_dropout")
+        return dx, None, None
+
+
+def dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    if not training or p <= 0.0:
+        return x
+    from .rng import next_seed
+    return Dropout.apply(x, p, next_seed())
+
+
+class SubsampleMask(torch.autograd.Function):
+    """Input side of a strided 1x1 MaskedConv1d: zero the frames >= length, keep every `stride`-th frame."""
+
+    @staticmethod
+    def forward(ctx, x, lens, stride, t_out):
+        x = _f32(x)
+        b, c, t_in = x.shape
+        y = torch.empty(b, c, t_out, dtype=torch.float32, device=x.device)
+        st = _lib.lib().ts_train_subsample_mask(x.data_ptr(), lens.data_ptr(), y.data_ptr(), b, c, t_in, t_out, stride, 0, _s(x))
+        _lib.check(st, "ts_train_subsample_mask")
+        ctx.save_for_backward(lens)
+        ctx.geom = (b, c, t_in, t_out, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lens,) = ctx.saved_tensors
+        b, c, t_in, t_out, stride = ctx.geom
+        dy = _f32(dy)
+        dx = torch.empty(b, c, t_in, dtype=torch.float32, device=dy.device)
+        st = _lib.lib().ts_train_subsample_mask(dy.data_ptr(), lens.data_ptr(), dx.data_ptr(), b, c, t_in, t_out, stride, 1, _s(dy))
+        _lib.check(st, "ts_train_subsample_mask")
+        return dx, None, None, None
+
+
+class SqueezeExciteTrain(torch.autograd.Function):
+    """SqueezeExcite.forward with autograd (citrinet/blocks.py:70-83): y = x * sigmoid(W2 relu(W1 mean_t(x))), the mean over ALL
+    frames (quirk A3).  The passes over the activation are HIP launches (csrc/train_extra.hip); the [B, C] bottleneck is four
+    tiny GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
+        b, c, t = x.shape
+        L = _lib.lib()
+        mean = torch.empty(b, c, dtype=torch.float32, device=x.device)
+        _lib.check(L.ts_train_se_pool(x.data_ptr(), mean.data_ptr(), b * c, t, _s(x)), "ts_train_se_pool")
+        h = torch.relu(mean @ w1.t())
+        g = torch.sigmoid(h @ w2.t()).contiguous()
+        y = torch.empty_like(x)
+        _lib.check(L.ts_train_se_scale(x.data_ptr(), g.data_ptr(), None, y.data_ptr(), b * c, t, _s(x)), "ts_train_se_scale")
+        ctx.save_for_backward(x, w1, w2, mean, h, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, mean, h, g = ctx.saved_tensors
+        dy = _f32(dy)
+        b, c, t = x.shape
+        L = _lib.lib()
+        dg = torch.empty(b, c, dtype=torch.float32, device=x.device)
+        _lib.check(L.ts_train_se_rowdot(dy.data_ptr(), x.data_ptr(), dg.data_ptr(), b * c, t, _s(x)), "ts_train_se_rowdot")
+        dz = dg * g * (1.0 - g)
+        dw2 = dz.t() @ h
+        dh = (dz @ w2) * (h > 0).to(dz.dtype)
+        dw1 = dh.t() @ mean
+        dmean = (dh @ w1).contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(L.ts_train_se_scale(dy.data_ptr(), g.data_ptr(), dmean.data_ptr(), dx.data_ptr(), b * c, t, _s(x)), "ts_train_se_scale")
+        return dx, dw1, dw2
+
+
 def batch_norm_train(bn: torch.nn.BatchNorm1d, v: Tensor, relu: bool) -> Tensor:
     """BatchNorm1d(train) through the kernels + the module's running-statistics update (momentum, unbiased variance)."""
     running = None
@@ -195,4 +284,10 @@ def batch_norm_train(bn: torch.nn.BatchNorm1d, v: Tensor, relu: bool) -> Tensor:
         # momentum=None (cumulative average) needs the counter's value: one host read, the reference default is 0.1
         m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
         running = (bn.running_mean, bn.running_var, m, bn.num_batches_tracked)
-    return BatchNormTrain.apply(v, bn.weight, bn.bias, bn.eps, relu, running)
+    y = BatchNormTrain.apply(v, bn.weight, bn.bias, bn.eps, relu, running)
+    if running is not None:
+        # the launch updated the buffers through raw pointers: make the change visible to `_version`-keyed caches
+        # (blocks._PackedCache folds running_mean / running_var into the inference weights)
+        for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+            torch.autograd.graph.increment_version(t)
+    return y

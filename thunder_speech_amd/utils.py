@@ -92,6 +92,6 @@ class GraphedForward:
             entry = self._graphs[key] = (graph, static_in, out)
         graph, static_in, out = entry
         for dst, src in zip(static_in, args):
-            dst.copy_(src)
+            dst.copy_(src)                                       # bumps dst._version: host-side caches keyed on it go stale
         graph.replay()
         return out
