@@ -147,7 +147,8 @@ const float* ts_frontend_logmel_ptr(const ts_frontend_desc* desc, const void* wo
  *     (frequency span, then a time span drawn with cut_FREQ_width: reference quirk, spec_augment.py:99-100), n_time time
  *     masks, n_freq frequency masks; each span is value = u * width, min = u' * (size - value), [long(min), long(min) + long(value)).
  *     (The Python mirror can instead fill the table from torch.rand(1) draws on the host, exactly as the reference does.)
- *   ts_spec_mask_apply : features[b][f0:f1][t0:t1] = 0 on a bf16 [B][channels][pitch] tensor, in place.  ts_mel_frontend_fwd
+ *   ts_spec_mask_apply : features[b][f0:f1][t0:t1] = 0 on a [B][channels][pitch] tensor, in place; elem_bytes = 2 (bf16, the
+ *     internal layout) or 4 (f32, a reference-layout tensor handed to the standalone module).  ts_mel_frontend_fwd
  *     applies the same table inside its normaliser when ts_frontend_desc.masks is set (no extra pass).
  *   ts_dropout : y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) per element from (seed, element index) -- nn.Dropout in
  *     train mode (quartznet/blocks.py:227-228, blocks.py:238); the backward pass is the same call on dy with the same seed.
@@ -156,8 +157,8 @@ const float* ts_frontend_logmel_ptr(const ts_frontend_desc* desc, const void* wo
 int ts_spec_masks_draw(uint64_t seed, int32_t n_time, int32_t time_width, int32_t n_freq, int32_t freq_width, int32_t n_cutout,
                        int32_t cut_time_width, int32_t cut_freq_width, int32_t n_mels, int32_t n_frames, int32_t* table,
                        void* stream);
-int ts_spec_mask_apply(void* features, int32_t batch, int32_t channels, int32_t t, int32_t pitch, const int32_t* table,
-                       int32_t n_masks, void* stream);
+int ts_spec_mask_apply(void* features, int32_t elem_bytes, int32_t batch, int32_t channels, int32_t t, int32_t pitch,
+                       const int32_t* table, int32_t n_masks, void* stream);
 int ts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

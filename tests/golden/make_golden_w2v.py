@@ -1,5 +1,9 @@
-"""Generates tests/golden/w2v_tiny.npz from the REAL transformers Wav2Vec2Model (run in the build container only):
-a tiny group-norm / post-LN configuration with seeded random weights, one unmasked and one masked forward pass."""
+"""Generates tests/golden/w2v_tiny.npz / w2v_tiny_layer.npz / w2v_mid.npz from the REAL transformers Wav2Vec2Model (run in the
+build container only): small configurations with seeded random weights, one unmasked and one masked forward pass each.
+w2v_mid has head_dim 64 and 64 channels per positional-conv group, the geometry at which the HIP path takes its fused
+attention / MFMA positional-conv kernels (the tiny ones exercise the fallback kernels).  Its 1 M-element positional-conv
+direction tensor is not stored: it is drawn from a seeded torch generator here and re-drawn by tests/test_oracle_w2v.load_fixture
+(same torch build on both sides; a stored checksum guards against generator drift)."""
 import numpy as np
 import torch
 from transformers import Wav2Vec2Config, Wav2Vec2Model
@@ -10,9 +14,12 @@ CFG = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermedi
 
 
 LAYER = dict(CFG, feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)
+MID = dict(CFG, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_conv_pos_embeddings=128,
+           num_conv_pos_embedding_groups=2)
+REGEN_SEED, REGEN_SCALE = 4321, 0.05
 
 
-def main(cfg=CFG, name="w2v_tiny.npz"):
+def main(cfg=CFG, name="w2v_tiny.npz", regen=()):
     torch.manual_seed(0)
     model = Wav2Vec2Model(Wav2Vec2Config(**cfg)).eval()
     with torch.no_grad():                      # make the norms / biases non-trivial
@@ -21,6 +28,8 @@ def main(cfg=CFG, name="w2v_tiny.npz"):
                 v.copy_(1.0 + 0.2 * torch.randn_like(v))
             elif k.endswith(".bias"):
                 v.copy_(0.1 * torch.randn_like(v))
+            if any(k.endswith(r) for r in regen):
+                v.copy_(REGEN_SCALE * torch.randn(v.shape, generator=torch.Generator().manual_seed(REGEN_SEED)))
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 8000, generator=g)
     lengths = torch.tensor([8000, 5000])
@@ -30,7 +39,11 @@ def main(cfg=CFG, name="w2v_tiny.npz"):
         xm = x * mask
         out_masked = model(xm, attention_mask=mask).last_hidden_state
         feat = model.feature_extractor(x).transpose(1, 2)
-    arrays = {"sd/" + k: v.numpy() for k, v in model.state_dict().items()}
+    arrays = {"sd/" + k: v.numpy() for k, v in model.state_dict().items() if not any(k.endswith(r) for r in regen)}
+    for k, v in model.state_dict().items():
+        if any(k.endswith(r) for r in regen):
+            arrays["regen/" + k] = np.asarray([REGEN_SEED] + list(v.shape), dtype=np.int64)
+            arrays["regen_sum/" + k] = np.asarray(float(v.double().abs().sum()))
     arrays.update(x=x.numpy(), lengths=lengths.numpy(), out=out.numpy(), out_masked=out_masked.numpy(), feat=feat.numpy(),
                   out_lengths=model._get_feat_extract_output_lengths(lengths).numpy())
     for k, v in cfg.items():
@@ -44,3 +57,4 @@ def main(cfg=CFG, name="w2v_tiny.npz"):
 if __name__ == "__main__":
     main()
     main(LAYER, "w2v_tiny_layer.npz")
+    main(MID, "w2v_mid.npz", regen=("pos_conv_embed.conv.parametrizations.weight.original1", "pos_conv_embed.conv.weight_v"))

@@ -139,11 +139,7 @@ def test_tail_zero_fast_kernels_match_oracle(cin, cout, k, stride, dil, t, lens,
     _run_case_tail_zero(cin, cout, k, stride, dil, t, lens, res)
 
 
-def test_padding_region_never_leaks():
-    """Frames >= length and the pitch padding are poisoned in the input; outputs must not change."""
-    got1, _ = _run_case(64, 64, 33, 1, 1, 200, [200, 120], True, seed=3)
-    got2, _ = _run_case(64, 64, 33, 1, 1, 200, [200, 120], True, seed=3)
-    assert torch.equal(got1, got2)
+# (the poison test lives in tests/test_gpu_configs.py::test_padding_region_never_leaks: different garbage per run)
 
 
 @pytest.mark.parametrize("k", [63, 75, 39, 87])

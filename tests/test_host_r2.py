@@ -1,0 +1,112 @@
+"""CPU-only checks of the round-2 host logic: module tree with augmentation, reference-exact mask draws, the fine-tuning
+schedule object, the packed-weight cache noticing raw-pointer updates, text encoding (host path) against the reference fixture."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+
+def test_filterbank_tree_with_augmentation():
+    from thunder_speech_amd.quartznet.spec_augment import SpecAugment, SpecCutout
+    from thunder_speech_amd.quartznet.transform import FilterbankFeatures
+    fb = FilterbankFeatures()
+    assert len(fb) == 4
+    fb = FilterbankFeatures(num_time_masks=2, num_freq_masks=1, mask_time_width=40, mask_freq_width=15)
+    assert len(fb) == 5 and isinstance(fb[4].layer[0], SpecAugment)
+    sa = fb[4].layer[0]
+    assert (sa.time_masks, sa.freq_masks, sa.time_width, sa.freq_width) == (2, 1, 40, 15)
+    fb = FilterbankFeatures(num_cutout_masks=3)
+    assert isinstance(fb[4].layer[0], SpecCutout) and fb[4].layer[0].rect_masks == 3
+    with pytest.raises(ValueError):
+        FilterbankFeatures(num_cutout_masks=1, num_time_masks=1)
+    assert not list(fb.state_dict()) or set(fb.state_dict()) == {"1.window", "2.layer.0.fb"}
+
+
+def test_mask_draws_reproduce_the_reference_under_the_same_seed(golden):
+    """rng='torch' (default): the table equals what the reference's SpecAugment / SpecCutout drew under the same manual_seed."""
+    from thunder_speech_amd.quartznet.spec_augment import SpecAugment, SpecCutout
+    g = golden("r2_misc.npz")
+    for i in range(3):
+        n_time, tw, n_freq, fw = [int(v) for v in g[f"specaug{i}_cfg"]]
+        m = SpecAugment(freq_masks=n_freq, time_masks=n_time, freq_width=fw, time_width=tw)
+        torch.manual_seed(int(g[f"specaug{i}_seed"]))
+        assert np.array_equal(m.draw(64, 301, "cpu").numpy(), g[f"specaug{i}_table"])
+    for i in range(2):
+        n, tw, fw = [int(v) for v in g[f"cutout{i}_cfg"]]
+        m = SpecCutout(rect_masks=n, time_width=tw, freq_width=fw)
+        torch.manual_seed(int(g[f"cutout{i}_seed"]))
+        assert np.array_equal(m.draw(64, 301, "cpu").numpy(), g[f"cutout{i}_table"])
+    assert SpecAugment().draw(64, 301, "cpu") is None
+    x = torch.randn(2, 64, 50)
+    assert SpecAugment(time_masks=2).eval()(x) is x                  # identity in eval mode, like the reference
+
+
+def test_text_encode_host_path_matches_reference_fixture(golden):
+    from thunder_speech_amd.text_processing.transform import BatchTextTransformer
+    g = golden("r2_misc.npz")
+    labels = [" "] + [chr(ord("a") + i) for i in range(26)] + ["'"]
+    t1 = BatchTextTransformer(tokens=labels)
+    e, l = t1.encode([str(s) for s in g["enc_texts"]])
+    assert np.array_equal(e.numpy(), g["enc1"]) and np.array_equal(l.numpy(), g["len1"])
+    t2 = BatchTextTransformer(tokens=labels, start_token="<bos>", end_token="<eos>", unknown_token="<unk>")
+    e, l = t2.encode([str(s) for s in g["enc_texts_unk"]])
+    assert np.array_equal(e.numpy(), g["enc2"]) and np.array_equal(l.numpy(), g["len2"])
+    e, l = t1.encode([str(s) for s in g["enc_texts_unk"]])
+    assert np.array_equal(e.numpy(), g["enc3"]) and np.array_equal(l.numpy(), g["len3"])
+    assert t1.decode_prediction(torch.from_numpy(g["enc1"]), remove_repeated=False) == [str(s) for s in g["dec1"]]
+
+
+def test_finetune_schedule_freezes_and_unfreezes_like_base_finetuning():
+    from thunder_speech_amd.callbacks import FinetuneEncoderDecoder
+    from thunder_speech_amd.registry import load_pretrained
+    m = load_pretrained("QuartzNet5x5_synthetic")
+    cb = FinetuneEncoderDecoder(unfreeze_encoder_at_epoch=2, encoder_initial_lr_div=5, train_batchnorm=True)
+    cb.on_fit_start(None, m)
+    with pytest.raises(Exception):
+        cb.on_fit_start(None, nn.Linear(2, 2))
+    m.train()
+    cb.freeze_before_training(m)
+    bn = [x for x in m.encoder.modules() if isinstance(x, nn.BatchNorm1d)]
+    convs = [x for x in m.encoder.modules() if isinstance(x, nn.Conv1d)]
+    assert all(p.requires_grad for b in bn for p in b.parameters()) and all(b.training for b in bn)
+    assert not any(p.requires_grad for c in convs for p in c.parameters())
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    n0 = len(opt.param_groups)
+    cb.finetune_function(m, 1, opt)
+    assert len(opt.param_groups) == n0                                  # not yet
+    cb.finetune_function(m, 2, opt)
+    assert all(p.requires_grad for c in convs for p in c.parameters())
+    assert len(opt.param_groups) == n0 + 1 and abs(opt.param_groups[-1]["lr"] - 1e-3 / 5) < 1e-12
+    ids = [id(p) for g in opt.param_groups for p in g["params"]]
+    assert len(ids) == len(set(ids))                                    # no parameter in two groups
+    # train_batchnorm = False: BatchNorm frozen too until the unfreeze
+    m2 = load_pretrained("QuartzNet5x5_synthetic").train()
+    cb2 = FinetuneEncoderDecoder(train_batchnorm=False)
+    cb2.freeze_before_training(m2)
+    assert not any(p.requires_grad for p in m2.encoder.parameters())
+    assert not any(b.training for b in m2.encoder.modules() if isinstance(b, nn.BatchNorm1d))
+
+
+def test_packed_cache_sees_version_bumps():
+    """optim.FusedAdamW and batch_norm_train update tensors through raw pointers and then bump `_version`; the cache key must
+    change with it."""
+    from thunder_speech_amd.blocks import _PackedCache
+    from thunder_speech_amd.optim import _bump_versions
+    w = torch.zeros(4)
+    cache, builds = _PackedCache(), []
+    build = lambda: builds.append(1) or len(builds)
+    assert cache.get([w], build) == 1 and cache.get([w], build) == 1
+    _bump_versions([w])
+    assert cache.get([w], build) == 2
+
+
+def test_ctc_rejects_bad_targets_on_the_host():
+    from thunder_speech_amd.ctc_loss import _prepare_targets
+    t, tl, _ = _prepare_targets(torch.tensor([1, 2, 3, 4, 5]), torch.tensor([2, 3]), 2, 6, "cpu")   # concatenated 1-D form
+    assert t.tolist() == [[1, 2, 0], [3, 4, 5]] and tl.tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        _prepare_targets(torch.tensor([1, 2, 3]), torch.tensor([2, 3]), 2, 6, "cpu")                # lengths do not add up
+    with pytest.raises(ValueError):
+        _prepare_targets(torch.tensor([[1, 9]]), torch.tensor([2]), 1, 6, "cpu")                     # id outside [0, V)
+    t, _, _ = _prepare_targets(torch.tensor([[1, 9]]), torch.tensor([1]), 1, 6, "cpu")               # ... but padding may hold anything
+    assert t.tolist() == [[1, 0]]

@@ -9,12 +9,20 @@ from oracle import w2v as ow
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-FIXTURES = ["w2v_tiny.npz", "w2v_tiny_layer.npz"]          # group-norm / post-LN and layer-norm / stable-LN families
+# group-norm / post-LN and layer-norm / stable-LN families at toy size (fallback kernels on the GPU), and a mid-size group-norm
+# configuration with head_dim 64 and 64 channels per positional-conv group (fused attention / MFMA positional conv on the GPU)
+FIXTURES = ["w2v_tiny.npz", "w2v_tiny_layer.npz", "w2v_mid.npz"]
 
 
 def load_fixture(name="w2v_tiny.npz"):
     z = np.load(os.path.join(HERE, "golden", name))
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    for k in z.files:                                     # large tensors drawn from a seeded generator instead of being stored
+        if k.startswith("regen/"):
+            seed, *shape = [int(v) for v in z[k]]
+            t = 0.05 * torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+            assert abs(float(t.double().abs().sum()) - float(z["regen_sum/" + k[6:]])) < 1e-6 * t.numel(), "torch generator drift"
+            sd[k[6:]] = t
     c = {k[4:]: z[k] for k in z.files if k.startswith("cfg/")}
     cfg = ow.W2VConfig(conv_dim=tuple(int(v) for v in c["conv_dim"]), conv_kernel=tuple(int(v) for v in c["conv_kernel"]),
                        conv_stride=tuple(int(v) for v in c["conv_stride"]), hidden_size=int(c["hidden_size"]),

@@ -148,7 +148,7 @@ def lib() -> C.CDLL:
         getattr(L, fn).restype = C.c_int
     u64 = C.c_uint64
     L.ts_spec_masks_draw.argtypes = [u64] + [i32] * 9 + [vp, vp]
-    L.ts_spec_mask_apply.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp]
+    L.ts_spec_mask_apply.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp]
     L.ts_dropout.argtypes = [vp, vp, i64, f32, u64, vp]
     L.ts_audio_prep_workspace_bytes.argtypes = [i64]
     L.ts_audio_prep_workspace_bytes.restype = i64

@@ -61,15 +61,15 @@ __global__ void spec_draw_kernel(const SpecDrawArgs a) {
   }
 }
 
-// one workgroup per (mask, clip): zero the rectangle rows [f0, f1) x frames [t0, t1) of a bf16 [B][C][pitch] tensor
-__global__ __launch_bounds__(256) void spec_apply_kernel(unsigned short* __restrict__ x, int channels, int t, int pitch,
-                                                          const int* __restrict__ table) {
+// one workgroup per (mask, clip): zero the rectangle rows [f0, f1) x frames [t0, t1) of a [B][C][pitch] tensor (bf16 or f32)
+template <class E>
+__global__ __launch_bounds__(256) void spec_apply_kernel(E* __restrict__ x, int channels, int t, int pitch, const int* __restrict__ table) {
   const int* m = table + 4 * blockIdx.x;
   const int f0 = max(m[0], 0), f1 = min(m[1], channels), t0 = max(m[2], 0), t1 = min(m[3], t);
   if (f1 <= f0 || t1 <= t0) return;
   const int w = t1 - t0;
-  unsigned short* base = x + (size_t)blockIdx.y * channels * pitch;
-  for (int idx = threadIdx.x; idx < (f1 - f0) * w; idx += 256) base[(size_t)(f0 + idx / w) * pitch + t0 + idx % w] = 0;
+  E* base = x + (size_t)blockIdx.y * channels * pitch;
+  for (int idx = threadIdx.x; idx < (f1 - f0) * w; idx += 256) base[(size_t)(f0 + idx / w) * pitch + t0 + idx % w] = E(0);
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float p,
@@ -104,13 +104,18 @@ extern "C" int ts_spec_masks_draw(uint64_t seed, int32_t n_time, int32_t time_wi
   return ts::hip_status(hipGetLastError());
 }
 
-extern "C" int ts_spec_mask_apply(void* features, int32_t batch, int32_t channels, int32_t t, int32_t pitch, const int32_t* table,
-                                  int32_t n_masks, void* stream) {
+extern "C" int ts_spec_mask_apply(void* features, int32_t elem_bytes, int32_t batch, int32_t channels, int32_t t, int32_t pitch,
+                                  const int32_t* table, int32_t n_masks, void* stream) {
   if (!features || batch <= 0 || channels <= 0 || t <= 0 || pitch < t || n_masks < 0 || (n_masks && !table)) return TS_EINVAL;
+  if (elem_bytes != 2 && elem_bytes != 4) return TS_EINVAL;
   if (!n_masks) return TS_OK;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ts::spec_apply_kernel, dim3(n_masks, batch), dim3(256), 0, (hipStream_t)stream,
-                     static_cast<unsigned short*>(features), channels, t, pitch, table);
+  if (elem_bytes == 2)
+    hipLaunchKernelGGL(ts::spec_apply_kernel<unsigned short>, dim3(n_masks, batch), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<unsigned short*>(features), channels, t, pitch, table);
+  else
+    hipLaunchKernelGGL(ts::spec_apply_kernel<float>, dim3(n_masks, batch), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<float*>(features), channels, t, pitch, table);
   return ts::hip_status(hipGetLastError());
 }
 

@@ -11,6 +11,44 @@ from torch import Tensor
 from . import _lib
 
 
+def _prepare_targets(targets: Tensor, target_lengths: Tensor, b: int, v: int, dev):
+    """-> (int32 [B, S_max] padded targets, int32 [B] lengths, bool [B] rows holding a wild id | None) on `dev`.
+
+    F.ctc_loss accepts padded 2-D targets or the 1-D concatenation of all targets (sum(target_lengths) entries); both are
+    accepted here, the 1-D form is scattered into the padded layout.  Ids the kernels would index with (positions < length)
+    must lie in [0, V).  Host tensors are checked here (ValueError); for device tensors the check stays on the device, without
+    a host synchronisation: an utterance with a wild id is made infeasible (its input length becomes 0, so its loss is the
+    infinity that zero_infinity turns into 0 and its gradient is 0).  Padding positions are rewritten to 0 either way, so no
+    kernel ever indexes with a wild id."""
+    tl = target_lengths.to(dtype=torch.int64)
+    if targets.dim() == 1:
+        tl_host = tl.cpu()
+        if int(tl_host.sum()) != targets.numel():
+            raise ValueError("calculate_ctc: 1-D targets must hold exactly sum(target_lengths) labels (F.ctc_loss's concatenated format)")
+        s_max = max(int(tl_host.max()) if b else 0, 1)
+        rows = torch.arange(b).repeat_interleave(tl_host)
+        cols = torch.cat([torch.arange(int(n)) for n in tl_host.tolist()]) if targets.numel() else torch.zeros(0, dtype=torch.int64)
+        padded = torch.zeros(b, s_max, dtype=torch.int64, device=targets.device)
+        padded[rows.to(targets.device), cols.to(targets.device)] = targets.to(torch.int64)
+        targets = padded
+    elif targets.dim() != 2 or targets.shape[0] != b:
+        raise ValueError("calculate_ctc: targets must be [batch, S] or the 1-D concatenation of the target sequences")
+    if targets.shape[1] == 0:
+        targets = torch.zeros(b, 1, dtype=torch.int64, device=targets.device)
+    tg = targets.to(device=dev, dtype=torch.int64)
+    tl = tl.to(dev)
+    valid = torch.arange(tg.shape[1], device=dev)[None, :] < tl[:, None]
+    bad = valid & ((tg < 0) | (tg >= v))
+    bad_rows = None
+    if not targets.is_cuda:
+        if bool(bad.any()):
+            raise ValueError(f"calculate_ctc: target ids must lie in [0, {v}) (the number of classes of the logits)")
+    else:
+        bad_rows = bad.any(dim=1)
+    tg = torch.where(valid & ~bad, tg, torch.zeros_like(tg))
+    return tg.to(torch.int32).contiguous(), tl.to(torch.int32).contiguous(), bad_rows
+
+
 class _CtcFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, targets: Tensor, input_lengths: Tensor, target_lengths: Tensor, blank: int):
@@ -22,15 +60,12 @@ class _CtcFunction(torch.autograd.Function):
             lg = lg.to(torch.float32).contiguous()
         pitch = lg.stride(1)
         dev = lg.device
-        tg = targets.to(device=dev, dtype=torch.int32).contiguous()
-        if tg.dim() == 1:
-            tg = tg.view(b, -1)
-        s_max = tg.shape[1] if tg.numel() else 0
-        if s_max == 0:
-            tg = torch.zeros(b, 1, dtype=torch.int32, device=dev)
-            s_max = 1
+        tg, tl, bad_rows = _prepare_targets(targets, target_lengths, b, v, dev)
+        s_max = tg.shape[1]
         il = input_lengths.to(device=dev, dtype=torch.int64).to(torch.int32).contiguous()     # .long() (A5)
-        tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        if bad_rows is not None:
+            il = torch.where(bad_rows, torch.zeros_like(il), il)
+            tl = torch.where(bad_rows & (tl == 0), torch.ones_like(tl), tl)    # keep the utterance infeasible even with an empty target
         L = _lib.lib()
         ws = torch.empty(L.ts_ctc_workspace_bytes(b, v, t, s_max), dtype=torch.uint8, device=dev)
         nll = torch.empty(b, dtype=torch.float32, device=dev)

@@ -100,10 +100,16 @@ class MaskedConv1d(nn.Module):
                                         stride=self.stride, dilation=1, padding=0, relu=False,
                                         bias_extra=None if conv.bias is None else conv.bias.detach())
         layer = self._cache.get(tensors, build)
-        xi = _t.pack(x)
+        if self.use_mask:
+            # mask_fill (quartznet/blocks.py:158-167) happens ONCE, on the input: it is packed with the frames >= length zeroed
+            # and the launch then runs unmasked, so the frames beyond the output length keep the partial sums the reference's
+            # conv leaves there (the fused blocks re-mask between their own convs instead)
+            xi = _t.pack(_t.unpack(x), lengths, slot=("mconv", id(self)))      # (the standalone module is not on the hot path)
+        else:
+            xi = _t.pack(x)
         b, _, t = xi.shape
-        li = _t.lengths_i32(lengths, xi.device) if self.use_mask else torch.full((b,), t, dtype=torch.int32, device=xi.device)
-        y, t_out = layer.run(_t.backing(xi), t, li)
+        full = torch.full((b,), t, dtype=torch.int32, device=xi.device)
+        y, t_out = layer.run(_t.backing(xi), t, full)
         return y[:, :, :t_out], self.get_seq_len(lengths)
 
 

@@ -71,14 +71,14 @@ class _MaskTable(nn.Module):
         if not self.training or self.n_masks() == 0:
             return x
         _t.require_gpu(x, type(self).__name__)
-        internal = _t.is_internal(x)
-        xi = x if internal else _t.pack(x)
+        # like masked_fill, the result is a new tensor unless x is an internal (library-layout) view, which is masked in place
+        xi = x if _t.is_internal(x) else x.to(torch.float32).clone(memory_format=torch.contiguous_format)
         b, f, t = xi.shape
         table = self.draw(f, t, xi.device)
-        st = _lib.lib().ts_spec_mask_apply(xi.data_ptr(), b, f, t, xi.stride(1), table.data_ptr(), table.shape[0],
+        st = _lib.lib().ts_spec_mask_apply(xi.data_ptr(), xi.element_size(), b, f, t, xi.stride(1), table.data_ptr(), table.shape[0],
                                            torch.cuda.current_stream(xi.device).cuda_stream)
         _lib.check(st, "ts_spec_mask_apply")
-        return xi if internal else _t.unpack(xi).to(x.dtype)
+        return xi
 
 
 class SpecAugment(_MaskTable):
