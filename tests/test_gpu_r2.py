@@ -243,7 +243,8 @@ def test_train_mode_dropout_in_blocks(golden, monkeypatch):
     frac = float((y1 == 0).float().mean())
     blk0 = _block(QuartznetBlock, sd, dropout=0.0)
     y0, _ = blk0(x, lengths)
-    assert frac > float((y0 == 0).float().mean()) + 0.15              # ~30 % more zeros than ReLU alone leaves
+    z0 = float((y0 == 0).float().mean())
+    assert frac > z0 + 0.2 * (1.0 - z0)                                  # the final dropout alone zeroes ~30 % of what ReLU left
     # only the final dropout active: y = y0 * keep / (1 - p) with the oracle's mask for the first seed drawn
     blk3 = _block(QuartznetBlock, sd, dropout=0.0)
     blk3.mout[1].layer[0].p = 0.5
