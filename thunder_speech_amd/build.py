@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = True, only=None) -> str:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
                "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
                f'-DTS_BUILD_TARGET="{ARCH}"', "-c", src, "-o", obj]
-        cmd[1:1] = os.environ.get("TS_CXXFLAGS", "").split()        # diagnostic builds, e.g. TS_CXXFLAGS=-DTS_EXP=8
+        cmd[1:1] = os.environ.get("TS_CXXFLAGS", "").split()        # diagnostic builds (tools/variants.py), e.g. TS_CXXFLAGS=-DTS_STAMP
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -118,10 +118,11 @@ class CitrinetBlock(_FusedBlockBase):
                                                padding=0, relu=False))
         return layers
 
-    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=0):
+    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=None):
         """Same contract as _FusedBlockBase._run_fused; the tail of the block is the SE launch sequence."""
         _t.require_gpu(x, type(self).__name__)
         self._check_eval()
+        slot = (id(self), 0) if slot is None else slot
         layers = self._cache.get(self._params(), self._compile)
         convs = layers[:self.repeat]
         res_layer = layers[self.repeat] if self.res is not None else None

@@ -6,12 +6,11 @@
 // Replaces the reference's per-sub-block ATen chain (quartznet/blocks.py:166-182 masked_fill + conv1d
 // (groups=C) + masked_fill + conv1d(k=1), :222 batch_norm, :332-337 residual add + relu).
 //
-// Three kernels live in this file, newest last (DESIGN.md section 3.1 has the measurements behind each step):
+// Two kernels live in this file (DESIGN.md section 3.1 has the measurements behind each step; the single-stream pipelined
+// kernel that sat between them in round 1 is gone):
 //   tcs_kernel        first design and generic fallback: 4 producer + 4 consumer waves, 64/128-frame tiles, masked
-//                     producers for caller tensors; still runs the stride-2 stem, the dilated layer and the fp32 decoder.
-//   tcs_pipe_kernel   all 8 waves accumulate, 96/192-frame tiles, both jobs software-pipelined in one instruction stream,
-//                     raw buffer loads, tap fragments by DMA into LDS.  Kept behind TS_NO_SPLIT=1.
-//   tcs_split_kernel  12 waves = 8 pointwise consumers + 4 depthwise producers on the same tiles: the default for every
+//                     producers for caller tensors; still runs the stride-2 stem, odd shapes and the fp32 decoder.
+//   tcs_split_kernel  12 waves = 8 pointwise consumers + 4 depthwise producers, 96/192-frame tiles: the default for every
 //                     depthwise / pointwise-only layer with tail-zero tensors.
 // Common to all of them:
 //  * layout NCT-p: bf16 [B][C][Tp], time contiguous.  A tile = TT output frames x CO_WG output channels of one
@@ -40,9 +39,6 @@ constexpr int XMAX = 5;        // staged row length <= 64 * XMAX elements
 constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
 #ifndef TS_SPLIT_RING
 #define TS_SPLIT_RING 2
-#endif
-#ifndef TS_PIPE_RING
-#define TS_PIPE_RING 2
 #endif
 #ifndef TS_WIN_DIST
 #define TS_WIN_DIST 1
@@ -76,7 +72,6 @@ struct TcsArgs {
   int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
   int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
   int xcd;                     // split kernel: 1 = XCD-contiguous tile order (grid is a multiple of 8)
-  int privb;                   // pipelined kernel: bytes of a wave's private LDS region
 #ifdef TS_STAMP
   long long* dbg;              // diagnostic build only: s_memtime stamps of one workgroup
 #endif
@@ -699,24 +694,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
 }
 
 // ======================================================================================================
-// Pipelined all-waves kernel (tail-zero input, stride 1, depthwise taps in registers): the kernel the QuartzNet /
-// Citrinet body layers run on.
-//
-// All 8 waves hold accumulators and every wave does both jobs, software-pipelined one stage apart: while a wave
-// accumulates stage g of the pointwise GEMM out of dwt[g & 1] (v_mfma_f32_32x32x16_bf16), the SAME instruction stream
-// runs the depthwise FIR of stage g+1 (v_mfma_f32_4x4x4_16b_bf16) into dwt[(g+1) & 1], so the matrix pipe always has
-// independent work while LDS reads of the other job are in flight.  One s_barrier per stage.
-//   wave grid WM x WN (time x output channels), wave tile = 32*MT frames x 64 channels:
-//     WM = 1: tile 96 frames x 512 channels   (c_out > 256)
-//     WM = 2: tile 192 frames x 256 channels  (c_out <= 256)
-//   96-frame granules: 751 frames (15 s of audio after the stride-2 stem) = 8 x 96 = 4 x 192 with 2 % waste, and
-//   64 clips give 512 / 256 tiles = exactly 2 / 1 per CU.
-//   depthwise of a stage: wave w runs channels [8w, 8w+8) for all TT frames: 16 MFMA blocks = 8 channels x 2 segments,
-//   4 lane runs of TT/8 frames per segment, M = TT/32 steps of 4 frames per run; the lane's input window slides through
-//   registers (3 new 8-byte LDS reads per pass of 3 k-steps).
-// Prefetch streams, each with one issue site per loop body: X (input rows, one stage ahead -> wave-private LDS rows),
-// T (tap fragments of the next depthwise stage, loaded when the current one is done), I (identity rows of the residual
-// stages), W (weight fragments, 2-deep ring).
+// helpers of the split kernel
 // ======================================================================================================
 // compile-time loop: f(std::integral_constant<int, I>) for I in [A, B)
 template <int A, int B, class F>
@@ -733,44 +711,6 @@ __device__ __forceinline__ void vm_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15) | ((n >> 4) << 14));
   asm volatile("" ::: "memory");
 }
-
-// Tap DMA bookkeeping of the pipelined kernel.  The hardware retires vector-memory operations in order, so "the DMA of
-// quad q has landed" == "at most (operations issued after it) are still outstanding".  A main body issues, in program
-// order (the sched barriers pin it):
-//   [taps of passes < dist read] ks0: NT | passes [0, p1) | ks1: NT | passes [p1, p2) | ks2: NT | passes [p2, npass) | rows: XJ | ks3: NT
-// and at the end of pass i one DMA per tap quad whose last k-step that pass consumed (ascending quad order); the taps of
-// pass i + dist are read at the start of pass i.  wait_count() walks that list.  Residual bodies and epilogues between
-// two main bodies only add operations, which makes the waits stricter, never weaker.
-struct TapSched {
-  int npass, p1, p2, xj, nt, nk, nkq, dist;
-  constexpr int last_pass(int q) const { return ((4 * q + 3 < nk ? 4 * q + 3 : nk - 1)) / 3; }
-  // walk one body: position (operations issued before it) of the DMA of quad `q` (want_dma) or of the read point of the
-  // taps of pass `q` (!want_dma); q == -1 returns the operations per body
-  constexpr int walk(bool want_dma, int q) const {
-    int n = 0;
-    if (!want_dma && q >= 0 && q < dist) return 0;          // read in dw_begin, ahead of ks0
-    n += nt;                                                  // ks0
-    for (int i = 0; i < npass; ++i) {
-      if (i == p1) n += nt;                                   // ks1
-      if (i == p2) n += nt;                                   // ks2
-      if (!want_dma && q == i + dist) return n;
-      for (int r = 0; r < nkq; ++r)
-        if (last_pass(r) == i) {
-          if (want_dma && r == q) return n;
-          ++n;
-        }
-    }
-    if (p1 >= npass) n += nt;
-    if (p2 >= npass) n += nt;
-    return n + xj + nt;                                       // rows, ks3
-  }
-  // counter value that guarantees the taps of pass `for_pass` have landed when they are read
-  constexpr int wait_count(int for_pass) const {
-    int kmax = 3 * for_pass + 2;
-    if (kmax > nk - 1) kmax = nk - 1;
-    return (walk(true, -1) - 1 - walk(true, kmax / 4)) + walk(false, for_pass);
-  }
-};
 
 // position of a tile in the (clip, output-channel split, time tile) grid, advanced by the grid stride without divisions
 struct TilePos {
@@ -801,456 +741,18 @@ struct TilePos {
   }
 };
 
-template <int NPASS, int XJ, int MT, int WM>
-__global__ __launch_bounds__(512, 2) void tcs_pipe_kernel(const TcsArgs a) {
-  constexpr int WN = 8 / WM, NT = 2;
-  constexpr int FW = 32 * MT;                     // frames of a wave tile
-  constexpr int TT = FW * WM;
-  constexpr int M = TT / 32, RUN = TT / 8, SEG = TT / 2;
-  constexpr int NK = NPASS * NKP;
-  constexpr int NP = NK + M - 1;                  // 4-sample window groups a lane reads per stage
-  constexpr int ROWB = TT <= 128 ? 256 : 512;     // dwt row pitch: 16 / 32 swizzled 16-byte chunks
-  constexpr int TILEB = KC * ROWB;
-  constexpr int EP = FW * 2 + 24;                 // epilogue tile row pitch: 8 x odd bytes -> the 8-byte MFMA-layout writes of a half-wave hit 64 distinct banks
-  static_assert((EP / 8) % 2 == 1, "");
-  constexpr int IDJ = (TT + 63) / 64;
-  constexpr int NKQ = (NK + 3) / 4;               // tap fragments travel global -> LDS in quads of 4 k-steps (1 KiB per wave)
-  static_assert(RUN % 4 == 0, "lane runs are whole 4-frame steps");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const dwt = smem;                                   // [2][KC][ROWB]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* const priv = smem + 2 * TILEB + (size_t)wave * a.privb;   // staged input rows / epilogue tile (never live together)
-  char* const tapl = priv + a.privb - NKQ * 1024;                 // this wave's tap fragments of the running depthwise stage
-  const int n_main = a.c_in / KC;
-  const int n_res = a.c_res / KC;
-  const int n_stage = n_main + n_res;
-  const int tile_step = gridDim.x;
-  auto taddr = [](int c, int t) { return c * ROWB + ((((t >> 3) ^ ((c & 3) * 5))) << 4) + ((t & 7) << 1); };
-
-  // All global reads are raw buffer loads: descriptor + 32-bit lane offset (loop-invariant VGPR) + 32-bit scalar offset
-  // that carries the whole stream position.  No 64-bit address registers, no VALU pointer math, one s_add per advance.
-  constexpr int RSRC_FLAGS = 0x00020000;          // gfx9 raw buffer: 32-bit data format
-  auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
-  const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(a.x) - TS_GUARD_BYTES);   // offsets may reach into the front guard
-  // exact bound: the last quad of a stage over-reads up to 3 k-steps, out-of-range lanes must return 0 instead of faulting
-  const i32x4 rt = raw_rsrc(a.taps, (unsigned)n_main * (KC * 4 * NK * 4 * 2));
-  const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
-  const __amdgpu_buffer_rsrc_t rwm = rsrc(a.pw_w);
-  const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? a.res_w : a.pw_w);
-  auto ld16 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); };
-  auto ld8 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); };
-
-  // ---- depthwise-job lane geometry
-  const int r8 = lane >> 3, sub = lane & 7;        // staging: row r8 of the wave's 8 channels, 16-B groups sub + 8j
-  const int cl = (lane >> 2) & 7;                  // MFMA block -> channel 8*wave + cl ...
-  const int hh = lane >> 5;                        // ... and segment
-  const int q = lane & 3;
-  char* const xw = priv + ((size_t)r8 * a.xpitch + sub * 8) * 2;
-  const char* const xrow = priv + ((size_t)cl * a.xpitch + a.woff + hh * SEG + q * RUN) * 2;
-  int dw_out[M];                                   // 8-byte slots of the lane's 4-frame steps in the swizzled tile
-#pragma unroll
-  for (int m = 0; m < M; ++m) dw_out[m] = taddr(wave * 8 + cl, hh * SEG + q * RUN + 4 * m);
-  const int lane_x = ((wave * 8 + r8) * a.pitch_in + sub * 8) * 2;
-  // tap fragments [chunk][16-ch group][k][64 lanes][4]: this wave owns lanes [32 (wave & 1), +32) of group wave >> 1.
-  // DMA lane L fetches 16 bytes of k-step 4j + (L >> 4); in LDS the fragment of (k, lane t) lands at k * 256 + t * 8.
-  const int lane_t = (wave >> 1) * NK * 512 + (lane >> 4) * 512 + (wave & 1) * 256 + (lane & 15) * 16;
-  const char* const trow = tapl + (cl * 4 + q) * 8;
-  const int lane_i = ((wave * 8 + r8) * a.pitch_res + sub * 8) * 2;
-  const int id_out = taddr(wave * 8 + r8, sub * 8);
-  const int chunk_x = KC * a.pitch_in * 2;           // bytes
-  const int chunk_t = KC * 4 * NK * 4 * 2;
-  const int chunk_i = KC * a.pitch_res * 2;
-
-  // ---- pointwise-job lane geometry
-  const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
-  const int n_cot = (a.c_out + 31) >> 5;
-  const int h = lane >> 5;
-  const int gq = (lane >> 4) & 1;
-  const int q4 = (lane >> 2) & 3;
-  const int p4 = lane & 3;
-  int abase[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abase[mt] = taddr(8 * h + q4, wm * FW + 32 * mt + 16 * gq + 4 * p4);
-  const int rsub = lane >> 4, csub = lane & 15;    // epilogue read-back: 4 rows per instruction, 16-byte column csub
-  const unsigned floor2 = a.relu ? 0u : 0x80008000u;
-  const int lane_w = lane * 16;
-
-  // ---- X / T stream: next depthwise stage (runs on across tile boundaries; parks on its last tile at the end)
-  u32x4 X[XJ];
-  TilePos dwp;
-  dwp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-  int dw_tile = blockIdx.x, dw_chunk = 0;
-  auto x_origin = [&](const TilePos& p) { return (p.b * a.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
-  int x_soff = x_origin(dwp);
-  auto dw_issue = [&]() {            // X <- rows of the next depthwise stage
-#pragma unroll
-    for (int j = 0; j < XJ; ++j) X[j] = ld16(rx, lane_x + j * 128, x_soff);
-    if (++dw_chunk == n_main) {      // once per tile: next tile (or park on this one)
-      dw_chunk = 0;
-      if (dw_tile + tile_step < a.n_tiles) { dw_tile += tile_step; dwp.advance(a.n_tt, a.n_z); }
-      x_soff = x_origin(dwp);
-    } else {
-      x_soff += chunk_x;
-    }
-  };
-  // ---- T stream: tap fragments of the NEXT depthwise stage, DMA'd quad by quad into the slots the running stage has
-  //      finished with (buffer_load ... lds: no VGPR round trip, 1/4 of the vector-memory instructions of register taps)
-  constexpr int P1 = (NPASS + 2) / 3, P2 = (2 * NPASS + 2) / 3;
-  int t_next = (n_main > 1 ? 1 : 0) * chunk_t;      // scalar byte offset of the next stage's fragments
-  auto tap_dma = [&](int jq, int soff, float after = 0.f) {
-    lds_dma16(rt, tapl + jq * 1024, lane_t, soff + jq * 2048, after);
-  };
-  auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
-  // ---- I stream: next identity (residual) stage
-  u32x4 I[IDJ];
-  TilePos idp;
-  idp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-  int id_tile = blockIdx.x, id_s = 0;
-  auto i_origin = [&](const TilePos& p) { return (p.b * a.c_res * a.pitch_res + p.tt * TT) * 2; };
-  int i_soff = i_origin(idp);
-  auto id_issue = [&]() {
-#pragma unroll
-    for (int j = 0; j < IDJ; ++j) I[j] = ld16(ri, lane_i + j * 128, i_soff);
-    if (++id_s == n_res) {
-      id_s = 0;
-      if (id_tile + tile_step < a.n_tiles) { id_tile += tile_step; idp.advance(a.n_tt, a.n_z); }
-      i_soff = i_origin(idp);
-    } else {
-      i_soff += chunk_i;
-    }
-  };
-  // ---- W stream: weight fragments of the current (wc) and the next (wn) stage of this wave's output-channel tiles
-  constexpr int RING = TS_PIPE_RING;              // 4: every weight fragment is requested a whole stage before its MFMA
-  s16x8 ring[RING][NT];
-  TilePos wp;
-  wp.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-  int w_tile = blockIdx.x, w_s = 0;
-  __amdgpu_buffer_rsrc_t rwc = rwm, rwn = rwm;
-  int wc_soff[NT], wn_soff[NT];
-  auto w_seek = [&](bool res) {      // wn <- first main / first residual stage of tile position wp
-    rwn = res ? rwr : rwm;
-    const int kt = res ? a.kt_res : a.kt_main;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int cot = (wp.z * WN + wn) * NT + nt;
-      wn_soff[nt] = (cot < n_cot ? cot : n_cot - 1) * kt * 1024;
-    }
-  };
-  auto w_advance = [&]() {           // wc <- wn; wn <- the stage after it
-    rwc = rwn;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wc_soff[nt] = wn_soff[nt];
-    ++w_s;
-    if (w_s == n_stage) {            // once per tile
-      w_s = 0;
-      if (w_tile + tile_step < a.n_tiles) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
-      w_seek(false);
-    } else if (w_s == n_main) {
-      w_seek(true);
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wn_soff[nt] += 4096;
-    }
-  };
-  auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      slot[nt] = __builtin_bit_cast(s16x8, next ? ld16(rwn, lane_w + ks * 1024, wn_soff[nt]) : ld16(rwc, lane_w + ks * 1024, wc_soff[nt]));
-  };
-
-  unsigned gs = 0;                 // stages done by this workgroup (dwt buffer parity)
-  // ---- depthwise job pieces
-  s16x4 P[NP];
-  u32x2 T[NK];
-  f32x4 d[M];
-  constexpr TapSched TS{NPASS, (NPASS + 2) / 3, (2 * NPASS + 2) / 3, XJ, NT, NK, NKQ, TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS};
-  auto tap_drain = [&]() { vm_wait<NT>(); };   // every tap DMA of the previous stage was issued before the NT weight loads of its last k-step
-  auto xs_write = [&]() {
-#pragma unroll
-    for (int j = 0; j < XJ; ++j) {
-      u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 128);
-      d2[0] = u32x2{X[j][0], X[j][1]};
-      d2[1] = u32x2{X[j][2], X[j][3]};
-    }
-  };
-  auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
-  auto tap_load = [&](int kk) { T[kk] = *reinterpret_cast<const u32x2*>(trow + kk * 256); };
-  // operand prefetch distance in passes: an LDS round trip with all 8 waves reading costs about 3 passes of MFMA time
-  constexpr int WD = TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS;
-  auto dw_begin = [&]() {
-#pragma unroll
-    for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < M - 1 + NKP * WD; ++u) win_load(u);
-    vm_wait<TS.wait_count(WD - 1)>();
-#pragma unroll
-    for (int kk = 0; kk < NKP * WD; ++kk) tap_load(kk);
-  };
-  auto dw_pass = [&](auto pc) {
-    constexpr int p = decltype(pc)::value;
-    if constexpr (p + WD < NPASS) {
-#pragma unroll
-      for (int u = 0; u < NKP; ++u) win_load((p + WD) * NKP + M - 1 + u);
-      vm_wait<TS.wait_count(p + WD)>();
-#pragma unroll
-      for (int u = 0; u < NKP; ++u) tap_load((p + WD) * NKP + u);
-    }
-#pragma unroll
-    for (int kk = 0; kk < NKP; ++kk)
-#pragma unroll
-      for (int m = 0; m < M; ++m)
-        d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m], d[m], 0, 0, 0);
-    // quads whose last k-step this pass consumed are refilled with the next stage's fragments (the MFMAs above could
-    // only issue once their tap reads had returned, so the slots are no longer being read)
-#pragma unroll
-    for (int jq = 0; jq < NKQ; ++jq)
-      if (TS.last_pass(jq) == p) tap_dma(jq, t_next, d[M - 1][3]);      // behind the pass's last MFMA
-  };
-  auto dw_store = [&](char* dst) {
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-      *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
-  };
-
-  // ---- pointwise job pieces
-  f32x16 acc[MT][NT];
-  float bnext[NT];
-  auto bias_fetch = [&](const TilePos& p) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = ((p.z * WN + wn) * NT + nt) * 32 + (lane & 31);
-      bnext[nt] = a.bias[col < a.c_out ? col : 0];
-    }
-  };
-  s16x8 af[MT], afB[MT];            // afB: second buffer of the residual stages (no depthwise to hide the read behind)
-  auto read_a = [&](const char* src, int ks, s16x8 (&f)[MT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB + 4 * ROWB));
-      f[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-  };
-  // k-step ks of the current stage; its ring slot is refilled with the k-step RING further on (of the next stage when
-  // that is past this one's four)
-  auto mfma_ks = [&](int ks, const s16x8 (&f)[MT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
-    load_w(ring[ks % RING], ks + RING >= 4, (ks + RING) & 3);
-  };
-
-#ifdef TS_NO_SB
-#define SB() do { } while (0)
-#else
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#endif
-  // pointwise stage gs  ||  depthwise of the next main stage (of the next tile after the last stage of a tile).
-  // SB pins the interleaving: left alone, the scheduler hoists every LDS read to the top of the block and spills.
-  // Two jobs per stage, interleaved in one instruction stream: pointwise GEMM of stage gs out of dwt[gs & 1] and the
-  // depthwise FIR of the next main stage (of the next tile after the last stage of a tile) into the other buffer.
-  // SB pins the order: left alone, the scheduler hoists every LDS read to the top of the block and spills.
-  auto body_main = [&]() {
-    const char* const src = dwt + (gs & 1) * TILEB;
-    char* const dst = dwt + ((gs + 1) & 1) * TILEB;
-    constexpr int P1 = (NPASS + 2) / 3, P2 = (2 * NPASS + 2) / 3;
-    PSTAMP(4 * gs);
-#if !defined(TS_EXP) || !(TS_EXP & 1)     // diagnostic builds: TS_EXP & 1 drops the depthwise job, & 2 the pointwise job
-#define DWJ(x) x
-#else
-#define DWJ(x)
-#endif
-#if !defined(TS_EXP) || !(TS_EXP & 2)
-#define PWJ(x) x
-#else
-#define PWJ(x)
-#endif
-    DWJ(xs_write();)
-    PWJ(read_a(src, 0, af);)
-    DWJ(dw_begin();)
-    SB();
-    PWJ(mfma_ks(0, af);)
-    SB();
-    PWJ(read_a(src, 1, af);)
-    static_for<0, P1>([&](auto pc) { DWJ(dw_pass(pc);) SB(); });
-    PWJ(mfma_ks(1, af);)
-    SB();
-    PWJ(read_a(src, 2, af);)
-    static_for<P1, P2>([&](auto pc) { DWJ(dw_pass(pc);) SB(); });
-    PWJ(mfma_ks(2, af);)
-    SB();
-    PWJ(read_a(src, 3, af);)
-    static_for<P2, NPASS>([&](auto pc) { DWJ(dw_pass(pc);) SB(); });
-    DWJ(dw_issue();)
-    PWJ(mfma_ks(3, af);)
-    SB();
-    DWJ(dw_store(dst); tap_advance();)
-    w_advance();
-#undef DWJ
-#undef PWJ
-    PSTAMP(4 * gs + 1);
-    stage_barrier();
-    PSTAMP(4 * gs + 2);
-    ++gs;
-  };
-  // pointwise stage gs  ||  copy of the next residual stage's block-input rows
-  auto body_res = [&]() {
-    const char* const src = dwt + (gs & 1) * TILEB;
-    char* const dst = dwt + ((gs + 1) & 1) * TILEB;
-#pragma unroll
-    for (int j = 0; j < IDJ; ++j) *reinterpret_cast<u32x4*>(dst + (id_out ^ (j << 7))) = I[j];
-    PSTAMP(4 * gs);
-    id_issue();
-    read_a(src, 0, af);
-    read_a(src, 1, afB);
-    SB();
-    mfma_ks(0, af);
-    read_a(src, 2, af);
-    SB();
-    mfma_ks(1, afB);
-    read_a(src, 3, afB);
-    SB();
-    mfma_ks(2, af);
-    SB();
-    mfma_ks(3, afB);
-    w_advance();
-    PSTAMP(4 * gs + 1);
-    stage_barrier();
-    PSTAMP(4 * gs + 2);
-    ++gs;
-  };
-
-  // ---- prologue: depthwise of the first stage alone
-  TilePos pos;
-  pos.init(blockIdx.x, tile_step, a.n_tt, a.n_z);
-  dw_issue();
-#pragma unroll
-  for (int jq = 0; jq < NKQ; ++jq) tap_dma(jq, 0);
-  if (n_res) id_issue();
-  w_seek(false);
-  w_advance();
-#pragma unroll
-  for (int r = 0; r < RING; ++r) load_w(ring[r], false, r);
-  bias_fetch(pos);
-  {
-    vm_wait<0>();                                  // first rows and taps are in
-    xs_write();
-    dw_begin();
-    dw_issue();
-    static_for<0, NPASS>([&](auto pc) { dw_pass(pc); SB(); });
-    dw_store(dwt);
-    tap_advance();
-    vm_wait<0>();                                  // the in-body waits count on a full body's worth of operations behind each DMA
-    stage_barrier();
-  }
-
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += tile_step) {
-    const int b = pos.b, t0 = pos.tt * TT;
-    const int cot0 = (pos.z * WN + wn) * NT;
-    const int len_b = a.zero_tail ? a.len_in[b] : 0;        // fetched now, used by the epilogue
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
-
-    for (int s = 0; s + 1 < n_main; ++s) body_main();
-    for (int s = 0; s < n_res; ++s) body_res();
-    body_main();
-    PSTAMP(4 * (gs - 1) + 3);
-
-    // ---- epilogue: bias of the next tile first, then bf16 pack + ReLU on packed pairs, transposed through the
-    //      wave-private LDS region.  The tap DMAs are drained first: after the stores below, a counter wait would also
-    //      have to wait for the stores.
-    tap_drain();
-    pos.advance_if(tile + tile_step < a.n_tiles, a.n_tt, a.n_z);
-    bias_fetch(pos);
-    unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
-    int len_out = 0x7fffffff;
-    if (a.zero_tail) len_out = conv_len(len_b, a.kernel, 1, a.padding, a.dilation);
-    const int tw = t0 + wm * FW;
-    const bool partial = tw + FW > len_out;
-    u32x4 keep = u32x4{~0u, ~0u, ~0u, ~0u};                 // tail zeroing is applied to the 16-byte vectors on their way out
-    if (partial) keep = keep_first(keep, len_out - (tw + csub * 8));
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-    if (tile == (int)blockIdx.x) PSTAMP(100);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int cob = (cot0 + nt) * 32;
-      char* const row = priv + (size_t)(lane & 31) * EP + 8 * h;
-      const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
-              pack_bf16_settled(acc[mt][nt][4 * rg + 0], acc[mt][nt][4 * rg + 1])), f2));
-          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
-              pack_bf16_settled(acc[mt][nt][4 * rg + 2], acc[mt][nt][4 * rg + 3])), f2));
-          *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = u32x2{lo, hi};
-        }
-      }
-      if (tile == (int)blockIdx.x) PSTAMP(101 + 2 * nt);
-      if (csub < FW / 8) {
-        unsigned short* const yrow = yb + (size_t)(b * a.c_out + cob + rsub) * a.pitch_out + tw + csub * 8;
-        const char* const prow = priv + (size_t)rsub * EP + csub * 16;
-        u32x4 v[8];                                           // all reads first: one LDS round trip per output-channel tile
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * i * EP);   // rows are only 8-byte aligned
-          v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (partial) v[i] &= keep;
-          if (cob + 4 * i + rsub < a.c_out) *reinterpret_cast<u32x4*>(yrow + (size_t)(4 * i) * a.pitch_out) = v[i];
-        }
-      }
-      if (tile == (int)blockIdx.x) PSTAMP(102 + 2 * nt);
-    }
-  }
-#undef SB
-}
-
-template <int NPASS, int XJ, int MT, int WM>
-static int launch_pipe(TcsArgs& a, hipStream_t stream) {
-  constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);
-  constexpr int ROWB = TT <= 128 ? 256 : 512;
-  a.n_tt = (a.t_out + TT - 1) / TT;
-  a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
-  a.n_tiles = a.batch * a.n_tt * a.n_z;
-  const int xs_b = 8 * a.xpitch * 2, ep_b = 32 * (FW * 2 + 24);
-  a.privb = round_up(xs_b > ep_b ? xs_b : ep_b, 16) + (NPASS * NKP + 3) / 4 * 1024;
-  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * a.privb;
-  if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = tcs_pipe_kernel<NPASS, XJ, MT, WM>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  const int n_cu = cu_count();
-  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
-  return hip_status(hipGetLastError());
-}
-
 // ======================================================================================================
 // Split kernel: 12 waves = 8 consumer waves (pointwise GEMM, accumulators) + 4 producer waves (depthwise FIR).
 //
-// In the pipelined kernel above the two jobs share an instruction stream and measurably do not overlap (skeleton +
-// pointwise + depthwise times add up).  Here they are different waves: every SIMD runs two consumer waves and one
+// When the two jobs share an instruction stream they measurably do not overlap (skeleton + pointwise + depthwise times add
+// up: round 1's pipelined kernel).  Here they are different waves: every SIMD runs two consumer waves and one
 // producer wave, so the LDS-heavy depthwise stream issues while the consumers sit in their MFMA bursts.  Three waves
 // per SIMD leave 168 VGPRs each: enough for the 96 accumulators + ring + A fragments of a consumer, and for the
 // 16-channel windows of a producer.
 //   producer p (wave 8 + p): channels [16p, 16p + 16) of the stage, 16 MFMA blocks = 16 channels, 4 lane runs of TT/4
 //     frames, M = TT/16 steps per run (each tap fragment read feeds M MFMAs: 6 or 12, against 3 or 6 above);
 //     rows global -> registers (a stage ahead) -> wave-private LDS rows; taps global -> LDS by DMA, 2 k-steps per KiB.
-//   consumer w: output tile 96 frames x 64 channels, exactly the pointwise job of the pipelined kernel.
+//   consumer w: output tile 96 frames x 64 channels.
 //   iteration i: producers write stage i into dwt[i & 1], consumers read stage i-1 out of dwt[(i-1) & 1]; one barrier.
 //   The epilogue runs after the barrier that ends the last stage of a tile, so the producers work through it.
 // ======================================================================================================
@@ -1347,9 +849,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     int x_soff = x_origin(dwp);
     auto dw_issue = [&]() {
 #pragma unroll
-#if defined(TS_EXP) && (TS_EXP & 128)           // timing experiment: the input rows are fetched once (wrong results)
-      if (gs == 0)
-#endif
       for (int j = 0; j < XP; ++j) X[j] = ld16(rx, lane_x + j * 64, x_soff);
       if (++dw_chunk == n_main) {
         dw_chunk = 0;
@@ -1361,9 +860,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     };
     int t_next = (n_main > 1 ? 1 : 0) * chunk_t;
     auto tap_dma = [&](int h, int soff, float after = 0.f) {
-#if defined(TS_EXP) && (TS_EXP & 64)            // timing experiment: taps fetched once, never refilled (wrong results)
-      if (gs != 0) return;
-#endif
       lds_dma16(rt, tapl + h * 1024, lane_t, soff + h * 1024, after);
     };
     auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
@@ -1460,7 +956,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         // Everything this wave has in flight is a stage old except the last tap DMAs: drain it all.  (Measured: DMA-to-LDS
         // loads and register loads retire out of order with respect to each other, so a counted vmcnt cannot separate them;
         // hipcc's own waits for the row loads assume in-order retirement and are not enough once DMAs are in the queue.)
-#if !defined(TS_EXP) || !(TS_EXP & 1)          // diagnostic builds: TS_EXP & 1 drops the producers' work, & 2 the consumers'
         PSTAMP(8 * gs);
         vm_wait<0>();
         PSTAMP(8 * gs + 1);
@@ -1490,7 +985,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         }
         tap_advance();
         PSTAMP(8 * gs + 5);
-#endif
         stage_barrier();
         PSTAMP(8 * gs + 6);
       }
@@ -1563,9 +1057,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     }
   };
   auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
-#if defined(TS_EXP) && (TS_EXP & 512)           // timing experiment: the weight fragments are never reloaded (wrong results)
-    if (gs != 0) return;
-#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
       slot[nt] = __builtin_bit_cast(s16x8, next ? ld16(rwn, lane_w + ks * 1024, wn_soff[nt]) : ld16(rwc, lane_w + ks * 1024, wc_soff[nt]));
@@ -1581,9 +1072,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   };
   s16x8 af[MT], afB[MT];
   auto read_a = [&](const char* src, int ks, s16x8 (&f)[MT]) {
-#if defined(TS_EXP) && (TS_EXP & 256)           // timing experiment: the A fragments are read once (wrong results)
-    if (gs != 0) return;
-#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB));
@@ -1620,21 +1108,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
     for (int s = 0; s < n_stage; ++s, ++gs) {
       const char* const src = dwt + (gs & 1) * TILEB;
-#if defined(TS_EXP) && (TS_EXP & 4)          // timing experiment only (reads the next tile before it is complete)
-      if (s == 0) { read_a(src, 0, af); read_a(src, 1, afB); }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(0, af);
-      read_a(src, 2, af);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(1, afB);
-      read_a(src, 3, afB);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(2, af);
-      read_a(dwt + ((gs + 1) & 1) * TILEB, 0, af);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(3, afB);
-      read_a(dwt + ((gs + 1) & 1) * TILEB, 1, afB);
-#elif !defined(TS_EXP) || !(TS_EXP & 2)
       PSTAMP(8 * gs);
       read_a(src, 0, af);
       read_a(src, 1, afB);
@@ -1648,7 +1121,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       mfma_ks(2, af);
       __builtin_amdgcn_sched_barrier(0);
       mfma_ks(3, afB);
-#endif
       w_advance();
       PSTAMP(8 * gs + 1);
       stage_barrier();
@@ -1702,9 +1174,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #pragma unroll
           for (int i = 0; i < ER / 4; ++i) {
             if (partial) v[i] &= keep;
-#if defined(TS_EXP) && (TS_EXP & 8)            // timing experiment: the epilogue without its global stores
-            if (a.c_out < 0)
-#endif
             if (cob + half * ER + 4 * i + rsub < a.c_out) *reinterpret_cast<u32x4*>(yrow + (size_t)(4 * i) * a.pitch_out) = v[i];
           }
         }
@@ -1812,8 +1281,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     if (d->flags & TS_TCS_TAPS_PHASE) {
       // dilation 2 as two interleaved dilation-1 sequences; dw_taps are packed for (K, stride 1, dilation 1, padding / 2)
       const bool ok = (d->flags & TS_TCS_IN_TAILZERO) && (d->flags & TS_TCS_OUT_ZERO_TAIL) && d->stride == 1 && d->dilation == 2 &&
-                      d->padding % 2 == 0 && d->c_in % KC == 0 && d->c_res == 0 && round_up(d->c_out, 32) > 256 &&
-                      getenv("TS_NO_SPLIT") == nullptr;
+                      d->padding % 2 == 0 && d->c_in % KC == 0 && d->c_res == 0 && round_up(d->c_out, 32) > 256;
       if (!ok) return TS_EUNSUPPORTED;
       TcsArgs w = a;
       w.padl8 = 2 * round_up(d->padding / 2, 4);      // frames staged before the tile: even, so staged parity == frame parity
@@ -1834,8 +1302,8 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     a.xpitch = a.xe + 4;                              // row pitch == 8 (mod 16) bytes: conflict-free window reads
     const int xj = a.xe / 64;
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
-    if (tz && d->stride == 1 && a.npass <= 7 && getenv("TS_NO_PIPE") == nullptr) {
-      // pipelined all-waves kernel: 96-frame granules, its own window geometry
+    if (tz && d->stride == 1 && a.npass <= 7) {
+      // split kernel: 96-frame granules, its own window geometry
       TcsArgs w = a;
       const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;
       const int TTp = 96 * WM;
@@ -1846,9 +1314,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       const bool fits = (n_ttp - 1) * TTp - w.padl8 + w.xe <= d->pitch_in && d->pitch_out >= n_ttp * TTp &&
                         (d->c_res == 0 || d->pitch_res >= (n_ttp - 1) * TTp + round_up(TTp, 64));
       if (fits) {
-        static const bool use_split = getenv("TS_NO_SPLIT") == nullptr;      // diagnostic switch: the single-stream pipelined kernel
-#define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) \
-          return use_split ? launch_split<NP_, XJ_, 3, WM_>(w, stream) : launch_pipe<NP_, XJ_, 3, WM_>(w, stream);
+#define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) return launch_split<NP_, XJ_, 3, WM_>(w, stream);
         TS_PIPE(3, 4, 2) TS_PIPE(4, 4, 2) TS_PIPE(5, 3, 1) TS_PIPE(6, 3, 1) TS_PIPE(7, 3, 1)      /* QuartzNet: K 33..75 */
         TS_PIPE(2, 2, 1) TS_PIPE(3, 3, 1) TS_PIPE(4, 3, 1) TS_PIPE(2, 4, 2)                         /* Citrinet: K 11..41 */
 #undef TS_PIPE
@@ -1884,7 +1350,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     // without a depthwise stage a tail-zero input needs no mask whether or not the output tail is zeroed: frames >= length
     // come out as relu(shift), which is what the reference computes from its masked input (quirk A2)
     const bool tz_in = (d->flags & TS_TCS_IN_TAILZERO) && d->c_in % KC == 0;
-    if (tz_in && d->c_res == 0 && getenv("TS_NO_SPLIT") == nullptr) {
+    if (tz_in && d->c_res == 0) {
       // pointwise only: the split kernel with identity stages only (the layer's input plays the residual input's role)
       TcsArgs w = a;
       const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;

@@ -237,13 +237,14 @@ class _FusedBlockBase(nn.Module):
         out = T.AddRelu.apply(h, r_out)
         return T.dropout(out, out_drop.p, out_drop.training), out_lengths
 
-    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=0):
+    def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=None):
         """Run the block's launches.  `internal=True` (set by the encoder for every block but the last): the block
         output is never shown to the caller, so it is written into a library-owned arena buffer with frames >=
         length zeroed (tail-zero invariant) and the next block runs mask-free.  The last sub-block of a
         caller-visible block keeps the reference's values beyond the length (quirk A2) in a fresh buffer."""
         _t.require_gpu(x, type(self).__name__)
         self._check_eval()
+        slot = (id(self), 0) if slot is None else slot          # arena buffers are owned by the calling encoder, or by this block
         layers = self._cache.get(self._params(), self._compile)
         was_internal = _t.is_internal(x)
         xi = x if was_internal else _t.pack(x, lengths, slot=("blk", id(self)))
@@ -329,7 +330,7 @@ class EncoderSequential(MultiSequential):
         blocks = list(self.children())
         for i, blk in enumerate(blocks):
             if isinstance(blk, _FusedBlockBase):
-                x, audio_lengths, _ = blk._run_fused(x, audio_lengths, internal=i < len(blocks) - 1, slot=i % 2)
+                x, audio_lengths, _ = blk._run_fused(x, audio_lengths, internal=i < len(blocks) - 1, slot=(id(self), i % 2))
             else:
                 x, audio_lengths = blk(x, audio_lengths)
         return x, audio_lengths

@@ -57,9 +57,13 @@ def alloc(b: int, c: int, t: int, device, dtype=torch.bfloat16) -> torch.Tensor:
 
 
 def arena(slot, b: int, c: int, t: int, device) -> torch.Tensor:
-    """Library-owned, zero-initialised, guarded bf16 buffer [B, C, pitch] for (slot, shape); reused across calls."""
+    """Library-owned, zero-initialised, guarded bf16 buffer [B, C, pitch] for (slot, shape, device, STREAM); reused across calls.
+    `slot` names the owner (callers put id(module) into it), so two modules of equal shape never share scratch, and the
+    current stream is part of the key, so the same module driven from two streams (or eagerly and under graph capture) gets
+    separate buffers instead of racing on one."""
     pitch = _lib.time_pitch(t)
-    key = (slot, b, c, pitch, str(device))
+    dev = torch.device(device)
+    key = (slot, b, c, pitch, str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
     flat = _ARENA.get(key)
     if flat is None:
         flat = torch.zeros(b * c * pitch + 2 * _GUARD, dtype=torch.bfloat16, device=device)
