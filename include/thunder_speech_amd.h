@@ -198,6 +198,11 @@ int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * words (param, grad, exp_avg, exp_avg_sq pointers, element count); max_numel = the largest element count; one shared step. */
 int ts_adamw_multi_step(const void* table, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int32_t step, void* stream);
+/* Wire format of the data-parallel gradient exchange (what Lightning DDP's all-reduce moves for the reference, module.py:102-127):
+ * pack: wire[i] = bf16(grad[i] * scale) (scale = 1 / world, so the collective's SUM is the mean); unpack: grad[i] = f32(wire[i]).
+ * Both pointers 16-byte aligned; the collective itself is RCCL's (torch.distributed). */
+int ts_grad_wire_pack(const float* grad, void* wire_bf16, int64_t n, float scale, void* stream);
+int ts_grad_wire_unpack(const void* wire_bf16, float* grad, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-mode encoder ops (fine-tuning with the encoder unfrozen), first unfused version: fp32 activations in the

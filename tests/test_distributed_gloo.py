@@ -96,3 +96,113 @@ def test_two_rank_gradient_allreduce_averages_in_buckets():
     assert n_big == 1 and n_small > 1 and untouched
     want = [1.5 * (i + 1) for i in range(4)]                   # mean of (rank + 1) * (i + 1) over ranks 0, 1
     assert small == pytest.approx(want) and big == pytest.approx(want)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GradientSync: flat buffer + hooks + buckets (the overlapped exchange of SURVEY 8e), and the statement it has to satisfy:
+# n ranks x local batch b == one process averaging the gradients of n independent b-batches (per-rank BatchNorm statistics,
+# quirk A4; the reference's DDP test is tests/quartznet/test_module_qn.py:33-53).
+# ----------------------------------------------------------------------------------------------------------------------
+def _tiny_model_state():
+    """A 2-block QuartzNet-style stack + decoder evaluated by the ORACLE (CPU, train-mode BatchNorm): the gloo test needs a
+    model that runs without a GPU; the product modules refuse CPU tensors by design."""
+    from oracle import tcs as otcs
+    arch = [otcs.BlockSpec(8, 16, repeat=2, kernel=5), otcs.BlockSpec(16, 16, repeat=1, kernel=3, residual=False)]
+    sd = otcs.synth_encoder_state(arch, seed=3)
+    dsd = otcs.synth_decoder_state(16, 6, seed=4)
+    return arch, sd, dsd
+
+
+def _tiny_loss(arch, params, buffers, dparams, rank_seed):
+    from oracle import tcs as otcs
+    g = torch.Generator().manual_seed(100 + rank_seed)
+    x = torch.randn(3, 8, 40, generator=g)
+    lengths = torch.tensor([40, 33, 21])
+    sd = dict(buffers)
+    sd.update(params)
+    h, hl = x, lengths
+    for i, spec in enumerate(arch):
+        h, hl = otcs.block_forward(spec, sd, f"{i}.", h, hl, training=True)          # batch statistics of THIS rank's clips only
+    logits = otcs.conv1d_decoder_forward(dparams, h)
+    targets = torch.randint(0, 5, (3, 4), generator=g)
+    return torch.nn.functional.ctc_loss(logits.permute(2, 0, 1).log_softmax(2), targets, hl.long(), torch.tensor([4, 3, 2]), blank=5,
+                                        reduction="mean", zero_infinity=True)
+
+
+def _split(sd):
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    buffers = {k: v.clone() for k, v in sd.items() if k not in params}
+    return params, buffers
+
+
+def _sync_worker(rank, world, port, out):
+    from thunder_speech_amd.parallel import GradientSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        arch, sd, dsd = _tiny_model_state()
+        params, buffers = _split(sd)
+        dparams = {k: torch.nn.Parameter(v.clone()) for k, v in dsd.items()}
+        every = list(params.values()) + list(dparams.values())
+        sync = GradientSync(every, bucket_bytes=2048)                 # several buckets
+        opt = torch.optim.AdamW(every, lr=1e-2)
+        launched_during_backward = []
+        for step in range(2):
+            sync.zero_grad()
+            loss = _tiny_loss(arch, params, buffers, dparams, rank + 10 * step)
+            loss.backward()
+            launched_during_backward.append(sum(sync._launched))         # buckets already exchanged by the hooks, before finish()
+            sync.finish()
+            opt.step()
+        dist.barrier()
+        out.put((rank, {k: v.detach().numpy().copy() for k, v in list(params.items()) + [("dec." + k, v) for k, v in dparams.items()]},
+                 len(sync.buckets), launched_during_backward, sync.n_collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_equals_one_process_averaging_two_independent_batches():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict()
+    for _ in range(2):
+        rank, state, n_buckets, launched, n_coll = out.get(timeout=300)
+        results[rank] = (state, n_buckets, launched, n_coll)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single process: two independent local batches per step (each with its OWN BatchNorm statistics), gradients averaged
+    torch.set_num_threads(1)
+    arch, sd, dsd = _tiny_model_state()
+    params, buffers = _split(sd)
+    dparams = {k: torch.nn.Parameter(v.clone()) for k, v in dsd.items()}
+    every = list(params.values()) + list(dparams.values())
+    opt = torch.optim.AdamW(every, lr=1e-2)
+    for step in range(2):
+        grads = [torch.zeros_like(p) for p in every]
+        for rank in range(2):
+            for p in every:
+                p.grad = None
+            _tiny_loss(arch, params, dict(buffers), dparams, rank + 10 * step).backward()
+            for g, p in zip(grads, every):
+                g += p.grad / 2
+        for g, p in zip(grads, every):
+            p.grad = g
+        opt.step()
+    want = {k: v.detach() for k, v in list(params.items()) + [("dec." + k, v) for k, v in dparams.items()]}
+    for rank in (0, 1):
+        state, n_buckets, launched, n_coll = results[rank]
+        assert n_buckets > 2 and n_coll == 2 * n_buckets                     # one all-reduce per bucket per step (gloo path)
+        assert all(n == n_buckets for n in launched)                         # every bucket went out from a hook, during backward
+        for k, v in want.items():
+            got = torch.from_numpy(state[k])
+            assert torch.allclose(got, v, rtol=1e-5, atol=1e-6), (rank, k, float((got - v).abs().max()))
+    for k in want:                                                           # replicas stay bit-identical
+        assert (results[0][0][k] == results[1][0][k]).all(), k

@@ -387,3 +387,38 @@ def test_ctc_concatenated_targets_and_wild_ids(golden):
                                        reduction="none", zero_infinity=True)
     want = float((per / tl[keep]).sum() / 3)
     assert abs(float(c) - want) < 1e-4 and float(lg.grad[1].abs().max()) == 0.0 and torch.isfinite(lg.grad).all()
+
+
+def test_gradient_sync_on_the_gpu_flat_views_and_wire_format():
+    """parallel.GradientSync on one GPU: gradients accumulate into the flat buffer through the .grad views, FusedAdamW consumes the
+    views, and the bf16 wire kernels round-trip to bf16(grad / world)."""
+    from thunder_speech_amd import _lib
+    from thunder_speech_amd.optim import FusedAdamW
+    from thunder_speech_amd.parallel import GradientSync
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in ((29, 64, 1), (29,), (5, 7), (1003,), (256, 256, 1), (256, 1, 33), (256,), (256,), (512, 256, 1))]
+    sync = GradientSync(ps, bucket_bytes=8192)
+    assert len(sync.buckets) >= 3 and sync.flat.is_cuda
+    opt, ref = FusedAdamW(ps, lr=1e-2), None
+    ps_ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt_ref = torch.optim.AdamW(ps_ref, lr=1e-2)
+    for step in range(3):
+        sync.zero_grad()
+        sum((p * p).sum() * (i + 1) for i, p in enumerate(ps)).backward()
+        sync.finish()
+        for i, p in enumerate(ps):
+            assert p.grad.data_ptr() >= sync.flat.data_ptr() and torch.allclose(p.grad, 2 * (i + 1) * p.detach())
+        opt.step()
+        opt_ref.zero_grad()
+        sum((p * p).sum() * (i + 1) for i, p in enumerate(ps_ref)).backward()
+        opt_ref.step()
+    for p, q in zip(ps, ps_ref):
+        torch.testing.assert_close(p, q, rtol=2e-5, atol=2e-6)
+    g = torch.randn(100003, device=DEV)[:100000]                      # 16-byte aligned, length not a multiple of 8 below
+    for n in (100000, 99997, 5):
+        wire = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        back = torch.empty(n, dtype=torch.float32, device=DEV)
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().ts_grad_wire_pack(g.data_ptr(), wire.data_ptr(), n, 0.125, st), "pack")
+        _lib.check(_lib.lib().ts_grad_wire_unpack(wire.data_ptr(), back.data_ptr(), n, st), "unpack")
+        assert torch.equal(wire, (g[:n] * 0.125).to(torch.bfloat16)) and torch.equal(back, wire.float())

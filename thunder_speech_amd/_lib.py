@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "ts_spec_masks_draw", "ts_spec_mask_apply", "ts_dropout",
     "ts_audio_prep_workspace_bytes", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance", "ts_encode_chars",
     "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot",
+    "ts_grad_wire_pack", "ts_grad_wire_unpack",
 ]
 
 
@@ -165,6 +166,9 @@ def lib() -> C.CDLL:
     L.ts_train_se_rowdot.argtypes = [vp, vp, vp, i64, i32, vp]
     for fn in ("ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot"):
         getattr(L, fn).restype = C.c_int
+    L.ts_grad_wire_pack.argtypes = [vp, vp, i64, f32, vp]
+    L.ts_grad_wire_unpack.argtypes = [vp, vp, i64, vp]
+    L.ts_grad_wire_pack.restype = L.ts_grad_wire_unpack.restype = C.c_int
     if L.ts_abi_version() != ABI_VERSION:
         raise RuntimeError("thunder_speech_amd: ABI version mismatch between the Python binding and the .so")
     _lib = L

@@ -108,7 +108,54 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned long lo
   }
 }
 
+// Gradient wire format of the data-parallel exchange (bf16 buckets over xGMI): pack = scale (1 / world) and round
+// to bf16, unpack = widen back into the fp32 gradient buffer.  8 elements per thread, 16-byte stores.
+__global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict__ g, unsigned short* __restrict__ w, long long n, float scale) {
+  const long long n8 = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(g + 8 * i), b = *reinterpret_cast<const f32x4*>(g + 8 * i + 4);
+    *reinterpret_cast<u32x4*>(w + 8 * i) = u32x4{pack_bf16(a[0] * scale, a[1] * scale), pack_bf16(a[2] * scale, a[3] * scale),
+                                                  pack_bf16(b[0] * scale, b[1] * scale), pack_bf16(b[2] * scale, b[3] * scale)};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long long i = (n8 << 3) + threadIdx.x;
+    w[i] = (unsigned short)(pack_bf16(g[i] * scale, 0.f) & 0xffffu);
+  }
+}
+__global__ __launch_bounds__(256) void grad_unpack_kernel(const unsigned short* __restrict__ w, float* __restrict__ g, long long n) {
+  const long long n8 = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(w + 8 * i);
+    *reinterpret_cast<f32x4*>(g + 8 * i) = f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])};
+    *reinterpret_cast<f32x4*>(g + 8 * i + 4) = f32x4{bf16_lo(v[2]), bf16_hi(v[2]), bf16_lo(v[3]), bf16_hi(v[3])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long long i = (n8 << 3) + threadIdx.x;
+    g[i] = bf16_to_f32(w[i]);
+  }
+}
+
 }  // namespace ts
+
+extern "C" int ts_grad_wire_pack(const float* grad, void* wire_bf16, int64_t n, float scale, void* stream) {
+  if (!grad || !wire_bf16 || n <= 0) return TS_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(wire_bf16)) & 15) return TS_EINVAL;
+  const long long blocks = ((n >> 3) + 255) / 256;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::grad_pack_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), grad, static_cast<unsigned short*>(wire_bf16), (long long)n, scale);
+  return ts::hip_status(hipGetLastError());
+}
+
+extern "C" int ts_grad_wire_unpack(const void* wire_bf16, float* grad, int64_t n, void* stream) {
+  if (!grad || !wire_bf16 || n <= 0) return TS_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(wire_bf16)) & 15) return TS_EINVAL;
+  const long long blocks = ((n >> 3) + 255) / 256;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::grad_unpack_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), static_cast<const unsigned short*>(wire_bf16), grad, (long long)n);
+  return ts::hip_status(hipGetLastError());
+}
 
 extern "C" int ts_adamw_multi_step(const void* table, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2, float eps,
                                    float weight_decay, int32_t step, void* stream_) {

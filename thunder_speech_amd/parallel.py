@@ -1,9 +1,11 @@
 """Multi-GPU helpers.
 
 Fine-tuning: data parallel, one process per GPU, replicas hold the full weights; the ONE exchange step per
-training step is the gradient average -- `allreduce_gradients` flattens the gradients into a few large buckets (xGMI
-is point-to-point: few big collectives beat many small ones) and calls `torch.distributed.all_reduce` (RCCL on the
-GPUs, gloo in the CPU tests).  BatchNorm statistics stay per rank, as under the reference's Lightning DDP (quirk A4).
+training step is the gradient average.  `GradientSync` does it the way the hardware wants it: flat gradient buffer with
+parameter views, buckets launched from autograd hooks while the backward pass is still running, bf16 on the wire,
+reduce-scatter + all-gather (RCCL on the GPUs; fp32 + all-reduce over gloo in the CPU tests).  `allreduce_gradients` is the
+simple post-backward form (kept for callers that manage their own .grad tensors).  BatchNorm statistics stay per rank, as
+under the reference's Lightning DDP (quirk A4).
 
 Inference shards by clip: every clip is an independent unit (eval-mode BatchNorm uses
 running statistics; the reference tests batch independence in tests/utils.py:70-97), so each rank owns a
@@ -33,6 +35,153 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class GradientSync:
+    """The one exchange step of data-parallel fine-tuning, overlapped with the backward pass.
+
+    What Lightning's DDP does for the reference (module.py:102-127 runs under `Trainer(strategy="ddp")`; BatchNorm statistics
+    stay per rank, quirk A4), laid out for xGMI's point-to-point links:
+      * ONE flat fp32 gradient buffer; every `p.grad` is a view into it, so autograd accumulates straight into the bucket
+        memory -- no torch.cat staging, no copy-back;
+      * buckets are filled in REVERSE parameter order (the order gradients become ready) and each bucket's collective is
+        launched from a post-accumulate hook the moment its last gradient has landed, on a side stream: it overlaps the rest of
+        the backward pass; `finish()` (call it before the optimizer step) makes the compute stream wait for the side stream;
+      * wire format bf16 (half the bytes over the links; the mean is formed by pre-scaling with 1 / world inside the pack
+        kernel, ts_grad_wire_pack) and reduce-scatter + all-gather instead of a ring all-reduce, so that RCCL can drive all
+        seven links of a GPU at once; few large buckets (default 32 MiB of fp32 gradient each).
+    CPU tensors (the gloo tests) take the same bucket / hook logic with fp32 on the wire and a plain all-reduce (gloo has no
+    reduce-scatter), synchronously.
+
+        sync = GradientSync(trainable_parameters)
+        loss.backward(); sync.finish(); optimizer.step(); optimizer.zero_grad(set_to_none=False)   # keep the views!
+    """
+
+    def __init__(self, params, bucket_bytes: int = 32 << 20, wire_dtype=None, collective: str = None):
+        import torch.distributed as dist
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradientSync: no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("GradientSync: fp32 parameters on one device only")
+        self.device = dev
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        on_gpu = dev.type == "cuda"
+        self.wire_dtype = wire_dtype if wire_dtype is not None else (torch.bfloat16 if on_gpu else torch.float32)
+        self.collective = collective or ("reduce_scatter" if on_gpu else "all_reduce")
+        if self.collective not in ("reduce_scatter", "all_reduce"):
+            raise ValueError("collective must be 'reduce_scatter' or 'all_reduce'")
+        # ---- buckets over the REVERSED parameter list; every segment starts 16-byte aligned and every bucket's length is a
+        # multiple of 8 * world elements (the shards of the reduce-scatter stay 16-byte aligned)
+        align = 8 * max(self.world, 1)
+        self.buckets = []                       # (start, length, [param indices])
+        self._bucket_of = {}
+        offsets, off, cur, cur_start = {}, 0, [], 0
+        for idx in reversed(range(len(self.params))):
+            n = self.params[idx].numel()
+            if cur and (off - cur_start + n) * 4 > bucket_bytes:
+                off = -(-off // align) * align
+                self.buckets.append((cur_start, off - cur_start, cur))
+                cur, cur_start = [], off
+            offsets[idx] = off
+            cur.append(idx)
+            off = -(-(off + n) // 4) * 4
+        off = -(-off // align) * align
+        self.buckets.append((cur_start, off - cur_start, cur))
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for b, (_, _, members) in enumerate(self.buckets):
+            for idx in members:
+                self._bucket_of[idx] = b
+        for idx, p in enumerate(self.params):
+            p.grad = self.flat[offsets[idx]: offsets[idx] + p.numel()].view_as(p)
+        self._wire = [torch.empty(length, dtype=self.wire_dtype, device=dev) if self.wire_dtype != torch.float32 else None
+                      for (_, length, _) in self.buckets]
+        self._pending = [len(m) for (_, _, m) in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._side = torch.cuda.Stream(device=dev) if on_gpu else None
+        self.n_collectives = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(idx)) for idx, p in enumerate(self.params)]
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _make_hook(self, idx):
+        def hook(param):
+            if param.grad is None or param.grad.data_ptr() != self._view_ptr(idx):
+                raise RuntimeError("GradientSync: a parameter's .grad no longer points into the flat bucket buffer "
+                                   "(use optimizer.zero_grad(set_to_none=False) or GradientSync.zero_grad())")
+            b = self._bucket_of[idx]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _view_ptr(self, idx):
+        if not hasattr(self, "_ptrs"):
+            self._ptrs = {}
+        if idx not in self._ptrs:
+            self._ptrs[idx] = self.params[idx].grad.data_ptr()
+        return self._ptrs[idx]
+
+    def _launch(self, b: int) -> None:
+        import torch.distributed as dist
+        self._launched[b] = True
+        if self.world == 1:
+            return
+        start, length, _ = self.buckets[b]
+        seg = self.flat[start: start + length]
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))      # the bucket's gradients are complete on the compute stream
+            ctx = torch.cuda.stream(self._side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.wire_dtype == torch.float32:
+                wire = seg
+                wire.mul_(1.0 / self.world)
+            else:
+                wire = self._wire[b]
+                if seg.is_cuda:
+                    from . import _lib
+                    st = _lib.lib().ts_grad_wire_pack(seg.data_ptr(), wire.data_ptr(), length, 1.0 / self.world, self._side.cuda_stream)
+                    _lib.check(st, "ts_grad_wire_pack")
+                else:
+                    wire.copy_(seg * (1.0 / self.world))
+            if self.collective == "reduce_scatter":
+                shard = wire.view(self.world, -1)[dist.get_rank()]
+                dist.reduce_scatter_tensor(shard, wire, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(wire, shard)
+                self.n_collectives += 2
+            else:
+                dist.all_reduce(wire, op=dist.ReduceOp.SUM)
+                self.n_collectives += 1
+            if wire is not seg:
+                if seg.is_cuda:
+                    from . import _lib
+                    st = _lib.lib().ts_grad_wire_unpack(wire.data_ptr(), seg.data_ptr(), length, self._side.cuda_stream)
+                    _lib.check(st, "ts_grad_wire_unpack")
+                else:
+                    seg.copy_(wire)
+
+    def finish(self) -> None:
+        """After backward(): launch whatever has not been launched (parameters that received no gradient this step keep their
+        zeros), then make the compute stream wait for the exchange.  Resets the per-step bookkeeping."""
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self._pending = [len(m) for (_, _, m) in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+    def zero_grad(self) -> None:
+        """One memset of the flat buffer (instead of one per parameter); the .grad views stay in place."""
+        self.flat.zero_()
+
+    def close(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def allreduce_gradients(params, bucket_bytes: int = 64 << 20) -> int:

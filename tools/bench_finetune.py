@@ -1,7 +1,8 @@
 """Config C4, first phase: QuartzNet15x5 fine-tuning with the encoder frozen (what the reference's
 FinetuneEncoderDecoder callback does until `unfreeze_encoder_at_epoch`), global batch 256 x 10 s split over the ranks.
-Step = front end + frozen encoder forward + trainable decoder forward + CTC loss/gradient + decoder backward + ONE
-bucketed gradient all-reduce (RCCL) + fused AdamW.  A measurement tool, not the bench line:
+Step = front end + frozen encoder forward + trainable decoder forward + CTC loss/gradient + decoder backward + the
+gradient exchange (parallel.GradientSync: flat buffer, bf16 buckets launched from autograd hooks during backward, RCCL
+reduce-scatter + all-gather) + fused AdamW.  A measurement tool, not the bench line:
     python tools/bench_finetune.py                      # 1 GPU, local batch 32
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_finetune.py --global-batch 256
 """
@@ -28,7 +29,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from thunder_speech_amd.optim import FusedAdamW
-    from thunder_speech_amd.parallel import allreduce_gradients, max_over_ranks
+    from thunder_speech_amd.parallel import GradientSync, max_over_ranks
     from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
     from thunder_speech_amd.utils import variance_preserving_init_
     torch.manual_seed(0)
@@ -47,6 +48,7 @@ def main():
         m.graph_frozen_encoder()
     trainable = [p for p in m.parameters() if p.requires_grad]
     opt = FusedAdamW(trainable, lr=1e-3)
+    sync = GradientSync(trainable)
     B = (args.global_batch // world) if args.global_batch else 32
     g = torch.Generator().manual_seed(1234 + rank)
     wav = (0.1 * torch.randn(B, 16000 * args.seconds, generator=g)).to(dev)
@@ -54,10 +56,10 @@ def main():
     texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(60, 140, (B,), generator=g)]
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        sync.zero_grad()
         loss = m.training_step((wav, lengths, texts), 0)
         loss.backward()
-        allreduce_gradients(trainable)
+        sync.finish()
         opt.step()
         return loss
 
