@@ -9,9 +9,11 @@ resident in HBM, replayed from a hipGraph.
 
 Prints ONE JSON line on rank 0.  Inference shards by clip (independent units, no collective on the data path):
 every rank runs its own 64-clip batch, scaling is "weak".  `roofline` is for the dominant kernel family
-(ts::tcs_pipe_kernel / ts::tcs_kernel, all 78 launches of a step): algorithmic bytes (ideal fusion, SURVEY 8d) / HIP-event time of the
+(ts::tcs_split_kernel / ts::tcs_kernel, all 78 launches of a step): algorithmic bytes (ideal fusion, SURVEY 8d) / HIP-event time of the
 encoder segment.  `cpu_baseline` times the CPU oracle (a port of the reference path, fp32 torch-CPU ops) on a
-bounded sample of the same workload on this box's host cores.
+bounded sample of the same workload on this box's host cores (16 threads, where torch-CPU peaks, plus a 1-thread figure).
+At N = 1 the same JSON object also carries `extra`: the other BASELINE.json configurations (C3, C4 phases 1 and 2, C5) measured by
+tools/bench_extra.py in the same process, each with its own roofline (and oracle check where affordable); --no-extra skips them.
 """
 from __future__ import annotations
 
@@ -93,11 +95,13 @@ def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seconds", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / C5 measurements (extra.*)")
+    ap.add_argument("--extra", default="c3,c4,c5", help="which of c3,c4,c5 to measure at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -202,6 +206,13 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(module)
+            one = cpu_baseline(module, clips=2, seconds=15, iters=1, threads=1)
+            result["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
+        if not args.no_extra and world == 1:
+            del module
+            torch.cuda.empty_cache()
+            from tools import bench_extra
+            result["extra"] = bench_extra.run(device, tuple(n for n in args.extra.split(",") if n), check=not args.no_cpu_baseline)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

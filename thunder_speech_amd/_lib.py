@@ -175,7 +175,12 @@ def lib() -> C.CDLL:
     return L
 
 
+CALLS = 0          # C-ABI calls checked so far (bench.py reports calls per training step)
+
+
 def check(status: int, what: str) -> None:
+    global CALLS
+    CALLS += 1
     if status == 0:
         return
     if status == -1:

@@ -1,0 +1,223 @@
+"""The other BASELINE.json configurations, measured by the same process as the headline line (bench.py puts the result under
+`extra`): C3 Citrinet-1024 inference 32 x 20 s, C4 QuartzNet15x5 fine-tuning (phase 1: frozen encoder, phase 2: everything
+trainable) at local batch 32 x 10 s, C5 wav2vec2-large geometry inference 16 x 20 s.  Each entry carries ms/step, the
+metric's value, its own roofline object and -- where an oracle run is affordable -- the CPU oracle timed on ONE clip of the
+same workload, which doubles as a parity check of the HIP output (max / rms error on that clip).
+
+    python tools/bench_extra.py c3 c4 c5            # stand-alone, prints one JSON object
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TF = 2500.0
+FP32_PEAK_TF = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def _timed(run, steps, warmup=2):
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _graphed(step, device):
+    side, graph = torch.cuda.Stream(device), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = step()
+    return graph.replay, out
+
+
+def c3(device, batch=32, seconds=20, steps=20, check=True):
+    """Citrinet-1024 (reference constructor, SURVEY 8c layer list), bf16 inference; MFMA-bound (5 051 GFLOP / 8.41 GB per batch)."""
+    from thunder_speech_amd.citrinet.compatibility import CITRINET_1024_KERNELS, CITRINET_1024_STRIDES, build_synthetic_citrinet
+    from thunder_speech_amd.module import greedy_decode
+    from thunder_speech_amd.utils import variance_preserving_init_
+    torch.manual_seed(0)
+    module = build_synthetic_citrinet()
+    variance_preserving_init_(module.encoder, module.decoder, seed=0)
+    module = module.to(device).eval()
+    g = torch.Generator().manual_seed(1234)
+    wav = (0.1 * torch.randn(batch, 16000 * seconds, generator=g)).to(device)
+    lengths = torch.full((batch,), 16000 * seconds, dtype=torch.int32, device=device)
+
+    def step():
+        logits, _ = module(wav, lengths)
+        return logits, greedy_decode(logits)
+
+    with torch.no_grad():
+        step(); step(); torch.cuda.synchronize()
+        replay, out = _graphed(step, device)
+        dt = _timed(replay, steps)
+    gflop = 5051.0 * batch / 32 * seconds / 20
+    gbytes = 8.41 * batch / 32 * seconds / 20
+    res = {"workload": f"Citrinet-1024 inference, batch {batch}x{seconds} s, bf16, hipGraph replay (BASELINE.json configs[2])",
+           "ms_per_step": dt * 1e3, "value": batch * seconds / dt, "unit": "audio-seconds/s", "steps": steps,
+           "roofline": {"bound": "mfma", "achieved": gflop / dt / 1e3, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": gflop / dt / 1e3 / MFMA_BF16_PEAK_TF, "hbm_frac": gbytes / dt / HBM_PEAK_GBS}}
+    if check:
+        from oracle import frontend as ofe, tcs as otcs
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        arch = otcs.citrinet_arch([1024] * 21, CITRINET_1024_KERNELS, CITRINET_1024_STRIDES, feat_in=80)
+        sd = {k: v.detach().cpu() for k, v in module.encoder.state_dict().items()}
+        dsd = {k: v.detach().cpu() for k, v in module.decoder.state_dict().items()}
+        x0, l0 = wav[:1].cpu(), lengths[:1].cpu()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            feats, fl = ofe.filterbank_features(x0, l0, ofe.FrontendConfig(n_window_size=400, nfilt=80))
+            enc, _ = otcs.encoder_forward(arch, sd, feats, fl)
+            ref = otcs.conv1d_decoder_forward(dsd, enc)
+            cdt = time.perf_counter() - t0
+        got = out[0][:1].float().cpu()
+        scale = float(ref.abs().max())
+        res["cpu_baseline"] = {"value": seconds / cdt, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"Citrinet-1024 fp32 oracle, 1x{seconds} s clip, one pass"}
+        res["check"] = {"vs": "fp32 oracle logits, clip 0, all frames", "max_err_over_scale": float((got - ref).abs().max()) / scale,
+                        "rms_err_over_scale": float((got - ref).pow(2).mean().sqrt()) / scale, "logit_scale": scale}
+    return res
+
+
+def c5(device, batch=16, seconds=20, steps=10, check=True):
+    """wav2vec2-large-960h geometry (random weights: the checkpoint needs the network), bf16-operand inference; MFMA-bound."""
+    from tools.bench_c5 import config, random_state
+    from thunder_speech_amd.huggingface.encoder import Wav2Vec2Plan
+    from thunder_speech_amd.huggingface.transform import Wav2Vec2Preprocess
+    cfg = config(False, 24)
+    sd = random_state(cfg)
+    plan = Wav2Vec2Plan(cfg, sd, device, precision="bf16")
+    pre = Wav2Vec2Preprocess()
+    x = (0.1 * torch.randn(batch, 16000 * seconds, generator=torch.Generator().manual_seed(1234))).to(device)
+    lengths = torch.full((batch,), 16000 * seconds, dtype=torch.int32, device=device)
+
+    def step():
+        xn, _ = pre(x, lengths)
+        return plan.forward(xn, None)
+
+    with torch.no_grad():
+        step(); step(); torch.cuda.synchronize()
+        replay, out = _graphed(step, device)
+        dt = _timed(replay, steps)
+    t = out.shape[1]
+    c, ffn, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    flops = 2 * batch * (sum(((16000 * seconds) // (5 * 2 ** i)) * 512 * 512 * k for i, k in enumerate(cfg.conv_kernel[1:], start=1))
+                         + t * L * (4 * c * c + 2 * c * ffn + 2 * t * c) + t * c * (c // 16) * 128)
+    res = {"workload": f"wav2vec2-large geometry inference, batch {batch}x{seconds} s, bf16 operands / fp32 accumulation, hipGraph replay "
+                       "(BASELINE.json configs[4])",
+           "ms_per_step": dt * 1e3, "value": batch * seconds / dt, "unit": "audio-seconds/s", "steps": steps, "frames": t,
+           "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": flops / dt / 1e12 / MFMA_BF16_PEAK_TF}}
+    if check:
+        from oracle import w2v as ow
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        ocfg = ow.W2VConfig(conv_dim=cfg.conv_dim, conv_kernel=cfg.conv_kernel, conv_stride=cfg.conv_stride, hidden_size=c,
+                            num_hidden_layers=L, num_attention_heads=cfg.num_attention_heads, intermediate_size=ffn,
+                            num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+                            num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups)
+        x0 = x[:1].cpu()
+        xn = (x0 - x0.mean(dim=1, keepdim=True)) / torch.sqrt(x0.var(dim=1, keepdim=True) + 1e-7)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref, _ = ow.forward(ocfg, sd, xn)
+            cdt = time.perf_counter() - t0
+        err = (out[:1].float().cpu() - ref).abs()
+        res["cpu_baseline"] = {"value": seconds / cdt, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"wav2vec2-large fp32 oracle, 1x{seconds} s clip, one pass"}
+        res["check"] = {"vs": "fp32 oracle last_hidden_state (LayerNorm-ed, unit scale), clip 0", "max_err": float(err.max()),
+                        "rms_err": float(err.pow(2).mean().sqrt())}
+    return res
+
+
+def c4(device, local_batch=32, seconds=10, steps1=30, steps2=10):
+    """QuartzNet15x5 fine-tuning, one rank's share of config C4 (global 256 x 10 s over 8 GPUs = local 32).  Phase 1 = the
+    reference recipe's first epochs (FinetuneEncoderDecoder: encoder frozen), phase 2 = everything trainable."""
+    from thunder_speech_amd import _lib
+    from thunder_speech_amd.optim import FusedAdamW
+    from thunder_speech_amd.parallel import GradientSync
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.utils import variance_preserving_init_
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+    wav = (0.1 * torch.randn(local_batch, 16000 * seconds, generator=g)).to(device)
+    lengths = torch.full((local_batch,), 16000.0 * seconds, device=device)
+    texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(60, 140, (local_batch,), generator=g)]
+    fwd_gflop = 4826.9 * local_batch * seconds / 2560.0             # 4 826.9 GFLOP forward per 256 x 10 s
+    for phase, steps in ((1, steps1), (2, steps2)):
+        torch.manual_seed(0)
+        m = build_synthetic_quartznet(repeat_blocks=3)
+        variance_preserving_init_(m.encoder, m.decoder, seed=0)
+        m = m.to(device).train()
+        if phase == 1:
+            m.encoder.eval()
+            for p in m.encoder.parameters():
+                p.requires_grad_(False)
+            m.graph_frozen_encoder()
+        trainable = [p for p in m.parameters() if p.requires_grad]
+        opt, sync = FusedAdamW(trainable, lr=1e-3), GradientSync(trainable)
+
+        def step():
+            sync.zero_grad()
+            loss = m.training_step((wav, lengths, texts), 0)
+            loss.backward()
+            sync.finish()
+            opt.step()
+            return loss
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        c0 = _lib.CALLS
+        step()
+        calls = _lib.CALLS - c0
+        dt = _timed(step, steps, warmup=0)
+        model_flop = (3.0 if phase == 2 else 1.0) * fwd_gflop      # phase 1: forward only through the frozen encoder
+        out[f"c4_phase{phase}"] = {
+            "workload": f"QuartzNet15x5 fine-tune step (CTC), local batch {local_batch}x{seconds} s, "
+                        + ("encoder frozen + hipGraph-replayed, decoder trainable" if phase == 1 else "everything trainable, fp32 activations")
+                        + " (BASELINE.json configs[3], one rank's share)",
+            "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s", "audio_seconds_per_s": local_batch * seconds / dt,
+            "steps": steps, "c_abi_calls_per_step": calls,
+            "roofline": {"bound": "mfma", "model": "3 x forward FLOPs (BASELINE.md section 3)" if phase == 2 else "1 x forward FLOPs (frozen encoder)",
+                         "achieved": model_flop / dt / 1e3, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": model_flop / dt / 1e3 / MFMA_BF16_PEAK_TF, "frac_of_fp32_vector_peak": model_flop / dt / 1e3 / FP32_PEAK_TF}}
+        sync.close()
+        del m, opt, sync
+        torch.cuda.empty_cache()
+    return out
+
+
+def run(device, which=("c3", "c4", "c5"), check=True):
+    extra = {}
+    for name in which:
+        t0 = time.perf_counter()
+        try:
+            if name == "c3":
+                extra["c3"] = c3(device, check=check)
+            elif name == "c4":
+                extra.update(c4(device))
+            elif name == "c5":
+                extra["c5"] = c5(device, check=check)
+        except Exception as e:                      # an extra must never take the headline line down with it
+            extra[name] = {"error": f"{type(e).__name__}: {e}"}
+        extra.setdefault("_wall_s", {})[name] = round(time.perf_counter() - t0, 1)
+        torch.cuda.empty_cache()
+    return extra
+
+
+if __name__ == "__main__":
+    names = [a for a in sys.argv[1:] if not a.startswith("-")] or ["c3", "c4", "c5"]
+    print(json.dumps(run(torch.device("cuda", 0), names, check="--no-check" not in sys.argv)))
