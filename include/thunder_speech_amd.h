@@ -60,6 +60,10 @@ typedef struct ts_tcs_desc {
   int32_t flags;                /* TS_TCS_* bits below */
   const void* dw_taps;          /* bf16 [c_in_pad64/64][4 waves][NK][64 lanes][4]  shifted Toeplitz rows of the depthwise taps,
                                    lane = 4*(channel % 16) + row (plan.tap_fragments) */
+  const void* dw_taps_raw;      /* stride-1 layers (may be NULL: the kernels that read the pre-shifted fragments run instead): the same
+                                   NK k-steps as raw taps, bf16 [c_in_pad64/64][4 groups of 16 channels][KiB-padded image]; per channel
+                                   16 NK + 16 bytes = two copies of wp[n] = w[n - 3 - (round_up(padding, 4) - padding)], n < 4 NK + 4, the
+                                   second shifted by one element (plan.pack_dw_taps_raw).  With TS_TCS_TAPS_PHASE: the phase-split form. */
   const void* pw_w;             /* bf16 [c_out_pad32/32][c_in_pad64/16][64][8]  MFMA B-fragments of W*bn_scale */
   const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */

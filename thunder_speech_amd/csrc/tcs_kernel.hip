@@ -52,6 +52,7 @@ struct TcsArgs {
   const int* len_in;
   const int* len_res;
   const unsigned short* taps;  // [c_in_pad][4][4*nk]
+  const unsigned short* taps_raw;  // split kernel: raw tap image, see plan.pack_dw_taps_raw
   const unsigned short* pw_w;  // fragments
   const unsigned short* res_w;
   const float* bias;
@@ -756,13 +757,6 @@ struct TilePos {
 //   iteration i: producers write stage i into dwt[i & 1], consumers read stage i-1 out of dwt[(i-1) & 1]; one barrier.
 //   The epilogue runs after the barrier that ends the last stage of a tile, so the producers work through it.
 // ======================================================================================================
-// Tap pairs of a producer: pair h holds k-steps 2h and 2h+1 and is free for the next stage's fragments once the pass that
-// consumes its last k-step has issued its MFMAs.
-struct ProdSched {
-  int npass, xp, nk, nkh, dist;
-  constexpr int last_pass(int h) const { return ((2 * h + 1 < nk ? 2 * h + 1 : nk - 1)) / 3; }
-};
-
 // DIL == 2 (dilation-2 layers, K87 of QuartzNet): the even and the odd frames of a row are two independent dilation-1
 // sequences (y[2s+p] = sum_u w[u] x[2(s+u)+p - pad], pad even).  The producers stage each row as [even | odd] halves,
 // lane runs 0,1 filter the even half and 2,3 the odd half with dilation-1 tap fragments (no zero-stuffed Toeplitz rows:
@@ -780,7 +774,14 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   constexpr int EP = FW * 2 + 24;
   constexpr int XP = 2 * XJ;                      // 16 rows x 128*XJ bytes per wave, 1 KiB per instruction
   constexpr int IDP = (2 * TT + 63) / 64;         // identity rows: 16 rows x 2*TT bytes
-  constexpr int NKH = (NK + 1) / 2;               // tap fragments travel in pairs of k-steps (1 KiB per wave)
+  // Depthwise taps: RAW, not as Toeplitz fragments.  Per channel two copies of the zero-padded tap array wp[n] = w[n - 3 - d]
+  // (copy 1 shifted by one element), CST bytes per channel; Toeplitz row i of k-step k is wp[4k + 3 - i .. +3]: a 4-byte
+  // aligned pair of dwords of copy (i even) at dword 2k + (i < 2) -- one ds_read2_b32.  Half the bytes of the pre-shifted
+  // fragments, so the taps of a 16-channel group fit TWICE: the image of the NEXT stage is fetched by DMA at the start of the
+  // running one (a whole stage ahead of its first use) and no DMA sits inside the MFMA passes any more.
+  constexpr int CST = 16 * NK + 16;               // bytes per channel: 2 copies of 4 NK + 4 bf16
+  constexpr int NTD = (16 * CST + 1023) / 1024;   // KiB (= DMA instructions) per 16-channel group and stage
+  constexpr int TAPB = NTD * 1024;
   constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
   constexpr int ER = (WM == 2 || DIL == 2) ? 16 : 32;   // output-channel rows of a consumer's epilogue tile
   constexpr int PHW = 32 * XJ;                    // DIL == 2: frames of a staged half row
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const dwt = smem;                                             // [2][KC][ROWB]
   char* const cons0 = smem + 2 * TILEB;                               // [8][32][EP] epilogue tiles
-  char* const prod0 = cons0 + 8 * ER * EP;                            // [4][XSB + NKH KiB]
+  char* const prod0 = cons0 + 8 * ER * EP;                            // [4][XSB + 2 * TAPB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -817,28 +818,29 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     __builtin_amdgcn_s_setprio(TS_PROD_PRIO);
 #endif
     const int pw = wave - 8;
-    char* const xs = prod0 + (size_t)pw * (XSB + NKH * 1024);
-    char* const tapl = xs + XSB;
+    char* const xs = prod0 + (size_t)pw * (XSB + 2 * TAPB);
+    char* const tapl = xs + XSB;                   // two tap images: stage gs reads tapl[gs & 1]
     const int xpitch = 64 * XJ + 4;
     const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(a.x) - TS_GUARD_BYTES);
-    const i32x4 rt = raw_rsrc(a.taps, (unsigned)n_main * (KC * 4 * NK * 4 * 2));
+    const i32x4 rt = raw_rsrc(a.taps_raw, (unsigned)n_main * (4 * TAPB));
     const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
     const int row = lane >> 2, sub = lane & 3;     // staging: row of the wave's 16 channels, 16-byte group sub + 4j
     const int q = lane & 3;                        // depthwise: channel = row, time run q
     char* const xw = xs + ((size_t)row * xpitch + sub * (DIL == 2 ? 4 : 8)) * 2;
     const char* const xrow = DIL == 2 ? xs + ((size_t)row * xpitch + (q >> 1) * PHW + a.woff + (q & 1) * RUN) * 2
                                       : xs + ((size_t)row * xpitch + a.woff + q * RUN) * 2;
-    const char* const trow = tapl + lane * 8;      // fragment of (k, lane) at k * 512 + lane * 8
+    // this lane's Toeplitz row inside a tap image: channel `row`, copy by the parity of q, one dword in for q < 2
+    const int tap_off = row * CST + ((lane & 1) ? 0 : CST / 2) + ((lane & 3) < 2 ? 4 : 0);
     int dw_out[M];
 #pragma unroll
     for (int m = 0; m < M; ++m)
       dw_out[m] = DIL == 2 ? taddr(pw * 16 + row, (q & 1) * 2 * RUN + 8 * m + 4 * (q >> 1)) : taddr(pw * 16 + row, q * RUN + 4 * m);
     const int lane_x = ((pw * 16 + row) * a.pitch_in + sub * 8) * 2;
-    const int lane_t = pw * NK * 512 + lane * 16;  // [chunk][16-ch group][k][64 lanes][4]: a pair of k-steps is 1 KiB contiguous
+    const int lane_t = pw * TAPB + lane * 16;      // [chunk][16-ch group][TAPB]
     const int lane_i = ((pw * 16 + row) * a.pitch_res + sub * 8) * 2;
     const int id_out = taddr(pw * 16 + row, sub * 8);
     const int chunk_x = KC * a.pitch_in * 2;
-    const int chunk_t = KC * 4 * NK * 4 * 2;
+    const int chunk_t = 4 * TAPB;
     const int chunk_i = KC * a.pitch_res * 2;
 
     u32x4 X[XP];
@@ -859,8 +861,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       }
     };
     int t_next = (n_main > 1 ? 1 : 0) * chunk_t;
-    auto tap_dma = [&](int h, int soff, float after = 0.f) {
-      lds_dma16(rt, tapl + h * 1024, lane_t, soff + h * 1024, after);
+    auto tap_dma = [&](int buf, int soff) {        // the whole image of a stage into tapl[buf]
+#pragma unroll
+      for (int h = 0; h < NTD; ++h) lds_dma16(rt, tapl + buf * TAPB + h * 1024, lane_t, soff + h * 1024);
     };
     auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
     u32x4 I[IDP], I2[IDP];                          // identity rows in flight: one stage ahead (two when n_res is even)
@@ -885,7 +888,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     u32x2 T[NK];
     f32x4 d[M];
     constexpr int WD = TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS;
-    constexpr ProdSched PS{NPASS, XP, NK, NKH, WD};   // which pass frees which tap pair
+    typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+    const char* trow = tapl + tap_off;             // re-pointed at the running stage's image at every stage start
     auto xs_write = [&]() {
 #pragma unroll
       for (int j = 0; j < XP; ++j) {
@@ -902,7 +906,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       }
     };
     auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
-    auto tap_load = [&](int kk) { T[kk] = *reinterpret_cast<const u32x2*>(trow + kk * 512); };
+    auto tap_load = [&](int kk) { const u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(trow + kk * 8); T[kk] = u32x2{v[0], v[1]}; };
     auto dw_begin = [&]() {
 #pragma unroll
       for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -924,16 +928,13 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #pragma unroll
         for (int m = 0; m < M; ++m)
           d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m], d[m], 0, 0, 0);
-#pragma unroll
-      for (int h = 0; h < NKH; ++h)
-        if (PS.last_pass(h) == p) tap_dma(h, t_next, d[M - 1][3]);   // behind the pass's last MFMA
     };
 
+    unsigned ds = 0;                               // depthwise stages started: selects the tap image
     // prologue: rows and taps of the first stage (a pointwise-only layer has identity stages only: n_main == 0)
     if (n_main) {
       dw_issue();
-#pragma unroll
-      for (int h = 0; h < NKH; ++h) tap_dma(h, 0);
+      tap_dma(0, 0);
     }
     // Identity rows are fetched TWO stages ahead when the stage count is even (register sets alternate, statically):
     // an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
@@ -953,16 +954,20 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     for (int tile = tile0; tile < tile_end; tile += tile_step) {
       for (int s = 0; s < n_main; ++s, ++gs) {
         char* const dst = dwt + (gs & 1) * TILEB;
-        // Everything this wave has in flight is a stage old except the last tap DMAs: drain it all.  (Measured: DMA-to-LDS
-        // loads and register loads retire out of order with respect to each other, so a counted vmcnt cannot separate them;
-        // hipcc's own waits for the row loads assume in-order retirement and are not enough once DMAs are in the queue.)
+        // Everything this wave has in flight -- the rows and the tap image of THIS stage -- was issued at the start of the
+        // previous stage: the drain is cheap.  (DMA-to-LDS loads and register loads retire out of order with respect to each
+        // other, so a counted vmcnt could not separate them anyway.)
         PSTAMP(8 * gs);
         vm_wait<0>();
         PSTAMP(8 * gs + 1);
+        trow = tapl + (ds & 1) * TAPB + tap_off;
         xs_write();
         PSTAMP(8 * gs + 2);
         dw_begin();
-        dw_issue();
+        dw_issue();                                   // rows of the next depthwise stage (possibly of the next tile)
+        tap_dma((ds + 1) & 1, t_next);                // ... and its tap image, into the buffer the previous stage has finished with
+        tap_advance();
+        ++ds;
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(8 * gs + 3);
         static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
@@ -983,7 +988,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
             *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{m0, m1};
           }
         }
-        tap_advance();
         PSTAMP(8 * gs + 5);
         stage_barrier();
         PSTAMP(8 * gs + 6);
@@ -1186,11 +1190,11 @@ template <int NPASS, int XJ, int MT, int WM, int DIL = 1>
 static int launch_split(TcsArgs& a, hipStream_t stream) {
   constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);
   constexpr int ROWB = TT <= 128 ? 256 : 512;
-  constexpr int NKH = (NPASS * NKP + 1) / 2;
+  constexpr int NK_ = NPASS * NKP, TAPB = (16 * (16 * NK_ + 16) + 1023) / 1024 * 1024;
   a.n_tt = (a.t_out + TT - 1) / TT;
   a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
   a.n_tiles = a.batch * a.n_tt * a.n_z;
-  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) + (size_t)4 * (16 * (64 * XJ + 4) * 2 + NKH * 1024);
+  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) + (size_t)4 * (16 * (64 * XJ + 4) * 2 + 2 * TAPB);
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
   auto kern = tcs_split_kernel<NPASS, XJ, MT, WM, DIL>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1254,6 +1258,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   a.len_in = len_in;
   a.len_res = len_res;
   a.taps = static_cast<const unsigned short*>(d->dw_taps);
+  a.taps_raw = static_cast<const unsigned short*>(d->dw_taps_raw);
   a.pw_w = static_cast<const unsigned short*>(d->pw_w);
   a.res_w = static_cast<const unsigned short*>(d->res_w);
   a.bias = d->bias;
@@ -1289,7 +1294,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       const int n_ttp = (d->t_out + 95) / 96;
       const bool fits = a.npass == 8 && 24 + 4 * (5 + d->dw_ksteps) <= 160 && (n_ttp - 1) * 96 - w.padl8 + 320 <= d->pitch_in &&
                         d->pitch_in - d->t_in >= w.padl8 && d->pitch_out >= n_ttp * 96;
-      return fits ? launch_split<8, 5, 3, 1, 2>(w, stream) : TS_EUNSUPPORTED;
+      return (fits && d->dw_taps_raw) ? launch_split<8, 5, 3, 1, 2>(w, stream) : TS_EUNSUPPORTED;
     }
     a.taps_lds = d->dw_ksteps <= NKMAX;
     const int padl4 = round_up(d->padding, 4);
@@ -1313,7 +1318,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       w.xpitch = w.xe + 4;
       const bool fits = (n_ttp - 1) * TTp - w.padl8 + w.xe <= d->pitch_in && d->pitch_out >= n_ttp * TTp &&
                         (d->c_res == 0 || d->pitch_res >= (n_ttp - 1) * TTp + round_up(TTp, 64));
-      if (fits) {
+      if (fits && d->dw_taps_raw) {
 #define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) return launch_split<NP_, XJ_, 3, WM_>(w, stream);
         TS_PIPE(3, 4, 2) TS_PIPE(4, 4, 2) TS_PIPE(5, 3, 1) TS_PIPE(6, 3, 1) TS_PIPE(7, 3, 1)      /* QuartzNet: K 33..75 */
         TS_PIPE(2, 2, 1) TS_PIPE(3, 3, 1) TS_PIPE(4, 3, 1) TS_PIPE(2, 4, 2)                         /* Citrinet: K 11..41 */

@@ -59,6 +59,28 @@ def pack_dw_taps(w: torch.Tensor, stride: int, dilation: int, padding: int) -> T
     return out.to(torch.bfloat16).contiguous(), nk
 
 
+def pack_dw_taps_raw(w: torch.Tensor, padding: int) -> torch.Tensor:
+    """w: [C, 1, K] depthwise taps of a stride-1, dilation-1 conv -> the RAW tap image of the split kernel, bf16
+    [C_pad64/64][4][TAPB/2]: per 16-channel group a KiB-padded block, per channel CST = 16 NK + 16 bytes holding two copies of the
+    zero-padded array wp[n] = w[n - 3 - d] (d = round_up(padding, 4) - padding, n < 4 NK + 4), the second shifted by one
+    element.  Toeplitz row i of k-step k (pack_dw_taps: row_i[v] = w[v - i - d]) is wp[4k + 3 - i .. 4k + 6 - i], i.e. a
+    4-byte-aligned pair of dwords of copy (i even): half the bytes of the four pre-shifted rows."""
+    c, _, k = w.shape
+    nk = dw_ksteps(k, 1, 1, padding)
+    d = round_up(padding, 4) - padding
+    n = 4 * nk + 4
+    cp = round_up(c, KC)
+    wp = torch.zeros(cp, n + 1, dtype=torch.float32, device=w.device)
+    wp[:c, 3 + d: 3 + d + k] = w[:, 0, :]
+    img = torch.stack([wp[:, :n], wp[:, 1: n + 1]], dim=1)                  # [C, 2 copies, n]
+    cst = 16 * nk + 16                                                        # bytes per channel
+    tapb = (16 * cst + 1023) // 1024 * 1024
+    grp = img.reshape(cp // 16, 16 * 2 * n)                                   # one row per 16-channel group (cst / 2 elements per channel)
+    out = torch.zeros(cp // 16, tapb // 2, dtype=torch.float32, device=w.device)
+    out[:, : 16 * 2 * n] = grp
+    return out.to(torch.bfloat16).reshape(cp // KC, 4, tapb // 2).contiguous()
+
+
 def tap_fragments(taps: torch.Tensor) -> torch.Tensor:
     """[C_pad64, 4, 4*NK] Toeplitz rows -> the order the producer waves load them in:
     [chunk(64 ch)][wave(16 ch)][k-step][lane = 4*(ch % 16) + row][4 samples], so that one wave-instruction reads
@@ -113,6 +135,8 @@ class TcsLayer:
     out_fp32: bool = False
     taps_phase: Optional[torch.Tensor] = None      # dilation 2: the same taps packed for the phase-split kernel
     nk_phase: int = 0
+    taps_raw: Optional[torch.Tensor] = None        # stride 1: raw tap image of the split kernel (pack_dw_taps_raw)
+    taps_phase_raw: Optional[torch.Tensor] = None
 
     def out_size(self, t_in: int) -> int:
         return conv_out_size(t_in, self.kernel, self.stride, self.padding, self.dilation)
@@ -145,6 +169,7 @@ class TcsLayer:
         d.dw_ksteps = self.nk
         d.flags = (_lib.TCS_IN_TAILZERO if in_tail_zero else 0) | (_lib.TCS_OUT_ZERO_TAIL if zero_tail else 0)
         d.dw_taps = self.taps.data_ptr() if self.taps is not None else None
+        d.dw_taps_raw = self.taps_raw.data_ptr() if self.taps_raw is not None else None
         d.pw_w = self.pw.data_ptr()
         d.bias = self.bias.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -154,12 +179,14 @@ class TcsLayer:
             # dilation 2: offer the phase-split fragments first; the library declines geometries it has no such kernel for
             d.flags |= _lib.TCS_TAPS_PHASE
             d.dw_taps, d.dw_ksteps = self.taps_phase.data_ptr(), self.nk_phase
+            d.dw_taps_raw = self.taps_phase_raw.data_ptr()
             st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
             if st != _lib.TS_EUNSUPPORTED:
                 _lib.check(st, "ts_tcs_subblock_fwd")
                 return out, t_out
             d.flags &= ~_lib.TCS_TAPS_PHASE
             d.dw_taps, d.dw_ksteps = self.taps.data_ptr(), self.nk
+            d.dw_taps_raw = None
         st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
         _lib.check(st, "ts_tcs_subblock_fwd")
         return out, t_out
@@ -190,10 +217,13 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
     taps, nk = (None, 0)
     if dw_w is not None:
         taps, nk = pack_dw_taps(cpu(dw_w), stride, dilation, padding)
-    taps_phase, nk_phase = None, 0
+    taps_phase, nk_phase, taps_raw, taps_phase_raw = None, 0, None, None
+    if dw_w is not None and stride == 1 and dilation == 1:
+        taps_raw = pack_dw_taps_raw(cpu(dw_w), padding).to(device)
     if dw_w is not None and stride == 1 and dilation == 2 and padding % 2 == 0 and res_w is None:
         taps_phase, nk_phase = pack_dw_taps(cpu(dw_w), 1, 1, padding // 2)
         taps_phase = tap_fragments(taps_phase).to(device)
+        taps_phase_raw = pack_dw_taps_raw(cpu(dw_w), padding // 2).to(device)
     c_res, res_p = 0, None
     if res_w is not None:
         r2 = cpu(res_w).reshape(res_w.shape[0], res_w.shape[1])
@@ -204,4 +234,5 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
     return TcsLayer(c_in=cin, c_out=cout, kernel=kernel, stride=stride, dilation=dilation, padding=padding,
                     depthwise=dw_w is not None, relu=relu, taps=None if taps is None else tap_fragments(taps).to(device), nk=nk,
                     pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
-                    res_stride=res_stride, out_fp32=out_fp32, taps_phase=taps_phase, nk_phase=nk_phase)
+                    res_stride=res_stride, out_fp32=out_fp32, taps_phase=taps_phase, nk_phase=nk_phase, taps_raw=taps_raw,
+                    taps_phase_raw=taps_phase_raw)
