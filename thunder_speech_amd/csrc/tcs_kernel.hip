@@ -775,11 +775,12 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   constexpr int XP = 2 * XJ;                      // 16 rows x 128*XJ bytes per wave, 1 KiB per instruction
   constexpr int IDP = (2 * TT + 63) / 64;         // identity rows: 16 rows x 2*TT bytes
   // Depthwise taps: RAW, not as Toeplitz fragments.  Per channel two copies of the zero-padded tap array wp[n] = w[n - 3 - d]
-  // (copy 1 shifted by one element), CST bytes per channel; Toeplitz row i of k-step k is wp[4k + 3 - i .. +3]: a 4-byte
-  // aligned pair of dwords of copy (i even) at dword 2k + (i < 2) -- one ds_read2_b32.  Half the bytes of the pre-shifted
-  // fragments, so the taps of a 16-channel group fit TWICE: the image of the NEXT stage is fetched by DMA at the start of the
-  // running one (a whole stage ahead of its first use) and no DMA sits inside the MFMA passes any more.
-  constexpr int CST = 16 * NK + 16;               // bytes per channel: 2 copies of 4 NK + 4 bf16
+  // (copy 1 shifted by one element), their dwords interleaved (dword j of copy c at byte 8 j + 4 c), CST bytes per channel;
+  // Toeplitz row i of k-step k is wp[4k + 3 - i .. +3] = dwords 2k + (i < 2) and the next one of copy (i even): one
+  // ds_read2_b32.  CST = 16 (mod 32) bytes puts the 8 channels x 4 rows of a half-wave on 32 different banks.  Half the bytes of
+  // the pre-shifted fragments, so the taps of a 16-channel group fit TWICE: the image of the NEXT stage is fetched by DMA at
+  // the start of the running one (a whole stage ahead of its first use) and no DMA sits inside the MFMA passes any more.
+  constexpr int CST = (16 * NK + 16) % 32 == 16 ? 16 * NK + 16 : 16 * NK + 32;
   constexpr int NTD = (16 * CST + 1023) / 1024;   // KiB (= DMA instructions) per 16-channel group and stage
   constexpr int TAPB = NTD * 1024;
   constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     const char* const xrow = DIL == 2 ? xs + ((size_t)row * xpitch + (q >> 1) * PHW + a.woff + (q & 1) * RUN) * 2
                                       : xs + ((size_t)row * xpitch + a.woff + q * RUN) * 2;
     // this lane's Toeplitz row inside a tap image: channel `row`, copy by the parity of q, one dword in for q < 2
-    const int tap_off = row * CST + ((lane & 1) ? 0 : CST / 2) + ((lane & 3) < 2 ? 4 : 0);
+    const int tap_off = row * CST + ((lane & 1) ? 0 : 4) + ((lane & 3) < 2 ? 8 : 0);
     int dw_out[M];
 #pragma unroll
     for (int m = 0; m < M; ++m)
@@ -888,7 +889,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     u32x2 T[NK];
     f32x4 d[M];
     constexpr int WD = TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS;
-    typedef unsigned u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
     const char* trow = tapl + tap_off;             // re-pointed at the running stage's image at every stage start
     auto xs_write = [&]() {
 #pragma unroll
@@ -906,7 +906,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       }
     };
     auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
-    auto tap_load = [&](int kk) { const u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(trow + kk * 8); T[kk] = u32x2{v[0], v[1]}; };
+    auto tap_load = [&](int kk) {
+      T[kk] = u32x2{*reinterpret_cast<const unsigned*>(trow + kk * 16), *reinterpret_cast<const unsigned*>(trow + kk * 16 + 8)};
+    };
     auto dw_begin = [&]() {
 #pragma unroll
       for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1190,7 +1192,7 @@ template <int NPASS, int XJ, int MT, int WM, int DIL = 1>
 static int launch_split(TcsArgs& a, hipStream_t stream) {
   constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);
   constexpr int ROWB = TT <= 128 ? 256 : 512;
-  constexpr int NK_ = NPASS * NKP, TAPB = (16 * (16 * NK_ + 16) + 1023) / 1024 * 1024;
+  constexpr int NK_ = NPASS * NKP, CST = (16 * NK_ + 16) % 32 == 16 ? 16 * NK_ + 16 : 16 * NK_ + 32, TAPB = (16 * CST + 1023) / 1024 * 1024;
   a.n_tt = (a.t_out + TT - 1) / TT;
   a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
   a.n_tiles = a.batch * a.n_tt * a.n_z;

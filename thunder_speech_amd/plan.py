@@ -61,10 +61,12 @@ def pack_dw_taps(w: torch.Tensor, stride: int, dilation: int, padding: int) -> T
 
 def pack_dw_taps_raw(w: torch.Tensor, padding: int) -> torch.Tensor:
     """w: [C, 1, K] depthwise taps of a stride-1, dilation-1 conv -> the RAW tap image of the split kernel, bf16
-    [C_pad64/64][4][TAPB/2]: per 16-channel group a KiB-padded block, per channel CST = 16 NK + 16 bytes holding two copies of the
-    zero-padded array wp[n] = w[n - 3 - d] (d = round_up(padding, 4) - padding, n < 4 NK + 4), the second shifted by one
-    element.  Toeplitz row i of k-step k (pack_dw_taps: row_i[v] = w[v - i - d]) is wp[4k + 3 - i .. 4k + 6 - i], i.e. a
-    4-byte-aligned pair of dwords of copy (i even): half the bytes of the four pre-shifted rows."""
+    [C_pad64/64][4][TAPB/2]: per 16-channel group a KiB-padded block, per channel CST bytes (16 NK + 16 rounded up to 16 mod 32,
+    so that a half-wave's reads fall on 32 different LDS banks) holding two copies of the zero-padded array
+    wp[n] = w[n - 3 - d] (d = round_up(padding, 4) - padding, n < 4 NK + 4), the second shifted by one element, with their
+    DWORDS INTERLEAVED: dword j of copy c sits at byte 8 j + 4 c.  Toeplitz row i of k-step k (pack_dw_taps: row_i[v] =
+    w[v - i - d]) is wp[4k + 3 - i .. 4k + 6 - i] = dwords 2k + (i < 2) and the following one of copy (i even): half the bytes
+    of the four pre-shifted rows."""
     c, _, k = w.shape
     nk = dw_ksteps(k, 1, 1, padding)
     d = round_up(padding, 4) - padding
@@ -72,13 +74,19 @@ def pack_dw_taps_raw(w: torch.Tensor, padding: int) -> torch.Tensor:
     cp = round_up(c, KC)
     wp = torch.zeros(cp, n + 1, dtype=torch.float32, device=w.device)
     wp[:c, 3 + d: 3 + d + k] = w[:, 0, :]
-    img = torch.stack([wp[:, :n], wp[:, 1: n + 1]], dim=1)                  # [C, 2 copies, n]
-    cst = 16 * nk + 16                                                        # bytes per channel
+    pairs = torch.stack([wp[:, :n].reshape(cp, n // 2, 2), wp[:, 1: n + 1].reshape(cp, n // 2, 2)], dim=2)   # [C, dword j, copy, 2]
+    cst = raw_tap_channel_stride(nk)
+    chan = torch.zeros(cp, cst // 2, dtype=torch.float32, device=w.device)
+    chan[:, : 2 * n] = pairs.reshape(cp, 2 * n)
     tapb = (16 * cst + 1023) // 1024 * 1024
-    grp = img.reshape(cp // 16, 16 * 2 * n)                                   # one row per 16-channel group (cst / 2 elements per channel)
     out = torch.zeros(cp // 16, tapb // 2, dtype=torch.float32, device=w.device)
-    out[:, : 16 * 2 * n] = grp
+    out[:, : 16 * cst // 2] = chan.reshape(cp // 16, 16 * cst // 2)
     return out.to(torch.bfloat16).reshape(cp // KC, 4, tapb // 2).contiguous()
+
+
+def raw_tap_channel_stride(nk: int) -> int:
+    """Bytes per channel of the raw tap image (mirror of CST in csrc/tcs_kernel.hip)."""
+    return 16 * nk + 16 if (16 * nk + 16) % 32 == 16 else 16 * nk + 32
 
 
 def tap_fragments(taps: torch.Tensor) -> torch.Tensor:
