@@ -70,6 +70,15 @@ def load_components_from_citrinet_config(config_path: Union[str, Path, Dict], se
     return encoder, audio_transform, text_transform
 
 
+def _find_tokenizer(root: Path) -> Path:
+    """`tokenizer.model` (what the reference opens, citrinet/compatibility.py:156); newer NeMo archives prefix the file name with
+    a content hash, so any `*tokenizer.model` is accepted."""
+    found = sorted(root.rglob("tokenizer.model")) or sorted(root.rglob("*tokenizer.model"))
+    if not found:
+        raise FileNotFoundError("the .nemo archive holds no sentencepiece tokenizer.model")
+    return found[0]
+
+
 def load_citrinet_checkpoint(checkpoint: Union[str, CitrinetCheckpoint], save_folder: Optional[str] = None,
                              augment_params: Optional[dict] = None) -> BaseCTCModule:
     """Local `.nemo` file (or a checkpoint name whose file already sits in `save_folder` / `~/.thunder`) -> module."""
@@ -85,7 +94,7 @@ def load_citrinet_checkpoint(checkpoint: Union[str, CitrinetCheckpoint], save_fo
             tar.extractall(tmp, filter="data")      # untrusted archive: no absolute paths, links out of tmp, devices
         root = Path(tmp)
         encoder, audio_transform, text_transform = load_components_from_citrinet_config(
-            next(root.rglob("model_config.yaml")), next(root.rglob("tokenizer.model")), augment_params)
+            next(root.rglob("model_config.yaml")), _find_tokenizer(root), augment_params)
         decoder = conv1d_decoder(640, num_classes=text_transform.num_tokens)
         load_quartznet_weights(encoder, decoder, str(next(root.rglob("model_weights.ckpt"))))
     return BaseCTCModule(encoder=encoder, decoder=decoder, audio_transform=audio_transform, text_transform=text_transform,
