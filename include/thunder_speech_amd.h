@@ -154,16 +154,12 @@ const float* ts_frontend_logmel_ptr(const ts_frontend_desc* desc, const void* wo
  *   ts_spec_mask_apply : features[b][f0:f1][t0:t1] = 0 on a [B][channels][pitch] tensor, in place; elem_bytes = 2 (bf16, the
  *     internal layout) or 4 (f32, a reference-layout tensor handed to the standalone module).  ts_mel_frontend_fwd
  *     applies the same table inside its normaliser when ts_frontend_desc.masks is set (no extra pass).
- *   ts_dropout : y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) per element from (seed, element index) -- nn.Dropout in
- *     train mode (quartznet/blocks.py:227-228, blocks.py:238); the backward pass is the same call on dy with the same seed.
- *     x, y f32, 16-byte aligned, may alias.
  * ---------------------------------------------------------------------------------------------- */
 int ts_spec_masks_draw(uint64_t seed, int32_t n_time, int32_t time_width, int32_t n_freq, int32_t freq_width, int32_t n_cutout,
                        int32_t cut_time_width, int32_t cut_freq_width, int32_t n_mels, int32_t n_frames, int32_t* table,
                        void* stream);
 int ts_spec_mask_apply(void* features, int32_t elem_bytes, int32_t batch, int32_t channels, int32_t t, int32_t pitch,
                        const int32_t* table, int32_t n_masks, void* stream);
-int ts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy CTC decode: argmax over classes then run-collapse (torch.unique_consecutive), replaces
@@ -209,8 +205,11 @@ int ts_grad_wire_pack(const float* grad, void* wire_bf16, int64_t n, float scale
 int ts_grad_wire_unpack(const void* wire_bf16, float* grad, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Training-mode encoder ops (fine-tuning with the encoder unfrozen), first unfused version: fp32 activations in the
- * reference layout [B][C][T] (contiguous), one entry point per reference op and direction.  Lengths are int32 [B].
+ * Training-mode encoder ops (fine-tuning with the encoder unfrozen): one entry point per reference op and direction.
+ * Activations are [B][C][pitch] rows, time contiguous, pitch a multiple of 8 elements with 16-byte (bf16) / 32-byte (f32)
+ * aligned rows; columns >= T are scratch.  `act` selects the element type of every activation pointer of the call:
+ * 0 = f32 (the reference's arithmetic), 1 = bf16 storage with f32 arithmetic inside the kernels (mixed precision).
+ * Parameters, their gradients, statistics and lengths (int32 [B]) are f32 / int32 in both modes.
  *   depthwise MaskedConv1d (quartznet/blocks.py:169-182, groups = C): x masked by len_in; y masked by len_out when given
  *   1x1 MaskedConv1d: plain GEMMs (rocBLAS) on inputs the caller has masked with ts_train_mask_time
  *   BatchNorm1d in train mode (quartznet/blocks.py:222, statistics over all B*T frames incl. padding -- quirk A4 --,
@@ -218,45 +217,55 @@ int ts_grad_wire_unpack(const void* wire_bf16, float* grad, int64_t n, void* str
  *   residual add + ReLU (quartznet/blocks.py:332-337)
  * Workspaces: pwconv_bwd B*c_out*c_in floats; bn_fwd and bn_bwd 16*C doubles each (8 clip-group partial sums).
  * ---------------------------------------------------------------------------------------------- */
-int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* y, int32_t batch,
+/* reference layout f32 [rows][t] (contiguous) <-> pitched activation rows: the boundary of the training path */
+int ts_train_act_import(const float* src, void* dst, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+int ts_train_act_export(const void* src, float* dst, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
                         int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride, int32_t dilation,
-                        int32_t padding, void* stream);
+                        int32_t padding, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);
 /* len_out (may be NULL) in both directions: the forward zeroes y from len_out[b] on -- the re-masking the next MaskedConv1d applies
  * (quartznet/blocks.py:169-171) -- and the backward treats dy as zero there; no separate masking pass is needed then. */
-int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* dx,
+int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* dx,
                         float* dw, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride,
-                        int32_t dilation, int32_t padding, void* stream);
-int ts_train_mask_time(const float* x, const int32_t* len, float* y, int32_t batch, int32_t channels, int32_t t, void* stream);
-/* precision (pointwise convs): 0 = f32 GEMM operands; 1 = bf16 operands (u, w, dv are bf16 copies made by ts_train_cast_bf16),
- * f32 accumulation and f32 results -- the opt-in mixed-precision mode of the fine-tuning step. */
+                        int32_t dilation, int32_t padding, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);
+int ts_train_mask_time(const void* x, const int32_t* len, void* y, int32_t batch, int32_t channels, int32_t t, int32_t pitch_x,
+                       int32_t pitch_y, int32_t act, void* stream);
+/* pointwise convs.  precision: 0 = f32 operands and results; 1 = bf16 operands (u, dv; w = a bf16 copy made by ts_train_cast_bf16),
+ * f32 results (the decoder's logits); 2 = bf16 operands AND bf16 results (the mixed-precision encoder).  f32 accumulation always;
+ * d weight is f32 always. */
 int ts_train_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
-int ts_train_pwconv_fwd(const void* u, const void* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t, int32_t precision,
-                        void* stream);
-int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, float* du, float* dw, float* workspace, int32_t batch,
-                        int32_t c_in, int32_t c_out, int32_t t, int32_t precision, void* stream);
+int ts_train_pwconv_fwd(const void* u, const void* w, void* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t, int32_t pitch_u,
+                        int32_t pitch_v, int32_t precision, void* stream);
+int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, void* du, float* dw, float* workspace, int32_t batch,
+                        int32_t c_in, int32_t c_out, int32_t t, int32_t pitch_u, int32_t pitch_v, int32_t precision, void* stream);
 /* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
  * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */
-int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace, int32_t batch,
-                    int32_t channels, int32_t t, float eps, int32_t relu, float* running_mean, float* running_var, float momentum,
-                    int64_t* num_batches_tracked, void* stream);
-int ts_train_bn_bwd(const float* dy, const float* y, const float* v, const float* gamma, const float* mean_rstd, float* dv,
-                    float* dgamma, float* dbeta, void* workspace, int32_t batch, int32_t channels, int32_t t, int32_t relu,
-                    void* stream);
-int ts_train_add_relu_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
-int ts_train_relu_bwd(const float* dout, const float* out, float* din, int64_t n, void* stream);
+int ts_train_bn_fwd(const void* v, const float* gamma, const float* beta, void* y, float* mean_rstd, void* workspace, int32_t batch,
+                    int32_t channels, int32_t t, int32_t pitch, float eps, int32_t relu, float* running_mean, float* running_var,
+                    float momentum, int64_t* num_batches_tracked, int32_t act, void* stream);
+int ts_train_bn_bwd(const void* dy, const void* y, const void* v, const float* gamma, const float* mean_rstd, void* dv,
+                    float* dgamma, float* dbeta, void* workspace, int32_t batch, int32_t channels, int32_t t, int32_t pitch,
+                    int32_t relu, int32_t act, void* stream);
+int ts_train_add_relu_fwd(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+int ts_train_relu_bwd(const void* dout, const void* out, void* din, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
 /* strided 1x1 MaskedConv1d (residual branch of a strided block: quartznet/blocks.py:301-311, citrinet/blocks.py:156-165) =
  * this mask + subsample pass followed by the pointwise GEMM.  backward = 0: y[b,c,j] = x[b,c,j*stride] if j*stride < len[b] else 0
- * (x [B][C][t_in], y [B][C][t_out]); backward = 1: x is dy [B][C][t_out], y is dx [B][C][t_in], zero where the forward read nothing. */
-int ts_train_subsample_mask(const float* x, const int32_t* len, float* y, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out,
-                            int32_t stride, int32_t backward, void* stream);
+ * (x rows of t_in, y rows of t_out); backward = 1: x is dy (t_out), y is dx (t_in), zero where the forward read nothing. */
+int ts_train_subsample_mask(const void* x, const int32_t* len, void* y, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out,
+                            int32_t stride, int32_t backward, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);
 /* SqueezeExcite in train mode (citrinet/blocks.py:70-83), the passes over the [rows = B*C][t] activation:
  *   ts_train_se_pool   mean[row] = mean_t x[row][t]           (AdaptiveAvgPool1d(1) over ALL frames, quirk A3)
  *   ts_train_se_scale  y = x * gate[row] (+ add_mean[row] / t when add_mean != NULL: the pooled gradient, backward pass)
  *   ts_train_se_rowdot out[row] = sum_t a[row][t] * b[row][t]  (d gate = sum_t dy * x)
- * The [B, C] bottleneck in between (Linear -> ReLU -> Linear -> sigmoid) is a few tiny GEMMs on the caller's side. */
-int ts_train_se_pool(const float* x, float* mean, int64_t rows, int32_t t, void* stream);
-int ts_train_se_scale(const float* x, const float* gate, const float* add_mean, float* y, int64_t rows, int32_t t, void* stream);
-int ts_train_se_rowdot(const float* a, const float* b, float* out, int64_t rows, int32_t t, void* stream);
+ * mean / gate / add_mean / out are f32 [rows].  The [B, C] bottleneck in between is a few tiny GEMMs on the caller's side. */
+int ts_train_se_pool(const void* x, float* mean, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+int ts_train_se_scale(const void* x, const float* gate, const float* add_mean, void* y, int64_t rows, int32_t t, int32_t pitch,
+                      int32_t act, void* stream);
+int ts_train_se_rowdot(const void* a, const void* b, float* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+/* nn.Dropout in train mode on activation rows (quartznet/blocks.py:227-228, blocks.py:238): y = x * keep / (1 - p), keep ~
+ * Bernoulli(1 - p) from the Philox stream (seed, element index row * t + i) -- independent of pitch and element type; the backward
+ * pass is the same call on dy with the same seed.  x and y may alias. */
+int ts_train_dropout(const void* x, void* y, int64_t rows, int32_t t, int32_t pitch, float p, uint64_t seed, int32_t act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * wav2vec2 waveform normalisation, replaces Wav2Vec2Preprocess.forward (huggingface/transform.py:34-55 -> normalize_tensor,

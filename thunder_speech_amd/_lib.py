@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
     "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_attention_workspace_bytes",
     "ts_w2v_attention_fwd",
-    "ts_spec_masks_draw", "ts_spec_mask_apply", "ts_dropout",
+    "ts_spec_masks_draw", "ts_spec_mask_apply", "ts_train_dropout", "ts_train_act_import", "ts_train_act_export",
     "ts_audio_prep_workspace_bytes", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance", "ts_encode_chars",
     "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot",
     "ts_grad_wire_pack", "ts_grad_wire_unpack",
@@ -133,38 +133,38 @@ def lib() -> C.CDLL:
     for fn in ("ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd", "ts_w2v_mask_rows",
                "ts_w2v_posconv_fwd", "ts_w2v_attention_fwd"):
         getattr(L, fn).restype = C.c_int
-    L.ts_train_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
-    L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [i32] * 8 + [vp]
-    L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, vp]
-    L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.ts_train_act_import.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_act_export.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_dwconv_fwd.argtypes = [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]
+    L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [i32] * 11 + [vp]
+    L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_cast_bf16.argtypes = [vp, vp, i64, vp]
-    L.ts_train_cast_bf16.restype = C.c_int
-    L.ts_train_pwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
-    L.ts_train_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, f32, vp, vp]
-    L.ts_train_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    L.ts_train_add_relu_fwd.argtypes = [vp, vp, vp, i64, vp]
-    L.ts_train_relu_bwd.argtypes = [vp, vp, vp, i64, vp]
-    for fn in ("ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd",
-               "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd"):
-        getattr(L, fn).restype = C.c_int
+    L.ts_train_pwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.ts_train_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, vp, f32, vp, i32, vp]
+    L.ts_train_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.ts_train_add_relu_fwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_relu_bwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
     u64 = C.c_uint64
+    L.ts_train_subsample_mask.argtypes = [vp, vp, vp] + [i32] * 9 + [vp]
+    L.ts_train_se_pool.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_se_scale.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_se_rowdot.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_dropout.argtypes = [vp, vp, i64, i32, i32, f32, u64, i32, vp]
+    for fn in ("ts_train_act_import", "ts_train_act_export", "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time",
+               "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd",
+               "ts_train_add_relu_fwd", "ts_train_relu_bwd", "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale",
+               "ts_train_se_rowdot", "ts_train_dropout"):
+        getattr(L, fn).restype = C.c_int
     L.ts_spec_masks_draw.argtypes = [u64] + [i32] * 9 + [vp, vp]
     L.ts_spec_mask_apply.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp]
-    L.ts_dropout.argtypes = [vp, vp, i64, f32, u64, vp]
     L.ts_audio_prep_workspace_bytes.argtypes = [i64]
     L.ts_audio_prep_workspace_bytes.restype = i64
     L.ts_audio_prep.argtypes = [vp, i32, i64, vp, i32, i32, i32, i32, vp, i64, vp, vp]
     L.ts_collate_pad.argtypes = [vp, i32, i64, vp, vp]
     L.ts_edit_distance.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     L.ts_encode_chars.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    for fn in ("ts_spec_masks_draw", "ts_spec_mask_apply", "ts_dropout", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance",
-               "ts_encode_chars"):
-        getattr(L, fn).restype = C.c_int
-    L.ts_train_subsample_mask.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
-    L.ts_train_se_pool.argtypes = [vp, vp, i64, i32, vp]
-    L.ts_train_se_scale.argtypes = [vp, vp, vp, vp, i64, i32, vp]
-    L.ts_train_se_rowdot.argtypes = [vp, vp, vp, i64, i32, vp]
-    for fn in ("ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot"):
+    for fn in ("ts_spec_masks_draw", "ts_spec_mask_apply", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance", "ts_encode_chars"):
         getattr(L, fn).restype = C.c_int
     L.ts_grad_wire_pack.argtypes = [vp, vp, i64, f32, vp]
     L.ts_grad_wire_unpack.argtypes = [vp, vp, i64, vp]

@@ -108,7 +108,7 @@ class _Conv1dDecoder(nn.Conv1d):
             # way (GEMM forward / backward in train_ops.PointwiseConv); the bias add on the [B, V, T] logits is the one
             # broadcast left to autograd
             from .train_ops import PointwiseConv
-            return PointwiseConv.apply(x, self.weight) + self.bias.view(1, -1, 1)
+            return PointwiseConv.apply(x, self.weight, True) + self.bias.view(1, -1, 1)       # f32 logits in either activation mode
         xi = _t.pack(x)
         b, _, t = xi.shape
         if self.training and grad_on and (self.weight.requires_grad or self.bias.requires_grad):
@@ -176,9 +176,8 @@ class _LinearDecoder(nn.Sequential):
             # training path (blocks.py:226-248: transpose -> dropout -> Linear -> transpose): dropout is elementwise and the
             # Linear over the channel axis is a 1x1 conv on [B, C, T], so the two transposes cancel here as well
             from . import train_ops as T
-            h = _t.unpack(x) if _t.is_internal(x) else x.to(torch.float32)
-            h = T.dropout(h, drop.p, drop.training)
-            return T.PointwiseConv.apply(h, lin.weight.unsqueeze(-1)) + lin.bias.view(1, -1, 1)
+            h = T.dropout(T.to_act(x), drop.p, drop.training)
+            return T.PointwiseConv.apply(h, lin.weight.unsqueeze(-1), True) + lin.bias.view(1, -1, 1)
         layer = self._cache.get([lin.weight, lin.bias], lambda: _plan.make_tcs_layer(
             lin.weight.device, dw_w=None, pw_w=lin.weight.detach(), bn=None, kernel=1, stride=1, dilation=1,
             padding=0, relu=False, bias_extra=lin.bias.detach(), out_fp32=True))

@@ -1,4 +1,4 @@
-// Training-time augmentation on the device: SpecAugment / SpecCutout mask geometry + application, dropout.
+// Training-time augmentation on the device: SpecAugment / SpecCutout mask geometry + application (dropout: csrc/train_extra.hip).
 //
 // Reference: quartznet/spec_augment.py:23-102 (SpecAugment = torchaudio.functional.mask_along_axis per mask, SpecCutout =
 // _create_mask twice per rectangle), wired into FilterbankFeatures after the normaliser (quartznet/transform.py:299-320);
@@ -9,8 +9,6 @@
 //   * ts_spec_mask_apply zeroes the rectangles of an existing feature tensor (standalone module call);
 //   * ts_spec_masks_draw fills the table from a Philox stream on the device (graph-capturable); the Python side can also
 //     fill it with the reference's own host draws, which reproduces the reference bit for bit under torch.manual_seed.
-// Dropout is y = x * keep / (1 - p) with keep ~ Bernoulli(1 - p) drawn per element from (seed, element index): the backward
-// pass re-draws the same mask from the seed, nothing is stored.
 #include "ts_common.hpp"
 #include "ts_philox.hpp"
 
@@ -72,25 +70,6 @@ __global__ __launch_bounds__(256) void spec_apply_kernel(E* __restrict__ x, int 
   for (int idx = threadIdx.x; idx < (f1 - f0) * w; idx += 256) base[(size_t)(f0 + idx / w) * pitch + t0 + idx % w] = E(0);
 }
 
-__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float p,
-                                                       float scale, unsigned long long seed) {
-  // 4 elements per thread = one Philox call; grid-stride
-  const long long n4 = (n + 3) >> 2;
-  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n4; g += (long long)gridDim.x * 256) {
-    const Philox4 r = philox(seed, PHILOX_DROPOUT, (unsigned long long)g);
-    const long long e = g << 2;
-    if (e + 3 < n) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = u01(r.v[i]) >= p ? v[i] * scale : 0.f;
-      *reinterpret_cast<f32x4*>(y + e) = o;
-    } else {
-      for (int i = 0; i < 4 && e + i < n; ++i) y[e + i] = u01(r.v[i]) >= p ? x[e + i] * scale : 0.f;
-    }
-  }
-}
-
 }  // namespace ts
 
 extern "C" int ts_spec_masks_draw(uint64_t seed, int32_t n_time, int32_t time_width, int32_t n_freq, int32_t freq_width,
@@ -116,19 +95,5 @@ extern "C" int ts_spec_mask_apply(void* features, int32_t elem_bytes, int32_t ba
   else
     hipLaunchKernelGGL(ts::spec_apply_kernel<float>, dim3(n_masks, batch), dim3(256), 0, (hipStream_t)stream,
                        static_cast<float*>(features), channels, t, pitch, table);
-  return ts::hip_status(hipGetLastError());
-}
-
-extern "C" int ts_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
-  if (!x || !y || n < 0 || !(p >= 0.f) || p > 1.f) return TS_EINVAL;
-  if (!n) return TS_OK;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return TS_EINVAL;
-  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
-  const long long n4 = (n + 3) >> 2;
-  const long long blocks = (n4 + 255) / 256;
-  const int grid = (int)(blocks < 2048 ? blocks : 2048);
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(ts::dropout_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, p, scale,
-                     (unsigned long long)seed);
   return ts::hip_status(hipGetLastError());
 }

@@ -1,7 +1,10 @@
-// Training-mode encoder kernels (fine-tuning phase 2: encoder unfrozen).  First, unfused version:
-// fp32 activations in the reference layout [B][C][T] (contiguous), one launch per reference op, so that every op's
-// forward AND backward can be checked against the oracle's autograd.  The pointwise convolutions and their two backward
-// products are plain GEMMs and go to rocBLAS (the only library calls in this repo); everything else is hand-written.
+// Training-mode encoder kernels (fine-tuning phase 2: encoder unfrozen): one launch per reference op and
+// direction, so that every op's forward AND backward can be checked against the oracle's autograd.  Activations are [B][C][pitch]
+// rows (time contiguous, pitch a multiple of 8 elements, 16-byte aligned rows; columns >= T are scratch) in one of two element
+// types, selected per call by `act`: 0 = f32 (the reference's arithmetic), 1 = bf16 storage with f32 arithmetic inside every
+// kernel (mixed precision: half the activation traffic, bf16 MFMA GEMMs; parameters, gradients of parameters, statistics stay
+// f32).  The pointwise convolutions and their two backward products are plain GEMMs and go to rocBLAS; everything else is
+// hand-written.
 //   masked depthwise conv fwd / bwd-data / bwd-weight   quartznet/blocks.py:169-182 (MaskedConv1d, groups = C)
 //   masked 1x1 conv fwd / bwd-data / bwd-weight          same class, kernel_size = 1            (rocBLAS sgemm)
 //   BatchNorm1d(train) [+ ReLU] fwd / bwd                quartznet/blocks.py:222 (eps 1e-3), statistics over ALL B*T frames (A4)
@@ -18,17 +21,66 @@ __device__ __forceinline__ int clamp_len(const int* len, int b, int t) {
   return l < 0 ? 0 : (l > t ? t : l);
 }
 
+// element access of the two activation types (f32 / bf16 bits)
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float ldf(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ldf(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
+__device__ __forceinline__ void stf(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void stf(bf16_t* p, size_t i, float v) { p[i] = (bf16_t)(pack_bf16(v, 0.f) & 0xffffu); }
+// 8 consecutive elements of a 16-byte aligned row position
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const u32x4 a = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_lo(a[j]); v[2 * j + 1] = bf16_hi(a[j]); }
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+}
+
 constexpr int DW_TILE = 1024;      // output frames per workgroup (forward) / input frames per workgroup (backward-data)
 constexpr int DW_KMAX = 128;       // taps cached in LDS
 
+// 8 consecutive outputs of a stride-1 FIR out of LDS: acc[m] = sum_j taps[j] * xp[m + j], j < k8 (a multiple of 8; taps are
+// zero-padded).  Eight taps at a time: two 16-byte reads fetch the taps (same address in every lane: broadcast), two more the
+// next 8 samples of the window; the 64 FMAs of the step index a 16-register window statically -- no per-tap register shifts,
+// 4 LDS reads per 64 FMAs (the one-tap-at-a-time loop needs 16 reads and 56 moves).  xp and taps must be 16-byte aligned.
+__device__ __forceinline__ void fir8(const float* __restrict__ xp, const float* __restrict__ taps, int k8, float (&acc)[8]) {
+  float win[16];
+  {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xp), b = *reinterpret_cast<const f32x4*>(xp + 4);
+    win[0] = a[0]; win[1] = a[1]; win[2] = a[2]; win[3] = a[3]; win[4] = b[0]; win[5] = b[1]; win[6] = b[2]; win[7] = b[3];
+  }
+  for (int j0 = 0; j0 < k8; j0 += 8) {
+    const f32x4 c = *reinterpret_cast<const f32x4*>(xp + j0 + 8), d = *reinterpret_cast<const f32x4*>(xp + j0 + 12);
+    win[8] = c[0]; win[9] = c[1]; win[10] = c[2]; win[11] = c[3]; win[12] = d[0]; win[13] = d[1]; win[14] = d[2]; win[15] = d[3];
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(taps + j0), w1 = *reinterpret_cast<const f32x4*>(taps + j0 + 4);
+    const float w[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m] = fmaf(w[jj], win[m + jj], acc[m]);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) win[m] = win[m + 8];
+  }
+}
+
 // y[b,c,t] = sum_k w[c,k] * xm[b,c,t*s + k*d - p],  xm = x zeroed from len_in[b] on;  y zeroed from len_out[b] on when given.
 // One workgroup = one (clip, channel) row segment of DW_TILE outputs: the input span and the taps are staged in LDS once.
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const int* __restrict__ len_in,
+template <class T>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, const int* __restrict__ len_in,
                                                      const int* __restrict__ len_out, const float* __restrict__ w,
-                                                     float* __restrict__ y, int batch, int ch, int t_in, int t_out, int k, int s,
-                                                     int d, int p) {
-  extern __shared__ float sm[];
-  float* const ws = sm;                 // [k]
+                                                     T* __restrict__ y, int batch, int ch, int t_in, int t_out, int k, int s,
+                                                     int d, int p, int pitch_in, int pitch_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* const ws = sm;                 // [k], zero-padded to a multiple of 8
   float* const xs = sm + DW_KMAX;       // [span]
   const int row = blockIdx.y, b = row / ch, c = row % ch;
   const int t0 = blockIdx.x * DW_TILE;
@@ -36,34 +88,24 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
   const int i0 = t0 * s - p;
   const int span = (nt - 1) * s + (k - 1) * d + 1;
   const int li = clamp_len(len_in, b, t_in);
-  const float* xr = x + (size_t)row * t_in;
-  for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
-  for (int e = threadIdx.x; e < span + 14; e += 256) {      // + 14: overreach of the 8-output sliding window (zeros)
+  const T* xr = x + (size_t)row * pitch_in;
+  T* const yr = y + (size_t)row * pitch_out;
+  const int k8 = (k + 7) & ~7;
+  for (int j = threadIdx.x; j < k8; j += 256) ws[j] = j < k ? w[(size_t)c * k + j] : 0.f;
+  for (int e = threadIdx.x; e < span + 24; e += 256) {      // + 24: overreach of the 8-output x 8-tap window (zeros)
     const int i = i0 + e;
-    xs[e] = (e < span && i >= 0 && i < li) ? xr[i] : 0.f;
+    xs[e] = (e < span && i >= 0 && i < li) ? ldf(xr, i) : 0.f;
   }
   __syncthreads();
   const int lo = len_out ? clamp_len(len_out, b, t_out) : t_out;
   if (s == 1 && d == 1) {
-    // every body layer: 4 consecutive outputs per thread, the input window slides through registers -- per tap one LDS read
-    // of the weight (broadcast) and one of the next sample feed 4 FMAs (the one-output form needs 2 reads per FMA)
-    for (int t8 = threadIdx.x * 8; t8 < nt; t8 += 2048) {    // 8 outputs per thread: 2 LDS reads per 8 FMAs
+    // every body layer: 8 consecutive outputs per thread through the 8-tap micro-kernel
+    for (int t8 = threadIdx.x * 8; t8 < nt; t8 += 2048) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const float* xp = xs + t8;                          // xs holds (nt - 1) + k samples (+ zero slack); excess outputs are discarded
-      float w[8];
-#pragma unroll
-      for (int m = 0; m < 7; ++m) w[m] = xp[m];
-      for (int j = 0; j < k; ++j) {
-        const float wj = ws[j];
-        w[7] = xp[j + 7];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) acc[m] = fmaf(wj, w[m], acc[m]);
-#pragma unroll
-        for (int m = 0; m < 7; ++m) w[m] = w[m + 1];
-      }
+      fir8(xs + t8, ws, k8, acc);                          // xs holds (nt - 1) + k samples (+ zero slack); excess outputs are discarded
 #pragma unroll
       for (int m = 0; m < 8; ++m)
-        if (t8 + m < nt) y[(size_t)row * t_out + t0 + t8 + m] = t0 + t8 + m < lo ? acc[m] : 0.f;
+        if (t8 + m < nt) stf(yr, t0 + t8 + m, t0 + t8 + m < lo ? acc[m] : 0.f);
     }
     return;
   }
@@ -71,17 +113,18 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     float acc = 0.f;
     const float* xp = xs + tt * s;
     for (int j = 0; j < k; ++j) acc = fmaf(ws[j], xp[j * d], acc);
-    y[(size_t)row * t_out + t0 + tt] = t0 + tt < lo ? acc : 0.f;
+    stf(yr, t0 + tt, t0 + tt < lo ? acc : 0.f);
   }
 }
 
 // dx[b,c,i] = (i < len_in) ? sum_k w[c,k] * dy[b,c,(i + p - k*d)/s] : 0    (terms with a non-integer or out-of-range index drop out)
 // One workgroup = DW_TILE input frames of one row; the dy span that can reach them is staged in LDS.
-__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const int* __restrict__ len_in,
+template <class T>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const T* __restrict__ dy, const int* __restrict__ len_in,
                                                           const int* __restrict__ len_out, const float* __restrict__ w,
-                                                          float* __restrict__ dx, int batch, int ch, int t_in, int t_out, int k, int s,
-                                                          int d, int p) {
-  extern __shared__ float sm[];
+                                                          T* __restrict__ dx, int batch, int ch, int t_in, int t_out, int k, int s,
+                                                          int d, int p, int pitch_in, int pitch_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* const ws = sm;
   float* const gs = sm + DW_KMAX;
   const int row = blockIdx.y, b = row / ch, c = row % ch;
@@ -91,40 +134,33 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
   const int n_lo = i0 + p - (k - 1) * d, n_hi = i0 + ni - 1 + p;
   const int g0 = n_lo <= 0 ? 0 : (n_lo + s - 1) / s;
   const int g1 = n_hi < 0 ? -1 : (n_hi / s < t_out - 1 ? n_hi / s : t_out - 1);
-  const float* gr = dy + (size_t)row * t_out;
+  const T* gr = dy + (size_t)row * pitch_out;
+  T* const dxr = dx + (size_t)row * pitch_in;
   for (int j = threadIdx.x; j < k; j += 256) ws[j] = w[(size_t)c * k + j];
   const int li = clamp_len(len_in, b, t_in);
   const int lo = len_out ? clamp_len(len_out, b, t_out) : t_out;     // the forward zeroed y from here on: so is its gradient
   if (s == 1 && d == 1) {
-    // every body layer: gs2[e] = dy[n_lo + e] with zeros outside the row, dx[i0 + ii] = sum_j w[j] gs2[ii + k - 1 - j];
-    // 4 consecutive outputs per thread, the window slides DOWN one sample per tap (2 LDS reads per 4 FMAs, no bounds checks)
-    const int n2 = ni + k - 1 + 14;
+    // every body layer: the same FIR with the taps FLIPPED: dx[i0 + ii] = sum_j' w[k-1-j'] gs[8 + ii + j'], gs[8 + q] = dy[n_lo + q]
+    // (zeros outside the row; 8 zero samples in front keep the window reads aligned, the flipped taps are padded at the END)
+    const int k8 = (k + 7) & ~7;
+    __syncthreads();                                        // ws is rewritten below (the loop above filled it in forward order)
+    for (int j = threadIdx.x; j < k8; j += 256) ws[j] = j < k ? w[(size_t)c * k + (k - 1 - j)] : 0.f;
+    const int n2 = ni + k - 1 + 8 + 24;
     for (int e = threadIdx.x; e < n2; e += 256) {
-      const int n = n_lo + e - 3;                           // 3 zero samples of slack below the window
-      gs[e] = (n >= 0 && n < lo) ? gr[n] : 0.f;
+      const int n = n_lo + e - 8;
+      gs[e] = (n >= 0 && n < lo) ? ldf(gr, n) : 0.f;
     }
     __syncthreads();
-    for (int i8 = threadIdx.x * 8; i8 < ni; i8 += 2048) {   // 8 outputs per thread: 2 LDS reads per 8 FMAs
+    for (int i8 = threadIdx.x * 8; i8 < ni; i8 += 2048) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const float* gp = gs + 3 + i8 + k - 1;                // sample of output i8, tap 0
-      float w[8];
-#pragma unroll
-      for (int m = 0; m < 8; ++m) w[m] = gp[m];
-      for (int j = 0; j < k; ++j) {
-        const float wj = ws[j];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) acc[m] = fmaf(wj, w[m], acc[m]);
-#pragma unroll
-        for (int m = 7; m > 0; --m) w[m] = w[m - 1];
-        w[0] = gp[-1 - j];
-      }
+      fir8(gs + 8 + i8, ws, k8, acc);
 #pragma unroll
       for (int m = 0; m < 8; ++m)
-        if (i8 + m < ni) dx[(size_t)row * t_in + i0 + i8 + m] = i0 + i8 + m < li ? acc[m] : 0.f;
+        if (i8 + m < ni) stf(dxr, i0 + i8 + m, i0 + i8 + m < li ? acc[m] : 0.f);
     }
     return;
   }
-  for (int e = threadIdx.x; e <= g1 - g0; e += 256) gs[e] = g0 + e < lo ? gr[g0 + e] : 0.f;
+  for (int e = threadIdx.x; e <= g1 - g0; e += 256) gs[e] = g0 + e < lo ? ldf(gr, g0 + e) : 0.f;
   __syncthreads();
   for (int ii = threadIdx.x; ii < ni; ii += 256) {
     const int i = i0 + ii;
@@ -145,7 +181,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
         }
       }
     }
-    dx[(size_t)row * t_in + i] = acc;
+    stf(dxr, i, acc);
   }
 }
 
@@ -153,24 +189,26 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
 // go through LDS once.  Thread = (group of 4 taps, contiguous slice of the frames); for stride 1 / dilation 1 (every layer but
 // the stem and the dilated one) it slides a 4-sample x window through registers: per frame 2 LDS reads feed 4 FMAs (the
 // one-tap-per-thread form needs 8).  fp32 partials per clip, fp64 across clips and slices.
-__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <class T>
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const int* __restrict__ len_in, const int* __restrict__ len_out,
                                                             float* __restrict__ dw, int batch, int ch, int t_in, int t_out, int k, int s,
-                                                            int d, int p) {
-  extern __shared__ float sm[];
-  float* const gs = sm;                       // [t_out]
-  float* const xs = sm + t_out + 4;           // [-p .. t_in + 7]: zero margins, so the sliding window needs no bounds checks
+                                                            int d, int p, int pitch_in, int pitch_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* const gs = sm;                       // [t_out], zero-padded to the 8-frame steps of the slices
+  const int gpad = round_up(t_out + 16, 4);
+  float* const xs = sm + gpad;                // [-p .. t_in + ...]: zero margins, so the sliding window needs no bounds checks
   const int xoff = p + 4;                     // xs index of input frame 0
-  const int xlen = t_in + 2 * p + 16;
-  double* const red = reinterpret_cast<double*>(sm + round_up(t_out + 4 + xlen, 2));   // [256][TG]
+  const int xlen = round_up(t_in + 2 * p + 48, 2);
+  double* const red = reinterpret_cast<double*>(sm + gpad + xlen);   // [256][TG]
   const int c = blockIdx.x;
   constexpr int TG = 8;                       // taps per thread
   const int ng = (k + TG - 1) / TG;           // tap groups
   const int nq = 256 / ng;                    // frame slices
   const int g = threadIdx.x % ng, q = threadIdx.x / ng;
   const bool active = q < nq;
-  const int per_q = (t_out + nq - 1) / nq;
-  const int t_lo = q * per_q, t_hi = t_lo + per_q < t_out ? t_lo + per_q : t_out;
+  const int per_q = (s == 1 && d == 1) ? round_up((t_out + nq - 1) / nq, 8) : (t_out + nq - 1) / nq;   // 8-frame steps (vector LDS reads)
+  const int t_lo = q * per_q < t_out ? q * per_q : t_out, t_hi = t_lo + per_q < t_out ? t_lo + per_q : t_out;
   double acc[TG];
 #pragma unroll
   for (int jj = 0; jj < TG; ++jj) acc[jj] = 0.0;
@@ -180,10 +218,10 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
     const int li = clamp_len(len_in, b, t_in);
     __syncthreads();
     const int lo = len_out ? clamp_len(len_out, b, t_out) : t_out;
-    for (int e = threadIdx.x; e < t_out; e += 256) gs[e] = e < lo ? dy[((size_t)b * ch + c) * t_out + e] : 0.f;
+    for (int e = threadIdx.x; e < gpad; e += 256) gs[e] = e < lo ? ldf(dy, ((size_t)b * ch + c) * pitch_out + e) : 0.f;
     for (int e = threadIdx.x; e < xlen; e += 256) {
       const int i = e - xoff;
-      xs[e] = (i >= 0 && i < li) ? x[((size_t)b * ch + c) * t_in + i] : 0.f;
+      xs[e] = (i >= 0 && i < li) ? ldf(x, ((size_t)b * ch + c) * pitch_in + i) : 0.f;
     }
     __syncthreads();
     if (active) {
@@ -191,18 +229,26 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
 #pragma unroll
       for (int jj = 0; jj < TG; ++jj) part[jj] = 0.f;
       if (s == 1 && d == 1) {
-        // taps TG g .. TG g + TG-1 of frame t read x[t + TG g - p + 0..TG-1]: a window that moves by one sample per frame
+        // taps TG g .. TG g + TG-1 of frame t read x[t + TG g - p + 0..TG-1].  8 frames per step: two 16-byte reads fetch the
+        // gradients, two more the next 8 samples of a 16-register window; the 64 FMAs index the window statically (4 LDS reads
+        // per 64 FMAs instead of 16).  Frames >= t_out hold zero gradients, so whole 8-frame steps are safe.
         const float* xw = xs + xoff + TG * g - p;
-        float w[TG];
+        float win[16];
+        if (t_lo < t_hi) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(xw + t_lo), b2 = *reinterpret_cast<const f32x4*>(xw + t_lo + 4);
+          win[0] = a[0]; win[1] = a[1]; win[2] = a[2]; win[3] = a[3]; win[4] = b2[0]; win[5] = b2[1]; win[6] = b2[2]; win[7] = b2[3];
+        }
+        for (int t = t_lo; t < t_hi; t += 8) {
+          const f32x4 c4 = *reinterpret_cast<const f32x4*>(xw + t + 8), d4 = *reinterpret_cast<const f32x4*>(xw + t + 12);
+          win[8] = c4[0]; win[9] = c4[1]; win[10] = c4[2]; win[11] = c4[3]; win[12] = d4[0]; win[13] = d4[1]; win[14] = d4[2]; win[15] = d4[3];
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + t), g1 = *reinterpret_cast<const f32x4*>(gs + t + 4);
+          const float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
 #pragma unroll
-        for (int jj = 0; jj < TG - 1; ++jj) w[jj] = xw[t_lo + jj];
-        for (int t = t_lo; t < t_hi; ++t) {
-          const float gv = gs[t];
-          w[TG - 1] = xw[t + TG - 1];
+          for (int m = 0; m < 8; ++m)
 #pragma unroll
-          for (int jj = 0; jj < TG; ++jj) part[jj] = fmaf(gv, w[jj], part[jj]);
+            for (int jj = 0; jj < TG; ++jj) part[jj] = fmaf(gv[m], win[m + jj], part[jj]);
 #pragma unroll
-          for (int jj = 0; jj < TG - 1; ++jj) w[jj] = w[jj + 1];
+          for (int m = 0; m < 8; ++m) win[m] = win[m + 8];
         }
       } else {
         for (int t = t_lo; t < t_hi; ++t) {
@@ -230,13 +276,25 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Row-wise streaming kernels: grid (rows = B * C, 2048-frame chunks), 256 threads x 8 elements (16 / 32 bytes per lane).
+// Rows are pitched and 16-byte aligned, so every access is a whole vector; columns >= t are scratch and may be overwritten.
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int ROW_CHUNK = 2048;
+
 // y = x with frames >= len[b] zeroed (the re-masking in front of every MaskedConv1d, and of gradients on the way back)
-__global__ __launch_bounds__(256) void mask_time_kernel(const float* __restrict__ x, const int* __restrict__ len, float* __restrict__ y,
-                                                        int batch, int ch, int t) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)batch * ch * t) return;
-  const int tt = (int)(idx % t), b = (int)(idx / ((long long)t * ch));
-  y[idx] = tt < clamp_len(len, b, t) ? x[idx] : 0.f;
+template <class T>
+__global__ __launch_bounds__(256) void mask_time_kernel(const T* __restrict__ x, const int* __restrict__ len, T* __restrict__ y,
+                                                        int ch, int t, int pitch_x, int pitch_y) {
+  const int row = blockIdx.x, b = row / ch;
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
+  const int l = clamp_len(len, b, t);
+  float v[8];
+  load8(x + (size_t)row * pitch_x + i, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = i + j < l ? v[j] : 0.f;
+  store8(y + (size_t)row * pitch_y + i, v);
 }
 
 // Per-channel sums over all B*T frames in BN_G clip groups (grid ch x BN_G): part[g][c] = (s1, s2), fp64 accumulation; the
@@ -246,10 +304,10 @@ __global__ __launch_bounds__(256) void mask_time_kernel(const float* __restrict_
 //          -- g and xhat are recomputed here and in the apply kernel instead of being written out and read back twice
 constexpr int BN_G = 8;
 
-template <int MODE>
-__global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict__ a, const float* __restrict__ y, const float* __restrict__ v,
+template <int MODE, class T>
+__global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ v,
                                                         const float* __restrict__ mean_rstd, double* __restrict__ part, int batch,
-                                                        int ch, int t, int relu) {
+                                                        int ch, int t, int pitch, int relu) {
   __shared__ double r1[256], r2[256];
   const int c = blockIdx.x, grp = blockIdx.y;
   const int per = (batch + BN_G - 1) / BN_G;
@@ -258,18 +316,24 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* __restrict_
   if (MODE == 1) { mu = mean_rstd[2 * c]; rs = mean_rstd[2 * c + 1]; }
   double s1 = 0.0, s2 = 0.0;
   for (int b = b_lo; b < b_hi; ++b) {
-    const size_t row = ((size_t)b * ch + c) * t;
-    for (int i = threadIdx.x; i < t; i += 256) {
-      if (MODE == 0) {
-        const double va = a[row + i];
-        s1 += va;
-        s2 += va * va;
-      } else {
-        const float gv = (relu && !(y[row + i] > 0.f)) ? 0.f : a[row + i];
-        const float xh = (v[row + i] - mu) * rs;
-        s1 += (double)gv;
-        s2 += (double)gv * (double)xh;
+    const size_t row = ((size_t)b * ch + c) * pitch;
+    for (int i = threadIdx.x * 8; i < t; i += 2048) {
+      float va[8], vy[8], vv[8];
+      load8(a + row + i, va);
+      if (MODE == 1) { load8(v + row + i, vv); if (relu) load8(y + row + i, vy); }
+      float p1 = 0.f, p2 = 0.f;                 // 8 terms in f32, then f64 across the row
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (i + j < t) {
+          if (MODE == 0) { p1 += va[j]; p2 = fmaf(va[j], va[j], p2); }
+          else {
+            const float gv = (relu && !(vy[j] > 0.f)) ? 0.f : va[j];
+            p1 += gv;
+            p2 = fmaf(gv, (vv[j] - mu) * rs, p2);
+          }
+        }
       }
+      s1 += (double)p1; s2 += (double)p2;
     }
   }
   r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
@@ -288,16 +352,15 @@ __device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch
 }
 
 // BatchNorm(train) forward: stats[c] = (sum v, sum v^2) -> mean, rstd (biased variance, eps), y = gamma*(v-mean)*rstd + beta [ReLU].
-// One workgroup per (clip, channel) row segment: the channel's statistics are reduced ONCE per workgroup (not per element) and the
-// row is streamed with no index arithmetic.
-__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v, const double* __restrict__ part,
+template <class T>
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const T* __restrict__ v, const double* __restrict__ part,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ y, float* __restrict__ mean_rstd, int batch, int ch, int t,
+                                                     T* __restrict__ y, float* __restrict__ mean_rstd, int batch, int ch, int t, int pitch,
                                                      float eps, int relu, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float momentum,
                                                      long long* __restrict__ num_batches_tracked) {
   __shared__ float sh[2];
-  const int row = blockIdx.x, c = row % ch;     // grid: x = (clip, channel) rows, y = 1024-frame chunks
+  const int row = blockIdx.x, c = row % ch;
   if (threadIdx.x == 0) {
     const double n = (double)batch * t;
     double s1, s2;
@@ -317,23 +380,28 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ v
     }
   }
   __syncthreads();
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
   const float mu = sh[0], sc = gamma[c] * sh[1], be = beta[c];
-  const size_t base = (size_t)row * t;
-  for (int i = blockIdx.y * 1024 + threadIdx.x; i < t && i < (int)(blockIdx.y + 1) * 1024; i += 256) {
-    float o = sc * (v[base + i] - mu) + be;
-    if (relu) o = o > 0.f ? o : 0.f;
-    y[base + i] = o;
+  float x[8];
+  load8(v + (size_t)row * pitch + i, x);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float o = sc * (x[j] - mu) + be;
+    x[j] = (relu && !(o > 0.f)) ? 0.f : o;
   }
+  store8(y + (size_t)row * pitch + i, x);
 }
 
-// dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (y > 0) when relu,  xhat = (v - mean) * rstd; same row-wise shape
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                           const float* __restrict__ v, const double* __restrict__ part,
-                                                           const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                                                           float* __restrict__ dv, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int batch, int ch, int t, int relu) {
+// dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (y > 0) when relu,  xhat = (v - mean) * rstd
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ v,
+                                                           const double* __restrict__ part, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_rstd, T* __restrict__ dv,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int batch, int ch, int t,
+                                                           int pitch, int relu) {
   __shared__ float sh[2];
-  const int row = blockIdx.x, c = row % ch;     // grid: x = (clip, channel) rows, y = 1024-frame chunks
+  const int row = blockIdx.x, c = row % ch;
   if (threadIdx.x == 0) {
     const double n = (double)batch * t;
     double s1, s2;
@@ -342,28 +410,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (row < ch && blockIdx.y == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
   }
   __syncthreads();
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
   const float mg = sh[0], mgx = sh[1], mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1], k = gamma[c] * rs;
-  const size_t base = (size_t)row * t;
-  for (int i = blockIdx.y * 1024 + threadIdx.x; i < t && i < (int)(blockIdx.y + 1) * 1024; i += 256) {
-    const float g = (relu && !(y[base + i] > 0.f)) ? 0.f : dy[base + i];
-    const float xhat = (v[base + i] - mu) * rs;
-    dv[base + i] = k * (g - mg - xhat * mgx);
+  const size_t base = (size_t)row * pitch + i;
+  float g[8], vy[8], vv[8];
+  load8(dy + base, g);
+  load8(v + base, vv);
+  if (relu) load8(y + base, vy);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float gj = (relu && !(vy[j] > 0.f)) ? 0.f : g[j];
+    g[j] = k * (gj - mg - (vv[j] - mu) * rs * mgx);
   }
+  store8(dv + base, g);
 }
 
 // out = relu(a + b); backward: da = db = dout * (out > 0)
-__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
-                                                           long long n) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
-  const float s = a[idx] + (b ? b[idx] : 0.f);
-  o[idx] = s > 0.f ? s : 0.f;
+template <class T>
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
+  const size_t base = (size_t)blockIdx.x * pitch + i;
+  float x[8], z[8];
+  load8(a + base, x);
+  if (b) load8(b + base, z);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float s = x[j] + (b ? z[j] : 0.f); x[j] = s > 0.f ? s : 0.f; }
+  store8(o + base, x);
 }
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, float* __restrict__ din,
-                                                       long long n) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
-  din[idx] = out[idx] > 0.f ? dout[idx] : 0.f;
+template <class T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ din, int t, int pitch) {
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
+  const size_t base = (size_t)blockIdx.x * pitch + i;
+  float g[8], o[8];
+  load8(dout + base, g);
+  load8(out + base, o);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+  store8(din + base, g);
 }
 
 // sum of `parts` partial [rows] vectors (the per-clip dW of the pointwise backward)
@@ -375,52 +461,113 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
   out[idx] = s;
 }
 
+// reference-layout f32 [rows][t] (contiguous) <-> pitched activation rows of either type: the boundary of the training path
+template <class T>
+__global__ __launch_bounds__(256) void act_import_kernel(const float* __restrict__ src, T* __restrict__ dst, int t, int pitch) {
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = i + j < t ? src[(size_t)blockIdx.x * t + i + j] : 0.f;
+  store8(dst + (size_t)blockIdx.x * pitch + i, v);
+}
+template <class T>
+__global__ __launch_bounds__(256) void act_export_kernel(const T* __restrict__ src, float* __restrict__ dst, int t, int pitch) {
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
+  float v[8];
+  load8(src + (size_t)blockIdx.x * pitch + i, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (i + j < t) dst[(size_t)blockIdx.x * t + i + j] = v[j];
+}
+
 static inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
+static inline dim3 row_grid(long long rows, int t) { return dim3((unsigned)rows, (unsigned)((t + ROW_CHUNK - 1) / ROW_CHUNK)); }
+static inline bool rows_ok(const void* p, int pitch, int act) {
+  return pitch % 8 == 0 && reinterpret_cast<uintptr_t>(p) % (act ? 16 : 32) == 0;
+}
 
 }  // namespace ts
 
 using namespace ts;
 #define TS_STREAM hipStream_t stream = reinterpret_cast<hipStream_t>(stream_); (void)hipGetLastError()
+// dispatch on the activation type: ACT(kernel, grid, block, lds, args...) launches kernel<float> or kernel<bf16_t>
+#define TS_ACT(act, expr_f32, expr_bf16) do { if (act) { expr_bf16; } else { expr_f32; } } while (0)
 
-extern "C" int ts_train_dwconv_fwd(const float* x, const int32_t* len_in, const int32_t* len_out, const float* w, float* y, int32_t batch,
+extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
                                    int32_t ch, int32_t t_in, int32_t t_out, int32_t k, int32_t stride, int32_t dil, int32_t pad,
-                                   void* stream_) {
+                                   int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_) {
   if (!x || !w || !y || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0 || stride <= 0 || dil <= 0) return TS_EINVAL;
+  if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
-  const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 16) * sizeof(float);
+  const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 32) * sizeof(float);
   if (lds > 64 * 1024) return TS_EUNSUPPORTED;
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3((t_out + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds, stream, x, len_in, len_out, w, y,
-                     batch, ch, t_in, t_out, k, stride, dil, pad);
+  const dim3 grid((t_out + DW_TILE - 1) / DW_TILE, batch * ch);
+  TS_ACT(act,
+         hipLaunchKernelGGL(dw_fwd_kernel<float>, grid, dim3(256), lds, stream, (const float*)x, len_in, len_out, w, (float*)y, batch, ch, t_in,
+                            t_out, k, stride, dil, pad, pitch_in, pitch_out),
+         hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)x, len_in, len_out, w, (bf16_t*)y, batch, ch, t_in,
+                            t_out, k, stride, dil, pad, pitch_in, pitch_out));
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_dwconv_bwd(const float* dy, const float* x, const int32_t* len_in, const int32_t* len_out, const float* w,
-                                   float* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
-                                   int32_t stride, int32_t dil, int32_t pad, void* stream_) {
+extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w,
+                                   void* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
+                                   int32_t stride, int32_t dil, int32_t pad, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_) {
   if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
+  if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
-  const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 16) * sizeof(float);
-  const size_t lds_w = (size_t)round_up(t_out + 4 + t_in + 2 * pad + 16, 2) * sizeof(float) + 256 * 8 * sizeof(double);
+  const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 48) * sizeof(float);
+  const size_t lds_w = (size_t)(round_up(t_out + 16, 4) + round_up(t_in + 2 * pad + 48, 2)) * sizeof(float) + 256 * 8 * sizeof(double);
   if (k > 256) return TS_EUNSUPPORTED;
   if (lds_d > 64 * 1024 || lds_w > 64 * 1024) return TS_EUNSUPPORTED;
-  hipLaunchKernelGGL(dw_bwd_data_kernel, dim3((t_in + DW_TILE - 1) / DW_TILE, batch * ch), dim3(256), lds_d, stream, dy, len_in, len_out, w,
-                     dx, batch, ch, t_in, t_out, k, stride, dil, pad);
+  const dim3 gd((t_in + DW_TILE - 1) / DW_TILE, batch * ch), gw(ch, batch < 8 ? batch : 8);
+  TS_ACT(act,
+         hipLaunchKernelGGL(dw_bwd_data_kernel<float>, gd, dim3(256), lds_d, stream, (const float*)dy, len_in, len_out, w, (float*)dx, batch, ch,
+                            t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
+         hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, gd, dim3(256), lds_d, stream, (const bf16_t*)dy, len_in, len_out, w, (bf16_t*)dx, batch, ch,
+                            t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out));
   if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)ch * k, stream) != hipSuccess) return TS_EUNSUPPORTED;
-  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(ch, batch < 8 ? batch : 8), dim3(256), lds_w, stream, dy, x, len_in, len_out, dw, batch, ch,
-                     t_in, t_out, k, stride, dil, pad);
+  TS_ACT(act,
+         hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, gw, dim3(256), lds_w, stream, (const float*)dy, (const float*)x, len_in, len_out, dw, batch,
+                            ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
+         hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, gw, dim3(256), lds_w, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, dw, batch,
+                            ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out));
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_mask_time(const float* x, const int32_t* len, float* y, int32_t batch, int32_t ch, int32_t t, void* stream_) {
-  if (!x || !len || !y || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
+extern "C" int ts_train_mask_time(const void* x, const int32_t* len, void* y, int32_t batch, int32_t ch, int32_t t, int32_t pitch_x,
+                                  int32_t pitch_y, int32_t act, void* stream_) {
+  if (!x || !len || !y || batch <= 0 || ch <= 0 || t <= 0 || act < 0 || act > 1) return TS_EINVAL;
+  if (!rows_ok(x, pitch_x, act) || !rows_ok(y, pitch_y, act) || pitch_x < t || pitch_y < t) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(mask_time_kernel, dim3(blocks((long long)batch * ch * t)), dim3(256), 0, stream, x, len, y, batch, ch, t);
+  TS_ACT(act,
+         hipLaunchKernelGGL(mask_time_kernel<float>, row_grid((long long)batch * ch, t), dim3(256), 0, stream, (const float*)x, len, (float*)y, ch, t, pitch_x, pitch_y),
+         hipLaunchKernelGGL(mask_time_kernel<bf16_t>, row_grid((long long)batch * ch, t), dim3(256), 0, stream, (const bf16_t*)x, len, (bf16_t*)y, ch, t, pitch_x, pitch_y));
   return hip_status(hipGetLastError());
 }
 
-// fp32 -> bf16 (round to nearest even): the operand copies of the mixed-precision GEMMs
+extern "C" int ts_train_act_import(const float* src, void* dst, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!src || !dst || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1 || !rows_ok(dst, pitch, act)) return TS_EINVAL;
+  TS_STREAM;
+  TS_ACT(act,
+         hipLaunchKernelGGL(act_import_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, src, (float*)dst, t, pitch),
+         hipLaunchKernelGGL(act_import_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, src, (bf16_t*)dst, t, pitch));
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_act_export(const void* src, float* dst, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!src || !dst || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1 || !rows_ok(src, pitch, act)) return TS_EINVAL;
+  TS_STREAM;
+  TS_ACT(act,
+         hipLaunchKernelGGL(act_export_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)src, dst, t, pitch),
+         hipLaunchKernelGGL(act_export_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)src, dst, t, pitch));
+  return hip_status(hipGetLastError());
+}
+
+// fp32 -> bf16 (round to nearest even): operand copies of the weights for the bf16 GEMMs
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long n) {
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -431,12 +578,14 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-static rocblas_status gemm_ex(rocblas_handle h, bool bf16, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const void* a,
-                              int lda, long long sa, const void* b, int ldb, long long sb, float* c, int ldc, long long sc, int batch) {
+// C = A . B through rocBLAS, strided-batched; in: operand type (f32 / bf16), out: result type (f32 / bf16), f32 accumulation
+static rocblas_status gemm_ex(rocblas_handle h, bool in_bf16, bool out_bf16, rocblas_operation ta, rocblas_operation tb, int m, int n, int k,
+                              const void* a, int lda, long long sa, const void* b, int ldb, long long sb, void* c, int ldc, long long sc, int batch) {
   const float one = 1.f, zero = 0.f;
-  const rocblas_datatype in = bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
-  return rocblas_gemm_strided_batched_ex(h, ta, tb, m, n, k, &one, a, in, lda, sa, b, in, ldb, sb, &zero, c, rocblas_datatype_f32_r, ldc, sc, c,
-                                         rocblas_datatype_f32_r, ldc, sc, batch, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+  const rocblas_datatype in = in_bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
+  const rocblas_datatype out = out_bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
+  return rocblas_gemm_strided_batched_ex(h, ta, tb, m, n, k, &one, a, in, lda, sa, b, in, ldb, sb, &zero, c, out, ldc, sc, c, out, ldc, sc, batch,
+                                         rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
 }
 
 extern "C" int ts_train_cast_bf16(const float* x, void* y, int64_t n, void* stream_) {
@@ -447,37 +596,38 @@ extern "C" int ts_train_cast_bf16(const float* x, void* y, int64_t n, void* stre
   return hip_status(hipGetLastError());
 }
 
-// v[b] = W . u[b]   (W [c_out][c_in] row-major, u [B][c_in][t], v [B][c_out][t]); u is expected masked by the caller.
-// precision 0: f32 operands; 1: u and w are bf16 (ts_train_cast_bf16), f32 accumulation and result.
-extern "C" int ts_train_pwconv_fwd(const void* u, const void* w, float* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t,
-                                   int32_t precision, void* stream_) {
-  if (!u || !w || !v || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0) return TS_EINVAL;
-  if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
+// v[b] = W . u[b]   (W [c_out][c_in] row-major, u [B][c_in][pitch_u], v [B][c_out][pitch_v]); u is expected masked by the caller.
+// precision 0: f32 operands and result; 1: u and w bf16, v f32 (the decoder's logits); 2: u, w and v bf16.  f32 accumulation always.
+extern "C" int ts_train_pwconv_fwd(const void* u, const void* w, void* v, int32_t batch, int32_t c_in, int32_t c_out, int32_t t,
+                                   int32_t pitch_u, int32_t pitch_v, int32_t precision, void* stream_) {
+  if (!u || !w || !v || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
+  if (precision < 0 || precision > 2) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int e = blas(stream, &h)) return e;
-  // row-major [c][t] == column-major [t][c]:  V(t x c_out) = U(t x c_in) . Wc(c_in x c_out)
-  const rocblas_status st = gemm_ex(h, precision != 0, rocblas_operation_none, rocblas_operation_none, t, c_out, c_in, u, t, (long long)c_in * t,
-                                    w, c_in, 0, v, t, (long long)c_out * t, batch);
+  // row-major [c][pitch] == column-major [pitch][c]:  V(t x c_out) = U(t x c_in) . Wc(c_in x c_out)
+  const rocblas_status st = gemm_ex(h, precision != 0, precision == 2, rocblas_operation_none, rocblas_operation_none, t, c_out, c_in, u, pitch_u,
+                                    (long long)c_in * pitch_u, w, c_in, 0, v, pitch_v, (long long)c_out * pitch_v, batch);
   return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
 }
 
-// du[b] = W^T . dv[b];  dW = sum_b dv[b] . u[b]^T  (workspace: batch * c_out * c_in floats); precision 1: dv, u, w are bf16
-extern "C" int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, float* du, float* dw, float* workspace, int32_t batch,
-                                   int32_t c_in, int32_t c_out, int32_t t, int32_t precision, void* stream_) {
-  if (!dv || !u || !w || !du || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0) return TS_EINVAL;
-  if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
+// du[b] = W^T . dv[b];  dW = sum_b dv[b] . u[b]^T  (workspace: batch * c_out * c_in floats, f32 always); precision as above
+// (1: dv, u, w bf16 and du f32; 2: du bf16 as well)
+extern "C" int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, void* du, float* dw, float* workspace, int32_t batch,
+                                   int32_t c_in, int32_t c_out, int32_t t, int32_t pitch_u, int32_t pitch_v, int32_t precision, void* stream_) {
+  if (!dv || !u || !w || !du || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
+  if (precision < 0 || precision > 2) return TS_EUNSUPPORTED;
   TS_STREAM;
   rocblas_handle h;
   if (int e = blas(stream, &h)) return e;
   const bool bf = precision != 0;
   // dU(t x c_in) = dV(t x c_out) . Wc^T(c_out x c_in)
-  rocblas_status st = gemm_ex(h, bf, rocblas_operation_none, rocblas_operation_transpose, t, c_in, c_out, dv, t, (long long)c_out * t, w, c_in, 0,
-                              du, t, (long long)c_in * t, batch);
+  rocblas_status st = gemm_ex(h, bf, precision == 2, rocblas_operation_none, rocblas_operation_transpose, t, c_in, c_out, dv, pitch_v,
+                              (long long)c_out * pitch_v, w, c_in, 0, du, pitch_u, (long long)c_in * pitch_u, batch);
   if (st != rocblas_status_success) return TS_EUNSUPPORTED;
   // per clip: dWc_b(c_in x c_out) = U^T(c_in x t) . dV(t x c_out)
-  st = gemm_ex(h, bf, rocblas_operation_transpose, rocblas_operation_none, c_in, c_out, t, u, t, (long long)c_in * t, dv, t, (long long)c_out * t,
-               workspace, c_in, (long long)c_in * c_out, batch);
+  st = gemm_ex(h, bf, false, rocblas_operation_transpose, rocblas_operation_none, c_in, c_out, t, u, pitch_u, (long long)c_in * pitch_u, dv, pitch_v,
+               (long long)c_out * pitch_v, workspace, c_in, (long long)c_in * c_out, batch);
   if (st != rocblas_status_success) return TS_EUNSUPPORTED;
   const long long rows = (long long)c_in * c_out;
   hipLaunchKernelGGL(sum_parts_kernel, dim3(blocks(rows)), dim3(256), 0, stream, workspace, dw, rows, batch);
@@ -485,44 +635,64 @@ extern "C" int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w,
 }
 
 // workspace: 16 * c doubles (8 clip-group partials of 2 sums).  mean_rstd f32 [c][2] is saved for the backward.
-extern "C" int ts_train_bn_fwd(const float* v, const float* gamma, const float* beta, float* y, float* mean_rstd, void* workspace,
-                               int32_t batch, int32_t ch, int32_t t, float eps, int32_t relu, float* running_mean, float* running_var,
-                               float momentum, int64_t* num_batches_tracked, void* stream_) {
-  if (!v || !gamma || !beta || !y || !mean_rstd || !workspace || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
+extern "C" int ts_train_bn_fwd(const void* v, const float* gamma, const float* beta, void* y, float* mean_rstd, void* workspace,
+                               int32_t batch, int32_t ch, int32_t t, int32_t pitch, float eps, int32_t relu, float* running_mean,
+                               float* running_var, float momentum, int64_t* num_batches_tracked, int32_t act, void* stream_) {
+  if (!v || !gamma || !beta || !y || !mean_rstd || !workspace || batch <= 0 || ch <= 0 || t <= 0 || act < 0 || act > 1) return TS_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return TS_EINVAL;
+  if (!rows_ok(v, pitch, act) || !rows_ok(y, pitch, act) || pitch < t) return TS_EINVAL;
   TS_STREAM;
   double* sums = static_cast<double*>(workspace);
-  hipLaunchKernelGGL(chan_sums_kernel<0>, dim3(ch, BN_G), dim3(256), 0, stream, v, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, sums, batch, ch, t, 0);
-  hipLaunchKernelGGL(bn_fwd_kernel, dim3(batch * ch, (t + 1023) / 1024), dim3(256), 0, stream, v, sums, gamma, beta, y, mean_rstd, batch,
-                     ch, t, eps, relu, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
+  long long* nbt = reinterpret_cast<long long*>(num_batches_tracked);
+  const dim3 rg = row_grid((long long)batch * ch, t);
+  TS_ACT(act,
+         { hipLaunchKernelGGL((chan_sums_kernel<0, float>), dim3(ch, BN_G), dim3(256), 0, stream, (const float*)v, (const float*)nullptr, (const float*)nullptr,
+                              (const float*)nullptr, sums, batch, ch, t, pitch, 0);
+           hipLaunchKernelGGL(bn_fwd_kernel<float>, rg, dim3(256), 0, stream, (const float*)v, sums, gamma, beta, (float*)y, mean_rstd, batch, ch, t, pitch,
+                              eps, relu, running_mean, running_var, momentum, nbt); },
+         { hipLaunchKernelGGL((chan_sums_kernel<0, bf16_t>), dim3(ch, BN_G), dim3(256), 0, stream, (const bf16_t*)v, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                              (const float*)nullptr, sums, batch, ch, t, pitch, 0);
+           hipLaunchKernelGGL(bn_fwd_kernel<bf16_t>, rg, dim3(256), 0, stream, (const bf16_t*)v, sums, gamma, beta, (bf16_t*)y, mean_rstd, batch, ch, t, pitch,
+                              eps, relu, running_mean, running_var, momentum, nbt); });
   return hip_status(hipGetLastError());
 }
 
-// workspace: c * 2 doubles + 2 * batch*ch*t floats (g, xhat)
-extern "C" int ts_train_bn_bwd(const float* dy, const float* y, const float* v, const float* gamma, const float* mean_rstd, float* dv,
-                               float* dgamma, float* dbeta, void* workspace, int32_t batch, int32_t ch, int32_t t, int32_t relu,
-                               void* stream_) {
+extern "C" int ts_train_bn_bwd(const void* dy, const void* y, const void* v, const float* gamma, const float* mean_rstd, void* dv,
+                               float* dgamma, float* dbeta, void* workspace, int32_t batch, int32_t ch, int32_t t, int32_t pitch, int32_t relu,
+                               int32_t act, void* stream_) {
   if (!dy || !y || !v || !gamma || !mean_rstd || !dv || !dgamma || !dbeta || !workspace || batch <= 0 || ch <= 0 || t <= 0) return TS_EINVAL;
+  if (act < 0 || act > 1 || !rows_ok(dy, pitch, act) || !rows_ok(y, pitch, act) || !rows_ok(v, pitch, act) || !rows_ok(dv, pitch, act) || pitch < t) return TS_EINVAL;
   TS_STREAM;
-  const long long n = (long long)batch * ch * t;
   double* sums = static_cast<double*>(workspace);
-  hipLaunchKernelGGL(chan_sums_kernel<1>, dim3(ch, BN_G), dim3(256), 0, stream, dy, y, v, mean_rstd, sums, batch, ch, t, relu);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(batch * ch, (t + 1023) / 1024), dim3(256), 0, stream, dy, y, v, sums, gamma, mean_rstd, dv, dgamma, dbeta, batch,
-                     ch, t, relu);
+  const dim3 rg = row_grid((long long)batch * ch, t);
+  TS_ACT(act,
+         { hipLaunchKernelGGL((chan_sums_kernel<1, float>), dim3(ch, BN_G), dim3(256), 0, stream, (const float*)dy, (const float*)y, (const float*)v, mean_rstd, sums,
+                              batch, ch, t, pitch, relu);
+           hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, rg, dim3(256), 0, stream, (const float*)dy, (const float*)y, (const float*)v, sums, gamma, mean_rstd,
+                              (float*)dv, dgamma, dbeta, batch, ch, t, pitch, relu); },
+         { hipLaunchKernelGGL((chan_sums_kernel<1, bf16_t>), dim3(ch, BN_G), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)v, mean_rstd, sums,
+                              batch, ch, t, pitch, relu);
+           hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, rg, dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)v, sums, gamma, mean_rstd,
+                              (bf16_t*)dv, dgamma, dbeta, batch, ch, t, pitch, relu); });
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_add_relu_fwd(const float* a, const float* b, float* out, int64_t n, void* stream_) {
-  if (!a || !out || n <= 0) return TS_EINVAL;
+extern "C" int ts_train_add_relu_fwd(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!a || !out || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1) return TS_EINVAL;
+  if (!rows_ok(a, pitch, act) || !rows_ok(out, pitch, act) || (b && !rows_ok(b, pitch, act))) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(add_relu_fwd_kernel, dim3(blocks(n)), dim3(256), 0, stream, a, b, out, (long long)n);
+  TS_ACT(act,
+         hipLaunchKernelGGL(add_relu_fwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, t, pitch),
+         hipLaunchKernelGGL(add_relu_fwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, t, pitch));
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_relu_bwd(const float* dout, const float* out, float* din, int64_t n, void* stream_) {
-  if (!dout || !out || !din || n <= 0) return TS_EINVAL;
+extern "C" int ts_train_relu_bwd(const void* dout, const void* out, void* din, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!dout || !out || !din || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1) return TS_EINVAL;
+  if (!rows_ok(dout, pitch, act) || !rows_ok(out, pitch, act) || !rows_ok(din, pitch, act)) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks(n)), dim3(256), 0, stream, dout, out, din, (long long)n);
+  TS_ACT(act,
+         hipLaunchKernelGGL(relu_bwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)dout, (const float*)out, (float*)din, t, pitch),
+         hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)out, (bf16_t*)din, t, pitch));
   return hip_status(hipGetLastError());
 }

@@ -93,8 +93,13 @@ class GradientSync:
         for b, (_, _, members) in enumerate(self.buckets):
             for idx in members:
                 self._bucket_of[idx] = b
+        from . import train_ops
+        self._views = []
         for idx, p in enumerate(self.params):
-            p.grad = self.flat[offsets[idx]: offsets[idx] + p.numel()].view_as(p)
+            view = self.flat[offsets[idx]: offsets[idx] + p.numel()].view_as(p)
+            self._views.append(view)
+            p.grad = view
+            train_ops._GRAD_VIEWS[id(p)] = view          # the training kernels write parameter gradients straight into the bucket
         self._wire = [torch.empty(length, dtype=self.wire_dtype, device=dev) if self.wire_dtype != torch.float32 else None
                       for (_, length, _) in self.buckets]
         self._pending = [len(m) for (_, _, m) in self.buckets]
@@ -106,21 +111,18 @@ class GradientSync:
     # ------------------------------------------------------------------------------------------------------------------
     def _make_hook(self, idx):
         def hook(param):
-            if param.grad is None or param.grad.data_ptr() != self._view_ptr(idx):
-                raise RuntimeError("GradientSync: a parameter's .grad no longer points into the flat bucket buffer "
-                                   "(use optimizer.zero_grad(set_to_none=False) or GradientSync.zero_grad())")
+            view = self._views[idx]
+            if param.grad is None:
+                return
+            if param.grad.data_ptr() != view.data_ptr():
+                # a gradient that was produced elsewhere (plain autograd ops, a set_to_none zero_grad): move it into the bucket
+                view.copy_(param.grad)
+                param.grad = view
             b = self._bucket_of[idx]
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b)
         return hook
-
-    def _view_ptr(self, idx):
-        if not hasattr(self, "_ptrs"):
-            self._ptrs = {}
-        if idx not in self._ptrs:
-            self._ptrs[idx] = self.params[idx].grad.data_ptr()
-        return self._ptrs[idx]
 
     def _launch(self, b: int) -> None:
         import torch.distributed as dist
@@ -166,6 +168,9 @@ class GradientSync:
     def finish(self) -> None:
         """After backward(): launch whatever has not been launched (parameters that received no gradient this step keep their
         zeros), then make the compute stream wait for the exchange.  Resets the per-step bookkeeping."""
+        for p, view in zip(self.params, self._views):
+            if p.grad is None:
+                p.grad = view                             # no gradient this step: the zeros of the bucket
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
@@ -175,13 +180,20 @@ class GradientSync:
         self._launched = [False] * len(self.buckets)
 
     def zero_grad(self) -> None:
-        """One memset of the flat buffer (instead of one per parameter); the .grad views stay in place."""
+        """One memset of the flat buffer (instead of one per parameter) and `.grad = None` for every parameter: the backward
+        kernels of the training path then write their result straight into the bucket views and autograd adopts those tensors
+        as `.grad` (train_ops.grad_out) -- no accumulate kernel, no copy.  Parameters that receive no gradient keep the zeros."""
         self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def close(self) -> None:
+        from . import train_ops
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            train_ops._GRAD_VIEWS.pop(id(p), None)
 
 
 def allreduce_gradients(params, bucket_bytes: int = 64 << 20) -> int:

@@ -194,14 +194,15 @@ class _FusedBlockBase(nn.Module):
 
     def _forward_train(self, x: torch.Tensor, lengths: torch.Tensor):
         """Training-mode forward (batch-statistics BatchNorm, autograd through every op): the reference's op sequence
-        (quartznet/blocks.py:317-338), one HIP launch per op and direction (train_ops.py), fp32 [B, C, T] activations."""
+        (quartznet/blocks.py:317-338), one HIP launch per op and direction (train_ops.py); activations f32 (default) or bf16
+        (mixed precision), see train_ops.set_activation_dtype.  Returns activation rows: a [B, C, T] view with a padded pitch."""
         from .. import train_ops as T
         _t.require_gpu(x, type(self).__name__)
         # Dropout modules of the reference tree: after the ReLU of every repeat but the last (mconv), and after the block's
         # final ReLU (mout) -- quartznet/blocks.py:227-228; each follows its own training flag like nn.Dropout does
         drops = [m.layer[0] for m in self.mconv if isinstance(m, Masked) and isinstance(m.layer[0], nn.Dropout)]
         out_drop = self.mout[1].layer[0]
-        x = _t.unpack(x) if _t.is_internal(x) else x.to(torch.float32)
+        x = T.to_act(x)              # activation rows of the training path's element type (train_ops.set_activation_dtype)
         dev = x.device
         len_in = _t.lengths_i32(lengths, dev)
         h, lh, out_lengths = x, len_in, lengths
@@ -210,19 +211,13 @@ class _FusedBlockBase(nn.Module):
             last = r == len(subs) - 1
             if pw.kernel_size != 1 or pw.stride != 1:
                 raise NotImplementedError("training mode: dense convs other than 1x1 / stride 1 have no HIP kernel")
-            if dw is not None:
-                lh_in = lh
-                if dw.stride != 1 or 2 * dw.padding != dw.dilation * (dw.kernel_size - 1):
-                    out_lengths = dw.get_seq_len(out_lengths)      # only length-changing convs cost host work / tiny launches
-                    lh = _t.lengths_i32(out_lengths, dev)
-                # the depthwise launch writes its output already masked for the pointwise conv (and masks the gradient on the way back)
-                h = T.DepthwiseConv.apply(h, dw.conv.weight, lh_in, dw.kernel_size, dw.stride, dw.dilation, dw.padding, lh)
-            else:
-                h = T.MaskTime.apply(h, lh)
-            h = T.PointwiseConv.apply(h, pw.conv.weight)
-            h = T.batch_norm_train(bn, h, relu=not last)
-            if not last and r < len(drops):
-                h = T.dropout(h, drops[r].p, drops[r].training)
+            lh_in = lh
+            if dw is not None and (dw.stride != 1 or 2 * dw.padding != dw.dilation * (dw.kernel_size - 1)):
+                out_lengths = dw.get_seq_len(out_lengths)          # only length-changing convs cost host work / tiny launches
+                lh = _t.lengths_i32(out_lengths, dev)
+            # one autograd node per repeat: [depthwise (its output already masked for the pointwise conv) | mask] -> 1x1 -> BN -> ReLU -> Dropout
+            drop = drops[r] if (not last and r < len(drops)) else None
+            h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop.p if (drop is not None and drop.training) else 0.0)
         if self._has_se():
             se = self.mconv[len(self.mconv) - 1].layer[0]          # citrinet/blocks.py:154: SE closes the main branch
             h = T.SqueezeExciteTrain.apply(h, se.fc[0].weight, se.fc[2].weight)

@@ -1,6 +1,14 @@
 """Training-mode encoder ops (fine-tuning with the encoder unfrozen): one torch.autograd.Function per reference op, each
-forward AND backward a call into csrc/train_enc.hip (fp32 activations, reference layout [B, C, T]).  PyTorch only chains the
-Functions; no ATen compute op touches an activation."""
+forward AND backward a call into csrc/train_enc.hip / train_extra.hip.  PyTorch only chains the Functions; no ATen compute op
+touches an activation.
+
+Activation tensors are [B, C, T] views of pitched rows ([B, C, P], P = T rounded up to 8 elements, 32-byte aligned) in ONE of
+two element types, chosen with `set_activation_dtype`:
+  * "fp32" (default): the reference's arithmetic -- what the parity tests against the reference's autograd use;
+  * "bf16": mixed precision (the reference under Lightning's precision="bf16-mixed"): activations and their gradients are
+    stored as bf16, every kernel computes in f32, the pointwise GEMMs run on bf16 operands with f32 accumulation; parameters,
+    parameter gradients, BatchNorm statistics and the logits stay f32.
+`to_act` / `from_act` are the boundary Functions (reference-layout f32 tensor <-> activation rows)."""
 from __future__ import annotations
 
 import torch
@@ -8,35 +16,137 @@ from torch import Tensor
 
 from . import _lib
 
+_ACT_DTYPE = torch.float32
 
-# Operand precision of the pointwise-conv GEMMs (forward and both backward products): "fp32" (default: the reference's
-# arithmetic) or "bf16" (opt-in mixed precision: bf16 operands, fp32 accumulation / results / master weights, like Lightning's
-# precision="bf16-mixed" for the reference).  Set through `set_gemm_precision`.
-_GEMM_BF16 = False
+
+def set_activation_dtype(name: str) -> None:
+    """"fp32" or "bf16": the element type of every activation the training path allocates from now on."""
+    global _ACT_DTYPE
+    if name not in ("fp32", "bf16"):
+        raise ValueError(f"activation dtype must be 'fp32' or 'bf16', got {name!r}")
+    _ACT_DTYPE = torch.bfloat16 if name == "bf16" else torch.float32
+
+
+def activation_dtype() -> torch.dtype:
+    return _ACT_DTYPE
 
 
 def set_gemm_precision(precision: str) -> None:
-    global _GEMM_BF16
-    if precision not in ("fp32", "bf16"):
-        raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
-    _GEMM_BF16 = precision == "bf16"
-
-
-def _bf16(t: Tensor) -> Tensor:
-    """bf16 operand copy of a contiguous fp32 tensor (ts_train_cast_bf16)."""
-    y = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
-    _lib.check(_lib.lib().ts_train_cast_bf16(t.data_ptr(), y.data_ptr(), t.numel(), _s(t)), "ts_train_cast_bf16")
-    return y
+    """Round-1 name of the mixed-precision switch: "bf16" now selects bf16 activations (and with them bf16 GEMM operands)."""
+    set_activation_dtype(precision)
 
 
 def _s(t: Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _f32(t: Tensor) -> Tensor:
-    if not t.is_cuda:
+def _code(t: Tensor) -> int:
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def alloc(b: int, c: int, t: int, device, dtype=None) -> Tensor:
+    """Uninitialised activation [b, c, t] on pitched rows."""
+    p = (t + 7) // 8 * 8
+    return torch.empty(b, c, p, dtype=dtype or _ACT_DTYPE, device=device)[:, :, :t]
+
+
+def alloc_like(x: Tensor) -> Tensor:
+    return alloc(x.shape[0], x.shape[1], x.shape[2], x.device, x.dtype)
+
+
+def is_act(x: Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(2) == 1 and x.stride(1) % 8 == 0
+            and x.stride(1) >= x.shape[2] and x.stride(0) == x.shape[1] * x.stride(1) and x.data_ptr() % 32 == 0)
+
+
+def _pitch(x: Tensor) -> int:
+    return x.stride(1)
+
+
+def _import(x: Tensor, dtype) -> Tensor:
+    """Any [B, C, T] tensor -> activation rows of `dtype` (a copy unless it already is one)."""
+    if not x.is_cuda:
         raise RuntimeError("thunder_speech_amd training ops run on the GPU only (no CPU fallback)")
-    return t.to(torch.float32).contiguous()
+    if is_act(x) and x.dtype == dtype:
+        return x
+    if is_act(x):                                            # the other element type: through f32
+        x = _export(x)
+    src = x.to(torch.float32).contiguous()
+    b, c, t = src.shape
+    out = alloc(b, c, t, src.device, dtype)
+    st = _lib.lib().ts_train_act_import(src.data_ptr(), out.data_ptr(), b * c, t, _pitch(out), _code(out), _s(out))
+    _lib.check(st, "ts_train_act_import")
+    return out
+
+
+def _export(x: Tensor) -> Tensor:
+    """Activation rows -> contiguous f32 [B, C, T]."""
+    b, c, t = x.shape
+    out = torch.empty(b, c, t, dtype=torch.float32, device=x.device)
+    st = _lib.lib().ts_train_act_export(x.data_ptr(), out.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x))
+    _lib.check(st, "ts_train_act_export")
+    return out
+
+
+class _ToAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src_dtype = x.dtype
+        return _import(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _export(_import(dy, dy.dtype if is_act(dy) else torch.float32)).to(ctx.src_dtype), None
+
+
+class _FromAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.dtype = x.dtype
+        return _export(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _import(dy, ctx.dtype)
+
+
+def to_act(x: Tensor) -> Tensor:
+    """Boundary into the training path: activation rows of the current activation dtype (identity if x already is one)."""
+    if is_act(x) and x.dtype == _ACT_DTYPE:
+        return x
+    return _ToAct.apply(x, _ACT_DTYPE)
+
+
+def from_act(x: Tensor) -> Tensor:
+    """Boundary out of the training path: contiguous f32 [B, C, T] (autograd flows back into the activation rows)."""
+    return _FromAct.apply(x)
+
+
+def _g(dy: Tensor, like: Tensor) -> Tensor:
+    """An incoming gradient as activation rows of `like`'s element type (test cotangents arrive as plain f32 tensors)."""
+    return _import(dy, like.dtype)
+
+
+# Parameter-gradient buffers.  parallel.GradientSync registers, per parameter, the view of its flat bucket buffer the gradient
+# has to end up in; the backward kernels then write there directly and autograd adopts the returned tensor as `.grad` (no
+# per-parameter accumulate kernel, no copy into the bucket).
+_GRAD_VIEWS = {}
+
+
+def grad_out(param, shape) -> Tensor:
+    """f32 tensor of `shape` for the gradient of `param`: its registered flat-buffer view when it has one and `.grad` is unset
+    (first -- and in the fine-tuning loop only -- contribution of the step), else a fresh tensor."""
+    view = _GRAD_VIEWS.get(id(param)) if param is not None else None
+    if view is not None and param.grad is None:
+        return view.view(shape)
+    dev = view.device if view is not None else param.device
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def _w_bf16(w2: Tensor) -> Tensor:
+    y = torch.empty(w2.shape, dtype=torch.bfloat16, device=w2.device)
+    _lib.check(_lib.lib().ts_train_cast_bf16(w2.data_ptr(), y.data_ptr(), w2.numel(), _s(w2)), "ts_train_cast_bf16")
+    return y
 
 
 class DepthwiseConv(torch.autograd.Function):
@@ -45,15 +155,17 @@ class DepthwiseConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, len_in, k, stride, dil, pad, len_out=None):
-        x, w2 = _f32(x), _f32(w).view(w.shape[0], -1)
+        x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
+        w2 = w.detach().to(torch.float32).contiguous().view(w.shape[0], -1)
         b, c, t_in = x.shape
         t_out = (t_in + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        y = torch.empty(b, c, t_out, dtype=torch.float32, device=x.device)
+        y = alloc(b, c, t_out, x.device, x.dtype)
         st = _lib.lib().ts_train_dwconv_fwd(x.data_ptr(), len_in.data_ptr(), len_out.data_ptr() if len_out is not None else None,
-                                            w2.data_ptr(), y.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad, _s(x))
+                                            w2.data_ptr(), y.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad, _pitch(x), _pitch(y),
+                                            _code(x), _s(x))
         _lib.check(st, "ts_train_dwconv_fwd")
         ctx.save_for_backward(x, w2, len_in)
-        ctx.len_out = len_out
+        ctx.len_out, ctx.param = len_out, w
         ctx.geom = (k, stride, dil, pad, t_out, w.shape)
         return y
 
@@ -61,12 +173,13 @@ class DepthwiseConv(torch.autograd.Function):
     def backward(ctx, dy):
         x, w2, len_in = ctx.saved_tensors
         k, stride, dil, pad, t_out, wshape = ctx.geom
-        dy = _f32(dy)
+        dy = _g(dy, x)
         b, c, t_in = x.shape
-        dx, dw = torch.empty_like(x), torch.empty_like(w2)
+        dx, dw = alloc_like(x), grad_out(ctx.param, w2.shape)
         lo = ctx.len_out
         st = _lib.lib().ts_train_dwconv_bwd(dy.data_ptr(), x.data_ptr(), len_in.data_ptr(), lo.data_ptr() if lo is not None else None,
-                                            w2.data_ptr(), dx.data_ptr(), dw.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad, _s(x))
+                                            w2.data_ptr(), dx.data_ptr(), dw.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad,
+                                            _pitch(x), _pitch(dy), _code(x), _s(x))
         _lib.check(st, "ts_train_dwconv_bwd")
         return dx, dw.view(wshape), None, None, None, None, None, None
 
@@ -76,56 +189,61 @@ class MaskTime(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lens):
-        x = _f32(x)
+        x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
         b, c, t = x.shape
-        y = torch.empty_like(x)
-        _lib.check(_lib.lib().ts_train_mask_time(x.data_ptr(), lens.data_ptr(), y.data_ptr(), b, c, t, _s(x)), "ts_train_mask_time")
+        y = alloc_like(x)
+        st = _lib.lib().ts_train_mask_time(x.data_ptr(), lens.data_ptr(), y.data_ptr(), b, c, t, _pitch(x), _pitch(y), _code(x), _s(x))
+        _lib.check(st, "ts_train_mask_time")
         ctx.save_for_backward(lens)
+        ctx.dtype = x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (lens,) = ctx.saved_tensors
-        dy = _f32(dy)
+        dy = _import(dy, ctx.dtype)
         b, c, t = dy.shape
-        dx = torch.empty_like(dy)
-        _lib.check(_lib.lib().ts_train_mask_time(dy.data_ptr(), lens.data_ptr(), dx.data_ptr(), b, c, t, _s(dy)), "ts_train_mask_time")
+        dx = alloc_like(dy)
+        st = _lib.lib().ts_train_mask_time(dy.data_ptr(), lens.data_ptr(), dx.data_ptr(), b, c, t, _pitch(dy), _pitch(dx), _code(dy), _s(dy))
+        _lib.check(st, "ts_train_mask_time")
         return dx, None
 
 
 class PointwiseConv(torch.autograd.Function):
-    """1x1 conv without bias on an already masked input: v[b] = W . u[b] (rocBLAS), du = W^T dv, dW = sum_b dv u^T."""
+    """1x1 conv without bias on an already masked input: v[b] = W . u[b] (rocBLAS), du = W^T dv, dW = sum_b dv u^T.
+    f32 activations: f32 GEMMs.  bf16 activations: bf16 operands, f32 accumulation; the result is bf16 too, except with
+    `f32_out` (the decoder's logits feed the CTC kernel in f32)."""
 
     @staticmethod
-    def forward(ctx, u, w):
-        u, w2 = _f32(u), _f32(w).view(w.shape[0], -1)
+    def forward(ctx, u, w, f32_out=False):
+        u = _import(u, u.dtype if is_act(u) else _ACT_DTYPE)
+        w2 = w.detach().to(torch.float32).contiguous().view(w.shape[0], -1)
         b, c_in, t = u.shape
         c_out = w2.shape[0]
-        v = torch.empty(b, c_out, t, dtype=torch.float32, device=u.device)
-        prec = 1 if _GEMM_BF16 else 0
-        if prec:
-            u, w2 = _bf16(u), _bf16(w2)            # the bf16 copies are what the backward needs too: half the saved bytes
-        _lib.check(_lib.lib().ts_train_pwconv_fwd(u.data_ptr(), w2.data_ptr(), v.data_ptr(), b, c_in, c_out, t, prec, _s(v)),
-                   "ts_train_pwconv_fwd")
-        ctx.save_for_backward(u, w2)
-        ctx.wshape, ctx.prec = w.shape, prec
+        bf = u.dtype == torch.bfloat16
+        prec = 0 if not bf else (1 if f32_out else 2)
+        wk = _w_bf16(w2) if bf else w2
+        v = alloc(b, c_out, t, u.device, torch.float32 if (f32_out or not bf) else torch.bfloat16)
+        st = _lib.lib().ts_train_pwconv_fwd(u.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(v), prec, _s(v))
+        _lib.check(st, "ts_train_pwconv_fwd")
+        ctx.save_for_backward(u, wk)
+        ctx.wshape, ctx.f32_out, ctx.param = w.shape, f32_out, w
         return v
 
     @staticmethod
     def backward(ctx, dv):
-        u, w2 = ctx.saved_tensors
-        dv = _f32(dv)
+        u, wk = ctx.saved_tensors
+        bf = u.dtype == torch.bfloat16
+        dv = _import(dv, u.dtype)                      # bf16 mode: the f32 logit gradient becomes a bf16 GEMM operand
         b, c_in, t = u.shape
-        c_out = w2.shape[0]
-        du = torch.empty(u.shape, dtype=torch.float32, device=u.device)
-        dw = torch.empty(w2.shape, dtype=torch.float32, device=u.device)
+        c_out = wk.shape[0]
+        du = alloc_like(u)
+        dw = grad_out(ctx.param, wk.shape)
         ws = torch.empty(b * c_out * c_in, dtype=torch.float32, device=u.device)
-        if ctx.prec:
-            dv = _bf16(dv)
-        st = _lib.lib().ts_train_pwconv_bwd(dv.data_ptr(), u.data_ptr(), w2.data_ptr(), du.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in,
-                                            c_out, t, ctx.prec, _s(du))
+        st = _lib.lib().ts_train_pwconv_bwd(dv.data_ptr(), u.data_ptr(), wk.data_ptr(), du.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in,
+                                            c_out, t, _pitch(u), _pitch(dv), 2 if bf else 0, _s(du))
         _lib.check(st, "ts_train_pwconv_bwd")
-        return du, dw.view(ctx.wshape)
+        return du, dw.view(ctx.wshape), None
 
 
 class BatchNormTrain(torch.autograd.Function):
@@ -134,31 +252,32 @@ class BatchNormTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, v, gamma, beta, eps, relu, running):
-        v, g, be = _f32(v), _f32(gamma), _f32(beta)
+        v = _import(v, v.dtype if is_act(v) else _ACT_DTYPE)
+        g, be = gamma.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
         b, c, t = v.shape
-        y = torch.empty_like(v)
+        y = alloc_like(v)
         mr = torch.empty(c, 2, dtype=torch.float32, device=v.device)
         ws = torch.empty(16 * c, dtype=torch.float64, device=v.device)
         rm, rv, mom, nbt = running if running is not None else (None, None, 0.0, None)
-        st = _lib.lib().ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c, t,
+        st = _lib.lib().ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c, t, _pitch(v),
                                         float(eps), int(relu), rm.data_ptr() if rm is not None else None,
                                         rv.data_ptr() if rv is not None else None, float(mom),
-                                        nbt.data_ptr() if nbt is not None else None, _s(v))
+                                        nbt.data_ptr() if nbt is not None else None, _code(v), _s(v))
         _lib.check(st, "ts_train_bn_fwd")
         ctx.save_for_backward(v, y, g, mr)
-        ctx.relu = relu
+        ctx.relu, ctx.params = relu, (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         v, y, g, mr = ctx.saved_tensors
-        dy = _f32(dy)
+        dy = _g(dy, v)
         b, c, t = v.shape
-        dv = torch.empty_like(v)
-        dg, db = torch.empty(c, dtype=torch.float32, device=v.device), torch.empty(c, dtype=torch.float32, device=v.device)
+        dv = alloc_like(v)
+        dg, db = grad_out(ctx.params[0], (c,)), grad_out(ctx.params[1], (c,))
         ws = torch.empty(16 * c, dtype=torch.float64, device=v.device)
         st = _lib.lib().ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(),
-                                        db.data_ptr(), ws.data_ptr(), b, c, t, int(ctx.relu), _s(v))
+                                        db.data_ptr(), ws.data_ptr(), b, c, t, _pitch(v), int(ctx.relu), _code(v), _s(v))
         _lib.check(st, "ts_train_bn_bwd")
         return dv, dg, db, None, None, None
 
@@ -168,10 +287,11 @@ class AddRelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        a = _f32(a)
-        bb = _f32(b) if b is not None else None
-        out = torch.empty_like(a)
-        st = _lib.lib().ts_train_add_relu_fwd(a.data_ptr(), bb.data_ptr() if bb is not None else None, out.data_ptr(), a.numel(), _s(a))
+        a = _import(a, a.dtype if is_act(a) else _ACT_DTYPE)
+        bb = _import(b, a.dtype) if b is not None else None
+        out = alloc_like(a)
+        st = _lib.lib().ts_train_add_relu_fwd(a.data_ptr(), bb.data_ptr() if bb is not None else None, out.data_ptr(), a.shape[0] * a.shape[1],
+                                              a.shape[2], _pitch(a), _code(a), _s(a))
         _lib.check(st, "ts_train_add_relu_fwd")
         ctx.save_for_backward(out)
         ctx.has_b = b is not None
@@ -180,30 +300,38 @@ class AddRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (out,) = ctx.saved_tensors
-        dout = _f32(dout)
-        din = torch.empty_like(out)
-        _lib.check(_lib.lib().ts_train_relu_bwd(dout.data_ptr(), out.data_ptr(), din.data_ptr(), out.numel(), _s(out)), "ts_train_relu_bwd")
+        dout = _g(dout, out)
+        din = alloc_like(out)
+        st = _lib.lib().ts_train_relu_bwd(dout.data_ptr(), out.data_ptr(), din.data_ptr(), out.shape[0] * out.shape[1], out.shape[2],
+                                          _pitch(out), _code(out), _s(out))
+        _lib.check(st, "ts_train_relu_bwd")
         return din, (din if ctx.has_b else None)
 
 
 class Dropout(torch.autograd.Function):
     """nn.Dropout in train mode: y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) drawn per element from a Philox stream
-    (csrc/augment.hip).  Nothing is saved: the backward pass re-draws the mask from the same seed."""
+    (csrc/train_extra.hip).  Nothing is saved: the backward pass re-draws the mask from the same seed."""
 
     @staticmethod
     def forward(ctx, x, p, seed):
-        x = _f32(x)
-        y = torch.empty_like(x)
-        _lib.check(_lib.lib().ts_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed), _s(x)), "ts_dropout")
-        ctx.p, ctx.seed = float(p), int(seed)
-        return y
+        x3 = x if x.dim() == 3 else x.reshape(1, 1, -1)
+        x3 = _import(x3, x3.dtype if is_act(x3) else _ACT_DTYPE)
+        y = alloc_like(x3)
+        st = _lib.lib().ts_train_dropout(x3.data_ptr(), y.data_ptr(), x3.shape[0] * x3.shape[1], x3.shape[2], _pitch(x3), float(p), int(seed),
+                                         _code(x3), _s(x3))
+        _lib.check(st, "ts_train_dropout")
+        ctx.p, ctx.seed, ctx.shape, ctx.dtype = float(p), int(seed), x.shape, x3.dtype
+        return y if x.dim() == 3 else y.reshape(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        dy = _f32(dy)
-        dx = torch.empty_like(dy)
-        _lib.check(_lib.lib().ts_dropout(dy.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, ctx.seed, _s(dy)), "ts_dropout")
-        return dx, None, None
+        d3 = dy if dy.dim() == 3 else dy.reshape(1, 1, -1)
+        d3 = _import(d3, ctx.dtype)
+        dx = alloc_like(d3)
+        st = _lib.lib().ts_train_dropout(d3.data_ptr(), dx.data_ptr(), d3.shape[0] * d3.shape[1], d3.shape[2], _pitch(d3), ctx.p, ctx.seed,
+                                         _code(d3), _s(d3))
+        _lib.check(st, "ts_train_dropout")
+        return (dx if len(ctx.shape) == 3 else dx.reshape(ctx.shape)), None, None
 
 
 def dropout(x: Tensor, p: float, training: bool) -> Tensor:
@@ -218,22 +346,24 @@ class SubsampleMask(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lens, stride, t_out):
-        x = _f32(x)
+        x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
         b, c, t_in = x.shape
-        y = torch.empty(b, c, t_out, dtype=torch.float32, device=x.device)
-        st = _lib.lib().ts_train_subsample_mask(x.data_ptr(), lens.data_ptr(), y.data_ptr(), b, c, t_in, t_out, stride, 0, _s(x))
+        y = alloc(b, c, t_out, x.device, x.dtype)
+        st = _lib.lib().ts_train_subsample_mask(x.data_ptr(), lens.data_ptr(), y.data_ptr(), b, c, t_in, t_out, stride, 0, _pitch(x), _pitch(y),
+                                                _code(x), _s(x))
         _lib.check(st, "ts_train_subsample_mask")
         ctx.save_for_backward(lens)
-        ctx.geom = (b, c, t_in, t_out, stride)
+        ctx.geom = (b, c, t_in, t_out, stride, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (lens,) = ctx.saved_tensors
-        b, c, t_in, t_out, stride = ctx.geom
-        dy = _f32(dy)
-        dx = torch.empty(b, c, t_in, dtype=torch.float32, device=dy.device)
-        st = _lib.lib().ts_train_subsample_mask(dy.data_ptr(), lens.data_ptr(), dx.data_ptr(), b, c, t_in, t_out, stride, 1, _s(dy))
+        b, c, t_in, t_out, stride, dtype = ctx.geom
+        dy = _import(dy, dtype)
+        dx = alloc(b, c, t_in, dy.device, dtype)
+        st = _lib.lib().ts_train_subsample_mask(dy.data_ptr(), lens.data_ptr(), dx.data_ptr(), b, c, t_in, t_out, stride, 1, _pitch(dx), _pitch(dy),
+                                                _code(dy), _s(dy))
         _lib.check(st, "ts_train_subsample_mask")
         return dx, None, None, None
 
@@ -241,53 +371,176 @@ class SubsampleMask(torch.autograd.Function):
 class SqueezeExciteTrain(torch.autograd.Function):
     """SqueezeExcite.forward with autograd (citrinet/blocks.py:70-83): y = x * sigmoid(W2 relu(W1 mean_t(x))), the mean over ALL
     frames (quirk A3).  The passes over the activation are HIP launches (csrc/train_extra.hip); the [B, C] bottleneck is four
-    tiny GEMMs."""
+    tiny f32 GEMMs."""
 
     @staticmethod
     def forward(ctx, x, w1, w2):
-        x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
+        x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
+        w1, w2 = w1.detach().to(torch.float32), w2.detach().to(torch.float32)
         b, c, t = x.shape
         L = _lib.lib()
         mean = torch.empty(b, c, dtype=torch.float32, device=x.device)
-        _lib.check(L.ts_train_se_pool(x.data_ptr(), mean.data_ptr(), b * c, t, _s(x)), "ts_train_se_pool")
+        _lib.check(L.ts_train_se_pool(x.data_ptr(), mean.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)), "ts_train_se_pool")
         h = torch.relu(mean @ w1.t())
         g = torch.sigmoid(h @ w2.t()).contiguous()
-        y = torch.empty_like(x)
-        _lib.check(L.ts_train_se_scale(x.data_ptr(), g.data_ptr(), None, y.data_ptr(), b * c, t, _s(x)), "ts_train_se_scale")
+        y = alloc_like(x)
+        _lib.check(L.ts_train_se_scale(x.data_ptr(), g.data_ptr(), None, y.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)), "ts_train_se_scale")
         ctx.save_for_backward(x, w1, w2, mean, h, g)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w1, w2, mean, h, g = ctx.saved_tensors
-        dy = _f32(dy)
+        dy = _g(dy, x)
         b, c, t = x.shape
         L = _lib.lib()
         dg = torch.empty(b, c, dtype=torch.float32, device=x.device)
-        _lib.check(L.ts_train_se_rowdot(dy.data_ptr(), x.data_ptr(), dg.data_ptr(), b * c, t, _s(x)), "ts_train_se_rowdot")
+        _lib.check(L.ts_train_se_rowdot(dy.data_ptr(), x.data_ptr(), dg.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)), "ts_train_se_rowdot")
         dz = dg * g * (1.0 - g)
         dw2 = dz.t() @ h
         dh = (dz @ w2) * (h > 0).to(dz.dtype)
         dw1 = dh.t() @ mean
         dmean = (dh @ w1).contiguous()
-        dx = torch.empty_like(x)
-        _lib.check(L.ts_train_se_scale(dy.data_ptr(), g.data_ptr(), dmean.data_ptr(), dx.data_ptr(), b * c, t, _s(x)), "ts_train_se_scale")
+        dx = alloc_like(x)
+        _lib.check(L.ts_train_se_scale(dy.data_ptr(), g.data_ptr(), dmean.data_ptr(), dx.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)),
+                   "ts_train_se_scale")
         return dx, dw1, dw2
 
 
-def batch_norm_train(bn: torch.nn.BatchNorm1d, v: Tensor, relu: bool) -> Tensor:
-    """BatchNorm1d(train) through the kernels + the module's running-statistics update (momentum, unbiased variance)."""
-    running = None
-    if bn.track_running_stats and bn.running_mean is not None:
-        if bn.running_mean.dtype != torch.float32 or bn.running_var.dtype != torch.float32 or not bn.running_mean.is_cuda:
-            raise RuntimeError("batch_norm_train: fp32 running statistics on the GPU only")
-        # momentum=None (cumulative average) needs the counter's value: one host read, the reference default is 0.1
-        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-        running = (bn.running_mean, bn.running_var, m, bn.num_batches_tracked)
-    y = BatchNormTrain.apply(v, bn.weight, bn.bias, bn.eps, relu, running)
+class SubBlockCfg:
+    """Non-tensor arguments of SubBlock (one per call)."""
+    __slots__ = ("len_in", "len_out", "k", "stride", "dil", "pad", "eps", "relu", "running", "drop_p", "drop_seed")
+
+
+class SubBlock(torch.autograd.Function):
+    """One repeat of a QuartzNet / Citrinet block as ONE autograd node (quartznet/blocks.py:195-228): [depthwise MaskedConv1d |
+    mask] -> 1x1 MaskedConv1d -> BatchNorm1d(train) [-> ReLU] [-> Dropout].  The same launches as the fine-grained Functions
+    above, in the same order -- what is fused is the host side: four autograd nodes, their argument marshalling and their
+    intermediate Python tensors become one (the training step is host-bound otherwise)."""
+
+    @staticmethod
+    def forward(ctx, x, dw_w, pw_w, gamma, beta, cfg):
+        L = _lib.lib()
+        x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
+        b, c_in, t_in = x.shape
+        st_, code, bf = _s(x), _code(x), x.dtype == torch.bfloat16
+        if dw_w is not None:
+            w_dw = dw_w.detach().to(torch.float32).contiguous().view(dw_w.shape[0], -1)
+            t_out = (t_in + 2 * cfg.pad - cfg.dil * (cfg.k - 1) - 1) // cfg.stride + 1
+            mid = alloc(b, c_in, t_out, x.device, x.dtype)
+            _lib.check(L.ts_train_dwconv_fwd(x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), mid.data_ptr(), b, c_in,
+                                             t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(mid), code, st_), "ts_train_dwconv_fwd")
+        else:
+            w_dw, t_out = None, t_in
+            mid = alloc_like(x)
+            _lib.check(L.ts_train_mask_time(x.data_ptr(), cfg.len_in.data_ptr(), mid.data_ptr(), b, c_in, t_in, _pitch(x), _pitch(mid), code, st_),
+                       "ts_train_mask_time")
+        w_pw = pw_w.detach().to(torch.float32).contiguous().view(pw_w.shape[0], -1)
+        c_out = w_pw.shape[0]
+        wk = _w_bf16(w_pw) if bf else w_pw
+        v = alloc(b, c_out, t_out, x.device, x.dtype)
+        _lib.check(L.ts_train_pwconv_fwd(mid.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t_out, _pitch(mid), _pitch(v), 2 if bf else 0, st_),
+                   "ts_train_pwconv_fwd")
+        g, be = gamma.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
+        y = alloc_like(v)
+        mr = torch.empty(c_out, 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
+        rm, rv, mom, nbt = cfg.running if cfg.running is not None else (None, None, 0.0, None)
+        _lib.check(L.ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c_out, t_out, _pitch(v),
+                                     float(cfg.eps), int(cfg.relu), rm.data_ptr() if rm is not None else None,
+                                     rv.data_ptr() if rv is not None else None, float(mom), nbt.data_ptr() if nbt is not None else None, code, st_),
+                   "ts_train_bn_fwd")
+        out = y
+        if cfg.drop_p > 0.0:
+            out = alloc_like(y)
+            _lib.check(L.ts_train_dropout(y.data_ptr(), out.data_ptr(), b * c_out, t_out, _pitch(y), float(cfg.drop_p), int(cfg.drop_seed), code, st_),
+                       "ts_train_dropout")
+        ctx.save_for_backward(x, mid, v, y, g, mr, wk, *([w_dw] if w_dw is not None else []))
+        ctx.cfg, ctx.params = cfg, (dw_w, pw_w, gamma, beta)
+        ctx.shapes = (None if dw_w is None else dw_w.shape, pw_w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x, mid, v, y, g, mr, wk = saved[:7]
+        w_dw = saved[7] if len(saved) > 7 else None
+        cfg = ctx.cfg
+        dw_p, pw_p, ga_p, be_p = ctx.params
+        b, c_in, t_in = x.shape
+        c_out, t_out = v.shape[1], v.shape[2]
+        st_, code, bf = _s(x), _code(x), x.dtype == torch.bfloat16
+        dy = _g(dy, y)
+        if cfg.drop_p > 0.0:
+            d2 = alloc_like(dy)
+            _lib.check(L.ts_train_dropout(dy.data_ptr(), d2.data_ptr(), b * c_out, t_out, _pitch(dy), float(cfg.drop_p), int(cfg.drop_seed), code, st_),
+                       "ts_train_dropout")
+            dy = d2
+        dv = alloc_like(v)
+        dg, db = grad_out(ga_p, (c_out,)), grad_out(be_p, (c_out,))
+        ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
+        _lib.check(L.ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                     ws.data_ptr(), b, c_out, t_out, _pitch(v), int(cfg.relu), code, st_), "ts_train_bn_bwd")
+        dmid = alloc_like(mid)
+        dpw = grad_out(pw_p, wk.shape)
+        ws2 = torch.empty(b * c_out * c_in, dtype=torch.float32, device=x.device)
+        _lib.check(L.ts_train_pwconv_bwd(dv.data_ptr(), mid.data_ptr(), wk.data_ptr(), dmid.data_ptr(), dpw.data_ptr(), ws2.data_ptr(), b, c_in, c_out, t_out,
+                                         _pitch(mid), _pitch(dv), 2 if bf else 0, st_), "ts_train_pwconv_bwd")
+        dx = alloc_like(x)
+        if w_dw is not None:
+            ddw = grad_out(dw_p, w_dw.shape)
+            _lib.check(L.ts_train_dwconv_bwd(dmid.data_ptr(), x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), dx.data_ptr(),
+                                             ddw.data_ptr(), b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(dmid), code, st_),
+                       "ts_train_dwconv_bwd")
+            ddw = ddw.view(ctx.shapes[0])
+        else:
+            ddw = None
+            _lib.check(L.ts_train_mask_time(dmid.data_ptr(), cfg.len_in.data_ptr(), dx.data_ptr(), b, c_in, t_in, _pitch(dmid), _pitch(dx), code, st_),
+                       "ts_train_mask_time")
+        return dx, ddw, dpw.view(ctx.shapes[1]), dg, db, None
+
+
+def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Tensor, len_out: Tensor, relu: bool, drop_p: float = 0.0) -> Tensor:
+    """x -> [dropout](relu?(BN_train(pw(mask(dw(mask(x))))))): one repeat of a block.  dw_conv / pw_conv are the MaskedConv1d modules
+    (dw_conv None for a non-separable 1x1 repeat), len_in / len_out int32 device lengths before / after the depthwise conv."""
+    cfg = SubBlockCfg()
+    cfg.len_in, cfg.len_out = len_in, len_out
+    if dw_conv is not None:
+        cfg.k, cfg.stride, cfg.dil, cfg.pad = dw_conv.kernel_size, dw_conv.stride, dw_conv.dilation, dw_conv.padding
+    else:
+        cfg.k, cfg.stride, cfg.dil, cfg.pad = 1, 1, 1, 0
+    cfg.eps, cfg.relu, cfg.running = bn.eps, relu, _running(bn)
+    cfg.drop_p, cfg.drop_seed = (float(drop_p), 0)
+    if cfg.drop_p > 0.0:
+        from .rng import next_seed
+        cfg.drop_seed = next_seed()
+    y = SubBlock.apply(x, None if dw_conv is None else dw_conv.conv.weight, pw_conv.conv.weight, bn.weight, bn.bias, cfg)
+    _bump_running(bn, cfg.running)
+    return y
+
+
+def _running(bn: torch.nn.BatchNorm1d):
+    if not (bn.track_running_stats and bn.running_mean is not None):
+        return None
+    if bn.running_mean.dtype != torch.float32 or bn.running_var.dtype != torch.float32 or not bn.running_mean.is_cuda:
+        raise RuntimeError("batch_norm_train: fp32 running statistics on the GPU only")
+    # momentum=None (cumulative average) needs the counter's value: one host read, the reference default is 0.1
+    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+    return (bn.running_mean, bn.running_var, m, bn.num_batches_tracked)
+
+
+def _bump_running(bn, running) -> None:
     if running is not None:
         # the launch updated the buffers through raw pointers: make the change visible to `_version`-keyed caches
         # (blocks._PackedCache folds running_mean / running_var into the inference weights)
         for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
             torch.autograd.graph.increment_version(t)
+
+
+def batch_norm_train(bn: torch.nn.BatchNorm1d, v: Tensor, relu: bool) -> Tensor:
+    """BatchNorm1d(train) through the kernels + the module's running-statistics update (momentum, unbiased variance)."""
+    running = _running(bn)
+    y = BatchNormTrain.apply(v, bn.weight, bn.bias, bn.eps, relu, running)
+    _bump_running(bn, running)
     return y
