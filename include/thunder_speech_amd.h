@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 3
+#define TS_ABI_VERSION 4
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -264,8 +264,13 @@ int ts_train_se_scale(const void* x, const float* gate, const float* add_mean, v
 int ts_train_se_rowdot(const void* a, const void* b, float* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
 /* nn.Dropout in train mode on activation rows (quartznet/blocks.py:227-228, blocks.py:238): y = x * keep / (1 - p), keep ~
  * Bernoulli(1 - p) from the Philox stream (seed, element index row * t + i) -- independent of pitch and element type; the backward
- * pass is the same call on dy with the same seed.  x and y may alias. */
-int ts_train_dropout(const void* x, void* y, int64_t rows, int32_t t, int32_t pitch, float p, uint64_t seed, int32_t act, void* stream);
+ * pass is the same call on dy with the same seed.  x and y may alias.  `nonce` (device uint64, may be NULL) is added to the seed
+ * inside the kernel: a training step replayed from a hipGraph bumps it once per replay (ts_counter_add, captured in the graph),
+ * so every replay draws a new mask although the by-value seed is frozen in the graph. */
+int ts_train_dropout(const void* x, void* y, int64_t rows, int32_t t, int32_t pitch, float p, uint64_t seed, const uint64_t* nonce,
+                     int32_t act, void* stream);
+/* *counter += inc on the device (one thread); captured at the head of a graphed training step. */
+int ts_counter_add(uint64_t* counter, uint64_t inc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * wav2vec2 waveform normalisation, replaces Wav2Vec2Preprocess.forward (huggingface/transform.py:34-55 -> normalize_tensor,

@@ -130,3 +130,103 @@ def test_bf16_activation_mode_stays_within_bf16_tolerance(golden, name):
     for k in gp0:
         assert gp1[k].dtype == torch.float32 and rel(gp1[k], gp0[k]) <= 0.35 and rms(gp1[k], gp0[k]) <= 0.2, (k, rel(gp1[k], gp0[k]), rms(gp1[k], gp0[k]))
     assert not torch.equal(y1, y0)                      # the mode really changes the arithmetic
+
+
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+@pytest.mark.parametrize("batch,ch,t,k", [(1, 2, 37, 5), (5, 6, 501, 33), (3, 4, 512, 75), (2, 2, 1100, 127), (33, 2, 64, 11), (2, 8, 1536, 39)])
+def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k):
+    """The packed-FMA "same" depthwise kernels (one wavefront = two channel rows, csrc/train_enc.hip dw_fwd_pair / dw_bwd_pair)
+    against F.conv1d(groups = C) + autograd on the masked input (quartznet/blocks.py:169-182): ragged lengths, several 512-frame
+    wave tiles, clip counts that leave waves idle.  fp32 rows: 2e-5 of the scale; bf16 rows: inputs are rounded once (so the
+    reference sees the same values) and the outputs once more: 1 % of the scale."""
+    from thunder_speech_amd import train_ops as T
+    g = torch.Generator().manual_seed(batch * 1000 + t + k)
+    x = torch.randn(batch, ch, t, generator=g)
+    w = torch.randn(ch, 1, k, generator=g) / k ** 0.5
+    cot = torch.randn(batch, ch, t, generator=g)
+    lengths = torch.randint(max(1, t // 3), t + 1, (batch,), generator=g)
+    lengths[0] = t
+    if act == "bf16":
+        x, cot = x.bfloat16().float(), cot.bfloat16().float()
+    mask = (torch.arange(t)[None, :] < lengths[:, None])[:, None, :]
+    xr, wr = (x * mask).double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv1d(xr, wr, padding=(k - 1) // 2, groups=ch) * mask        # len_out = len_in: re-masked output
+    (yr * cot.double()).sum().backward()
+
+    T.set_activation_dtype(act)
+    try:
+        xg = x.cuda().requires_grad_(True)
+        wg = w.cuda().requires_grad_(True)
+        li = lengths.to(torch.int32).cuda()
+        y = T.DepthwiseConv.apply(T.to_act(xg), wg, li, k, 1, 1, (k - 1) // 2, li)
+        assert y.dtype == (torch.bfloat16 if act == "bf16" else torch.float32)
+        (T.from_act(y) * cot.cuda()).sum().backward()
+    finally:
+        T.set_activation_dtype("fp32")
+    tol = 1e-2 if act == "bf16" else 2e-5
+    for name, got, ref in (("y", T.from_act(y).detach(), yr), ("dx", xg.grad * mask.cuda(), xr.grad * mask), ("dw", wg.grad, wr.grad)):
+        ref = ref.detach().float().cuda()
+        err = float((got.float() - ref).abs().max())
+        assert err <= tol * max(float(ref.abs().max()), 1.0), (name, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+def test_graphed_training_step_follows_the_eager_step(act):
+    """train_graph.GraphedTrainStep (features -> encoder -> decoder -> CTC -> backward replayed from ONE hipGraph, front end /
+    exchange / optimizer outside) against the same steps launched eagerly (module.py:102-113 + backward + GradientSync.finish +
+    FusedAdamW): same seeds, so the dither draws are the same too; the first loss agrees to 1e-6 relative, the later ones to 1 % (fp32; the
+    weight gradients of the depthwise convolutions leave through float atomics, whose order is not fixed, and the loss falls 5x in
+    these 4 steps) / 5 % (bf16 activations), the parameters after 4 steps to 2 % of their scale, and the BatchNorm running statistics count exactly 4 steps: the warm-up and
+    capture passes leave no trace."""
+    from thunder_speech_amd import train_ops
+    from thunder_speech_amd.optim import FusedAdamW
+    from thunder_speech_amd.parallel import GradientSync
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.train_graph import GraphedTrainStep
+    arch = otcs.quartznet_arch(repeat_blocks=1)
+    g = torch.Generator().manual_seed(9)
+    wavs = [(0.1 * torch.randn(4, 24000, generator=g)).cuda() for _ in range(2)]
+    lengths = torch.tensor([24000.0, 20000.0, 16000.0, 24000.0]).cuda()
+    texts = [["abc", "hello", "data", "test"], ["speech", "to", "text x", "qrs"]]
+
+    def make():
+        m = build_synthetic_quartznet(repeat_blocks=1, encoder_state=otcs.synth_encoder_state(arch, seed=0, calibrate=True),
+                                      decoder_state=otcs.synth_decoder_state(1024, 29, seed=1)).cuda().train()
+        params = [p for p in m.parameters() if p.requires_grad]
+        return m, FusedAdamW(params, lr=1e-3, weight_decay=0.0), GradientSync(params)
+
+    train_ops.set_activation_dtype(act)
+    try:
+        torch.manual_seed(5)
+        m0, opt0, sync0 = make()
+        eager = []
+        for i in range(4):
+            sync0.zero_grad()
+            loss = m0.training_step((wavs[i % 2], lengths, texts[i % 2]), 0)
+            loss.backward()
+            sync0.finish()
+            opt0.step()
+            eager.append(float(loss.detach()))
+        sync0.close()
+        torch.manual_seed(5)
+        m1, opt1, sync1 = make()
+        step = GraphedTrainStep(m1, opt1, sync1, max_target_len=16)
+        graphed = [float(step((wavs[i % 2], lengths, texts[i % 2]))) for i in range(4)]
+        sync1.close()
+    finally:
+        train_ops.set_activation_dtype("fp32")
+    assert step.replays == 4 and len(step._graphs) == 1
+    # the first step sees identical parameters; afterwards the two runs drift apart through the atomics' summation order, amplified
+    # by a loss that falls 5x in 4 steps
+    assert abs(eager[0] - graphed[0]) <= (1e-3 if act == "bf16" else 1e-6) * abs(eager[0]), (eager, graphed)
+    tol = 5e-2 if act == "bf16" else 1e-2
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= tol * abs(a), (eager, graphed)
+    assert eager[-1] != eager[0]
+    for (k, p0), p1 in zip(m0.named_parameters(), m1.parameters()):
+        assert float((p0 - p1).abs().max()) <= (5e-2 if act == "bf16" else 2e-2) * max(float(p0.abs().max()), 1e-2), k
+    for (k, b0), b1 in zip(m0.named_buffers(), m1.buffers()):
+        if k.endswith("num_batches_tracked"):
+            assert int(b0) == int(b1) == 4, k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            assert float((b0 - b1).abs().max()) <= (5e-2 if act == "bf16" else 2e-2) * max(float(b0.abs().max()), 1e-2), k

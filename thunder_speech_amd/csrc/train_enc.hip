@@ -277,6 +277,208 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
+// "Same" depthwise convolutions (stride 1, dilation 1, odd k, pad = (k-1)/2, even channel count: every body layer of QuartzNet /
+// Citrinet) -- the VALU-bound part of the training step.  One WAVEFRONT owns TWO adjacent channel rows of one clip and every
+// product is a packed-f32 FMA over the pair (v_pk_fma_f32: lane-half 0 = channel c, lane-half 1 = channel c + 1), which doubles
+// the FMA rate of the one-row form; each lane computes 8 consecutive frames from a 16-entry register window (fir_pair), the taps
+// come in over the scalar unit (uniform per wave), so a step of 64 packed FMAs costs 4 LDS reads.  No workgroup barrier in the
+// streaming part: a wave stages its own rows (LDS operations of one wave execute in order).
+// LDS layout of a staged row pair: float2 samples, 2-sample chunks dealt round-robin over 4 sub-arrays, so that the four 16-byte
+// reads of a window step are lane-contiguous in each sub-array (a lane's window starts 8 samples after its neighbour's).
+// ----------------------------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int PT = 512;                                        // frames per wave tile
+struct __attribute__((aligned(16))) v2fx2 { v2f a, b; };
+
+__device__ __forceinline__ int ppos(int e, int q) { const int h = e >> 1; return ((h >> 2) << 1) + (h & 3) * q + (e & 1); }
+
+// stage frames [org, org + n) of rows ra / rb (zeros outside [0, lim)) at sample index 0.. of `dst` (n a multiple of 8)
+template <class T>
+__device__ __forceinline__ void stage_pair(v2f* dst, int q, const T* ra, const T* rb, int org, int n, int lim, int lane) {
+  const int a0 = org & ~7;
+  for (int i8 = a0 + 8 * lane; i8 < org + n; i8 += 512) {
+    float a[8], b[8];
+    if (i8 >= 0 && i8 < lim) { load8(ra + i8, a); load8(rb + i8, b); }
+    else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) { a[m] = 0.f; b[m] = 0.f; }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int i = i8 + m, e = i - org;
+      if (e >= 0 && e < n) dst[ppos(e, q)] = i < lim ? v2f{a[m], b[m]} : v2f{0.f, 0.f};
+    }
+  }
+}
+
+// entries e0 .. e0 + 7 (e0 a multiple of 8) of a staged pair -> win[off .. off + 7]
+__device__ __forceinline__ void win_load(const v2f* src, int q, int e0, v2f (&win)[16], int off) {
+  const int base = (e0 >> 3) << 1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const v2fx2 v = *reinterpret_cast<const v2fx2*>(src + base + r * q);
+    win[off + 2 * r] = v.a; win[off + 2 * r + 1] = v.b;
+  }
+}
+
+// One FIR over the pair: acc[m] += sum_j tap(j) * src[e0 + m + j], j < k8.  `raw(j)` returns the (clamped-index) tap pair of
+// step j as loaded, `sel(j, v)` zeroes it outside the tap range: the loads of step j0 + 8 are issued before the 64 FMAs of step
+// j0 and only selected after them, so the scalar-load latency hides behind the FMA block.
+template <class R, class S>
+__device__ __forceinline__ void fir_pair(const v2f* src, int q, int e0, int k8, R raw, S sel, v2f (&acc)[8]) {
+  v2f win[16], wn[8];
+  win_load(src, q, e0, win, 0);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) wn[jj] = raw(jj);
+  for (int j0 = 0; j0 < k8; j0 += 8) {
+    win_load(src, q, e0 + j0 + 8, win, 8);
+    v2f w[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) w[jj] = sel(j0 + jj, wn[jj]);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) wn[jj] = raw(j0 + 8 + jj);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m] = __builtin_elementwise_fma(w[jj], win[m + jj], acc[m]);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) win[m] = win[m + 8];
+  }
+}
+
+__device__ __forceinline__ void store_pair(float* ra, float* rb, const v2f (&acc)[8], int t, int lim) {
+  float a[8], b[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) { const bool on = t + m < lim; a[m] = on ? acc[m][0] : 0.f; b[m] = on ? acc[m][1] : 0.f; }
+  store8(ra + t, a); store8(rb + t, b);
+}
+__device__ __forceinline__ void store_pair(bf16_t* ra, bf16_t* rb, const v2f (&acc)[8], int t, int lim) {
+  float a[8], b[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) { const bool on = t + m < lim; a[m] = on ? acc[m][0] : 0.f; b[m] = on ? acc[m][1] : 0.f; }
+  store8(ra + t, a); store8(rb + t, b);
+}
+
+__host__ __device__ constexpr int pair_xl(int k8) { return PT + k8 + 16; }                       // staged x samples per tile
+__host__ __device__ constexpr int pair_gl(int k, int p) { return round_up(p, 8) + PT + round_up(k + round_up(p, 8) - p, 8) + 16; }
+
+// forward: y[r, t] = sum_j w[c, j] xm[r, t + j - p]; grid = row pairs / 4, 4 waves per workgroup
+template <class T>
+__global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ x, const int* __restrict__ len_in, const int* __restrict__ len_out,
+                                                          const float* __restrict__ w, T* __restrict__ y, int batch, int ch, int t, int k, int p,
+                                                          int pitch) {
+  extern __shared__ __attribute__((aligned(16))) v2f sm2[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int k8 = (k + 7) & ~7, xl = pair_xl(k8), q = xl >> 2;
+  v2f* const xs = sm2 + wave * xl;
+  const long long rp = (long long)blockIdx.x * 4 + wave;
+  if (rp * 2 >= (long long)batch * ch) return;
+  const int b = (int)(rp * 2 / ch), c = (int)(rp * 2 % ch);
+  const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
+  const T* const xa = x + (size_t)rp * 2 * pitch;
+  const T* const xb = xa + pitch;
+  T* const ya = y + (size_t)rp * 2 * pitch;
+  T* const yb = ya + pitch;
+  const float* const wa = w + (size_t)c * k;
+  const float* const wb = wa + k;
+  auto raw = [&](int j) { const int jc = j < k ? j : k - 1; return v2f{wa[jc], wb[jc]}; };     // scalar loads (uniform address)
+  auto sel = [&](int j, v2f v) { return j < k ? v : v2f{0.f, 0.f}; };
+  for (int t0 = 0; t0 < t; t0 += PT) {
+    stage_pair(xs, q, xa, xb, t0 - p, xl, li, lane);
+    __builtin_amdgcn_wave_barrier();
+    const int t8 = 8 * lane;
+    if (t0 + t8 < t) {
+      v2f acc[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
+      fir_pair(xs + ((t8 >> 3) << 1), q, 0, k8, raw, sel, acc);
+      store_pair(ya, yb, acc, t0 + t8, lo);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// backward, data AND weights in one pass over dy / x:
+//   dx[r, i] = (i < len_in) sum_j w[c, j] dym[r, i + p - j]          (the forward FIR with the taps flipped)
+//   dw[c, j] += sum_{b, t} dym[r, t] xm[r, t + j - p]
+// Workgroup = one channel pair x (4 waves x clips_per_wave clips); lane = (tap group of 8, frame slice) for the weight part,
+// partial sums stay in registers over the wave's clips, are combined across the workgroup in LDS and leave as one atomicAdd per
+// (channel, tap) -- dw must be zero on entry.
+template <class T>
+__global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ dy, const T* __restrict__ x, const int* __restrict__ len_in,
+                                                          const int* __restrict__ len_out, const float* __restrict__ w, T* __restrict__ dx,
+                                                          float* __restrict__ dw, int batch, int ch, int t, int k, int p, int pitch,
+                                                          int clips_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) v2f sm2[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int k8 = (k + 7) & ~7, xl = pair_xl(k8), qx = xl >> 2;
+  const int o = round_up(p, 8), fpad = o - p, kf8 = round_up(k + fpad, 8), gl = pair_gl(k, p), qg = gl >> 2;
+  v2f* const xs = sm2 + wave * (xl + gl);
+  v2f* const gs = xs + xl;
+  const int c = 2 * blockIdx.x;
+  const float* const wa = w + (size_t)c * k;
+  const float* const wb = wa + k;
+  auto rawf = [&](int j) { const int jj = j - fpad, jc = jj < 0 ? 0 : (jj < k ? jj : k - 1); return v2f{wa[k - 1 - jc], wb[k - 1 - jc]}; };
+  auto self = [&](int j, v2f v) { const int jj = j - fpad; return (jj >= 0 && jj < k) ? v : v2f{0.f, 0.f}; };
+  const int ng = k8 >> 3, nq = 64 / ng, g = lane % ng, sl = lane / ng;
+  const bool active = sl < nq;
+  v2f part[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) part[jj] = v2f{0.f, 0.f};
+  const int b_lo = (blockIdx.y * 4 + wave) * clips_per_wave;
+  for (int b = b_lo; b < b_lo + clips_per_wave && b < batch; ++b) {
+    const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
+    const size_t r0 = ((size_t)b * ch + c) * pitch;
+    for (int t0 = 0; t0 < t; t0 += PT) {
+      stage_pair(xs, qx, x + r0, x + r0 + pitch, t0 - p, xl, li, lane);
+      stage_pair(gs, qg, dy + r0, dy + r0 + pitch, t0 - o, gl, lo, lane);
+      __builtin_amdgcn_wave_barrier();
+      const int nt = t - t0 < PT ? t - t0 : PT;
+      const int i8 = 8 * lane;
+      if (i8 < nt) {
+        v2f acc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
+        fir_pair(gs + ((i8 >> 3) << 1), qg, 0, kf8, rawf, self, acc);
+        store_pair(dx + r0, dx + r0 + pitch, acc, t0 + i8, li);
+      }
+      if (active) {
+        const int per = round_up((nt + nq - 1) / nq, 8);
+        const int lo_t = sl * per < nt ? sl * per : nt, hi_t = lo_t + per < nt ? lo_t + per : nt;
+        if (lo_t < hi_t) {
+          v2f win[16];
+          win_load(xs, qx, lo_t + 8 * g, win, 0);
+          for (int tt = lo_t; tt < hi_t; tt += 8) {
+            win_load(xs, qx, tt + 8 * g + 8, win, 8);
+            v2f gv[16];
+            win_load(gs, qg, o + tt, gv, 0);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+              for (int jj = 0; jj < 8; ++jj) part[jj] = __builtin_elementwise_fma(gv[m], win[m + jj], part[jj]);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) win[m] = win[m + 8];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  v2f* const red = sm2;                                  // [4 waves][64 lanes][8]
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) red[(threadIdx.x) * 8 + jj] = active ? part[jj] : v2f{0.f, 0.f};
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * k; idx += 256) {
+    const int sel = idx / k, j = idx % k, gj = j >> 3, jj = j & 7;
+    float tot = 0.f;
+    for (int wv = 0; wv < 4; ++wv)
+      for (int r = 0; r < nq; ++r) tot += red[((wv * 64) + r * ng + gj) * 8 + jj][sel];
+    atomicAdd(dw + (size_t)(c + sel) * k + j, tot);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
 // Row-wise streaming kernels: grid (rows = B * C, 2048-frame chunks), 256 threads x 8 elements (16 / 32 bytes per lane).
 // Rows are pitched and 16-byte aligned, so every access is a whole vector; columns >= t are scratch and may be overwritten.
 // ----------------------------------------------------------------------------------------------------------------------
@@ -492,6 +694,11 @@ static inline bool rows_ok(const void* p, int pitch, int act) {
 using namespace ts;
 #define TS_STREAM hipStream_t stream = reinterpret_cast<hipStream_t>(stream_); (void)hipGetLastError()
 // dispatch on the activation type: ACT(kernel, grid, block, lds, args...) launches kernel<float> or kernel<bf16_t>
+// the "same" geometry the pair kernels cover
+static bool pair_geometry(int ch, int t_in, int t_out, int k, int stride, int dil, int pad, int pitch_in, int pitch_out) {
+  return stride == 1 && dil == 1 && (k & 1) && pad == (k - 1) / 2 && t_in == t_out && (ch & 1) == 0 && pitch_in == pitch_out && k <= DW_KMAX;
+}
+
 #define TS_ACT(act, expr_f32, expr_bf16) do { if (act) { expr_bf16; } else { expr_f32; } } while (0)
 
 extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
@@ -501,6 +708,16 @@ extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const i
   if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
+  if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
+    const size_t lds2 = 4 * (size_t)pair_xl(round_up(k, 8)) * sizeof(v2f);
+    const dim3 grid2((unsigned)(((long long)batch * ch / 2 + 3) / 4));
+    TS_ACT(act,
+           hipLaunchKernelGGL(dw_fwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)x, len_in, len_out, w, (float*)y, batch, ch,
+                              t_in, k, pad, pitch_in),
+           hipLaunchKernelGGL(dw_fwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)x, len_in, len_out, w, (bf16_t*)y, batch,
+                              ch, t_in, k, pad, pitch_in));
+    return hip_status(hipGetLastError());
+  }
   const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 32) * sizeof(float);
   if (lds > 64 * 1024) return TS_EUNSUPPORTED;
   const dim3 grid((t_out + DW_TILE - 1) / DW_TILE, batch * ch);
@@ -519,6 +736,18 @@ extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t*
   if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
+  if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
+    const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k, 8)) + pair_gl(k, pad)) * sizeof(v2f);
+    const int cpw = batch > 32 ? (batch + 31) / 32 : 1;
+    const dim3 grid2(ch / 2, (batch + 4 * cpw - 1) / (4 * cpw));
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)ch * k, stream) != hipSuccess) return TS_EUNSUPPORTED;
+    TS_ACT(act,
+           hipLaunchKernelGGL(dw_bwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)dy, (const float*)x, len_in, len_out, w,
+                              (float*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw),
+           hipLaunchKernelGGL(dw_bwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, w,
+                              (bf16_t*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw));
+    return hip_status(hipGetLastError());
+  }
   const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 48) * sizeof(float);
   const size_t lds_w = (size_t)(round_up(t_out + 16, 4) + round_up(t_in + 2 * pad + 48, 2)) * sizeof(float) + 256 * 8 * sizeof(double);
   if (k > 256) return TS_EUNSUPPORTED;

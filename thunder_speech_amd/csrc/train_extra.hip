@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, 
 // element (row, i) draws word (e & 3) of Philox counter e >> 2, e = row * t + i: the mask depends on the LOGICAL index only
 template <class T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int t, int pitch, float p, float scale,
-                                                       unsigned long long seed) {
+                                                       unsigned long long seed, const unsigned long long* __restrict__ nonce) {
   const long long row = blockIdx.x;
+  if (nonce) seed += *nonce;                             // replay counter of a captured training step (hipGraph): a new mask per replay
   for (int i = blockIdx.y * 1024 + threadIdx.x; i < t && i < (int)(blockIdx.y + 1) * 1024; i += 256) {
     const unsigned long long e = (unsigned long long)row * t + i;
     const Philox4 r = philox(seed, PHILOX_DROPOUT, e >> 2);
@@ -142,12 +143,24 @@ extern "C" int ts_train_se_scale(const void* x, const float* gate, const float* 
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_dropout(const void* x, void* y, int64_t rows, int32_t t, int32_t pitch, float p, uint64_t seed, int32_t act, void* stream) {
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; }
+
+extern "C" int ts_counter_add(uint64_t* counter, uint64_t inc, void* stream) {
+  if (!counter) return TS_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)counter, (unsigned long long)inc);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_dropout(const void* x, void* y, int64_t rows, int32_t t, int32_t pitch, float p, uint64_t seed, const uint64_t* nonce,
+                                int32_t act, void* stream) {
   if (!x || !y || rows <= 0 || t <= 0 || pitch < t || !(p >= 0.f) || p > 1.f || act < 0 || act > 1) return TS_EINVAL;
   const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
   (void)hipGetLastError();
   TS_ACT(act,
-         hipLaunchKernelGGL(dropout_kernel<float>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, t, pitch, p, scale, (unsigned long long)seed),
-         hipLaunchKernelGGL(dropout_kernel<bf16_t>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, t, pitch, p, scale, (unsigned long long)seed));
+         hipLaunchKernelGGL(dropout_kernel<float>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, t, pitch, p, scale, (unsigned long long)seed,
+                            (const unsigned long long*)nonce),
+         hipLaunchKernelGGL(dropout_kernel<bf16_t>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, t, pitch, p, scale, (unsigned long long)seed,
+                            (const unsigned long long*)nonce));
   return hip_status(hipGetLastError());
 }

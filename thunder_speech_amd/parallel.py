@@ -106,6 +106,7 @@ class GradientSync:
         self._launched = [False] * len(self.buckets)
         self._side = torch.cuda.Stream(device=dev) if on_gpu else None
         self.n_collectives = 0
+        self._hold = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(idx)) for idx, p in enumerate(self.params)]
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -120,7 +121,7 @@ class GradientSync:
                 param.grad = view
             b = self._bucket_of[idx]
             self._pending[b] -= 1
-            if self._pending[b] == 0:
+            if self._pending[b] == 0 and not self._hold:
                 self._launch(b)
         return hook
 
@@ -165,17 +166,25 @@ class GradientSync:
                 else:
                     seg.copy_(wire)
 
-    def finish(self) -> None:
+    def hold(self, on: bool = True) -> None:
+        """While held, the hooks only collect the gradients into the buckets and every collective waits for finish(): the mode of
+        a backward pass that is captured into / replayed from a hipGraph (train_graph.GraphedTrainStep), where the host-side hooks
+        do not run per step."""
+        self._hold = bool(on)
+
+    def finish(self, exchange: bool = True) -> None:
         """After backward(): launch whatever has not been launched (parameters that received no gradient this step keep their
-        zeros), then make the compute stream wait for the exchange.  Resets the per-step bookkeeping."""
+        zeros), then make the compute stream wait for the exchange.  Resets the per-step bookkeeping.  `exchange=False` does the
+        bookkeeping only (warm-up / capture passes of a graphed step, whose gradients are discarded)."""
         for p, view in zip(self.params, self._views):
             if p.grad is None:
                 p.grad = view                             # no gradient this step: the zeros of the bucket
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
-        if self._side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        if exchange:
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)
+            if self._side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
         self._pending = [len(m) for (_, _, m) in self.buckets]
         self._launched = [False] * len(self.buckets)
 

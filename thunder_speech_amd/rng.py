@@ -10,3 +10,22 @@ import torch
 
 def next_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+_NONCE = {}
+
+
+def replay_nonce(device) -> torch.Tensor:
+    """Device-side uint64 (stored as int64 [1]) every dropout kernel adds to its by-value seed.  Zero outside hipGraphs; a graphed
+    training step (train_graph.GraphedTrainStep) captures `bump_replay_nonce` at its head, so each replay of the frozen launch
+    arguments still draws fresh masks."""
+    key = str(torch.device(device))
+    if key not in _NONCE:
+        _NONCE[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _NONCE[key]
+
+
+def bump_replay_nonce(device) -> None:
+    from . import _lib
+    n = replay_nonce(device)
+    _lib.check(_lib.lib().ts_counter_add(n.data_ptr(), 0x9E3779B97F4A7C15, torch.cuda.current_stream(n.device).cuda_stream), "ts_counter_add")

@@ -40,6 +40,11 @@ def _s(t: Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _nonce(t: Tensor) -> int:
+    from .rng import replay_nonce
+    return replay_nonce(t.device).data_ptr()
+
+
 def _code(t: Tensor) -> int:
     return 1 if t.dtype == torch.bfloat16 else 0
 
@@ -55,8 +60,10 @@ def alloc_like(x: Tensor) -> Tensor:
 
 
 def is_act(x: Tensor) -> bool:
-    return (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(2) == 1 and x.stride(1) % 8 == 0
-            and x.stride(1) >= x.shape[2] and x.stride(0) == x.shape[1] * x.stride(1) and x.data_ptr() % 32 == 0)
+    # the pitch must be THE pitch `alloc` gives this length: kernels take one pitch for a tensor and its gradient / its
+    # same-shape output, so a foreign row layout (e.g. the front end's feature rows, padded to its own tile) is re-packed
+    return (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(2) == 1
+            and x.stride(1) == (x.shape[2] + 7) // 8 * 8 and x.stride(0) == x.shape[1] * x.stride(1) and x.data_ptr() % 32 == 0)
 
 
 def _pitch(x: Tensor) -> int:
@@ -317,7 +324,7 @@ class Dropout(torch.autograd.Function):
         x3 = x if x.dim() == 3 else x.reshape(1, 1, -1)
         x3 = _import(x3, x3.dtype if is_act(x3) else _ACT_DTYPE)
         y = alloc_like(x3)
-        st = _lib.lib().ts_train_dropout(x3.data_ptr(), y.data_ptr(), x3.shape[0] * x3.shape[1], x3.shape[2], _pitch(x3), float(p), int(seed),
+        st = _lib.lib().ts_train_dropout(x3.data_ptr(), y.data_ptr(), x3.shape[0] * x3.shape[1], x3.shape[2], _pitch(x3), float(p), int(seed), _nonce(x3),
                                          _code(x3), _s(x3))
         _lib.check(st, "ts_train_dropout")
         ctx.p, ctx.seed, ctx.shape, ctx.dtype = float(p), int(seed), x.shape, x3.dtype
@@ -328,7 +335,7 @@ class Dropout(torch.autograd.Function):
         d3 = dy if dy.dim() == 3 else dy.reshape(1, 1, -1)
         d3 = _import(d3, ctx.dtype)
         dx = alloc_like(d3)
-        st = _lib.lib().ts_train_dropout(d3.data_ptr(), dx.data_ptr(), d3.shape[0] * d3.shape[1], d3.shape[2], _pitch(d3), ctx.p, ctx.seed,
+        st = _lib.lib().ts_train_dropout(d3.data_ptr(), dx.data_ptr(), d3.shape[0] * d3.shape[1], d3.shape[2], _pitch(d3), ctx.p, ctx.seed, _nonce(d3),
                                          _code(d3), _s(d3))
         _lib.check(st, "ts_train_dropout")
         return (dx if len(ctx.shape) == 3 else dx.reshape(ctx.shape)), None, None
@@ -453,7 +460,7 @@ class SubBlock(torch.autograd.Function):
         out = y
         if cfg.drop_p > 0.0:
             out = alloc_like(y)
-            _lib.check(L.ts_train_dropout(y.data_ptr(), out.data_ptr(), b * c_out, t_out, _pitch(y), float(cfg.drop_p), int(cfg.drop_seed), code, st_),
+            _lib.check(L.ts_train_dropout(y.data_ptr(), out.data_ptr(), b * c_out, t_out, _pitch(y), float(cfg.drop_p), int(cfg.drop_seed), _nonce(x), code, st_),
                        "ts_train_dropout")
         ctx.save_for_backward(x, mid, v, y, g, mr, wk, *([w_dw] if w_dw is not None else []))
         ctx.cfg, ctx.params = cfg, (dw_w, pw_w, gamma, beta)
@@ -474,7 +481,7 @@ class SubBlock(torch.autograd.Function):
         dy = _g(dy, y)
         if cfg.drop_p > 0.0:
             d2 = alloc_like(dy)
-            _lib.check(L.ts_train_dropout(dy.data_ptr(), d2.data_ptr(), b * c_out, t_out, _pitch(dy), float(cfg.drop_p), int(cfg.drop_seed), code, st_),
+            _lib.check(L.ts_train_dropout(dy.data_ptr(), d2.data_ptr(), b * c_out, t_out, _pitch(dy), float(cfg.drop_p), int(cfg.drop_seed), _nonce(x), code, st_),
                        "ts_train_dropout")
             dy = d2
         dv = alloc_like(v)

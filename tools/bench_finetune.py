@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--unfreeze", action="store_true", help="phase 2: encoder trainable (training-mode kernels, full backward)")
     ap.add_argument("--graph-encoder", action="store_true", help="phase 1: replay front end + frozen encoder from a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="phase 2: replay encoder + decoder + loss + backward from one hipGraph (train_graph.GraphedTrainStep)")
     ap.add_argument("--gemm-bf16", action="store_true", help="phase 2: bf16 operands for the pointwise-conv GEMMs (opt-in mixed precision)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -55,7 +56,14 @@ def main():
     lengths = torch.full((B,), 16000.0 * args.seconds, device=dev)
     texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(60, 140, (B,), generator=g)]
 
+    graphed = None
+    if args.graph and args.unfreeze:
+        from thunder_speech_amd.train_graph import GraphedTrainStep
+        graphed = GraphedTrainStep(m, opt, sync, max_target_len=160)
+
     def step():
+        if graphed is not None:
+            return graphed((wav, lengths, texts))
         sync.zero_grad()
         loss = m.training_step((wav, lengths, texts), 0)
         loss.backward()
@@ -72,7 +80,7 @@ def main():
     torch.cuda.synchronize()
     dt = max_over_ranks((time.perf_counter() - t0) / args.steps, dev)
     if rank == 0:
-        print(f"C4 phase {2 if args.unfreeze else 1} ({'encoder unfrozen' if args.unfreeze else 'frozen encoder'}{', bf16 GEMM operands' if args.gemm_bf16 else ''}), {world} GPU(s), local batch {B} x {args.seconds} s: {dt * 1e3:.2f} ms/step, "
+        print(f"C4 phase {2 if args.unfreeze else 1} ({'encoder unfrozen' if args.unfreeze else 'frozen encoder'}{', bf16 activations' if args.gemm_bf16 else ''}{', hipGraph' if graphed is not None else ''}), {world} GPU(s), local batch {B} x {args.seconds} s: {dt * 1e3:.2f} ms/step, "
               f"{1 / dt:.1f} step/s, {world * B * args.seconds / dt:,.0f} audio-s/s, loss {float(loss.detach()):.3f}")
     if world > 1:
         dist.destroy_process_group()

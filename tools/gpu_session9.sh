@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out/s9
+python -m pytest tests/test_gpu_train_encoder.py -m gpu -q --timeout 900 -x -k "graphed or dropout or pair" > gpurun_out/s9/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/s9/pytest.log
+grep -E "^FAILED|^ERROR|passed|failed|rc=" gpurun_out/s9/pytest.log | head -30
+timeout 600 python tools/bench_finetune.py --unfreeze --steps 20 --gemm-bf16 --graph 2>&1 | grep -v amdgpu | tail -4
+timeout 600 python tools/bench_finetune.py --unfreeze --steps 20 --graph 2>&1 | grep -v amdgpu | tail -2
