@@ -194,8 +194,10 @@ int ts_decoder_bwd(const float* grad_logits, const void* x, int32_t batch, int32
                    int32_t pitch_g, int32_t pitch_x, float* d_weight, float* d_bias, void* stream);
 int ts_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
-/* The same update for all tensors of a parameter group in one launch.  table: device array of n_tensors entries of five 64-bit
- * words (param, grad, exp_avg, exp_avg_sq pointers, element count); max_numel = the largest element count; one shared step. */
+/* The same update for all tensors of a parameter group in one launch.  table: device array of n_tensors entries of SIX 64-bit
+ * words (param, grad, exp_avg, exp_avg_sq pointers, element count, bf16 shadow pointer or 0); max_numel = the largest element
+ * count; one shared step.  A non-zero shadow receives the updated parameter rounded to bf16 (the GEMM operand copy of the
+ * mixed-precision training path: no separate cast launch per layer and step). */
 int ts_adamw_multi_step(const void* table, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int32_t step, void* stream);
 /* Wire format of the data-parallel gradient exchange (what Lightning DDP's all-reduce moves for the reference, module.py:102-127):
@@ -224,7 +226,8 @@ int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len
                         int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride, int32_t dilation,
                         int32_t padding, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);
 /* len_out (may be NULL) in both directions: the forward zeroes y from len_out[b] on -- the re-masking the next MaskedConv1d applies
- * (quartznet/blocks.py:169-171) -- and the backward treats dy as zero there; no separate masking pass is needed then. */
+ * (quartznet/blocks.py:169-171) -- and the backward treats dy as zero there; no separate masking pass is needed then.
+ * dw ACCUMULATES: dw += sum_{b,t} dy * x (float atomics over clip groups); hand in zeros for a plain gradient. */
 int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* dx,
                         float* dw, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride,
                         int32_t dilation, int32_t padding, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);
@@ -248,6 +251,9 @@ int ts_train_bn_bwd(const void* dy, const void* y, const void* v, const float* g
                     int32_t relu, int32_t act, void* stream);
 int ts_train_add_relu_fwd(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_relu_bwd(const void* dout, const void* out, void* din, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+/* out = a + b on activation rows: the sum of the two gradients that meet where a block input feeds both the main branch and the
+ * residual branch (autograd's own accumulation would leave the row layout). */
+int ts_train_add(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
 /* strided 1x1 MaskedConv1d (residual branch of a strided block: quartznet/blocks.py:301-311, citrinet/blocks.py:156-165) =
  * this mask + subsample pass followed by the pointwise GEMM.  backward = 0: y[b,c,j] = x[b,c,j*stride] if j*stride < len[b] else 0
  * (x rows of t_in, y rows of t_out); backward = 1: x is dy (t_out), y is dx (t_in), zero where the forward read nothing. */

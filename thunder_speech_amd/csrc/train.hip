@@ -79,11 +79,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   p[i] = pi;
 }
 
-// all tensors of a parameter group in ONE launch: table[i] = (param, grad, exp_avg, exp_avg_sq, n) as 64-bit words; blockIdx.y is the
-// tensor, blockIdx.x its 1024-element block (blocks past a tensor's end leave at once)
+// all tensors of a parameter group in ONE launch: table[i] = (param, grad, exp_avg, exp_avg_sq, n, bf16 shadow | 0) as 64-bit words;
+// blockIdx.y is the tensor, blockIdx.x its 1024-element block (blocks past a tensor's end leave at once).  A non-zero shadow pointer
+// receives the updated parameter rounded to bf16: the GEMM operand copy of the mixed-precision training path, refreshed for free.
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned long long* __restrict__ table, float lr, float beta1, float beta2,
                                                           float eps, float weight_decay, float bias_c1, float bias_c2) {
-  const unsigned long long* e = table + (size_t)blockIdx.y * 5;
+  const unsigned long long* e = table + (size_t)blockIdx.y * 6;
   const long long n = (long long)e[4];
   const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
   if ((long long)blockIdx.x * 1024 >= n) return;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned long lo
   const float* g = reinterpret_cast<const float*>(e[1]);
   float* m = reinterpret_cast<float*>(e[2]);
   float* v = reinterpret_cast<float*>(e[3]);
+  unsigned short* shadow = reinterpret_cast<unsigned short*>(e[5]);
   const float step_size = lr / bias_c1, inv_sqrt_c2 = 1.f / sqrtf(bias_c2), decay = 1.f - lr * weight_decay;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned long lo
       v[i] = vi;
       pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_c2 + eps);
       p[i] = pi;
+      if (shadow) shadow[i] = (unsigned short)(pack_bf16(pi, 0.f) & 0xffffu);
     }
   }
 }

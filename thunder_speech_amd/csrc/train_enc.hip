@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
     const int j = threadIdx.x, gj = j / TG, jj = j % TG;
     double tot = 0.0;
     for (int r = 0; r < nq; ++r) tot += red[(r * ng + gj) * TG + jj];
-    atomicAdd(dw + (size_t)c * k + j, (float)tot);       // dw is zeroed by the launcher; clips are split over blockIdx.y
+    atomicAdd(dw + (size_t)c * k + j, (float)tot);       // dw accumulates (zero on entry for a plain gradient); clips are split over blockIdx.y
   }
 }
 
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
 //   dw[c, j] += sum_{b, t} dym[r, t] xm[r, t + j - p]
 // Workgroup = one channel pair x (4 waves x clips_per_wave clips); lane = (tap group of 8, frame slice) for the weight part,
 // partial sums stay in registers over the wave's clips, are combined across the workgroup in LDS and leave as one atomicAdd per
-// (channel, tap) -- dw must be zero on entry.
+// (channel, tap): dw ACCUMULATES (the caller hands in zeros for a plain gradient).
 template <class T>
 __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ dy, const T* __restrict__ x, const int* __restrict__ len_in,
                                                           const int* __restrict__ len_out, const float* __restrict__ w, T* __restrict__ dx,
@@ -628,9 +628,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   store8(dv + base, g);
 }
 
-// out = relu(a + b); backward: da = db = dout * (out > 0)
-template <class T>
-__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
+// out = relu(a + b) (RELU) or a + b; backward of the first: da = db = dout * (out > 0)
+template <class T, bool RELU>
+__device__ __forceinline__ void add_rows(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
   const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
   if (i >= t) return;
   const size_t base = (size_t)blockIdx.x * pitch + i;
@@ -638,8 +638,16 @@ __global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* __restrict__
   load8(a + base, x);
   if (b) load8(b + base, z);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { const float s = x[j] + (b ? z[j] : 0.f); x[j] = s > 0.f ? s : 0.f; }
+  for (int j = 0; j < 8; ++j) { const float s = x[j] + (b ? z[j] : 0.f); x[j] = (!RELU || s > 0.f) ? s : 0.f; }
   store8(o + base, x);
+}
+template <class T>
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
+  add_rows<T, true>(a, b, o, t, pitch);
+}
+template <class T>
+__global__ __launch_bounds__(256) void add_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
+  add_rows<T, false>(a, b, o, t, pitch);
 }
 template <class T>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ din, int t, int pitch) {
@@ -740,7 +748,6 @@ extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t*
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k, 8)) + pair_gl(k, pad)) * sizeof(v2f);
     const int cpw = batch > 32 ? (batch + 31) / 32 : 1;
     const dim3 grid2(ch / 2, (batch + 4 * cpw - 1) / (4 * cpw));
-    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)ch * k, stream) != hipSuccess) return TS_EUNSUPPORTED;
     TS_ACT(act,
            hipLaunchKernelGGL(dw_bwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)dy, (const float*)x, len_in, len_out, w,
                               (float*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw),
@@ -758,7 +765,6 @@ extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t*
                             t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
          hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, gd, dim3(256), lds_d, stream, (const bf16_t*)dy, len_in, len_out, w, (bf16_t*)dx, batch, ch,
                             t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out));
-  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)ch * k, stream) != hipSuccess) return TS_EUNSUPPORTED;
   TS_ACT(act,
          hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, gw, dim3(256), lds_w, stream, (const float*)dy, (const float*)x, len_in, len_out, dw, batch,
                             ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
@@ -913,6 +919,16 @@ extern "C" int ts_train_add_relu_fwd(const void* a, const void* b, void* out, in
   TS_ACT(act,
          hipLaunchKernelGGL(add_relu_fwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, t, pitch),
          hipLaunchKernelGGL(add_relu_fwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, t, pitch));
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_add(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!a || !b || !out || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1) return TS_EINVAL;
+  if (!rows_ok(a, pitch, act) || !rows_ok(out, pitch, act) || !rows_ok(b, pitch, act)) return TS_EINVAL;
+  TS_STREAM;
+  TS_ACT(act,
+         hipLaunchKernelGGL(add_fwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, t, pitch),
+         hipLaunchKernelGGL(add_fwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, t, pitch));
   return hip_status(hipGetLastError());
 }
 

@@ -52,7 +52,10 @@ class FusedAdamW(torch.optim.Optimizer):
             steps = {st["step"] for _, _, st in todo}
             if len(todo) >= 8 and len(steps) == 1 and all(p.device == dev for p, _, _ in todo):
                 # one launch for the whole group: a pointer table (rebuilt every step: gradients are fresh tensors) and one grid
-                rows = [[p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()] for p, g, st in todo]
+                from .train_ops import bf16_shadow
+                shadows = [bf16_shadow(p) for p, _, _ in todo]          # bf16 GEMM operand copies the training path keeps (if any)
+                rows = [[p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                         sh[0].data_ptr() if sh is not None else 0] for (p, g, st), sh in zip(todo, shadows)]
                 # pinned + non_blocking: the upload is queued behind the step's kernels instead of making the host wait for them
                 # (the pinned-memory allocator does not recycle the block before the copy has run)
                 table = torch.tensor(rows, dtype=torch.int64, pin_memory=True).to(dev, non_blocking=True)
@@ -60,6 +63,9 @@ class FusedAdamW(torch.optim.Optimizer):
                                            float(group["eps"]), float(group["weight_decay"]), int(steps.pop()), stream)
                 _lib.check(rc, "ts_adamw_multi_step")
                 _bump_versions(p for p, _, _ in todo)
+                for (p, _, _), sh in zip(todo, shadows):
+                    if sh is not None:
+                        sh[1] = p._version                                # the kernel refreshed the copy: it matches the new version
                 continue
             for p, g, st in todo:
                 rc = L.ts_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),

@@ -99,7 +99,7 @@ class GradientSync:
             view = self.flat[offsets[idx]: offsets[idx] + p.numel()].view_as(p)
             self._views.append(view)
             p.grad = view
-            train_ops._GRAD_VIEWS[id(p)] = view          # the training kernels write parameter gradients straight into the bucket
+            train_ops._GRAD_VIEWS[id(p)] = (view, self)  # the training kernels write parameter gradients straight into the bucket
         self._wire = [torch.empty(length, dtype=self.wire_dtype, device=dev) if self.wire_dtype != torch.float32 else None
                       for (_, length, _) in self.buckets]
         self._pending = [len(m) for (_, _, m) in self.buckets]
@@ -107,6 +107,7 @@ class GradientSync:
         self._side = torch.cuda.Stream(device=dev) if on_gpu else None
         self.n_collectives = 0
         self._hold = False
+        self._clean = True                      # the flat buffer holds zeros only (between zero_grad() and the first gradient of the step)
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(idx)) for idx, p in enumerate(self.params)]
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -176,6 +177,7 @@ class GradientSync:
         """After backward(): launch whatever has not been launched (parameters that received no gradient this step keep their
         zeros), then make the compute stream wait for the exchange.  Resets the per-step bookkeeping.  `exchange=False` does the
         bookkeeping only (warm-up / capture passes of a graphed step, whose gradients are discarded)."""
+        self._clean = False
         for p, view in zip(self.params, self._views):
             if p.grad is None:
                 p.grad = view                             # no gradient this step: the zeros of the bucket
@@ -193,8 +195,14 @@ class GradientSync:
         kernels of the training path then write their result straight into the bucket views and autograd adopts those tensors
         as `.grad` (train_ops.grad_out) -- no accumulate kernel, no copy.  Parameters that receive no gradient keep the zeros."""
         self.flat.zero_()
+        self._clean = True
         for p in self.params:
             p.grad = None
+
+    def is_clean(self) -> bool:
+        """True between zero_grad() and finish(): every bucket view not yet written this step still holds zeros, so a kernel that
+        accumulates into one (the depthwise weight gradient) needs no memset of its own."""
+        return self._clean
 
     def close(self) -> None:
         from . import train_ops

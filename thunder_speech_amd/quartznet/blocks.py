@@ -205,6 +205,8 @@ class _FusedBlockBase(nn.Module):
         x = T.to_act(x)              # activation rows of the training path's element type (train_ops.set_activation_dtype)
         dev = x.device
         len_in = _t.lengths_i32(lengths, dev)
+        if self.res is not None:     # two consumers: one node adds the two gradients on the way back (on activation rows)
+            x, x_res = T.Fork.apply(x)
         h, lh, out_lengths = x, len_in, lengths
         subs = list(self._sub_blocks())
         for r, (dw, pw, bn) in enumerate(subs):
@@ -225,10 +227,10 @@ class _FusedBlockBase(nn.Module):
         if self.res is not None:
             rc, rbn = self.res[0], self.res[1].layer[0]
             if rc.stride != 1:       # strided 1x1 MaskedConv1d: mask + subsample, then the pointwise GEMM
-                r_in = T.SubsampleMask.apply(x, len_in, rc.stride, (x.shape[2] - 1) // rc.stride + 1)
-            else:
-                r_in = T.MaskTime.apply(x, len_in)
-            r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(r_in, rc.conv.weight), relu=False)
+                r_in = T.SubsampleMask.apply(x_res, len_in, rc.stride, (x_res.shape[2] - 1) // rc.stride + 1)
+                r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(r_in, rc.conv.weight), relu=False)
+            else:                    # mask -> 1x1 -> BatchNorm as one node, like a repeat without depthwise conv and ReLU
+                r_out = T.sub_block(x_res, None, rc, rbn, len_in, len_in, relu=False)
         out = T.AddRelu.apply(h, r_out)
         return T.dropout(out, out_drop.p, out_drop.training), out_lengths
 

@@ -40,7 +40,8 @@ class GraphedTrainStep:
     # ------------------------------------------------------------------------------------------------------------------
     def _body(self, feats, flen, y, ylen):
         m = self.module
-        rng.bump_replay_nonce(feats.device)
+        if torch.cuda.is_current_stream_capturing():
+            rng.bump_replay_nonce(feats.device)
         self.sync.zero_grad()
         encoded, out_lengths = m.encoder(feats, flen)
         probabilities = m.decoder(encoded)

@@ -40,7 +40,11 @@ def _s(t: Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _nonce(t: Tensor) -> int:
+def _nonce(t: Tensor):
+    """Device replay counter for the dropout seed -- only while the launch is being captured into a hipGraph (whose by-value seed is
+    frozen); eager launches draw a fresh seed per call and pass NULL, so their masks are a pure function of that seed."""
+    if not torch.cuda.is_current_stream_capturing():
+        return None
     from .rng import replay_nonce
     return replay_nonce(t.device).data_ptr()
 
@@ -135,25 +139,78 @@ def _g(dy: Tensor, like: Tensor) -> Tensor:
 
 
 # Parameter-gradient buffers.  parallel.GradientSync registers, per parameter, the view of its flat bucket buffer the gradient
-# has to end up in; the backward kernels then write there directly and autograd adopts the returned tensor as `.grad` (no
-# per-parameter accumulate kernel, no copy into the bucket).
+# has to end up in (and itself: it knows whether the buffer is still all zeros); the backward kernels then write there directly and
+# autograd adopts the returned tensor as `.grad` (no per-parameter accumulate kernel, no copy into the bucket).
 _GRAD_VIEWS = {}
 
 
-def grad_out(param, shape) -> Tensor:
+def grad_out(param, shape, zeroed: bool = False) -> Tensor:
     """f32 tensor of `shape` for the gradient of `param`: its registered flat-buffer view when it has one and `.grad` is unset
-    (first -- and in the fine-tuning loop only -- contribution of the step), else a fresh tensor."""
-    view = _GRAD_VIEWS.get(id(param)) if param is not None else None
-    if view is not None and param.grad is None:
-        return view.view(shape)
-    dev = view.device if view is not None else param.device
-    return torch.empty(shape, dtype=torch.float32, device=dev)
+    (first -- and in the fine-tuning loop only -- contribution of the step), else a fresh tensor.  `zeroed`: the kernel about to
+    receive it ACCUMULATES, so the tensor must hold zeros -- free for a bucket view (GradientSync.zero_grad cleared the whole
+    buffer with one memset), one fill launch otherwise."""
+    ent = _GRAD_VIEWS.get(id(param)) if param is not None else None
+    if ent is not None and param.grad is None:
+        view, owner = ent
+        out = view.view(shape)
+        if zeroed and not owner.is_clean():
+            out.zero_()
+        return out
+    dev = ent[0].device if ent is not None else param.device
+    return (torch.zeros if zeroed else torch.empty)(shape, dtype=torch.float32, device=dev)
 
 
-def _w_bf16(w2: Tensor) -> Tensor:
-    y = torch.empty(w2.shape, dtype=torch.bfloat16, device=w2.device)
+# bf16 operand copies of the weights (mixed precision).  One per parameter, reused while the parameter's version counter stands;
+# optim.FusedAdamW writes the copy inside its update kernel and re-stamps it, so a fine-tuning step launches no cast at all.
+_BF16_SHADOW = {}
+
+
+def bf16_shadow(param: Tensor, create: bool = False):
+    """[bf16 copy [C_out, rest], version it matches, weakref to its parameter] or None."""
+    import weakref
+    ent = _BF16_SHADOW.get(id(param))
+    if ent is not None and (ent[2]() is not param or ent[0].numel() != param.numel() or ent[0].device != param.device):
+        ent = None                               # the id was recycled by another tensor, or the parameter moved
+        _BF16_SHADOW.pop(id(param), None)
+    if ent is None and create:
+        if len(_BF16_SHADOW) > 4096:             # entries of parameters that no longer exist
+            for k in [k for k, e in _BF16_SHADOW.items() if e[2]() is None]:
+                del _BF16_SHADOW[k]
+        ent = _BF16_SHADOW[id(param)] = [torch.empty(param.shape[0], param.numel() // max(param.shape[0], 1), dtype=torch.bfloat16,
+                                                     device=param.device), -1, weakref.ref(param)]
+    return ent
+
+
+def _w_bf16(w2: Tensor, param: Tensor = None) -> Tensor:
+    ent = bf16_shadow(param, create=True) if (param is not None and param.dim() >= 2) else None
+    if ent is not None and ent[1] == param._version:
+        return ent[0]
+    y = ent[0] if ent is not None else torch.empty(w2.shape, dtype=torch.bfloat16, device=w2.device)
     _lib.check(_lib.lib().ts_train_cast_bf16(w2.data_ptr(), y.data_ptr(), w2.numel(), _s(w2)), "ts_train_cast_bf16")
+    if ent is not None:
+        ent[1] = param._version
     return y
+
+
+class Fork(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (a block input: main branch + residual branch).  The backward pass adds the two
+    gradients with one kernel on activation rows; autograd's own accumulation (an ATen add) leaves the row layout, which costs a
+    re-import on the way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        dtype = g1.dtype if is_act(g1) else (g2.dtype if is_act(g2) else _ACT_DTYPE)
+        g1, g2 = _import(g1, dtype), _import(g2, dtype)
+        out = alloc_like(g1)
+        st = _lib.lib().ts_train_add(g1.data_ptr(), g2.data_ptr(), out.data_ptr(), g1.shape[0] * g1.shape[1], g1.shape[2], _pitch(g1), _code(g1), _s(g1))
+        _lib.check(st, "ts_train_add")
+        return out
 
 
 class DepthwiseConv(torch.autograd.Function):
@@ -182,7 +239,7 @@ class DepthwiseConv(torch.autograd.Function):
         k, stride, dil, pad, t_out, wshape = ctx.geom
         dy = _g(dy, x)
         b, c, t_in = x.shape
-        dx, dw = alloc_like(x), grad_out(ctx.param, w2.shape)
+        dx, dw = alloc_like(x), grad_out(ctx.param, w2.shape, zeroed=True)
         lo = ctx.len_out
         st = _lib.lib().ts_train_dwconv_bwd(dy.data_ptr(), x.data_ptr(), len_in.data_ptr(), lo.data_ptr() if lo is not None else None,
                                             w2.data_ptr(), dx.data_ptr(), dw.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad,
@@ -229,7 +286,7 @@ class PointwiseConv(torch.autograd.Function):
         c_out = w2.shape[0]
         bf = u.dtype == torch.bfloat16
         prec = 0 if not bf else (1 if f32_out else 2)
-        wk = _w_bf16(w2) if bf else w2
+        wk = _w_bf16(w2, w) if bf else w2
         v = alloc(b, c_out, t, u.device, torch.float32 if (f32_out or not bf) else torch.bfloat16)
         st = _lib.lib().ts_train_pwconv_fwd(u.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(v), prec, _s(v))
         _lib.check(st, "ts_train_pwconv_fwd")
@@ -444,7 +501,7 @@ class SubBlock(torch.autograd.Function):
                        "ts_train_mask_time")
         w_pw = pw_w.detach().to(torch.float32).contiguous().view(pw_w.shape[0], -1)
         c_out = w_pw.shape[0]
-        wk = _w_bf16(w_pw) if bf else w_pw
+        wk = _w_bf16(w_pw, pw_w) if bf else w_pw
         v = alloc(b, c_out, t_out, x.device, x.dtype)
         _lib.check(L.ts_train_pwconv_fwd(mid.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t_out, _pitch(mid), _pitch(v), 2 if bf else 0, st_),
                    "ts_train_pwconv_fwd")
@@ -496,7 +553,7 @@ class SubBlock(torch.autograd.Function):
                                          _pitch(mid), _pitch(dv), 2 if bf else 0, st_), "ts_train_pwconv_bwd")
         dx = alloc_like(x)
         if w_dw is not None:
-            ddw = grad_out(dw_p, w_dw.shape)
+            ddw = grad_out(dw_p, w_dw.shape, zeroed=True)
             _lib.check(L.ts_train_dwconv_bwd(dmid.data_ptr(), x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), dx.data_ptr(),
                                              ddw.data_ptr(), b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(dmid), code, st_),
                        "ts_train_dwconv_bwd")

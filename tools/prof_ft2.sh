@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(f)))
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 steps = 13
 print(f"total kernel time per step {tot/1e6/steps:.2f} ms, launches per step {sum(int(r['Calls']) for r in rows)/steps:.0f}")
-for r in rows[:22]:
+for r in rows[:40]:
     print(f"{r['Name'][:90]:90s} {int(r['Calls'])/steps:7.1f} {int(r['TotalDurationNs'])/1e6/steps:8.3f} ms/step {float(r['AverageNs'])/1e3:8.1f} us")
 os.system(f"cp {f} gpurun_out/prof_ft2/kernel_stats.csv")
 PY
