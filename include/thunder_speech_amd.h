@@ -241,6 +241,22 @@ int ts_train_pwconv_fwd(const void* u, const void* w, void* v, int32_t batch, in
                         int32_t pitch_v, int32_t precision, void* stream);
 int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, void* du, float* dw, float* workspace, int32_t batch,
                         int32_t c_in, int32_t c_out, int32_t t, int32_t pitch_u, int32_t pitch_v, int32_t precision, void* stream);
+/* Mixed-precision path (u, v, dv, du bf16): the forward product and the data gradient run on the inference kernel's pointwise-only
+ * mode -- ts_tcs_subblock_fwd with depthwise = 0, kernel = 1, flags = TS_TCS_IN_TAILZERO, a zero bias, and pw_w = the B-fragments of W
+ * (forward) or of W^T (data gradient: c_in and c_out swap roles); it wants c_in % 64 == 0 and pitches >= round_up(T, 192).
+ *   ts_train_pack_pw_multi      packs, for n_tensors layers in ONE launch, W (f32 [c_out][c_in]) into both fragment sets (layout of
+ *                               ts_tcs_desc.pw_w: bf16 [n_pad32/32][k_pad64/16][64][8]).  table: device array of n_tensors rows of five
+ *                               64-bit words (W pointer, forward fragments pointer [n = c_out, k = c_in], backward fragments pointer
+ *                               [n = c_in, k = c_out], c_out, c_in); max_groups = the largest per-layer group count
+ *                               (c_out_pad32 * c_in_pad64 + c_in_pad32 * c_out_pad64) / 8.
+ *   ts_train_pwconv_wgrad_mfma  dw += sum_b dv[b] . u[b]^T on hand-written MFMA kernels (csrc/train_gemm.hip): split over clip groups,
+ *                               f32 partials in `workspace` (ts_train_pwconv_wgrad_workspace floats), summed onto dw by a second
+ *                               launch.  c_in, c_out multiples of 8, pitches multiples of 8 and >= round_up(T, 64), 16-byte aligned
+ *                               bases; anything else returns TS_EUNSUPPORTED (callers fall back to ts_train_pwconv_bwd). */
+int ts_train_pack_pw_multi(const void* table, int32_t n_tensors, int64_t max_groups, void* stream);
+int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, int32_t c_out);
+int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, float* dw, float* workspace, int32_t batch, int32_t c_in, int32_t c_out,
+                               int32_t t, int32_t pitch_u, int32_t pitch_v, void* stream);
 /* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
  * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */
 int ts_train_bn_fwd(const void* v, const float* gamma, const float* beta, void* y, float* mean_rstd, void* workspace, int32_t batch,

@@ -234,3 +234,53 @@ def test_graphed_training_step_follows_the_eager_step(act):
             assert int(b0) == int(b1) == 4, k
         elif k.endswith("running_mean") or k.endswith("running_var"):
             assert float((b0 - b1).abs().max()) <= (5e-2 if act == "bf16" else 2e-2) * max(float(b0.abs().max()), 1e-2), k
+
+
+@pytest.mark.parametrize("batch,c_in,c_out,t", [(2, 64, 256, 501), (3, 256, 200, 77), (1, 192, 128, 1000), (32, 512, 512, 501), (5, 128, 72, 8)])
+def test_bf16_pointwise_products_match_a_float64_product(batch, c_in, c_out, t):
+    """The three products of a 1x1 convolution on the bf16 training path (quartznet/blocks.py:169-182 with kernel_size 1), through
+    train_ops' helpers, against float64 products of the SAME bf16-rounded operands:
+      forward v = W u and data gradient du = W^T dv on the inference kernel's pointwise-only mode (ts_tcs_subblock_fwd) fed with
+      fragments from ts_train_pack_pw_multi -- bf16 results: half an ulp (0.4 %) of each value + f32 accumulation, 6e-3 of the scale;
+      weight gradient dW = sum_b dv u^T on csrc/train_gemm.hip -- f32, 2e-3 of the scale, and it ACCUMULATES onto dw.
+    The rows carry NaN bit patterns in their pitch padding: nothing may leak into frames < T; partial tiles in every dimension; the
+    fragment packer is checked bit for bit against plan.pack_pw_frags (both orientations)."""
+    from thunder_speech_amd import plan
+    from thunder_speech_amd import train_ops as T
+    g = torch.Generator().manual_seed(c_in + c_out + t)
+    u = torch.randn(batch, c_in, t, generator=g).bfloat16()
+    w = torch.nn.Parameter((torch.randn(c_out, c_in, 1, generator=g) / c_in ** 0.5).cuda())
+    dv = torch.randn(batch, c_out, t, generator=g).bfloat16()
+    w2 = w.detach().view(c_out, c_in)
+    wb = w2.bfloat16().double().cpu()
+
+    def rows(x):
+        b, c, tt = x.shape
+        buf = torch.full((b, c, T.row_pitch(tt)), float("nan"), dtype=torch.bfloat16, device="cuda")
+        buf[:, :, :tt] = x.cuda()
+        return buf[:, :, :tt]
+    ur, dvr = rows(u), rows(dv)
+    assert T.is_act(ur) and T.is_act(dvr)
+    fw, bk = T.pw_frags(w, w2)
+    assert torch.equal(fw, plan.pack_pw_frags(w2)) and torch.equal(bk, plan.pack_pw_frags(w2.t().contiguous()))
+    v = T._pw_fwd(ur, w, w2)
+    ref = torch.einsum("oc,bct->bot", wb, u.double())
+    used_tcs = c_in % 64 == 0
+    assert v.dtype == torch.bfloat16 and float((v.double().cpu() - ref).abs().max()) <= 6e-3 * float(ref.abs().max())
+    du, dw = T._pw_bwd(dvr, ur, w, w2)
+    ref_du = torch.einsum("oc,bot->bct", wb, dv.double())
+    ref_dw = torch.einsum("bot,bct->oc", dv.double(), u.double())
+    assert float((du.double().cpu() - ref_du).abs().max()) <= 6e-3 * float(ref_du.abs().max())
+    assert float((dw.double().cpu() - ref_dw).abs().max()) <= 2e-3 * float(ref_dw.abs().max())
+    if c_out % 64 == 0 and c_in % 8 == 0:
+        T._wgrad(dvr, ur, dw)                            # it ACCUMULATES
+        assert float((dw.double().cpu() - 2 * ref_dw).abs().max()) <= 4e-3 * float(ref_dw.abs().max())
+    # the library path gives the same numbers to rounding
+    T.set_pointwise_backend("rocblas")
+    try:
+        v2 = T._pw_fwd(ur, w, w2)
+        du2, dw2 = T._pw_bwd(dvr, ur, w, w2)
+    finally:
+        T.set_pointwise_backend("mfma")
+    assert float((v2.double() - v.double()).abs().max()) <= 8e-3 * float(ref.abs().max()) or not used_tcs
+    assert float((dw2.double().cpu() - ref_dw).abs().max()) <= 2e-3 * float(ref_dw.abs().max())

@@ -547,10 +547,9 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ a,
   if (threadIdx.x == 0) { part[((size_t)grp * ch + c) * 2] = r1[0]; part[((size_t)grp * ch + c) * 2 + 1] = r2[0]; }
 }
 
-__device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch, int c, double& s1, double& s2) {
+__device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch, int c, double& s1, double& s2, int ng = BN_G) {
   s1 = 0.0; s2 = 0.0;
-#pragma unroll
-  for (int g = 0; g < BN_G; ++g) { s1 += part[((size_t)g * ch + c) * 2]; s2 += part[((size_t)g * ch + c) * 2 + 1]; }
+  for (int g = 0; g < ng; ++g) { s1 += part[((size_t)g * ch + c) * 2]; s2 += part[((size_t)g * ch + c) * 2 + 1]; }
 }
 
 // BatchNorm(train) forward: stats[c] = (sum v, sum v^2) -> mean, rstd (biased variance, eps), y = gamma*(v-mean)*rstd + beta [ReLU].
@@ -560,13 +559,13 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const T* __restrict__ v, co
                                                      T* __restrict__ y, float* __restrict__ mean_rstd, int batch, int ch, int t, int pitch,
                                                      float eps, int relu, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float momentum,
-                                                     long long* __restrict__ num_batches_tracked) {
+                                                     long long* __restrict__ num_batches_tracked, int ng) {
   __shared__ float sh[2];
   const int row = blockIdx.x, c = row % ch;
   if (threadIdx.x == 0) {
     const double n = (double)batch * t;
     double s1, s2;
-    bn_total(part, ch, c, s1, s2);
+    bn_total(part, ch, c, s1, s2, ng);
     const double mu = s1 / n;
     double var = s2 / n - mu * mu;
     var = var < 0.0 ? 0.0 : var;
@@ -880,15 +879,16 @@ extern "C" int ts_train_bn_fwd(const void* v, const float* gamma, const float* b
   double* sums = static_cast<double*>(workspace);
   long long* nbt = reinterpret_cast<long long*>(num_batches_tracked);
   const dim3 rg = row_grid((long long)batch * ch, t);
+  const int ng = BN_G;
   TS_ACT(act,
          { hipLaunchKernelGGL((chan_sums_kernel<0, float>), dim3(ch, BN_G), dim3(256), 0, stream, (const float*)v, (const float*)nullptr, (const float*)nullptr,
-                              (const float*)nullptr, sums, batch, ch, t, pitch, 0);
+                                (const float*)nullptr, sums, batch, ch, t, pitch, 0);
            hipLaunchKernelGGL(bn_fwd_kernel<float>, rg, dim3(256), 0, stream, (const float*)v, sums, gamma, beta, (float*)y, mean_rstd, batch, ch, t, pitch,
-                              eps, relu, running_mean, running_var, momentum, nbt); },
+                              eps, relu, running_mean, running_var, momentum, nbt, ng); },
          { hipLaunchKernelGGL((chan_sums_kernel<0, bf16_t>), dim3(ch, BN_G), dim3(256), 0, stream, (const bf16_t*)v, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
-                              (const float*)nullptr, sums, batch, ch, t, pitch, 0);
+                                (const float*)nullptr, sums, batch, ch, t, pitch, 0);
            hipLaunchKernelGGL(bn_fwd_kernel<bf16_t>, rg, dim3(256), 0, stream, (const bf16_t*)v, sums, gamma, beta, (bf16_t*)y, mean_rstd, batch, ch, t, pitch,
-                              eps, relu, running_mean, running_var, momentum, nbt); });
+                              eps, relu, running_mean, running_var, momentum, nbt, ng); });
   return hip_status(hipGetLastError());
 }
 

@@ -1,0 +1,246 @@
+// Weight-side kernels of the mixed-precision (bf16) training path's 1x1 convolutions (fine-tuning phase 2, SURVEY 8 config C4;
+// quartznet/blocks.py:169-182 with kernel_size = 1) on activation rows [B][C][pitch] (time contiguous):
+//
+//   forward    v[b][co][t]  = sum_ci W[co][ci] u[b][ci][t]     } both run on the INFERENCE kernel's pointwise-only mode
+//   data grad  du[b][ci][t] = sum_co W[co][ci] dv[b][co][t]    } (ts_tcs_subblock_fwd, tcs_kernel.hip: 520-750 TF/s on these shapes,
+//                                                                 rocBLAS' strided-batched call reaches 320); what they need from
+//                                                                 here is the weights in MFMA B-fragment order, W and W^T:
+//                                                                 pack_pw_multi_kernel, one launch for all layers after the optimizer step
+//   weight grad dW[co][ci] += sum_{b,t} dv[b][co][t] u[b][ci][t]  wgrad_gemm_kernel + wgrad_reduce_kernel
+//
+// The weight gradient contracts over (clip, frame): both operands are K-contiguous rows, staged as [128 rows][64 frames] (16-byte
+// chunks swizzled by row), fragments by ds_read_b128, v_mfma_f32_32x32x16_bf16, 128 x 128 tiles, 4 waves (2 x 2).  rocBLAS needs B
+// clip-sized products plus a reduction of the B partials (25-33 + 10 us per layer); here clip groups are split over workgroups
+// until every CU has a tile, so the reduction reads 8-16 partials.
+#include "ts_common.hpp"
+
+namespace ts {
+
+typedef unsigned short bf16_t;
+constexpr int GK = 64;                 // K per step
+constexpr int GTILE = 128;             // tile edge (frames / channels)
+constexpr int AROWB = GTILE * 2;       // bytes per LDS row of an activation / transposed-weight tile
+constexpr int ATILEB = GK * AROWB;     // 16 KiB
+
+// Workgroups are dealt to the 8 XCDs round-robin by id; tiles that share operands should share an XCD's L2.  Logical tile index of
+// workgroup `id`: XCD x = id % 8 owns the contiguous range [x * n / 8, (x + 1) * n / 8) (n a multiple of 8; identity otherwise).
+__device__ __forceinline__ int xcd_tile(int id, int n) { return (n & 7) ? id : (id & 7) * (n >> 3) + (id >> 3); }
+
+__device__ __forceinline__ int taddr(int c, int t) { return c * AROWB + ((((t >> 3) ^ ((c & 3) * 5))) << 4) + ((t & 7) << 1); }
+
+struct WgradArgs {
+  const bf16_t* dv;       // [B][M][pitch_v]
+  const bf16_t* u;        // [B][N][pitch_u]
+  float* part;            // [split][M][N] partial products, one per clip group
+  int batch, M, N, t, pitch_v, pitch_u, n_mt, n_nt, clips_per_wg;
+};
+
+constexpr int WROWB = GK * 2;            // 128-byte rows: 64 frames
+constexpr int WTILEB = GTILE * WROWB;    // 16 KiB
+__device__ __forceinline__ int waddr(int r, int c) { return r * WROWB + ((c ^ (r & 7)) << 4); }
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  constexpr int n = N < 63 ? N : 63;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15) | ((n >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
+
+constexpr int WD = 4;                    // LDS ring depth (stages of one 64-frame K-step: 16 KiB of dv rows + 16 KiB of u rows)
+constexpr int WSTAGEB = 2 * WTILEB;
+
+// Split-K over clip groups: workgroup (tile, sp) contracts clips [sp * clips_per_wg, ...) and stores its f32 partial tile to
+// part[sp] (plain coalesced stores; device-scope float atomics cost 18 us per layer here, measured) -- wgrad_reduce_kernel sums
+// the partials.  Operand rows arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave and instruction) into a ring of WD stages, so
+// three K-steps of loads are in flight while one is multiplied: a K-step is only 512 MFMA cycles, far less than the load latency.
+// The swizzle is applied on the SOURCE address (the DMA's LDS image is lane-linear).  The pitch padding of the last K-step of a clip
+// (frames >= T: arbitrary bits) is zeroed in LDS by the wave that fetched those rows, between its own vmcnt wait and the barrier.
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = xcd_tile(blockIdx.x, gridDim.x);              // the tiles of one clip group read the same rows of dv and u
+  const int nt_i = id % a.n_nt; id /= a.n_nt;
+  const int mt_i = id % a.n_mt;
+  const int sp = id / a.n_mt;
+  const int m0 = mt_i * GTILE, n0 = nt_i * GTILE;
+  const int b_lo = sp * a.clips_per_wg, b_hi = b_lo + a.clips_per_wg < a.batch ? b_lo + a.clips_per_wg : a.batch;
+  const int nk = (a.t + GK - 1) / GK, S = (b_hi - b_lo) * nk;
+  const i32x4 ra = raw_rsrc(a.dv, (unsigned)((size_t)a.batch * a.M * a.pitch_v * 2));
+  const i32x4 rb = raw_rsrc(a.u, (unsigned)((size_t)a.batch * a.N * a.pitch_u * 2));
+  // this wave fetches rows [32 wave, 32 wave + 32) of both tiles: DMA q covers 8 rows, lane -> (row lane >> 3, LDS slot lane & 7)
+  const int lr = lane >> 3, csrc = (lane & 7) ^ lr;      // logical chunk that lands in this lane's slot (row & 7 == lr)
+  int offa[4], offb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 32 * wave + 8 * q + lr;
+    const int m = m0 + r < a.M ? m0 + r : a.M - 1, n = n0 + r < a.N ? n0 + r : a.N - 1;
+    offa[q] = (m * a.pitch_v + 8 * csrc) * 2;
+    offb[q] = (n * a.pitch_u + 8 * csrc) * 2;
+  }
+  auto issue = [&](int s) {
+    const int b = b_lo + s / nk, tk = (s % nk) * GK;
+    char* const st = smem + (s % WD) * WSTAGEB;
+    const int sa = (b * a.M * a.pitch_v + tk) * 2, sb = (b * a.N * a.pitch_u + tk) * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      lds_dma16(ra, st + (32 * wave + 8 * q) * WROWB, offa[q], sa);
+      lds_dma16(rb, st + WTILEB + (32 * wave + 8 * q) * WROWB, offb[q], sb);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int s = 0; s < WD - 1 && s < S; ++s) issue(s);
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int s = 0; s < S; ++s) {
+    const int ahead = S - 1 - s < WD - 2 ? S - 1 - s : WD - 2;          // stages issued after s and still allowed in flight
+    if (ahead >= 2) vm_wait<16>(); else if (ahead == 1) vm_wait<8>(); else vm_wait<0>();
+    char* const st = smem + (s % WD) * WSTAGEB;
+    const int nv = a.t - (s % nk) * GK;                    // valid frames of this K-step
+    if (nv < GK) {
+      // zero the padding this wave fetched: lane -> one row (lanes 0..31 dv rows, 32..63 u rows), chunks from nv / 8 on
+      char* const row = st + (lane >> 5) * WTILEB;
+      const int r = 32 * wave + (lane & 31);
+      for (int c = nv >> 3; c < 8; ++c) {
+        u32x4* const p = reinterpret_cast<u32x4*>(row + waddr(r, c));
+        *p = keep_first(*p, nv - 8 * c);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                          // stage s complete in LDS; every wave is done with stage s - 1
+    asm volatile("" ::: "memory");
+    if (s + WD - 1 < S) issue(s + WD - 1);                 // into the slot of stage s - 1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const s16x8*>(st + waddr(wm * 64 + 32 * i + fr, 2 * ks + fh));
+        bf[i] = *reinterpret_cast<const s16x8*>(st + WTILEB + waddr(wn * 64 + 32 * i + fr, 2 * ks + fh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* const out = a.part + (size_t)sp * a.M * a.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + 32 * j + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m < a.M && n < a.N) out[(size_t)m * a.N + n] = acc[i][j][r];
+      }
+    }
+}
+
+// dw[i] += sum_p part[p][i]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long long n, int n_parts) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(dw + i);
+    for (int p = 0; p < n_parts; ++p) s += *reinterpret_cast<const f32x4*>(part + (size_t)p * n + i);
+    *reinterpret_cast<f32x4*>(dw + i) = s;
+  } else {
+    for (long long k = i; k < n; ++k) {
+      float s = dw[k];
+      for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + k];
+      dw[k] = s;
+    }
+  }
+}
+
+// B-fragments of v_mfma_f32_32x32x16_bf16 for D[t][n] += X[k][t] * Wn[n][k] (tcs_kernel.hip, plan.pack_pw_frags): group (nt, ks, lane)
+// = 8 bf16: Wn[32 nt + lane % 32][16 ks + 8 (lane / 32) + 0..7], groups ordered [n_pad32 / 32][k_pad64 / 16][64].  Per layer two sets:
+// the forward one (Wn = W: n = c_out, k = c_in) and the backward one (Wn = W^T: n = c_in, k = c_out).  table rows: (W f32 ptr,
+// forward fragments ptr, backward fragments ptr, c_out, c_in) as 64-bit words; blockIdx.y = layer.
+__global__ __launch_bounds__(256) void pack_pw_multi_kernel(const unsigned long long* __restrict__ table) {
+  const unsigned long long* e = table + (size_t)blockIdx.y * 5;
+  const float* w = reinterpret_cast<const float*>(e[0]);
+  const int co = (int)e[3], ci = (int)e[4];
+  const long long gf = (long long)(round_up(co, 32) / 32) * (round_up(ci, 64) / 16) * 64;
+  const long long gb = (long long)(round_up(ci, 32) / 32) * (round_up(co, 64) / 16) * 64;
+  long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= gf + gb) return;
+  const bool bwd = g >= gf;
+  if (bwd) g -= gf;
+  const int kt = bwd ? round_up(co, 64) / 16 : round_up(ci, 64) / 16;
+  const int lane = (int)(g & 63), ks = (int)((g >> 6) % kt), nt = (int)((g >> 6) / kt);
+  const int n = 32 * nt + (lane & 31), k = 16 * ks + 8 * (lane >> 5);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = bwd ? k + j : n, col = bwd ? n : k + j;           // element of W[c_out][c_in]
+    v[j] = (row < co && col < ci) ? w[(size_t)row * ci + col] : 0.f;
+  }
+  unsigned short* const out = reinterpret_cast<unsigned short*>(bwd ? e[2] : e[1]) + (size_t)g * 8;
+  *reinterpret_cast<u32x4*>(out) = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+}
+
+}  // namespace ts
+
+using namespace ts;
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int wgrad_split(int batch, int c_in, int c_out) {
+  const int tiles = ((c_out + GTILE - 1) / GTILE) * ((c_in + GTILE - 1) / GTILE);
+  int split = (cu_count() + tiles - 1) / tiles;            // one workgroup per CU (128 KiB of LDS each)
+  split = split < 1 ? 1 : (split > batch ? batch : split);
+  const int cpw = (batch + split - 1) / split;
+  return (batch + cpw - 1) / cpw;
+}
+
+/* floats of workspace ts_train_pwconv_wgrad_mfma needs: one [c_out][c_in] partial per clip group */
+extern "C" int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, int32_t c_out) {
+  if (batch <= 0 || c_in <= 0 || c_out <= 0) return TS_EINVAL;
+  return (int64_t)wgrad_split(batch, c_in, c_out) * c_in * c_out;
+}
+
+/* dw += sum_b dv[b] . u[b]^T; see include/thunder_speech_amd.h */
+extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, float* dw, float* workspace, int32_t batch, int32_t c_in,
+                                          int32_t c_out, int32_t t, int32_t pitch_u, int32_t pitch_v, void* stream_) {
+  if (!dv || !u || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
+  const int tk_end = round_up(t, GK);
+  if (c_out % 8 || c_in % 8 || pitch_u % 8 || pitch_v % 8 || pitch_u < tk_end || pitch_v < tk_end || !aligned16(u) || !aligned16(dv) ||
+      !aligned16(dw) || !aligned16(workspace) || ((size_t)c_out * c_in) % 4)
+    return TS_EUNSUPPORTED;
+  if ((size_t)batch * c_out * pitch_v * 2 >= (1ull << 31) || (size_t)batch * c_in * pitch_u * 2 >= (1ull << 31)) return TS_EUNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  static int attr = 0;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WD * WSTAGEB) != hipSuccess)
+      return TS_EUNSUPPORTED;
+    attr = 1;
+  }
+  WgradArgs g;
+  g.dv = (const bf16_t*)dv; g.u = (const bf16_t*)u; g.part = workspace;
+  g.batch = batch; g.M = c_out; g.N = c_in; g.t = t; g.pitch_v = pitch_v; g.pitch_u = pitch_u;
+  g.n_mt = (c_out + GTILE - 1) / GTILE; g.n_nt = (c_in + GTILE - 1) / GTILE;
+  const int split = wgrad_split(batch, c_in, c_out);
+  g.clips_per_wg = (batch + split - 1) / split;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(wgrad_gemm_kernel, dim3((unsigned)(g.n_mt * g.n_nt * split)), dim3(256), WD * WSTAGEB, stream, g);
+  const long long n = (long long)c_out * c_in;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, workspace, dw, n, split);
+  return hip_status(hipGetLastError());
+}
+
+/* W (f32 [c_out][c_in]) of every listed layer -> bf16 MFMA B-fragments of W and of W^T; see include/thunder_speech_amd.h */
+extern "C" int ts_train_pack_pw_multi(const void* table, int32_t n_tensors, int64_t max_groups, void* stream_) {
+  if (!table || n_tensors <= 0 || max_groups <= 0) return TS_EINVAL;
+  if (n_tensors > 65535) return TS_EUNSUPPORTED;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(pack_pw_multi_kernel, dim3((unsigned)((max_groups + 255) / 256), n_tensors), dim3(256), 0, (hipStream_t)stream_,
+                     static_cast<const unsigned long long*>(table));
+  return hip_status(hipGetLastError());
+}

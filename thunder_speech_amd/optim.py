@@ -66,6 +66,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 for (p, _, _), sh in zip(todo, shadows):
                     if sh is not None:
                         sh[1] = p._version                                # the kernel refreshed the copy: it matches the new version
+                from .train_ops import refresh_pw_frags
+                refresh_pw_frags([p for p, _, _ in todo])                 # MFMA fragment copies of the 1x1-conv weights: one launch
                 continue
             for p, g, st in todo:
                 rc = L.ts_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),

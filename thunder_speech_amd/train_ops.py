@@ -2,7 +2,7 @@
 forward AND backward a call into csrc/train_enc.hip / train_extra.hip.  PyTorch only chains the Functions; no ATen compute op
 touches an activation.
 
-Activation tensors are [B, C, T] views of pitched rows ([B, C, P], P = T rounded up to 8 elements, 32-byte aligned) in ONE of
+Activation tensors are [B, C, T] views of pitched rows ([B, C, P], P = T rounded up to 192 frames, 32-byte aligned) in ONE of
 two element types, chosen with `set_activation_dtype`:
   * "fp32" (default): the reference's arithmetic -- what the parity tests against the reference's autograd use;
   * "bf16": mixed precision (the reference under Lightning's precision="bf16-mixed"): activations and their gradients are
@@ -53,10 +53,18 @@ def _code(t: Tensor) -> int:
     return 1 if t.dtype == torch.bfloat16 else 0
 
 
+PITCH_QUANTUM = 192      # frames; the pointwise-only mode of the inference kernel (forward / data-gradient GEMMs) works in 96- and
+                         # 192-frame tiles and reads / writes whole tiles: rows are padded so that every tile lies inside its row
+
+
+def row_pitch(t: int) -> int:
+    # whole 192-frame tiles + the 64-frame granule the 96-frame tiling's last stage copy reaches past the final tile start
+    return (t + PITCH_QUANTUM - 1) // PITCH_QUANTUM * PITCH_QUANTUM + 64
+
+
 def alloc(b: int, c: int, t: int, device, dtype=None) -> Tensor:
     """Uninitialised activation [b, c, t] on pitched rows."""
-    p = (t + 7) // 8 * 8
-    return torch.empty(b, c, p, dtype=dtype or _ACT_DTYPE, device=device)[:, :, :t]
+    return torch.empty(b, c, row_pitch(t), dtype=dtype or _ACT_DTYPE, device=device)[:, :, :t]
 
 
 def alloc_like(x: Tensor) -> Tensor:
@@ -67,7 +75,7 @@ def is_act(x: Tensor) -> bool:
     # the pitch must be THE pitch `alloc` gives this length: kernels take one pitch for a tensor and its gradient / its
     # same-shape output, so a foreign row layout (e.g. the front end's feature rows, padded to its own tile) is re-packed
     return (x.is_cuda and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(2) == 1
-            and x.stride(1) == (x.shape[2] + 7) // 8 * 8 and x.stride(0) == x.shape[1] * x.stride(1) and x.data_ptr() % 32 == 0)
+            and x.stride(1) == row_pitch(x.shape[2]) and x.stride(0) == x.shape[1] * x.stride(1) and x.data_ptr() % 32 == 0)
 
 
 def _pitch(x: Tensor) -> int:
@@ -192,6 +200,158 @@ def _w_bf16(w2: Tensor, param: Tensor = None) -> Tensor:
     return y
 
 
+# bf16 pointwise convolutions: forward and data gradient on the inference kernel's pointwise-only mode (ts_tcs_subblock_fwd), weight
+# gradient on csrc/train_gemm.hip; set_pointwise_backend("rocblas") routes all three to the library's strided-batched GEMMs instead
+# (the f32 path always uses those).
+_OWN_GEMM = True
+
+
+def set_pointwise_backend(name: str) -> None:
+    global _OWN_GEMM
+    if name not in ("mfma", "rocblas"):
+        raise ValueError("pointwise backend must be 'mfma' or 'rocblas'")
+    _OWN_GEMM = name == "mfma"
+
+
+# Weights in MFMA B-fragment order (W for the forward product, W^T for the data gradient), one pair per parameter, reused while the
+# parameter's version counter stands.  optim.FusedAdamW re-packs every registered pair in ONE launch after its update
+# (refresh_pw_frags), so a fine-tuning step launches no per-layer packing.
+_PW_FRAGS = {}
+
+
+def _frag_shapes(c_out: int, c_in: int):
+    r = lambda x, m: (x + m - 1) // m * m
+    return (r(c_out, 32) // 32, r(c_in, 64) // 16, 64, 8), (r(c_in, 32) // 32, r(c_out, 64) // 16, 64, 8)
+
+
+def _pack_rows(entries):
+    """ONE launch packing the (param, w2 f32 [c_out, c_in], fwd, bwd) entries."""
+    dev = entries[0][1].device
+    rows = [[w2.data_ptr(), f.data_ptr(), bk.data_ptr(), w2.shape[0], w2.shape[1]] for _, w2, f, bk in entries]
+    groups = max(f.numel() // 8 + bk.numel() // 8 for _, _, f, bk in entries)
+    table = torch.tensor(rows, dtype=torch.int64, pin_memory=True).to(dev, non_blocking=True)
+    _lib.check(_lib.lib().ts_train_pack_pw_multi(table.data_ptr(), len(rows), groups, torch.cuda.current_stream(dev).cuda_stream), "ts_train_pack_pw_multi")
+
+
+def pw_frags(param: Tensor, w2: Tensor):
+    """(forward fragments, backward fragments) of the 1x1-conv weight `param` (w2 = its f32 [c_out, c_in] view)."""
+    import weakref
+    ent = _PW_FRAGS.get(id(param))
+    if ent is not None and (ent[3]() is not param or ent[0].device != param.device):
+        ent = None
+    if ent is None:
+        if len(_PW_FRAGS) > 4096:
+            for k in [k for k, e in _PW_FRAGS.items() if e[3]() is None]:
+                del _PW_FRAGS[k]
+        sf, sb = _frag_shapes(w2.shape[0], w2.shape[1])
+        ent = _PW_FRAGS[id(param)] = [torch.empty(sf, dtype=torch.bfloat16, device=param.device),
+                                      torch.empty(sb, dtype=torch.bfloat16, device=param.device), -1, weakref.ref(param)]
+    if ent[2] != param._version:
+        _pack_rows([(param, w2, ent[0], ent[1])])
+        ent[2] = param._version
+    return ent[0], ent[1]
+
+
+def refresh_pw_frags(params) -> None:
+    """Re-pack, in one launch, the fragment pairs of those `params` that have one (called by FusedAdamW after its update)."""
+    todo = []
+    for p in params:
+        ent = _PW_FRAGS.get(id(p))
+        if ent is not None and ent[3]() is p and p.dtype == torch.float32 and p.is_contiguous():
+            todo.append((p, p.detach().view(p.shape[0], -1), ent[0], ent[1]))
+    if todo:
+        _pack_rows(todo)
+        for p, _, _, _ in todo:
+            _PW_FRAGS[id(p)][2] = p._version
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n: int, device) -> Tensor:
+    key = str(torch.device(device))
+    z = _ZERO_BIAS.get(key)
+    if z is None or z.numel() < n:
+        z = _ZERO_BIAS[key] = torch.zeros(max(4096, (n + 31) // 32 * 32), dtype=torch.float32, device=device)
+    return z
+
+
+def _tcs_ok(bf: bool, k: int) -> bool:
+    return _OWN_GEMM and bf and k % 64 == 0
+
+
+def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int) -> None:
+    """y[b] = Wn . x[b] on the inference kernel's pointwise-only mode: x bf16 rows [B, K, T], frags = B-fragments of Wn [n_out, K],
+    y bf16 rows [B, n_out, T].  Frames beyond T inside the row pitch are read and written as scratch (every frame is independent)."""
+    import ctypes as C
+    b, k, t = x.shape
+    d = _lib.TcsDesc()
+    d.batch, d.c_in, d.c_out, d.t_in, d.t_out, d.pitch_in, d.pitch_out = b, k, n_out, t, t, _pitch(x), _pitch(y)
+    d.kernel, d.stride, d.dilation, d.padding, d.depthwise, d.relu, d.out_fp32 = 1, 1, 1, 0, 0, 0, 0
+    d.flags = 1                                          # TS_TCS_IN_TAILZERO: no masks (the operand is masked already), whole tiles
+    d.pw_w, d.bias = frags.data_ptr(), _zero_bias(n_out, x.device).data_ptr()
+    st = _lib.lib().ts_tcs_subblock_fwd(C.byref(d), x.data_ptr(), lens.data_ptr(), None, None, y.data_ptr(), _s(x))
+    _lib.check(st, "ts_tcs_subblock_fwd")
+
+
+def _wgrad(dv: Tensor, u: Tensor, dw: Tensor) -> None:
+    """dw += sum_b dv[b] . u[b]^T (csrc/train_gemm.hip); dv [B, c_out, T], u [B, c_in, T] bf16 rows, dw f32 [c_out, c_in]."""
+    L = _lib.lib()
+    b, c_out, t = dv.shape
+    c_in = u.shape[1]
+    ws = torch.empty(L.ts_train_pwconv_wgrad_workspace(b, c_in, c_out), dtype=torch.float32, device=dv.device)
+    _lib.check(L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)),
+               "ts_train_pwconv_wgrad_mfma")
+
+
+_LENS = {}
+
+
+def _full_lengths(b: int, t: int, device) -> Tensor:
+    key = (b, t, str(torch.device(device)))
+    if key not in _LENS:
+        if len(_LENS) > 256:
+            _LENS.clear()
+        _LENS[key] = torch.full((b,), t, dtype=torch.int32, device=device)
+    return _LENS[key]
+
+
+def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False) -> Tensor:
+    """v[b] = W . u[b] for activation rows u [B, c_in, T] (masked already); w2 = f32 [c_out, c_in] view of `param`."""
+    b, c_in, t = u.shape
+    c_out = w2.shape[0]
+    bf = u.dtype == torch.bfloat16
+    v = alloc(b, c_out, t, u.device, torch.float32 if (f32_out or not bf) else torch.bfloat16)
+    if not f32_out and _tcs_ok(bf, c_in):
+        _tcs_pointwise(u, pw_frags(param, w2)[0], v, _full_lengths(b, t, u.device), c_out)
+    else:
+        wk = _w_bf16(w2, param) if bf else w2
+        prec = 0 if not bf else (1 if f32_out else 2)
+        st = _lib.lib().ts_train_pwconv_fwd(u.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(v), prec, _s(v))
+        _lib.check(st, "ts_train_pwconv_fwd")
+    return v
+
+
+def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor):
+    """(du, dw) = (W^T . dv[b], sum_b dv[b] . u[b]^T); dw f32 [c_out, c_in] (the bucket view of `param` when it has one)."""
+    b, c_in, t = u.shape
+    c_out = w2.shape[0]
+    bf = u.dtype == torch.bfloat16
+    du = alloc_like(u)
+    if _tcs_ok(bf, c_out) and c_in % 8 == 0:
+        _tcs_pointwise(dv, pw_frags(param, w2)[1], du, _full_lengths(b, t, u.device), c_in)
+        dw = grad_out(param, (c_out, c_in), zeroed=True)
+        _wgrad(dv, u, dw)
+        return du, dw
+    wk = _w_bf16(w2, param) if bf else w2
+    dw = grad_out(param, (c_out, c_in))
+    ws = torch.empty(b * c_out * c_in, dtype=torch.float32, device=u.device)
+    st = _lib.lib().ts_train_pwconv_bwd(dv.data_ptr(), u.data_ptr(), wk.data_ptr(), du.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in,
+                                        c_out, t, _pitch(u), _pitch(dv), 2 if bf else 0, _s(du))
+    _lib.check(st, "ts_train_pwconv_bwd")
+    return du, dw
+
+
 class Fork(torch.autograd.Function):
     """x -> (x, x) for a tensor with two consumers (a block input: main branch + residual branch).  The backward pass adds the two
     gradients with one kernel on activation rows; autograd's own accumulation (an ATen add) leaves the row layout, which costs a
@@ -282,31 +442,17 @@ class PointwiseConv(torch.autograd.Function):
     def forward(ctx, u, w, f32_out=False):
         u = _import(u, u.dtype if is_act(u) else _ACT_DTYPE)
         w2 = w.detach().to(torch.float32).contiguous().view(w.shape[0], -1)
-        b, c_in, t = u.shape
-        c_out = w2.shape[0]
-        bf = u.dtype == torch.bfloat16
-        prec = 0 if not bf else (1 if f32_out else 2)
-        wk = _w_bf16(w2, w) if bf else w2
-        v = alloc(b, c_out, t, u.device, torch.float32 if (f32_out or not bf) else torch.bfloat16)
-        st = _lib.lib().ts_train_pwconv_fwd(u.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(v), prec, _s(v))
-        _lib.check(st, "ts_train_pwconv_fwd")
-        ctx.save_for_backward(u, wk)
-        ctx.wshape, ctx.f32_out, ctx.param = w.shape, f32_out, w
+        v = _pw_fwd(u, w, w2, f32_out)
+        ctx.save_for_backward(u)
+        ctx.wshape, ctx.param = w.shape, w
         return v
 
     @staticmethod
     def backward(ctx, dv):
-        u, wk = ctx.saved_tensors
-        bf = u.dtype == torch.bfloat16
+        (u,) = ctx.saved_tensors
+        w = ctx.param
         dv = _import(dv, u.dtype)                      # bf16 mode: the f32 logit gradient becomes a bf16 GEMM operand
-        b, c_in, t = u.shape
-        c_out = wk.shape[0]
-        du = alloc_like(u)
-        dw = grad_out(ctx.param, wk.shape)
-        ws = torch.empty(b * c_out * c_in, dtype=torch.float32, device=u.device)
-        st = _lib.lib().ts_train_pwconv_bwd(dv.data_ptr(), u.data_ptr(), wk.data_ptr(), du.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in,
-                                            c_out, t, _pitch(u), _pitch(dv), 2 if bf else 0, _s(du))
-        _lib.check(st, "ts_train_pwconv_bwd")
+        du, dw = _pw_bwd(dv, u, w, w.detach().to(torch.float32).contiguous().view(w.shape[0], -1))
         return du, dw.view(ctx.wshape), None
 
 
@@ -501,14 +647,11 @@ class SubBlock(torch.autograd.Function):
                        "ts_train_mask_time")
         w_pw = pw_w.detach().to(torch.float32).contiguous().view(pw_w.shape[0], -1)
         c_out = w_pw.shape[0]
-        wk = _w_bf16(w_pw, pw_w) if bf else w_pw
-        v = alloc(b, c_out, t_out, x.device, x.dtype)
-        _lib.check(L.ts_train_pwconv_fwd(mid.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t_out, _pitch(mid), _pitch(v), 2 if bf else 0, st_),
-                   "ts_train_pwconv_fwd")
+        v = _pw_fwd(mid, pw_w, w_pw)
+        ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
         g, be = gamma.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
         y = alloc_like(v)
         mr = torch.empty(c_out, 2, dtype=torch.float32, device=x.device)
-        ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
         rm, rv, mom, nbt = cfg.running if cfg.running is not None else (None, None, 0.0, None)
         _lib.check(L.ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c_out, t_out, _pitch(v),
                                      float(cfg.eps), int(cfg.relu), rm.data_ptr() if rm is not None else None,
@@ -519,7 +662,7 @@ class SubBlock(torch.autograd.Function):
             out = alloc_like(y)
             _lib.check(L.ts_train_dropout(y.data_ptr(), out.data_ptr(), b * c_out, t_out, _pitch(y), float(cfg.drop_p), int(cfg.drop_seed), _nonce(x), code, st_),
                        "ts_train_dropout")
-        ctx.save_for_backward(x, mid, v, y, g, mr, wk, *([w_dw] if w_dw is not None else []))
+        ctx.save_for_backward(x, mid, v, y, g, mr, *([w_dw] if w_dw is not None else []))
         ctx.cfg, ctx.params = cfg, (dw_w, pw_w, gamma, beta)
         ctx.shapes = (None if dw_w is None else dw_w.shape, pw_w.shape)
         return out
@@ -528,8 +671,8 @@ class SubBlock(torch.autograd.Function):
     def backward(ctx, dy):
         L = _lib.lib()
         saved = ctx.saved_tensors
-        x, mid, v, y, g, mr, wk = saved[:7]
-        w_dw = saved[7] if len(saved) > 7 else None
+        x, mid, v, y, g, mr = saved[:6]
+        w_dw = saved[6] if len(saved) > 6 else None
         cfg = ctx.cfg
         dw_p, pw_p, ga_p, be_p = ctx.params
         b, c_in, t_in = x.shape
@@ -546,11 +689,7 @@ class SubBlock(torch.autograd.Function):
         ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
         _lib.check(L.ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                      ws.data_ptr(), b, c_out, t_out, _pitch(v), int(cfg.relu), code, st_), "ts_train_bn_bwd")
-        dmid = alloc_like(mid)
-        dpw = grad_out(pw_p, wk.shape)
-        ws2 = torch.empty(b * c_out * c_in, dtype=torch.float32, device=x.device)
-        _lib.check(L.ts_train_pwconv_bwd(dv.data_ptr(), mid.data_ptr(), wk.data_ptr(), dmid.data_ptr(), dpw.data_ptr(), ws2.data_ptr(), b, c_in, c_out, t_out,
-                                         _pitch(mid), _pitch(dv), 2 if bf else 0, st_), "ts_train_pwconv_bwd")
+        dmid, dpw = _pw_bwd(dv, mid, pw_p, pw_p.detach().to(torch.float32).contiguous().view(pw_p.shape[0], -1))
         dx = alloc_like(x)
         if w_dw is not None:
             ddw = grad_out(dw_p, w_dw.shape, zeroed=True)
