@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
 // Citrinet) -- the VALU-bound part of the training step.  One WAVEFRONT owns TWO adjacent channel rows of one clip and every
 // product is a packed-f32 FMA over the pair (v_pk_fma_f32: lane-half 0 = channel c, lane-half 1 = channel c + 1), which doubles
 // the FMA rate of the one-row form; each lane computes 8 consecutive frames from a 16-entry register window (fir_pair), the taps
-// come in over the scalar unit (uniform per wave), so a step of 64 packed FMAs costs 4 LDS reads.  No workgroup barrier in the
+// are broadcast reads of a per-wave LDS copy, so a step of 64 packed FMAs costs 8 LDS reads.  No workgroup barrier in the
 // streaming part: a wave stages its own rows (LDS operations of one wave execute in order).
 // LDS layout of a staged row pair: float2 samples, 2-sample chunks dealt round-robin over 4 sub-arrays, so that the four 16-byte
 // reads of a window step are lane-contiguous in each sub-array (a lane's window starts 8 samples after its neighbour's).
@@ -290,24 +290,53 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int PT = 512;                                        // frames per wave tile
 struct __attribute__((aligned(16))) v2fx2 { v2f a, b; };
 
-__device__ __forceinline__ int ppos(int e, int q) { const int h = e >> 1; return ((h >> 2) << 1) + (h & 3) * q + (e & 1); }
+// Staging of frames [a0, a0 + n) of rows ra / rb (a0 and n multiples of 8, n <= 1024; zeros outside [0, lim)) in two halves, so that
+// the global loads of the NEXT row pair are in flight while the current one is filtered:
+//   stage_fetch  a lane loads 8 aligned frames of both rows, twice (frames a0 + 8 lane and a0 + 8 (lane + 64)), raw, into registers
+//   stage_write  converts them, zeroes what lies outside [0, lim) and writes four 16-byte chunks per 8 frames, one per sub-array
+// The FIR origin is therefore 8-aligned; the callers shift their TAPS by (t0 - p) & 7 instead of the samples.
+template <class T> struct Raw8;
+template <> struct Raw8<float> { f32x4 lo, hi; };
+template <> struct Raw8<bf16_t> { u32x4 v; };
+__device__ __forceinline__ void raw_load(Raw8<float>& r, const float* p) { r.lo = *reinterpret_cast<const f32x4*>(p); r.hi = *reinterpret_cast<const f32x4*>(p + 4); }
+__device__ __forceinline__ void raw_load(Raw8<bf16_t>& r, const bf16_t* p) { r.v = *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void raw_get(const Raw8<float>& r, float (&v)[8]) {
+  v[0] = r.lo[0]; v[1] = r.lo[1]; v[2] = r.lo[2]; v[3] = r.lo[3]; v[4] = r.hi[0]; v[5] = r.hi[1]; v[6] = r.hi[2]; v[7] = r.hi[3];
+}
+__device__ __forceinline__ void raw_get(const Raw8<bf16_t>& r, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_lo(r.v[j]); v[2 * j + 1] = bf16_hi(r.v[j]); }
+}
+template <class T> struct Staged { Raw8<T> a[2], b[2]; };
 
-// stage frames [org, org + n) of rows ra / rb (zeros outside [0, lim)) at sample index 0.. of `dst` (n a multiple of 8)
 template <class T>
-__device__ __forceinline__ void stage_pair(v2f* dst, int q, const T* ra, const T* rb, int org, int n, int lim, int lane) {
-  const int a0 = org & ~7;
-  for (int i8 = a0 + 8 * lane; i8 < org + n; i8 += 512) {
+__device__ __forceinline__ void stage_fetch(Staged<T>& st, const T* ra, const T* rb, int a0, int n, int lim, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int u = lane + 64 * it, i8 = a0 + 8 * u;
+    if (8 * u < n && i8 >= 0 && i8 < lim) { raw_load(st.a[it], ra + i8); raw_load(st.b[it], rb + i8); }
+  }
+}
+template <class T>
+__device__ __forceinline__ void stage_write(const Staged<T>& st, v2f* dst, int q, int a0, int n, int lim, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int u = lane + 64 * it, i8 = a0 + 8 * u;
+    if (8 * u >= n) continue;
     float a[8], b[8];
-    if (i8 >= 0 && i8 < lim) { load8(ra + i8, a); load8(rb + i8, b); }
-    else {
+    if (i8 >= 0 && i8 < lim) {
+      raw_get(st.a[it], a); raw_get(st.b[it], b);
+      if (i8 + 8 > lim) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) if (i8 + m >= lim) { a[m] = 0.f; b[m] = 0.f; }
+      }
+    } else {
 #pragma unroll
       for (int m = 0; m < 8; ++m) { a[m] = 0.f; b[m] = 0.f; }
     }
+    v2f* const d = dst + 2 * u;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int i = i8 + m, e = i - org;
-      if (e >= 0 && e < n) dst[ppos(e, q)] = i < lim ? v2f{a[m], b[m]} : v2f{0.f, 0.f};
-    }
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<v2fx2*>(d + r * q) = v2fx2{v2f{a[2 * r], b[2 * r]}, v2f{a[2 * r + 1], b[2 * r + 1]}};
   }
 }
 
@@ -321,22 +350,21 @@ __device__ __forceinline__ void win_load(const v2f* src, int q, int e0, v2f (&wi
   }
 }
 
-// One FIR over the pair: acc[m] += sum_j tap(j) * src[e0 + m + j], j < k8.  `raw(j)` returns the (clamped-index) tap pair of
-// step j as loaded, `sel(j, v)` zeroes it outside the tap range: the loads of step j0 + 8 are issued before the 64 FMAs of step
-// j0 and only selected after them, so the scalar-load latency hides behind the FMA block.
-template <class R, class S>
-__device__ __forceinline__ void fir_pair(const v2f* src, int q, int e0, int k8, R raw, S sel, v2f (&acc)[8]) {
-  v2f win[16], wn[8];
+// One FIR over the pair: acc[m] += sum_j taps[j] * src[e0 + m + j], j < k8 (a multiple of 8; `taps` = float2 pairs in LDS, zero-padded,
+// 16-byte aligned: every lane reads the same address, a broadcast).  The alternatives were measured: taps over the scalar memory path
+// cost 1.5x the kernel time (SMEM and LDS share one wait counter, so every LDS wait also waits for the step's 16 scalar loads); taps
+// in registers handed to the packed FMAs through v_readlane cost 1.13x (SGPR-write hazards, fewer waves).
+__device__ __forceinline__ void fir_pair(const v2f* src, int q, int e0, int k8, const v2f* taps, v2f (&acc)[8]) {
+  v2f win[16];
   win_load(src, q, e0, win, 0);
-#pragma unroll
-  for (int jj = 0; jj < 8; ++jj) wn[jj] = raw(jj);
   for (int j0 = 0; j0 < k8; j0 += 8) {
     win_load(src, q, e0 + j0 + 8, win, 8);
     v2f w[8];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) w[jj] = sel(j0 + jj, wn[jj]);
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) wn[jj] = raw(j0 + 8 + jj);
+    for (int r = 0; r < 4; ++r) {
+      const v2fx2 v = *reinterpret_cast<const v2fx2*>(taps + j0 + 2 * r);
+      w[2 * r] = v.a; w[2 * r + 1] = v.b;
+    }
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
@@ -360,39 +388,58 @@ __device__ __forceinline__ void store_pair(bf16_t* ra, bf16_t* rb, const v2f (&a
 }
 
 __host__ __device__ constexpr int pair_xl(int k8) { return PT + k8 + 16; }                       // staged x samples per tile
+constexpr int PAIR_TAPS = DW_KMAX + 16;                                                          // float2 tap slots per wave (k + 7 rounded up to 8)
 __host__ __device__ constexpr int pair_gl(int k, int p) { return round_up(p, 8) + PT + round_up(k + round_up(p, 8) - p, 8) + 16; }
 
-// forward: y[r, t] = sum_j w[c, j] xm[r, t + j - p]; grid = row pairs / 4, 4 waves per workgroup
+// forward: y[r, t] = sum_j w[c, j] xm[r, t + j - p].  A wave walks over `pairs_per_wave` consecutive row pairs (times the 512-frame
+// tiles of a row): while one pair is filtered out of LDS, the rows of the next are already on their way from HBM.
 template <class T>
 __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ x, const int* __restrict__ len_in, const int* __restrict__ len_out,
                                                           const float* __restrict__ w, T* __restrict__ y, int batch, int ch, int t, int k, int p,
-                                                          int pitch) {
+                                                          int pitch, int pairs_per_wave) {
   extern __shared__ __attribute__((aligned(16))) v2f sm2[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int k8 = (k + 7) & ~7, xl = pair_xl(k8), q = xl >> 2;
-  v2f* const xs = sm2 + wave * xl;
-  const long long rp = (long long)blockIdx.x * 4 + wave;
-  if (rp * 2 >= (long long)batch * ch) return;
-  const int b = (int)(rp * 2 / ch), c = (int)(rp * 2 % ch);
-  const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
-  const T* const xa = x + (size_t)rp * 2 * pitch;
-  const T* const xb = xa + pitch;
-  T* const ya = y + (size_t)rp * 2 * pitch;
-  T* const yb = ya + pitch;
-  const float* const wa = w + (size_t)c * k;
-  const float* const wb = wa + k;
-  auto raw = [&](int j) { const int jc = j < k ? j : k - 1; return v2f{wa[jc], wb[jc]}; };     // scalar loads (uniform address)
-  auto sel = [&](int j, v2f v) { return j < k ? v : v2f{0.f, 0.f}; };
-  for (int t0 = 0; t0 < t; t0 += PT) {
-    stage_pair(xs, q, xa, xb, t0 - p, xl, li, lane);
+  const int sh = (-p) & 7;                                 // (t0 - p) & 7 for every tile (PT is a multiple of 8): the taps move, not the samples
+  const int k8 = round_up(k + sh, 8), xl = pair_xl(round_up(k + 7, 8)), q = xl >> 2;
+  v2f* const xs = sm2 + wave * (xl + PAIR_TAPS);
+  v2f* const tp = xs + xl;                                 // this wave's taps, shifted by sh and zero-padded
+  const long long n_pairs = (long long)batch * ch / 2;
+  const long long rp0 = ((long long)blockIdx.x * 4 + wave) * pairs_per_wave;
+  if (rp0 >= n_pairs) return;
+  const int np = rp0 + pairs_per_wave <= n_pairs ? pairs_per_wave : (int)(n_pairs - rp0);
+  const int n_tiles = (t + PT - 1) / PT, items = np * n_tiles;
+  Staged<T> st;
+  auto fetch = [&](int it) {
+    const long long rp = rp0 + it / n_tiles;
+    const int b = (int)(rp * 2 / ch), t0 = (it % n_tiles) * PT;
+    const T* const xa = x + (size_t)rp * 2 * pitch;
+    stage_fetch(st, xa, xa + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
+  };
+  fetch(0);
+  for (int it = 0; it < items; ++it) {
+    const long long rp = rp0 + it / n_tiles;
+    const int b = (int)(rp * 2 / ch), c = (int)(rp * 2 % ch), t0 = (it % n_tiles) * PT;
+    const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
+    stage_write(st, xs, q, t0 - p - sh, xl, li, lane);
+    // y[t0 + tt] = sum_j' w'[j'] xs[tt + j'],  xs[e] = xm[t0 - p - sh + e],  w'[j'] = w[j' - sh]
+    if (it % n_tiles == 0) {
+      const float* const wa = w + (size_t)c * k;
+      for (int j = lane; j < k8; j += 64) { const int jj = j - sh; tp[j] = (jj >= 0 && jj < k) ? v2f{wa[jj], wa[k + jj]} : v2f{0.f, 0.f}; }
+    }
+    if (it + 1 < items) fetch(it + 1);
     __builtin_amdgcn_wave_barrier();
+    T* const ya = y + (size_t)rp * 2 * pitch;
     const int t8 = 8 * lane;
     if (t0 + t8 < t) {
       v2f acc[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
-      fir_pair(xs + ((t8 >> 3) << 1), q, 0, k8, raw, sel, acc);
-      store_pair(ya, yb, acc, t0 + t8, lo);
+#ifndef DWV_NO_FIR
+      fir_pair(xs + ((t8 >> 3) << 1), q, 0, k8, tp, acc);
+#else
+      acc[0] = xs[lane];
+#endif
+      store_pair(ya, ya + pitch, acc, t0 + t8, lo);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -411,37 +458,54 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
                                                           int clips_per_wave) {
   extern __shared__ __attribute__((aligned(16))) v2f sm2[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int k8 = (k + 7) & ~7, xl = pair_xl(k8), qx = xl >> 2;
+  const int sh = (-p) & 7;                                 // x is staged from the 8-aligned frame t0 - p - sh: tap j sits at window offset j + sh
+  const int k8 = round_up(k + sh, 8), xl = pair_xl(round_up(k + 7, 8)), qx = xl >> 2;
   const int o = round_up(p, 8), fpad = o - p, kf8 = round_up(k + fpad, 8), gl = pair_gl(k, p), qg = gl >> 2;
-  v2f* const xs = sm2 + wave * (xl + gl);
+  v2f* const xs = sm2 + wave * (xl + gl + PAIR_TAPS);
   v2f* const gs = xs + xl;
+  v2f* const tp = gs + gl;                                 // this wave's taps, flipped, padded by fpad zeros in front
   const int c = 2 * blockIdx.x;
-  const float* const wa = w + (size_t)c * k;
-  const float* const wb = wa + k;
-  auto rawf = [&](int j) { const int jj = j - fpad, jc = jj < 0 ? 0 : (jj < k ? jj : k - 1); return v2f{wa[k - 1 - jc], wb[k - 1 - jc]}; };
-  auto self = [&](int j, v2f v) { const int jj = j - fpad; return (jj >= 0 && jj < k) ? v : v2f{0.f, 0.f}; };
+  {
+    const float* const wa = w + (size_t)c * k;
+    for (int j = lane; j < kf8; j += 64) { const int jj = j - fpad; tp[j] = (jj >= 0 && jj < k) ? v2f{wa[k - 1 - jj], wa[2 * k - 1 - jj]} : v2f{0.f, 0.f}; }
+  }
   const int ng = k8 >> 3, nq = 64 / ng, g = lane % ng, sl = lane / ng;
   const bool active = sl < nq;
   v2f part[8];
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) part[jj] = v2f{0.f, 0.f};
   const int b_lo = (blockIdx.y * 4 + wave) * clips_per_wave;
-  for (int b = b_lo; b < b_lo + clips_per_wave && b < batch; ++b) {
+  const int nb = b_lo >= batch ? 0 : (b_lo + clips_per_wave <= batch ? clips_per_wave : batch - b_lo);
+  const int n_tiles = (t + PT - 1) / PT, items = nb * n_tiles;
+  Staged<T> sx, sg;
+  auto fetch = [&](int it) {
+    const int b = b_lo + it / n_tiles, t0 = (it % n_tiles) * PT;
+    const size_t r0 = ((size_t)b * ch + c) * pitch;
+    stage_fetch(sx, x + r0, x + r0 + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
+    stage_fetch(sg, dy + r0, dy + r0 + pitch, t0 - o, gl, len_out ? clamp_len(len_out, b, t) : t, lane);
+  };
+  if (items > 0) fetch(0);
+  for (int it = 0; it < items; ++it) {
+    const int b = b_lo + it / n_tiles, t0 = (it % n_tiles) * PT;
     const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
     const size_t r0 = ((size_t)b * ch + c) * pitch;
-    for (int t0 = 0; t0 < t; t0 += PT) {
-      stage_pair(xs, qx, x + r0, x + r0 + pitch, t0 - p, xl, li, lane);
-      stage_pair(gs, qg, dy + r0, dy + r0 + pitch, t0 - o, gl, lo, lane);
+    {
+      stage_write(sx, xs, qx, t0 - p - sh, xl, li, lane);
+      stage_write(sg, gs, qg, t0 - o, gl, lo, lane);
+      if (it + 1 < items) fetch(it + 1);                   // the next clip's rows travel while this one is filtered
       __builtin_amdgcn_wave_barrier();
       const int nt = t - t0 < PT ? t - t0 : PT;
       const int i8 = 8 * lane;
+#ifndef DWV_NO_DX
       if (i8 < nt) {
         v2f acc[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
-        fir_pair(gs + ((i8 >> 3) << 1), qg, 0, kf8, rawf, self, acc);
+        fir_pair(gs + ((i8 >> 3) << 1), qg, 0, kf8, tp, acc);
         store_pair(dx + r0, dx + r0 + pitch, acc, t0 + i8, li);
       }
+#endif
+#ifndef DWV_NO_DW
       if (active) {
         const int per = round_up((nt + nq - 1) / nq, 8);
         const int lo_t = sl * per < nt ? sl * per : nt, hi_t = lo_t + per < nt ? lo_t + per : nt;
@@ -461,6 +525,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
           }
         }
       }
+#endif
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -470,7 +535,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
   for (int jj = 0; jj < 8; ++jj) red[(threadIdx.x) * 8 + jj] = active ? part[jj] : v2f{0.f, 0.f};
   __syncthreads();
   for (int idx = threadIdx.x; idx < 2 * k; idx += 256) {
-    const int sel = idx / k, j = idx % k, gj = j >> 3, jj = j & 7;
+    const int sel = idx / k, j = idx % k, gj = (j + sh) >> 3, jj = (j + sh) & 7;      // register jj of tap group gj holds tap 8 gj + jj - sh
     float tot = 0.f;
     for (int wv = 0; wv < 4; ++wv)
       for (int r = 0; r < nq; ++r) tot += red[((wv * 64) + r * ng + gj) * 8 + jj][sel];
@@ -716,13 +781,16 @@ extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const i
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
   if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
-    const size_t lds2 = 4 * (size_t)pair_xl(round_up(k, 8)) * sizeof(v2f);
-    const dim3 grid2((unsigned)(((long long)batch * ch / 2 + 3) / 4));
+    const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + PAIR_TAPS) * sizeof(v2f);
+    // pairs per wave: 2 (the second pair's loads overlap the first one's FIR) once that still leaves >= 16 waves per CU
+    const long long n_pairs = (long long)batch * ch / 2;
+    const int ppw = n_pairs >= 32LL * cu_count() ? 2 : 1;
+    const dim3 grid2((unsigned)((n_pairs + 4 * ppw - 1) / (4 * ppw)));
     TS_ACT(act,
            hipLaunchKernelGGL(dw_fwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)x, len_in, len_out, w, (float*)y, batch, ch,
-                              t_in, k, pad, pitch_in),
+                              t_in, k, pad, pitch_in, ppw),
            hipLaunchKernelGGL(dw_fwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)x, len_in, len_out, w, (bf16_t*)y, batch,
-                              ch, t_in, k, pad, pitch_in));
+                              ch, t_in, k, pad, pitch_in, ppw));
     return hip_status(hipGetLastError());
   }
   const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 32) * sizeof(float);
@@ -744,8 +812,8 @@ extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t*
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
   if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
-    const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k, 8)) + pair_gl(k, pad)) * sizeof(v2f);
-    const int cpw = batch > 32 ? (batch + 31) / 32 : 1;
+    const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + pair_gl(k, pad) + PAIR_TAPS) * sizeof(v2f);
+    const int cpw = batch >= 16 ? (batch + 15) / 16 : 1;        // >= 2 clips per wave: the second clip's loads overlap the first one's FIR
     const dim3 grid2(ch / 2, (batch + 4 * cpw - 1) / (4 * cpw));
     TS_ACT(act,
            hipLaunchKernelGGL(dw_bwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)dy, (const float*)x, len_in, len_out, w,
