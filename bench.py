@@ -149,7 +149,10 @@ def main():
             run_enc = lambda: encoder_only(feats, fl)
         else:
             g_step, g_enc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
+                step()                          # the library's arena buffers are per stream: let this stream's exist (and be zeroed once)
+                encoder_only(feats, fl)         # before the capture, or their one-time zero fill would be replayed with every step
                 with torch.cuda.graph(g_step, stream=side):
                     out = step()
                 with torch.cuda.graph(g_enc, stream=side):

@@ -318,18 +318,20 @@ class EncoderSequential(MultiSequential):
 
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "encoder")
-        if self.training:                       # training mode: plain chain of the blocks' training forwards (fp32, autograd)
+        if self.training:                       # training mode: plain chain of the blocks' training forwards (autograd)
             x = audio
-            for blk in self.children():
-                x, audio_lengths = blk(x, audio_lengths)
+            with _t.lengths_scope():
+                for blk in self.children():
+                    x, audio_lengths = blk(x, audio_lengths)
             return x, audio_lengths
-        x = audio if _t.is_internal(audio) else _t.pack(audio, audio_lengths, slot=("enc", id(self)))
-        blocks = list(self.children())
-        for i, blk in enumerate(blocks):
-            if isinstance(blk, _FusedBlockBase):
-                x, audio_lengths, _ = blk._run_fused(x, audio_lengths, internal=i < len(blocks) - 1, slot=(id(self), i % 2))
-            else:
-                x, audio_lengths = blk(x, audio_lengths)
+        with _t.lengths_scope():                # the int32 copy of a lengths tensor is made once per forward, not once per block
+            x = audio if _t.is_internal(audio) else _t.pack(audio, audio_lengths, slot=("enc", id(self)))
+            blocks = list(self.children())
+            for i, blk in enumerate(blocks):
+                if isinstance(blk, _FusedBlockBase):
+                    x, audio_lengths, _ = blk._run_fused(x, audio_lengths, internal=i < len(blocks) - 1, slot=(id(self), i % 2))
+                else:
+                    x, audio_lengths = blk(x, audio_lengths)
         return x, audio_lengths
 
 

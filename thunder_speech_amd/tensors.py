@@ -104,10 +104,38 @@ def unpack(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_LEN_SCOPE = None
+
+
+class lengths_scope:
+    """One forward pass of an encoder: inside it, lengths_i32 converts a given lengths tensor object once and hands the result to every
+    later caller (the same object flows through all length-preserving blocks).  Unlike the attribute cache below, this also holds while
+    a hipGraph is being captured -- the conversion is recorded once per forward instead of once per block (37 tiny copy kernels in a
+    QuartzNet15x5 step otherwise, ~5 us each even inside a graph) -- and nothing outlives the forward, so no capture sees another's
+    tensors."""
+
+    def __enter__(self):
+        global _LEN_SCOPE
+        self._prev, _LEN_SCOPE = _LEN_SCOPE, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _LEN_SCOPE
+        _LEN_SCOPE = self._prev
+        return False
+
+
 def lengths_i32(lengths: torch.Tensor, device) -> torch.Tensor:
     """Reference lengths may be float or int (A5); the kernels take floor()ed int32 on the device."""
     if lengths.dtype == torch.int32 and lengths.device == torch.device(device) and lengths.is_contiguous():
         return lengths
+    if _LEN_SCOPE is not None:
+        hit = _LEN_SCOPE.get(id(lengths))
+        if hit is not None and hit[0] is lengths and hit[1] == lengths._version and hit[2].device == torch.device(device):
+            return hit[2]
+        out = lengths.to(device=device, dtype=torch.int64).to(torch.int32).contiguous()
+        _LEN_SCOPE[id(lengths)] = (lengths, lengths._version, out)
+        return out
     # while a hipGraph is being captured the conversion must be RECORDED (a replay refreshes `lengths` in place and the
     # kernels have to see the new values), so the cache is neither read nor written
     capturing = lengths.is_cuda and torch.cuda.is_current_stream_capturing()

@@ -142,7 +142,7 @@ def c5(device, batch=16, seconds=20, steps=10, check=True):
     return res
 
 
-def c4(device, local_batch=32, seconds=10, steps1=30, steps2=10):
+def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
     """QuartzNet15x5 fine-tuning, one rank's share of config C4 (global 256 x 10 s over 8 GPUs = local 32).  Phase 1 = the
     reference recipe's first epochs (FinetuneEncoderDecoder: encoder frozen), phase 2 = everything trainable."""
     from thunder_speech_amd import _lib
@@ -156,7 +156,12 @@ def c4(device, local_batch=32, seconds=10, steps1=30, steps2=10):
     lengths = torch.full((local_batch,), 16000.0 * seconds, device=device)
     texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(60, 140, (local_batch,), generator=g)]
     fwd_gflop = 4826.9 * local_batch * seconds / 2560.0             # 4 826.9 GFLOP forward per 256 x 10 s
-    for phase, steps in ((1, steps1), (2, steps2)):
+    from thunder_speech_amd import train_ops
+    from thunder_speech_amd.train_graph import GraphedTrainStep
+    # phase 2 twice: the mixed-precision path (bf16 activations, f32 master weights / gradients / statistics; fwd+bwd replayed from one
+    # hipGraph) is the measured configuration; the f32 path (the reference's arithmetic, what the parity tests check) is reported beside it
+    for tag, phase, steps, act, graph in (("c4_phase1", 1, steps1, "fp32", False), ("c4_phase2", 2, steps2, "bf16", True),
+                                          ("c4_phase2_fp32", 2, max(steps2 // 3, 5), "fp32", False)):
         torch.manual_seed(0)
         m = build_synthetic_quartznet(repeat_blocks=3)
         variance_preserving_init_(m.encoder, m.decoder, seed=0)
@@ -166,36 +171,46 @@ def c4(device, local_batch=32, seconds=10, steps1=30, steps2=10):
             for p in m.encoder.parameters():
                 p.requires_grad_(False)
             m.graph_frozen_encoder()
-        trainable = [p for p in m.parameters() if p.requires_grad]
-        opt, sync = FusedAdamW(trainable, lr=1e-3), GradientSync(trainable)
+        train_ops.set_activation_dtype(act)
+        try:
+            trainable = [p for p in m.parameters() if p.requires_grad]
+            opt, sync = FusedAdamW(trainable, lr=1e-3), GradientSync(trainable)
+            graphed = GraphedTrainStep(m, opt, sync, max_target_len=160) if graph else None
 
-        def step():
-            sync.zero_grad()
-            loss = m.training_step((wav, lengths, texts), 0)
-            loss.backward()
-            sync.finish()
-            opt.step()
-            return loss
+            def step():
+                if graphed is not None:
+                    return graphed((wav, lengths, texts))
+                sync.zero_grad()
+                loss = m.training_step((wav, lengths, texts), 0)
+                loss.backward()
+                sync.finish()
+                opt.step()
+                return loss
 
-        for _ in range(3):
+            first = float(step())
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            c0 = _lib.CALLS
             step()
-        torch.cuda.synchronize()
-        c0 = _lib.CALLS
-        step()
-        calls = _lib.CALLS - c0
-        dt = _timed(step, steps, warmup=0)
+            calls = _lib.CALLS - c0
+            dt = _timed(step, steps, warmup=0)
+            last = float(step())
+        finally:
+            train_ops.set_activation_dtype("fp32")
         model_flop = (3.0 if phase == 2 else 1.0) * fwd_gflop      # phase 1: forward only through the frozen encoder
-        out[f"c4_phase{phase}"] = {
-            "workload": f"QuartzNet15x5 fine-tune step (CTC), local batch {local_batch}x{seconds} s, "
-                        + ("encoder frozen + hipGraph-replayed, decoder trainable" if phase == 1 else "everything trainable, fp32 activations")
-                        + " (BASELINE.json configs[3], one rank's share)",
+        how = ("encoder frozen + hipGraph-replayed, decoder trainable" if phase == 1 else
+               "everything trainable, " + ("bf16 activations (mixed precision: f32 master weights, gradients, BatchNorm statistics), encoder + decoder + "
+                                           "CTC + backward replayed from one hipGraph" if act == "bf16" else "f32 activations (the reference's arithmetic), eager launches"))
+        out[tag] = {
+            "workload": f"QuartzNet15x5 fine-tune step (CTC), local batch {local_batch}x{seconds} s, {how} (BASELINE.json configs[3], one rank's share)",
             "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s", "audio_seconds_per_s": local_batch * seconds / dt,
-            "steps": steps, "c_abi_calls_per_step": calls,
+            "steps": steps, "c_abi_calls_per_step": calls, "dtype": act, "loss_first_last": [first, last],
             "roofline": {"bound": "mfma", "model": "3 x forward FLOPs (BASELINE.md section 3)" if phase == 2 else "1 x forward FLOPs (frozen encoder)",
                          "achieved": model_flop / dt / 1e3, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": model_flop / dt / 1e3 / MFMA_BF16_PEAK_TF, "frac_of_fp32_vector_peak": model_flop / dt / 1e3 / FP32_PEAK_TF}}
         sync.close()
-        del m, opt, sync
+        del m, opt, sync, graphed
         torch.cuda.empty_cache()
     return out
 
