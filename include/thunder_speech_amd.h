@@ -231,6 +231,26 @@ int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len
 int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* dx,
                         float* dw, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride,
                         int32_t dilation, int32_t padding, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);
+/* BatchNorm(train) [+ ReLU] between two repeats folded into the depthwise launches ("same" geometry only: stride 1, dilation 1, odd
+ * kernel, padding (k-1)/2, even channel count; anything else TS_EUNSUPPORTED), so that the normalised tensor is never stored:
+ *   ts_train_bn_stats       clip-group sums of v only (sums: 16*C doubles = [8][C][2] (sum v, sum v^2)), no apply pass
+ *   ts_train_dwconv_fwd_bn  y = dwconv(mask(x)), x = relu?(gamma * (v - mean) * rstd + beta) formed while v is staged; mean / rstd come
+ *                           out of in_sums inside the kernel, which also publishes in_mean_rstd (f32 [C][2], needed by the backward
+ *                           calls) and applies the running-statistics update (momentum, unbiased variance, batch counter)
+ *   ts_train_dwconv_bwd_bn  dw as ts_train_dwconv_bwd; g = dL/dx * (x > 0 when in_relu); in_dbeta += sum g, in_dgamma += sum g * xhat
+ *                           (both ACCUMULATE: they are the parameter gradients of that BatchNorm and the sums its backward needs)
+ *   ts_train_bn_bwd_sums    dv = gamma * rstd * (g - dbeta / n - xhat * dgamma / n), n = B * T */
+int ts_train_bn_stats(const void* v, void* sums, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
+int ts_train_dwconv_fwd_bn(const void* v, const void* in_sums, const float* in_gamma, const float* in_beta, float in_eps, int32_t in_relu,
+                           float* in_mean_rstd, float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                           const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch, int32_t channels,
+                           int32_t t, int32_t kernel, int32_t padding, int32_t pitch, int32_t act, void* stream);
+int ts_train_dwconv_bwd_bn(const void* dy, const void* v, const float* in_mean_rstd, const float* in_gamma, const float* in_beta,
+                           int32_t in_relu, const int32_t* len_in, const int32_t* len_out, const float* w, void* g, float* dw,
+                           float* in_dgamma, float* in_dbeta, int32_t batch, int32_t channels, int32_t t, int32_t kernel, int32_t padding,
+                           int32_t pitch, int32_t act, void* stream);
+int ts_train_bn_bwd_sums(const void* g, const void* v, const float* gamma, const float* mean_rstd, const float* dgamma, const float* dbeta,
+                         void* dv, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_mask_time(const void* x, const int32_t* len, void* y, int32_t batch, int32_t channels, int32_t t, int32_t pitch_x,
                        int32_t pitch_y, int32_t act, void* stream);
 /* pointwise convs.  precision: 0 = f32 operands and results; 1 = bf16 operands (u, dv; w = a bf16 copy made by ts_train_cast_bf16),

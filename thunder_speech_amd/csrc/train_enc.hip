@@ -317,8 +317,64 @@ __device__ __forceinline__ void stage_fetch(Staged<T>& st, const T* ra, const T*
     if (8 * u < n && i8 >= 0 && i8 < lim) { raw_load(st.a[it], ra + i8); raw_load(st.b[it], rb + i8); }
   }
 }
+// Input transform of the rows being staged: the BatchNorm(train) [+ ReLU] of the PREVIOUS repeat, y = relu?(v * scale + shift), applied on
+// the fly so that y is never stored (train_ops.SubBlock hands the un-normalised v of a repeat to the next one).  on == false: identity.
+struct RowAffine { float sa, ha, sb, hb; bool relu, on; };
+constexpr int BN_G = 8;                                   // clip groups of the BatchNorm partial sums
+__device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch, int c, double& s1, double& s2, int ng = BN_G) {
+  s1 = 0.0; s2 = 0.0;
+  for (int g = 0; g < ng; ++g) { s1 += part[((size_t)g * ch + c) * 2]; s2 += part[((size_t)g * ch + c) * 2 + 1]; }
+}
+struct PairAffine { const float* mean_rstd; const float* gamma; const float* beta; int relu; };   // per channel; mean_rstd == nullptr: none
+// forward side: the previous repeat only left the clip-group sums of its 1x1 output (chan_sums_kernel<0>); the depthwise kernel turns
+// them into mean / rstd itself (a few double operations per wave), and the wave that owns clip 0 of a channel pair publishes mean_rstd
+// for the backward pass and updates the running statistics -- no finalize launch, no device-scope fence (a fence writes back the
+// whole XCD L2: 66 us per layer when tried)
+struct PairBnIn {
+  const double* part; const float* gamma; const float* beta; float eps; int relu; double n;
+  float* mean_rstd; float* running_mean; float* running_var; float momentum; long long* nbt;
+};
+
+__device__ __forceinline__ RowAffine row_affine(const PairAffine& p, int c) {
+  RowAffine r{1.f, 0.f, 1.f, 0.f, false, false};
+  if (p.mean_rstd) {
+    r.sa = p.gamma[c] * p.mean_rstd[2 * c + 1];     r.ha = p.beta[c] - p.mean_rstd[2 * c] * r.sa;
+    r.sb = p.gamma[c + 1] * p.mean_rstd[2 * c + 3]; r.hb = p.beta[c + 1] - p.mean_rstd[2 * c + 2] * r.sb;
+    r.relu = p.relu != 0; r.on = true;
+  }
+  return r;
+}
+
+__device__ __forceinline__ RowAffine row_affine(const PairBnIn& p, int c, int ch, bool publish) {
+  RowAffine r{1.f, 0.f, 1.f, 0.f, false, false};
+  if (p.part) {
+    float sc[2], hs[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      double s1, s2;
+      bn_total(p.part, ch, c + e, s1, s2);
+      const double mu = s1 / p.n;
+      double var = s2 / p.n - mu * mu;
+      var = var < 0.0 ? 0.0 : var;
+      const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+      sc[e] = p.gamma[c + e] * rstd; hs[e] = p.beta[c + e] - (float)mu * sc[e];
+      if (publish) {
+        p.mean_rstd[2 * (c + e)] = (float)mu; p.mean_rstd[2 * (c + e) + 1] = rstd;
+        if (p.running_mean) {      // nn.BatchNorm1d's update: momentum blend of the batch mean and the UNBIASED batch variance
+          p.running_mean[c + e] = (1.f - p.momentum) * p.running_mean[c + e] + p.momentum * (float)mu;
+          p.running_var[c + e] = (1.f - p.momentum) * p.running_var[c + e] + p.momentum * (float)(var * (p.n / (p.n > 1.0 ? p.n - 1.0 : 1.0)));
+          if (c + e == 0 && p.nbt) *p.nbt += 1;
+        }
+      }
+    }
+    r.sa = sc[0]; r.ha = hs[0]; r.sb = sc[1]; r.hb = hs[1]; r.relu = p.relu != 0; r.on = true;
+  }
+  return r;
+}
+
 template <class T>
-__device__ __forceinline__ void stage_write(const Staged<T>& st, v2f* dst, int q, int a0, int n, int lim, int lane) {
+__device__ __forceinline__ void stage_write(const Staged<T>& st, v2f* dst, int q, int a0, int n, int lim, int lane,
+                                            const RowAffine af = RowAffine{1.f, 0.f, 1.f, 0.f, false, false}) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int u = lane + 64 * it, i8 = a0 + 8 * u;
@@ -326,6 +382,13 @@ __device__ __forceinline__ void stage_write(const Staged<T>& st, v2f* dst, int q
     float a[8], b[8];
     if (i8 >= 0 && i8 < lim) {
       raw_get(st.a[it], a); raw_get(st.b[it], b);
+      if (af.on) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          a[m] = fmaf(a[m], af.sa, af.ha); b[m] = fmaf(b[m], af.sb, af.hb);
+          if (af.relu) { a[m] = a[m] > 0.f ? a[m] : 0.f; b[m] = b[m] > 0.f ? b[m] : 0.f; }
+        }
+      }
       if (i8 + 8 > lim) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) if (i8 + m >= lim) { a[m] = 0.f; b[m] = 0.f; }
@@ -396,7 +459,7 @@ __host__ __device__ constexpr int pair_gl(int k, int p) { return round_up(p, 8) 
 template <class T>
 __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ x, const int* __restrict__ len_in, const int* __restrict__ len_out,
                                                           const float* __restrict__ w, T* __restrict__ y, int batch, int ch, int t, int k, int p,
-                                                          int pitch, int pairs_per_wave) {
+                                                          int pitch, int pairs_per_wave, PairBnIn aff) {
   extern __shared__ __attribute__((aligned(16))) v2f sm2[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int sh = (-p) & 7;                                 // (t0 - p) & 7 for every tile (PT is a multiple of 8): the taps move, not the samples
@@ -420,7 +483,7 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
     const long long rp = rp0 + it / n_tiles;
     const int b = (int)(rp * 2 / ch), c = (int)(rp * 2 % ch), t0 = (it % n_tiles) * PT;
     const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
-    stage_write(st, xs, q, t0 - p - sh, xl, li, lane);
+    stage_write(st, xs, q, t0 - p - sh, xl, li, lane, row_affine(aff, c, ch, b == 0 && t0 == 0 && lane == 0));
     // y[t0 + tt] = sum_j' w'[j'] xs[tt + j'],  xs[e] = xm[t0 - p - sh + e],  w'[j'] = w[j' - sh]
     if (it % n_tiles == 0) {
       const float* const wa = w + (size_t)c * k;
@@ -455,7 +518,8 @@ template <class T>
 __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ dy, const T* __restrict__ x, const int* __restrict__ len_in,
                                                           const int* __restrict__ len_out, const float* __restrict__ w, T* __restrict__ dx,
                                                           float* __restrict__ dw, int batch, int ch, int t, int k, int p, int pitch,
-                                                          int clips_per_wave) {
+                                                          int clips_per_wave, PairAffine aff, float* __restrict__ in_dgamma,
+                                                          float* __restrict__ in_dbeta) {
   extern __shared__ __attribute__((aligned(16))) v2f sm2[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int sh = (-p) & 7;                                 // x is staged from the 8-aligned frame t0 - p - sh: tap j sits at window offset j + sh
@@ -474,6 +538,13 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
   v2f part[8];
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) part[jj] = v2f{0.f, 0.f};
+  // with an input transform (x = relu?(BatchNorm(v)) of the previous repeat, applied at staging) this kernel also does the first half of
+  // that BatchNorm's backward: it stores g = dL/dy * (y > 0) instead of dL/dy and accumulates sum g (-> in_dbeta) and sum g * xhat
+  // (-> in_dgamma) per channel -- exactly the two sums ts_train_bn_bwd_sums needs, and the parameter gradients themselves
+  const RowAffine af = row_affine(aff, c);
+  const float mu_a = aff.mean_rstd ? aff.mean_rstd[2 * c] : 0.f, rs_a = aff.mean_rstd ? aff.mean_rstd[2 * c + 1] : 0.f;
+  const float mu_b = aff.mean_rstd ? aff.mean_rstd[2 * c + 2] : 0.f, rs_b = aff.mean_rstd ? aff.mean_rstd[2 * c + 3] : 0.f;
+  v2f s1 = v2f{0.f, 0.f}, s2 = v2f{0.f, 0.f};
   const int b_lo = (blockIdx.y * 4 + wave) * clips_per_wave;
   const int nb = b_lo >= batch ? 0 : (b_lo + clips_per_wave <= batch ? clips_per_wave : batch - b_lo);
   const int n_tiles = (t + PT - 1) / PT, items = nb * n_tiles;
@@ -490,7 +561,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
     const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
     const size_t r0 = ((size_t)b * ch + c) * pitch;
     {
-      stage_write(sx, xs, qx, t0 - p - sh, xl, li, lane);
+      stage_write(sx, xs, qx, t0 - p - sh, xl, li, lane, af);
       stage_write(sg, gs, qg, t0 - o, gl, lo, lane);
       if (it + 1 < items) fetch(it + 1);                   // the next clip's rows travel while this one is filtered
       __builtin_amdgcn_wave_barrier();
@@ -502,6 +573,19 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
         fir_pair(gs + ((i8 >> 3) << 1), qg, 0, kf8, tp, acc);
+        if (af.on && t0 + i8 < li) {
+          float va[8], vb[8];
+          load8(x + r0 + t0 + i8, va); load8(x + r0 + pitch + t0 + i8, vb);
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const bool in = t0 + i8 + m < li;
+            const float ya = fmaf(va[m], af.sa, af.ha), yb = fmaf(vb[m], af.sb, af.hb);
+            const float ga = (in && (!af.relu || ya > 0.f)) ? acc[m][0] : 0.f, gb = (in && (!af.relu || yb > 0.f)) ? acc[m][1] : 0.f;
+            acc[m] = v2f{ga, gb};
+            s1 += acc[m];
+            s2 += v2f{ga != 0.f ? ga * (va[m] - mu_a) * rs_a : 0.f, gb != 0.f ? gb * (vb[m] - mu_b) * rs_b : 0.f};   // pitch padding may hold NaN bits
+          }
+        }
         store_pair(dx + r0, dx + r0 + pitch, acc, t0 + i8, li);
       }
 #endif
@@ -541,6 +625,20 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
       for (int r = 0; r < nq; ++r) tot += red[((wv * 64) + r * ng + gj) * 8 + jj][sel];
     atomicAdd(dw + (size_t)(c + sel) * k + j, tot);
   }
+  if (af.on) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s1[0] += __shfl_xor(s1[0], off); s1[1] += __shfl_xor(s1[1], off);
+      s2[0] += __shfl_xor(s2[0], off); s2[1] += __shfl_xor(s2[1], off);
+    }
+    float* const rs = reinterpret_cast<float*>(sm2 + 2048);       // behind `red`: [4 waves][4]
+    if (lane == 0) { rs[wave * 4] = s1[0]; rs[wave * 4 + 1] = s1[1]; rs[wave * 4 + 2] = s2[0]; rs[wave * 4 + 3] = s2[1]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const float tot = rs[threadIdx.x] + rs[4 + threadIdx.x] + rs[8 + threadIdx.x] + rs[12 + threadIdx.x];
+      atomicAdd((threadIdx.x < 2 ? in_dbeta : in_dgamma) + c + (threadIdx.x & 1), tot);
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -569,8 +667,6 @@ __global__ __launch_bounds__(256) void mask_time_kernel(const T* __restrict__ x,
 //   MODE 0 (forward statistics):  s1 = sum v,  s2 = sum v^2
 //   MODE 1 (backward statistics): g = dy * (y > 0 if relu), xhat = (v - mean) * rstd:  s1 = sum g,  s2 = sum g * xhat
 //          -- g and xhat are recomputed here and in the apply kernel instead of being written out and read back twice
-constexpr int BN_G = 8;
-
 template <int MODE, class T>
 __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ v,
                                                         const float* __restrict__ mean_rstd, double* __restrict__ part, int batch,
@@ -610,11 +706,6 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ a,
     __syncthreads();
   }
   if (threadIdx.x == 0) { part[((size_t)grp * ch + c) * 2] = r1[0]; part[((size_t)grp * ch + c) * 2 + 1] = r2[0]; }
-}
-
-__device__ __forceinline__ void bn_total(const double* __restrict__ part, int ch, int c, double& s1, double& s2, int ng = BN_G) {
-  s1 = 0.0; s2 = 0.0;
-  for (int g = 0; g < ng; ++g) { s1 += part[((size_t)g * ch + c) * 2]; s2 += part[((size_t)g * ch + c) * 2 + 1]; }
 }
 
 // BatchNorm(train) forward: stats[c] = (sum v, sum v^2) -> mean, rstd (biased variance, eps), y = gamma*(v-mean)*rstd + beta [ReLU].
@@ -690,6 +781,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     g[j] = k * (gj - mg - (vv[j] - mu) * rs * mgx);
   }
   store8(dv + base, g);
+}
+
+// second half of a BatchNorm(train) backward whose first half ran in dw_bwd_pair_kernel's epilogue: g = dL/dy * (y > 0) is stored,
+// S1 = sum g (= dbeta) and S2 = sum g * xhat (= dgamma) are complete:  dv = gamma * rstd * (g - S1 / n - xhat * S2 / n)
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const T* __restrict__ g, const T* __restrict__ v, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_rstd, const float* __restrict__ dgamma,
+                                                          const float* __restrict__ dbeta, T* __restrict__ dv, int batch, int ch, int t, int pitch) {
+  const int row = blockIdx.x, c = row % ch;
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
+  const float inv_n = 1.f / ((float)batch * (float)t);
+  const float mg = dbeta[c] * inv_n, mgx = dgamma[c] * inv_n, mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1], k = gamma[c] * rs;
+  const size_t base = (size_t)row * pitch + i;
+  float gg[8], vv[8];
+  load8(g + base, gg);
+  load8(v + base, vv);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gg[j] = k * (gg[j] - mg - (vv[j] - mu) * rs * mgx);
+  store8(dv + base, gg);
 }
 
 // out = relu(a + b) (RELU) or a + b; backward of the first: da = db = dout * (out > 0)
@@ -773,13 +884,14 @@ static bool pair_geometry(int ch, int t_in, int t_out, int k, int stride, int di
 
 #define TS_ACT(act, expr_f32, expr_bf16) do { if (act) { expr_bf16; } else { expr_f32; } } while (0)
 
-extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
-                                   int32_t ch, int32_t t_in, int32_t t_out, int32_t k, int32_t stride, int32_t dil, int32_t pad,
-                                   int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_) {
+static int dwconv_fwd_impl(const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
+                           int32_t ch, int32_t t_in, int32_t t_out, int32_t k, int32_t stride, int32_t dil, int32_t pad,
+                           int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_, PairBnIn aff) {
   if (!x || !w || !y || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0 || stride <= 0 || dil <= 0) return TS_EINVAL;
   if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
+  if (aff.part && !pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) return TS_EUNSUPPORTED;
   if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + PAIR_TAPS) * sizeof(v2f);
     // pairs per wave: 2 (the second pair's loads overlap the first one's FIR) once that still leaves >= 16 waves per CU
@@ -788,9 +900,9 @@ extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const i
     const dim3 grid2((unsigned)((n_pairs + 4 * ppw - 1) / (4 * ppw)));
     TS_ACT(act,
            hipLaunchKernelGGL(dw_fwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)x, len_in, len_out, w, (float*)y, batch, ch,
-                              t_in, k, pad, pitch_in, ppw),
+                              t_in, k, pad, pitch_in, ppw, aff),
            hipLaunchKernelGGL(dw_fwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)x, len_in, len_out, w, (bf16_t*)y, batch,
-                              ch, t_in, k, pad, pitch_in, ppw));
+                              ch, t_in, k, pad, pitch_in, ppw, aff));
     return hip_status(hipGetLastError());
   }
   const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 32) * sizeof(float);
@@ -804,22 +916,43 @@ extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const i
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w,
-                                   void* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
-                                   int32_t stride, int32_t dil, int32_t pad, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_) {
+extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
+                                   int32_t ch, int32_t t_in, int32_t t_out, int32_t k, int32_t stride, int32_t dil, int32_t pad,
+                                   int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_) {
+  return dwconv_fwd_impl(x, len_in, len_out, w, y, batch, ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out, act, stream_,
+                         PairBnIn{nullptr, nullptr, nullptr, 0.f, 0, 1.0, nullptr, nullptr, nullptr, 0.f, nullptr});
+}
+
+// the same with x = relu?(BatchNorm(v)) formed on the fly from the previous repeat's un-normalised output v and the clip-group sums
+// ts_train_bn_stats left in `in_sums`; publishes in_mean_rstd (f32 [C][2], for the backward pass) and updates the running statistics
+extern "C" int ts_train_dwconv_fwd_bn(const void* v, const void* in_sums, const float* in_gamma, const float* in_beta, float in_eps,
+                                      int32_t in_relu, float* in_mean_rstd, float* running_mean, float* running_var, float momentum,
+                                      int64_t* num_batches_tracked, const int32_t* len_in, const int32_t* len_out, const float* w, void* y,
+                                      int32_t batch, int32_t ch, int32_t t, int32_t k, int32_t pad, int32_t pitch, int32_t act, void* stream_) {
+  if (!in_sums || !in_gamma || !in_beta || !in_mean_rstd || (running_mean == nullptr) != (running_var == nullptr)) return TS_EINVAL;
+  return dwconv_fwd_impl(v, len_in, len_out, w, y, batch, ch, t, t, k, 1, 1, pad, pitch, pitch, act, stream_,
+                         PairBnIn{static_cast<const double*>(in_sums), in_gamma, in_beta, in_eps, in_relu, (double)batch * t, in_mean_rstd,
+                                  running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked)});
+}
+
+static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w,
+                           void* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
+                           int32_t stride, int32_t dil, int32_t pad, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_,
+                           PairAffine aff, float* in_dgamma, float* in_dbeta) {
   if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
   if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
+  if (aff.mean_rstd && !pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) return TS_EUNSUPPORTED;
   if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + pair_gl(k, pad) + PAIR_TAPS) * sizeof(v2f);
     const int cpw = batch >= 16 ? (batch + 15) / 16 : 1;        // >= 2 clips per wave: the second clip's loads overlap the first one's FIR
     const dim3 grid2(ch / 2, (batch + 4 * cpw - 1) / (4 * cpw));
     TS_ACT(act,
            hipLaunchKernelGGL(dw_bwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)dy, (const float*)x, len_in, len_out, w,
-                              (float*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw),
+                              (float*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta),
            hipLaunchKernelGGL(dw_bwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, w,
-                              (bf16_t*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw));
+                              (bf16_t*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta));
     return hip_status(hipGetLastError());
   }
   const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 48) * sizeof(float);
@@ -837,6 +970,52 @@ extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t*
                             ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
          hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, gw, dim3(256), lds_w, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, dw, batch,
                             ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out));
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w,
+                                   void* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
+                                   int32_t stride, int32_t dil, int32_t pad, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_) {
+  return dwconv_bwd_impl(dy, x, len_in, len_out, w, dx, dw, batch, ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out, act, stream_,
+                         PairAffine{nullptr, nullptr, nullptr, 0}, nullptr, nullptr);
+}
+
+// backward of ts_train_dwconv_fwd_bn: dw as above; `g` receives dL/dy * (y > 0) (y = the transformed input) and in_dbeta / in_dgamma
+// ACCUMULATE sum g and sum g * xhat per channel: the first half of the previous BatchNorm's backward (ts_train_bn_bwd_sums is the second)
+extern "C" int ts_train_dwconv_bwd_bn(const void* dy, const void* v, const float* in_mean_rstd, const float* in_gamma, const float* in_beta,
+                                      int32_t in_relu, const int32_t* len_in, const int32_t* len_out, const float* w, void* g, float* dw,
+                                      float* in_dgamma, float* in_dbeta, int32_t batch, int32_t ch, int32_t t, int32_t k, int32_t pad,
+                                      int32_t pitch, int32_t act, void* stream_) {
+  if (!in_mean_rstd || !in_gamma || !in_beta || !in_dgamma || !in_dbeta) return TS_EINVAL;
+  return dwconv_bwd_impl(dy, v, len_in, len_out, w, g, dw, batch, ch, t, t, k, 1, 1, pad, pitch, pitch, act, stream_,
+                         PairAffine{in_mean_rstd, in_gamma, in_beta, in_relu}, in_dgamma, in_dbeta);
+}
+
+// BatchNorm(train) batch sums without the apply pass: sums = double [8 clip groups][C][2] (sum v, sum v^2), consumed by
+// ts_train_dwconv_fwd_bn
+extern "C" int ts_train_bn_stats(const void* v, void* sums, int32_t batch, int32_t ch, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!v || !sums || batch <= 0 || ch <= 0 || t <= 0 || act < 0 || act > 1 || !rows_ok(v, pitch, act) || pitch < t) return TS_EINVAL;
+  TS_STREAM;
+  double* part = static_cast<double*>(sums);
+  TS_ACT(act,
+         hipLaunchKernelGGL((chan_sums_kernel<0, float>), dim3(ch, BN_G), dim3(256), 0, stream, (const float*)v, (const float*)nullptr, (const float*)nullptr,
+                            (const float*)nullptr, part, batch, ch, t, pitch, 0),
+         hipLaunchKernelGGL((chan_sums_kernel<0, bf16_t>), dim3(ch, BN_G), dim3(256), 0, stream, (const bf16_t*)v, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                            (const float*)nullptr, part, batch, ch, t, pitch, 0));
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_bn_bwd_sums(const void* g, const void* v, const float* gamma, const float* mean_rstd, const float* dgamma,
+                                    const float* dbeta, void* dv, int32_t batch, int32_t ch, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!g || !v || !gamma || !mean_rstd || !dgamma || !dbeta || !dv || batch <= 0 || ch <= 0 || t <= 0 || act < 0 || act > 1) return TS_EINVAL;
+  if (!rows_ok(g, pitch, act) || !rows_ok(v, pitch, act) || !rows_ok(dv, pitch, act) || pitch < t) return TS_EINVAL;
+  TS_STREAM;
+  const dim3 rg = row_grid((long long)batch * ch, t);
+  TS_ACT(act,
+         hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, rg, dim3(256), 0, stream, (const float*)g, (const float*)v, gamma, mean_rstd, dgamma, dbeta, (float*)dv,
+                            batch, ch, t, pitch),
+         hipLaunchKernelGGL(bn_bwd_sums_kernel<bf16_t>, rg, dim3(256), 0, stream, (const bf16_t*)g, (const bf16_t*)v, gamma, mean_rstd, dgamma, dbeta, (bf16_t*)dv,
+                            batch, ch, t, pitch));
   return hip_status(hipGetLastError());
 }
 

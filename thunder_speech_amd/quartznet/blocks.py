@@ -219,7 +219,10 @@ class _FusedBlockBase(nn.Module):
                 lh = _t.lengths_i32(out_lengths, dev)
             # one autograd node per repeat: [depthwise (its output already masked for the pointwise conv) | mask] -> 1x1 -> BN -> ReLU -> Dropout
             drop = drops[r] if (not last and r < len(drops)) else None
-            h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop.p if (drop is not None and drop.training) else 0.0)
+            drop_p = drop.p if (drop is not None and drop.training) else 0.0
+            # between two repeats the BatchNorm (+ ReLU) is folded into the next repeat's depthwise launches (train_ops.SubBlock)
+            lazy = T._LAZY_BN and not last and drop_p == 0.0 and T.same_depthwise(subs[r + 1][0])
+            h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop_p, lazy_out=lazy)
         if self._has_se():
             se = self.mconv[len(self.mconv) - 1].layer[0]          # citrinet/blocks.py:154: SE closes the main branch
             h = T.SqueezeExciteTrain.apply(h, se.fc[0].weight, se.fc[2].weight)

@@ -619,29 +619,66 @@ class SqueezeExciteTrain(torch.autograd.Function):
 
 class SubBlockCfg:
     """Non-tensor arguments of SubBlock (one per call)."""
-    __slots__ = ("len_in", "len_out", "k", "stride", "dil", "pad", "eps", "relu", "running", "drop_p", "drop_seed")
+    __slots__ = ("len_in", "len_out", "k", "stride", "dil", "pad", "eps", "relu", "running", "drop_p", "drop_seed",
+                 "lazy_in", "lazy_out", "out_sums")
+
+
+# BatchNorm between two repeats folded into the neighbouring depthwise launches (no normalised tensor in memory): on by default
+_LAZY_BN = True
+
+
+def set_lazy_batchnorm(on: bool) -> None:
+    global _LAZY_BN
+    _LAZY_BN = bool(on)
+
+
+def same_depthwise(conv) -> bool:
+    """The geometry the pair kernels (and with them the folded BatchNorm) cover: MaskedConv1d depthwise, stride 1, dilation 1, odd K, same padding."""
+    return (conv is not None and conv.stride == 1 and conv.dilation == 1 and conv.kernel_size % 2 == 1 and conv.kernel_size <= 128
+            and conv.padding == (conv.kernel_size - 1) // 2 and conv.conv.in_channels % 2 == 0)
 
 
 class SubBlock(torch.autograd.Function):
     """One repeat of a QuartzNet / Citrinet block as ONE autograd node (quartznet/blocks.py:195-228): [depthwise MaskedConv1d |
-    mask] -> 1x1 MaskedConv1d -> BatchNorm1d(train) [-> ReLU] [-> Dropout].  The same launches as the fine-grained Functions
-    above, in the same order -- what is fused is the host side: four autograd nodes, their argument marshalling and their
-    intermediate Python tensors become one (the training step is host-bound otherwise)."""
+    mask] -> 1x1 MaskedConv1d -> BatchNorm1d(train) [-> ReLU] [-> Dropout].  What is fused is the host side (one node instead of
+    four) and, between two repeats of a block, the BatchNorm itself:
+      * `cfg.lazy_out`: the node stops after the clip-group SUMS of its 1x1 output v (ts_train_bn_stats) and returns v; mean / rstd,
+        the running-statistics update and the normalisation + ReLU happen inside the next repeat's depthwise launch while it stages
+        its input (`cfg.lazy_in` = (sums, relu, eps, running buffers) of that BatchNorm: ts_train_dwconv_fwd_bn) -- the normalised
+        tensor never exists in memory;
+      * backward: the next repeat's depthwise backward (ts_train_dwconv_bwd_bn) also forms the two sums of that BatchNorm's backward
+        (= its dgamma / dbeta) and ts_train_bn_bwd_sums finishes it, so the node returns dL/dv complete."""
 
     @staticmethod
-    def forward(ctx, x, dw_w, pw_w, gamma, beta, cfg):
+    def forward(ctx, x, dw_w, pw_w, gamma, beta, gamma_in, beta_in, cfg):
         L = _lib.lib()
         x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
         b, c_in, t_in = x.shape
-        st_, code, bf = _s(x), _code(x), x.dtype == torch.bfloat16
+        st_, code = _s(x), _code(x)
+        lazy = cfg.lazy_in
         if dw_w is not None:
             w_dw = dw_w.detach().to(torch.float32).contiguous().view(dw_w.shape[0], -1)
             t_out = (t_in + 2 * cfg.pad - cfg.dil * (cfg.k - 1) - 1) // cfg.stride + 1
             mid = alloc(b, c_in, t_out, x.device, x.dtype)
-            _lib.check(L.ts_train_dwconv_fwd(x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), mid.data_ptr(), b, c_in,
-                                             t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(mid), code, st_), "ts_train_dwconv_fwd")
+            if lazy is not None:
+                g_in, b_in = gamma_in.detach().to(torch.float32).contiguous(), beta_in.detach().to(torch.float32).contiguous()
+                in_mr = torch.empty(c_in, 2, dtype=torch.float32, device=x.device)
+                sums, relu_in, eps_in, run_in = lazy
+                rm_i, rv_i, mom_i, nbt_i = run_in if run_in is not None else (None, None, 0.0, None)
+                _lib.check(L.ts_train_dwconv_fwd_bn(x.data_ptr(), sums.data_ptr(), g_in.data_ptr(), b_in.data_ptr(), float(eps_in), int(relu_in),
+                                                    in_mr.data_ptr(), rm_i.data_ptr() if rm_i is not None else None,
+                                                    rv_i.data_ptr() if rv_i is not None else None, float(mom_i),
+                                                    nbt_i.data_ptr() if nbt_i is not None else None,
+                                                    cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), mid.data_ptr(), b, c_in, t_in,
+                                                    cfg.k, cfg.pad, _pitch(x), code, st_), "ts_train_dwconv_fwd_bn")
+            else:
+                g_in = b_in = in_mr = None
+                _lib.check(L.ts_train_dwconv_fwd(x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), mid.data_ptr(), b, c_in,
+                                                 t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(mid), code, st_), "ts_train_dwconv_fwd")
         else:
-            w_dw, t_out = None, t_in
+            if lazy is not None:
+                raise RuntimeError("SubBlock: a folded BatchNorm input needs a depthwise convolution")
+            w_dw, t_out, g_in, b_in, in_mr = None, t_in, None, None, None
             mid = alloc_like(x)
             _lib.check(L.ts_train_mask_time(x.data_ptr(), cfg.len_in.data_ptr(), mid.data_ptr(), b, c_in, t_in, _pitch(x), _pitch(mid), code, st_),
                        "ts_train_mask_time")
@@ -650,63 +687,89 @@ class SubBlock(torch.autograd.Function):
         v = _pw_fwd(mid, pw_w, w_pw)
         ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
         g, be = gamma.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
-        y = alloc_like(v)
         mr = torch.empty(c_out, 2, dtype=torch.float32, device=x.device)
         rm, rv, mom, nbt = cfg.running if cfg.running is not None else (None, None, 0.0, None)
-        _lib.check(L.ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c_out, t_out, _pitch(v),
-                                     float(cfg.eps), int(cfg.relu), rm.data_ptr() if rm is not None else None,
-                                     rv.data_ptr() if rv is not None else None, float(mom), nbt.data_ptr() if nbt is not None else None, code, st_),
-                   "ts_train_bn_fwd")
-        out = y
-        if cfg.drop_p > 0.0:
-            out = alloc_like(y)
-            _lib.check(L.ts_train_dropout(y.data_ptr(), out.data_ptr(), b * c_out, t_out, _pitch(y), float(cfg.drop_p), int(cfg.drop_seed), _nonce(x), code, st_),
-                       "ts_train_dropout")
-        ctx.save_for_backward(x, mid, v, y, g, mr, *([w_dw] if w_dw is not None else []))
-        ctx.cfg, ctx.params = cfg, (dw_w, pw_w, gamma, beta)
+        if cfg.lazy_out:
+            _lib.check(L.ts_train_bn_stats(v.data_ptr(), ws.data_ptr(), b, c_out, t_out, _pitch(v), code, st_), "ts_train_bn_stats")
+            cfg.out_sums = ws
+            y, out = None, v
+        else:
+            y = alloc_like(v)
+            _lib.check(L.ts_train_bn_fwd(v.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), mr.data_ptr(), ws.data_ptr(), b, c_out, t_out, _pitch(v),
+                                         float(cfg.eps), int(cfg.relu), rm.data_ptr() if rm is not None else None,
+                                         rv.data_ptr() if rv is not None else None, float(mom), nbt.data_ptr() if nbt is not None else None, code, st_),
+                       "ts_train_bn_fwd")
+            out = y
+            if cfg.drop_p > 0.0:
+                out = alloc_like(y)
+                _lib.check(L.ts_train_dropout(y.data_ptr(), out.data_ptr(), b * c_out, t_out, _pitch(y), float(cfg.drop_p), int(cfg.drop_seed), _nonce(x), code, st_),
+                           "ts_train_dropout")
+        saved = [x, mid, v, g, mr] + ([y] if y is not None else []) + ([w_dw] if w_dw is not None else []) + ([in_mr, g_in, b_in] if lazy is not None else [])
+        ctx.save_for_backward(*saved)
+        ctx.cfg, ctx.params = cfg, (dw_w, pw_w, gamma, beta, gamma_in, beta_in)
         ctx.shapes = (None if dw_w is None else dw_w.shape, pw_w.shape)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        saved = ctx.saved_tensors
-        x, mid, v, y, g, mr = saved[:6]
-        w_dw = saved[6] if len(saved) > 6 else None
+        saved = list(ctx.saved_tensors)
         cfg = ctx.cfg
-        dw_p, pw_p, ga_p, be_p = ctx.params
+        x, mid, v, g, mr = saved[:5]
+        rest = saved[5:]
+        y = rest.pop(0) if not cfg.lazy_out else None
+        dw_p, pw_p, ga_p, be_p, gin_p, bin_p = ctx.params
+        w_dw = rest.pop(0) if dw_p is not None else None
+        in_mr, g_in, b_in = rest if cfg.lazy_in is not None else (None, None, None)
         b, c_in, t_in = x.shape
         c_out, t_out = v.shape[1], v.shape[2]
-        st_, code, bf = _s(x), _code(x), x.dtype == torch.bfloat16
-        dy = _g(dy, y)
-        if cfg.drop_p > 0.0:
-            d2 = alloc_like(dy)
-            _lib.check(L.ts_train_dropout(dy.data_ptr(), d2.data_ptr(), b * c_out, t_out, _pitch(dy), float(cfg.drop_p), int(cfg.drop_seed), _nonce(x), code, st_),
-                       "ts_train_dropout")
-            dy = d2
-        dv = alloc_like(v)
-        dg, db = grad_out(ga_p, (c_out,)), grad_out(be_p, (c_out,))
-        ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
-        _lib.check(L.ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                     ws.data_ptr(), b, c_out, t_out, _pitch(v), int(cfg.relu), code, st_), "ts_train_bn_bwd")
+        st_, code = _s(x), _code(x)
+        if cfg.lazy_out:
+            dv, dg, db = _g(dy, v), None, None          # the next repeat already took this BatchNorm's backward: dy IS dL/dv
+        else:
+            dy = _g(dy, y)
+            if cfg.drop_p > 0.0:
+                d2 = alloc_like(dy)
+                _lib.check(L.ts_train_dropout(dy.data_ptr(), d2.data_ptr(), b * c_out, t_out, _pitch(dy), float(cfg.drop_p), int(cfg.drop_seed), _nonce(x), code, st_),
+                           "ts_train_dropout")
+                dy = d2
+            dv = alloc_like(v)
+            dg, db = grad_out(ga_p, (c_out,)), grad_out(be_p, (c_out,))
+            ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
+            _lib.check(L.ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                         ws.data_ptr(), b, c_out, t_out, _pitch(v), int(cfg.relu), code, st_), "ts_train_bn_bwd")
         dmid, dpw = _pw_bwd(dv, mid, pw_p, pw_p.detach().to(torch.float32).contiguous().view(pw_p.shape[0], -1))
         dx = alloc_like(x)
+        dg_in = db_in = None
         if w_dw is not None:
             ddw = grad_out(dw_p, w_dw.shape, zeroed=True)
-            _lib.check(L.ts_train_dwconv_bwd(dmid.data_ptr(), x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), dx.data_ptr(),
-                                             ddw.data_ptr(), b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(dmid), code, st_),
-                       "ts_train_dwconv_bwd")
+            if cfg.lazy_in is not None:
+                gbuf = alloc_like(x)
+                dg_in, db_in = grad_out(gin_p, (c_in,), zeroed=True), grad_out(bin_p, (c_in,), zeroed=True)
+                _lib.check(L.ts_train_dwconv_bwd_bn(dmid.data_ptr(), x.data_ptr(), in_mr.data_ptr(), g_in.data_ptr(), b_in.data_ptr(), int(cfg.lazy_in[1]),
+                                                    cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), gbuf.data_ptr(), ddw.data_ptr(),
+                                                    dg_in.data_ptr(), db_in.data_ptr(), b, c_in, t_in, cfg.k, cfg.pad, _pitch(x), code, st_),
+                           "ts_train_dwconv_bwd_bn")
+                _lib.check(L.ts_train_bn_bwd_sums(gbuf.data_ptr(), x.data_ptr(), g_in.data_ptr(), in_mr.data_ptr(), dg_in.data_ptr(), db_in.data_ptr(),
+                                                  dx.data_ptr(), b, c_in, t_in, _pitch(x), code, st_), "ts_train_bn_bwd_sums")
+            else:
+                _lib.check(L.ts_train_dwconv_bwd(dmid.data_ptr(), x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), dx.data_ptr(),
+                                                 ddw.data_ptr(), b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(dmid), code, st_),
+                           "ts_train_dwconv_bwd")
             ddw = ddw.view(ctx.shapes[0])
         else:
             ddw = None
             _lib.check(L.ts_train_mask_time(dmid.data_ptr(), cfg.len_in.data_ptr(), dx.data_ptr(), b, c_in, t_in, _pitch(dmid), _pitch(dx), code, st_),
                        "ts_train_mask_time")
-        return dx, ddw, dpw.view(ctx.shapes[1]), dg, db, None
+        return dx, ddw, dpw.view(ctx.shapes[1]), dg, db, dg_in, db_in, None
 
 
-def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Tensor, len_out: Tensor, relu: bool, drop_p: float = 0.0) -> Tensor:
+def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Tensor, len_out: Tensor, relu: bool, drop_p: float = 0.0,
+              lazy_out: bool = False) -> Tensor:
     """x -> [dropout](relu?(BN_train(pw(mask(dw(mask(x))))))): one repeat of a block.  dw_conv / pw_conv are the MaskedConv1d modules
-    (dw_conv None for a non-separable 1x1 repeat), len_in / len_out int32 device lengths before / after the depthwise conv."""
+    (dw_conv None for a non-separable 1x1 repeat), len_in / len_out int32 device lengths before / after the depthwise conv.
+    `lazy_out` (only between two repeats, see SubBlock): the result is the UN-normalised 1x1 output carrying its pending BatchNorm
+    (`._ts_lazy`); hand it to the next sub_block call and to nothing else."""
     cfg = SubBlockCfg()
     cfg.len_in, cfg.len_out = len_in, len_out
     if dw_conv is not None:
@@ -718,8 +781,19 @@ def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Ten
     if cfg.drop_p > 0.0:
         from .rng import next_seed
         cfg.drop_seed = next_seed()
-    y = SubBlock.apply(x, None if dw_conv is None else dw_conv.conv.weight, pw_conv.conv.weight, bn.weight, bn.bias, cfg)
-    _bump_running(bn, cfg.running)
+    pending = getattr(x, "_ts_lazy", None)              # (sums, relu, bn module, running buffers) of the previous repeat's BatchNorm
+    cfg.lazy_in = (pending[0], pending[1], pending[2].eps, pending[3]) if pending is not None else None
+    cfg.lazy_out, cfg.out_sums = bool(lazy_out) and cfg.drop_p == 0.0, None
+    if pending is not None and not same_depthwise(dw_conv):
+        raise RuntimeError("sub_block: the input carries a pending BatchNorm but this repeat cannot apply it")
+    gamma_in, beta_in = (pending[2].weight, pending[2].bias) if pending is not None else (None, None)
+    y = SubBlock.apply(x, None if dw_conv is None else dw_conv.conv.weight, pw_conv.conv.weight, bn.weight, bn.bias, gamma_in, beta_in, cfg)
+    if pending is not None:
+        _bump_running(pending[2], pending[3])           # this launch applied the previous BatchNorm's running-statistics update
+    if cfg.lazy_out:
+        y._ts_lazy = (cfg.out_sums, bool(relu), bn, cfg.running)
+    else:
+        _bump_running(bn, cfg.running)
     return y
 
 
