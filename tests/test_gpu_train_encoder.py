@@ -133,14 +133,17 @@ def test_bf16_activation_mode_stays_within_bf16_tolerance(golden, name):
 
 
 @pytest.mark.parametrize("act", ["fp32", "bf16"])
-@pytest.mark.parametrize("batch,ch,t,k", [(1, 2, 37, 5), (5, 6, 501, 33), (3, 4, 512, 75), (2, 2, 1100, 127), (33, 2, 64, 11), (2, 8, 1536, 39)])
-def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k):
+@pytest.mark.parametrize("batch,ch,t,k,dil", [(1, 2, 37, 5, 1), (5, 6, 501, 33, 1), (3, 4, 512, 75, 1), (2, 2, 1100, 127, 1), (33, 2, 64, 11, 1),
+                                               (2, 8, 1536, 39, 1), (3, 4, 501, 87, 2), (2, 3, 1100, 33, 2), (33, 2, 64, 11, 2), (1, 1, 37, 5, 2),
+                                               (2, 2, 2050, 127, 2)])
+def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k, dil):
     """The packed-FMA "same" depthwise kernels (one wavefront = two channel rows, csrc/train_enc.hip dw_fwd_pair / dw_bwd_pair)
     against F.conv1d(groups = C) + autograd on the masked input (quartznet/blocks.py:169-182): ragged lengths, several 512-frame
-    wave tiles, clip counts that leave waves idle.  fp32 rows: 2e-5 of the scale; bf16 rows: inputs are rounded once (so the
+    wave tiles, clip counts that leave waves idle; dilation 2 (the K87 block of QuartzNet) runs the same kernels in phase-split form
+    (a row = (even, odd) frame pairs; odd channel counts allowed).  fp32 rows: 2e-5 of the scale; bf16 rows: inputs are rounded once (so the
     reference sees the same values) and the outputs once more: 1 % of the scale."""
     from thunder_speech_amd import train_ops as T
-    g = torch.Generator().manual_seed(batch * 1000 + t + k)
+    g = torch.Generator().manual_seed(batch * 1000 + t + k + dil)
     x = torch.randn(batch, ch, t, generator=g)
     w = torch.randn(ch, 1, k, generator=g) / k ** 0.5
     cot = torch.randn(batch, ch, t, generator=g)
@@ -150,7 +153,7 @@ def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k)
         x, cot = x.bfloat16().float(), cot.bfloat16().float()
     mask = (torch.arange(t)[None, :] < lengths[:, None])[:, None, :]
     xr, wr = (x * mask).double().requires_grad_(True), w.double().requires_grad_(True)
-    yr = torch.nn.functional.conv1d(xr, wr, padding=(k - 1) // 2, groups=ch) * mask        # len_out = len_in: re-masked output
+    yr = torch.nn.functional.conv1d(xr, wr, padding=dil * (k - 1) // 2, dilation=dil, groups=ch) * mask        # len_out = len_in: re-masked output
     (yr * cot.double()).sum().backward()
 
     T.set_activation_dtype(act)
@@ -158,7 +161,7 @@ def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k)
         xg = x.cuda().requires_grad_(True)
         wg = w.cuda().requires_grad_(True)
         li = lengths.to(torch.int32).cuda()
-        y = T.DepthwiseConv.apply(T.to_act(xg), wg, li, k, 1, 1, (k - 1) // 2, li)
+        y = T.DepthwiseConv.apply(T.to_act(xg), wg, li, k, 1, dil, dil * (k - 1) // 2, li)
         assert y.dtype == (torch.bfloat16 if act == "bf16" else torch.float32)
         (T.from_act(y) * cot.cuda()).sum().backward()
     finally:

@@ -309,12 +309,21 @@ __device__ __forceinline__ void raw_get(const Raw8<bf16_t>& r, float (&v)[8]) {
 }
 template <class T> struct Staged { Raw8<T> a[2], b[2]; };
 
-template <class T>
+// PH (phase split, dilation-2 layers): the "pair" is ONE row seen as (even frame, odd frame) entries -- y[2s + ph] = sum_u w[u] x[2 (s + u)
+// + ph - pad] is a dilation-1 convolution of each phase with the same taps -- so entry e = frames (2e, 2e + 1): 8 entries = 16 consecutive
+// frames of the row (two raw loads), ra = the row, rb unused; a0, n, the FIR and the tiles count entries, `lim` stays in frames.
+template <class T, bool PH = false>
 __device__ __forceinline__ void stage_fetch(Staged<T>& st, const T* ra, const T* rb, int a0, int n, int lim, int lane) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int u = lane + 64 * it, i8 = a0 + 8 * u;
-    if (8 * u < n && i8 >= 0 && i8 < lim) { raw_load(st.a[it], ra + i8); raw_load(st.b[it], rb + i8); }
+    const int u = lane + 64 * it;
+    if (PH) {
+      const int i16 = 2 * a0 + 16 * u;
+      if (8 * u < n && i16 >= 0 && i16 < lim) { raw_load(st.a[it], ra + i16); if (i16 + 8 < lim) raw_load(st.b[it], ra + i16 + 8); }
+    } else {
+      const int i8 = a0 + 8 * u;
+      if (8 * u < n && i8 >= 0 && i8 < lim) { raw_load(st.a[it], ra + i8); raw_load(st.b[it], rb + i8); }
+    }
   }
 }
 // Input transform of the rows being staged: the BatchNorm(train) [+ ReLU] of the PREVIOUS repeat, y = relu?(v * scale + shift), applied on
@@ -372,13 +381,34 @@ __device__ __forceinline__ RowAffine row_affine(const PairBnIn& p, int c, int ch
   return r;
 }
 
-template <class T>
+template <class T, bool PH = false>
 __device__ __forceinline__ void stage_write(const Staged<T>& st, v2f* dst, int q, int a0, int n, int lim, int lane,
                                             const RowAffine af = RowAffine{1.f, 0.f, 1.f, 0.f, false, false}) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int u = lane + 64 * it, i8 = a0 + 8 * u;
     if (8 * u >= n) continue;
+    if (PH) {
+      const int i16 = 2 * a0 + 16 * u;
+      float f[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) f[m] = 0.f;
+      if (i16 >= 0 && i16 < lim) {
+        float lo[8], hi[8];
+        raw_get(st.a[it], lo);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = i16 + m < lim ? lo[m] : 0.f;
+        if (i16 + 8 < lim) {
+          raw_get(st.b[it], hi);
+#pragma unroll
+          for (int m = 0; m < 8; ++m) f[8 + m] = i16 + 8 + m < lim ? hi[m] : 0.f;
+        }
+      }
+      v2f* const d = dst + 2 * u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<v2fx2*>(d + r * q) = v2fx2{v2f{f[4 * r], f[4 * r + 1]}, v2f{f[4 * r + 2], f[4 * r + 3]}};
+      continue;
+    }
     float a[8], b[8];
     if (i8 >= 0 && i8 < lim) {
       raw_get(st.a[it], a); raw_get(st.b[it], b);
@@ -450,13 +480,26 @@ __device__ __forceinline__ void store_pair(bf16_t* ra, bf16_t* rb, const v2f (&a
   store8(ra + t, a); store8(rb + t, b);
 }
 
+// PH: entries te .. te + 7 of one row = frames 2 te .. 2 te + 15
+template <class T>
+__device__ __forceinline__ void store_phase(T* row, const v2f (&acc)[8], int te, int lim) {
+  float a[8], b[8];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    a[2 * m] = 2 * te + 2 * m < lim ? acc[m][0] : 0.f;             a[2 * m + 1] = 2 * te + 2 * m + 1 < lim ? acc[m][1] : 0.f;
+    b[2 * m] = 2 * te + 8 + 2 * m < lim ? acc[4 + m][0] : 0.f;     b[2 * m + 1] = 2 * te + 9 + 2 * m < lim ? acc[4 + m][1] : 0.f;
+  }
+  store8(row + 2 * te, a); store8(row + 2 * te + 8, b);
+}
+
 __host__ __device__ constexpr int pair_xl(int k8) { return PT + k8 + 16; }                       // staged x samples per tile
 constexpr int PAIR_TAPS = DW_KMAX + 16;                                                          // float2 tap slots per wave (k + 7 rounded up to 8)
 __host__ __device__ constexpr int pair_gl(int k, int p) { return round_up(p, 8) + PT + round_up(k + round_up(p, 8) - p, 8) + 16; }
 
 // forward: y[r, t] = sum_j w[c, j] xm[r, t + j - p].  A wave walks over `pairs_per_wave` consecutive row pairs (times the 512-frame
 // tiles of a row): while one pair is filtered out of LDS, the rows of the next are already on their way from HBM.
-template <class T>
+// PH: one wave item = ONE row of a dilation-2 layer as (even, odd) phases; `p` = padding / 2, tiles and FIR in entries (2 frames).
+template <class T, bool PH = false>
 __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ x, const int* __restrict__ len_in, const int* __restrict__ len_out,
                                                           const float* __restrict__ w, T* __restrict__ y, int batch, int ch, int t, int k, int p,
                                                           int pitch, int pairs_per_wave, PairBnIn aff) {
@@ -466,34 +509,38 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
   const int k8 = round_up(k + sh, 8), xl = pair_xl(round_up(k + 7, 8)), q = xl >> 2;
   v2f* const xs = sm2 + wave * (xl + PAIR_TAPS);
   v2f* const tp = xs + xl;                                 // this wave's taps, shifted by sh and zero-padded
-  const long long n_pairs = (long long)batch * ch / 2;
+  constexpr int RPI = PH ? 1 : 2;                          // rows per item
+  const int te = PH ? (t + 1) / 2 : t;                     // length in entries
+  const long long n_pairs = (long long)batch * ch / RPI;
   const long long rp0 = ((long long)blockIdx.x * 4 + wave) * pairs_per_wave;
   if (rp0 >= n_pairs) return;
   const int np = rp0 + pairs_per_wave <= n_pairs ? pairs_per_wave : (int)(n_pairs - rp0);
-  const int n_tiles = (t + PT - 1) / PT, items = np * n_tiles;
+  const int n_tiles = (te + PT - 1) / PT, items = np * n_tiles;
   Staged<T> st;
   auto fetch = [&](int it) {
     const long long rp = rp0 + it / n_tiles;
-    const int b = (int)(rp * 2 / ch), t0 = (it % n_tiles) * PT;
-    const T* const xa = x + (size_t)rp * 2 * pitch;
-    stage_fetch(st, xa, xa + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
+    const int b = (int)(rp * RPI / ch), t0 = (it % n_tiles) * PT;
+    const T* const xa = x + (size_t)rp * RPI * pitch;
+    stage_fetch<T, PH>(st, xa, xa + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
   };
   fetch(0);
   for (int it = 0; it < items; ++it) {
     const long long rp = rp0 + it / n_tiles;
-    const int b = (int)(rp * 2 / ch), c = (int)(rp * 2 % ch), t0 = (it % n_tiles) * PT;
+    const int b = (int)(rp * RPI / ch), c = (int)(rp * RPI % ch), t0 = (it % n_tiles) * PT;
     const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
-    stage_write(st, xs, q, t0 - p - sh, xl, li, lane, row_affine(aff, c, ch, b == 0 && t0 == 0 && lane == 0));
+    if (PH) stage_write<T, true>(st, xs, q, t0 - p - sh, xl, li, lane);
+    else stage_write<T, false>(st, xs, q, t0 - p - sh, xl, li, lane, row_affine(aff, c, ch, b == 0 && t0 == 0 && lane == 0));
     // y[t0 + tt] = sum_j' w'[j'] xs[tt + j'],  xs[e] = xm[t0 - p - sh + e],  w'[j'] = w[j' - sh]
     if (it % n_tiles == 0) {
       const float* const wa = w + (size_t)c * k;
-      for (int j = lane; j < k8; j += 64) { const int jj = j - sh; tp[j] = (jj >= 0 && jj < k) ? v2f{wa[jj], wa[k + jj]} : v2f{0.f, 0.f}; }
+      const int wb = PH ? 0 : k;                           // phase split: both components use the row's own taps
+      for (int j = lane; j < k8; j += 64) { const int jj = j - sh; tp[j] = (jj >= 0 && jj < k) ? v2f{wa[jj], wa[wb + jj]} : v2f{0.f, 0.f}; }
     }
     if (it + 1 < items) fetch(it + 1);
     __builtin_amdgcn_wave_barrier();
-    T* const ya = y + (size_t)rp * 2 * pitch;
+    T* const ya = y + (size_t)rp * RPI * pitch;
     const int t8 = 8 * lane;
-    if (t0 + t8 < t) {
+    if (t0 + t8 < te) {
       v2f acc[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
@@ -502,7 +549,7 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
 #else
       acc[0] = xs[lane];
 #endif
-      store_pair(ya, ya + pitch, acc, t0 + t8, lo);
+      if (PH) store_phase(ya, acc, t0 + t8, lo); else store_pair(ya, ya + pitch, acc, t0 + t8, lo);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -514,7 +561,7 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
 // Workgroup = one channel pair x (4 waves x clips_per_wave clips); lane = (tap group of 8, frame slice) for the weight part,
 // partial sums stay in registers over the wave's clips, are combined across the workgroup in LDS and leave as one atomicAdd per
 // (channel, tap): dw ACCUMULATES (the caller hands in zeros for a plain gradient).
-template <class T>
+template <class T, bool PH = false>
 __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ dy, const T* __restrict__ x, const int* __restrict__ len_in,
                                                           const int* __restrict__ len_out, const float* __restrict__ w, T* __restrict__ dx,
                                                           float* __restrict__ dw, int batch, int ch, int t, int k, int p, int pitch,
@@ -528,10 +575,12 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
   v2f* const xs = sm2 + wave * (xl + gl + PAIR_TAPS);
   v2f* const gs = xs + xl;
   v2f* const tp = gs + gl;                                 // this wave's taps, flipped, padded by fpad zeros in front
-  const int c = 2 * blockIdx.x;
+  const int c = PH ? blockIdx.x : 2 * blockIdx.x;          // PH: one row per workgroup column, entries = (even, odd) frames, p = padding / 2
+  const int te = PH ? (t + 1) / 2 : t;
   {
     const float* const wa = w + (size_t)c * k;
-    for (int j = lane; j < kf8; j += 64) { const int jj = j - fpad; tp[j] = (jj >= 0 && jj < k) ? v2f{wa[k - 1 - jj], wa[2 * k - 1 - jj]} : v2f{0.f, 0.f}; }
+    const int wb = PH ? 0 : k;
+    for (int j = lane; j < kf8; j += 64) { const int jj = j - fpad; tp[j] = (jj >= 0 && jj < k) ? v2f{wa[k - 1 - jj], wa[wb + k - 1 - jj]} : v2f{0.f, 0.f}; }
   }
   const int ng = k8 >> 3, nq = 64 / ng, g = lane % ng, sl = lane / ng;
   const bool active = sl < nq;
@@ -547,13 +596,13 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
   v2f s1 = v2f{0.f, 0.f}, s2 = v2f{0.f, 0.f};
   const int b_lo = (blockIdx.y * 4 + wave) * clips_per_wave;
   const int nb = b_lo >= batch ? 0 : (b_lo + clips_per_wave <= batch ? clips_per_wave : batch - b_lo);
-  const int n_tiles = (t + PT - 1) / PT, items = nb * n_tiles;
+  const int n_tiles = (te + PT - 1) / PT, items = nb * n_tiles;
   Staged<T> sx, sg;
   auto fetch = [&](int it) {
     const int b = b_lo + it / n_tiles, t0 = (it % n_tiles) * PT;
     const size_t r0 = ((size_t)b * ch + c) * pitch;
-    stage_fetch(sx, x + r0, x + r0 + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
-    stage_fetch(sg, dy + r0, dy + r0 + pitch, t0 - o, gl, len_out ? clamp_len(len_out, b, t) : t, lane);
+    stage_fetch<T, PH>(sx, x + r0, x + r0 + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
+    stage_fetch<T, PH>(sg, dy + r0, dy + r0 + pitch, t0 - o, gl, len_out ? clamp_len(len_out, b, t) : t, lane);
   };
   if (items > 0) fetch(0);
   for (int it = 0; it < items; ++it) {
@@ -561,11 +610,11 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
     const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
     const size_t r0 = ((size_t)b * ch + c) * pitch;
     {
-      stage_write(sx, xs, qx, t0 - p - sh, xl, li, lane, af);
-      stage_write(sg, gs, qg, t0 - o, gl, lo, lane);
+      stage_write<T, PH>(sx, xs, qx, t0 - p - sh, xl, li, lane, af);
+      stage_write<T, PH>(sg, gs, qg, t0 - o, gl, lo, lane);
       if (it + 1 < items) fetch(it + 1);                   // the next clip's rows travel while this one is filtered
       __builtin_amdgcn_wave_barrier();
-      const int nt = t - t0 < PT ? t - t0 : PT;
+      const int nt = te - t0 < PT ? te - t0 : PT;
       const int i8 = 8 * lane;
 #ifndef DWV_NO_DX
       if (i8 < nt) {
@@ -573,7 +622,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
         fir_pair(gs + ((i8 >> 3) << 1), qg, 0, kf8, tp, acc);
-        if (af.on && t0 + i8 < li) {
+        if (!PH && af.on && t0 + i8 < li) {
           float va[8], vb[8];
           load8(x + r0 + t0 + i8, va); load8(x + r0 + pitch + t0 + i8, vb);
 #pragma unroll
@@ -586,7 +635,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
             s2 += v2f{ga != 0.f ? ga * (va[m] - mu_a) * rs_a : 0.f, gb != 0.f ? gb * (vb[m] - mu_b) * rs_b : 0.f};   // pitch padding may hold NaN bits
           }
         }
-        store_pair(dx + r0, dx + r0 + pitch, acc, t0 + i8, li);
+        if (PH) store_phase(dx + r0, acc, t0 + i8, li); else store_pair(dx + r0, dx + r0 + pitch, acc, t0 + i8, li);
       }
 #endif
 #ifndef DWV_NO_DW
@@ -618,11 +667,14 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) red[(threadIdx.x) * 8 + jj] = active ? part[jj] : v2f{0.f, 0.f};
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * k; idx += 256) {
+  for (int idx = threadIdx.x; idx < (PH ? k : 2 * k); idx += 256) {
     const int sel = idx / k, j = idx % k, gj = (j + sh) >> 3, jj = (j + sh) & 7;      // register jj of tap group gj holds tap 8 gj + jj - sh
     float tot = 0.f;
     for (int wv = 0; wv < 4; ++wv)
-      for (int r = 0; r < nq; ++r) tot += red[((wv * 64) + r * ng + gj) * 8 + jj][sel];
+      for (int r = 0; r < nq; ++r) {
+        const v2f e = red[((wv * 64) + r * ng + gj) * 8 + jj];
+        tot += PH ? e[0] + e[1] : e[sel];                  // phase split: both phases of the row feed the same tap
+      }
     atomicAdd(dw + (size_t)(c + sel) * k + j, tot);
   }
   if (af.on) {
@@ -882,6 +934,11 @@ static bool pair_geometry(int ch, int t_in, int t_out, int k, int stride, int di
   return stride == 1 && dil == 1 && (k & 1) && pad == (k - 1) / 2 && t_in == t_out && (ch & 1) == 0 && pitch_in == pitch_out && k <= DW_KMAX;
 }
 
+// dilation-2 "same" layers (QuartzNet's K87 block): the pair kernels in phase-split form
+static bool phase_geometry(int t_in, int t_out, int k, int stride, int dil, int pad, int pitch_in, int pitch_out) {
+  return stride == 1 && dil == 2 && (k & 1) && pad == k - 1 && (pad & 1) == 0 && t_in == t_out && pitch_in == pitch_out && k <= DW_KMAX;
+}
+
 #define TS_ACT(act, expr_f32, expr_bf16) do { if (act) { expr_bf16; } else { expr_f32; } } while (0)
 
 static int dwconv_fwd_impl(const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
@@ -903,6 +960,18 @@ static int dwconv_fwd_impl(const void* x, const int32_t* len_in, const int32_t* 
                               t_in, k, pad, pitch_in, ppw, aff),
            hipLaunchKernelGGL(dw_fwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)x, len_in, len_out, w, (bf16_t*)y, batch,
                               ch, t_in, k, pad, pitch_in, ppw, aff));
+    return hip_status(hipGetLastError());
+  }
+  if (phase_geometry(t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
+    const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + PAIR_TAPS) * sizeof(v2f);
+    const long long n_rows = (long long)batch * ch;
+    const int ppw = n_rows >= 32LL * cu_count() ? 2 : 1;
+    const dim3 grid2((unsigned)((n_rows + 4 * ppw - 1) / (4 * ppw)));
+    TS_ACT(act,
+           { hipLaunchKernelGGL((dw_fwd_pair_kernel<float, true>), grid2, dim3(256), lds2, stream, (const float*)x, len_in, len_out, w, (float*)y, batch, ch,
+                               t_in, k, pad / 2, pitch_in, ppw, aff); },
+           { hipLaunchKernelGGL((dw_fwd_pair_kernel<bf16_t, true>), grid2, dim3(256), lds2, stream, (const bf16_t*)x, len_in, len_out, w, (bf16_t*)y, batch,
+                               ch, t_in, k, pad / 2, pitch_in, ppw, aff); });
     return hip_status(hipGetLastError());
   }
   const size_t lds = (DW_KMAX + (size_t)(DW_TILE - 1) * stride + (size_t)(k - 1) * dil + 1 + 32) * sizeof(float);
@@ -953,6 +1022,17 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
                               (float*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta),
            hipLaunchKernelGGL(dw_bwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, w,
                               (bf16_t*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta));
+    return hip_status(hipGetLastError());
+  }
+  if (phase_geometry(t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
+    const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + pair_gl(k, pad / 2) + PAIR_TAPS) * sizeof(v2f);
+    const int cpw = batch >= 16 ? (batch + 15) / 16 : 1;
+    const dim3 grid2(ch, (batch + 4 * cpw - 1) / (4 * cpw));
+    TS_ACT(act,
+           { hipLaunchKernelGGL((dw_bwd_pair_kernel<float, true>), grid2, dim3(256), lds2, stream, (const float*)dy, (const float*)x, len_in, len_out, w,
+                               (float*)dx, dw, batch, ch, t_in, k, pad / 2, pitch_in, cpw, aff, in_dgamma, in_dbeta); },
+           { hipLaunchKernelGGL((dw_bwd_pair_kernel<bf16_t, true>), grid2, dim3(256), lds2, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, w,
+                               (bf16_t*)dx, dw, batch, ch, t_in, k, pad / 2, pitch_in, cpw, aff, in_dgamma, in_dbeta); });
     return hip_status(hipGetLastError());
   }
   const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 48) * sizeof(float);
