@@ -249,6 +249,14 @@ int ts_train_dwconv_bwd_bn(const void* dy, const void* v, const float* in_mean_r
                            int32_t in_relu, const int32_t* len_in, const int32_t* len_out, const float* w, void* g, float* dw,
                            float* in_dgamma, float* in_dbeta, int32_t batch, int32_t channels, int32_t t, int32_t kernel, int32_t padding,
                            int32_t pitch, int32_t act, void* stream);
+/* Block tail (quartznet/blocks.py:332-337): out = relu(BatchNorm(va) + BatchNorm(vb)), main and residual branch, from the clip-group
+ * sums of both (ts_train_bn_stats) in one pass; publishes both mean_rstd, applies both running-statistics updates.  Backward: two
+ * ts_train_bn_bwd calls with dy = d out, y = out, relu = 1 (the gate of the shared ReLU). */
+int ts_train_bn2_add_relu_fwd(const void* va, const void* sums_a, const float* gamma_a, const float* beta_a, float eps_a, float* mean_rstd_a,
+                              float* running_mean_a, float* running_var_a, float momentum_a, int64_t* num_batches_tracked_a,
+                              const void* vb, const void* sums_b, const float* gamma_b, const float* beta_b, float eps_b, float* mean_rstd_b,
+                              float* running_mean_b, float* running_var_b, float momentum_b, int64_t* num_batches_tracked_b,
+                              void* out, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_bn_bwd_sums(const void* g, const void* v, const float* gamma, const float* mean_rstd, const float* dgamma, const float* dbeta,
                          void* dv, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_mask_time(const void* x, const int32_t* len, void* y, int32_t batch, int32_t channels, int32_t t, int32_t pitch_x,

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "ts_decoder_bwd", "ts_adamw_step", "ts_adamw_multi_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_workspace", "ts_train_pwconv_wgrad_mfma",
     "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
-    "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums",
+    "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd",
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
     "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_attention_workspace_bytes",
     "ts_w2v_attention_fwd",
@@ -147,6 +147,7 @@ def lib() -> C.CDLL:
     L.ts_train_dwconv_fwd_bn.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_dwconv_bwd_bn.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_bn_bwd_sums.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.ts_train_bn2_add_relu_fwd.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, f32, vp] * 2 + [vp, i32, i32, i32, i32, i32, vp]
     L.ts_train_pack_pw_multi.argtypes = [vp, i32, i64, vp]
     L.ts_train_pwconv_wgrad_workspace.argtypes = [i32, i32, i32]
     L.ts_train_pwconv_wgrad_workspace.restype = C.c_int64
@@ -163,7 +164,7 @@ def lib() -> C.CDLL:
     L.ts_counter_add.argtypes = [vp, u64, vp]
     L.ts_train_add.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
     for fn in ("ts_train_act_import", "ts_train_act_export", "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time",
-               "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_mfma", "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd",
+               "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_mfma", "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd",
                "ts_train_add_relu_fwd", "ts_train_relu_bwd", "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale",
                "ts_train_se_rowdot", "ts_train_dropout", "ts_counter_add", "ts_train_add"):
         getattr(L, fn).restype = C.c_int

@@ -802,6 +802,52 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const T* __restrict__ v, co
   store8(y + (size_t)row * pitch + i, x);
 }
 
+// Block tail (quartznet/blocks.py:332-337): out = relu(BatchNorm(v_a) + BatchNorm(v_b)) -- main branch and residual branch -- from the
+// clip-group sums of both in ONE pass (instead of two BatchNorm apply passes and an add + ReLU pass); publishes both mean_rstd and
+// applies both running-statistics updates.
+struct BnSide {
+  const void* v; const double* part; const float* gamma; const float* beta; float eps;
+  float* mean_rstd; float* running_mean; float* running_var; float momentum; long long* nbt;
+};
+template <class T>
+__global__ __launch_bounds__(256) void bn2_add_relu_kernel(BnSide a, BnSide b, T* __restrict__ out, int batch, int ch, int t, int pitch) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x, c = row % ch;
+  if (threadIdx.x < 2) {
+    const BnSide& s = threadIdx.x == 0 ? a : b;
+    const double n = (double)batch * t;
+    double s1, s2;
+    bn_total(s.part, ch, c, s1, s2);
+    const double mu = s1 / n;
+    double var = s2 / n - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)s.eps));
+    const float sc = s.gamma[c] * rstd;
+    sh[2 * threadIdx.x] = sc; sh[2 * threadIdx.x + 1] = s.beta[c] - (float)mu * sc;
+    if (row < ch && blockIdx.y == 0) {
+      s.mean_rstd[2 * c] = (float)mu; s.mean_rstd[2 * c + 1] = rstd;
+      if (s.running_mean) {
+        s.running_mean[c] = (1.f - s.momentum) * s.running_mean[c] + s.momentum * (float)mu;
+        s.running_var[c] = (1.f - s.momentum) * s.running_var[c] + s.momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+        if (c == 0 && s.nbt) *s.nbt += 1;
+      }
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
+  if (i >= t) return;
+  const float sa = sh[0], ha = sh[1] + sh[3], sb = sh[2];
+  float x[8], z[8];
+  load8(static_cast<const T*>(a.v) + (size_t)row * pitch + i, x);
+  load8(static_cast<const T*>(b.v) + (size_t)row * pitch + i, z);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float o = fmaf(x[j], sa, fmaf(z[j], sb, ha));
+    x[j] = o > 0.f ? o : 0.f;
+  }
+  store8(out + (size_t)row * pitch + i, x);
+}
+
 // dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (y > 0) when relu,  xhat = (v - mean) * rstd
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ v,
@@ -1082,6 +1128,27 @@ extern "C" int ts_train_bn_stats(const void* v, void* sums, int32_t batch, int32
                             (const float*)nullptr, part, batch, ch, t, pitch, 0),
          hipLaunchKernelGGL((chan_sums_kernel<0, bf16_t>), dim3(ch, BN_G), dim3(256), 0, stream, (const bf16_t*)v, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
                             (const float*)nullptr, part, batch, ch, t, pitch, 0));
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_bn2_add_relu_fwd(const void* va, const void* sums_a, const float* gamma_a, const float* beta_a, float eps_a,
+                                         float* mean_rstd_a, float* running_mean_a, float* running_var_a, float momentum_a, int64_t* nbt_a,
+                                         const void* vb, const void* sums_b, const float* gamma_b, const float* beta_b, float eps_b,
+                                         float* mean_rstd_b, float* running_mean_b, float* running_var_b, float momentum_b, int64_t* nbt_b,
+                                         void* out, int32_t batch, int32_t ch, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!va || !sums_a || !gamma_a || !beta_a || !mean_rstd_a || !vb || !sums_b || !gamma_b || !beta_b || !mean_rstd_b || !out) return TS_EINVAL;
+  if (batch <= 0 || ch <= 0 || t <= 0 || act < 0 || act > 1 || pitch < t) return TS_EINVAL;
+  if ((running_mean_a == nullptr) != (running_var_a == nullptr) || (running_mean_b == nullptr) != (running_var_b == nullptr)) return TS_EINVAL;
+  if (!rows_ok(va, pitch, act) || !rows_ok(vb, pitch, act) || !rows_ok(out, pitch, act)) return TS_EINVAL;
+  TS_STREAM;
+  const BnSide a{va, static_cast<const double*>(sums_a), gamma_a, beta_a, eps_a, mean_rstd_a, running_mean_a, running_var_a, momentum_a,
+                 reinterpret_cast<long long*>(nbt_a)};
+  const BnSide b{vb, static_cast<const double*>(sums_b), gamma_b, beta_b, eps_b, mean_rstd_b, running_mean_b, running_var_b, momentum_b,
+                 reinterpret_cast<long long*>(nbt_b)};
+  const dim3 rg = row_grid((long long)batch * ch, t);
+  TS_ACT(act,
+         hipLaunchKernelGGL(bn2_add_relu_kernel<float>, rg, dim3(256), 0, stream, a, b, (float*)out, batch, ch, t, pitch),
+         hipLaunchKernelGGL(bn2_add_relu_kernel<bf16_t>, rg, dim3(256), 0, stream, a, b, (bf16_t*)out, batch, ch, t, pitch));
   return hip_status(hipGetLastError());
 }
 

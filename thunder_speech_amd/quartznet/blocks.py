@@ -209,6 +209,9 @@ class _FusedBlockBase(nn.Module):
             x, x_res = T.Fork.apply(x)
         h, lh, out_lengths = x, len_in, lengths
         subs = list(self._sub_blocks())
+        # block tail relu(BN(main) + BN(residual)) in one pass: both branches then end un-normalised (train_ops.block_tail)
+        fuse_tail = (T._LAZY_BN and self.res is not None and self.res[0].stride == 1 and not self._has_se()
+                     and not (out_drop.training and out_drop.p > 0.0))
         for r, (dw, pw, bn) in enumerate(subs):
             last = r == len(subs) - 1
             if pw.kernel_size != 1 or pw.stride != 1:
@@ -221,7 +224,7 @@ class _FusedBlockBase(nn.Module):
             drop = drops[r] if (not last and r < len(drops)) else None
             drop_p = drop.p if (drop is not None and drop.training) else 0.0
             # between two repeats the BatchNorm (+ ReLU) is folded into the next repeat's depthwise launches (train_ops.SubBlock)
-            lazy = T._LAZY_BN and not last and drop_p == 0.0 and T.same_depthwise(subs[r + 1][0])
+            lazy = (fuse_tail and drop_p == 0.0) if last else (T._LAZY_BN and drop_p == 0.0 and T.same_depthwise(subs[r + 1][0]))
             h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop_p, lazy_out=lazy)
         if self._has_se():
             se = self.mconv[len(self.mconv) - 1].layer[0]          # citrinet/blocks.py:154: SE closes the main branch
@@ -233,8 +236,8 @@ class _FusedBlockBase(nn.Module):
                 r_in = T.SubsampleMask.apply(x_res, len_in, rc.stride, (x_res.shape[2] - 1) // rc.stride + 1)
                 r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(r_in, rc.conv.weight), relu=False)
             else:                    # mask -> 1x1 -> BatchNorm as one node, like a repeat without depthwise conv and ReLU
-                r_out = T.sub_block(x_res, None, rc, rbn, len_in, len_in, relu=False)
-        out = T.AddRelu.apply(h, r_out)
+                r_out = T.sub_block(x_res, None, rc, rbn, len_in, len_in, relu=False, lazy_out=fuse_tail)
+        out = T.block_tail(h, r_out) if (fuse_tail and getattr(h, "_ts_lazy", None) is not None) else T.AddRelu.apply(h, r_out)
         return T.dropout(out, out_drop.p, out_drop.training), out_lengths
 
     def _run_fused(self, x: torch.Tensor, lengths: torch.Tensor, internal: bool = False, slot=None):

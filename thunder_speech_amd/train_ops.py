@@ -797,6 +797,58 @@ def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Ten
     return y
 
 
+class BlockTail(torch.autograd.Function):
+    """out = relu(BatchNorm(v_main) + BatchNorm(v_res)) (quartznet/blocks.py:332-337) as ONE pass over the two un-normalised tensors
+    (both branches end in a `lazy_out` sub_block, which left their clip-group sums); backward = the two BatchNorm backwards with the
+    shared ReLU's gate taken from `out`."""
+
+    @staticmethod
+    def forward(ctx, va, gamma_a, beta_a, vb, gamma_b, beta_b, cfg):
+        L = _lib.lib()
+        b, c, t = va.shape
+        out = alloc_like(va)
+        ga, ba = gamma_a.detach().to(torch.float32).contiguous(), beta_a.detach().to(torch.float32).contiguous()
+        gb, bb = gamma_b.detach().to(torch.float32).contiguous(), beta_b.detach().to(torch.float32).contiguous()
+        mra, mrb = (torch.empty(c, 2, dtype=torch.float32, device=va.device) for _ in range(2))
+        args = []
+        for v, sums, g, be, eps, mr, run in ((va, cfg[0][0], ga, ba, cfg[0][1], mra, cfg[0][2]), (vb, cfg[1][0], gb, bb, cfg[1][1], mrb, cfg[1][2])):
+            rm, rv, mom, nbt = run if run is not None else (None, None, 0.0, None)
+            args += [v.data_ptr(), sums.data_ptr(), g.data_ptr(), be.data_ptr(), float(eps), mr.data_ptr(), rm.data_ptr() if rm is not None else None,
+                     rv.data_ptr() if rv is not None else None, float(mom), nbt.data_ptr() if nbt is not None else None]
+        _lib.check(L.ts_train_bn2_add_relu_fwd(*args, out.data_ptr(), b, c, t, _pitch(va), _code(va), _s(va)), "ts_train_bn2_add_relu_fwd")
+        ctx.save_for_backward(va, vb, out, ga, gb, mra, mrb)
+        ctx.params = (gamma_a, beta_a, gamma_b, beta_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        va, vb, out, ga, gb, mra, mrb = ctx.saved_tensors
+        b, c, t = va.shape
+        dout = _g(dout, out)
+        grads = []
+        for v, g, mr, (gp, bp) in ((va, ga, mra, ctx.params[:2]), (vb, gb, mrb, ctx.params[2:])):
+            dv = alloc_like(v)
+            dg, db = grad_out(gp, (c,)), grad_out(bp, (c,))
+            ws = torch.empty(16 * c, dtype=torch.float64, device=v.device)
+            _lib.check(L.ts_train_bn_bwd(dout.data_ptr(), out.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                         ws.data_ptr(), b, c, t, _pitch(v), 1, _code(v), _s(v)), "ts_train_bn_bwd")
+            grads += [dv, dg, db]
+        return (*grads, None)
+
+
+def block_tail(h: Tensor, r: Tensor) -> Tensor:
+    """relu(BN(h) + BN(r)) for two `lazy_out` sub_block results (main branch, residual branch)."""
+    ph, pr = getattr(h, "_ts_lazy", None), getattr(r, "_ts_lazy", None)
+    if ph is None or pr is None or ph[1] or pr[1]:
+        raise RuntimeError("block_tail: both inputs must carry a pending BatchNorm without ReLU")
+    cfg = ((ph[0], ph[2].eps, ph[3]), (pr[0], pr[2].eps, pr[3]))
+    out = BlockTail.apply(h, ph[2].weight, ph[2].bias, r, pr[2].weight, pr[2].bias, cfg)
+    _bump_running(ph[2], ph[3])
+    _bump_running(pr[2], pr[3])
+    return out
+
+
 def _running(bn: torch.nn.BatchNorm1d):
     if not (bn.track_running_stats and bn.running_mean is not None):
         return None
