@@ -295,9 +295,11 @@ int ts_train_bn_bwd(const void* dy, const void* y, const void* v, const float* g
                     int32_t relu, int32_t act, void* stream);
 int ts_train_add_relu_fwd(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_relu_bwd(const void* dout, const void* out, void* din, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
-/* out = a + b on activation rows: the sum of the two gradients that meet where a block input feeds both the main branch and the
- * residual branch (autograd's own accumulation would leave the row layout). */
-int ts_train_add(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+/* out = a + mask(b) on activation rows: the sum of the two gradients that meet where a block input feeds both the main branch and the
+ * residual branch (autograd's own accumulation would leave the row layout).  len_b (int32 [rows / channels], may be NULL): b counts
+ * only up to its clip's length -- the backward of the residual MaskedConv1d's input mask, folded into the sum. */
+int ts_train_add(const void* a, const void* b, const int32_t* len_b, int32_t channels, void* out, int64_t rows, int32_t t, int32_t pitch,
+                 int32_t act, void* stream);
 /* strided 1x1 MaskedConv1d (residual branch of a strided block: quartznet/blocks.py:301-311, citrinet/blocks.py:156-165) =
  * this mask + subsample pass followed by the pointwise GEMM.  backward = 0: y[b,c,j] = x[b,c,j*stride] if j*stride < len[b] else 0
  * (x rows of t_in, y rows of t_out); backward = 1: x is dy (t_out), y is dx (t_in), zero where the forward read nothing. */

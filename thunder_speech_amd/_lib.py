@@ -162,7 +162,7 @@ def lib() -> C.CDLL:
     L.ts_train_se_rowdot.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
     L.ts_train_dropout.argtypes = [vp, vp, i64, i32, i32, f32, u64, vp, i32, vp]
     L.ts_counter_add.argtypes = [vp, u64, vp]
-    L.ts_train_add.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_add.argtypes = [vp, vp, vp, i32, vp, i64, i32, i32, i32, vp]
     for fn in ("ts_train_act_import", "ts_train_act_export", "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time",
                "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_mfma", "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd",
                "ts_train_add_relu_fwd", "ts_train_relu_bwd", "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale",

@@ -694,18 +694,25 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
-// Row-wise streaming kernels: grid (rows = B * C, 2048-frame chunks), 256 threads x 8 elements (16 / 32 bytes per lane).
+// Row-wise streaming kernels: one WAVE = one (row, 512-frame chunk) unit, 64 lanes x 8 elements (16 / 32 bytes per lane), four
+// units per 256-thread workgroup (a 10 s clip is 501 frames: with one workgroup per row three of its four waves had nothing to do).
 // Rows are pitched and 16-byte aligned, so every access is a whole vector; columns >= t are scratch and may be overwritten.
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr int ROW_CHUNK = 2048;
+constexpr int ROW_CHUNK = 512;
+// defines `row`, `chunk`, `i` (first frame of this lane) and returns from the kernel when the unit lies outside the tensor
+#define TS_ROW_UNIT(n_rows)                                                                   \
+  const int _cpr = (t + ROW_CHUNK - 1) / ROW_CHUNK;                                           \
+  const long long _u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);                        \
+  const long long _r = _u / _cpr;                                                             \
+  const int row = (int)_r, chunk = (int)(_u % _cpr), i = chunk * ROW_CHUNK + (threadIdx.x & 63) * 8; \
+  if (_r >= (long long)(n_rows) || i >= t) return
 
 // y = x with frames >= len[b] zeroed (the re-masking in front of every MaskedConv1d, and of gradients on the way back)
 template <class T>
 __global__ __launch_bounds__(256) void mask_time_kernel(const T* __restrict__ x, const int* __restrict__ len, T* __restrict__ y,
-                                                        int ch, int t, int pitch_x, int pitch_y) {
-  const int row = blockIdx.x, b = row / ch;
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
+                                                        int batch, int ch, int t, int pitch_x, int pitch_y) {
+  TS_ROW_UNIT((long long)batch * ch);
+  const int b = row / ch;
   const int l = clamp_len(len, b, t);
   float v[8];
   load8(x + (size_t)row * pitch_x + i, v);
@@ -730,9 +737,9 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ a,
   float mu = 0.f, rs = 0.f;
   if (MODE == 1) { mu = mean_rstd[2 * c]; rs = mean_rstd[2 * c + 1]; }
   double s1 = 0.0, s2 = 0.0;
-  for (int b = b_lo; b < b_hi; ++b) {
+  for (int b = b_lo + (threadIdx.x >> 6); b < b_hi; b += 4) {          // one wave per clip row (a 10 s clip = 501 frames = 63 lanes x 8)
     const size_t row = ((size_t)b * ch + c) * pitch;
-    for (int i = threadIdx.x * 8; i < t; i += 2048) {
+    for (int i = (threadIdx.x & 63) * 8; i < t; i += 512) {
       float va[8], vy[8], vv[8];
       load8(a + row + i, va);
       if (MODE == 1) { load8(v + row + i, vv); if (relu) load8(y + row + i, vy); }
@@ -768,30 +775,28 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const T* __restrict__ v, co
                                                      float eps, int relu, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float momentum,
                                                      long long* __restrict__ num_batches_tracked, int ng) {
-  __shared__ float sh[2];
-  const int row = blockIdx.x, c = row % ch;
-  if (threadIdx.x == 0) {
+  TS_ROW_UNIT((long long)batch * ch);
+  const int c = row % ch;
+  float mu, sc;
+  {                                                        // every lane forms the channel's statistics (a few double operations)
     const double n = (double)batch * t;
     double s1, s2;
     bn_total(part, ch, c, s1, s2, ng);
-    const double mu = s1 / n;
-    double var = s2 / n - mu * mu;
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    sh[0] = (float)mu; sh[1] = rstd;
-    if (row < ch && blockIdx.y == 0) {                           // clip 0's workgroup of this channel publishes the statistics
-      mean_rstd[2 * c] = (float)mu; mean_rstd[2 * c + 1] = rstd;
+    mu = (float)m; sc = gamma[c] * rstd;
+    if (row < ch && chunk == 0 && (threadIdx.x & 63) == 0) {     // clip 0's wave of this channel publishes the statistics
+      mean_rstd[2 * c] = mu; mean_rstd[2 * c + 1] = rstd;
       if (running_mean) {    // nn.BatchNorm1d's update: momentum blend of the batch mean and the UNBIASED batch variance
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
         if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
       }
     }
   }
-  __syncthreads();
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
-  const float mu = sh[0], sc = gamma[c] * sh[1], be = beta[c];
+  const float be = beta[c];
   float x[8];
   load8(v + (size_t)row * pitch + i, x);
 #pragma unroll
@@ -811,10 +816,12 @@ struct BnSide {
 };
 template <class T>
 __global__ __launch_bounds__(256) void bn2_add_relu_kernel(BnSide a, BnSide b, T* __restrict__ out, int batch, int ch, int t, int pitch) {
-  __shared__ float sh[4];
-  const int row = blockIdx.x, c = row % ch;
-  if (threadIdx.x < 2) {
-    const BnSide& s = threadIdx.x == 0 ? a : b;
+  TS_ROW_UNIT((long long)batch * ch);
+  const int c = row % ch;
+  float scs[2], hs[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const BnSide& s = e == 0 ? a : b;
     const double n = (double)batch * t;
     double s1, s2;
     bn_total(s.part, ch, c, s1, s2);
@@ -822,9 +829,8 @@ __global__ __launch_bounds__(256) void bn2_add_relu_kernel(BnSide a, BnSide b, T
     double var = s2 / n - mu * mu;
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + (double)s.eps));
-    const float sc = s.gamma[c] * rstd;
-    sh[2 * threadIdx.x] = sc; sh[2 * threadIdx.x + 1] = s.beta[c] - (float)mu * sc;
-    if (row < ch && blockIdx.y == 0) {
+    scs[e] = s.gamma[c] * rstd; hs[e] = s.beta[c] - (float)mu * scs[e];
+    if (row < ch && chunk == 0 && (threadIdx.x & 63) == 0) {
       s.mean_rstd[2 * c] = (float)mu; s.mean_rstd[2 * c + 1] = rstd;
       if (s.running_mean) {
         s.running_mean[c] = (1.f - s.momentum) * s.running_mean[c] + s.momentum * (float)mu;
@@ -833,10 +839,7 @@ __global__ __launch_bounds__(256) void bn2_add_relu_kernel(BnSide a, BnSide b, T
       }
     }
   }
-  __syncthreads();
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
-  const float sa = sh[0], ha = sh[1] + sh[3], sb = sh[2];
+  const float sa = scs[0], ha = hs[0] + hs[1], sb = scs[1];
   float x[8], z[8];
   load8(static_cast<const T*>(a.v) + (size_t)row * pitch + i, x);
   load8(static_cast<const T*>(b.v) + (size_t)row * pitch + i, z);
@@ -855,19 +858,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean_rstd, T* __restrict__ dv,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int batch, int ch, int t,
                                                            int pitch, int relu) {
-  __shared__ float sh[2];
-  const int row = blockIdx.x, c = row % ch;
-  if (threadIdx.x == 0) {
+  TS_ROW_UNIT((long long)batch * ch);
+  const int c = row % ch;
+  float mg, mgx;
+  {
     const double n = (double)batch * t;
     double s1, s2;
     bn_total(part, ch, c, s1, s2);
-    sh[0] = (float)(s1 / n); sh[1] = (float)(s2 / n);
-    if (row < ch && blockIdx.y == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+    mg = (float)(s1 / n); mgx = (float)(s2 / n);
+    if (row < ch && chunk == 0 && (threadIdx.x & 63) == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
   }
-  __syncthreads();
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
-  const float mg = sh[0], mgx = sh[1], mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1], k = gamma[c] * rs;
+  const float mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1], k = gamma[c] * rs;
   const size_t base = (size_t)row * pitch + i;
   float g[8], vy[8], vv[8];
   load8(dy + base, g);
@@ -887,9 +888,8 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const T* __restrict__ g, const T* __restrict__ v, const float* __restrict__ gamma,
                                                           const float* __restrict__ mean_rstd, const float* __restrict__ dgamma,
                                                           const float* __restrict__ dbeta, T* __restrict__ dv, int batch, int ch, int t, int pitch) {
-  const int row = blockIdx.x, c = row % ch;
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
+  TS_ROW_UNIT((long long)batch * ch);
+  const int c = row % ch;
   const float inv_n = 1.f / ((float)batch * (float)t);
   const float mg = dbeta[c] * inv_n, mgx = dgamma[c] * inv_n, mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1], k = gamma[c] * rs;
   const size_t base = (size_t)row * pitch + i;
@@ -903,30 +903,35 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const T* __restrict__ 
 
 // out = relu(a + b) (RELU) or a + b; backward of the first: da = db = dout * (out > 0)
 template <class T, bool RELU>
-__device__ __forceinline__ void add_rows(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
-  const size_t base = (size_t)blockIdx.x * pitch + i;
+__device__ __forceinline__ void add_rows(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long rows, int t, int pitch,
+                                         const int* __restrict__ len_b = nullptr, int ch = 1) {
+  TS_ROW_UNIT(rows);
+  const size_t base = (size_t)row * pitch + i;
   float x[8], z[8];
   load8(a + base, x);
   if (b) load8(b + base, z);
+  if (len_b) {                                             // b counts only up to its clip's length (the mask of a MaskedConv1d input, backward)
+    const int l = clamp_len(len_b, row / ch, t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = i + j < l ? z[j] : 0.f;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { const float s = x[j] + (b ? z[j] : 0.f); x[j] = (!RELU || s > 0.f) ? s : 0.f; }
   store8(o + base, x);
 }
 template <class T>
-__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
-  add_rows<T, true>(a, b, o, t, pitch);
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long rows, int t, int pitch) {
+  add_rows<T, true>(a, b, o, rows, t, pitch);
 }
 template <class T>
-__global__ __launch_bounds__(256) void add_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int t, int pitch) {
-  add_rows<T, false>(a, b, o, t, pitch);
+__global__ __launch_bounds__(256) void add_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long rows, int t, int pitch,
+                                                      const int* __restrict__ len_b, int ch) {
+  add_rows<T, false>(a, b, o, rows, t, pitch, len_b, ch);
 }
 template <class T>
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ din, int t, int pitch) {
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
-  const size_t base = (size_t)blockIdx.x * pitch + i;
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ din, long long rows, int t, int pitch) {
+  TS_ROW_UNIT(rows);
+  const size_t base = (size_t)row * pitch + i;
   float g[8], o[8];
   load8(dout + base, g);
   load8(out + base, o);
@@ -946,26 +951,24 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
 
 // reference-layout f32 [rows][t] (contiguous) <-> pitched activation rows of either type: the boundary of the training path
 template <class T>
-__global__ __launch_bounds__(256) void act_import_kernel(const float* __restrict__ src, T* __restrict__ dst, int t, int pitch) {
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
+__global__ __launch_bounds__(256) void act_import_kernel(const float* __restrict__ src, T* __restrict__ dst, long long rows, int t, int pitch) {
+  TS_ROW_UNIT(rows);
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = i + j < t ? src[(size_t)blockIdx.x * t + i + j] : 0.f;
-  store8(dst + (size_t)blockIdx.x * pitch + i, v);
+  for (int j = 0; j < 8; ++j) v[j] = i + j < t ? src[(size_t)row * t + i + j] : 0.f;
+  store8(dst + (size_t)row * pitch + i, v);
 }
 template <class T>
-__global__ __launch_bounds__(256) void act_export_kernel(const T* __restrict__ src, float* __restrict__ dst, int t, int pitch) {
-  const int i = blockIdx.y * ROW_CHUNK + threadIdx.x * 8;
-  if (i >= t) return;
+__global__ __launch_bounds__(256) void act_export_kernel(const T* __restrict__ src, float* __restrict__ dst, long long rows, int t, int pitch) {
+  TS_ROW_UNIT(rows);
   float v[8];
-  load8(src + (size_t)blockIdx.x * pitch + i, v);
+  load8(src + (size_t)row * pitch + i, v);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) if (i + j < t) dst[(size_t)blockIdx.x * t + i + j] = v[j];
+  for (int j = 0; j < 8; ++j) if (i + j < t) dst[(size_t)row * t + i + j] = v[j];
 }
 
 static inline unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
-static inline dim3 row_grid(long long rows, int t) { return dim3((unsigned)rows, (unsigned)((t + ROW_CHUNK - 1) / ROW_CHUNK)); }
+static inline dim3 row_grid(long long rows, int t) { return dim3((unsigned)((rows * ((t + ROW_CHUNK - 1) / ROW_CHUNK) + 3) / 4)); }
 static inline bool rows_ok(const void* p, int pitch, int act) {
   return pitch % 8 == 0 && reinterpret_cast<uintptr_t>(p) % (act ? 16 : 32) == 0;
 }
@@ -1172,8 +1175,8 @@ extern "C" int ts_train_mask_time(const void* x, const int32_t* len, void* y, in
   if (!rows_ok(x, pitch_x, act) || !rows_ok(y, pitch_y, act) || pitch_x < t || pitch_y < t) return TS_EINVAL;
   TS_STREAM;
   TS_ACT(act,
-         hipLaunchKernelGGL(mask_time_kernel<float>, row_grid((long long)batch * ch, t), dim3(256), 0, stream, (const float*)x, len, (float*)y, ch, t, pitch_x, pitch_y),
-         hipLaunchKernelGGL(mask_time_kernel<bf16_t>, row_grid((long long)batch * ch, t), dim3(256), 0, stream, (const bf16_t*)x, len, (bf16_t*)y, ch, t, pitch_x, pitch_y));
+         hipLaunchKernelGGL(mask_time_kernel<float>, row_grid((long long)batch * ch, t), dim3(256), 0, stream, (const float*)x, len, (float*)y, batch, ch, t, pitch_x, pitch_y),
+         hipLaunchKernelGGL(mask_time_kernel<bf16_t>, row_grid((long long)batch * ch, t), dim3(256), 0, stream, (const bf16_t*)x, len, (bf16_t*)y, batch, ch, t, pitch_x, pitch_y));
   return hip_status(hipGetLastError());
 }
 
@@ -1181,8 +1184,8 @@ extern "C" int ts_train_act_import(const float* src, void* dst, int64_t rows, in
   if (!src || !dst || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1 || !rows_ok(dst, pitch, act)) return TS_EINVAL;
   TS_STREAM;
   TS_ACT(act,
-         hipLaunchKernelGGL(act_import_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, src, (float*)dst, t, pitch),
-         hipLaunchKernelGGL(act_import_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, src, (bf16_t*)dst, t, pitch));
+         hipLaunchKernelGGL(act_import_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, src, (float*)dst, (long long)rows, t, pitch),
+         hipLaunchKernelGGL(act_import_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, src, (bf16_t*)dst, (long long)rows, t, pitch));
   return hip_status(hipGetLastError());
 }
 
@@ -1190,8 +1193,8 @@ extern "C" int ts_train_act_export(const void* src, float* dst, int64_t rows, in
   if (!src || !dst || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1 || !rows_ok(src, pitch, act)) return TS_EINVAL;
   TS_STREAM;
   TS_ACT(act,
-         hipLaunchKernelGGL(act_export_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)src, dst, t, pitch),
-         hipLaunchKernelGGL(act_export_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)src, dst, t, pitch));
+         hipLaunchKernelGGL(act_export_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)src, dst, (long long)rows, t, pitch),
+         hipLaunchKernelGGL(act_export_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)src, dst, (long long)rows, t, pitch));
   return hip_status(hipGetLastError());
 }
 
@@ -1311,18 +1314,19 @@ extern "C" int ts_train_add_relu_fwd(const void* a, const void* b, void* out, in
   if (!rows_ok(a, pitch, act) || !rows_ok(out, pitch, act) || (b && !rows_ok(b, pitch, act))) return TS_EINVAL;
   TS_STREAM;
   TS_ACT(act,
-         hipLaunchKernelGGL(add_relu_fwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, t, pitch),
-         hipLaunchKernelGGL(add_relu_fwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, t, pitch));
+         hipLaunchKernelGGL(add_relu_fwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, (long long)rows, t, pitch),
+         hipLaunchKernelGGL(add_relu_fwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (long long)rows, t, pitch));
   return hip_status(hipGetLastError());
 }
 
-extern "C" int ts_train_add(const void* a, const void* b, void* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream_) {
-  if (!a || !b || !out || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1) return TS_EINVAL;
+extern "C" int ts_train_add(const void* a, const void* b, const int32_t* len_b, int32_t ch, void* out, int64_t rows, int32_t t, int32_t pitch,
+                            int32_t act, void* stream_) {
+  if (!a || !b || !out || rows <= 0 || t <= 0 || pitch < t || act < 0 || act > 1 || (len_b && (ch <= 0 || rows % ch))) return TS_EINVAL;
   if (!rows_ok(a, pitch, act) || !rows_ok(out, pitch, act) || !rows_ok(b, pitch, act)) return TS_EINVAL;
   TS_STREAM;
   TS_ACT(act,
-         hipLaunchKernelGGL(add_fwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, t, pitch),
-         hipLaunchKernelGGL(add_fwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, t, pitch));
+         hipLaunchKernelGGL(add_fwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, (long long)rows, t, pitch, len_b, ch),
+         hipLaunchKernelGGL(add_fwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (long long)rows, t, pitch, len_b, ch));
   return hip_status(hipGetLastError());
 }
 
@@ -1331,7 +1335,7 @@ extern "C" int ts_train_relu_bwd(const void* dout, const void* out, void* din, i
   if (!rows_ok(dout, pitch, act) || !rows_ok(out, pitch, act) || !rows_ok(din, pitch, act)) return TS_EINVAL;
   TS_STREAM;
   TS_ACT(act,
-         hipLaunchKernelGGL(relu_bwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)dout, (const float*)out, (float*)din, t, pitch),
-         hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)out, (bf16_t*)din, t, pitch));
+         hipLaunchKernelGGL(relu_bwd_kernel<float>, row_grid(rows, t), dim3(256), 0, stream, (const float*)dout, (const float*)out, (float*)din, (long long)rows, t, pitch),
+         hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, row_grid(rows, t), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)out, (bf16_t*)din, (long long)rows, t, pitch));
   return hip_status(hipGetLastError());
 }

@@ -206,7 +206,7 @@ class _FusedBlockBase(nn.Module):
         dev = x.device
         len_in = _t.lengths_i32(lengths, dev)
         if self.res is not None:     # two consumers: one node adds the two gradients on the way back (on activation rows)
-            x, x_res = T.Fork.apply(x)
+            x, x_res = T.Fork.apply(x, len_in if self.res[0].stride == 1 else None)
         h, lh, out_lengths = x, len_in, lengths
         subs = list(self._sub_blocks())
         # block tail relu(BN(main) + BN(residual)) in one pass: both branches then end un-normalised (train_ops.block_tail)
@@ -236,7 +236,7 @@ class _FusedBlockBase(nn.Module):
                 r_in = T.SubsampleMask.apply(x_res, len_in, rc.stride, (x_res.shape[2] - 1) // rc.stride + 1)
                 r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(r_in, rc.conv.weight), relu=False)
             else:                    # mask -> 1x1 -> BatchNorm as one node, like a repeat without depthwise conv and ReLU
-                r_out = T.sub_block(x_res, None, rc, rbn, len_in, len_in, relu=False, lazy_out=fuse_tail)
+                r_out = T.sub_block(x_res, None, rc, rbn, len_in, len_in, relu=False, lazy_out=fuse_tail, bwd_mask=False)
         out = T.block_tail(h, r_out) if (fuse_tail and getattr(h, "_ts_lazy", None) is not None) else T.AddRelu.apply(h, r_out)
         return T.dropout(out, out_drop.p, out_drop.training), out_lengths
 

@@ -358,19 +358,24 @@ class Fork(torch.autograd.Function):
     re-import on the way."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, res_len=None):
+        ctx.res_len = res_len          # int32 lengths: the second output feeds a MaskedConv1d whose input mask's backward is applied HERE
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
     def backward(ctx, g1, g2):
         if g1 is None or g2 is None:
-            return g1 if g2 is None else g2
+            if g2 is not None and ctx.res_len is not None:
+                return MaskTime.apply(g2, ctx.res_len), None
+            return (g1 if g2 is None else g2), None
         dtype = g1.dtype if is_act(g1) else (g2.dtype if is_act(g2) else _ACT_DTYPE)
         g1, g2 = _import(g1, dtype), _import(g2, dtype)
         out = alloc_like(g1)
-        st = _lib.lib().ts_train_add(g1.data_ptr(), g2.data_ptr(), out.data_ptr(), g1.shape[0] * g1.shape[1], g1.shape[2], _pitch(g1), _code(g1), _s(g1))
+        ln = ctx.res_len
+        st = _lib.lib().ts_train_add(g1.data_ptr(), g2.data_ptr(), ln.data_ptr() if ln is not None else None, g1.shape[1], out.data_ptr(),
+                                     g1.shape[0] * g1.shape[1], g1.shape[2], _pitch(g1), _code(g1), _s(g1))
         _lib.check(st, "ts_train_add")
-        return out
+        return out, None
 
 
 class DepthwiseConv(torch.autograd.Function):
@@ -620,7 +625,7 @@ class SqueezeExciteTrain(torch.autograd.Function):
 class SubBlockCfg:
     """Non-tensor arguments of SubBlock (one per call)."""
     __slots__ = ("len_in", "len_out", "k", "stride", "dil", "pad", "eps", "relu", "running", "drop_p", "drop_seed",
-                 "lazy_in", "lazy_out", "out_sums")
+                 "lazy_in", "lazy_out", "out_sums", "bwd_mask")
 
 
 # BatchNorm between two repeats folded into the neighbouring depthwise launches (no normalised tensor in memory): on by default
@@ -759,19 +764,22 @@ class SubBlock(torch.autograd.Function):
             ddw = ddw.view(ctx.shapes[0])
         else:
             ddw = None
-            _lib.check(L.ts_train_mask_time(dmid.data_ptr(), cfg.len_in.data_ptr(), dx.data_ptr(), b, c_in, t_in, _pitch(dmid), _pitch(dx), code, st_),
-                       "ts_train_mask_time")
+            if cfg.bwd_mask:
+                _lib.check(L.ts_train_mask_time(dmid.data_ptr(), cfg.len_in.data_ptr(), dx.data_ptr(), b, c_in, t_in, _pitch(dmid), _pitch(dx), code, st_),
+                           "ts_train_mask_time")
+            else:
+                dx = dmid            # the consumer of this gradient (Fork with res_len) applies the input mask's backward
         return dx, ddw, dpw.view(ctx.shapes[1]), dg, db, dg_in, db_in, None
 
 
 def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Tensor, len_out: Tensor, relu: bool, drop_p: float = 0.0,
-              lazy_out: bool = False) -> Tensor:
+              lazy_out: bool = False, bwd_mask: bool = True) -> Tensor:
     """x -> [dropout](relu?(BN_train(pw(mask(dw(mask(x))))))): one repeat of a block.  dw_conv / pw_conv are the MaskedConv1d modules
     (dw_conv None for a non-separable 1x1 repeat), len_in / len_out int32 device lengths before / after the depthwise conv.
     `lazy_out` (only between two repeats, see SubBlock): the result is the UN-normalised 1x1 output carrying its pending BatchNorm
     (`._ts_lazy`); hand it to the next sub_block call and to nothing else."""
     cfg = SubBlockCfg()
-    cfg.len_in, cfg.len_out = len_in, len_out
+    cfg.len_in, cfg.len_out, cfg.bwd_mask = len_in, len_out, bool(bwd_mask)   # bwd_mask False: x comes out of Fork(x, res_len), which masks the gradient
     if dw_conv is not None:
         cfg.k, cfg.stride, cfg.dil, cfg.pad = dw_conv.kernel_size, dw_conv.stride, dw_conv.dilation, dw_conv.padding
     else:
