@@ -408,6 +408,12 @@ int ts_encode_chars(const int32_t* text, const int32_t* off, int32_t n_rows, con
  * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].
  * ---------------------------------------------------------------------------------------------- */
 /* len (may be NULL): int32 [B]; frames >= len[b] are written as 0 so that dst satisfies the tail-zero invariant. */
+/* Length arithmetic in one launch: out[i] = floor((in[i] + add) / div) + plus, in the arithmetic of the input type, written as `out_kind`
+ * (`out` may be NULL) and, when out_i32 != NULL, once more as int32 -- what the kernels take.  kinds: 0 f32, 1 int64, 2 int32.
+ * Replaces the ATen chains of MaskedConv1d.get_seq_len (quartznet/blocks.py:150-163: add = 2p - d(k-1) - 1, div = stride, plus = 1, same
+ * dtype out) and PowerSpectrum.get_sequence_length (quartznet/transform.py:170-175: add = 0, div = hop, plus = 1, int64 out). */
+int ts_lengths_map(const void* in, int32_t in_kind, void* out, int32_t out_kind, int32_t* out_i32, int32_t n, int64_t add, int64_t div,
+                   int64_t plus, void* stream);
 int ts_pack_activation(const float* src, const int32_t* len, int32_t batch, int32_t channels, int32_t t, void* dst_bf16,
                        int32_t pitch, void* stream);
 int ts_unpack_activation(const void* src_bf16, int32_t batch, int32_t channels, int32_t t, int32_t pitch,

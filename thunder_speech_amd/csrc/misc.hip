@@ -31,7 +31,39 @@ __global__ void unpack_kernel(const unsigned short* __restrict__ src, float* __r
   dst[idx] = bf16_to_f32(src[(size_t)row * pitch + c]);
 }
 
+// out[i] = floor((in[i] + add) / div) + plus in the arithmetic of the input type (f32 lengths stay f32 operations, integer lengths
+// use floor division), written in `out_kind` and, optionally, once more as int32 (what the kernels take).  kinds: 0 f32, 1 i64, 2 i32
+__global__ void lengths_map_kernel(const void* __restrict__ in, int in_kind, void* __restrict__ out, int out_kind, int* __restrict__ out_i32,
+                                   int n, long long add, long long div, long long plus) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r;
+  if (in_kind == 0) {
+    r = (double)(floorf((static_cast<const float*>(in)[i] + (float)add) / (float)div) + (float)plus);
+  } else {
+    const long long v = (in_kind == 1 ? static_cast<const long long*>(in)[i] : (long long)static_cast<const int*>(in)[i]) + add;
+    long long q = v / div;
+    if ((v % div != 0) && ((v < 0) != (div < 0))) --q;                      // floor, like torch.div(rounding_mode="floor")
+    r = (double)(q + plus);
+  }
+  if (out) {
+    if (out_kind == 0) static_cast<float*>(out)[i] = (float)r;
+    else if (out_kind == 1) static_cast<long long*>(out)[i] = (long long)r;
+    else static_cast<int*>(out)[i] = (int)r;
+  }
+  if (out_i32) out_i32[i] = (int)r;
+}
+
 }  // namespace ts
+
+extern "C" int ts_lengths_map(const void* in, int32_t in_kind, void* out, int32_t out_kind, int32_t* out_i32, int32_t n, int64_t add,
+                              int64_t div, int64_t plus, void* stream) {
+  if (!in || (!out && !out_i32) || n <= 0 || div == 0 || in_kind < 0 || in_kind > 2 || out_kind < 0 || out_kind > 2) return TS_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::lengths_map_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, in_kind, out, out_kind,
+                     out_i32, n, (long long)add, (long long)div, (long long)plus);
+  return ts::hip_status(hipGetLastError());
+}
 
 extern "C" int ts_abi_version(void) { return TS_ABI_VERSION; }
 extern "C" const char* ts_build_target(void) { return TS_BUILD_TARGET; }

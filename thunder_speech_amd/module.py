@@ -70,8 +70,10 @@ class BaseCTCModule(_Base):
                 not any(p.requires_grad for p in self.encoder.parameters()):
             encoded, out_lengths = graphed(x, lengths)             # front end + frozen encoder replayed from a hipGraph
             return self.decoder(encoded), out_lengths
-        features, feature_lengths = self.audio_transform(x, lengths)
-        encoded, out_lengths = self.encoder(features, feature_lengths)
+        from . import tensors as _t
+        with _t.lengths_scope():       # the front end's frame lengths reach the encoder with their int32 copy already made
+            features, feature_lengths = self.audio_transform(x, lengths)
+            encoded, out_lengths = self.encoder(features, feature_lengths)
         return self.decoder(encoded), out_lengths
 
     def graph_frozen_encoder(self, enable: bool = True) -> "BaseCTCModule":

@@ -56,7 +56,7 @@ def init_weights(m: nn.Module, mode: InitMode = InitMode.xavier_uniform):
 
 
 def _conv_len(lengths: torch.Tensor, k: int, s: int, p: int, d: int) -> torch.Tensor:
-    return torch.div(lengths + 2 * p - d * (k - 1) - 1, s, rounding_mode="floor") + 1
+    return _t.lengths_map(lengths, 2 * p - d * (k - 1) - 1, s, 1)
 
 
 class MaskedConv1d(nn.Module):

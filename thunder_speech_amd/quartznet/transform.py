@@ -80,6 +80,8 @@ class PowerSpectrum(_FusedOnly):
         self.stft_func = torch.stft          # kept for patch_stft(); the HIP front end does not call it
 
     def get_sequence_length(self, lengths: torch.Tensor) -> torch.Tensor:
+        if lengths.is_cuda and lengths.dtype in (torch.float32, torch.int64, torch.int32) and not _t._NO_MAP:
+            return _t.lengths_map(lengths, 0, self.hop_length, 1, out_dtype=torch.long)      # one launch (+ the int32 copy for the kernels)
         return (torch.floor(lengths / self.hop_length) + 1).to(dtype=torch.long)
 
 

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -116,13 +118,36 @@ class lengths_scope:
 
     def __enter__(self):
         global _LEN_SCOPE
-        self._prev, _LEN_SCOPE = _LEN_SCOPE, {}
+        self._prev, _LEN_SCOPE = _LEN_SCOPE, (dict(_LEN_SCOPE) if _LEN_SCOPE else {})      # a nested scope sees the outer one's entries
         return self
 
     def __exit__(self, *exc):
         global _LEN_SCOPE
         _LEN_SCOPE = self._prev
         return False
+
+
+_KINDS = {torch.float32: 0, torch.int64: 1, torch.int32: 2}
+_NO_MAP = bool(os.environ.get("TS_NO_LENGTHS_MAP"))       # diagnostic switch: the plain torch expressions
+
+
+def lengths_map(lengths: torch.Tensor, add: int, div: int, plus: int, out_dtype=None) -> torch.Tensor:
+    """floor((lengths + add) / div) + plus in ONE launch (ts_lengths_map) for f32 / int64 / int32 device lengths, in the input type's
+    arithmetic; the int32 copy the kernels need is produced by the same launch and remembered for lengths_i32 (inside a lengths_scope).
+    Anything else (CPU tensors, other dtypes) takes the plain torch expression."""
+    out_dtype = out_dtype or lengths.dtype
+    if _NO_MAP or not (lengths.is_cuda and lengths.dim() == 1 and lengths.is_contiguous() and lengths.dtype in _KINDS and out_dtype in _KINDS):
+        r = torch.div(lengths + add, div, rounding_mode="floor") + plus
+        return r.to(out_dtype)
+    out = torch.empty(lengths.shape, dtype=out_dtype, device=lengths.device)
+    i32 = out if out_dtype == torch.int32 else torch.empty(lengths.shape, dtype=torch.int32, device=lengths.device)
+    st = _lib.lib().ts_lengths_map(lengths.data_ptr(), _KINDS[lengths.dtype], out.data_ptr(), _KINDS[out_dtype],
+                                   None if i32 is out else i32.data_ptr(), lengths.numel(), int(add), int(div), int(plus),
+                                   torch.cuda.current_stream(lengths.device).cuda_stream)
+    _lib.check(st, "ts_lengths_map")
+    if _LEN_SCOPE is not None:
+        _LEN_SCOPE[id(out)] = (out, out._version, i32)
+    return out
 
 
 def lengths_i32(lengths: torch.Tensor, device) -> torch.Tensor:
