@@ -135,7 +135,7 @@ def _split(sd):
     return params, buffers
 
 
-def _sync_worker(rank, world, port, out):
+def _sync_worker(rank, world, port, out, hold=False):
     from thunder_speech_amd.parallel import GradientSync
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -146,6 +146,7 @@ def _sync_worker(rank, world, port, out):
         dparams = {k: torch.nn.Parameter(v.clone()) for k, v in dsd.items()}
         every = list(params.values()) + list(dparams.values())
         sync = GradientSync(every, bucket_bytes=2048)                 # several buckets
+        sync.hold(hold)                                               # held (a graphed step): the hooks only collect, finish() exchanges
         opt = torch.optim.AdamW(every, lr=1e-2)
         launched_during_backward = []
         for step in range(2):
@@ -162,13 +163,16 @@ def _sync_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_training_step_equals_one_process_averaging_two_independent_batches():
+@pytest.mark.parametrize("hold", [False, True])
+def test_two_rank_training_step_equals_one_process_averaging_two_independent_batches(hold):
+    """hold=True is the mode train_graph.GraphedTrainStep puts GradientSync in (no collective while the backward pass is captured /
+    replayed; every bucket goes out in finish()): same result, nothing launched from the hooks."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, out, hold)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict()
@@ -200,7 +204,7 @@ def test_two_rank_training_step_equals_one_process_averaging_two_independent_bat
     for rank in (0, 1):
         state, n_buckets, launched, n_coll = results[rank]
         assert n_buckets > 2 and n_coll == 2 * n_buckets                     # one all-reduce per bucket per step (gloo path)
-        assert all(n == n_buckets for n in launched)                         # every bucket went out from a hook, during backward
+        assert all(n == (0 if hold else n_buckets) for n in launched)        # every bucket went out from a hook, during backward (or none, held)
         for k, v in want.items():
             got = torch.from_numpy(state[k])
             assert torch.allclose(got, v, rtol=1e-5, atol=1e-6), (rank, k, float((got - v).abs().max()))
