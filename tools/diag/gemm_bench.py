@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from thunder_speech_amd import _lib
 L = _lib.lib()
-shapes = [(32, 512, 512, 501), (32, 256, 256, 501), (32, 1024, 1024, 501)] if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1].split(","))]
+shapes = [(32, 512, 512, 501), (32, 256, 256, 501), (32, 1024, 1024, 501), (32, 256, 512, 501), (32, 512, 256, 501), (32, 512, 1024, 501), (32, 1024, 512, 501)] if len(sys.argv) < 2 else [tuple(int(v) for v in sys.argv[1].split(","))]
 st = torch.cuda.current_stream().cuda_stream
 for (b, ci, co, t) in shapes:
     p = (t + 191) // 192 * 192 + 64
@@ -52,19 +52,20 @@ for (b, ci, co, t) in shapes:
     d = _lib.TcsDesc()
     d.batch, d.c_in, d.c_out, d.t_in, d.t_out, d.pitch_in, d.pitch_out = b, ci, co, t, t, p, p
     d.kernel, d.stride, d.dilation, d.padding, d.depthwise, d.relu, d.out_fp32 = 1, 1, 1, 0, 0, 0, 0
-    d.flags = 1
-    d.pw_w, d.bias = frags.data_ptr(), bias.data_ptr()
-    fn = lambda: L.ts_tcs_subblock_fwd(C.byref(d), u.data_ptr(), lens.data_ptr(), None, None, y.data_ptr(), st)
-    for _ in range(5):
-        rc = fn()
-    assert rc == 0, rc
-    torch.cuda.synchronize()
-    ref = torch.einsum("oc,bct->bot", w.bfloat16().float(), u[:, :, :t].float())
-    err = float((y[:, :, :t].float() - ref).abs().max()) / float(ref.abs().max())
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(50):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 50 * 1e3
-    print(f"tcs pointwise-only B={b} Cin={ci} Cout={co} T={t} pitch {p}: {us:8.1f} us  {2.0*b*t*ci*co/us/1e6:7.1f} TF/s  rel err {err:.2e}")
+    for flags in (1, 0):
+        d.flags = flags
+        d.pw_w, d.bias = frags.data_ptr(), bias.data_ptr()
+        fn = lambda: L.ts_tcs_subblock_fwd(C.byref(d), u.data_ptr(), lens.data_ptr(), None, None, y.data_ptr(), st)
+        for _ in range(5):
+            rc = fn()
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        ref = torch.einsum("oc,bct->bot", w.bfloat16().float(), u[:, :, :t].float())
+        err = float((y[:, :, :t].float() - ref).abs().max()) / float(ref.abs().max())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        print(f"tcs pointwise-only flags={flags} B={b} Cin={ci} Cout={co} T={t} pitch {p}: {us:8.1f} us  {2.0*b*t*ci*co/us/1e6:7.1f} TF/s  rel err {err:.2e}")
