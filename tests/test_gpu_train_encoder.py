@@ -173,8 +173,8 @@ def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k,
         assert err <= tol * max(float(ref.abs().max()), 1.0), (name, err, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("act", ["fp32", "bf16"])
-def test_graphed_training_step_follows_the_eager_step(act):
+@pytest.mark.parametrize("act,optimizer", [("fp32", "fused"), ("bf16", "fused"), ("bf16", "torch")])
+def test_graphed_training_step_follows_the_eager_step(act, optimizer):
     """train_graph.GraphedTrainStep (features -> encoder -> decoder -> CTC -> backward replayed from ONE hipGraph, front end /
     exchange / optimizer outside) against the same steps launched eagerly (module.py:102-113 + backward + GradientSync.finish +
     FusedAdamW): same seeds, so the dither draws are the same too; the first loss agrees to 1e-6 relative, the later ones to 1 % (fp32; the
@@ -196,7 +196,10 @@ def test_graphed_training_step_follows_the_eager_step(act):
         m = build_synthetic_quartznet(repeat_blocks=1, encoder_state=otcs.synth_encoder_state(arch, seed=0, calibrate=True),
                                       decoder_state=otcs.synth_decoder_state(1024, 29, seed=1)).cuda().train()
         params = [p for p in m.parameters() if p.requires_grad]
-        return m, FusedAdamW(params, lr=1e-3, weight_decay=0.0), GradientSync(params)
+        # "torch": a plain torch optimizer -- the graph reads derived weight copies (MFMA fragments) that only FusedAdamW refreshes by
+        # itself; GraphedTrainStep has to bring them up to date after ANY optimizer step
+        opt = FusedAdamW(params, lr=1e-3, weight_decay=0.0) if optimizer == "fused" else torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0)
+        return m, opt, GradientSync(params)
 
     train_ops.set_activation_dtype(act)
     try:

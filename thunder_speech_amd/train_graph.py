@@ -22,7 +22,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from . import rng
+from . import rng, train_ops
 from .ctc_loss import calculate_ctc
 
 
@@ -95,4 +95,5 @@ class GraphedTrainStep:
             torch.autograd.graph.increment_version(b)
         self.sync.finish()                       # ranks > 1: all buckets go out now (bf16 wire, reduce-scatter + all-gather)
         self.optimizer.step()
+        train_ops.refresh_weight_copies(self.sync.params)     # the graph reads the weights' bf16 / fragment copies: keep them current
         return loss

@@ -257,12 +257,24 @@ def refresh_pw_frags(params) -> None:
     todo = []
     for p in params:
         ent = _PW_FRAGS.get(id(p))
-        if ent is not None and ent[3]() is p and p.dtype == torch.float32 and p.is_contiguous():
+        if ent is not None and ent[3]() is p and ent[2] != p._version and p.dtype == torch.float32 and p.is_contiguous():
             todo.append((p, p.detach().view(p.shape[0], -1), ent[0], ent[1]))
     if todo:
         _pack_rows(todo)
         for p, _, _, _ in todo:
             _PW_FRAGS[id(p)][2] = p._version
+
+
+def refresh_weight_copies(params) -> None:
+    """Bring every derived copy of `params` the training path keeps (MFMA fragments, plain bf16 operands) up to date with the
+    parameters' current versions.  The eager path does this lazily inside each forward; a step replayed from a hipGraph cannot -- its
+    launches read the copies' buffers as captured -- so train_graph.GraphedTrainStep calls this after every optimizer step (a no-op
+    after FusedAdamW, which refreshes them itself; what keeps any OTHER optimizer correct)."""
+    refresh_pw_frags(params)
+    for p in params:
+        ent = _BF16_SHADOW.get(id(p))
+        if ent is not None and ent[2]() is p and ent[1] != p._version:
+            _w_bf16(p.detach().to(torch.float32).contiguous().view(p.shape[0], -1), p)
 
 
 _ZERO_BIAS = {}
