@@ -279,11 +279,12 @@ int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, void* du, 
  *                               (c_out_pad32 * c_in_pad64 + c_in_pad32 * c_out_pad64) / 8.
  *   ts_train_pwconv_wgrad_mfma  dw += sum_b dv[b] . u[b]^T on hand-written MFMA kernels (csrc/train_gemm.hip): split over clip groups,
  *                               f32 partials in `workspace` (ts_train_pwconv_wgrad_workspace floats), summed onto dw by a second
- *                               launch.  c_in, c_out multiples of 8, pitches multiples of 8 and >= round_up(T, 64), 16-byte aligned
+ *                               launch.  len_u (may be NULL): frames >= len_u[b] of u count as zero -- the input mask of the MaskedConv1d
+ *                               applied inside the product, so that the masked copy of u need not exist.  c_in, c_out multiples of 8, pitches multiples of 8 and >= round_up(T, 64), 16-byte aligned
  *                               bases; anything else returns TS_EUNSUPPORTED (callers fall back to ts_train_pwconv_bwd). */
 int ts_train_pack_pw_multi(const void* table, int32_t n_tensors, int64_t max_groups, void* stream);
 int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, int32_t c_out);
-int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, float* dw, float* workspace, int32_t batch, int32_t c_in, int32_t c_out,
+int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const int32_t* len_u, float* dw, float* workspace, int32_t batch, int32_t c_in, int32_t c_out,
                                int32_t t, int32_t pitch_u, int32_t pitch_v, void* stream);
 /* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
  * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */

@@ -151,7 +151,7 @@ def lib() -> C.CDLL:
     L.ts_train_pack_pw_multi.argtypes = [vp, i32, i64, vp]
     L.ts_train_pwconv_wgrad_workspace.argtypes = [i32, i32, i32]
     L.ts_train_pwconv_wgrad_workspace.restype = C.c_int64
-    L.ts_train_pwconv_wgrad_mfma.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.ts_train_pwconv_wgrad_mfma.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_add_relu_fwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
     L.ts_train_relu_bwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]

@@ -32,6 +32,7 @@ struct WgradArgs {
   const bf16_t* dv;       // [B][M][pitch_v]
   const bf16_t* u;        // [B][N][pitch_u]
   float* part;            // [split][M][N] partial products, one per clip group
+  const int* len_u;       // null, or per clip: frames >= len_u[b] of u count as zero (the input mask of a MaskedConv1d, applied here)
   int batch, M, N, t, pitch_v, pitch_u, n_mt, n_nt, clips_per_wg;
 };
 
@@ -101,12 +102,17 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs a) {
     const int ahead = S - 1 - s < WD - 2 ? S - 1 - s : WD - 2;          // stages issued after s and still allowed in flight
     if (ahead >= 2) vm_wait<16>(); else if (ahead == 1) vm_wait<8>(); else vm_wait<0>();
     char* const st = smem + (s % WD) * WSTAGEB;
-    const int nv = a.t - (s % nk) * GK;                    // valid frames of this K-step
+    int nv = a.t - (s % nk) * GK;                          // valid frames of this K-step
+    if (a.len_u && lane >= 32) {                           // u rows: the clip's own length
+      int l = a.len_u[b_lo + s / nk];
+      l = l < 0 ? 0 : (l > a.t ? a.t : l);
+      nv = l - (s % nk) * GK;
+    }
     if (nv < GK) {
       // zero the padding this wave fetched: lane -> one row (lanes 0..31 dv rows, 32..63 u rows), chunks from nv / 8 on
       char* const row = st + (lane >> 5) * WTILEB;
       const int r = 32 * wave + (lane & 31);
-      for (int c = nv >> 3; c < 8; ++c) {
+      for (int c = nv > 0 ? nv >> 3 : 0; c < 8; ++c) {
         u32x4* const p = reinterpret_cast<u32x4*>(row + waddr(r, c));
         *p = keep_first(*p, nv - 8 * c);
       }
@@ -207,7 +213,7 @@ extern "C" int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, 
 }
 
 /* dw += sum_b dv[b] . u[b]^T; see include/thunder_speech_amd.h */
-extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, float* dw, float* workspace, int32_t batch, int32_t c_in,
+extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const int32_t* len_u, float* dw, float* workspace, int32_t batch, int32_t c_in,
                                           int32_t c_out, int32_t t, int32_t pitch_u, int32_t pitch_v, void* stream_) {
   if (!dv || !u || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
   const int tk_end = round_up(t, GK);
@@ -223,7 +229,7 @@ extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, float* 
     attr = 1;
   }
   WgradArgs g;
-  g.dv = (const bf16_t*)dv; g.u = (const bf16_t*)u; g.part = workspace;
+  g.dv = (const bf16_t*)dv; g.u = (const bf16_t*)u; g.part = workspace; g.len_u = len_u;
   g.batch = batch; g.M = c_out; g.N = c_in; g.t = t; g.pitch_v = pitch_v; g.pitch_u = pitch_u;
   g.n_mt = (c_out + GTILE - 1) / GTILE; g.n_nt = (c_in + GTILE - 1) / GTILE;
   const int split = wgrad_split(batch, c_in, c_out);

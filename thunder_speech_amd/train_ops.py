@@ -309,13 +309,14 @@ def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int
     _lib.check(st, "ts_tcs_subblock_fwd")
 
 
-def _wgrad(dv: Tensor, u: Tensor, dw: Tensor) -> None:
-    """dw += sum_b dv[b] . u[b]^T (csrc/train_gemm.hip); dv [B, c_out, T], u [B, c_in, T] bf16 rows, dw f32 [c_out, c_in]."""
+def _wgrad(dv: Tensor, u: Tensor, dw: Tensor, len_u: Tensor = None) -> None:
+    """dw += sum_b dv[b] . mask(u[b], len_u)^T (csrc/train_gemm.hip); dv [B, c_out, T], u [B, c_in, T] bf16 rows, dw f32 [c_out, c_in]."""
     L = _lib.lib()
     b, c_out, t = dv.shape
     c_in = u.shape[1]
     ws = torch.empty(L.ts_train_pwconv_wgrad_workspace(b, c_in, c_out), dtype=torch.float32, device=dv.device)
-    _lib.check(L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)),
+    _lib.check(L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), len_u.data_ptr() if len_u is not None else None, dw.data_ptr(), ws.data_ptr(),
+                                            b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)),
                "ts_train_pwconv_wgrad_mfma")
 
 
@@ -331,15 +332,25 @@ def _full_lengths(b: int, t: int, device) -> Tensor:
     return _LENS[key]
 
 
-def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False) -> Tensor:
-    """v[b] = W . u[b] for activation rows u [B, c_in, T] (masked already); w2 = f32 [c_out, c_in] view of `param`."""
+def _pw_masks_inside(u_dtype, c_in: int, c_out: int) -> bool:
+    """True when both directions of this 1x1 conv run on kernels that apply the MaskedConv1d input mask themselves (the generic
+    pointwise kernel masks by length; the weight-gradient kernel takes len_u), so the masked copy of the input need not be made."""
+    bf = u_dtype == torch.bfloat16
+    return _tcs_ok(bf, c_in) and _tcs_ok(bf, c_out) and c_in % 8 == 0
+
+
+def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False, lens: Tensor = None) -> Tensor:
+    """v[b] = W . u[b] for activation rows u [B, c_in, T]; w2 = f32 [c_out, c_in] view of `param`.  `lens` (only with
+    _pw_masks_inside): u is NOT masked yet, frames >= lens[b] count as zero; otherwise u is masked already."""
     b, c_in, t = u.shape
     c_out = w2.shape[0]
     bf = u.dtype == torch.bfloat16
     v = alloc(b, c_out, t, u.device, torch.float32 if (f32_out or not bf) else torch.bfloat16)
     if not f32_out and _tcs_ok(bf, c_in):
-        _tcs_pointwise(u, pw_frags(param, w2)[0], v, _full_lengths(b, t, u.device), c_out)
+        _tcs_pointwise(u, pw_frags(param, w2)[0], v, lens if lens is not None else _full_lengths(b, t, u.device), c_out)
     else:
+        if lens is not None:
+            raise RuntimeError("_pw_fwd: an unmasked input needs the kernels that mask inside")
         wk = _w_bf16(w2, param) if bf else w2
         prec = 0 if not bf else (1 if f32_out else 2)
         st = _lib.lib().ts_train_pwconv_fwd(u.data_ptr(), wk.data_ptr(), v.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(v), prec, _s(v))
@@ -347,8 +358,9 @@ def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False) -> Tens
     return v
 
 
-def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor):
-    """(du, dw) = (W^T . dv[b], sum_b dv[b] . u[b]^T); dw f32 [c_out, c_in] (the bucket view of `param` when it has one)."""
+def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor, len_u: Tensor = None):
+    """(du, dw) = (W^T . dv[b], sum_b dv[b] . u[b]^T); dw f32 [c_out, c_in] (the bucket view of `param` when it has one).  len_u: u is
+    the UNMASKED input (see _pw_fwd); du is then the gradient w.r.t. the masked input -- the caller still owes the mask's backward."""
     b, c_in, t = u.shape
     c_out = w2.shape[0]
     bf = u.dtype == torch.bfloat16
@@ -356,8 +368,10 @@ def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor):
     if _tcs_ok(bf, c_out) and c_in % 8 == 0:
         _tcs_pointwise(dv, pw_frags(param, w2)[1], du, _full_lengths(b, t, u.device), c_in)
         dw = grad_out(param, (c_out, c_in), zeroed=True)
-        _wgrad(dv, u, dw)
+        _wgrad(dv, u, dw, len_u)
         return du, dw
+    if len_u is not None:
+        raise RuntimeError("_pw_bwd: an unmasked input needs the kernels that mask inside")
     wk = _w_bf16(w2, param) if bf else w2
     dw = grad_out(param, (c_out, c_in))
     ws = torch.empty(b * c_out * c_in, dtype=torch.float32, device=u.device)
@@ -699,12 +713,16 @@ class SubBlock(torch.autograd.Function):
             if lazy is not None:
                 raise RuntimeError("SubBlock: a folded BatchNorm input needs a depthwise convolution")
             w_dw, t_out, g_in, b_in, in_mr = None, t_in, None, None, None
-            mid = alloc_like(x)
-            _lib.check(L.ts_train_mask_time(x.data_ptr(), cfg.len_in.data_ptr(), mid.data_ptr(), b, c_in, t_in, _pitch(x), _pitch(mid), code, st_),
-                       "ts_train_mask_time")
+            if _pw_masks_inside(x.dtype, c_in, pw_w.shape[0]):
+                mid = x                  # the 1x1 kernels (forward and weight gradient) mask by length themselves: no masked copy
+            else:
+                mid = alloc_like(x)
+                _lib.check(L.ts_train_mask_time(x.data_ptr(), cfg.len_in.data_ptr(), mid.data_ptr(), b, c_in, t_in, _pitch(x), _pitch(mid), code, st_),
+                           "ts_train_mask_time")
         w_pw = pw_w.detach().to(torch.float32).contiguous().view(pw_w.shape[0], -1)
         c_out = w_pw.shape[0]
-        v = _pw_fwd(mid, pw_w, w_pw)
+        inside = dw_w is None and mid is x
+        v = _pw_fwd(mid, pw_w, w_pw, lens=cfg.len_in if inside else None)
         ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
         g, be = gamma.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
         mr = torch.empty(c_out, 2, dtype=torch.float32, device=x.device)
@@ -758,7 +776,8 @@ class SubBlock(torch.autograd.Function):
             ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
             _lib.check(L.ts_train_bn_bwd(dy.data_ptr(), y.data_ptr(), v.data_ptr(), g.data_ptr(), mr.data_ptr(), dv.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                          ws.data_ptr(), b, c_out, t_out, _pitch(v), int(cfg.relu), code, st_), "ts_train_bn_bwd")
-        dmid, dpw = _pw_bwd(dv, mid, pw_p, pw_p.detach().to(torch.float32).contiguous().view(pw_p.shape[0], -1))
+        inside = dw_p is None and mid.data_ptr() == x.data_ptr()          # forward fed the unmasked x to kernels that mask inside
+        dmid, dpw = _pw_bwd(dv, mid, pw_p, pw_p.detach().to(torch.float32).contiguous().view(pw_p.shape[0], -1), len_u=cfg.len_in if inside else None)
         dx = alloc_like(x)
         dg_in = db_in = None
         if w_dw is not None:
