@@ -113,7 +113,7 @@ class _Conv1dDecoder(nn.Conv1d):
         b, _, t = xi.shape
         if self.training and grad_on and (self.weight.requires_grad or self.bias.requires_grad):
             return _DecoderFunction.apply(self.weight, self.bias, self, _t.backing(xi), t)
-        full = torch.full((b,), t, dtype=torch.int32, device=xi.device)   # the decoder conv is not masked
+        full = _t.full_lengths(b, t, xi.device)   # the decoder conv is not masked
         y, t_out = self._layer().run(_t.backing(xi), t, full)
         return y[:, :, :t_out]
 
@@ -125,7 +125,7 @@ class _DecoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bias, module, xb, t):
         b = xb.shape[0]
-        full = torch.full((b,), t, dtype=torch.int32, device=xb.device)
+        full = _t.full_lengths(b, t, xb.device)
         y, t_out = module._build(True).run(xb, t, full)
         ctx.save_for_backward(xb)
         ctx.t, ctx.shape = t, weight.shape
@@ -183,7 +183,7 @@ class _LinearDecoder(nn.Sequential):
             padding=0, relu=False, bias_extra=lin.bias.detach(), out_fp32=True))
         xi = _t.pack(x)
         b, _, t = xi.shape
-        full = torch.full((b,), t, dtype=torch.int32, device=xi.device)
+        full = _t.full_lengths(b, t, xi.device)
         y, t_out = layer.run(_t.backing(xi), t, full)
         return y[:, :, :t_out]
 

@@ -108,7 +108,7 @@ class MaskedConv1d(nn.Module):
         else:
             xi = _t.pack(x)
         b, _, t = xi.shape
-        full = torch.full((b,), t, dtype=torch.int32, device=xi.device)
+        full = _t.full_lengths(b, t, xi.device)
         y, t_out = layer.run(_t.backing(xi), t, full)
         return y[:, :, :t_out], self.get_seq_len(lengths)
 

@@ -127,6 +127,25 @@ class lengths_scope:
         return False
 
 
+_FULL = {}
+
+
+def full_lengths(b: int, t: int, device) -> torch.Tensor:
+    """int32 [b] filled with t ("every frame is valid": the decoder convs are not masked).  Constant, so it is made once per (b, t,
+    device) instead of once per forward -- except while a hipGraph is being captured, where a cached tensor must not be born inside
+    the graph's private pool."""
+    key = (b, t, str(torch.device(device)))
+    hit = _FULL.get(key)
+    if hit is not None:
+        return hit
+    out = torch.full((b,), t, dtype=torch.int32, device=device)
+    if not (out.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if len(_FULL) > 256:
+            _FULL.clear()
+        _FULL[key] = out
+    return out
+
+
 _KINDS = {torch.float32: 0, torch.int64: 1, torch.int32: 2}
 _NO_MAP = bool(os.environ.get("TS_NO_LENGTHS_MAP"))       # diagnostic switch: the plain torch expressions
 
