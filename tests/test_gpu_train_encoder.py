@@ -135,12 +135,14 @@ def test_bf16_activation_mode_stays_within_bf16_tolerance(golden, name):
 @pytest.mark.parametrize("act", ["fp32", "bf16"])
 @pytest.mark.parametrize("batch,ch,t,k,dil", [(1, 2, 37, 5, 1), (5, 6, 501, 33, 1), (3, 4, 512, 75, 1), (2, 2, 1100, 127, 1), (33, 2, 64, 11, 1),
                                                (2, 8, 1536, 39, 1), (3, 4, 501, 87, 2), (2, 3, 1100, 33, 2), (33, 2, 64, 11, 2), (1, 1, 37, 5, 2),
-                                               (2, 2, 2050, 127, 2)])
+                                               (2, 2, 2050, 127, 2), (32, 4, 501, 63, 1), (20, 2, 1100, 127, 1), (17, 6, 90, 5, 1), (32, 2, 501, 75, 1),
+                                               (40, 2, 333, 39, 1)])
 def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k, dil):
     """The packed-FMA "same" depthwise kernels (one wavefront = two channel rows, csrc/train_enc.hip dw_fwd_pair / dw_bwd_pair)
     against F.conv1d(groups = C) + autograd on the masked input (quartznet/blocks.py:169-182): ragged lengths, several 512-frame
     wave tiles, clip counts that leave waves idle; dilation 2 (the K87 block of QuartzNet) runs the same kernels in phase-split form
-    (a row = (even, odd) frame pairs; odd channel counts allowed).  fp32 rows: 2e-5 of the scale; bf16 rows: inputs are rounded once (so the
+    (a row = (even, odd) frame pairs; odd channel counts allowed); with bf16 rows and >= 17 clips the forward runs on the matrix cores
+    (dw_fwd_mfma_kernel: Toeplitz x clips, taps rounded to bf16).  fp32 rows: 2e-5 of the scale; bf16 rows: inputs are rounded once (so the
     reference sees the same values) and the outputs once more: 1 % of the scale."""
     from thunder_speech_amd import train_ops as T
     g = torch.Generator().manual_seed(batch * 1000 + t + k + dil)

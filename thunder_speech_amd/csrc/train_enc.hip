@@ -11,6 +11,8 @@
 //   residual add + ReLU fwd / bwd                        quartznet/blocks.py:332-337
 #include "ts_common.hpp"
 
+#include <cstdlib>
+
 #include "ts_blas.hpp"
 
 namespace ts {
@@ -555,6 +557,152 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Depthwise forward on the matrix cores (bf16 rows, >= 17 clips): for ONE channel the convolution of 32 clips is a matrix product,
+//   Y[t, b] = sum_i Toep[t, i] X[i, b],   Toep[t, i] = w[i - t + p],
+// v_mfma_f32_32x32x16_bf16 with M = 32 output frames, N = 32 CLIPS, K = 16 input frames.  A wave owns one channel, one group of 32
+// clips and a run of output blocks, and streams over the input in chunks of 16 frames:
+//   * B operand = chunk [16 frames][32 clips]: lane (clip, half) holds 8 consecutive frames of its clip = ONE 16-byte global load --
+//     the input never goes through LDS (masking by length, and the previous repeat's BatchNorm + ReLU, act on the fragment in
+//     registers); loads run DWM_AHEAD chunk pairs ahead through a register ring;
+//   * A operand = a 32 x 16 slice of the Toeplitz matrix: chunk ic meets output block ob with relative index r = ic - 2 ob and
+//     A_r[m, k'] = w[16 r + k' - m - sh] (sh = round_up(p, 16) - p: the chunks start 16-aligned at frame -round_up(p, 16)); the
+//     R <= 2 NB fragments of the channel are built once per wave (taps rounded to bf16) and live in registers;
+//   * block ob is met by chunks 2 ob .. 2 ob + R - 1, so NB = ceil(R / 2) accumulators are open at a time: acc[d] = block q - d while the
+//     chunk pair q is processed; the oldest leaves after it, the others shift down;
+//   * store: lane pairs (l, l ^ 32) exchange half their register groups so that each lane writes 8 consecutive frames (16 bytes).
+// MFMA work: 2 NB instructions per 32 x 32 outputs (K63: 6, 63 / 94 of the products useful) against 64 packed FMAs per 8 x 2 outputs of
+// the pair kernel; the kernel is bound by its memory traffic, not by arithmetic or LDS.
+// ----------------------------------------------------------------------------------------------------------------------
+constexpr int DWM_AHEAD = 4;                             // chunk pairs in flight
+constexpr int DWM_TAPG = 48, DWM_TAPN = 48 + 176;        // taps in LDS per wave: zero guards in front / behind
+
+template <int NB>
+__global__ __launch_bounds__(256) void dw_fwd_mfma_kernel(const bf16_t* __restrict__ x, const int* __restrict__ len_in, const int* __restrict__ len_out,
+                                                          const float* __restrict__ w, bf16_t* __restrict__ y, int batch, int ch, int t, int k, int p,
+                                                          int pitch, int n_seg, PairBnIn aff) {
+  __shared__ float tapz[4][DWM_TAPN];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n_cg = (batch + 31) >> 5;
+  const long long wid = (long long)blockIdx.x * 4 + wave;                 // wave id -> (channel, clip group, segment): segment fastest
+  if (wid >= (long long)ch * n_cg * n_seg) return;
+  const int seg = (int)(wid % n_seg), cg = (int)((wid / n_seg) % n_cg), c = (int)(wid / ((long long)n_seg * n_cg));
+  const int n_blk = (t + 31) >> 5, per = (n_blk + n_seg - 1) / n_seg;
+  const int ob_lo = seg * per, ob_hi = ob_lo + per < n_blk ? ob_lo + per : n_blk;
+  if (ob_lo >= ob_hi) return;
+  const int pup = round_up(p, 16), sh = pup - p, R = (k + 30 + sh) / 16 + 1;          // R <= 2 NB (launcher)
+  // ---- taps -> LDS (zero guards) -> the R Toeplitz fragments of this lane
+  float* const tz = tapz[wave];
+  for (int i = lane; i < DWM_TAPN; i += 64) { const int j = i - DWM_TAPG; tz[i] = (j >= 0 && j < k) ? w[(size_t)c * k + j] : 0.f; }
+  __builtin_amdgcn_wave_barrier();
+  const int m = lane & 31, h = lane >> 5;
+  s16x8 A[2 * NB];
+#pragma unroll
+  for (int r = 0; r < 2 * NB; ++r) {
+    const float* const tp = tz + DWM_TAPG + 16 * r + 8 * h - m - sh;                // >= -46, <= 16 (2 NB - 1) + 15
+    const u32x4 v = u32x4{pack_bf16(tp[0], tp[1]), pack_bf16(tp[2], tp[3]), pack_bf16(tp[4], tp[5]), pack_bf16(tp[6], tp[7])};
+    A[r] = r < R ? __builtin_bit_cast(s16x8, v) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  // ---- this lane's clip
+  const int b = cg * 32 + m;
+  const bool clip_on = b < batch;
+  const int li = clip_on ? clamp_len(len_in, b, t) : 0, lo = clip_on ? (len_out ? clamp_len(len_out, b, t) : t) : 0;
+  const bf16_t* const xr = x + ((size_t)(clip_on ? b : 0) * ch + c) * pitch;
+  bf16_t* const yr = y + ((size_t)(clip_on ? b : 0) * ch + c) * pitch;
+  // BatchNorm of the previous repeat on the fly (one channel: the pair helper on (c, c) would read c + 1 -> do it by hand)
+  float sc = 1.f, hs = 0.f;
+  bool aff_on = false, aff_relu = false;
+  if (aff.part) {
+    double s1, s2;
+    bn_total(aff.part, ch, c, s1, s2);
+    const double mu = s1 / aff.n;
+    double var = s2 / aff.n - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)aff.eps));
+    sc = aff.gamma[c] * rstd; hs = aff.beta[c] - (float)mu * sc;
+    aff_on = true; aff_relu = aff.relu != 0;
+    if (cg == 0 && seg == 0 && lane == 0) {
+      aff.mean_rstd[2 * c] = (float)mu; aff.mean_rstd[2 * c + 1] = rstd;
+      if (aff.running_mean) {
+        aff.running_mean[c] = (1.f - aff.momentum) * aff.running_mean[c] + aff.momentum * (float)mu;
+        aff.running_var[c] = (1.f - aff.momentum) * aff.running_var[c] + aff.momentum * (float)(var * (aff.n / (aff.n > 1.0 ? aff.n - 1.0 : 1.0)));
+        if (c == 0 && aff.nbt) *aff.nbt += 1;
+      }
+    }
+  }
+  // chunk pair q = chunks 2q (frames -pup + 32 q + 8 h ..) and 2q + 1 (+16): raw 16-byte loads, zero outside [0, li)
+  auto fetch = [&](int q, u32x4& e, u32x4& o) {
+    const int f0 = -pup + 32 * q + 8 * h, f1 = f0 + 16;
+    e = (f0 >= 0 && f0 < li) ? *reinterpret_cast<const u32x4*>(xr + f0) : u32x4{0u, 0u, 0u, 0u};
+    o = (f1 >= 0 && f1 < li) ? *reinterpret_cast<const u32x4*>(xr + f1) : u32x4{0u, 0u, 0u, 0u};
+  };
+  auto prep = [&](u32x4 v, int f0) {                      // input transform + length mask of one fragment
+    if (f0 < 0 || f0 >= li) return s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (aff_on) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a0 = fmaf(bf16_lo(v[j]), sc, hs), a1 = fmaf(bf16_hi(v[j]), sc, hs);
+        if (aff_relu) { a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f; }
+        v[j] = pack_bf16(a0, a1);
+      }
+    }
+    if (f0 + 8 > li) v = keep_first(v, li - f0);
+    return __builtin_bit_cast(s16x8, v);
+  };
+  f32x16 acc[NB];
+#pragma unroll
+  for (int d = 0; d < NB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  const int q_lo = ob_lo, q_hi = ob_hi + NB - 1;           // block ob is complete after chunk pair ob + NB - 1
+  u32x4 ring_e[DWM_AHEAD], ring_o[DWM_AHEAD];
+#pragma unroll
+  for (int a = 0; a < DWM_AHEAD; ++a) fetch(q_lo + a, ring_e[a], ring_o[a]);
+  for (int q0 = q_lo; q0 < q_hi; q0 += DWM_AHEAD) {
+#pragma unroll
+    for (int a = 0; a < DWM_AHEAD; ++a) {
+      const int q = q0 + a;
+      if (q < q_hi) {
+        const s16x8 be = prep(ring_e[a], -pup + 32 * q + 8 * h), bo = prep(ring_o[a], -pup + 32 * q + 16 + 8 * h);
+        fetch(q + DWM_AHEAD, ring_e[a], ring_o[a]);
+#pragma unroll
+        for (int d = 0; d < NB; ++d) {                     // acc[d] = block q - d: relative chunk indices 2 d (even chunk), 2 d + 1 (odd)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2 * d], be, acc[d], 0, 0, 0);
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2 * d + 1], bo, acc[d], 0, 0, 0);
+        }
+        const int ob = q - (NB - 1);
+        if (ob >= ob_lo && ob < ob_hi) {
+          // register group rg of acc = frames 32 ob + 8 rg + 4 h + 0..3 of this lane's clip: pack, trade two groups with lane ^ 32,
+          // store 8 consecutive frames twice
+          unsigned pk[4][2];
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            pk[rg][0] = pack_bf16(acc[NB - 1][4 * rg + 0], acc[NB - 1][4 * rg + 1]);
+            pk[rg][1] = pack_bf16(acc[NB - 1][4 * rg + 2], acc[NB - 1][4 * rg + 3]);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            // group this lane finishes: 2 u + h; it sends the other one of the pair (2 u + 1 - h) to its partner
+            const unsigned s0 = h ? pk[2 * u][0] : pk[2 * u + 1][0], s1 = h ? pk[2 * u][1] : pk[2 * u + 1][1];
+            const unsigned g0 = __shfl_xor(s0, 32), g1 = __shfl_xor(s1, 32);
+            const unsigned m0 = h ? pk[2 * u + 1][0] : pk[2 * u][0], m1 = h ? pk[2 * u + 1][1] : pk[2 * u][1];
+            const int f = 32 * ob + 8 * (2 * u + h);
+            u32x4 v = h ? u32x4{g0, g1, m0, m1} : u32x4{m0, m1, g0, g1};            // frames f .. f + 3 come from the h = 0 lane
+            if (clip_on && f < pitch) {
+              if (f + 8 > lo) v = keep_first(v, lo - f);
+              *reinterpret_cast<u32x4*>(yr + f) = v;
+            }
+          }
+        }
+#pragma unroll
+        for (int d = NB - 1; d > 0; --d) acc[d] = acc[d - 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+      }
+    }
+  }
+}
+
 // backward, data AND weights in one pass over dy / x:
 //   dx[r, i] = (i < len_in) sum_j w[c, j] dym[r, i + p - j]          (the forward FIR with the taps flipped)
 //   dw[c, j] += sum_{b, t} dym[r, t] xm[r, t + j - p]
@@ -999,6 +1147,19 @@ static int dwconv_fwd_impl(const void* x, const int32_t* len_in, const int32_t* 
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
   if (aff.part && !pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) return TS_EUNSUPPORTED;
   if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
+    static const bool no_mfma = getenv("TS_DW_NO_MFMA") != nullptr;                 // diagnostic switch
+    if (act == 1 && batch >= 17 && !no_mfma) {
+      // bf16 rows, enough clips to fill the MFMA's N dimension: the depthwise as Toeplitz x clips on the matrix cores
+      const int pup = round_up(pad, 16), R = (k + 30 + pup - pad) / 16 + 1, NB = (R + 1) / 2;
+      const int n_cg = (batch + 31) / 32, n_blk = (t_out + 31) / 32;
+      int n_seg = (8 * cu_count() + ch * n_cg - 1) / (ch * n_cg);                     // ~2 waves per SIMD
+      n_seg = n_seg < 1 ? 1 : (n_seg > n_blk ? n_blk : n_seg);
+      const dim3 gridm((unsigned)(((long long)ch * n_cg * n_seg + 3) / 4));
+#define TS_DWM(NB_) if (NB == NB_) { hipLaunchKernelGGL(dw_fwd_mfma_kernel<NB_>, gridm, dim3(256), 0, stream, (const bf16_t*)x, len_in, len_out, w, \
+                                                        (bf16_t*)y, batch, ch, t_in, k, pad, pitch_in, n_seg, aff); return hip_status(hipGetLastError()); }
+      TS_DWM(1) TS_DWM(2) TS_DWM(3) TS_DWM(4) TS_DWM(5)
+#undef TS_DWM
+    }
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + PAIR_TAPS) * sizeof(v2f);
     // pairs per wave: 2 (the second pair's loads overlap the first one's FIR) once that still leaves >= 16 waves per CU
     const long long n_pairs = (long long)batch * ch / 2;
