@@ -76,6 +76,10 @@ struct TcsArgs {
 #ifdef TS_STAMP
   long long* dbg;              // diagnostic build only: s_memtime stamps of one workgroup
 #endif
+#ifdef TS_EXP
+  int exp;                     // diagnostic build only (tools/variants.py): bit 0 no epilogue stores, 1 no depthwise FIR, 4 no producer loads,
+                               // 2 no pointwise k-loop, 3 no epilogue at all -- wrong results, timing experiments only
+#endif
 };
 
 // [ci][t] bf16 tile of the depthwise output / identity input, 16-byte chunks XOR-swizzled so that both
@@ -788,6 +792,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
   constexpr int PHW = 32 * XJ;                    // DIL == 2: frames of a staged half row
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef TS_EXP
+  if (a.exp & 32) return;
+#endif
   char* const dwt = smem;                                             // [2][KC][ROWB]
   char* const cons0 = smem + 2 * TILEB;                               // [8][32][EP] epilogue tiles
   char* const prod0 = cons0 + 8 * ER * EP;                            // [4][XSB + 2 * TAPB]
@@ -963,15 +970,30 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
         vm_wait<0>();
         PSTAMP(8 * gs + 1);
         trow = tapl + (ds & 1) * TAPB + tap_off;
+#ifdef TS_EXP
+        if (!(a.exp & 16))
+#endif
         xs_write();
         PSTAMP(8 * gs + 2);
+#ifdef TS_EXP
+        if (!(a.exp & 2))
+#endif
         dw_begin();
+#ifdef TS_EXP
+        if (!(a.exp & 16)) {
+#endif
         dw_issue();                                   // rows of the next depthwise stage (possibly of the next tile)
         tap_dma((ds + 1) & 1, t_next);                // ... and its tap image, into the buffer the previous stage has finished with
+#ifdef TS_EXP
+        }
+#endif
         tap_advance();
         ++ds;
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(8 * gs + 3);
+#ifdef TS_EXP
+        if (!(a.exp & 2))
+#endif
         static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PSTAMP(8 * gs + 4);
@@ -1115,6 +1137,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     for (int s = 0; s < n_stage; ++s, ++gs) {
       const char* const src = dwt + (gs & 1) * TILEB;
       PSTAMP(8 * gs);
+#ifdef TS_EXP
+      if (!(a.exp & 4)) {
+#endif
       read_a(src, 0, af);
       read_a(src, 1, afB);
       __builtin_amdgcn_sched_barrier(0);
@@ -1127,6 +1152,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       mfma_ks(2, af);
       __builtin_amdgcn_sched_barrier(0);
       mfma_ks(3, afB);
+#ifdef TS_EXP
+      }
+#endif
       w_advance();
       PSTAMP(8 * gs + 1);
       stage_barrier();
@@ -1143,6 +1171,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     u32x4 keep = u32x4{~0u, ~0u, ~0u, ~0u};
     if (partial) keep = keep_first(keep, len_out - (tw + csub * 8));
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#ifdef TS_EXP
+    if (!(a.exp & 8))
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cob = (cot0 + nt) * 32;
@@ -1180,6 +1211,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #pragma unroll
           for (int i = 0; i < ER / 4; ++i) {
             if (partial) v[i] &= keep;
+#ifdef TS_EXP
+            if (!(a.exp & 1))
+#endif
             if (cob + half * ER + 4 * i + rsub < a.c_out) *reinterpret_cast<u32x4*>(yrow + (size_t)(4 * i) * a.pitch_out) = v[i];
           }
         }
@@ -1253,6 +1287,9 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   TcsArgs a{};
 #ifdef TS_STAMP
   { const char* e = getenv("TS_DBG_PTR"); a.dbg = e ? (long long*)strtoull(e, nullptr, 10) : nullptr; }
+#endif
+#ifdef TS_EXP
+  { const char* e = getenv("TS_EXP"); a.exp = e ? atoi(e) : 0; }
 #endif
   a.x = static_cast<const unsigned short*>(x);
   a.xres = static_cast<const unsigned short*>(x_res);
