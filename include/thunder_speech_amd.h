@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 4
+#define TS_ABI_VERSION 5
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -64,6 +64,11 @@ typedef struct ts_tcs_desc {
                                    NK k-steps as raw taps, bf16 [c_in_pad64/64][4 groups of 16 channels][KiB-padded image]; per channel
                                    16 NK + 16 bytes = two copies of wp[n] = w[n - 3 - (round_up(padding, 4) - padding)], n < 4 NK + 4, the
                                    second shifted by one element (plan.pack_dw_taps_raw).  With TS_TCS_TAPS_PHASE: the phase-split form. */
+  const void* dw_taps_t16;      /* stride-1, dilation-1 layers with kernel <= 81 (may be NULL): the "sliding window" tap image of the merged
+                                   kernel, bytes [c_in_pad64/64][8 groups of 8 channels][8][(32 NC + 16) * 8]: per channel, window p (8 bytes)
+                                   = wp[p .. p + 3], wp[i] = w[i - 15 + o + padding] (0 outside the taps), o = -8 ceil(padding / 8),
+                                   NC = dw_t16_chunks = ceil((padding + 16 - o) / 32)  (plan.pack_dw_taps_t16) */
+  int32_t dw_t16_chunks;        /* NC of dw_taps_t16 (1..3); 0 = no image */
   const void* pw_w;             /* bf16 [c_out_pad32/32][c_in_pad64/16][64][8]  MFMA B-fragments of W*bn_scale */
   const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */

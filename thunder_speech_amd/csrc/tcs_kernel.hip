@@ -26,14 +26,12 @@
 //  * residual 1x1 conv = extra stages over the block input whose "depthwise" is a copy, accumulating into the same
 //    registers; bias = initial accumulator value; ReLU + bf16 pack in the epilogue.
 //  * a lone wave issues an instruction only every ~8 cycles on this chip, so the steady state is kept almost VALU-free.
-#include "ts_common.hpp"
+#include "tcs_shared.hpp"
 
 #include <cstdlib>
-#include <type_traits>
 
 namespace ts {
 
-constexpr int KC = 64;         // input channels per stage
 constexpr int NKP = 3;         // depthwise k-steps (of 4 samples) per pass
 constexpr int XMAX = 5;        // staged row length <= 64 * XMAX elements
 constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
@@ -45,42 +43,6 @@ constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
 #endif
 constexpr int RING_BYTES = 8;   // weight-fragment prefetch depth: RING_BYTES KiB per wave in flight
 
-struct TcsArgs {
-  const unsigned short* x;     // [B][c_in][pitch_in]
-  const unsigned short* xres;  // [B][c_res][pitch_res]
-  void* y;                     // [B][c_out][pitch_out] bf16 or f32
-  const int* len_in;
-  const int* len_res;
-  const unsigned short* taps;  // [c_in_pad][4][4*nk]
-  const unsigned short* taps_raw;  // split kernel: raw tap image, see plan.pack_dw_taps_raw
-  const unsigned short* pw_w;  // fragments
-  const unsigned short* res_w;
-  const float* bias;
-  int batch, c_in, c_out, c_res;
-  int pitch_in, pitch_out, pitch_res;
-  int t_out;
-  int kernel, stride, dilation, padding;
-  int npass;                   // nk = 3 * npass
-  int woff;                    // padL8 - padL4: element offset of the lane windows inside an xs row
-  int padl8;                   // xs row starts at input frame t0*stride - padl8
-  int xe;                      // staged elements per xs row (multiple of 64)
-  int xuse;                    // elements of a row the depthwise actually reads
-  int xpitch;                  // xs row pitch in elements (8-byte aligned rows, pitch == 8 mod 16 bytes)
-  int relu;
-  int res_stride;
-  int kt_main, kt_res;         // k-steps (16 channels) in the packed weights = c_pad64 / 16
-  int taps_lds;                // 1: taps of the stage are cached in LDS
-  int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
-  int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
-  int xcd;                     // split kernel: 1 = XCD-contiguous tile order (grid is a multiple of 8)
-#ifdef TS_STAMP
-  long long* dbg;              // diagnostic build only: s_memtime stamps of one workgroup
-#endif
-#ifdef TS_EXP
-  int exp;                     // diagnostic build only (tools/variants.py): bit 0 no epilogue stores, 1 no depthwise FIR, 4 no producer loads,
-                               // 2 no pointwise k-loop, 3 no epilogue at all -- wrong results, timing experiments only
-#endif
-};
 
 // [ci][t] bf16 tile of the depthwise output / identity input, 16-byte chunks XOR-swizzled so that both
 // the 8-byte row writes and the transposed reads spread over the banks.
@@ -96,23 +58,6 @@ struct DwTile {
   }
 };
 
-__device__ __forceinline__ int conv_len(int len, int k, int s, int p, int d) {
-  const int num = len + 2 * p - d * (k - 1) - 1;
-  return num < 0 ? 0 : num / s + 1;
-}
-
-// LDS writes of this wave complete -> workgroup barrier.  Outstanding global loads stay in flight.
-__device__ __forceinline__ void stage_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-__device__ __forceinline__ unsigned relu_bf16x2(unsigned v) {
-  // max(x, 0) on two packed bf16: sign-magnitude floats order like signed 16-bit integers around zero
-  const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), s16x2{0, 0});
-  return __builtin_bit_cast(unsigned, r);
-}
 
 #ifdef TS_STAMP
 // Diagnostic build (tools/diag): stamps of workgroup 7, first tile only.  Never compiled into the product library.
@@ -701,51 +646,6 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
 // ======================================================================================================
 // helpers of the split kernel
 // ======================================================================================================
-// compile-time loop: f(std::integral_constant<int, I>) for I in [A, B)
-template <int A, int B, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (A < B) {
-    f(std::integral_constant<int, A>{});
-    static_for<A + 1, B>(f);
-  }
-}
-// at most N vector-memory operations outstanding (N is clamped to the 6-bit counter)
-template <int N>
-__device__ __forceinline__ void vm_wait() {
-  constexpr int n = N < 63 ? N : 63;
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15) | ((n >> 4) << 14));
-  asm volatile("" ::: "memory");
-}
-
-// position of a tile in the (clip, output-channel split, time tile) grid, advanced by the grid stride without divisions
-struct TilePos {
-  int b, z, tt;
-  int sb, sz, st;       // the stride, decomposed the same way
-  __device__ __forceinline__ void init(int tile, int step, int n_tt, int n_z) {
-    tt = tile % n_tt; z = (tile / n_tt) % n_z; b = (tile / n_tt) / n_z;
-    st = step % n_tt; sz = (step / n_tt) % n_z; sb = (step / n_tt) / n_z;
-  }
-  // branch-free conditional advance (scalar selects)
-  __device__ __forceinline__ void advance_if(bool go, int n_tt, int n_z) {
-    tt += go ? st : 0;
-    const int c1 = tt >= n_tt ? 1 : 0;
-    tt -= c1 ? n_tt : 0;
-    z += (go ? sz : 0) + c1;
-    const int c2 = z >= n_z ? 1 : 0;
-    z -= c2 ? n_z : 0;
-    b += (go ? sb : 0) + c2;
-  }
-  __device__ __forceinline__ void advance(int n_tt, int n_z) {
-    tt += st;
-    const int c1 = tt >= n_tt ? 1 : 0;
-    tt -= c1 ? n_tt : 0;
-    z += sz + c1;
-    const int c2 = z >= n_z ? 1 : 0;
-    z -= c2 ? n_z : 0;
-    b += sb + c2;
-  }
-};
-
 // ======================================================================================================
 // Split kernel: 12 waves = 8 consumer waves (pointwise GEMM, accumulators) + 4 producer waves (depthwise FIR).
 //
@@ -1137,6 +1037,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     for (int s = 0; s < n_stage; ++s, ++gs) {
       const char* const src = dwt + (gs & 1) * TILEB;
       PSTAMP(8 * gs);
+#ifdef TS_CONS_DELAY
+      __builtin_amdgcn_s_sleep(TS_CONS_DELAY);          // diagnostic: shift the consumers' burst behind the producers' memory phase
+#endif
 #ifdef TS_EXP
       if (!(a.exp & 4)) {
 #endif
@@ -1346,6 +1249,25 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     a.xpitch = a.xe + 4;                              // row pitch == 8 (mod 16) bytes: conflict-free window reads
     const int xj = a.xe / 64;
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
+    if (tz && d->stride == 1 && d->dilation == 1 && d->dw_taps_t16 && d->dw_t16_chunks > 0) {
+      // merged kernel (csrc/tcs_v3.hip): 192-frame x 256-channel tiles, depthwise on v_mfma_f32_16x16x32_bf16
+      // Opt-in (TS_TCS_V3=1): parity-green but NOT faster on MI355X -- its tap image and whole-row loads put 2.75x the bytes of the
+      // split kernel's depthwise inputs through the CU's vector-memory path
+      const char* const v3_env = getenv("TS_TCS_V3");
+      const bool no_v3 = !(v3_env && v3_env[0] == '1');
+      TcsArgs w = a;
+      w.taps_t16 = static_cast<const unsigned char*>(d->dw_taps_t16);
+      w.t16_nc = d->dw_t16_chunks;
+      w.t16_o = -8 * ((d->padding + 7) / 8);
+      const int n_ttp = (d->t_out + 191) / 192;
+      const bool fits = d->padding + 16 - w.t16_o <= 32 * w.t16_nc && d->kernel == 2 * d->padding + 1 &&
+                        (n_ttp - 1) * 192 + w.t16_o + 272 <= d->pitch_in && d->pitch_in - d->t_in >= -w.t16_o &&
+                        d->pitch_out >= n_ttp * 192 && (d->c_res == 0 || d->pitch_res >= n_ttp * 192);
+      if (fits && !no_v3) {
+        const int st = launch_v3(w, stream);
+        if (st != TS_EUNSUPPORTED) return st;
+      }
+    }
     if (tz && d->stride == 1 && a.npass <= 7) {
       // split kernel: 96-frame granules, its own window geometry
       TcsArgs w = a;

@@ -84,6 +84,34 @@ def pack_dw_taps_raw(w: torch.Tensor, padding: int) -> torch.Tensor:
     return out.to(torch.bfloat16).reshape(cp // KC, 4, tapb // 2).contiguous()
 
 
+def t16_geometry(kernel: int, padding: int) -> Tuple[int, int]:
+    """(o, NC) of the merged kernel's depthwise (csrc/tcs_v3.hip): an output segment of 16 frames starting at frame t reads the
+    input frames [t + o, t + o + 32 NC); o is the first frame of chunk 0 (a multiple of 8: 16-byte aligned loads)."""
+    o = -8 * ((padding + 7) // 8)
+    nc = (padding + 16 - o + 31) // 32
+    return o, nc
+
+
+def pack_dw_taps_t16(w: torch.Tensor, padding: int) -> Tuple[Optional[torch.Tensor], int]:
+    """w: [C, 1, K] depthwise taps of a stride-1, dilation-1 "same" conv (K = 2 padding + 1) -> (image, NC): the sliding-window tap
+    image of the merged kernel, uint8 [C_pad64/64][8][8][(32 NC + 16) * 8] (stage, wave, channel of the wave, bytes), or (None, 0)
+    when the kernel is too long (NC > 3).  Per channel, window p (8 bytes) holds wp[p .. p + 3] as bf16, wp[i] = w[i - 15 + o +
+    padding] (0 outside the taps): the Toeplitz fragment A_c[m][8 kg + j] = w[o + padding + 32 c + 8 kg + j - m] of
+    v_mfma_f32_16x16x32_bf16 is then the windows 8 kg - m + 15 + 32 c and + 4 -- two aligned 8-byte LDS reads per lane."""
+    c, _, k = w.shape
+    o, nc = t16_geometry(k, padding)
+    if nc > 3 or k != 2 * padding + 1:
+        return None, 0
+    npos = 32 * nc + 16
+    cp = round_up(c, KC)
+    wp = torch.zeros(cp, npos + 3, dtype=torch.float32, device=w.device)
+    lo = 15 - o - padding                      # wp index of tap 0
+    wp[:c, lo: lo + k] = w[:, 0, :]
+    img = torch.stack([wp[:, j: j + npos] for j in range(4)], dim=2)          # [C, p, 4]
+    img = img.to(torch.bfloat16).contiguous().view(torch.uint8)               # [C, p, 8]
+    return img.reshape(cp // KC, 8, 8, npos * 8).contiguous(), nc
+
+
 def raw_tap_channel_stride(nk: int) -> int:
     """Bytes per channel of the raw tap image (mirror of CST in csrc/tcs_kernel.hip)."""
     return 16 * nk + 16 if (16 * nk + 16) % 32 == 16 else 16 * nk + 32
@@ -145,6 +173,8 @@ class TcsLayer:
     nk_phase: int = 0
     taps_raw: Optional[torch.Tensor] = None        # stride 1: raw tap image of the split kernel (pack_dw_taps_raw)
     taps_phase_raw: Optional[torch.Tensor] = None
+    taps_t16: Optional[torch.Tensor] = None        # stride 1, dilation 1, K <= 81: sliding-window tap image of the merged kernel
+    t16_chunks: int = 0
 
     def out_size(self, t_in: int) -> int:
         return conv_out_size(t_in, self.kernel, self.stride, self.padding, self.dilation)
@@ -178,6 +208,8 @@ class TcsLayer:
         d.flags = (_lib.TCS_IN_TAILZERO if in_tail_zero else 0) | (_lib.TCS_OUT_ZERO_TAIL if zero_tail else 0)
         d.dw_taps = self.taps.data_ptr() if self.taps is not None else None
         d.dw_taps_raw = self.taps_raw.data_ptr() if self.taps_raw is not None else None
+        d.dw_taps_t16 = self.taps_t16.data_ptr() if self.taps_t16 is not None else None
+        d.dw_t16_chunks = self.t16_chunks
         d.pw_w = self.pw.data_ptr()
         d.bias = self.bias.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -226,8 +258,11 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
     if dw_w is not None:
         taps, nk = pack_dw_taps(cpu(dw_w), stride, dilation, padding)
     taps_phase, nk_phase, taps_raw, taps_phase_raw = None, 0, None, None
+    taps_t16, t16_chunks = None, 0
     if dw_w is not None and stride == 1 and dilation == 1:
         taps_raw = pack_dw_taps_raw(cpu(dw_w), padding).to(device)
+        taps_t16, t16_chunks = pack_dw_taps_t16(cpu(dw_w), padding)
+        taps_t16 = None if taps_t16 is None else taps_t16.to(device)
     if dw_w is not None and stride == 1 and dilation == 2 and padding % 2 == 0 and res_w is None:
         taps_phase, nk_phase = pack_dw_taps(cpu(dw_w), 1, 1, padding // 2)
         taps_phase = tap_fragments(taps_phase).to(device)
@@ -243,4 +278,4 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
                     depthwise=dw_w is not None, relu=relu, taps=None if taps is None else tap_fragments(taps).to(device), nk=nk,
                     pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
                     res_stride=res_stride, out_fp32=out_fp32, taps_phase=taps_phase, nk_phase=nk_phase, taps_raw=taps_raw,
-                    taps_phase_raw=taps_phase_raw)
+                    taps_phase_raw=taps_phase_raw, taps_t16=taps_t16, t16_chunks=t16_chunks)
