@@ -37,13 +37,13 @@ def pmc_traffic(batch, seconds):
     separate runs, gfx950 correction applied; tools/prof_bench.sh writes profiles/*_traffic.json).  Counters cannot be read
     from inside the timed process, so this is the committed measurement; None for any other workload."""
     if (batch, seconds) != (64, 15):
-        return None
+        return None, None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
-        return json.load(f).get("traffic_bytes_per_launch")
+        return json.load(f).get("traffic_bytes_per_launch"), "committed PMC pass, profiles/" + os.path.basename(files[-1])
 
 
 def build_model(device, seed=0):
@@ -61,10 +61,15 @@ def encoder_layers(module):
     return layers
 
 
-def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16):
+CPU_THREAD_SWEEP = {8: 117, 16: 167, 32: 104, 64: 73}     # audio-s/s of this oracle on the pool's 256-core host (tools/cpu_threads.py)
+
+
+def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16, wav=None, keep_logits=False):
     """Oracle (port of the reference path) on the host cores, bounded sample.  16 threads is where torch-CPU
-    peaks for this model on the GPU box's 256-core host (8: 117, 16: 167, 32: 104, 64: 73 audio-s/s measured);
-    more threads only add synchronisation overhead, so `cores` reports the threads actually used."""
+    peaks for this model on the GPU box's 256-core host (CPU_THREAD_SWEEP, measured with tools/cpu_threads.py);
+    more threads only add synchronisation overhead, so `cores` reports the threads actually used and `host_cores` what the box has.
+    `wav` (CPU, [clips, samples]): time the oracle on these clips -- bench.py passes the first clips of the GPU batch, so that the
+    logits of the first pass double as the full-size parity check of the headline configuration."""
     from oracle import frontend as ofe
     from oracle import tcs as otcs
     from oracle import decode as odec
@@ -72,9 +77,12 @@ def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16):
     arch = otcs.quartznet_arch(repeat_blocks=3)
     sd = {k: v.detach().cpu() for k, v in module.encoder.state_dict().items()}
     dsd = {k: v.detach().cpu() for k, v in module.decoder.state_dict().items()}
-    g = torch.Generator().manual_seed(1234)
-    wav = 0.1 * torch.randn(clips, 16000 * seconds, generator=g)
+    if wav is None:
+        g = torch.Generator().manual_seed(1234)
+        wav = 0.1 * torch.randn(clips, 16000 * seconds, generator=g)
+    clips = wav.shape[0]
     lengths = torch.full((clips,), 16000 * seconds)
+    kept = {}
 
     def run():
         with torch.no_grad():
@@ -82,14 +90,42 @@ def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16):
             enc, _ = otcs.encoder_forward(arch, sd, feats, fl)
             logits = otcs.conv1d_decoder_forward(dsd, enc)
             ids = logits.argmax(1).numpy()
+            if keep_logits and not kept:
+                kept["logits"] = logits
             return [odec.collapse_repeats(r) for r in ids]
     run()
     t0 = time.perf_counter()
     for _ in range(iters):
         run()
     dt = (time.perf_counter() - t0) / iters
-    return {"value": clips * seconds / dt, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"QuartzNet15x5 fp32 oracle, {clips}x{seconds} s clips, {iters} timed passes after 1 warm-up"}
+    res = {"value": clips * seconds / dt, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+           "kind": "port", "thread_sweep_audio_s_per_s": {str(k): v for k, v in CPU_THREAD_SWEEP.items()},
+           "sample": f"QuartzNet15x5 fp32 oracle, {clips}x{seconds} s clips (the first {clips} of the GPU batch), {iters} timed passes "
+                     "after 1 warm-up"}
+    if keep_logits:
+        res["_logits"] = kept["logits"]
+    return res
+
+
+def parity_check(gpu_logits, ref_logits, gpu_ids, labels_blank=28):
+    """HIP logits [n, V, T'] (bf16 activations) vs the fp32 oracle's on the same clips: error relative to the logit scale, argmax
+    agreement on the frames the oracle decides by more than 6 sigma of the measured error, and the greedy strings of those clips
+    (strings are compared on the decided frames' collapse: a near-tie frame may legitimately flip under bf16 rounding)."""
+    import numpy as np
+    got = gpu_logits.float().cpu().numpy()
+    ref = ref_logits.float().numpy()
+    scale = float(np.abs(ref).max())
+    err = got - ref
+    rms = float(np.sqrt(np.mean(err.astype(np.float64) ** 2)))
+    top2 = np.sort(ref, axis=1)[:, -2:, :]
+    decided = (top2[:, 1] - top2[:, 0]) > 6 * rms
+    a_got, a_ref = got.argmax(1), ref.argmax(1)
+    agree_decided = bool(np.array_equal(a_got[decided], a_ref[decided]))
+    return {"vs": f"fp32 oracle logits on the first {got.shape[0]} clips of the batch, all {got.shape[2]} frames",
+            "max_err_over_scale": float(np.abs(err).max()) / scale, "rms_err_over_scale": rms / scale, "logit_scale": scale,
+            "decided_frames_frac": float(decided.mean()), "argmax_equal_on_decided_frames": agree_decided,
+            "argmax_equal_all_frames_frac": float((a_got == a_ref).mean()),
+            "device_argmax_equals_host_argmax_of_device_logits": bool(np.array_equal(gpu_ids, a_got)), "finite": bool(np.isfinite(got).all())}
 
 
 def main():
@@ -188,6 +224,7 @@ def main():
     n_launch = len(layers)
     achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
     value = world * B * S * args.steps / dt
+    traffic, traffic_source = pmc_traffic(B, S)
     result = {
         "metric": "audio-seconds/s (16 kHz) QuartzNet15x5 inference",
         "value": value, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -201,14 +238,27 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "ts::tcs_split_kernel / ts::tcs_kernel (all fused TCS launches of one step)",
                      "launches_per_step": n_launch,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(B, S),
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": alg_bytes / n_launch, "avg_launch_us": enc_ms * 1e3 / n_launch,
                      "encoder_ms": enc_ms, "mfma_tflops": alg_flops / (enc_ms * 1e-3) / 1e12,
                      "mfma_frac_of_dense_bf16_peak": alg_flops / (enc_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF},
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(module)
+            n_chk = min(16, B)
+            result["cpu_baseline"] = cpu_baseline(module, seconds=S, wav=wav[:n_chk].cpu(), keep_logits=True)
+            ref_logits = result["cpu_baseline"].pop("_logits")
+            with torch.no_grad():
+                logits, _ = module(wav, lengths)
+                ids, collapsed, counts = greedy_decode(logits)
+                torch.cuda.synchronize()
+            result["check"] = parity_check(logits[:n_chk], ref_logits, ids[:n_chk].cpu().numpy())
+            from oracle import decode as odec
+            ref_seqs = [list(odec.collapse_repeats(r)) for r in ref_logits.argmax(1).numpy()]
+            dev_seqs = [collapsed[i, : int(counts[i])].cpu().tolist() for i in range(n_chk)]
+            result["check"]["collapsed_sequences_equal"] = sum(int(a == b) for a, b in zip(ref_seqs, dev_seqs))
+            result["check"]["collapsed_sequences_compared"] = n_chk
+            result["check"]["all_logits_finite"] = bool(torch.isfinite(logits).all())
             one = cpu_baseline(module, clips=2, seconds=15, iters=1, threads=1)
             result["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
         if not args.no_extra and world == 1:

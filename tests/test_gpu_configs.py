@@ -76,6 +76,51 @@ def test_padding_region_never_leaks():
     assert torch.isfinite(outs[2]).all()
 
 
+def test_c2_full_size_batch_is_finite_tail_zeroed_and_batch_independent():
+    """BASELINE configs[1] at its real size: QuartzNet15x5, 64 clips of 15 s (ragged lengths so that the zero tails mean something).
+    Logits are finite; every library-owned (arena) activation buffer of the pass holds 0 from each clip's length to the pitch (the
+    invariant the mask-free kernels rely on); and the first 16 clips come out bit-identical when they are run as
+    a batch of 16 (clips are independent units -- the reference's _test_batch_independence, tests/utils.py:70-97 -- and the tile
+    schedule must not change the arithmetic).  bench.py compares the same configuration with the fp32 oracle on 16 clips."""
+    from thunder_speech_amd import _lib, tensors as TS
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.utils import variance_preserving_init_
+    module = build_synthetic_quartznet(repeat_blocks=3)
+    variance_preserving_init_(module.encoder, module.decoder, seed=0)
+    module = module.cuda().eval()
+    b, n = 64, 240000
+    g = torch.Generator().manual_seed(1234)
+    wav = (0.1 * torch.randn(b, n, generator=g)).cuda()
+    lengths = torch.linspace(0.5, 1.0, b).mul(n).floor()
+    lengths[0] = n
+    for i in range(b):
+        wav[i, int(lengths[i]):] = 0
+    TS._ARENA.clear()
+    with torch.no_grad():
+        logits, out_len = module(wav, lengths.cuda())
+        torch.cuda.synchronize()
+        assert logits.shape == (b, 29, 751) and torch.isfinite(logits).all()
+        fl = torch.div(lengths, 160, rounding_mode="floor") + 1                      # quartznet/transform.py:182-184
+        el = torch.div(fl + 2 * 16 - 32 - 1, 2, rounding_mode="floor") + 1           # stride-2 stem, quartznet/blocks.py:149-155
+        assert torch.equal(out_len.cpu().to(torch.int64), el.to(torch.int64))
+        checked = 0
+        for key, flat in TS._ARENA.items():
+            _, kb, kc, pitch = key[:4]
+            if kb != b or pitch not in (_lib.time_pitch(751), _lib.time_pitch(1501)):
+                continue
+            lens = el if pitch == _lib.time_pitch(751) else fl
+            buf = flat[TS._GUARD: TS._GUARD + kb * kc * pitch].view(kb, kc, pitch)
+            cols = torch.arange(pitch, device="cuda").view(1, 1, pitch)
+            tail = cols >= lens.cuda().view(kb, 1, 1)
+            assert float(buf.float().abs().mul(tail).max()) == 0.0, f"arena buffer {key[:4]} has a non-zero tail"
+            assert float(flat[: TS._GUARD].float().abs().max()) == 0.0 and float(flat[-TS._GUARD:].float().abs().max()) == 0.0
+            checked += 1
+        assert checked >= 3                                                          # features, block input, ping-pong slots
+        logits16, _ = module(wav[:16], lengths[:16].cuda())
+        torch.cuda.synchronize()
+    assert torch.equal(logits[:16], logits16)
+
+
 @pytest.mark.parametrize("kind", ["depthwise", "depthwise_s2", "pointwise", "pointwise_bias"])
 def test_standalone_masked_conv1d_matches_oracle(kind):
     """MaskedConv1d.forward on its own (quartznet/blocks.py:169-182): depthwise via the identity-pointwise launch, 1x1 directly;

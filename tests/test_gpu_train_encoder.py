@@ -93,6 +93,49 @@ def test_unfrozen_finetune_step_decreases_loss():
     assert losses[-1] < losses[0], losses
 
 
+def test_frozen_schedule_runs_the_encoder_in_train_mode_and_trains_batchnorm_only():
+    """What the reference's first fine-tuning phase really is (callbacks.py:56-62 -> Lightning ^1.7 BaseFinetuning.freeze): the
+    encoder's conv weights stop receiving gradients, its BatchNorm parameters keep them (train_batchnorm=True), and NO module leaves
+    train mode -- so the step is a train-mode forward (batch statistics, running-stat updates) and a backward through the whole
+    encoder that reaches the BatchNorm parameters."""
+    from torch import nn
+    from thunder_speech_amd.callbacks import FinetuneEncoderDecoder
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    arch = otcs.quartznet_arch(repeat_blocks=1)
+    m = build_synthetic_quartznet(repeat_blocks=1, encoder_state=otcs.synth_encoder_state(arch, seed=0, calibrate=True),
+                                  decoder_state=otcs.synth_decoder_state(1024, 29, seed=1)).cuda().train()
+    FinetuneEncoderDecoder(train_batchnorm=True).freeze_before_training(m)
+    bns = [x for x in m.encoder.modules() if isinstance(x, nn.BatchNorm1d)]
+    convs = [x for x in m.encoder.modules() if isinstance(x, nn.Conv1d)]
+    rm0 = [b.running_mean.clone() for b in bns]
+    g = torch.Generator().manual_seed(9)
+    wav = (0.1 * torch.randn(3, 24000, generator=g)).cuda()
+    lengths = torch.tensor([24000.0, 20000.0, 16000.0]).cuda()
+    loss = m.training_step((wav, lengths, ["abc", "hello", "data"]), 0)
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(c.weight.grad is None for c in convs)
+    assert all(b.weight.grad is not None and torch.isfinite(b.weight.grad).all() and float(b.weight.grad.abs().max()) > 0 for b in bns)
+    assert m.decoder.weight.grad is not None
+    assert all(not torch.equal(a, b.running_mean) for a, b in zip(rm0, bns))             # train-mode BatchNorm: statistics moved
+    assert all(int(b.num_batches_tracked) == 1 for b in bns)
+
+
+def test_batchnorm_in_eval_mode_inside_a_training_block_is_refused():
+    """the training kernels always normalise with batch statistics; a BatchNorm1d that was switched to eval() while
+    its block trains must not silently do that (nn.BatchNorm1d would use -- and keep -- its running statistics)."""
+    from torch import nn
+    from thunder_speech_amd.quartznet.blocks import QuartznetBlock
+    blk = QuartznetBlock(64, 64, repeat=2, kernel_size=(11,), separable=True).cuda().train()
+    bn = next(x for x in blk.modules() if isinstance(x, nn.BatchNorm1d))
+    bn.eval()
+    rm = bn.running_mean.clone()
+    x = torch.randn(2, 64, 100, device="cuda")
+    with pytest.raises(NotImplementedError):
+        blk(x, torch.tensor([100, 60], device="cuda"))
+    assert torch.equal(rm, bn.running_mean)
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_bf16_activation_mode_stays_within_bf16_tolerance(golden, name):
     """train_ops.set_activation_dtype("bf16") (mixed precision): activations and their gradients stored as bf16, f32 arithmetic in

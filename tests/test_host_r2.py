@@ -79,12 +79,18 @@ def test_finetune_schedule_freezes_and_unfreezes_like_base_finetuning():
     assert len(opt.param_groups) == n0 + 1 and abs(opt.param_groups[-1]["lr"] - 1e-3 / 5) < 1e-12
     ids = [id(p) for g in opt.param_groups for p in g["params"]]
     assert len(ids) == len(set(ids))                                    # no parameter in two groups
-    # train_batchnorm = False: BatchNorm frozen too until the unfreeze
+    # train_batchnorm = False: BatchNorm parameters frozen too until the unfreeze.  Like Lightning ^1.7's BaseFinetuning.freeze the
+    # schedule flips requires_grad ONLY: every module keeps its train flag (batch statistics, active Dropout)
     m2 = load_pretrained("QuartzNet5x5_synthetic").train()
     cb2 = FinetuneEncoderDecoder(train_batchnorm=False)
     cb2.freeze_before_training(m2)
     assert not any(p.requires_grad for p in m2.encoder.parameters())
-    assert not any(b.training for b in m2.encoder.modules() if isinstance(b, nn.BatchNorm1d))
+    assert all(x.training for x in m2.encoder.modules())
+    opt2 = torch.optim.AdamW([p for p in m2.parameters() if p.requires_grad], lr=1e-3)
+    cb2.finetune_function(m2, 1, opt2)                                  # train_bn = not train_batchnorm = True: BatchNorm joins too
+    assert all(p.requires_grad for p in m2.encoder.parameters())
+    assert {id(p) for p in m2.encoder.parameters()} <= {id(p) for g in opt2.param_groups for p in g["params"]}
+    assert all(x.training for x in m.encoder.modules())                 # the first schedule left the flags alone as well
 
 
 def test_packed_cache_sees_version_bumps():

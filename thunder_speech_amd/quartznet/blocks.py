@@ -198,6 +198,13 @@ class _FusedBlockBase(nn.Module):
         (mixed precision), see train_ops.set_activation_dtype.  Returns activation rows: a [B, C, T] view with a padded pitch."""
         from .. import train_ops as T
         _t.require_gpu(x, type(self).__name__)
+        # The training kernels normalise with batch statistics and update the running ones (nn.BatchNorm1d in train mode).  A
+        # BatchNorm switched to eval() inside a training-mode block would need running-statistics normalisation with no update:
+        # refuse it rather than silently use batch statistics (the reference's fine-tuning schedule never produces this state:
+        # BaseFinetuning.freeze flips requires_grad only, callbacks.py)
+        if any(isinstance(m, nn.BatchNorm1d) and not m.training for m in self.modules()):
+            raise NotImplementedError(f"{type(self).__name__}: a BatchNorm1d in eval mode inside a training-mode block has no HIP "
+                                      "kernel; put the whole block in eval() (inference launches) or the BatchNorm in train()")
         # Dropout modules of the reference tree: after the ReLU of every repeat but the last (mconv), and after the block's
         # final ReLU (mout) -- quartznet/blocks.py:227-228; each follows its own training flag like nn.Dropout does
         drops = [m.layer[0] for m in self.mconv if isinstance(m, Masked) and isinstance(m.layer[0], nn.Dropout)]
