@@ -261,11 +261,24 @@ def main():
             result["check"]["all_logits_finite"] = bool(torch.isfinite(logits).all())
             one = cpu_baseline(module, clips=2, seconds=15, iters=1, threads=1)
             result["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
+    # C4 as the reference runs it (DDP, strong scaling: global batch 256 x 10 s over the ranks), on EVERY N: all ranks take part
+    c4_ddp = None
+    if not args.no_extra and "c4" in args.extra.split(","):
+        del module
+        module = None
+        torch.cuda.empty_cache()
+        from tools import bench_extra
+        try:
+            c4_ddp = bench_extra.c4_ddp(device, world=world, rank=rank)
+        except Exception as e:                       # an extra must never take the headline line down with it
+            c4_ddp = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    if rank == 0:
         if not args.no_extra and world == 1:
-            del module
-            torch.cuda.empty_cache()
             from tools import bench_extra
             result["extra"] = bench_extra.run(device, tuple(n for n in args.extra.split(",") if n), check=not args.no_cpu_baseline)
+        if c4_ddp is not None:
+            result.setdefault("extra", {})["c4_ddp"] = c4_ddp
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -210,3 +210,62 @@ def test_two_rank_training_step_equals_one_process_averaging_two_independent_bat
             assert torch.allclose(got, v, rtol=1e-5, atol=1e-6), (rank, k, float((got - v).abs().max()))
     for k in want:                                                           # replicas stay bit-identical
         assert (results[0][0][k] == results[1][0][k]).all(), k
+
+
+def _wire_worker(rank, world, port, out):
+    """The GPU branch's exchange arithmetic on CPU tensors: bf16 wire with the 1 / world scaling inside the pack, reduce-scatter +
+    all-gather (spelled out over gloo), unpack to fp32."""
+    from thunder_speech_amd.parallel import GradientSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        params = [torch.nn.Parameter(torch.randn(n, generator=g)) for n in (1000, 37, 4096, 5)]
+        sync = GradientSync(params, bucket_bytes=8192, wire_dtype=torch.bfloat16, collective="reduce_scatter")
+        sync.zero_grad()
+        gr = torch.Generator().manual_seed(100 + rank)
+        grads = [torch.randn(p.shape, generator=gr) for p in params]
+        loss = sum((p * gg).sum() for p, gg in zip(params, grads))            # dL/dp = this rank's random gradient
+        loss.backward()
+        sync.finish()
+        out.put((rank, [p.grad.detach().clone().numpy() for p in params], sync.n_collectives, len(sync.buckets), sync.wire_bytes))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_wire_reduce_scatter_all_gather_arithmetic_at_world_2():
+    """ts_grad_wire_pack / unpack + reduce-scatter + all-gather, as GradientSync runs them on the GPUs (parallel.py _launch), checked
+    at world 2 over gloo: the averaged gradient is bf16(bf16(g0 / 2) + bf16(g1 / 2)) -- one rounding per rank in the pack, one in the
+    bf16 sum -- on EVERY rank bit for bit, and within bf16 resolution of the fp32 mean."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, grads, n_coll, n_buckets, wire_bytes = out.get(timeout=300)
+        res[rank] = (grads, n_coll, n_buckets, wire_bytes)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    shapes = (1000, 37, 4096, 5)
+    local = []
+    for rank in range(2):
+        gr = torch.Generator().manual_seed(100 + rank)
+        local.append([torch.randn(n, generator=gr) for n in shapes])
+    for i, n in enumerate(shapes):
+        a, b = local[0][i], local[1][i]
+        want = ((a * 0.5).to(torch.bfloat16).float() + (b * 0.5).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+        for rank in range(2):
+            got = torch.from_numpy(res[rank][0][i])
+            assert torch.equal(got, want), (rank, i, float((got - want).abs().max()))
+        mean = (a + b) / 2
+        assert float((want - mean).abs().max()) <= 2 ** -7 * float(mean.abs().max())
+    n_buckets = res[0][2]
+    assert n_buckets >= 2 and res[0][1] == 2 * n_buckets                       # reduce-scatter + all-gather per bucket
+    assert res[0][3] == res[1][3] and res[0][3] >= 2 * sum(shapes)             # bf16: two bytes per gradient element on the wire

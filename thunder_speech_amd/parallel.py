@@ -47,11 +47,12 @@ class GradientSync:
       * buckets are filled in REVERSE parameter order (the order gradients become ready) and each bucket's collective is
         launched from a post-accumulate hook the moment its last gradient has landed, on a side stream: it overlaps the rest of
         the backward pass; `finish()` (call it before the optimizer step) makes the compute stream wait for the side stream;
-      * wire format bf16 (half the bytes over the links; the mean is formed by pre-scaling with 1 / world inside the pack
-        kernel, ts_grad_wire_pack) and reduce-scatter + all-gather instead of a ring all-reduce, so that RCCL can drive all
-        seven links of a GPU at once; few large buckets (default 32 MiB of fp32 gradient each).
-    CPU tensors (the gloo tests) take the same bucket / hook logic with fp32 on the wire and a plain all-reduce (gloo has no
-    reduce-scatter), synchronously.
+      * the wire follows the precision mode: fp32 by default (what the reference's DDP averages), bf16 when the training path runs with
+        bf16 activations (half the bytes over the links; the mean is formed by pre-scaling with 1 / world inside the pack kernel,
+        ts_grad_wire_pack); reduce-scatter + all-gather instead of a ring all-reduce, so that RCCL can drive all seven links of a
+        GPU at once; few large buckets (default 32 MiB of fp32 gradient each).
+    CPU tensors (the gloo tests) take the same bucket / hook logic, by default with fp32 on the wire and a plain all-reduce; asked for
+    the GPU branch's form (wire_dtype=bf16, collective="reduce_scatter") they spell the same arithmetic out over gloo, synchronously.
 
         sync = GradientSync(trainable_parameters)
         loss.backward(); sync.finish(); optimizer.step(); optimizer.zero_grad(set_to_none=False)   # keep the views!
@@ -68,7 +69,12 @@ class GradientSync:
         self.device = dev
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         on_gpu = dev.type == "cuda"
-        self.wire_dtype = wire_dtype if wire_dtype is not None else (torch.bfloat16 if on_gpu else torch.float32)
+        if wire_dtype is None:
+            # the wire follows the precision mode: fp32 (the reference's DDP averages fp32 gradients) unless the training path runs in
+            # its mixed-precision mode (bf16 activations, train_ops.set_activation_dtype), where bf16 halves the bytes on the links
+            from . import train_ops
+            wire_dtype = torch.bfloat16 if (on_gpu and train_ops.activation_dtype() == torch.bfloat16) else torch.float32
+        self.wire_dtype = wire_dtype
         self.collective = collective or ("reduce_scatter" if on_gpu else "all_reduce")
         if self.collective not in ("reduce_scatter", "all_reduce"):
             raise ValueError("collective must be 'reduce_scatter' or 'all_reduce'")
@@ -106,6 +112,7 @@ class GradientSync:
         self._launched = [False] * len(self.buckets)
         self._side = torch.cuda.Stream(device=dev) if on_gpu else None
         self.n_collectives = 0
+        self.wire_bytes = 0                     # bytes this rank has put on the wire (per direction), summed over the collectives
         self._hold = False
         self._clean = True                      # the flat buffer holds zeros only (between zero_grad() and the first gradient of the step)
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(idx)) for idx, p in enumerate(self.params)]
@@ -139,6 +146,7 @@ class GradientSync:
         else:
             import contextlib
             ctx = contextlib.nullcontext()
+        self.wire_bytes += length * (2 if self.wire_dtype == torch.bfloat16 else 4)
         with ctx:
             if self.wire_dtype == torch.float32:
                 wire = seg
@@ -150,8 +158,19 @@ class GradientSync:
                     st = _lib.lib().ts_grad_wire_pack(seg.data_ptr(), wire.data_ptr(), length, 1.0 / self.world, self._side.cuda_stream)
                     _lib.check(st, "ts_grad_wire_pack")
                 else:
-                    wire.copy_(seg * (1.0 / self.world))
-            if self.collective == "reduce_scatter":
+                    wire.copy_(seg * (1.0 / self.world))      # what ts_grad_wire_pack does: scale in fp32, one rounding to the wire type
+            if self.collective == "reduce_scatter" and not seg.is_cuda:
+                # CPU (gloo has neither reduce-scatter nor bf16 sums): the same arithmetic, spelled out -- every rank's shard is the
+                # sum of the ranks' wire values ROUNDED TO THE WIRE TYPE, and the shards are then gathered
+                rank = dist.get_rank()
+                total = wire.to(torch.float32)
+                dist.all_reduce(total, op=dist.ReduceOp.SUM)
+                shard = total.view(self.world, -1)[rank].to(wire.dtype)
+                parts = [torch.empty_like(shard) for _ in range(self.world)]
+                dist.all_gather(parts, shard)
+                wire.copy_(torch.cat(parts))
+                self.n_collectives += 2
+            elif self.collective == "reduce_scatter":
                 shard = wire.view(self.world, -1)[dist.get_rank()]
                 dist.reduce_scatter_tensor(shard, wire, op=dist.ReduceOp.SUM)
                 dist.all_gather_into_tensor(wire, shard)

@@ -367,6 +367,10 @@ def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor, len_u: Tensor = No
     du = alloc_like(u)
     if _tcs_ok(bf, c_out) and c_in % 8 == 0:
         _tcs_pointwise(dv, pw_frags(param, w2)[1], du, _full_lengths(b, t, u.device), c_in)
+        if not param.requires_grad:
+            # frozen weight (the first phase of the reference's fine-tuning schedule freezes the convolutions but still backpropagates
+            # through them to the BatchNorm parameters, callbacks.py): the data gradient is all that is needed
+            return du, None
         dw = grad_out(param, (c_out, c_in), zeroed=True)
         _wgrad(dv, u, dw, len_u)
         return du, dw
@@ -487,7 +491,7 @@ class PointwiseConv(torch.autograd.Function):
         w = ctx.param
         dv = _import(dv, u.dtype)                      # bf16 mode: the f32 logit gradient becomes a bf16 GEMM operand
         du, dw = _pw_bwd(dv, u, w, w.detach().to(torch.float32).contiguous().view(w.shape[0], -1))
-        return du, dw.view(ctx.wshape), None
+        return du, None if dw is None else dw.view(ctx.wshape), None
 
 
 class BatchNormTrain(torch.autograd.Function):
@@ -803,7 +807,7 @@ class SubBlock(torch.autograd.Function):
                            "ts_train_mask_time")
             else:
                 dx = dmid            # the consumer of this gradient (Fork with res_len) applies the input mask's backward
-        return dx, ddw, dpw.view(ctx.shapes[1]), dg, db, dg_in, db_in, None
+        return dx, ddw, None if dpw is None else dpw.view(ctx.shapes[1]), dg, db, dg_in, db_in, None
 
 
 def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Tensor, len_out: Tensor, relu: bool, drop_p: float = 0.0,

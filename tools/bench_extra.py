@@ -160,13 +160,21 @@ def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
     from thunder_speech_amd.train_graph import GraphedTrainStep
     # phase 2 twice: the mixed-precision path (bf16 activations, f32 master weights / gradients / statistics; fwd+bwd replayed from one
     # hipGraph) is the measured configuration; the f32 path (the reference's arithmetic, what the parity tests check) is reported beside it
-    for tag, phase, steps, act, graph in (("c4_phase1", 1, steps1, "fp32", False), ("c4_phase2", 2, steps2, "bf16", True),
+    # phase 1 as the reference's schedule leaves the model (callbacks.py:56-62 -> BaseFinetuning.freeze: the encoder's convolutions stop
+    # receiving gradients, its BatchNorm parameters keep them, every module stays in train mode), and -- labelled as what it is -- the
+    # cheaper variant with the encoder in eval mode and fully frozen (train_batchnorm=False plus an explicit encoder.eval()), where front
+    # end + encoder replay from a hipGraph
+    from thunder_speech_amd.callbacks import FinetuneEncoderDecoder
+    for tag, phase, steps, act, graph in (("c4_phase1", 1, steps1, "bf16", True), ("c4_phase1_eval_frozen", 0, steps1, "fp32", False),
+                                          ("c4_phase2", 2, steps2, "bf16", True),
                                           ("c4_phase2_fp32", 2, max(steps2 // 3, 5), "fp32", False)):
         torch.manual_seed(0)
         m = build_synthetic_quartznet(repeat_blocks=3)
         variance_preserving_init_(m.encoder, m.decoder, seed=0)
         m = m.to(device).train()
         if phase == 1:
+            FinetuneEncoderDecoder(train_batchnorm=True).freeze_before_training(m)
+        if phase == 0:
             m.encoder.eval()
             for p in m.encoder.parameters():
                 p.requires_grad_(False)
@@ -198,21 +206,97 @@ def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
             last = float(step())
         finally:
             train_ops.set_activation_dtype("fp32")
-        model_flop = (3.0 if phase == 2 else 1.0) * fwd_gflop      # phase 1: forward only through the frozen encoder
-        how = ("encoder frozen + hipGraph-replayed, decoder trainable" if phase == 1 else
+        model_flop = (3.0 if phase == 2 else (2.0 if phase == 1 else 1.0)) * fwd_gflop      # phase 1: forward + data gradients; eval-frozen: forward only
+        how = ("encoder in eval mode and fully frozen (NOT the reference schedule's state: an explicit encoder.eval()), front end + encoder "
+               "hipGraph-replayed, decoder trainable" if phase == 0 else
+               "reference schedule's first phase: encoder convolutions frozen, BatchNorm parameters + decoder trainable, encoder in TRAIN mode "
+               "(batch statistics); bf16 activations, forward + backward from one hipGraph" if phase == 1 else
                "everything trainable, " + ("bf16 activations (mixed precision: f32 master weights, gradients, BatchNorm statistics), encoder + decoder + "
                                            "CTC + backward replayed from one hipGraph" if act == "bf16" else "f32 activations (the reference's arithmetic), eager launches"))
         out[tag] = {
             "workload": f"QuartzNet15x5 fine-tune step (CTC), local batch {local_batch}x{seconds} s, {how} (BASELINE.json configs[3], one rank's share)",
             "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s", "audio_seconds_per_s": local_batch * seconds / dt,
             "steps": steps, "c_abi_calls_per_step": calls, "dtype": act, "loss_first_last": [first, last],
-            "roofline": {"bound": "mfma", "model": "3 x forward FLOPs (BASELINE.md section 3)" if phase == 2 else "1 x forward FLOPs (frozen encoder)",
+            "roofline": {"bound": "mfma", "model": "3 x forward FLOPs (BASELINE.md section 3)" if phase == 2 else
+                                                    ("2 x forward FLOPs (no weight gradients in the encoder)" if phase == 1 else "1 x forward FLOPs (frozen encoder)"),
                          "achieved": model_flop / dt / 1e3, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": model_flop / dt / 1e3 / MFMA_BF16_PEAK_TF, "frac_of_fp32_vector_peak": model_flop / dt / 1e3 / FP32_PEAK_TF}}
         sync.close()
         del m, opt, sync, graphed
         torch.cuda.empty_cache()
     return out
+
+
+def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8):
+    """BASELINE.json configs[3] as the reference runs it (Trainer(strategy="ddp"), tests/quartznet/test_module_qn.py:33-53): QuartzNet15x5
+    fine-tuning, everything trainable, GLOBAL batch 256 x 10 s split over the ranks (strong scaling: local batch 256 / world), one
+    gradient exchange per step (parallel.GradientSync: bf16 wire, reduce-scatter + all-gather over RCCL), FusedAdamW, forward + backward
+    replayed from a hipGraph.  Every rank runs it; the time is the MAX over ranks between two barriers.  `exchange_ms_exposed` is the
+    step time minus the time of the same step with the exchange switched off (what the links cost after overlap)."""
+    from thunder_speech_amd import train_ops
+    from thunder_speech_amd.optim import FusedAdamW
+    from thunder_speech_amd.parallel import GradientSync, max_over_ranks
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.train_graph import GraphedTrainStep
+    from thunder_speech_amd.utils import variance_preserving_init_
+    import torch.distributed as dist
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} does not split over {world} ranks")
+    local = global_batch // world
+    g = torch.Generator().manual_seed(1234 + rank)
+    wav = (0.1 * torch.randn(local, 16000 * seconds, generator=g)).to(device)
+    lengths = torch.full((local,), 16000.0 * seconds, device=device)
+    texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(60, 140, (local,), generator=g)]
+    torch.manual_seed(0)
+    m = build_synthetic_quartznet(repeat_blocks=3)
+    variance_preserving_init_(m.encoder, m.decoder, seed=0)          # same seed on every rank: replicas start identical
+    m = m.to(device).train()
+    train_ops.set_activation_dtype("bf16")
+    try:
+        trainable = [p for p in m.parameters() if p.requires_grad]
+        opt, sync = FusedAdamW(trainable, lr=1e-3), GradientSync(trainable)
+        graphed = GraphedTrainStep(m, opt, sync, max_target_len=160)
+        step = lambda: graphed((wav, lengths, texts))
+
+        def timed(n):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return max_over_ranks((time.perf_counter() - t0) / n, device)
+
+        first = float(step())
+        for _ in range(2):
+            step()
+        c0, b0 = sync.n_collectives, sync.wire_bytes
+        dt = timed(steps)
+        n_coll, wire = (sync.n_collectives - c0) // steps, (sync.wire_bytes - b0) // steps
+        real_world, sync.world = sync.world, 1                        # exchange off: every rank steps on its local gradient
+        dt_local = timed(max(steps // 2, 2))
+        sync.world = real_world
+        last = float(step())
+    finally:
+        train_ops.set_activation_dtype("fp32")
+    fwd_gflop = 4826.9 * global_batch * seconds / 2560.0
+    res = {"workload": f"QuartzNet15x5 fine-tune step (CTC), GLOBAL batch {global_batch}x{seconds} s over {world} GPU(s) = local {local}, data-parallel, "
+                       "bf16 activations (mixed precision), forward + backward from one hipGraph, GradientSync + FusedAdamW (BASELINE.json configs[3])",
+           "n_gpus": world, "scaling": "strong", "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s",
+           "audio_seconds_per_s": global_batch * seconds / dt, "steps": steps, "loss_first_last": [first, last],
+           "n_collectives_per_step": n_coll, "wire_bytes_per_step_per_rank": wire, "wire_dtype": str(sync.wire_dtype).replace("torch.", ""),
+           "collective": sync.collective if world > 1 else "none (one rank)", "n_buckets": len(sync.buckets),
+           "ms_per_step_without_exchange": dt_local * 1e3, "exchange_ms_exposed": max(dt - dt_local, 0.0) * 1e3,
+           "roofline": {"bound": "mfma", "model": "3 x forward FLOPs of the global batch (BASELINE.md section 3) / (n_gpus x dense bf16 peak)",
+                        "achieved": 3.0 * fwd_gflop / dt / 1e3, "peak": MFMA_BF16_PEAK_TF * world, "unit": "TFLOP/s",
+                        "frac": 3.0 * fwd_gflop / dt / 1e3 / (MFMA_BF16_PEAK_TF * world)}}
+    sync.close()
+    del m, opt, sync, graphed
+    torch.cuda.empty_cache()
+    return res
 
 
 def run(device, which=("c3", "c4", "c5"), check=True):
