@@ -146,6 +146,22 @@ typedef struct ts_frontend_desc {
 int64_t ts_frontend_workspace_bytes(const ts_frontend_desc* desc);
 int ts_mel_frontend_fwd(const ts_frontend_desc* desc, const float* wave, const int32_t* wave_len,
                         void* features, int32_t* feat_len, void* workspace, void* stream);
+/* The five stage modules of the front end called ON THEIR OWN (reference quartznet/transform.py:71-255; the reference's tests drive each
+ * with arbitrary parameters, tests/quartznet/test_transform_qn.py:130-260).  Reference layout, f32, generic and simple: FilterbankFeatures
+ * itself never calls these -- its forward is ts_mel_frontend_fwd above.
+ *   ts_fe_preemph         y[b][0] = x[b][0], y[b][n] = x[b][n] - coeff * x[b][n-1]                       ([B][n] -> [B][n])
+ *   ts_fe_dither          y = x + dither * N(0, 1), the Philox stream of ts_mel_frontend_fwd's dither      ([B][n] -> [B][n])
+ *   ts_fe_power_spectrum  |STFT|^2 of torch.stft(n_fft, hop, center=True, pad_mode="reflect"); window: f32 [n_fft] (the win_length
+ *                         window centred in zeros); twiddle: f32 [n_fft][2] = (cos, sin)(2 pi j / n_fft); out [B][n_fft/2+1][n/hop+1]
+ *   ts_fe_mel             out[b][m][t] = log(sum_f fb[m][f] x[b][f][t] + 2^-24) (log_scale = 1) or the plain product; fb f32 [n_mels][n_freq]
+ *   ts_fe_normalize       masked per-(clip, feature) normalisation with the padded frames in the variance (quirk A1), 0 beyond len[b] */
+int ts_fe_preemph(const float* x, float* y, int32_t batch, int32_t n, float coeff, void* stream);
+int ts_fe_dither(const float* x, float* y, int32_t batch, int32_t n, float dither, uint64_t seed, void* stream);
+int ts_fe_power_spectrum(const float* x, const float* window, const float* twiddle, float* out, int32_t batch, int32_t n, int32_t n_fft,
+                         int32_t hop, void* stream);
+int ts_fe_mel(const float* x, const float* fb, float* out, int32_t batch, int32_t n_freq, int32_t n_mels, int32_t t, int32_t log_scale,
+              void* stream);
+int ts_fe_normalize(const float* x, const int32_t* len, float* out, int32_t batch, int32_t features, int32_t t, float guard, void* stream);
 /* Debug/parity hook: copy of the un-normalised log-mel [B][n_frames][n_mels] f32 left in workspace. */
 const float* ts_frontend_logmel_ptr(const ts_frontend_desc* desc, const void* workspace);
 
@@ -414,6 +430,14 @@ int ts_encode_chars(const int32_t* text, const int32_t* off, int32_t n_rows, con
  * Layout helpers at the boundary: reference-layout f32 [B][C][T] <-> NCT-p bf16 [B][C][pitch].
  * ---------------------------------------------------------------------------------------------- */
 /* len (may be NULL): int32 [B]; frames >= len[b] are written as 0 so that dst satisfies the tail-zero invariant. */
+/* im2col along time for the reference-valid convolutions that have no fused kernel of their own -- dense MaskedConv1d with
+ * kernel_size > 1 (quartznet/blocks.py:213-221, non-separable blocks) and depthwise stride > 2 (swept by the reference's
+ * tests/quartznet/test_blocks_qn.py:158-243): out bf16 [B][kernel * channels][pitch_out], row u * channels + c, frame t =
+ * mask(x)[b][c][t * stride + u * dilation - padding] (0 outside [0, len[b]) -- the MaskedConv1d input mask; len may be NULL), zero from
+ * t_out to the pitch.  The convolution is then ONE pointwise launch of ts_tcs_subblock_fwd over kernel * channels input channels
+ * (weights [c_out][u * channels + c] = W[c_out][c][u], or pw[c_out][c] * dw[c][u] for a separable pair). */
+int ts_im2col_time(const void* x, const int32_t* len, void* out, int32_t batch, int32_t channels, int32_t t_in, int32_t pitch_in,
+                   int32_t kernel, int32_t stride, int32_t dilation, int32_t padding, int32_t t_out, int32_t pitch_out, void* stream);
 /* Length arithmetic in one launch: out[i] = floor((in[i] + add) / div) + plus, in the arithmetic of the input type, written as `out_kind`
  * (`out` may be NULL) and, when out_i32 != NULL, once more as int32 -- what the kernels take.  kinds: 0 f32, 1 int64, 2 int32.
  * Replaces the ATen chains of MaskedConv1d.get_seq_len (quartznet/blocks.py:150-163: add = 2p - d(k-1) - 1, div = stride, plus = 1, same

@@ -148,10 +148,33 @@ def test_standalone_masked_conv1d_matches_oracle(kind):
     assert float((got - ref).abs().max()) <= 0.012 * max(1.0, float(ref.abs().max()))
 
 
-def test_dense_masked_conv1d_is_rejected_loudly():
+@pytest.mark.parametrize("cin,cout,k,stride,dil,groups", [(8, 8, 3, 1, 1, 1), (24, 40, 11, 1, 1, 1), (16, 32, 13, 2, 1, 1), (16, 24, 17, 3, 1, 1),
+                                                         (20, 20, 7, 1, 2, 1), (32, 32, 11, 3, 1, 32)])
+def test_dense_and_stride3_masked_conv1d_match_oracle(cin, cout, k, stride, dil, groups):
+    """MaskedConv1d forms that have no fused kernel of their own -- dense K > 1 (quartznet/blocks.py:213-221) and depthwise with
+    stride 3 (swept by the reference's tests/quartznet/test_blocks_qn.py:158-243) -- run as ts_im2col_time + one pointwise launch."""
+    from thunder_speech_amd.quartznet.blocks import MaskedConv1d
+    g = torch.Generator().manual_seed(k)
+    pad = dil * (k - 1) // 2 if dil > 1 else k // 2
+    m = MaskedConv1d(cin, cout, k, stride=stride, padding=pad, dilation=dil, groups=groups, bias=True)
+    with torch.no_grad():
+        m.conv.weight.copy_(bf16_round(torch.randn(m.conv.weight.shape, generator=g) * 0.2))
+        m.conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    x = bf16_round(torch.randn(3, cin, 157, generator=g))
+    lengths = torch.tensor([157.0, 100.0, 3.0])
+    ref, ref_len = otcs.masked_conv(x, lengths, m.conv.weight.detach(), stride, pad, dil, groups)
+    ref = ref + m.conv.bias.detach()[None, :, None]
+    y, yl = m.cuda().eval()(x.cuda(), lengths.cuda())
+    assert torch.equal(yl.cpu(), ref_len)
+    got = y.float().cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 0.012 * max(1.0, float(ref.abs().max()))
+
+
+def test_grouped_masked_conv1d_other_than_depthwise_is_rejected_loudly():
     from thunder_speech_amd.quartznet.blocks import MaskedConv1d
     with pytest.raises(NotImplementedError):
-        MaskedConv1d(8, 8, 3, padding=1).cuda()(torch.zeros(1, 8, 20, device="cuda"), torch.tensor([20], device="cuda"))
+        MaskedConv1d(8, 8, 3, padding=1, groups=2).cuda()(torch.zeros(1, 8, 20, device="cuda"), torch.tensor([20], device="cuda"))
 
 
 # ------------------------------------------------------------------------------------------------------------------ C3

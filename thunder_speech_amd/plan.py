@@ -175,8 +175,16 @@ class TcsLayer:
     taps_phase_raw: Optional[torch.Tensor] = None
     taps_t16: Optional[torch.Tensor] = None        # stride 1, dilation 1, K <= 81: sliding-window tap image of the merged kernel
     t16_chunks: int = 0
+    # Convolutions without a fused kernel of their own (dense K > 1, depthwise stride > 2): `pre` = (K, stride, dilation, padding,
+    # source channels, masked) describes an im2col pass (ts_im2col_time) in front of this -- then pointwise-only -- layer, whose c_in is
+    # K * source channels.  masked: the reference re-masks between a depthwise and its pointwise conv, so the pointwise input counts as
+    # zero beyond the OUTPUT length; a dense conv has no such mask (frames beyond the length keep their partial sums).
+    pre: Optional[Tuple[int, int, int, int, int, bool]] = None
 
     def out_size(self, t_in: int) -> int:
+        if self.pre is not None:
+            k, s, d, p = self.pre[:4]
+            return conv_out_size(t_in, k, s, p, d)
         return conv_out_size(t_in, self.kernel, self.stride, self.padding, self.dilation)
 
     def run(self, x: torch.Tensor, t_in: int, len_in: torch.Tensor, x_res: Optional[torch.Tensor] = None,
@@ -190,6 +198,17 @@ class TcsLayer:
         L = _lib.lib()
         b = x.shape[0]
         t_out = self.out_size(t_in)
+        if self.pre is not None:
+            from . import tensors as _t
+            k, s, dl, p, c_src, masked = self.pre
+            xcol = _t.arena(("im2col", id(self)), b, k * c_src, t_out, x.device)
+            st = L.ts_im2col_time(x.data_ptr(), len_in.data_ptr(), xcol.data_ptr(), b, c_src, t_in, x.shape[2], k, s, dl, p, t_out,
+                                  xcol.shape[2], torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(st, "ts_im2col_time")
+            # the pointwise launch masks its input at `len_in`: the output length when the reference masks there (or the caller wants
+            # zeroed tails anyway), every frame otherwise
+            len_in = _t.lengths_map(len_in, 2 * p - dl * (k - 1) - 1, s, 1) if (masked or zero_tail) else _t.full_lengths(b, t_out, x.device)
+            x, t_in, in_tail_zero = xcol, t_out, False
         pitch_out = _lib.time_pitch(t_out)
         if out is None:
             out = torch.empty(b, self.c_out, pitch_out, device=x.device,
@@ -230,6 +249,27 @@ class TcsLayer:
         st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
         _lib.check(st, "ts_tcs_subblock_fwd")
         return out, t_out
+
+
+def make_im2col_layer(device, *, w2: torch.Tensor, src_channels: int, kernel: int, stride: int, dilation: int, padding: int,
+                       masked: bool, **kw) -> TcsLayer:
+    """A convolution as im2col + ONE pointwise launch.  w2: [Cout, kernel * src_channels], column u * src_channels + c = the weight of
+    tap u of input channel c (dense conv: W[co][c][u]; separable pair: pw[co][c] * dw[c][u]).  `kw`: bn / relu / residual arguments of
+    make_tcs_layer."""
+    layer = make_tcs_layer(device, dw_w=None, pw_w=w2, kernel=1, stride=1, dilation=1, padding=0, **kw)
+    layer.pre = (int(kernel), int(stride), int(dilation), int(padding), int(src_channels), bool(masked))
+    return layer
+
+
+def dense_as_pointwise(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, K] -> [Cout, K * Cin], column u * Cin + c (the row order of ts_im2col_time)."""
+    return w.detach().permute(0, 2, 1).reshape(w.shape[0], -1)
+
+
+def separable_as_pointwise(dw_w: torch.Tensor, pw_w: torch.Tensor) -> torch.Tensor:
+    """depthwise [C, 1, K] then pointwise [Cout, C, 1] -> [Cout, K * C], column u * C + c = pw[co][c] * dw[c][u]."""
+    dw, pw = dw_w.detach()[:, 0, :], pw_w.detach().reshape(pw_w.shape[0], -1)            # [C, K], [Cout, C]
+    return (pw[:, None, :] * dw.t()[None, :, :]).reshape(pw.shape[0], -1)
 
 
 def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, bn: Sequence[torch.Tensor],

@@ -84,13 +84,24 @@ class MaskedConv1d(nn.Module):
         _t.require_gpu(x, "MaskedConv1d")
         conv = self.conv
         depthwise = conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1
-        if not depthwise and not (conv.groups == 1 and self.kernel_size == 1):
-            raise NotImplementedError("MaskedConv1d: only depthwise and 1x1 convolutions have HIP kernels "
-                                      "(dense K>1 convs are not on the QuartzNet/Citrinet hot path)")
+        if not depthwise and conv.groups != 1:
+            raise NotImplementedError("MaskedConv1d: grouped convolutions other than depthwise have no HIP kernel "
+                                      "(the reference builds dense and depthwise ones only, quartznet/blocks.py:185-224)")
         tensors = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
 
         def build():
             c = conv.out_channels
+            bias = None if conv.bias is None else conv.bias.detach()
+            if depthwise and self.stride > 2:
+                # no fused kernel for this stride: im2col + one pointwise launch over K * C "channels" (weights: identity x taps)
+                return _plan.make_im2col_layer(conv.weight.device, w2=_plan.separable_as_pointwise(conv.weight, torch.eye(c, device=conv.weight.device)),
+                                               src_channels=c, kernel=self.kernel_size, stride=self.stride, dilation=self.dilation,
+                                               padding=self.padding, masked=False, bn=None, relu=False, bias_extra=bias)
+            if not depthwise and self.kernel_size > 1:
+                # dense K > 1 (quartznet/blocks.py:213-221): im2col + one pointwise launch over K * Cin input channels
+                return _plan.make_im2col_layer(conv.weight.device, w2=_plan.dense_as_pointwise(conv.weight), src_channels=conv.in_channels,
+                                               kernel=self.kernel_size, stride=self.stride, dilation=self.dilation, padding=self.padding,
+                                               masked=False, bn=None, relu=False, bias_extra=bias)
             if depthwise:
                 return _plan.make_tcs_layer(conv.weight.device, dw_w=conv.weight.detach(), pw_w=torch.eye(c), bn=None,
                                             kernel=self.kernel_size, stride=self.stride, dilation=self.dilation,
@@ -171,18 +182,24 @@ class _FusedBlockBase(nn.Module):
         for r, (dw, pw, bn) in enumerate(subs):
             last = r == len(subs) - 1
             geom = dw if dw is not None else pw
-            if dw is None and geom.kernel_size != 1:
-                raise NotImplementedError("non-separable blocks with kernel_size > 1 have no HIP kernel "
-                                          "(the reference models only use kernel_size=1 there)")
-            kw = dict(dw_w=None if dw is None else dw.conv.weight, pw_w=pw.conv.weight, bn=_bn_tensors(bn),
-                      kernel=geom.kernel_size, stride=geom.stride, dilation=geom.dilation, padding=geom.padding,
-                      relu=True)
+            kw = dict(bn=_bn_tensors(bn), relu=True)
             if last and self._has_se():
                 kw["relu"] = False          # SE gate + residual + ReLU follow in separate launches
             elif last and self.res is not None:
                 rc = self.res[0]
                 kw.update(res_w=rc.conv.weight, res_bn=_bn_tensors(self.res[1].layer[0]), res_stride=rc.stride)
-            layers.append(_plan.make_tcs_layer(device, **kw))
+            geo = dict(kernel=geom.kernel_size, stride=geom.stride, dilation=geom.dilation, padding=geom.padding)
+            if dw is None and geom.kernel_size != 1:
+                # non-separable block with K > 1 (reference-valid, quartznet/blocks.py:213-221; no reference model uses it):
+                # im2col + one pointwise launch over K * Cin input channels
+                layers.append(_plan.make_im2col_layer(device, w2=_plan.dense_as_pointwise(pw.conv.weight), src_channels=pw.conv.in_channels,
+                                                      masked=False, **geo, **kw))
+            elif dw is not None and dw.stride > 2:
+                # depthwise stride 3+ has no fused kernel: the separable pair as ONE product over K * C input channels
+                layers.append(_plan.make_im2col_layer(device, w2=_plan.separable_as_pointwise(dw.conv.weight, pw.conv.weight),
+                                                      src_channels=dw.conv.in_channels, masked=True, **geo, **kw))
+            else:
+                layers.append(_plan.make_tcs_layer(device, dw_w=None if dw is None else dw.conv.weight, pw_w=pw.conv.weight, **geo, **kw))
         return layers
 
     def _has_se(self) -> bool:

@@ -43,31 +43,67 @@ def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sampl
     return torch.from_numpy(fb.astype(np.float32))
 
 
-class _FusedOnly(nn.Module):
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(f"{type(self).__name__} runs only fused inside FilterbankFeatures "
-                                  "(one HIP kernel computes pre-emphasis, STFT, mel and log together)")
+def _f32(x: torch.Tensor, what: str) -> torch.Tensor:
+    _t.require_gpu(x, what)
+    return x.to(torch.float32).contiguous()
 
 
-class FeatureBatchNormalizer(_FusedOnly):
+def _stream(x: torch.Tensor):
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+# The five stage modules also run ON THEIR OWN (the reference's tests call them directly with arbitrary parameters,
+# tests/quartznet/test_transform_qn.py:130-260): generic single-stage kernels of csrc/frontend_stages.hip, reference layout, f32.
+# Inside FilterbankFeatures none of these forwards is called -- the fused front end computes all stages in two launches.
+class FeatureBatchNormalizer(nn.Module):
     def __init__(self):
         super().__init__()
         self.div_guard = 1e-5
 
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """normalize_tensor with the length mask (reference transform.py:77-92 -> blocks.py:136-149, quirk A1)."""
+        xf = _f32(x, "FeatureBatchNormalizer")
+        b, f, t = xf.shape
+        out = torch.empty_like(xf)
+        st = _lib.lib().ts_fe_normalize(xf.data_ptr(), _t.lengths_i32(lengths, xf.device).data_ptr(), out.data_ptr(), b, f, t,
+                                        float(self.div_guard), _stream(xf))
+        _lib.check(st, "ts_fe_normalize")
+        return out, lengths
 
-class DitherAudio(_FusedOnly):
+
+class DitherAudio(nn.Module):
     def __init__(self, dither: float = 1e-5):
         super().__init__()
         self.dither = dither
 
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x + dither * N(0, 1) in training mode, identity in eval mode (reference transform.py:109-118)."""
+        if not self.training:
+            return x
+        xf = _f32(x, "DitherAudio")
+        out = torch.empty_like(xf)
+        st = _lib.lib().ts_fe_dither(xf.data_ptr(), out.data_ptr(), xf.shape[0], xf.shape[1], float(self.dither), _rng.next_seed(), _stream(xf))
+        _lib.check(st, "ts_fe_dither")
+        return out
 
-class PreEmphasisFilter(_FusedOnly):
+
+class PreEmphasisFilter(nn.Module):
     def __init__(self, preemph: float = 0.97):
         super().__init__()
         self.preemph = preemph
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """y[0] = x[0], y[n] = x[n] - preemph * x[n-1] (reference transform.py:136-144)."""
+        xf = _f32(x, "PreEmphasisFilter")
+        out = torch.empty_like(xf)
+        st = _lib.lib().ts_fe_preemph(xf.data_ptr(), out.data_ptr(), xf.shape[0], xf.shape[1], float(self.preemph), _stream(xf))
+        _lib.check(st, "ts_fe_preemph")
+        return out
 
-class PowerSpectrum(_FusedOnly):
+
+class PowerSpectrum(nn.Module):
     def __init__(self, n_window_size: int = 320, n_window_stride: int = 160, n_fft: Optional[int] = None):
         super().__init__()
         if n_window_size <= 0 or n_window_stride <= 0:
@@ -84,13 +120,51 @@ class PowerSpectrum(_FusedOnly):
             return _t.lengths_map(lengths, 0, self.hop_length, 1, out_dtype=torch.long)      # one launch (+ the int32 copy for the kernels)
         return (torch.floor(lengths / self.hop_length) + 1).to(dtype=torch.long)
 
+    def _stft_tables(self, device):
+        key = (str(device), self.window.data_ptr(), self.window._version)
+        if getattr(self, "_tab_key", None) != key:
+            win = torch.zeros(self.n_fft, dtype=torch.float32)
+            left = (self.n_fft - self.win_length) // 2
+            win[left:left + self.win_length] = self.window.detach().float().cpu()
+            ang = 2.0 * math.pi * torch.arange(self.n_fft, dtype=torch.float64) / self.n_fft
+            tw = torch.stack([torch.cos(ang), torch.sin(ang)], dim=1).to(torch.float32)
+            self._tab, self._tab_key = (win.to(device), tw.contiguous().to(device)), key
+        return self._tab
 
-class MelScale(_FusedOnly):
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """|STFT|^2 [B, n_fft/2 + 1, T // hop + 1] and the frame counts (reference transform.py:186-208)."""
+        xf = _f32(x, "PowerSpectrum")
+        b, n = xf.shape
+        if self.win_length > self.n_fft:
+            raise RuntimeError(f"PowerSpectrum: win_length {self.win_length} > n_fft {self.n_fft} (torch.stft refuses it too)")
+        win, tw = self._stft_tables(xf.device)
+        out = torch.empty(b, self.n_fft // 2 + 1, n // self.hop_length + 1, dtype=torch.float32, device=xf.device)
+        st = _lib.lib().ts_fe_power_spectrum(xf.data_ptr(), win.data_ptr(), tw.data_ptr(), out.data_ptr(), b, n, self.n_fft, self.hop_length,
+                                             _stream(xf))
+        _lib.check(st, "ts_fe_power_spectrum")
+        return out, self.get_sequence_length(lengths)
+
+
+class MelScale(nn.Module):
     def __init__(self, sample_rate: int, n_fft: int, nfilt: int, log_scale: bool = True):
         super().__init__()
         fb = melscale_fbanks(int(1 + n_fft // 2), 0.0, sample_rate / 2, nfilt, sample_rate).transpose(0, 1).unsqueeze(0)
         self.register_buffer("fb", fb.contiguous())
         self.log_scale = log_scale
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """log(fb @ x + 2^-24) (or the plain product), [B, n_freq, T] -> [B, nfilt, T] (reference transform.py:243-255)."""
+        xf = _f32(x, "MelScale")
+        b, f, t = xf.shape
+        fb = self.fb.to(device=xf.device, dtype=torch.float32).contiguous()
+        if fb.shape[2] != f:
+            raise RuntimeError(f"MelScale: the input has {f} frequency bins, the filterbank {fb.shape[2]}")
+        out = torch.empty(b, fb.shape[1], t, dtype=torch.float32, device=xf.device)
+        st = _lib.lib().ts_fe_mel(xf.data_ptr(), fb.data_ptr(), out.data_ptr(), b, f, fb.shape[1], t, int(bool(self.log_scale)), _stream(xf))
+        _lib.check(st, "ts_fe_mel")
+        return out
 
 
 class _FilterbankFeatures(MultiSequential):
