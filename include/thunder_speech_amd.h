@@ -377,6 +377,13 @@ int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const 
  * (GEMM accumulator; when y_bf16 is given only the bf16 copy holds the result). */
 int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, const float* bias, int32_t c_out,
                     int32_t kernel, int32_t stride, int32_t act, int32_t precision, float* y, void* y_bf16, void* stream);
+/* Token-major bf16 GEMM with fused epilogue (csrc/gemm_nt.hip) -- what ts_w2v_linear_fwd / ts_w2v_conv_fwd run in bf16 mode, exported for
+ * tests and tools:  y[m][n] = act(sum_k x[m][k] w[n][k] + bias[n]) + res[m][n],  x: bf16 rows of pitch lda, w: bf16 [n][k] rows of pitch
+ * ldw (torch.nn.Linear layout), f32 accumulation; bias / res (f32) may be NULL; gelu = 1: erf-GELU before the residual; y (f32, pitch ldc)
+ * and / or y_bf16 (pitch ld16) receive the result (either may be NULL, res == y is allowed).  n % 32 == 0, k % 32 == 0, lda % 8 == 0,
+ * 16-byte aligned operands; anything else returns TS_EUNSUPPORTED. */
+int ts_gemm_nt_bf16(const void* x, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res, int64_t ld_res, float* y,
+                    int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k, int32_t gelu, void* stream);
 /* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act bit 0: GELU (erf), bit 1:
  * only y_bf16 is wanted (y is then scratch space for the f32 GEMM result).  res == y (same pitch): the product is accumulated into y
  * in place (the residual stream).  lda / ldc / ld_res: row pitches in elements. */

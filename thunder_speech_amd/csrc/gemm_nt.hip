@@ -1,0 +1,270 @@
+// Token-major bf16 GEMM with fused epilogue for gfx950 (MI355X): the linears and convolutions of the wav2vec2 encoder
+// (transformers.Wav2Vec2Model reached from huggingface/compatibility.py:31-42: feature projection, q / k / v, out_proj, the two
+// feed-forward linears, conv layers 1-6 as overlapping-row products), replacing the hipBLASLt / rocBLAS calls of rounds 1-2.
+//
+//   y[m][n] = act( sum_k x[m][k] w[n][k] + bias[n] ) + res[m][n]          x: bf16 rows of pitch lda, w: bf16 [n][k] (nn.Linear layout)
+//
+// Both operands are K-contiguous rows ("NT" product), so A and B tiles are staged the same way and fragments of
+// v_mfma_f32_32x32x16_bf16 are plain 16-byte LDS reads.
+//  * 256 x 256 output tile per workgroup, 8 waves as 2 (rows) x 4 (columns): a wave owns 128 x 64 = 4 x 2 accumulator blocks
+//    (128 VGPRs); per 16-deep k-step 6 fragment reads feed 8 MFMAs.  The big tile is what keeps the operand stream under the
+//    L2 -> CU bandwidth: 32 KiB per 32-deep half-stage for 1 024 MFMA cycles per SIMD = 32 B / clk / CU.
+//  * operands travel global -> LDS by DMA (buffer_load ... lds, 1 KiB per wave-instruction) into a ring of FOUR half-stages
+//    (32 deep: A 16 KiB + B 16 KiB each, 128 KiB in all); up to three are in flight while one is multiplied, counted vmcnt waits.
+//    Rows are 64 bytes; the 16-byte chunk index is XOR-ed with (row >> 2) & 3 -- on the SOURCE address, the DMA's LDS image is
+//    lane-linear -- so that any 16 consecutive rows of a fragment read cover all 64 banks.  (Register staging -- 16-byte loads two
+//    half-stages ahead + ds_write_b128 -- was built as well and measured 15-25 % slower on every shape.)
+//  * ping-pong: a wave alternates a LOAD phase (fragment reads, DMA issue) with an MFMA phase of 16 back-to-back MFMAs, one barrier
+//    per phase, and the second wave row runs one phase behind the first: on every SIMD one wave multiplies while the other loads.
+//  * epilogue: bias and erf-GELU in registers, then staged through the idle ring for 16-byte row stores: residual add (f32), f32 and /
+//    or bf16 result; rows beyond M are clamped on the way in and
+//    masked on the way out; N % 32 == 0 and K % 32 == 0 (every linear of the supported checkpoints).
+//  * workgroup -> tile map keeps the column tiles of one row panel on one XCD (they share the A rows in that XCD's L2).
+#include "ts_common.hpp"
+
+#include <cstdlib>
+
+namespace ts {
+
+namespace {
+
+constexpr int GM = 256, GN = 256, GKH = 32;      // tile, half-stage depth
+constexpr int GRING = 4;
+constexpr int GROWB = GKH * 2;                   // 64-byte LDS rows
+constexpr int GHALFB = GM * GROWB;               // 16 KiB: one operand tile of a half-stage
+constexpr int GSTAGEB = 2 * GHALFB;              // 32 KiB
+
+struct GemmArgs {
+  const unsigned short* x;
+  const unsigned short* w;
+  const float* bias;
+  const float* res;
+  float* y;
+  unsigned short* y16;
+  long long lda, ldw, ld_res, ldc, ld16;
+  long long sx, sy;                              // batch strides (elements) of x and of y / y16 / res
+  int M, N, K, act;                              // act bit 0: GELU
+  int n_mt, n_nt;
+#ifdef TS_EXP
+  int exp;                                       // diagnostic builds: bit 0 no DMA in the loop, 1 no fragment reads, 2 no barriers, 3 no epilogue
+#endif
+};
+
+template <int N>
+__device__ __forceinline__ void vmw() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ float erf_as_g(float x) {
+  // Abramowitz-Stegun 7.1.26 is not accurate enough for parity: use the library erf (f32)
+  return erff(x);
+}
+__device__ __forceinline__ float gelu_g(float x) { return 0.5f * x * (1.f + erf_as_g(x * 0.70710678118654752f)); }
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // tile of this workgroup: XCD x = id % 8 owns a contiguous range of tiles, column tiles of a row panel adjacent
+  int id = blockIdx.x;
+  const int n_tiles = a.n_mt * a.n_nt;
+  if ((n_tiles & 7) == 0) id = (id & 7) * (n_tiles >> 3) + (id >> 3);
+  const int nt_i = id % a.n_nt, mt_i = id / a.n_nt;
+  const int m0 = mt_i * GM, n0 = nt_i * GN;
+  const int bz = blockIdx.y;
+  const unsigned short* const xb = a.x + (size_t)bz * a.sx;
+
+  const i32x4 ra = raw_rsrc(xb, 0x7fffffffu);
+  const i32x4 rb = raw_rsrc(a.w, 0x7fffffffu);
+  // DMA geometry: one instruction = 16 rows x 64 bytes; lane -> (row lane >> 2, LDS slot lane & 3); the slot holds source chunk
+  // slot ^ ((row >> 2) & 3).  Wave w fetches rows [32 w, 32 w + 32) of both tiles (two instructions each).
+  const int lrow = lane >> 2, lslot = lane & 3;
+  const int lchunk = lslot ^ ((lrow >> 2) & 3);
+  int offa[2], offb[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = 32 * wave + 16 * q + lrow;
+    const long long m = m0 + r < a.M ? m0 + r : a.M - 1;
+    const long long n = n0 + r < a.N ? n0 + r : a.N - 1;
+    offa[q] = (int)((m * a.lda + 8 * lchunk) * 2);
+    offb[q] = (int)((n * a.ldw + 8 * lchunk) * 2);
+  }
+  // the DMAs of a half-stage in two halves (A rows, B rows): one half is issued in the LOAD phase, the other between the MFMAs of the
+  // following MFMA phase -- all four in the LOAD phase made it longer than the partner's MFMA phase (measured), all four among the MFMAs
+  // made that phase the longer one
+  auto issue_a = [&](int s) {
+#ifdef TS_EXP
+    if ((a.exp & 1) && s >= GRING - 1) return;
+#endif
+    char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) lds_dma16(ra, st + (32 * wave + 16 * q) * GROWB, offa[q], s * GKH * 2);
+  };
+  auto issue_b = [&](int s, int q) {
+#ifdef TS_EXP
+    if ((a.exp & 1) && s >= GRING - 1) return;
+#endif
+    char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
+    lds_dma16(rb, st + GHALFB + (32 * wave + 16 * q) * GROWB, offb[q], s * GKH * 2);
+  };
+  auto issue = [&](int s) { issue_a(s); issue_b(s, 0); issue_b(s, 1); };
+  // fragment read offsets: lane (r = lane & 31, h = lane >> 5) reads chunk (2 ks + h) ^ ((r >> 2) & 3) of its row
+  const int fr = lane & 31, fh = lane >> 5;
+  const int fsw = (fr >> 2) & 3;
+  const int fa0 = (wm * 128 + fr) * GROWB + ((fh ^ fsw) << 4);            // ks = 0; ks = 1 is the same offset ^ 32
+  const int fb0 = GHALFB + (wn * 64 + fr) * GROWB + ((fh ^ fsw) << 4);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int S = a.K / GKH;
+  // Ping-pong between the two waves of a SIMD (wave w and w + 4: one of each wave row).  A wave alternates a LOAD phase -- read the 12
+  // fragments of half-stage s, issue the DMAs of half-stage s + 3, retire its DMAs of s + 1 -- with an MFMA phase of 16 back-to-back
+  // MFMAs; a barrier after every phase, and the second wave row runs ONE PHASE BEHIND the first, so on every SIMD one wave multiplies
+  // while the other loads (the staggered form of cdna_hip_programming.md's 8-phase template).
+  //   ring safety: L(s) overwrites the slot of half-stage s - 1, which both rows finished reading at least one barrier earlier;
+  //   L(s) reads half-stage s, whose DMAs every wave retired (counted vmcnt) at the end of its own L(s - 1), a barrier earlier.
+  s16x8 fa[2][4], fb[2][2];
+  auto load_phase = [&](int s) {
+    const char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
+#ifdef TS_EXP
+    if (!((a.exp & 2) && s > 0))
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const s16x8*>(st + ((fa0 + i * 32 * GROWB) ^ (ks << 5)));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[ks][j] = *reinterpret_cast<const s16x8*>(st + ((fb0 + j * 32 * GROWB) ^ (ks << 5)));
+    }
+    if (s + GRING - 1 < S) issue_a(s + GRING - 1);
+    // this wave's DMAs of half-stage s + 1 have landed; those of s + 2 and the A half of s + 3 (where they exist) may stay in flight
+    // (the B half of s + 3 follows in the MFMA phase)
+    const int after = S - 2 - s < 2 ? S - 2 - s : 2;
+    if (after >= 2) vmw<6>(); else if (after == 1) vmw<4>(); else vmw<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the fragment reads have returned: the slot may be refilled after the barrier
+  };
+  auto mfma_phase = [&](int s) {
+    const bool more = s + GRING - 1 < S;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) issue_b(s + GRING - 1, ks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_barrier = [&]() {
+#ifdef TS_EXP
+    if (a.exp & 4) return;
+#endif
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  for (int s = 0; s < GRING - 1 && s < S; ++s) issue(s);
+  if (S > 2) vmw<8>(); else if (S > 1) vmw<4>(); else vmw<0>();
+  phase_barrier();                                                        // half-stage 0 is in LDS
+  if (wm == 1) phase_barrier();                                           // the second wave row starts one phase later
+  for (int s = 0; s < S; ++s) {
+    load_phase(s);
+    __builtin_amdgcn_sched_barrier(0);
+    phase_barrier();
+    mfma_phase(s);
+    __builtin_amdgcn_sched_barrier(0);
+    phase_barrier();
+  }
+  if (wm == 0) phase_barrier();                                           // the first row's partner of the extra barrier above
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+  // The accumulator layout (lane = column, registers = rows) would store 2 or 4 bytes per lane; instead each wave stages its tile, 32
+  // columns at a time, as f32 [128 rows][32 columns] in its own 16 KiB of the (now idle) operand ring and reads it back row-wise:
+  // 16 bytes per lane for the residual load and the f32 store, 8 bytes per lane for the bf16 store.
+  const size_t yoff = (size_t)bz * a.sy;
+#ifdef TS_EXP
+  if ((a.exp & 8) && acc[0][0][0] != 12345.678f) return;
+#endif
+  __builtin_amdgcn_s_barrier();                    // every wave is done with the operand ring (all DMAs were drained in the loop)
+  asm volatile("" ::: "memory");
+  float* const ep = reinterpret_cast<float*>(smem + wave * 16384);
+  const int erow = lane >> 3, ecol = (lane & 7) * 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int nb = n0 + wn * 64 + 32 * j;
+    const float bv = (a.bias && nb + fr < a.N) ? a.bias[nb + fr] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + bv;
+        if (a.act & 1) v = gelu_g(v);
+        ep[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // wave-private tile: LDS operations of one wave are in order
+    if (nb + ecol < a.N) {
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int row = 8 * q + erow;
+        const int m = m0 + wm * 128 + row;
+        if (m < a.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 32 + ecol);
+          if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + yoff + (size_t)m * a.ld_res + nb + ecol);
+          if (a.y) *reinterpret_cast<f32x4*>(a.y + yoff + (size_t)m * a.ldc + nb + ecol) = v;
+          if (a.y16) *reinterpret_cast<u32x2*>(a.y16 + yoff + (size_t)m * a.ld16 + nb + ecol) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// y = act(x w^T + bias) + res; see the header of this file.  TS_EUNSUPPORTED for shapes the kernel does not take.
+int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
+                 const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
+                 int gelu, int batch) {
+  if (!x || !w || (!y && !y16) || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return TS_EINVAL;
+  if (N % 32 || K % GKH || lda % 8 || ldw % 8 || ldw < K) return TS_EUNSUPPORTED;
+  if ((y && (ldc % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) || (y16 && (ld16 % 4 || (reinterpret_cast<uintptr_t>(y16) & 7))) ||
+      (res && (ld_res % 4 || (reinterpret_cast<uintptr_t>(res) & 15))) || sy % 4)
+    return TS_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (sx % 8)) return TS_EUNSUPPORTED;
+  if (M * lda * 2 >= (1ll << 31) || (long long)N * ldw * 2 >= (1ll << 31)) return TS_EUNSUPPORTED;    // 32-bit buffer offsets
+  static int attr = 0;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384) != hipSuccess)
+      return TS_EUNSUPPORTED;
+    attr = 1;
+  }
+  GemmArgs a;
+  a.x = static_cast<const unsigned short*>(x); a.w = static_cast<const unsigned short*>(w); a.bias = bias; a.res = res; a.y = y;
+  a.y16 = static_cast<unsigned short*>(y16);
+  a.lda = lda; a.ldw = ldw; a.ld_res = ld_res; a.ldc = ldc; a.ld16 = ld16; a.sx = sx; a.sy = sy;
+  a.M = (int)M; a.N = N; a.K = K; a.act = gelu ? 1 : 0;
+  a.n_mt = (int)((M + GM - 1) / GM); a.n_nt = (N + GN - 1) / GN;
+#ifdef TS_EXP
+  { const char* e = getenv("TS_EXP"); a.exp = e ? atoi(e) : 0; }
+#endif
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(a.n_mt * a.n_nt), (unsigned)batch), dim3(512), 8 * 16384, stream, a);
+  return hip_status(hipGetLastError());
+}
+
+}  // namespace ts
+
+/* C-ABI form (tests, tools): y[m][n] = act(sum_k x[m][k] w[n][k] + bias[n]) + res[m][n]; see include/thunder_speech_amd.h */
+extern "C" int ts_gemm_nt_bf16(const void* x, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res, int64_t ld_res,
+                               float* y, int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k, int32_t gelu, void* stream) {
+  if (lda < 0 || ldw < k || (y && ldc < n) || (y_bf16 && ld16 < n) || (res && ld_res < n)) return TS_EINVAL;
+  return ts::gemm_nt_bf16((hipStream_t)stream, x, lda, 0, w, ldw, bias, res, ld_res, y, ldc, y_bf16, ld16, 0, rows, n, k, gelu, 1);
+}

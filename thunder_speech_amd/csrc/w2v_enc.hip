@@ -492,6 +492,16 @@ static int gemm_nt(rocblas_handle h, bool bf16, long long m, int n, int k, const
   return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
 }
 
+// our own token-major bf16 GEMM with the fused epilogue (csrc/gemm_nt.hip): the default of the bf16 mode since round 3
+int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
+                 const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
+                 int gelu, int batch);
+// TS_W2V_VENDOR_GEMM=1: the library GEMMs of rounds 1-2 instead (A/B timing; also what shapes our kernel declines fall back to)
+static bool vendor_gemm() {
+  static const bool v = [] { const char* e = getenv("TS_W2V_VENDOR_GEMM"); return e && e[0] == '1'; }();
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // hipBLASLt GEMM with a fused epilogue (bias, or bias + GELU) and a bf16 result: used when the consumer of a linear layer is
 // another GEMM, so neither the f32 product nor a separate bias / activation pass ever touches HBM.  Plans (descriptor, layouts,
@@ -611,6 +621,13 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
   // operand overlap when kernel > stride, which the GEMM kernels do not mind: they only ever use the row pitch) with the
   // bias / GELU epilogue fused and a bf16 result -- no f32 accumulator in HBM, no epilogue pass.  Declined plans fall through.
   static const bool overlap_ok = getenv("TS_W2V_NO_OVERLAP_GEMM") == nullptr;
+  if (precision && y_bf16 && overlap_ok && !vendor_gemm()) {
+    // ONE launch for all clips (grid.y = clip): rows of the operand overlap when kernel > stride, which a kernel that only ever uses
+    // the row pitch does not mind; bias + GELU in the epilogue, bf16 result only
+    const int st = gemm_nt_bf16(stream, x, (long long)stride * c_in, (long long)t_in * c_in, w_taps, (long long)kernel * c_in, bias, nullptr, 0,
+                                nullptr, 0, y_bf16, c_out, (long long)t_out * c_out, t_out, c_out, kernel * c_in, act != 0, batch);
+    if (st != TS_EUNSUPPORTED) return st;
+  }
   if (precision && y_bf16 && overlap_ok && c_in % 8 == 0 && c_out % 8 == 0) {
     bool ok = true;
     for (int b = 0; b < batch && ok; ++b)
@@ -646,6 +663,11 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
   TS_STREAM;
   rocblas_handle h;
   if (int st = blas(stream, &h)) return st;
+  if (precision && !vendor_gemm()) {
+    // bf16 operands: our GEMM with bias / GELU / residual in its epilogue; the f32 result is skipped when only the bf16 copy is wanted
+    const int st = gemm_nt_bf16(stream, x, lda, 0, w, k, bias, res, ld_res, (act & 2) ? nullptr : y, ldc, y_bf16, n, 0, rows, n, k, act & 1, 1);
+    if (st != TS_EUNSUPPORTED) return st;
+  }
   // bf16 operands, only the bf16 copy of the result wanted, a bias to add: one library GEMM with the epilogue fused
   if (precision && (act & 2) && bias && !res && n % 8 == 0 && k % 8 == 0 && lt_linear(stream, x, lda, w, bias, y_bf16, rows, n, k, (act & 1) != 0))
     return hip_status(hipGetLastError());
