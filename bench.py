@@ -199,14 +199,17 @@ def main():
             if world > 1:
                 dist.barrier()
 
+        from tools import prof_mark
         for _ in range(args.warmup):
             run_step()
         barrier(); torch.cuda.synchronize()
+        prof_mark.mark(device)                      # profiled runs (TS_PROF_MARK=1): brackets the timed region in the kernel trace
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run_step()
         torch.cuda.synchronize(); barrier()
         dt = time.perf_counter() - t0
+        prof_mark.mark(device)
         dt = max_over_ranks(dt, device)
 
         # dominant kernel family: the fused TCS launches of the encoder, timed with HIP events on the launch stream

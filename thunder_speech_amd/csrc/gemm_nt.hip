@@ -5,13 +5,13 @@
 //   y[m][n] = act( sum_k x[m][k] w[n][k] + bias[n] ) + res[m][n]          x: bf16 rows of pitch lda, w: bf16 [n][k] (nn.Linear layout)
 //
 // Both operands are K-contiguous rows ("NT" product), so A and B tiles are staged the same way and fragments of
-// v_mfma_f32_32x32x16_bf16 are plain 16-byte LDS reads.
-//  * 256 x 256 output tile per workgroup, 8 waves as 2 (rows) x 4 (columns): a wave owns 128 x 64 = 4 x 2 accumulator blocks
-//    (128 VGPRs); per 16-deep k-step 6 fragment reads feed 8 MFMAs.  The big tile is what keeps the operand stream under the
+// v_mfma_f32_16x16x32_bf16 are plain 16-byte LDS reads (that shape: it sustains a higher clock than 32x32x16 under load, MI355X_MICROARCH.md).
+//  * 256 x 256 output tile per workgroup, 8 waves as 2 (rows) x 4 (columns): a wave owns 128 x 64 = 8 x 4 accumulator blocks
+//    of 16 x 16 (128 VGPRs); per 32-deep half-stage 12 fragment reads feed 32 MFMAs.  The big tile is what keeps the operand stream under the
 //    L2 -> CU bandwidth: 32 KiB per 32-deep half-stage for 1 024 MFMA cycles per SIMD = 32 B / clk / CU.
 //  * operands travel global -> LDS by DMA (buffer_load ... lds, 1 KiB per wave-instruction) into a ring of FOUR half-stages
 //    (32 deep: A 16 KiB + B 16 KiB each, 128 KiB in all); up to three are in flight while one is multiplied, counted vmcnt waits.
-//    Rows are 64 bytes; the 16-byte chunk index is XOR-ed with (row >> 2) & 3 -- on the SOURCE address, the DMA's LDS image is
+//    Rows are 64 bytes; the 16-byte chunk index is XOR-ed with {0, 3, 2, 1}[(row >> 2) & 3] -- on the SOURCE address, the DMA's LDS image is
 //    lane-linear -- so that any 16 consecutive rows of a fragment read cover all 64 banks.  (Register staging -- 16-byte loads two
 //    half-stages ahead + ds_write_b128 -- was built as well and measured 15-25 % slower on every shape.)
 //  * ping-pong: a wave alternates a LOAD phase (fragment reads, DMA issue) with an MFMA phase of 16 back-to-back MFMAs, one barrier
@@ -56,9 +56,14 @@ __device__ __forceinline__ void vmw() {
   asm volatile("" ::: "memory");
 }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below f32 GELU noise; a third of the instructions of ocml's erff) -- the same
+// form as the other GELU sites of the encoder (csrc/w2v_enc.hip)
 __device__ __forceinline__ float erf_as_g(float x) {
-  // Abramowitz-Stegun 7.1.26 is not accurate enough for parity: use the library erf (f32)
-  return erff(x);
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float r = 1.f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_g(float x) { return 0.5f * x * (1.f + erf_as_g(x * 0.70710678118654752f)); }
 
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
   // DMA geometry: one instruction = 16 rows x 64 bytes; lane -> (row lane >> 2, LDS slot lane & 3); the slot holds source chunk
   // slot ^ ((row >> 2) & 3).  Wave w fetches rows [32 w, 32 w + 32) of both tiles (two instructions each).
   const int lrow = lane >> 2, lslot = lane & 3;
-  const int lchunk = lslot ^ ((lrow >> 2) & 3);
+  const int lchunk = lslot ^ ((4 - ((lrow >> 2) & 3)) & 3);
   int offa[2], offb[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -112,18 +117,19 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
   };
   auto issue = [&](int s) { issue_a(s); issue_b(s, 0); issue_b(s, 1); };
   // fragment read offsets: lane (r = lane & 31, h = lane >> 5) reads chunk (2 ks + h) ^ ((r >> 2) & 3) of its row
-  const int fr = lane & 31, fh = lane >> 5;
-  const int fsw = (fr >> 2) & 3;
-  const int fa0 = (wm * 128 + fr) * GROWB + ((fh ^ fsw) << 4);            // ks = 0; ks = 1 is the same offset ^ 32
-  const int fb0 = GHALFB + (wn * 64 + fr) * GROWB + ((fh ^ fsw) << 4);
+  // fragment reads of v_mfma_f32_16x16x32_bf16: lane (r = lane & 15, c = lane >> 4) reads chunk c of row r -- the whole 32-deep
+  // half-stage is ONE k-step; the swizzle table {0, 3, 2, 1}[(row >> 2) & 3] makes every 16-lane group of a ds_read_b128 (lanes
+  // {0-3, 12-15, 20-27}, ...) cover all 64 banks for this pattern
+  const int fr = lane & 15, fc = lane >> 4;
+  const int fsw = (4 - ((fr >> 2) & 3)) & 3;
+  const int fa0 = (wm * 128 + fr) * GROWB + ((fc ^ fsw) << 4);
+  const int fb0 = GHALFB + (wn * 64 + fr) * GROWB + ((fc ^ fsw) << 4);
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];                                 // 16 x 16 blocks: rows 16 i .., columns 16 j ..
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int S = a.K / GKH;
   // Ping-pong between the two waves of a SIMD (wave w and w + 4: one of each wave row).  A wave alternates a LOAD phase -- read the 12
@@ -132,18 +138,17 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
   // while the other loads (the staggered form of cdna_hip_programming.md's 8-phase template).
   //   ring safety: L(s) overwrites the slot of half-stage s - 1, which both rows finished reading at least one barrier earlier;
   //   L(s) reads half-stage s, whose DMAs every wave retired (counted vmcnt) at the end of its own L(s - 1), a barrier earlier.
-  s16x8 fa[2][4], fb[2][2];
+  s16x8 fa[8], fb[4];
   auto load_phase = [&](int s) {
     const char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
 #ifdef TS_EXP
     if (!((a.exp & 2) && s > 0))
 #endif
+    {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const s16x8*>(st + fa0 + i * 16 * GROWB);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const s16x8*>(st + ((fa0 + i * 32 * GROWB) ^ (ks << 5)));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[ks][j] = *reinterpret_cast<const s16x8*>(st + ((fb0 + j * 32 * GROWB) ^ (ks << 5)));
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const s16x8*>(st + fb0 + j * 16 * GROWB);
     }
     if (s + GRING - 1 < S) issue_a(s + GRING - 1);
     // this wave's DMAs of half-stage s + 1 have landed; those of s + 2 and the A half of s + 3 (where they exist) may stay in flight
@@ -156,13 +161,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
     const bool more = s + GRING - 1 < S;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 4 * half; i < 4 * half + 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) issue_b(s + GRING - 1, ks);
+      if (more) issue_b(s + GRING - 1, half);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -202,15 +207,19 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int nb = n0 + wn * 64 + 32 * j;
-    const float bv = (a.bias && nb + fr < a.N) ? a.bias[nb + fr] : 0.f;
+    float bv[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int jj = 0; jj < 2; ++jj) bv[jj] = (a.bias && nb + 16 * jj + fr < a.N) ? a.bias[nb + 16 * jj + fr] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] + bv;
-        if (a.act & 1) v = gelu_g(v);
-        ep[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh) * 32 + fr] = v;
-      }
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][2 * j + jj][r] + bv[jj];
+          if (a.act & 1) v = gelu_g(v);
+          ep[(16 * i + 4 * fc + r) * 32 + 16 * jj + fr] = v;
+        }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // wave-private tile: LDS operations of one wave are in order
     if (nb + ecol < a.N) {
 #pragma unroll 4

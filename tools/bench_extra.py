@@ -25,14 +25,18 @@ HBM_PEAK_GBS = 8000.0
 
 
 def _timed(run, steps, warmup=2):
+    from tools import prof_mark
     for _ in range(warmup):
         run()
     torch.cuda.synchronize()
+    prof_mark.mark()                                # profiled runs: brackets the timed region in the kernel trace
     t0 = time.perf_counter()
     for _ in range(steps):
         run()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / steps
+    prof_mark.mark()
+    return dt
 
 
 def _graphed(step, device):
@@ -165,9 +169,12 @@ def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
     # cheaper variant with the encoder in eval mode and fully frozen (train_batchnorm=False plus an explicit encoder.eval()), where front
     # end + encoder replay from a hipGraph
     from thunder_speech_amd.callbacks import FinetuneEncoderDecoder
+    only = os.environ.get("TS_C4_ONLY")             # profiled runs: one variant per process
     for tag, phase, steps, act, graph in (("c4_phase1", 1, steps1, "bf16", True), ("c4_phase1_eval_frozen", 0, steps1, "fp32", False),
                                           ("c4_phase2", 2, steps2, "bf16", True),
-                                          ("c4_phase2_fp32", 2, max(steps2 // 3, 5), "fp32", False)):
+                                          ("c4_phase2_fp32", 2, max(steps2 // 3, 5), "fp32", True)):
+        if only and tag != only:
+            continue
         torch.manual_seed(0)
         m = build_synthetic_quartznet(repeat_blocks=3)
         variance_preserving_init_(m.encoder, m.decoder, seed=0)
@@ -212,7 +219,8 @@ def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
                "reference schedule's first phase: encoder convolutions frozen, BatchNorm parameters + decoder trainable, encoder in TRAIN mode "
                "(batch statistics); bf16 activations, forward + backward from one hipGraph" if phase == 1 else
                "everything trainable, " + ("bf16 activations (mixed precision: f32 master weights, gradients, BatchNorm statistics), encoder + decoder + "
-                                           "CTC + backward replayed from one hipGraph" if act == "bf16" else "f32 activations (the reference's arithmetic), eager launches"))
+                                           "CTC + backward replayed from one hipGraph" if act == "bf16" else "f32 activations (the reference's arithmetic), encoder + decoder + CTC + "
+                                           "backward replayed from one hipGraph"))
         out[tag] = {
             "workload": f"QuartzNet15x5 fine-tune step (CTC), local batch {local_batch}x{seconds} s, {how} (BASELINE.json configs[3], one rank's share)",
             "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s", "audio_seconds_per_s": local_batch * seconds / dt,
