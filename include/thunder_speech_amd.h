@@ -201,6 +201,14 @@ int64_t ts_ctc_workspace_bytes(int32_t batch, int32_t n_classes, int32_t n_frame
 int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes, int32_t n_frames, int32_t pitch,
                 const int32_t* targets, int32_t s_max, const int32_t* input_len, const int32_t* target_len,
                 int32_t blank, float* nll, float* loss, float* grad, void* workspace, void* stream);
+/* Targets and lengths in the forms F.ctc_loss takes them (ctc_loss.py:36-47: padded [B][s_in] labels, int32 (kind 0) or int64 (1), row
+ * stride targets_stride; lengths int32 / int64 / float32 / float64 (kind 0..3), truncated toward zero like the reference's `.long()`)
+ * -> the int32 arrays ts_ctc_loss reads: targets_out [B][s_max] (s_max >= max(s_in, 1)) with positions >= length and ids outside
+ * [0, n_classes) set to 0; an utterance with such an id below its length gets input length 0 and a target length >= 1 (infeasible:
+ * loss 0 under zero_infinity, zero gradient) -- the device-side form of the ValueError host tensors get, without a host sync. */
+int ts_ctc_prepare(const void* targets, int32_t targets_kind, int64_t targets_stride, int32_t s_in, const void* target_len,
+                   int32_t target_len_kind, const void* input_len, int32_t input_len_kind, int32_t batch, int32_t s_max,
+                   int32_t n_classes, int32_t* targets_out, int32_t* target_len_out, int32_t* input_len_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fine-tuning with a frozen encoder (the first phase of FinetuneCTCModule + FinetuneEncoderDecoder, finetune.py:19-88,

@@ -101,3 +101,53 @@ def test_ctc_matches_oracle_on_training_like_shapes():
     (2.0 * loss).backward()
     np.testing.assert_allclose(float(loss.detach()), want_loss, rtol=2e-5)
     np.testing.assert_allclose(lg.grad.cpu().numpy(), 2.0 * want_grad, atol=2e-5)
+
+
+@pytest.mark.parametrize("tg_dtype,len_dtype", [(torch.int64, torch.int64), (torch.int32, torch.float32), (torch.int64, torch.float64), (torch.int16, torch.int32)])
+def test_ctc_prepare_kernel_equals_the_torch_rules(tg_dtype, len_dtype):
+    """ts_ctc_prepare (one launch) against ctc_loss._prepare_targets + the input-length rules it replaces for device targets:
+    padding and wild ids rewritten to 0, an utterance with a wild id below its length made infeasible, `.long()` truncation."""
+    from thunder_speech_amd import ctc_loss
+    g = torch.Generator().manual_seed(11)
+    b, s, v = 9, 37, 29
+    tg = torch.randint(0, v, (b, s), generator=g)
+    tl = torch.randint(0, s + 1, (b,), generator=g)
+    tl[0], tl[1] = 0, s
+    tg[2, int(tl[2]) :] = 999                      # wild ids in the padding only: harmless
+    tg[3, 0] = -1                                  # wild ids below the length: rows 3 and 4 become infeasible
+    tl[3] = max(int(tl[3]), 1)
+    tg[4, 5] = v
+    tl[4] = max(int(tl[4]), 6)
+    il = torch.randint(40, 200, (b,), generator=g).to(torch.float64) + 0.75
+    tgd, tld, ild = tg.to(tg_dtype).cuda(), tl.to(len_dtype).cuda(), il.to(len_dtype).cuda()
+    want_tg, want_tl, bad = ctc_loss._prepare_targets(tgd, tld, b, v, tgd.device)
+    want_il = ild.to(torch.int64).to(torch.int32)
+    want_il = torch.where(bad, torch.zeros_like(want_il), want_il)
+    want_tl = torch.where(bad & (want_tl == 0), torch.ones_like(want_tl), want_tl)
+    got_tg, got_tl, got_il = ctc_loss._prepare_on_device(tgd, tld, ild, b, v, tgd.device)
+    assert bad.cpu().tolist() == [False, False, False, True, True] + [False] * 4
+    assert torch.equal(got_tg, want_tg) and torch.equal(got_tl, want_tl) and torch.equal(got_il, want_il)
+    # no labels at all: [B, 0] targets behave like one padded column
+    e_tg, e_tl, e_il = ctc_loss._prepare_on_device(tgd[:, :0], torch.zeros_like(tld), ild, b, v, tgd.device)
+    assert e_tg.shape == (b, 1) and int(e_tg.abs().sum()) == 0 and int(e_tl.abs().sum()) == 0 and torch.equal(e_il, ild.to(torch.int64).to(torch.int32))
+
+
+def test_ctc_long_transcripts_take_two_states_per_thread():
+    """More than 511 labels: 2S+1 > 1024 extended states, i.e. the recursion kernel's two-states-per-thread instantiation; ragged
+    lengths, one infeasible utterance (fewer frames than labels)."""
+    from thunder_speech_amd.ctc_loss import calculate_ctc
+    rng = np.random.Generator(np.random.PCG64(5))
+    B, V, T, S = 3, 12, 1500, 700
+    logits = rng.standard_normal((B, V, T)).astype(np.float32)
+    tl = np.array([700, 520, 650])
+    tg = np.zeros((B, S), dtype=np.int64)
+    for b in range(B):
+        tg[b, : tl[b]] = rng.integers(0, V - 1, tl[b])
+    il = np.array([1500, 1377, 600])               # the last one cannot emit 650 labels in 600 frames: loss 0, gradient 0
+    want_loss, want_grad, _ = octc.calculate_ctc(logits, tg, il, tl, V - 1)
+    lg = torch.from_numpy(logits).cuda().requires_grad_(True)
+    loss = calculate_ctc(lg, torch.from_numpy(tg).cuda(), torch.from_numpy(il).cuda(), torch.from_numpy(tl).cuda(), V - 1)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), want_loss, rtol=5e-5)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), want_grad, atol=2e-5)
+    assert float(lg.grad[2].abs().max()) == 0.0

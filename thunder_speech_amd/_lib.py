@@ -22,7 +22,7 @@ GUARD_BYTES = 1024
 EXPORTED_SYMBOLS = [
     "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd",
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
-    "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss",
+    "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss", "ts_ctc_prepare",
     "ts_pack_activation", "ts_unpack_activation", "ts_lengths_map", "ts_im2col_time", "ts_fe_preemph", "ts_fe_dither", "ts_fe_power_spectrum", "ts_fe_mel", "ts_fe_normalize", "ts_gemm_nt_bf16", "ts_se_gate_fwd", "ts_se_apply_fwd",
     "ts_decoder_bwd", "ts_adamw_step", "ts_adamw_multi_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_workspace", "ts_train_pwconv_wgrad_mfma",
@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
     L.ts_ctc_workspace_bytes.restype = i64
     L.ts_ctc_loss.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.ts_ctc_loss.restype = C.c_int
+    L.ts_ctc_prepare.argtypes = [vp, i32, i64, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.ts_ctc_prepare.restype = C.c_int
     L.ts_pack_activation.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
     L.ts_pack_activation.restype = C.c_int
     L.ts_unpack_activation.argtypes = [vp, i32, i32, i32, i32, vp, vp]

@@ -49,6 +49,36 @@ def _prepare_targets(targets: Tensor, target_lengths: Tensor, b: int, v: int, de
     return tg.to(torch.int32).contiguous(), tl.to(torch.int32).contiguous(), bad_rows
 
 
+_KIND = {torch.int32: 0, torch.int64: 1, torch.float32: 2, torch.float64: 3}
+
+
+def _as_kind(t: Tensor, dev, ints_only: bool = False):
+    """-> (contiguous tensor on `dev` of a dtype ts_ctc_prepare reads, its kind code)."""
+    t = t.to(dev)
+    if t.dtype not in _KIND or (ints_only and t.dtype not in (torch.int32, torch.int64)):
+        t = t.to(torch.int64)
+    return t.contiguous(), _KIND[t.dtype]
+
+
+def _prepare_on_device(targets: Tensor, target_lengths: Tensor, input_lengths: Tensor, b: int, v: int, dev):
+    """_prepare_targets + the input-length handling for 2-D device targets, as ONE launch (ts_ctc_prepare)."""
+    if targets.shape[0] != b:
+        raise ValueError("calculate_ctc: targets must be [batch, S] or the 1-D concatenation of the target sequences")
+    s_in = targets.shape[1]
+    s_max = max(s_in, 1)
+    tg_in, tk = _as_kind(targets, dev, ints_only=True)
+    if s_in == 0:
+        tg_in = torch.empty(b, 1, dtype=tg_in.dtype, device=dev)
+    tl_in, lk = _as_kind(target_lengths, dev)
+    il_in, ik = _as_kind(input_lengths, dev)
+    out = torch.empty(b * s_max + 2 * b, dtype=torch.int32, device=dev)
+    tg, tl, il = out[: b * s_max].view(b, s_max), out[b * s_max: b * s_max + b], out[b * s_max + b:]
+    st = _lib.lib().ts_ctc_prepare(tg_in.data_ptr(), tk, tg_in.stride(0), s_in, tl_in.data_ptr(), lk, il_in.data_ptr(), ik, b, s_max, v,
+                                   tg.data_ptr(), tl.data_ptr(), il.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(st, "ts_ctc_prepare")
+    return tg, tl, il
+
+
 class _CtcFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, targets: Tensor, input_lengths: Tensor, target_lengths: Tensor, blank: int):
@@ -60,12 +90,15 @@ class _CtcFunction(torch.autograd.Function):
             lg = lg.to(torch.float32).contiguous()
         pitch = lg.stride(1)
         dev = lg.device
-        tg, tl, bad_rows = _prepare_targets(targets, target_lengths, b, v, dev)
+        if targets.is_cuda and targets.dim() == 2:
+            tg, tl, il = _prepare_on_device(targets, target_lengths, input_lengths, b, v, dev)
+        else:
+            tg, tl, bad_rows = _prepare_targets(targets, target_lengths, b, v, dev)
+            il = input_lengths.to(device=dev, dtype=torch.int64).to(torch.int32).contiguous()     # .long() (A5)
+            if bad_rows is not None:
+                il = torch.where(bad_rows, torch.zeros_like(il), il)
+                tl = torch.where(bad_rows & (tl == 0), torch.ones_like(tl), tl)    # keep the utterance infeasible even with an empty target
         s_max = tg.shape[1]
-        il = input_lengths.to(device=dev, dtype=torch.int64).to(torch.int32).contiguous()     # .long() (A5)
-        if bad_rows is not None:
-            il = torch.where(bad_rows, torch.zeros_like(il), il)
-            tl = torch.where(bad_rows & (tl == 0), torch.ones_like(tl), tl)    # keep the utterance infeasible even with an empty target
         L = _lib.lib()
         ws = torch.empty(L.ts_ctc_workspace_bytes(b, v, t, s_max), dtype=torch.uint8, device=dev)
         nll = torch.empty(b, dtype=torch.float32, device=dev)

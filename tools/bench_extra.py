@@ -41,7 +41,9 @@ def _timed(run, steps, warmup=2):
 
 def _graphed(step, device):
     side, graph = torch.cuda.Stream(device), torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream(device))
     with torch.cuda.stream(side):
+        step()          # the library's arena buffers are per stream: create (and zero) this stream's before the capture, not inside the graph
         with torch.cuda.graph(graph, stream=side):
             out = step()
     return graph.replay, out

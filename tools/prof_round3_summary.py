@@ -1,5 +1,5 @@
 """Condense the rocprofv3 outputs of tools/prof_round3.sh into the files that go under profiles/ (round3_*).  Per-kernel tables cover the
-TIMED REGION only: the dispatches between the two marker kernels (tools/prof_mark.py) that bracket each timed loop -- warm-up passes,
+TIMED REGION only: the dispatches between the two marker pairs (tools/prof_mark.py) that bracket each timed loop -- warm-up passes,
 graph capture and one-time weight packing are dropped, so the percentages are per-step shares."""
 import collections, csv, glob, json, os, sys
 
@@ -15,9 +15,9 @@ def trace(name, anchor=None):
         return None, 0, 0
     rows = list(csv.DictReader(open(fs[-1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if MARK in r["Kernel_Name"]]
+    marks = [i for i in range(len(rows) - 1) if MARK in rows[i]["Kernel_Name"] and MARK in rows[i + 1]["Kernel_Name"]]   # a marker is a PAIR
     if len(marks) >= 2:
-        rows = rows[marks[0] + 1: marks[1]]
+        rows = [r for r in rows[marks[0] + 2: marks[-1]] if MARK not in r["Kernel_Name"]]
     agg = collections.OrderedDict()
     for r in rows:
         k = r["Kernel_Name"]
@@ -53,7 +53,7 @@ def md_table(rows, top=18):
 
 
 md = ["# Round 3 -- rocprofv3 summaries (tools/prof_round3.sh on one MI355X)", "",
-      "Tables cover the timed region of each run only (between the two `ts::counter_add_kernel` markers of tools/prof_mark.py).", ""]
+      "Tables cover the timed region of each run only (between the two marker pairs of tools/prof_mark.py).", ""]
 rows, span, _ = trace("bench")
 if rows:
     bj = last_json("bench")
@@ -99,14 +99,9 @@ for name, title, key, anchor in (("c3", "C3 Citrinet-1024 inference 32 x 20 s (`
         continue
     bj = (last_json(name) or {}).get(key, {})
     steps = traced or bj.get("steps", 1)
-    graph = traced and traced != bj.get("steps", traced)
     md += [f"## {title}", "", f"bench line of the profiled run: {bj.get('ms_per_step', float('nan')):.2f} ms/step, {bj.get('value', float('nan')):.1f} {bj.get('unit', '')}", ""]
     t, tot = md_table(rows, top=22)
     md += t + ["", f"timed region: {sum(r['Calls'] for r in rows)} launches ({sum(r['Calls'] for r in rows) / steps:.0f} per step), kernel time {tot / 1e6 / steps:.2f} ms per step, "
                    f"{span / 1e6 / steps:.2f} ms wall per step in the trace.", ""]
-    if graph:
-        md[-2] = (f"timed region: the step is replayed from a hipGraph; rocprofv3 lists the graph's kernel nodes for {traced} of the {bj.get('steps')} replays: "
-                  f"{sum(r['Calls'] for r in rows) / steps:.0f} launches and {tot / 1e6 / steps:.2f} ms of kernel time per step (the profiler's per-node "
-                  f"instrumentation slows graph replay: {bj.get('ms_per_step', float('nan')):.2f} ms/step here against the unprofiled figure in DESIGN.md).")
 open(os.path.join(out, "round3_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md[:45]))
