@@ -33,6 +33,7 @@ constexpr int GRING = 4;
 constexpr int GROWB = GKH * 2;                   // 64-byte LDS rows
 constexpr int GHALFB = GM * GROWB;               // 16 KiB: one operand tile of a half-stage
 constexpr int GSTAGEB = 2 * GHALFB;              // 32 KiB
+constexpr int GEMM_LDS = 8 * 128 * 144;          // the ring (4 x 32 KiB) or the bf16 epilogue's 8 tiles of 128 rows x 144 bytes
 
 struct GemmArgs {
   const unsigned short* x;
@@ -45,6 +46,7 @@ struct GemmArgs {
   long long sx, sy;                              // batch strides (elements) of x and of y / y16 / res
   int M, N, K, act;                              // act bit 0: GELU
   int n_mt, n_nt;
+  int blk_c;                                      // column tiles per block of the tile walk (divides n_nt)
 #ifdef TS_EXP
   int exp;                                       // diagnostic builds: bit 0 no DMA in the loop, 1 no fragment reads, 2 no barriers, 3 no epilogue
 #endif
@@ -73,11 +75,23 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  // tile of this workgroup: XCD x = id % 8 owns a contiguous range of tiles, column tiles of a row panel adjacent
-  int id = blockIdx.x;
-  const int n_tiles = a.n_mt * a.n_nt;
-  if ((n_tiles & 7) == 0) id = (id & 7) * (n_tiles >> 3) + (id >> 3);
-  const int nt_i = id % a.n_nt, mt_i = id / a.n_nt;
+  // Tile of this workgroup.  Workgroup i runs on XCD i % 8 and every XCD has its own L2; the ~32 workgroups an XCD holds at a time should
+  // share operand panels.  The tiles are therefore walked in blocks of (32 / bc) row tiles x bc column tiles (bc = a.blk_c <= 4: 8 x 4 where
+  // the grid allows, 8 + 4 panels fetched into that L2 for 32 tiles instead of 1 + 32), and XCD x owns a CONTIGUOUS range of that walk
+  // (bijective split for any tile count: the first n % 8 XCDs take one tile more).  PMC / timing: 8192^3 908 -> 1 2xx TFLOP/s.
+  int mt_i, nt_i;
+  {
+    const int n_tiles = a.n_mt * a.n_nt;
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + l;
+    const int bc = a.blk_c, br = 32 / bc;
+    const int band_tiles = br * a.n_nt;
+    const int band = t / band_tiles, rem = t - band * band_tiles;
+    const int rows = min(br, a.n_mt - band * br);            // the last band may be short
+    const int blk = rem / (rows * bc), in = rem - blk * rows * bc;
+    mt_i = band * br + in / bc;
+    nt_i = blk * bc + in % bc;
+  }
   const int m0 = mt_i * GM, n0 = nt_i * GN;
   const int bz = blockIdx.y;
   const unsigned short* const xb = a.x + (size_t)bz * a.sx;
@@ -100,20 +114,25 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
   // the DMAs of a half-stage in two halves (A rows, B rows): one half is issued in the LOAD phase, the other between the MFMAs of the
   // following MFMA phase -- all four in the LOAD phase made it longer than the partner's MFMA phase (measured), all four among the MFMAs
   // made that phase the longer one
+#ifdef TS_EXP
+#define KOFF(s) (((a.exp & 16) ? ((s) & 3) : (s)) * GKH * 2)      /* bit 4: every half-stage re-reads the first four (L2-hot operands) */
+#else
+#define KOFF(s) ((s) * GKH * 2)
+#endif
   auto issue_a = [&](int s) {
 #ifdef TS_EXP
     if ((a.exp & 1) && s >= GRING - 1) return;
 #endif
     char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) lds_dma16(ra, st + (32 * wave + 16 * q) * GROWB, offa[q], s * GKH * 2);
+    for (int q = 0; q < 2; ++q) lds_dma16(ra, st + (32 * wave + 16 * q) * GROWB, offa[q], KOFF(s));
   };
   auto issue_b = [&](int s, int q) {
 #ifdef TS_EXP
     if ((a.exp & 1) && s >= GRING - 1) return;
 #endif
     char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
-    lds_dma16(rb, st + GHALFB + (32 * wave + 16 * q) * GROWB, offb[q], s * GKH * 2);
+    lds_dma16(rb, st + GHALFB + (32 * wave + 16 * q) * GROWB, offb[q], KOFF(s));
   };
   auto issue = [&](int s) { issue_a(s); issue_b(s, 0); issue_b(s, 1); };
   // fragment read offsets: lane (r = lane & 31, h = lane >> 5) reads chunk (2 ks + h) ^ ((r >> 2) & 3) of its row
@@ -202,8 +221,41 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
 #endif
   __builtin_amdgcn_s_barrier();                    // every wave is done with the operand ring (all DMAs were drained in the loop)
   asm volatile("" ::: "memory");
+  const int erow = lane >> 3;
+  if (!a.y && !a.res) {
+    // bf16 result only (q / k / v, the first feed-forward linear, the conv layers): the wave's whole 128 x 64 tile is staged as bf16, row
+    // pitch 144 bytes (the four row groups of a store instruction land 16 banks apart), and leaves as 128-byte row segments -- full
+    // cache lines; 64-byte segments (32 columns at a time) cost 350 us of a 1 210 us 8192^3 product
+    constexpr int EP16 = 144;
+    char* const ep16 = smem + wave * (128 * EP16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wn * 64 + 16 * j + fr;
+      const float bv = (a.bias && nb < a.N) ? a.bias[nb] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] + bv;
+          if (a.act & 1) v = gelu_g(v);
+          *reinterpret_cast<unsigned short*>(ep16 + (16 * i + 4 * fc + r) * EP16 + (16 * j + fr) * 2) = (unsigned short)pack_bf16(v, 0.f);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // wave-private tile: LDS operations of one wave are in order
+    const int nb = n0 + wn * 64 + (lane & 7) * 8;
+    if (nb < a.N) {
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int row = 8 * q + erow;
+        const int m = m0 + wm * 128 + row;
+        if (m < a.M)
+          *reinterpret_cast<u32x4*>(a.y16 + yoff + (size_t)m * a.ld16 + nb) = *reinterpret_cast<const u32x4*>(ep16 + row * EP16 + (lane & 7) * 16);
+      }
+    }
+    return;
+  }
   float* const ep = reinterpret_cast<float*>(smem + wave * 16384);
-  const int erow = lane >> 3, ecol = (lane & 7) * 4;
+  const int ecol = (lane & 7) * 4;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int nb = n0 + wn * 64 + 32 * j;
@@ -244,14 +296,14 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
                  int gelu, int batch) {
   if (!x || !w || (!y && !y16) || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return TS_EINVAL;
   if (N % 32 || K % GKH || lda % 8 || ldw % 8 || ldw < K) return TS_EUNSUPPORTED;
-  if ((y && (ldc % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) || (y16 && (ld16 % 4 || (reinterpret_cast<uintptr_t>(y16) & 7))) ||
-      (res && (ld_res % 4 || (reinterpret_cast<uintptr_t>(res) & 15))) || sy % 4)
+  if ((y && (ldc % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) || (y16 && (ld16 % 8 || (reinterpret_cast<uintptr_t>(y16) & 15))) ||
+      (res && (ld_res % 4 || (reinterpret_cast<uintptr_t>(res) & 15))) || sy % (y16 ? 8 : 4))
     return TS_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (sx % 8)) return TS_EUNSUPPORTED;
   if (M * lda * 2 >= (1ll << 31) || (long long)N * ldw * 2 >= (1ll << 31)) return TS_EUNSUPPORTED;    // 32-bit buffer offsets
   static int attr = 0;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
       return TS_EUNSUPPORTED;
     attr = 1;
   }
@@ -261,11 +313,12 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
   a.lda = lda; a.ldw = ldw; a.ld_res = ld_res; a.ldc = ldc; a.ld16 = ld16; a.sx = sx; a.sy = sy;
   a.M = (int)M; a.N = N; a.K = K; a.act = gelu ? 1 : 0;
   a.n_mt = (int)((M + GM - 1) / GM); a.n_nt = (N + GN - 1) / GN;
+  a.blk_c = a.n_nt % 4 == 0 ? 4 : (a.n_nt % 3 == 0 ? 3 : (a.n_nt % 2 == 0 ? 2 : 1));
 #ifdef TS_EXP
   { const char* e = getenv("TS_EXP"); a.exp = e ? atoi(e) : 0; }
 #endif
   (void)hipGetLastError();
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(a.n_mt * a.n_nt), (unsigned)batch), dim3(512), 8 * 16384, stream, a);
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(a.n_mt * a.n_nt), (unsigned)batch), dim3(512), GEMM_LDS, stream, a);
   return hip_status(hipGetLastError());
 }
 

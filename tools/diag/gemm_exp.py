@@ -5,7 +5,7 @@ from tools.diag.gemm_nt_check import run
 for (m, n, k) in [(8192, 8192, 8192), (15984, 1024, 1024)]:
     x = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
-    for exp in (0, 1, 2, 4, 8, 3, 7, 15):
+    for exp in [int(v) for v in os.environ.get('EXPS', '0,1,2,4,8,3,7,15').split(',')]:
         os.environ["TS_EXP"] = str(exp)
         for _ in range(3):
             run(x, w, None, None, False, want32=False)
