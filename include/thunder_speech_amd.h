@@ -382,9 +382,10 @@ int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samples, const 
                      int32_t c, int32_t kernel, int32_t stride, float eps, float* y, void* y_bf16, void* workspace, void* stream);
 /* conv layers 1..6: act(Conv1d(c_in, c_out, kernel, stride) + bias); bias f32 [c_out] or NULL; act 0 = none, 1 = GELU.  x [B][t_in][c_in];
  * w_taps [c_out][kernel][c_in] (the reference's [c_out][c_in][kernel] with the last two axes swapped); y f32 [B][t_out][c_out]
- * (GEMM accumulator; when y_bf16 is given only the bf16 copy holds the result). */
+ * (GEMM accumulator; when y_bf16 is given only the bf16 copy holds the result).  w_frag (may be NULL; bf16 mode): w_taps as MFMA B fragments,
+ * ts_gemm_nt_pack_w(w_taps, kernel * c_in, c_out, kernel * c_in, ...) -- static weights are packed once and then bypass LDS. */
 int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, const float* bias, int32_t c_out,
-                    int32_t kernel, int32_t stride, int32_t act, int32_t precision, float* y, void* y_bf16, void* stream);
+                    int32_t kernel, int32_t stride, int32_t act, int32_t precision, float* y, void* y_bf16, const void* w_frag, void* stream);
 /* Token-major bf16 GEMM with fused epilogue (csrc/gemm_nt.hip) -- what ts_w2v_linear_fwd / ts_w2v_conv_fwd run in bf16 mode, exported for
  * tests and tools:  y[m][n] = act(sum_k x[m][k] w[n][k] + bias[n]) + res[m][n],  x: bf16 rows of pitch lda, w: bf16 [n][k] rows of pitch
  * ldw (torch.nn.Linear layout), f32 accumulation; bias / res (f32) may be NULL; gelu = 1: erf-GELU before the residual; y (f32, pitch ldc)
@@ -392,11 +393,17 @@ int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, co
  * 16-byte aligned operands; anything else returns TS_EUNSUPPORTED. */
 int ts_gemm_nt_bf16(const void* x, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res, int64_t ld_res, float* y,
                     int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k, int32_t gelu, void* stream);
+/* The same product with the (static) weights additionally supplied as MFMA B fragments, w_frag[n / 16][k / 32][64][8] bf16 written by
+ * ts_gemm_nt_pack_w (n * k elements; n % 16 == 0, k % 32 == 0): the B operand then goes from L2 straight to registers instead of through LDS. */
+int ts_gemm_nt_pack_w(const void* w, int64_t ldw, int32_t n, int32_t k, void* w_frag, void* stream);
+int ts_gemm_nt_bf16_packed(const void* x, int64_t lda, const void* w, int64_t ldw, const void* w_frag, const float* bias, const float* res,
+                           int64_t ld_res, float* y, int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k, int32_t gelu,
+                           void* stream);
 /* y[r][:n] = act(x[r][:k] W^T + bias) + res[r][:n];  W [n][k]; bias / res (f32) may be NULL; act bit 0: GELU (erf), bit 1:
  * only y_bf16 is wanted (y is then scratch space for the f32 GEMM result).  res == y (same pitch): the product is accumulated into y
  * in place (the residual stream).  lda / ldc / ld_res: row pitches in elements. */
 int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res, float* y,
-                      int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision, void* stream);
+                      int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision, const void* w_frag, void* stream);
 /* y = act(LayerNorm(x + xbias + res) * w + b) over the last dimension; x, res (may be NULL), y f32 [rows][c]; xbias f32 [c] or
  * NULL: the bias of the linear layer that produced x, applied here instead of in a pass of its own; act 0 = none, 1 = GELU. */
 int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* xbias, const float* w, const float* b, float eps, int64_t rows,

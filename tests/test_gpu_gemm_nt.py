@@ -75,3 +75,35 @@ def test_gemm_nt_declines_shapes_it_does_not_take():
     st = _lib.lib().ts_gemm_nt_bf16(x.data_ptr(), 40, w.data_ptr(), 40, None, None, 0, y.data_ptr(), 48, None, 0, 64, 48, 40, 0,
                                     torch.cuda.current_stream().cuda_stream)
     assert st == _lib.TS_EUNSUPPORTED                                                       # n % 32, k % 32
+
+
+@pytest.mark.parametrize("m,n,k,gelu,use_res", [(300, 96, 64, False, True), (999, 1024, 1024, True, False), (1998, 1024, 4096, False, True),
+                                                 (513, 512, 1536, True, False), (257, 4096, 1024, True, False), (4000, 32, 96, False, False),
+                                                 (700, 64, 32, False, False)])
+def test_gemm_nt_packed_weights_give_the_same_bits(m, n, k, gelu, use_res):
+    """ts_gemm_nt_bf16_packed (B fragments from L2 straight into registers, ts_gemm_nt_pack_w) multiplies the same bf16 values in the
+    same order as the LDS path: results are bit-identical for every epilogue form; the packed image itself is checked against the
+    fragment layout it documents."""
+    from thunder_speech_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(7 * m + n + k)
+    x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(n, device="cuda", generator=g)
+    res = torch.randn(m, n, device="cuda", generator=g) if use_res else None
+    L, stream = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    wf = torch.empty_like(w)
+    _lib.check(L.ts_gemm_nt_pack_w(w.data_ptr(), k, n, k, wf.data_ptr(), stream), "ts_gemm_nt_pack_w")
+    lane = torch.arange(64, device="cuda")
+    want = w.view(n // 16, 16, k // 32, 4, 8)[:, lane & 15, :, lane >> 4, :].permute(1, 2, 0, 3)      # [n/16][k/32][lane][8]
+    assert torch.equal(wf.view(n // 16, k // 32, 64, 8), want)
+    for want32, want16 in ((True, True), (False, True), (True, False)):
+        if not want32 and res is not None:
+            continue
+        y, y16 = _run(x, w, bias, res, gelu, want32, want16)
+        yp = torch.empty_like(y) if want32 else None
+        yp16 = torch.empty_like(y16) if want16 else None
+        st = L.ts_gemm_nt_bf16_packed(x.data_ptr(), k, w.data_ptr(), k, wf.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None,
+                                      n if res is not None else 0, yp.data_ptr() if want32 else None, n, yp16.data_ptr() if want16 else None, n,
+                                      m, n, k, int(gelu), stream)
+        _lib.check(st, "ts_gemm_nt_bf16_packed")
+        assert (not want32 or torch.equal(y, yp)) and (not want16 or torch.equal(y16, yp16))

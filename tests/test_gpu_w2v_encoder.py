@@ -183,7 +183,7 @@ def test_fused_epilogue_linear_matches_unfused_path(act):
     y = torch.empty(rows, n, dtype=torch.float32, device="cuda")
     y16 = torch.zeros(rows, n, dtype=torch.bfloat16, device="cuda")
     st = L.ts_w2v_linear_fwd(xd.data_ptr(), k, wd.data_ptr(), bd.data_ptr(), None, n, y.data_ptr(), n, y16.data_ptr(), rows, n, k, act | 2, 1,
-                             torch.cuda.current_stream().cuda_stream)
+                             None, torch.cuda.current_stream().cuda_stream)
     assert st == 0
     torch.cuda.synchronize()
     err = (y16.float().cpu() - ref).abs()

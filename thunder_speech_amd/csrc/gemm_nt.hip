@@ -38,6 +38,7 @@ constexpr int GEMM_LDS = 8 * 128 * 144;          // the ring (4 x 32 KiB) or the
 struct GemmArgs {
   const unsigned short* x;
   const unsigned short* w;
+  const unsigned short* wf;                      // PB kernels: w as MFMA B fragments [N / 16][K / 32][64 lanes][8] (gemm_nt_pack_w)
   const float* bias;
   const float* res;
   float* y;
@@ -71,6 +72,13 @@ __device__ __forceinline__ float gelu_g(float x) { return 0.5f * x * (1.f + erf_
 
 }  // namespace
 
+// PB: the B operand does not pass through LDS.  The weights are static, so they are packed once (gemm_nt_pack_w) in the fragment order
+// of v_mfma_f32_16x16x32_bf16 -- 1 KiB per (16 columns, 32-deep step), lane-linear -- and every wave loads the four fragments of its 64
+// columns straight into a register ring three steps deep (perfectly coalesced 1-KiB loads, L2-resident: all row tiles share them).
+// That takes a quarter of the bytes off the LDS pipe (96 + 32 KiB per step were exactly the 128 B / clk it can move in a step's 1 024 MFMA
+// cycles), halves the LDS-DMA instructions -- whose issue cost is what the ring showed (tools/diag/gemm_exp.py: 21 % of the 8192^3
+// product with L2-hot sources) -- and leaves the MFMA phase free of memory instructions.
+template <bool PB>
 __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,17 +206,78 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  if constexpr (PB) {
+    // ---- B fragments from global memory into a 3-deep register ring; A through the LDS ring as before (its B halves stay unused) ----
+    const int S_ = S;
+    const i32x4 rf = raw_rsrc(a.wf, 0x7fffffffu);
+    int offf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int nb = (n0 + wn * 64) / 16 + j;
+      nb = nb < a.N / 16 ? nb : a.N / 16 - 1;                               // column blocks beyond N: any valid fragment, results are masked
+      offf[j] = nb * S_ * 1024 + lane * 16;
+    }
+    // the loads are inline asm: hipcc does not count the LDS-DMAs in its vmcnt model, so for loads it does track it would insert waits
+    // that are too strict (measured: vmcnt(0) at every use, 2-3x slower); with asm loads every wait of the loop is one of the counted
+    // vmw<> below, each followed by a sched_barrier so that no MFMA moves above it
+    s16x8 fbr[2][4];
+    auto load_b = [&](s16x8 (&slot)[4], int s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(slot[j]) : "v"(offf[j]), "s"(rf), "s"(s * 1024) : "memory");
+    };
+    // issue order of a wave: A0 B0 A1 A2 | B1 A3 | B2 A4 | ...  (A = 2 LDS-DMAs, B = 4 loads into the register set the previous step's
+    // MFMAs have just released).  At the end of LOAD(s) everything up to B(s) has to be there -- B(s) for this step's MFMAs, A(s+1),
+    // issued before it, for the next step's reads a barrier later: A(s+2) B(s+1) A(s+3) may stay in flight, 8 operations, fewer at the end.
+    auto wait_tail = [&](int s) {
+      const int left = S_ - 1 - s;                                            // steps after s
+      if (left >= 3) vmw<8>(); else if (left == 2) vmw<6>(); else if (left == 1) vmw<4>(); else vmw<0>();
+    };
+    issue_a(0);
+    load_b(fbr[0], 0);
+    if (S_ > 1) issue_a(1);
+    if (S_ > 2) issue_a(2);
+    if (S_ > 2) vmw<8>(); else if (S_ > 1) vmw<6>(); else vmw<4>();         // A(0) has landed
+    phase_barrier();
+    if (wm == 1) phase_barrier();
+    auto step = [&](int s, s16x8 (&cur)[4], s16x8 (&nxt)[4]) {
+      const char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
+      if (s + 1 < S_) load_b(nxt, s + 1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const s16x8*>(st + fa0 + i * 16 * GROWB);
+      if (s + GRING - 1 < S_) issue_a(s + GRING - 1);
+      wait_tail(s);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      phase_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], cur[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      phase_barrier();
+    };
+    int s = 0;
+    for (; s + 2 <= S_; s += 2) {
+      step(s, fbr[0], fbr[1]);
+      step(s + 1, fbr[1], fbr[0]);
+    }
+    if (s < S_) step(s, fbr[0], fbr[1]);
+  } else {
   for (int s = 0; s < GRING - 1 && s < S; ++s) issue(s);
-  if (S > 2) vmw<8>(); else if (S > 1) vmw<4>(); else vmw<0>();
-  phase_barrier();                                                        // half-stage 0 is in LDS
-  if (wm == 1) phase_barrier();                                           // the second wave row starts one phase later
-  for (int s = 0; s < S; ++s) {
-    load_phase(s);
-    __builtin_amdgcn_sched_barrier(0);
-    phase_barrier();
-    mfma_phase(s);
-    __builtin_amdgcn_sched_barrier(0);
-    phase_barrier();
+    if (S > 2) vmw<8>(); else if (S > 1) vmw<4>(); else vmw<0>();
+    phase_barrier();                                                        // half-stage 0 is in LDS
+    if (wm == 1) phase_barrier();                                           // the second wave row starts one phase later
+    for (int s = 0; s < S; ++s) {
+      load_phase(s);
+      __builtin_amdgcn_sched_barrier(0);
+      phase_barrier();
+      mfma_phase(s);
+      __builtin_amdgcn_sched_barrier(0);
+      phase_barrier();
+    }
   }
   if (wm == 0) phase_barrier();                                           // the first row's partner of the extra barrier above
   // ---- epilogue ------------------------------------------------------------------------------------------------------
@@ -291,9 +360,33 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
 }
 
 // y = act(x w^T + bias) + res; see the header of this file.  TS_EUNSUPPORTED for shapes the kernel does not take.
+// w as MFMA B fragments: out[N / 16][K / 32][64][8] bf16, lane (n = lane & 15, c = lane >> 4) of fragment (nb, s) holds
+// w[16 nb + n][32 s + 8 c .. + 7] -- N * K elements, N % 16 == 0 and K % 32 == 0
+__global__ void gemm_pack_w_kernel(const unsigned short* __restrict__ w, long long ldw, int N, int K, unsigned short* __restrict__ out) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte group
+  const int S = K / GKH;
+  if (g >= (long long)(N / 16) * S * 64) return;
+  const int lane = (int)(g & 63);
+  const long long f = g >> 6;
+  const int s = (int)(f % S), nb = (int)(f / S);
+  const unsigned short* src = w + (size_t)(16 * nb + (lane & 15)) * ldw + 32 * s + 8 * (lane >> 4);
+  *reinterpret_cast<u32x4*>(out + g * 8) = *reinterpret_cast<const u32x4*>(src);
+}
+
+int gemm_nt_pack_w(hipStream_t stream, const void* w, long long ldw, int N, int K, void* out) {
+  if (!w || !out || N <= 0 || K <= 0) return TS_EINVAL;
+  if (N % 16 || K % GKH || ldw % 8 || ldw < K || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return TS_EUNSUPPORTED;
+  const long long groups = (long long)(N / 16) * (K / GKH) * 64;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gemm_pack_w_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, static_cast<const unsigned short*>(w), ldw, N, K,
+                     static_cast<unsigned short*>(out));
+  return hip_status(hipGetLastError());
+}
+
+// wf: w in fragment order (gemm_nt_pack_w) or null
 int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
                  const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
-                 int gelu, int batch) {
+                 int gelu, int batch, const void* wf) {
   if (!x || !w || (!y && !y16) || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return TS_EINVAL;
   if (N % 32 || K % GKH || lda % 8 || ldw % 8 || ldw < K) return TS_EUNSUPPORTED;
   if ((y && (ldc % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) || (y16 && (ld16 % 8 || (reinterpret_cast<uintptr_t>(y16) & 15))) ||
@@ -303,12 +396,14 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
   if (M * lda * 2 >= (1ll << 31) || (long long)N * ldw * 2 >= (1ll << 31)) return TS_EUNSUPPORTED;    // 32-bit buffer offsets
   static int attr = 0;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
       return TS_EUNSUPPORTED;
     attr = 1;
   }
+  if (wf && (reinterpret_cast<uintptr_t>(wf) & 15)) return TS_EUNSUPPORTED;
   GemmArgs a;
-  a.x = static_cast<const unsigned short*>(x); a.w = static_cast<const unsigned short*>(w); a.bias = bias; a.res = res; a.y = y;
+  a.x = static_cast<const unsigned short*>(x); a.w = static_cast<const unsigned short*>(w); a.wf = static_cast<const unsigned short*>(wf); a.bias = bias; a.res = res; a.y = y;
   a.y16 = static_cast<unsigned short*>(y16);
   a.lda = lda; a.ldw = ldw; a.ld_res = ld_res; a.ldc = ldc; a.ld16 = ld16; a.sx = sx; a.sy = sy;
   a.M = (int)M; a.N = N; a.K = K; a.act = gelu ? 1 : 0;
@@ -318,7 +413,9 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
   { const char* e = getenv("TS_EXP"); a.exp = e ? atoi(e) : 0; }
 #endif
   (void)hipGetLastError();
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(a.n_mt * a.n_nt), (unsigned)batch), dim3(512), GEMM_LDS, stream, a);
+  const dim3 grid((unsigned)(a.n_mt * a.n_nt), (unsigned)batch);
+  if (wf) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(512), GEMM_LDS, stream, a);
+  else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(512), GEMM_LDS, stream, a);
   return hip_status(hipGetLastError());
 }
 
@@ -328,5 +425,16 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
 extern "C" int ts_gemm_nt_bf16(const void* x, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res, int64_t ld_res,
                                float* y, int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k, int32_t gelu, void* stream) {
   if (lda < 0 || ldw < k || (y && ldc < n) || (y_bf16 && ld16 < n) || (res && ld_res < n)) return TS_EINVAL;
-  return ts::gemm_nt_bf16((hipStream_t)stream, x, lda, 0, w, ldw, bias, res, ld_res, y, ldc, y_bf16, ld16, 0, rows, n, k, gelu, 1);
+  return ts::gemm_nt_bf16((hipStream_t)stream, x, lda, 0, w, ldw, bias, res, ld_res, y, ldc, y_bf16, ld16, 0, rows, n, k, gelu, 1, nullptr);
+}
+
+/* the same product with the weights ALSO given in fragment order (ts_gemm_nt_pack_w): the B operand then bypasses LDS */
+extern "C" int ts_gemm_nt_pack_w(const void* w, int64_t ldw, int32_t n, int32_t k, void* w_frag, void* stream) {
+  return ts::gemm_nt_pack_w((hipStream_t)stream, w, ldw, n, k, w_frag);
+}
+extern "C" int ts_gemm_nt_bf16_packed(const void* x, int64_t lda, const void* w, int64_t ldw, const void* w_frag, const float* bias, const float* res,
+                                      int64_t ld_res, float* y, int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k,
+                                      int32_t gelu, void* stream) {
+  if (!w_frag || lda < 0 || ldw < k || (y && ldc < n) || (y_bf16 && ld16 < n) || (res && ld_res < n)) return TS_EINVAL;
+  return ts::gemm_nt_bf16((hipStream_t)stream, x, lda, 0, w, ldw, bias, res, ld_res, y, ldc, y_bf16, ld16, 0, rows, n, k, gelu, 1, w_frag);
 }

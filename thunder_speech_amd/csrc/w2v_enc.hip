@@ -495,7 +495,7 @@ static int gemm_nt(rocblas_handle h, bool bf16, long long m, int n, int k, const
 // our own token-major bf16 GEMM with the fused epilogue (csrc/gemm_nt.hip): the default of the bf16 mode since round 3
 int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
                  const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
-                 int gelu, int batch);
+                 int gelu, int batch, const void* wf);
 // TS_W2V_VENDOR_GEMM=1: the library GEMMs of rounds 1-2 instead (A/B timing; also what shapes our kernel declines fall back to)
 static bool vendor_gemm() {
   static const bool v = [] { const char* e = getenv("TS_W2V_VENDOR_GEMM"); return e && e[0] == '1'; }();
@@ -609,7 +609,7 @@ extern "C" int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samp
 
 extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32_t c_in, const void* w_taps, const float* bias,
                                int32_t c_out, int32_t kernel, int32_t stride, int32_t act, int32_t precision, float* y, void* y_bf16,
-                               void* stream_) {
+                               const void* w_frag, void* stream_) {
   if (!x || !w_taps || !y || batch <= 0 || c_in <= 0 || c_out <= 0 || kernel <= 0 || stride <= 0 || t_in < kernel) return TS_EINVAL;
   if (c_out % 4 || precision < 0 || precision > 1 || act < 0 || act > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
@@ -625,7 +625,7 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
     // ONE launch for all clips (grid.y = clip): rows of the operand overlap when kernel > stride, which a kernel that only ever uses
     // the row pitch does not mind; bias + GELU in the epilogue, bf16 result only
     const int st = gemm_nt_bf16(stream, x, (long long)stride * c_in, (long long)t_in * c_in, w_taps, (long long)kernel * c_in, bias, nullptr, 0,
-                                nullptr, 0, y_bf16, c_out, (long long)t_out * c_out, t_out, c_out, kernel * c_in, act != 0, batch);
+                                nullptr, 0, y_bf16, c_out, (long long)t_out * c_out, t_out, c_out, kernel * c_in, act != 0, batch, w_frag);
     if (st != TS_EUNSUPPORTED) return st;
   }
   if (precision && y_bf16 && overlap_ok && c_in % 8 == 0 && c_out % 8 == 0) {
@@ -656,7 +656,7 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
 
 extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res,
                                  float* y, int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision,
-                                 void* stream_) {
+                                 const void* w_frag, void* stream_) {
   if (!x || !w || !y || rows <= 0 || n <= 0 || k <= 0 || lda < k || ldc < n || (res && ld_res < n)) return TS_EINVAL;
   if (n % 4 || ldc % 4 || (res && ld_res % 4) || act < 0 || act > 3 || precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   if ((act & 2) && !y_bf16) return TS_EINVAL;
@@ -665,7 +665,7 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
   if (int st = blas(stream, &h)) return st;
   if (precision && !vendor_gemm()) {
     // bf16 operands: our GEMM with bias / GELU / residual in its epilogue; the f32 result is skipped when only the bf16 copy is wanted
-    const int st = gemm_nt_bf16(stream, x, lda, 0, w, k, bias, res, ld_res, (act & 2) ? nullptr : y, ldc, y_bf16, n, 0, rows, n, k, act & 1, 1);
+    const int st = gemm_nt_bf16(stream, x, lda, 0, w, k, bias, res, ld_res, (act & 2) ? nullptr : y, ldc, y_bf16, n, 0, rows, n, k, act & 1, 1, w_frag);
     if (st != TS_EUNSUPPORTED) return st;
   }
   // bf16 operands, only the bf16 copy of the result wanted, a bias to add: one library GEMM with the epilogue fused

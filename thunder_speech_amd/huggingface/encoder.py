@@ -102,6 +102,27 @@ class Wav2Vec2Plan:
                 w2=gw(f(q + "feed_forward.output_dense.weight")), b2=f(q + "feed_forward.output_dense.bias"),
                 ln2=(f(q + "final_layer_norm.weight"), f(q + "final_layer_norm.bias"))))
 
+    def _frag(self, w: torch.Tensor):
+        """The bf16 GEMM weight `w` [n][k] in MFMA B-fragment order (ts_gemm_nt_pack_w), packed once per weight: the GEMM kernel then
+        loads its B operand from L2 straight into registers.  None in fp32 mode or for shapes the packed kernel does not take."""
+        if not self.prec:
+            return None
+        cache = self.__dict__.setdefault("_frags", {})
+        key = w.data_ptr()
+        if key not in cache:
+            w2 = w.reshape(w.shape[0], -1)
+            n, k = w2.shape
+            out = None
+            if n % 16 == 0 and k % 32 == 0 and w2.is_contiguous():
+                out = torch.empty_like(w2)
+                st = _lib.lib().ts_gemm_nt_pack_w(w2.data_ptr(), k, n, k, out.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+                if st == _lib.TS_EUNSUPPORTED:
+                    out = None
+                else:
+                    _lib.check(st, "ts_gemm_nt_pack_w")
+            cache[key] = (out, w)            # holds w so that the key stays unique
+        return cache[key][0]
+
     # ---- launch helpers: every helper returns (fp32 result, GEMM operand for the next stage) ------------------------
     def _buf(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
@@ -123,7 +144,7 @@ class Wav2Vec2Plan:
         res = into if into is not None else res
         y_op = self._op(b, t, n) if want_op else None
         st = L.ts_w2v_linear_fwd(x_op.data_ptr(), k, w.data_ptr(), self._ptr(bias), self._ptr(res), n, y.data_ptr(), n, self._ptr(y_op),
-                                 b * t, n, k, act | (2 if y_op is not None else 0), self.prec, stream)
+                                 b * t, n, k, act | (2 if y_op is not None else 0), self.prec, self._ptr(self._frag(w)), stream)
         _lib.check(st, "ts_w2v_linear_fwd")
         return y, (y_op if self.prec else y)
 
@@ -160,7 +181,7 @@ class Wav2Vec2Plan:
                     raise RuntimeError("wav2vec2: input too short for the conv feature extractor")
                 y = self._buf(b, t_out, self.dims[i])
                 _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self._ptr(self.conv_b[i]), self.dims[i],
-                                             k, s, 0, self.prec, y.data_ptr(), None, stream), "ts_w2v_conv_fwd")
+                                             k, s, 0, self.prec, y.data_ptr(), None, self._ptr(self._frag(w)), stream), "ts_w2v_conv_fwd")
                 h, x_op = self._ln(L, stream, y, self.conv_ln[i], act=1, eps=1e-5, want_op=i < n_conv - 1)
                 t = t_out
             return h
@@ -179,7 +200,7 @@ class Wav2Vec2Plan:
             y = self._buf(b, t_out, self.dims[i])
             y_op = None if last else self._op(b, t_out, self.dims[i])
             _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self._ptr(self.conv_b[i]), self.dims[i], k, s,
-                                         1, self.prec, y.data_ptr(), self._ptr(y_op), stream), "ts_w2v_conv_fwd")
+                                         1, self.prec, y.data_ptr(), self._ptr(y_op), self._ptr(self._frag(w)), stream), "ts_w2v_conv_fwd")
             h, t = y, t_out
             x_op = y_op if self.prec else y
         return h
