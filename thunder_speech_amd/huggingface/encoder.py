@@ -8,6 +8,8 @@ difference); the arithmetic runs in `Wav2Vec2Plan`, which keeps packed fp32 devi
 call per stage.  Group-norm / post-LN configurations only (wav2vec2-base-960h, -large-960h); no CPU fallback."""
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
@@ -105,7 +107,7 @@ class Wav2Vec2Plan:
     def _frag(self, w: torch.Tensor):
         """The bf16 GEMM weight `w` [n][k] in MFMA B-fragment order (ts_gemm_nt_pack_w), packed once per weight: the GEMM kernel then
         loads its B operand from L2 straight into registers.  None in fp32 mode or for shapes the packed kernel does not take."""
-        if not self.prec:
+        if not self.prec or os.environ.get("TS_W2V_NO_FRAG") == "1":          # (the switch is for A/B timing of the two operand paths)
             return None
         cache = self.__dict__.setdefault("_frags", {})
         key = w.data_ptr()
