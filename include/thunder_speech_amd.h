@@ -205,10 +205,13 @@ int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes, int32_t n
  * stride targets_stride; lengths int32 / int64 / float32 / float64 (kind 0..3), truncated toward zero like the reference's `.long()`)
  * -> the int32 arrays ts_ctc_loss reads: targets_out [B][s_max] (s_max >= max(s_in, 1)) with positions >= length and ids outside
  * [0, n_classes) set to 0; an utterance with such an id below its length gets input length 0 and a target length >= 1 (infeasible:
- * loss 0 under zero_infinity, zero gradient) -- the device-side form of the ValueError host tensors get, without a host sync. */
+ * loss 0 under zero_infinity, zero gradient) -- the device-side form of the ValueError host tensors get, without a host sync;
+ * bad_rows_total (may be NULL): device counter incremented once per such utterance, for the caller to inspect at a point where it
+ * synchronises anyway (epoch end). */
 int ts_ctc_prepare(const void* targets, int32_t targets_kind, int64_t targets_stride, int32_t s_in, const void* target_len,
                    int32_t target_len_kind, const void* input_len, int32_t input_len_kind, int32_t batch, int32_t s_max,
-                   int32_t n_classes, int32_t* targets_out, int32_t* target_len_out, int32_t* input_len_out, void* stream);
+                   int32_t n_classes, int32_t* targets_out, int32_t* target_len_out, int32_t* input_len_out, int32_t* bad_rows_total,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fine-tuning with a frozen encoder (the first phase of FinetuneCTCModule + FinetuneEncoderDecoder, finetune.py:19-88,

@@ -124,7 +124,9 @@ def test_ctc_prepare_kernel_equals_the_torch_rules(tg_dtype, len_dtype):
     want_il = ild.to(torch.int64).to(torch.int32)
     want_il = torch.where(bad, torch.zeros_like(want_il), want_il)
     want_tl = torch.where(bad & (want_tl == 0), torch.ones_like(want_tl), want_tl)
+    dropped = ctc_loss.bad_target_rows(tgd.device)
     got_tg, got_tl, got_il = ctc_loss._prepare_on_device(tgd, tld, ild, b, v, tgd.device)
+    assert ctc_loss.bad_target_rows(tgd.device) == dropped + 2          # the device-side count of dropped utterances (ADVICE: no silent shrinking)
     assert bad.cpu().tolist() == [False, False, False, True, True] + [False] * 4
     assert torch.equal(got_tg, want_tg) and torch.equal(got_tl, want_tl) and torch.equal(got_il, want_il)
     # no labels at all: [B, 0] targets behave like one padded column
@@ -151,3 +153,15 @@ def test_ctc_long_transcripts_take_two_states_per_thread():
     np.testing.assert_allclose(float(loss.detach()), want_loss, rtol=5e-5)
     np.testing.assert_allclose(lg.grad.cpu().numpy(), want_grad, atol=2e-5)
     assert float(lg.grad[2].abs().max()) == 0.0
+
+
+def test_error_rate_call_returns_the_batch_value_and_compute_the_running_one():
+    """torchmetrics' forward semantics: metric(preds, target) is THIS batch's value, compute() the accumulated one."""
+    from thunder_speech_amd.metrics import CharErrorRate, WordErrorRate
+    cer = CharErrorRate()
+    assert abs(float(cer(["abc"], ["abd"])) - 1 / 3) < 1e-6
+    assert float(cer(["xyz"], ["xyz"])) == 0.0
+    assert abs(float(cer.compute()) - 1 / 6) < 1e-6
+    wer = WordErrorRate()
+    assert abs(float(wer(["a b c d"], ["a x c d"])) - 0.25) < 1e-6 and abs(float(wer(["q"], ["q r"])) - 0.5) < 1e-6
+    assert abs(float(wer.compute()) - 2 / 6) < 1e-6

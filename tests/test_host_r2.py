@@ -116,3 +116,31 @@ def test_ctc_rejects_bad_targets_on_the_host():
         _prepare_targets(torch.tensor([[1, 9]]), torch.tensor([2]), 1, 6, "cpu")                     # id outside [0, V)
     t, _, _ = _prepare_targets(torch.tensor([[1, 9]]), torch.tensor([1]), 1, 6, "cpu")               # ... but padding may hold anything
     assert t.tolist() == [[1, 0]]
+
+
+def test_gradient_sync_hands_a_bucket_view_out_once_and_never_exchanges_a_stale_one():
+    """ADVICE (low): a parameter contributing twice in one backward must not get the same bucket view twice (train_ops.grad_out asks
+    GradientSync.claim); a parameter without a gradient after a plain optimizer.zero_grad(set_to_none=True) must present zeros, not last
+    step's gradient."""
+    import torch
+    from thunder_speech_amd.parallel import GradientSync
+    p, q = torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(3))
+    sync = GradientSync([p, q])
+    assert sync.claim(p) and not sync.claim(p) and sync.claim(q)
+    sync.zero_grad()
+    assert sync.claim(p)                                  # a new step starts with nothing handed out
+    ((p * 2).sum() + (q * 3).sum()).backward()
+    sync.finish()
+    assert torch.equal(p.grad, torch.full((4,), 2.0)) and torch.equal(q.grad, torch.full((3,), 3.0)) and sync.claim(p)
+    p.grad, q.grad = None, None                           # what optimizer.zero_grad() (set_to_none=True, the torch default) does
+    (p * 5).sum().backward()                              # q takes no part in this step
+    sync.finish()
+    assert torch.equal(p.grad, torch.full((4,), 5.0)) and torch.equal(q.grad, torch.zeros(3))
+    sync.close()
+
+
+def test_graphed_train_step_refuses_a_capture_without_an_eager_pass():
+    import pytest, torch
+    from thunder_speech_amd.train_graph import GraphedTrainStep
+    with pytest.raises(ValueError, match="warmup"):
+        GraphedTrainStep(torch.nn.Linear(1, 1), None, None, warmup=0)

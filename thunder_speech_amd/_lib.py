@@ -99,7 +99,7 @@ def lib() -> C.CDLL:
     L.ts_ctc_workspace_bytes.restype = i64
     L.ts_ctc_loss.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.ts_ctc_loss.restype = C.c_int
-    L.ts_ctc_prepare.argtypes = [vp, i32, i64, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.ts_ctc_prepare.argtypes = [vp, i32, i64, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.ts_ctc_prepare.restype = C.c_int
     L.ts_pack_activation.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
     L.ts_pack_activation.restype = C.c_int

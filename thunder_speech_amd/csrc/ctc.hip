@@ -260,7 +260,7 @@ __device__ __forceinline__ long long ctc_read_len(const void* p, int kind, int i
 
 __global__ __launch_bounds__(256) void ctc_prepare_kernel(const void* targets, int tg_kind, long long tg_stride, const void* target_len, int tl_kind,
                                                           const void* input_len, int il_kind, int s_in, int s_max, int n_classes,
-                                                          int* tg_out, int* tl_out, int* il_out) {
+                                                          int* tg_out, int* tl_out, int* il_out, int* bad_total) {
   const int b = blockIdx.x;
   long long tl = ctc_read_len(target_len, tl_kind, b);
   const long long tlc = tl < 0 ? 0 : (tl > s_in ? s_in : tl);
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void ctc_prepare_kernel(const void* targets, i
     tl = tl < -2147483647LL ? -2147483647LL : (tl > 2147483647LL ? 2147483647LL : tl);
     il_out[b] = bad ? 0 : (int)il;
     tl_out[b] = (bad && tl == 0) ? 1 : (int)tl;
+    if (bad && bad_total) atomicAdd(bad_total, 1);                            // running count of dropped utterances (the caller's to check)
   }
 }
 
@@ -347,12 +348,13 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
 
 extern "C" int ts_ctc_prepare(const void* targets, int32_t targets_kind, int64_t targets_stride, int32_t s_in, const void* target_len,
                               int32_t target_len_kind, const void* input_len, int32_t input_len_kind, int32_t batch, int32_t s_max,
-                              int32_t n_classes, int32_t* targets_out, int32_t* target_len_out, int32_t* input_len_out, void* stream) {
+                              int32_t n_classes, int32_t* targets_out, int32_t* target_len_out, int32_t* input_len_out, int32_t* bad_rows_total,
+                              void* stream) {
   if (!targets || !target_len || !input_len || !targets_out || !target_len_out || !input_len_out) return TS_EINVAL;
   if (batch <= 0 || s_max <= 0 || s_in < 0 || s_in > s_max || n_classes <= 0 || targets_stride < s_in) return TS_EINVAL;
   if (targets_kind < 0 || targets_kind > 1 || target_len_kind < 0 || target_len_kind > 3 || input_len_kind < 0 || input_len_kind > 3) return TS_EINVAL;
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::ctc_prepare_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, targets, targets_kind, (long long)targets_stride, target_len,
-                     target_len_kind, input_len, input_len_kind, s_in, s_max, n_classes, targets_out, target_len_out, input_len_out);
+                     target_len_kind, input_len, input_len_kind, s_in, s_max, n_classes, targets_out, target_len_out, input_len_out, bad_rows_total);
   return ts::hip_status(hipGetLastError());
 }

@@ -51,6 +51,32 @@ def _prepare_targets(targets: Tensor, target_lengths: Tensor, b: int, v: int, de
 
 _KIND = {torch.int32: 0, torch.int64: 1, torch.float32: 2, torch.float64: 3}
 
+# Device targets cannot be validated without a host synchronisation, so an utterance with a label id outside [0, V) is dropped
+# (made infeasible: loss 0, gradient 0) instead of raising as host targets do.  Every such utterance is COUNTED in a device cell per
+# GPU; `bad_target_rows()` reads it (one sync) -- call it where the loop synchronises anyway (validation / epoch end): a non-zero value
+# means a vocabulary / tokenizer mismatch is silently shrinking the training set.
+_BAD_ROWS = {}
+
+
+def _bad_counter(dev) -> Tensor:
+    key = str(torch.device(dev))
+    if key not in _BAD_ROWS:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("calculate_ctc: run one eager call before capturing a hipGraph (it creates the persistent bad-target counter)")
+        _BAD_ROWS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _BAD_ROWS[key]
+
+
+def bad_target_rows(device=None, reset: bool = False) -> int:
+    """Utterances dropped so far because of out-of-range label ids in DEVICE targets (synchronises)."""
+    total = 0
+    for key, cell in _BAD_ROWS.items():
+        if device is None or str(torch.device(device)) == key:
+            total += int(cell.item())
+            if reset:
+                cell.zero_()
+    return total
+
 
 def _as_kind(t: Tensor, dev, ints_only: bool = False):
     """-> (contiguous tensor on `dev` of a dtype ts_ctc_prepare reads, its kind code)."""
@@ -74,7 +100,8 @@ def _prepare_on_device(targets: Tensor, target_lengths: Tensor, input_lengths: T
     out = torch.empty(b * s_max + 2 * b, dtype=torch.int32, device=dev)
     tg, tl, il = out[: b * s_max].view(b, s_max), out[b * s_max: b * s_max + b], out[b * s_max + b:]
     st = _lib.lib().ts_ctc_prepare(tg_in.data_ptr(), tk, tg_in.stride(0), s_in, tl_in.data_ptr(), lk, il_in.data_ptr(), ik, b, s_max, v,
-                                   tg.data_ptr(), tl.data_ptr(), il.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                   tg.data_ptr(), tl.data_ptr(), il.data_ptr(), _bad_counter(dev).data_ptr(),
+                                   torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(st, "ts_ctc_prepare")
     return tg, tl, il
 
@@ -96,6 +123,7 @@ class _CtcFunction(torch.autograd.Function):
             tg, tl, bad_rows = _prepare_targets(targets, target_lengths, b, v, dev)
             il = input_lengths.to(device=dev, dtype=torch.int64).to(torch.int32).contiguous()     # .long() (A5)
             if bad_rows is not None:
+                _bad_counter(dev).add_(bad_rows.sum().to(torch.int32))
                 il = torch.where(bad_rows, torch.zeros_like(il), il)
                 tl = torch.where(bad_rows & (tl == 0), torch.ones_like(tl), tl)    # keep the utterance infeasible even with an empty target
         s_max = tg.shape[1]

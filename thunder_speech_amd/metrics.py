@@ -61,8 +61,10 @@ class _ErrorRate:
         target = [target] if isinstance(target, str) else list(target)
         p, r = self._symbols(preds, target)
         e = edit_distances(p, r, self.device).sum().to(torch.float64)
+        n = sum(len(s) for s in r)
         self.errors = e if self.errors is None else self.errors + e
-        self.total += sum(len(s) for s in r)
+        self.total += n
+        return e, n
 
     def compute(self) -> torch.Tensor:
         if self.errors is None:
@@ -70,8 +72,10 @@ class _ErrorRate:
         return (self.errors / max(self.total, 1)).to(torch.float32)
 
     def __call__(self, preds, target) -> torch.Tensor:
-        self.update(preds, target)
-        return self.compute()
+        """torchmetrics' `forward`: accumulate AND return the value of THIS batch (`compute()` gives the running value; the reference's
+        validation_step logs the metric object, which Lightning resolves with compute() at epoch end, module.py:153-163)."""
+        e, n = self.update(preds, target)
+        return (e / max(n, 1)).to(torch.float32)
 
     def to(self, device):
         self.device = torch.device(device)

@@ -115,6 +115,8 @@ class GradientSync:
         self.wire_bytes = 0                     # bytes this rank has put on the wire (per direction), summed over the collectives
         self._hold = False
         self._clean = True                      # the flat buffer holds zeros only (between zero_grad() and the first gradient of the step)
+        self._claimed = set()                   # parameters whose bucket view a backward kernel has taken this step (train_ops.grad_out)
+        self._zeroed = True                     # zero_grad() ran since the last finish(): untouched views hold zeros, not last step's gradient
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(idx)) for idx, p in enumerate(self.params)]
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -199,7 +201,11 @@ class GradientSync:
         self._clean = False
         for p, view in zip(self.params, self._views):
             if p.grad is None:
+                if not self._zeroed:
+                    view.zero_()                          # a plain optimizer.zero_grad(set_to_none=True) left last step's averaged gradient here
                 p.grad = view                             # no gradient this step: the zeros of the bucket
+        self._claimed.clear()
+        self._zeroed = False
         if exchange:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
@@ -215,8 +221,18 @@ class GradientSync:
         as `.grad` (train_ops.grad_out) -- no accumulate kernel, no copy.  Parameters that receive no gradient keep the zeros."""
         self.flat.zero_()
         self._clean = True
+        self._zeroed = True
+        self._claimed.clear()
         for p in self.params:
             p.grad = None
+
+    def claim(self, param) -> bool:
+        """True the first time a backward kernel asks for `param`'s bucket view in a step, False after that (see train_ops.grad_out)."""
+        k = id(param)
+        if k in self._claimed:
+            return False
+        self._claimed.add(k)
+        return True
 
     def is_clean(self) -> bool:
         """True between zero_grad() and finish(): every bucket view not yet written this step still holds zeros, so a kernel that

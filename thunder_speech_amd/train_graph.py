@@ -29,6 +29,10 @@ from .ctc_loss import calculate_ctc
 class GraphedTrainStep:
     def __init__(self, module, optimizer, sync, max_target_len: int = 512, warmup: int = 2):
         self.module, self.optimizer, self.sync = module, optimizer, sync
+        if int(warmup) < 1:
+            # the eager passes are what creates the per-stream arena buffers, packs the weight fragments and fills the length caches OUTSIDE
+            # the graph's private memory pool; a capture without them would bake one-time work (and pool-owned cache entries) into the graph
+            raise ValueError("GraphedTrainStep: warmup must be >= 1 (the capture relies on at least one eager pass)")
         self.max_target_len, self.warmup = int(max_target_len), int(warmup)
         self._graphs: Dict[Tuple, tuple] = {}
         self.replays = 0

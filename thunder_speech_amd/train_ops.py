@@ -158,7 +158,9 @@ def grad_out(param, shape, zeroed: bool = False) -> Tensor:
     receive it ACCUMULATES, so the tensor must hold zeros -- free for a bucket view (GradientSync.zero_grad cleared the whole
     buffer with one memset), one fill launch otherwise."""
     ent = _GRAD_VIEWS.get(id(param)) if param is not None else None
-    if ent is not None and param.grad is None:
+    if ent is not None and param.grad is None and ent[1].claim(param):
+        # (claim: a parameter that contributes twice in one backward -- tied weights, a module called twice -- gets the bucket view for
+        # its first contribution only; the second one takes a fresh tensor and autograd adds the two)
         view, owner = ent
         out = view.view(shape)
         if zeroed and not owner.is_clean():
@@ -227,6 +229,10 @@ def _frag_shapes(c_out: int, c_in: int):
 def _pack_rows(entries):
     """ONE launch packing the (param, w2 f32 [c_out, c_in], fwd, bwd) entries."""
     dev = entries[0][1].device
+    if torch.cuda.is_current_stream_capturing():
+        # the pointer table travels host -> device from a temporary pinned buffer: captured, every replay would re-read freed host memory
+        raise RuntimeError("weight fragments cannot be (re)packed while a hipGraph is being captured: run an eager pass first "
+                           "(GraphedTrainStep does; warmup >= 1)")
     rows = [[w2.data_ptr(), f.data_ptr(), bk.data_ptr(), w2.shape[0], w2.shape[1]] for _, w2, f, bk in entries]
     groups = max(f.numel() // 8 + bk.numel() // 8 for _, _, f, bk in entries)
     table = torch.tensor(rows, dtype=torch.int64, pin_memory=True).to(dev, non_blocking=True)
@@ -326,6 +332,9 @@ _LENS = {}
 def _full_lengths(b: int, t: int, device) -> Tensor:
     key = (b, t, str(torch.device(device)))
     if key not in _LENS:
+        if torch.cuda.is_current_stream_capturing():
+            # a tensor born during capture lives in the graph's private pool: never cache it for eager callers
+            return torch.full((b,), t, dtype=torch.int32, device=device)
         if len(_LENS) > 256:
             _LENS.clear()
         _LENS[key] = torch.full((b,), t, dtype=torch.int32, device=device)
