@@ -264,17 +264,40 @@ def main():
             result["check"]["all_logits_finite"] = bool(torch.isfinite(logits).all())
             one = cpu_baseline(module, clips=2, seconds=15, iters=1, threads=1)
             result["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
-    # C4 as the reference runs it (DDP, strong scaling: global batch 256 x 10 s over the ranks), on EVERY N: all ranks take part
+    # C4 as the reference runs it (DDP, strong scaling: global batch 256 x 10 s over the ranks), on EVERY N: all ranks take part.
+    # An extra must never take the headline line down with it: exceptions are recorded, and a watchdog on every rank covers what an
+    # exception handler cannot -- a collective that never returns (e.g. because ONE rank failed): past the deadline rank 0 prints the
+    # line with the error in place of the result and every rank leaves.
     c4_ddp = None
     if not args.no_extra and "c4" in args.extra.split(","):
         del module
         module = None
         torch.cuda.empty_cache()
+        import threading
+        deadline = float(os.environ.get("TS_BENCH_EXTRA_DEADLINE_S", "240"))
+
+        def give_up():
+            if rank == 0:
+                result.setdefault("extra", {})["c4_ddp"] = {"error": f"no result within {deadline:.0f} s (a rank failed or a collective did not return)"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(deadline, give_up)
+        dog.daemon = True
+        dog.start()
         from tools import bench_extra
         try:
             c4_ddp = bench_extra.c4_ddp(device, world=world, rank=rank)
-        except Exception as e:                       # an extra must never take the headline line down with it
+            if world > 1:
+                dist.barrier()                       # every rank got through: only now is it safe to stop the watchdogs
+        except Exception as e:
             c4_ddp = {"error": f"{type(e).__name__}: {e}"}
+            if world > 1:                            # the other ranks may be waiting in a collective this rank will never enter
+                if rank == 0:
+                    result.setdefault("extra", {})["c4_ddp"] = c4_ddp
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+        dog.cancel()
         torch.cuda.empty_cache()
     if rank == 0:
         if not args.no_extra and world == 1:
