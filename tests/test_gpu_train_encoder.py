@@ -121,6 +121,41 @@ def test_frozen_schedule_runs_the_encoder_in_train_mode_and_trains_batchnorm_onl
     assert all(int(b.num_batches_tracked) == 1 for b in bns)
 
 
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+def test_frozen_convolutions_leave_every_other_gradient_unchanged(act):
+    """With the convolution weights frozen the backward pass takes the data-gradient-only forms (no 1x1 weight-gradient GEMM, the depthwise
+    backward with a null weight-gradient pointer): the gradients that ARE still computed -- BatchNorm parameters, decoder -- and the loss
+    must be exactly those of the fully trainable step (same kernels for the data path, same order of operations)."""
+    from torch import nn
+    from thunder_speech_amd import train_ops
+    from thunder_speech_amd.callbacks import FinetuneEncoderDecoder
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    arch = otcs.quartznet_arch(repeat_blocks=1)
+    g = torch.Generator().manual_seed(3)
+    wav = (0.1 * torch.randn(4, 32000, generator=g)).cuda()
+    lengths = torch.tensor([32000.0, 30000.0, 20000.0, 16000.0]).cuda()
+    texts = ["abc", "hello world", "data", "xy"]
+    grads = {}
+    train_ops.set_activation_dtype(act)
+    try:
+        for frozen in (False, True):
+            m = build_synthetic_quartznet(repeat_blocks=1, encoder_state=otcs.synth_encoder_state(arch, seed=0, calibrate=True),
+                                          decoder_state=otcs.synth_decoder_state(1024, 29, seed=1)).cuda().train()
+            if frozen:
+                FinetuneEncoderDecoder(train_batchnorm=True).freeze_before_training(m)
+            torch.manual_seed(1234)                      # the dither / SpecAugment seeds of the step come from torch's CPU generator (rng.py)
+            loss = m.training_step((wav, lengths, texts), 0)
+            loss.backward()
+            grads[frozen] = (float(loss), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        train_ops.set_activation_dtype("fp32")
+    (l0, g0), (l1, g1) = grads[False], grads[True]
+    assert l0 == l1
+    assert g1 and set(g1) < set(g0) and not any(k.endswith("conv.weight") for k in g1)
+    for k, v in g1.items():
+        assert torch.equal(v, g0[k]), k
+
+
 def test_batchnorm_in_eval_mode_inside_a_training_block_is_refused():
     """the training kernels always normalise with batch statistics; a BatchNorm1d that was switched to eval() while
     its block trains must not silently do that (nn.BatchNorm1d would use -- and keep -- its running statistics)."""

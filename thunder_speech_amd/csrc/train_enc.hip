@@ -731,7 +731,10 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
     for (int j = lane; j < kf8; j += 64) { const int jj = j - fpad; tp[j] = (jj >= 0 && jj < k) ? v2f{wa[k - 1 - jj], wa[wb + k - 1 - jj]} : v2f{0.f, 0.f}; }
   }
   const int ng = k8 >> 3, nq = 64 / ng, g = lane % ng, sl = lane / ng;
-  const bool active = sl < nq;
+  // dw == nullptr: the depthwise weight is frozen (first phase of the reference's fine-tuning schedule): data gradient only -- the x rows
+  // are then not even staged (with an input transform the dx part reads the x values it needs straight from memory)
+  const bool need_dw = dw != nullptr;
+  const bool active = need_dw && sl < nq;
   v2f part[8];
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) part[jj] = v2f{0.f, 0.f};
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
   auto fetch = [&](int it) {
     const int b = b_lo + it / n_tiles, t0 = (it % n_tiles) * PT;
     const size_t r0 = ((size_t)b * ch + c) * pitch;
-    stage_fetch<T, PH>(sx, x + r0, x + r0 + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
+    if (need_dw) stage_fetch<T, PH>(sx, x + r0, x + r0 + pitch, t0 - p - sh, xl, clamp_len(len_in, b, t), lane);
     stage_fetch<T, PH>(sg, dy + r0, dy + r0 + pitch, t0 - o, gl, len_out ? clamp_len(len_out, b, t) : t, lane);
   };
   if (items > 0) fetch(0);
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
     const int li = clamp_len(len_in, b, t), lo = len_out ? clamp_len(len_out, b, t) : t;
     const size_t r0 = ((size_t)b * ch + c) * pitch;
     {
-      stage_write<T, PH>(sx, xs, qx, t0 - p - sh, xl, li, lane, af);
+      if (need_dw) stage_write<T, PH>(sx, xs, qx, t0 - p - sh, xl, li, lane, af);
       stage_write<T, PH>(sg, gs, qg, t0 - o, gl, lo, lane);
       if (it + 1 < items) fetch(it + 1);                   // the next clip's rows travel while this one is filtered
       __builtin_amdgcn_wave_barrier();
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) red[(threadIdx.x) * 8 + jj] = active ? part[jj] : v2f{0.f, 0.f};
   __syncthreads();
-  for (int idx = threadIdx.x; idx < (PH ? k : 2 * k); idx += 256) {
+  for (int idx = threadIdx.x; need_dw && idx < (PH ? k : 2 * k); idx += 256) {
     const int sel = idx / k, j = idx % k, gj = (j + sh) >> 3, jj = (j + sh) & 7;      // register jj of tap group gj holds tap 8 gj + jj - sh
     float tot = 0.f;
     for (int wv = 0; wv < 4; ++wv)
@@ -1218,7 +1221,7 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
                            void* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
                            int32_t stride, int32_t dil, int32_t pad, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_,
                            PairAffine aff, float* in_dgamma, float* in_dbeta) {
-  if (!dy || !x || !w || !dx || !dw || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;
+  if (!dy || !x || !w || !dx || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;      // dw may be null: frozen weight
   if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
@@ -1255,6 +1258,7 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
                             t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
          hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, gd, dim3(256), lds_d, stream, (const bf16_t*)dy, len_in, len_out, w, (bf16_t*)dx, batch, ch,
                             t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out));
+  if (dw)
   TS_ACT(act,
          hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, gw, dim3(256), lds_w, stream, (const float*)dy, (const float*)x, len_in, len_out, dw, batch,
                             ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),

@@ -446,13 +446,14 @@ class DepthwiseConv(torch.autograd.Function):
         k, stride, dil, pad, t_out, wshape = ctx.geom
         dy = _g(dy, x)
         b, c, t_in = x.shape
-        dx, dw = alloc_like(x), grad_out(ctx.param, w2.shape, zeroed=True)
+        dx = alloc_like(x)
+        dw = grad_out(ctx.param, w2.shape, zeroed=True) if ctx.param.requires_grad else None      # frozen weight: data gradient only
         lo = ctx.len_out
         st = _lib.lib().ts_train_dwconv_bwd(dy.data_ptr(), x.data_ptr(), len_in.data_ptr(), lo.data_ptr() if lo is not None else None,
-                                            w2.data_ptr(), dx.data_ptr(), dw.data_ptr(), b, c, t_in, t_out, k, stride, dil, pad,
-                                            _pitch(x), _pitch(dy), _code(x), _s(x))
+                                            w2.data_ptr(), dx.data_ptr(), dw.data_ptr() if dw is not None else None, b, c, t_in, t_out, k, stride,
+                                            dil, pad, _pitch(x), _pitch(dy), _code(x), _s(x))
         _lib.check(st, "ts_train_dwconv_bwd")
-        return dx, dw.view(wshape), None, None, None, None, None, None
+        return dx, (dw.view(wshape) if dw is not None else None), None, None, None, None, None, None
 
 
 class MaskTime(torch.autograd.Function):
@@ -794,21 +795,23 @@ class SubBlock(torch.autograd.Function):
         dx = alloc_like(x)
         dg_in = db_in = None
         if w_dw is not None:
-            ddw = grad_out(dw_p, w_dw.shape, zeroed=True)
+            # a frozen depthwise weight (callbacks.FinetuneEncoderDecoder's first phase) takes the data-gradient-only form of the kernel
+            ddw = grad_out(dw_p, w_dw.shape, zeroed=True) if dw_p.requires_grad else None
+            ddw_ptr = ddw.data_ptr() if ddw is not None else None
             if cfg.lazy_in is not None:
                 gbuf = alloc_like(x)
                 dg_in, db_in = grad_out(gin_p, (c_in,), zeroed=True), grad_out(bin_p, (c_in,), zeroed=True)
                 _lib.check(L.ts_train_dwconv_bwd_bn(dmid.data_ptr(), x.data_ptr(), in_mr.data_ptr(), g_in.data_ptr(), b_in.data_ptr(), int(cfg.lazy_in[1]),
-                                                    cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), gbuf.data_ptr(), ddw.data_ptr(),
+                                                    cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), gbuf.data_ptr(), ddw_ptr,
                                                     dg_in.data_ptr(), db_in.data_ptr(), b, c_in, t_in, cfg.k, cfg.pad, _pitch(x), code, st_),
                            "ts_train_dwconv_bwd_bn")
                 _lib.check(L.ts_train_bn_bwd_sums(gbuf.data_ptr(), x.data_ptr(), g_in.data_ptr(), in_mr.data_ptr(), dg_in.data_ptr(), db_in.data_ptr(),
                                                   dx.data_ptr(), b, c_in, t_in, _pitch(x), code, st_), "ts_train_bn_bwd_sums")
             else:
                 _lib.check(L.ts_train_dwconv_bwd(dmid.data_ptr(), x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), dx.data_ptr(),
-                                                 ddw.data_ptr(), b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(dmid), code, st_),
+                                                 ddw_ptr, b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(dmid), code, st_),
                            "ts_train_dwconv_bwd")
-            ddw = ddw.view(ctx.shapes[0])
+            ddw = ddw.view(ctx.shapes[0]) if ddw is not None else None
         else:
             ddw = None
             if cfg.bwd_mask:
