@@ -79,11 +79,13 @@ def test_gemm_nt_declines_shapes_it_does_not_take():
 
 @pytest.mark.parametrize("m,n,k,gelu,use_res", [(300, 96, 64, False, True), (999, 1024, 1024, True, False), (1998, 1024, 4096, False, True),
                                                  (513, 512, 1536, True, False), (257, 4096, 1024, True, False), (4000, 32, 96, False, False),
-                                                 (700, 64, 32, False, False)])
+                                                 (700, 64, 32, False, False),
+                                                 (9000, 2048, 256, True, True), (8200, 2080, 128, False, False), (15984, 3072, 1024, True, False)])
 def test_gemm_nt_packed_weights_give_the_same_bits(m, n, k, gelu, use_res):
     """ts_gemm_nt_bf16_packed (B fragments from L2 straight into registers, ts_gemm_nt_pack_w) multiplies the same bf16 values in the
     same order as the LDS path: results are bit-identical for every epilogue form; the packed image itself is checked against the
-    fragment layout it documents."""
+    fragment layout it documents.  The last three shapes have more tiles than the chip has CUs (several rounds of workgroups,
+    the blocked tile walk with short last bands), ragged in both directions."""
     from thunder_speech_amd import _lib
     g = torch.Generator(device="cuda").manual_seed(7 * m + n + k)
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)

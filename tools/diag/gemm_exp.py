@@ -8,12 +8,12 @@ for (m, n, k) in [(8192, 8192, 8192), (15984, 1024, 1024)]:
     for exp in [int(v) for v in os.environ.get('EXPS', '0,1,2,4,8,3,7,15').split(',')]:
         os.environ["TS_EXP"] = str(exp)
         for _ in range(3):
-            run(x, w, None, None, False, want32=False)
+            run(x, w, None, None, False, want32=False, packed=os.environ.get('PACKED') == '1')
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            run(x, w, None, None, False, want32=False)
+            run(x, w, None, None, False, want32=False, packed=os.environ.get('PACKED') == '1')
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         print(f"m {m} n {n} k {k} exp={exp:2d}: {ms * 1e3:8.1f} us  {2 * m * n * k / ms * 1e-9:7.1f} TFLOP/s")

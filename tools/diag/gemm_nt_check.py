@@ -44,7 +44,8 @@ def check():
     bad = 0
     g = torch.Generator(device=dev).manual_seed(0)
     for (m, n, k, gelu, use_res) in [(256, 256, 64, False, False), (300, 96, 32, False, True), (1000, 1024, 1024, True, False),
-                                     (15984, 1024, 4096, False, True), (999, 512, 1536, True, False), (257, 4096, 1024, True, False)]:
+                                     (15984, 1024, 4096, False, True), (999, 512, 1536, True, False), (257, 4096, 1024, True, False),
+                                     (15984, 3072, 1024, True, False), (9000, 2048, 256, False, True), (8200, 2080, 128, False, False)]:
         x = torch.randn(m, k, device=dev, generator=g).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev, generator=g) / k ** 0.5).to(torch.bfloat16)
         bias = torch.randn(n, device=dev, generator=g)
