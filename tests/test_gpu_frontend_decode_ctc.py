@@ -165,3 +165,29 @@ def test_error_rate_call_returns_the_batch_value_and_compute_the_running_one():
     wer = WordErrorRate()
     assert abs(float(wer(["a b c d"], ["a x c d"])) - 0.25) < 1e-6 and abs(float(wer(["q"], ["q r"])) - 0.5) < 1e-6
     assert abs(float(wer.compute()) - 2 / 6) < 1e-6
+
+
+def test_ctc_very_long_clip_uses_the_large_lds_configuration():
+    """20 000 frames (a 6.7-minute clip after the stride-2 stem): the per-frame log-sum-exp row no longer fits the default 64 KiB of LDS.
+    The blank is made likely, as in a trained model, so that the path scores stay where f32 log-domain arithmetic resolves them (with flat
+    random logits a 20 000-frame score is ~ -42 000, where one f32 ulp is 0.004 -- any f32 CTC is then only good to a percent)."""
+    from thunder_speech_amd.ctc_loss import calculate_ctc
+    rng = np.random.Generator(np.random.PCG64(6))
+    B, V, T = 2, 8, 20000
+    logits = rng.standard_normal((B, V, T)).astype(np.float32)
+    logits[:, V - 1] += 7.0
+    tl = np.array([40, 25])
+    tg = np.zeros((B, 40), dtype=np.int64)
+    for b in range(B):
+        tg[b, : tl[b]] = rng.integers(0, V - 1, tl[b])
+    il = np.array([20000, 12345])
+    lg = torch.from_numpy(logits).cuda().requires_grad_(True)
+    loss = calculate_ctc(lg, torch.from_numpy(tg).cuda(), torch.from_numpy(il).cuda(), torch.from_numpy(tl).cuda(), V - 1)
+    loss.backward()
+    ref_in = torch.from_numpy(logits).double().requires_grad_(True)
+    ref = torch.nn.functional.ctc_loss(ref_in.permute(2, 0, 1).log_softmax(2), torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl), blank=V - 1,
+                                       reduction="mean", zero_infinity=True)
+    ref.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(ref), rtol=2e-5)
+    want = ref_in.grad.numpy()
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), want, atol=1e-2 * float(np.abs(want).max()))    # f32 log-domain sums over 20 000 steps

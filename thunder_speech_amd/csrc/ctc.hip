@@ -330,14 +330,22 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
   a.feasible = reinterpret_cast<int*>(a.beta + (size_t)batch * (n_frames + 1) * a.rowp);
   const size_t lds = ((size_t)2 * (a.lmax + 4) + a.lmax + (size_t)n_frames) * sizeof(float);
   const size_t lds_g = ((size_t)a.lmax + 4 * (size_t)n_classes) * sizeof(float);
-  if (lds > 64 * 1024 || lds_g > 64 * 1024) return TS_EUNSUPPORTED;
+  // the per-frame log-sum-exp row lives in LDS next to the two state rows: 160 KiB hold about 38 000 frames (a 12-minute clip after the stem)
+  if (lds > 160 * 1024 || lds_g > 64 * 1024 || a.lmax > 4096) return TS_EUNSUPPORTED;            // ... or more than 2 047 labels in a transcript
   (void)hipGetLastError();
   const dim3 grid(batch, grad ? 2 : 1);                                                          // alpha || beta
   const dim3 block((unsigned)ctc_threads(a.lmax));
-  if (spt == 1) hipLaunchKernelGGL(ctc_kernel<1>, grid, block, lds, stream, a);
-  else if (spt == 2) hipLaunchKernelGGL(ctc_kernel<2>, grid, block, lds, stream, a);
-  else if (a.lmax <= 4096) hipLaunchKernelGGL(ctc_kernel<4>, grid, block, lds, stream, a);
-  else return TS_EUNSUPPORTED;                                                                     // more than 2 047 labels in a transcript
+  static bool big[3] = {false, false, false};                                                    // more than the default 64 KiB allowed, per instantiation
+  const int which = spt == 1 ? 0 : (spt == 2 ? 1 : 2);
+  if (lds > 64 * 1024 && !big[which]) {
+    const void* fn = which == 0 ? reinterpret_cast<const void*>(ctc_kernel<1>)
+                                : (which == 1 ? reinterpret_cast<const void*>(ctc_kernel<2>) : reinterpret_cast<const void*>(ctc_kernel<4>));
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TS_EUNSUPPORTED;
+    big[which] = true;
+  }
+  if (which == 0) hipLaunchKernelGGL(ctc_kernel<1>, grid, block, lds, stream, a);
+  else if (which == 1) hipLaunchKernelGGL(ctc_kernel<2>, grid, block, lds, stream, a);
+  else hipLaunchKernelGGL(ctc_kernel<4>, grid, block, lds, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (grad) hipLaunchKernelGGL(ctc_grad_kernel, dim3((n_frames + 3) / 4, batch), dim3(256), lds_g, stream, a);
