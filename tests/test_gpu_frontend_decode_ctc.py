@@ -191,3 +191,19 @@ def test_ctc_very_long_clip_uses_the_large_lds_configuration():
     np.testing.assert_allclose(float(loss.detach()), float(ref), rtol=2e-5)
     want = ref_in.grad.numpy()
     np.testing.assert_allclose(lg.grad.cpu().numpy(), want, atol=1e-2 * float(np.abs(want).max()))    # f32 log-domain sums over 20 000 steps
+
+
+@pytest.mark.parametrize("v,t", [(1024, 251), (1024, 64), (257, 700), (1024, 1025), (3, 5), (1000, 1)])
+def test_greedy_decode_large_vocabularies_and_ties(v, t):
+    """Clips shorter than the decode workgroup split the CLASSES over its threads (Citrinet: 251 frames x 1 024 sentencepiece classes);
+    quantised logits force ties, which must resolve to the lowest index like torch.argmax, within and across class slices."""
+    from thunder_speech_amd.module import greedy_decode
+    rng = np.random.Generator(np.random.PCG64(v + t))
+    logits = np.round(rng.standard_normal((3, v, t)) * 2.0).astype(np.float32) / 2.0      # many exact ties
+    logits[1, :, : max(t // 3, 1)] = 0.25                                                   # every class ties: index 0 wins
+    ids, collapsed, counts = greedy_decode(torch.from_numpy(logits).cuda())
+    ref_ids = odec.argmax_classes(logits)
+    assert np.array_equal(ref_ids, logits.argmax(1))                                         # the oracle's rule is numpy's / torch's: first maximum
+    assert np.array_equal(ids.cpu().numpy(), ref_ids)
+    for b in range(3):
+        assert np.array_equal(collapsed[b, : int(counts[b])].cpu().numpy(), odec.collapse_repeats(ref_ids[b]))
