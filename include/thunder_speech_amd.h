@@ -153,12 +153,16 @@ int ts_mel_frontend_fwd(const ts_frontend_desc* desc, const float* wave, const i
  *   ts_fe_dither          y = x + dither * N(0, 1), the Philox stream of ts_mel_frontend_fwd's dither      ([B][n] -> [B][n])
  *   ts_fe_power_spectrum  |STFT|^2 of torch.stft(n_fft, hop, center=True, pad_mode="reflect"); window: f32 [n_fft] (the win_length
  *                         window centred in zeros); twiddle: f32 [n_fft][2] = (cos, sin)(2 pi j / n_fft); out [B][n_fft/2+1][n/hop+1]
+ *   ts_fe_stft            the transform itself, out [B][n_fft/2+1][n/hop+1][2] = (re, im): convolution_stft of blocks.py:38-91 (the reference's
+ *                         export-friendly replacement of torch.stft; same arguments as ts_fe_power_spectrum)
  *   ts_fe_mel             out[b][m][t] = log(sum_f fb[m][f] x[b][f][t] + 2^-24) (log_scale = 1) or the plain product; fb f32 [n_mels][n_freq]
  *   ts_fe_normalize       masked per-(clip, feature) normalisation with the padded frames in the variance (quirk A1), 0 beyond len[b] */
 int ts_fe_preemph(const float* x, float* y, int32_t batch, int32_t n, float coeff, void* stream);
 int ts_fe_dither(const float* x, float* y, int32_t batch, int32_t n, float dither, uint64_t seed, void* stream);
 int ts_fe_power_spectrum(const float* x, const float* window, const float* twiddle, float* out, int32_t batch, int32_t n, int32_t n_fft,
                          int32_t hop, void* stream);
+int ts_fe_stft(const float* x, const float* window, const float* twiddle, float* out, int32_t batch, int32_t n, int32_t n_fft, int32_t hop,
+               void* stream);
 int ts_fe_mel(const float* x, const float* fb, float* out, int32_t batch, int32_t n_freq, int32_t n_mels, int32_t t, int32_t log_scale,
               void* stream);
 int ts_fe_normalize(const float* x, const int32_t* len, float* out, int32_t batch, int32_t features, int32_t t, float guard, void* stream);

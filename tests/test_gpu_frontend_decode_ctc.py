@@ -207,3 +207,22 @@ def test_greedy_decode_large_vocabularies_and_ties(v, t):
     assert np.array_equal(ids.cpu().numpy(), ref_ids)
     for b in range(3):
         assert np.array_equal(collapsed[b, : int(counts[b])].cpu().numpy(), odec.collapse_repeats(ref_ids[b]))
+
+
+def test_convolution_stft_and_fourier_matrix_match_the_reference_tests():
+    """The reference's own checks (tests/test_blocks.py:8-30): the Fourier matrix equals fft(eye) to 1e-3, convolution_stft equals
+    torch.stft(return_complex=False) to 1e-2 -- plus the oracle's float64 STFT at 1e-4 on a second geometry."""
+    from thunder_speech_amd.blocks import _fourier_matrix, convolution_stft
+    for n in (64, 128, 256, 512, 1024):
+        assert torch.allclose(torch.fft.fft(torch.eye(n)), _fourier_matrix(n, "cpu"), atol=1e-3)
+    torch.manual_seed(0)
+    x = torch.randn(10, 1000)
+    window = torch.hann_window(256, periodic=False)
+    got = convolution_stft(x.cuda(), n_fft=1024, hop_length=512, win_length=256, window=window).cpu()
+    want = torch.view_as_real(torch.stft(x, n_fft=1024, hop_length=512, win_length=256, window=window, return_complex=True))
+    assert got.shape == want.shape == (10, 513, 2, 2) and torch.allclose(got, want, atol=1e-2)
+    x2 = torch.randn(3, 4000, dtype=torch.float64)
+    w2 = torch.hann_window(300, periodic=False, dtype=torch.float64)
+    got2 = convolution_stft(x2.float().cuda(), n_fft=400, hop_length=160, win_length=300, window=w2.float()).cpu()
+    want2 = torch.view_as_real(torch.stft(x2, n_fft=400, hop_length=160, win_length=300, window=w2, return_complex=True)).float()
+    assert got2.shape == want2.shape and float((got2 - want2).abs().max()) <= 1e-4 * float(want2.abs().max())

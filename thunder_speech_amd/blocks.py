@@ -1,21 +1,59 @@
 """Shared building blocks -- mirror of the reference's src/thunder/blocks.py public names.
 
 `MultiSequential`, `Masked`, `lengths_to_mask`, `get_same_padding`, `conv1d_decoder`, `linear_decoder`,
-`SwapLastDimension`, `normalize_tensor` keep the reference signatures (blocks.py:9-19).  The decoders run
+`SwapLastDimension`, `normalize_tensor`, `convolution_stft` keep the reference signatures (blocks.py:9-19).  The decoders run
 the fused pointwise HIP kernel; the small tensor helpers are host-side plumbing.
 """
 from __future__ import annotations
 
+import math
 from typing import Optional, Tuple
 
 import torch
 from torch import Tensor, nn
 
+from . import _lib
 from . import plan as _plan
 from . import tensors as _t
 
-__all__ = ["MultiSequential", "Masked", "normalize_tensor", "lengths_to_mask", "get_same_padding",
+__all__ = ["convolution_stft", "MultiSequential", "Masked", "normalize_tensor", "lengths_to_mask", "get_same_padding",
            "conv1d_decoder", "SwapLastDimension", "linear_decoder"]
+
+
+def _fourier_matrix(n_fft: int, device) -> Tensor:
+    """The DFT matrix exp(-2 pi i j k / n) as complex64 [n, n] (reference blocks.py:29-35).  The phase j k is reduced mod n in integer
+    arithmetic before the trigonometry, so large n stay exact to f32 (the reference's f32 outer product drifts; its test allows 1e-3)."""
+    idx = torch.arange(n_fft, dtype=torch.int64)
+    ang = -2.0 * math.pi * ((idx[:, None] * idx[None, :]) % n_fft).to(torch.float64) / n_fft
+    return torch.complex(torch.cos(ang), torch.sin(ang)).to(torch.complex64).to(device)
+
+
+def convolution_stft(input_data: Tensor, n_fft: int = 1024, hop_length: int = 512, win_length: int = 1024,
+                     window: Optional[Tensor] = None, center: bool = True, return_complex: bool = False) -> Tensor:
+    """The reference's export-friendly STFT (blocks.py:38-91; `patch_stft` swaps it in for torch.stft): reflect-pad by n_fft / 2, frames of
+    n_fft samples every hop_length, the win_length window centred in zeros, one-sided transform; returns [B, n_fft/2+1, frames, 2] =
+    (real, imaginary) whatever `center` / `return_complex` say, as the reference does.  Here: one launch of the direct-DFT stage kernel
+    (ts_fe_stft), GPU tensors only."""
+    assert n_fft >= win_length
+    _t.require_gpu(input_data, "convolution_stft")
+    if window is None:
+        window = torch.hann_window(win_length, periodic=False)
+    x = input_data.detach().reshape(input_data.shape[0], -1).to(torch.float32).contiguous()
+    b, n = x.shape
+    if n_fft // 2 >= n:
+        raise RuntimeError(f"convolution_stft: reflect padding of {n_fft // 2} needs more than {n} samples")
+    win = torch.zeros(n_fft, dtype=torch.float32)
+    left = (n_fft - win_length) // 2
+    win[left:left + win_length] = window.detach().float().cpu()
+    ang = 2.0 * math.pi * torch.arange(n_fft, dtype=torch.float64) / n_fft
+    tw = torch.stack([torch.cos(ang), torch.sin(ang)], dim=1).to(torch.float32).contiguous()
+    frames = n // hop_length + 1
+    out = torch.empty(b, n_fft // 2 + 1, frames, 2, dtype=torch.float32, device=x.device)
+    win_d, tw_d = win.to(x.device), tw.to(x.device)          # named: they must outlive the launch
+    st = _lib.lib().ts_fe_stft(x.data_ptr(), win_d.data_ptr(), tw_d.data_ptr(), out.data_ptr(), b, n, n_fft, hop_length,
+                               torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(st, "ts_fe_stft")
+    return out
 
 
 class MultiSequential(nn.Sequential):

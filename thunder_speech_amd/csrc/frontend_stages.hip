@@ -34,6 +34,8 @@ __global__ void fe_dither_kernel(const float* __restrict__ x, float* __restrict_
 // |STFT|^2 as torch.stft(center=True, pad_mode="reflect") computes it: frame f covers the reflect-padded samples [f hop, f hop + n_fft),
 // window = `window` (n_fft entries: the win_length window centred in zeros).  One workgroup per (clip, frame): the windowed frame is
 // staged in LDS, thread k sums the DFT bin k over a cos/sin table of n_fft entries (index k j mod n_fft: exact phase reduction).
+// COMPLEX: out[b][k][f][2] = (re, im) of the transform itself (what the reference's convolution_stft returns, blocks.py:38-91)
+template <bool COMPLEX>
 __global__ void fe_power_kernel(const float* __restrict__ x, const float* __restrict__ window, const float* __restrict__ twiddle,
                                 float* __restrict__ out, int n, int n_fft, int hop, int frames) {
   extern __shared__ float frame[];                 // [n_fft]
@@ -58,7 +60,9 @@ __global__ void fe_power_kernel(const float* __restrict__ x, const float* __rest
       ph += k;
       if (ph >= n_fft) ph -= n_fft;
     }
-    out[((size_t)b * n_freq + k) * frames + f] = re * re + im * im;
+    const size_t o = ((size_t)b * n_freq + k) * frames + f;
+    if constexpr (COMPLEX) { out[2 * o] = re; out[2 * o + 1] = im; }
+    else out[o] = re * re + im * im;
   }
 }
 
@@ -129,7 +133,18 @@ extern "C" int ts_fe_power_spectrum(const float* x, const float* window, const f
   if (n_fft / 2 >= n) return TS_EINVAL;            // reflect padding needs n_fft / 2 < n (torch.stft raises as well)
   const int frames = n / hop + 1;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ts::fe_power_kernel, dim3(frames, batch), dim3(256), (size_t)n_fft * sizeof(float), (hipStream_t)stream, x, window, twiddle,
+  hipLaunchKernelGGL(ts::fe_power_kernel<false>, dim3(frames, batch), dim3(256), (size_t)n_fft * sizeof(float), (hipStream_t)stream, x, window, twiddle,
+                     out, n, n_fft, hop, frames);
+  return ts::hip_status(hipGetLastError());
+}
+
+extern "C" int ts_fe_stft(const float* x, const float* window, const float* twiddle, float* out, int32_t batch, int32_t n, int32_t n_fft,
+                          int32_t hop, void* stream) {
+  if (!x || !window || !twiddle || !out || batch <= 0 || n <= 0 || n_fft < 2 || n_fft > 8192 || hop <= 0) return TS_EINVAL;
+  if (n_fft / 2 >= n) return TS_EINVAL;
+  const int frames = n / hop + 1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::fe_power_kernel<true>, dim3(frames, batch), dim3(256), (size_t)n_fft * sizeof(float), (hipStream_t)stream, x, window, twiddle,
                      out, n, n_fft, hop, frames);
   return ts::hip_status(hipGetLastError());
 }

@@ -259,7 +259,9 @@ def FilterbankFeatures(sample_rate: int = 16000, n_window_size: int = 320, n_win
 
 
 def patch_stft(filterbank: nn.Module) -> nn.Module:
-    """Reference hook for FFT-less export targets (transform.py:324-336).  The HIP front end has its own FFT, so
-    this only records the request."""
-    filterbank[1].stft_func = "convolution_stft"
+    """Reference hook for FFT-less export targets (transform.py:324-336): `filterbank[1].stft_func = convolution_stft`.  The fused HIP
+    front end has its own FFT and never calls `stft_func`, so inside FilterbankFeatures this only records the request, as in the
+    reference's attribute; `blocks.convolution_stft` itself is callable (one launch of the direct-DFT stage kernel)."""
+    from ..blocks import convolution_stft
+    filterbank[1].stft_func = convolution_stft
     return filterbank
