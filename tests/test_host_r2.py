@@ -144,3 +144,37 @@ def test_graphed_train_step_refuses_a_capture_without_an_eager_pass():
     from thunder_speech_amd.train_graph import GraphedTrainStep
     with pytest.raises(ValueError, match="warmup"):
         GraphedTrainStep(torch.nn.Linear(1, 1), None, None, warmup=0)
+
+
+def test_masked_conv_mask_fill_and_length_formula_like_the_reference_test():
+    """tests/quartznet/test_blocks_qn.py:135-143 of the reference: mask_fill zeroes the tail, get_seq_len follows the conv formula."""
+    import torch
+    from thunder_speech_amd.quartznet.blocks import MaskedConv1d
+    x = torch.randn(10, 128, 1337)
+    lens = torch.Tensor([1000] * 10)
+    conv = MaskedConv1d(128, 10, 3)
+    x_mask = conv.mask_fill(x, lens)
+    assert conv.get_seq_len(lens)[0] == (1000 + 2 * 0 - 1 * (3 - 1) - 1) // 1 + 1
+    assert (x_mask[:, :, 1000:] == 0).all() and torch.equal(x_mask[:, :, :1000], x[:, :, :1000])
+
+
+def test_reference_utils_names(tmp_path):
+    """thunder.utils' small helpers (utils.py:32-147) under the same names."""
+    import struct, wave
+    import pytest
+    from thunder_speech_amd.quartznet.compatibility import QuartznetCheckpoint
+    from thunder_speech_amd.utils import BaseCheckpoint, audio_len, chain_calls, download_checkpoint, get_files
+    assert chain_calls(lambda x: 2 * x, lambda x: 3 * x, lambda x: 4 * x)(1) == 24
+    assert QuartznetCheckpoint.from_string("QuartzNet5x5LS_En") is QuartznetCheckpoint.QuartzNet5x5LS_En and issubclass(QuartznetCheckpoint, BaseCheckpoint)
+    with pytest.raises(ValueError):
+        QuartznetCheckpoint.from_string("nope")
+    (tmp_path / "a").mkdir()
+    wav = tmp_path / "a" / "x.wav"
+    with wave.open(str(wav), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes(struct.pack("<8000h", *([0] * 8000)))
+    (tmp_path / "b.txt").write_text("t")
+    assert get_files(tmp_path, ".wav") == [wav] and abs(audio_len(wav) - 0.5) < 1e-9
+    assert download_checkpoint(QuartznetCheckpoint.QuartzNet5x5LS_En, str(tmp_path)) if (tmp_path / "QuartzNet5x5LS-En").write_text("w") else False
+    with pytest.raises(FileNotFoundError):
+        download_checkpoint(QuartznetCheckpoint.QuartzNet15x5Base_En, str(tmp_path))

@@ -22,13 +22,14 @@ from ..module import BaseCTCModule
 from ..quartznet.compatibility import load_quartznet_weights
 from ..quartznet.transform import FilterbankFeatures
 from ..text_processing.transform import BatchTextTransformer
+from ..utils import BaseCheckpoint
 from .blocks import CitrinetEncoder
 
 __all__ = ["CitrinetCheckpoint", "load_components_from_citrinet_config", "fix_vocab", "load_citrinet_checkpoint",
            "build_synthetic_citrinet", "CITRINET_1024_KERNELS", "CITRINET_1024_STRIDES"]
 
 
-class CitrinetCheckpoint(str, Enum):
+class CitrinetCheckpoint(BaseCheckpoint):
     """Checkpoint names of the reference (values are the NGC file stems)."""
     stt_en_citrinet_256 = "stt_en_citrinet_256"
     stt_en_citrinet_512 = "stt_en_citrinet_512"

@@ -80,6 +80,12 @@ class MaskedConv1d(nn.Module):
     def get_seq_len(self, lengths: torch.Tensor) -> torch.Tensor:
         return _conv_len(lengths, self.kernel_size, self.stride, self.padding, self.dilation)
 
+    def mask_fill(self, x: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """x with the frames >= lengths[b] zeroed (reference quartznet/blocks.py:158-167).  A tensor helper like lengths_to_mask: plain torch on
+        whatever device x lives on; `forward` does not call it -- the kernels apply the mask while they load (or rely on the tail-zero invariant)."""
+        from ..blocks import lengths_to_mask
+        return x.masked_fill(~lengths_to_mask(lengths, x.shape[-1]).unsqueeze(1), 0)
+
     def forward(self, x: torch.Tensor, lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(x, "MaskedConv1d")
         conv = self.conv

@@ -22,11 +22,12 @@ from torch import nn
 from ..blocks import conv1d_decoder
 from ..module import BaseCTCModule
 from ..text_processing.transform import BatchTextTransformer
+from ..utils import BaseCheckpoint
 from .blocks import QuartznetEncoder
 from .transform import FilterbankFeatures
 
 
-class QuartznetCheckpoint(str, Enum):
+class QuartznetCheckpoint(BaseCheckpoint):
     """Names of the NeMo checkpoints the reference knows (compatibility.py:45-58)."""
     QuartzNet5x5LS_En = "QuartzNet5x5LS-En"
     QuartzNet15x5Base_En = "QuartzNet15x5Base-En"

@@ -1,11 +1,75 @@
-"""Small host-side helpers: synthetic weights for benchmarks / smoke tests and workload accounting."""
+"""Small host-side helpers: the reference's utils.py names (audio_len, get_default_cache_folder, get_files, chain_calls, BaseCheckpoint,
+download_checkpoint: utils.py:32-147) plus synthetic weights for benchmarks / smoke tests and workload accounting."""
 from __future__ import annotations
 
+import functools
 import math
-from typing import Dict, List, Tuple
+import os
+from enum import Enum
+from pathlib import Path
+from typing import Callable, Dict, List, Tuple, Union
 
 import torch
 from torch import nn
+
+
+def audio_len(item: Union[Path, str]) -> float:
+    """Length of an audio file in seconds (reference utils.py:32-42 asks torchaudio.info; torchaudio is not in this image, so PCM WAV files
+    are read with the standard library and anything else is refused)."""
+    import wave
+    try:
+        with wave.open(str(item), "rb") as f:
+            return f.getnframes() / float(f.getframerate())
+    except wave.Error as e:
+        raise RuntimeError(f"audio_len: {item} is not a PCM WAV file ({e}); other containers need torchaudio") from e
+
+
+def get_default_cache_folder() -> Path:
+    folder = Path.home() / ".thunder"
+    folder.mkdir(exist_ok=True)
+    return folder
+
+
+def get_files(directory: Union[str, Path], extension: str) -> List[Path]:
+    """All files below `directory` (links followed) whose name ends with `extension`."""
+    found: List[Path] = []
+    for root, _, files in os.walk(directory, followlinks=True):
+        found += [Path(root) / f for f in files if f.endswith(extension)]
+    return found
+
+
+def chain_calls(*funcs: Callable) -> Callable:
+    """g = chain_calls(f1, f2, f3): g(x) == f3(f2(f1(x)))."""
+    return lambda arg: functools.reduce(lambda x, f: f(x), funcs, arg)
+
+
+class BaseCheckpoint(str, Enum):
+    """Base class of the pretrained-checkpoint enums; `from_string` is the argparse / hydra helper of the reference (utils.py:100-121)."""
+
+    @classmethod
+    def from_string(cls, name: str) -> "BaseCheckpoint":
+        try:
+            return cls[name]
+        except KeyError as missing:
+            raise ValueError("Name provided is not a valid checkpoint") from missing
+
+
+def download_checkpoint(name: BaseCheckpoint, checkpoint_folder: str = None) -> Path:
+    """Path of the checkpoint file `name` in the cache folder, fetching it first when `name.value` is a URL and the file is not there yet
+    (reference utils.py:124-147).  Without network access the download fails with the URL in the message; a file that is already cached is
+    returned without touching the network."""
+    folder = Path(checkpoint_folder) if checkpoint_folder is not None else get_default_cache_folder()
+    url = str(name.value)
+    path = folder / url.split("/")[-1]
+    if not path.exists():
+        if "://" not in url:
+            raise FileNotFoundError(f"{path} not found and {url!r} is not a URL to fetch it from")
+        import urllib.request
+        try:
+            urllib.request.urlretrieve(url, path)
+        except OSError as e:
+            raise RuntimeError(f"download_checkpoint: could not fetch {url} ({e}); place the file at {path}") from e
+    return path
 
 
 def variance_preserving_init_(encoder: nn.Module, decoder: nn.Module = None, seed: int = 0) -> None:
