@@ -38,6 +38,9 @@ constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
 #ifndef TS_SPLIT_RING
 #define TS_SPLIT_RING 2
 #endif
+#ifndef TS_ROWS2
+#define TS_ROWS2 1            // producers request their rows TWO stages ahead (two register sets, counted vmcnt); 0: one stage, drain
+#endif
 #ifndef TS_WIN_DIST
 #define TS_WIN_DIST 1
 #endif
@@ -751,13 +754,20 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     const int chunk_t = 4 * TAPB;
     const int chunk_i = KC * a.pitch_res * 2;
 
-    u32x4 X[XP];
+    // ROWS2 (96-frame tiles, dilation 1, an even number of 64-channel stages): a stage's rows are requested TWO stages before it runs, into
+    // two register sets that alternate statically (the stage loop runs in pairs), and the stage start waits with a counted vmcnt instead of
+    // draining the queue -- the rows of the stage in between stay in flight.  A loaded HBM round trip is longer than one stage: the drain
+    // cost 950 of a stage's 5 500 stamped ticks (tools/diag/run_stamp_split.py).  Worth 1 % on the C2 step; the stage is then held by the rest
+    // of the producer chain.
+    constexpr bool ROWS2 = TS_ROWS2 && WM == 1 && DIL == 1;
+    const bool rows2 = ROWS2 && n_main > 0 && !(n_main & 1);
+    u32x4 X[ROWS2 ? 2 : 1][XP];
     TilePos dwp;
     dwp.init(tile0, tile_step, a.n_tt, a.n_z);
     int dw_tile = tile0, dw_chunk = 0;
     auto x_origin = [&](const TilePos& p) { return (p.b * a.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
     int x_soff = x_origin(dwp);
-    auto dw_issue = [&]() {
+    auto dw_issue = [&](u32x4 (&X)[XP]) {
 #pragma unroll
       for (int j = 0; j < XP; ++j) X[j] = ld16(rx, lane_x + j * 64, x_soff);
       if (++dw_chunk == n_main) {
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
     f32x4 d[M];
     constexpr int WD = TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS;
     const char* trow = tapl + tap_off;             // re-pointed at the running stage's image at every stage start
-    auto xs_write = [&]() {
+    auto xs_write = [&](const u32x4 (&X)[XP]) {
 #pragma unroll
       for (int j = 0; j < XP; ++j) {
         if constexpr (DIL == 2) {     // 8 frames -> 4 even + 4 odd (the staged span starts on an even frame)
@@ -841,8 +851,12 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 
     unsigned ds = 0;                               // depthwise stages started: selects the tap image
     // prologue: rows and taps of the first stage (a pointwise-only layer has identity stages only: n_main == 0)
-    if (n_main) {
-      dw_issue();
+    if (rows2) {
+      tap_dma(0, 0);
+      dw_issue(X[0]);                                // rows of stages 0 and 1
+      dw_issue(X[ROWS2 ? 1 : 0]);
+    } else if (n_main) {
+      dw_issue(X[0]);
       tap_dma(0, 0);
     }
     // Identity rows are fetched TWO stages ahead when the stage count is even (register sets alternate, statically):
@@ -860,7 +874,34 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
       stage_barrier();
       ++gs;
     };
+    auto stage2 = [&](u32x4 (&XS)[XP]) {
+      // rows of this stage: requested two stages ago; its tap image: at the start of the previous stage, BEFORE that stage's row request -- so
+      // everything but the XP youngest loads (the next stage's rows) has to be there, and those stay in flight through this stage.  (Identity
+      // loads issued in between only make the wait stricter; there are never fewer than XP younger operations: dw_issue always issues.)
+      char* const dst = dwt + (gs & 1) * TILEB;
+      vm_wait<XP>();
+      trow = tapl + (ds & 1) * TAPB + tap_off;
+      xs_write(XS);
+      dw_begin();
+      tap_dma((ds + 1) & 1, t_next);                // the next stage's tap image first ...
+      dw_issue(XS);                                 // ... then the rows of the stage after next, into the set just consumed
+      tap_advance();
+      ++ds;
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int m = 0; m < M; ++m) *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+      stage_barrier();
+      ++gs;
+    };
     for (int tile = tile0; tile < tile_end; tile += tile_step) {
+      if (rows2) {
+        for (int s = 0; s < n_main; s += 2) {
+          stage2(X[0]);
+          stage2(X[ROWS2 ? 1 : 0]);
+        }
+      } else
       for (int s = 0; s < n_main; ++s, ++gs) {
         char* const dst = dwt + (gs & 1) * TILEB;
         // Everything this wave has in flight -- the rows and the tap image of THIS stage -- was issued at the start of the
@@ -873,7 +914,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #ifdef TS_EXP
         if (!(a.exp & 16))
 #endif
-        xs_write();
+        xs_write(X[0]);
         PSTAMP(8 * gs + 2);
 #ifdef TS_EXP
         if (!(a.exp & 2))
@@ -882,7 +923,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
 #ifdef TS_EXP
         if (!(a.exp & 16)) {
 #endif
-        dw_issue();                                   // rows of the next depthwise stage (possibly of the next tile)
+        dw_issue(X[0]);                               // rows of the next depthwise stage (possibly of the next tile)
         tap_dma((ds + 1) & 1, t_next);                // ... and its tap image, into the buffer the previous stage has finished with
 #ifdef TS_EXP
         }
