@@ -357,10 +357,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run, mx * a.scale_log2e);                   // scale > 0: max commutes with it; finite (>= 1 valid key)
-      const float alpha = exp2f(m_run - m_new);
+      // bare v_exp_f32 (exp2): the arguments are <= 0 and a flushed denormal is a zero weight -- the library form's range handling
+      // (compare, scale, select around every exp) was a third of this VALU-bound loop's instructions
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float rs = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = exp2f(fmaf(s[i], a.scale_log2e, -m_new)); rs += s[i]; }
+      for (int i = 0; i < 16; ++i) { s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], a.scale_log2e, -m_new)); rs += s[i]; }
       l_run = l_run * alpha + rs;
       m_run = m_new;
       if (__any(alpha != 1.f)) {                                              // after the first tiles the running maximum rarely moves
