@@ -150,3 +150,32 @@ def test_hipgraph_replays_are_bit_identical_to_eager():
             torch.cuda.synchronize()
             assert torch.equal(out, eager), f"replay {it}: max diff {float((out - eager).abs().max())}"
     assert torch.equal(out_len, eager_len)
+
+
+@pytest.mark.parametrize("cin,cout,k,repeat,t,lens,residual", [
+    (512, 512, 63, 3, 751, [751, 700, 96, 1], True),          # the C2 body shape: 8 stages, rows requested two stages ahead
+    (128, 640, 75, 4, 389, [389, 388, 97], False),            # 2 stages per tile, 640 output channels = two channel splits
+    (64, 512, 33, 4, 192, [192, 191, 5], True),               # ONE 64-channel stage per tile: the single-set producer path
+    (192, 256, 21, 2, 97, [97, 96], True),                    # odd stage count, a tile boundary one frame in
+    (256, 1024, 83, 3, 193, [193, 100], True),                # longest taps the split kernel takes
+    (512, 128, 5, 1, 1001, [1001, 640], True),                # shortest taps, single repeat with residual
+])
+def test_split_kernel_block_geometries_match_oracle(cin, cout, k, repeat, t, lens, residual):
+    """Blocks whose sub-blocks all take the split kernel (c_in % 64 == 0, internal tail-zero tensors), over stage counts, channel splits, tap
+    lengths and frame counts around the 96 / 192-frame tiles, against the oracle's bf16-ordered evaluation; a second call (warm arena
+    buffers) must reproduce the first bit for bit.  (tools/diag/split_sweep.py draws such cases at random.)"""
+    from thunder_speech_amd.quartznet.blocks import QuartznetBlock
+    spec = otcs.BlockSpec(cin, cout, repeat=repeat, kernel=k, stride=1, dilation=1, residual=residual, separable=True)
+    sd = {key[2:]: v for key, v in otcs.synth_encoder_state([spec], seed=k + t).items()}
+    blk = QuartznetBlock(cin, cout, repeat=repeat, kernel_size=(k,), residual=residual, separable=True)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda().eval()
+    x = bf16_round(torch.randn(len(lens), cin, t, generator=torch.Generator().manual_seed(t)))
+    lengths = torch.tensor(lens)
+    want, want_len = otcs.block_forward(spec, sd, "", x, lengths, emulate_bf16=True)
+    with torch.no_grad():
+        got, got_len = blk(x.cuda(), lengths.cuda())
+        again, _ = blk(x.cuda(), lengths.cuda())
+    assert torch.equal(got_len.cpu(), want_len) and torch.equal(again, got)
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got.float().cpu() - want).abs().max()) <= 0.016 * scale
