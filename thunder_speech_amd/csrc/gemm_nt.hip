@@ -78,8 +78,22 @@ __device__ __forceinline__ float gelu_g(float x) { return 0.5f * x * (1.f + erf_
 // That takes a quarter of the bytes off the LDS pipe (96 + 32 KiB per step were exactly the 128 B / clk it can move in a step's 1 024 MFMA
 // cycles), halves the LDS-DMA instructions -- whose issue cost is what the ring showed (tools/diag/gemm_exp.py: 21 % of the 8192^3
 // product with L2-hot sources) -- and leaves the MFMA phase free of memory instructions.
-template <bool PB>
-__global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
+// WMR: wave rows.  2: the 256 x 256 tile above, 8 waves.  1 (packed weights only): a 128 x 256 tile on 4 waves and 72 KiB of LDS, so that TWO
+// workgroups share a CU: they fall out of step by themselves, one's epilogue and cold prologue run under the other's k-loop, and the matrix
+// core is handed back and forth between the two waves of a SIMD without the stagger barriers.
+#ifndef TS_HALF_TWO_BARRIERS
+#define TS_HALF_TWO_BARRIERS 0
+#endif
+template <bool PB, int WMR = 2>
+__global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmArgs a) {
+  static_assert(WMR == 2 || PB, "the half tile exists for packed weights only");
+  constexpr int GMT = 128 * WMR;                                             // rows of this instantiation's tile
+  constexpr int SLOTB = (PB && WMR == 1) ? GMT * GROWB : GSTAGEB;            // bytes of a ring slot (the half tile stages A only)
+#ifndef TS_HALF_RING
+#define TS_HALF_RING 4
+#endif
+  constexpr int RINGN = (PB && WMR == 1) ? TS_HALF_RING : GRING;             // half tile: 8 KiB slots; eight of them (distance 7) measured no better than four
+  constexpr int PD = RINGN - 1;                                              // A is requested PD half-stages ahead
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
     mt_i = band * br + in / bc;
     nt_i = blk * bc + in % bc;
   }
-  const int m0 = mt_i * GM, n0 = nt_i * GN;
+  const int m0 = mt_i * GMT, n0 = nt_i * GN;
   const int bz = blockIdx.y;
   const unsigned short* const xb = a.x + (size_t)bz * a.sx;
 
@@ -129,9 +143,9 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
 #endif
   auto issue_a = [&](int s) {
 #ifdef TS_EXP
-    if ((a.exp & 1) && s >= GRING - 1) return;
+    if ((a.exp & 1) && s >= PD) return;
 #endif
-    char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
+    char* const st = smem + (s & (RINGN - 1)) * SLOTB;
 #pragma unroll
     for (int q = 0; q < 2; ++q) lds_dma16(ra, st + (32 * wave + 16 * q) * GROWB, offa[q], KOFF(s));
   };
@@ -229,23 +243,29 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
     // issue order of a wave: A0 B0 A1 A2 | B1 A3 | B2 A4 | ...  (A = 2 LDS-DMAs, B = 4 loads into the register set the previous step's
     // MFMAs have just released).  At the end of LOAD(s) everything up to B(s) has to be there -- B(s) for this step's MFMAs, A(s+1),
     // issued before it, for the next step's reads a barrier later: A(s+2) B(s+1) A(s+3) may stay in flight, 8 operations, fewer at the end.
+    auto vm_dyn = [&](int n) {                                                // n even
+      switch (n) {
+        case 0: vmw<0>(); break;  case 2: vmw<2>(); break;  case 4: vmw<4>(); break;  case 6: vmw<6>(); break;  case 8: vmw<8>(); break;
+        case 10: vmw<10>(); break;  case 12: vmw<12>(); break;  case 14: vmw<14>(); break;  default: vmw<16>(); break;
+      }
+    };
+    // (general prefetch distance PD: after B(s) a wave has issued A(s-1+PD), B(s+1), A(s+PD) -- where those half-stages exist)
     auto wait_tail = [&](int s) {
       const int left = S_ - 1 - s;                                            // steps after s
-      if (left >= 3) vmw<8>(); else if (left == 2) vmw<6>(); else if (left == 1) vmw<4>(); else vmw<0>();
+      if (left >= PD) vmw<8>(); else vm_dyn((left >= PD - 1 ? 2 : 0) + (left >= 1 ? 4 : 0));
     };
     issue_a(0);
     load_b(fbr[0], 0);
-    if (S_ > 1) issue_a(1);
-    if (S_ > 2) issue_a(2);
-    if (S_ > 2) vmw<8>(); else if (S_ > 1) vmw<6>(); else vmw<4>();         // A(0) has landed
+    for (int p = 1; p < PD && p < S_; ++p) issue_a(p);
+    vm_dyn(4 + 2 * ((S_ < PD ? S_ : PD) - 1));                                // A(0) has landed
     phase_barrier();
-    if (wm == 1) phase_barrier();
+    if (WMR == 2 && wm == 1) phase_barrier();
     auto step = [&](int s, s16x8 (&cur)[4], s16x8 (&nxt)[4]) {
-      const char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
+      const char* const st = smem + (s & (RINGN - 1)) * SLOTB;
       if (s + 1 < S_) load_b(nxt, s + 1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const s16x8*>(st + fa0 + i * 16 * GROWB);
-      if (s + GRING - 1 < S_) issue_a(s + GRING - 1);
+      if (s + PD < S_) issue_a(s + PD);
       wait_tail(s);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], cur[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      phase_barrier();
+      if (WMR == 2 || TS_HALF_TWO_BARRIERS) phase_barrier();   // one wave row: the barrier after LOAD already orders ring reads, DMA waits and refills
     };
     int s = 0;
     for (; s + 2 <= S_; s += 2) {
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(const GemmArgs a) {
       phase_barrier();
     }
   }
-  if (wm == 0) phase_barrier();                                           // the first row's partner of the extra barrier above
+  if (WMR == 2 && wm == 0) phase_barrier();                               // the first row's partner of the extra barrier above
   // ---- epilogue ------------------------------------------------------------------------------------------------------
   // The accumulator layout (lane = column, registers = rows) would store 2 or 4 bytes per lane; instead each wave stages its tile, 32
   // columns at a time, as f32 [128 rows][32 columns] in its own 16 KiB of the (now idle) operand ring and reads it back row-wise:
@@ -414,7 +434,18 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
 #endif
   (void)hipGetLastError();
   const dim3 grid((unsigned)(a.n_mt * a.n_nt), (unsigned)batch);
-  if (wf) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(512), GEMM_LDS, stream, a);
+  static const int half_mode = getenv("TS_GEMM_HALF") ? atoi(getenv("TS_GEMM_HALF")) : 1;      // 128-row tiles for packed weights (0: the 256-row tile, for the A/B)
+  if (wf && half_mode) {
+    constexpr int LDS_H = 4 * 128 * 144;
+    static int attr_h = 0;
+    if (!attr_h) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H) != hipSuccess)
+        return TS_EUNSUPPORTED;
+      attr_h = 1;
+    }
+    a.n_mt = (int)((M + 127) / 128);
+    hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), dim3((unsigned)(a.n_mt * a.n_nt), (unsigned)batch), dim3(256), LDS_H, stream, a);
+  } else if (wf) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(512), GEMM_LDS, stream, a);
   else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(512), GEMM_LDS, stream, a);
   return hip_status(hipGetLastError());
 }
