@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 5
+#define TS_ABI_VERSION 6
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -64,11 +64,6 @@ typedef struct ts_tcs_desc {
                                    NK k-steps as raw taps, bf16 [c_in_pad64/64][4 groups of 16 channels][KiB-padded image]; per channel
                                    16 NK + 16 bytes = two copies of wp[n] = w[n - 3 - (round_up(padding, 4) - padding)], n < 4 NK + 4, the
                                    second shifted by one element (plan.pack_dw_taps_raw).  With TS_TCS_TAPS_PHASE: the phase-split form. */
-  const void* dw_taps_t16;      /* stride-1, dilation-1 layers with kernel <= 81 (may be NULL): the "sliding window" tap image of the merged
-                                   kernel, bytes [c_in_pad64/64][8 groups of 8 channels][8][(32 NC + 16) * 8]: per channel, window p (8 bytes)
-                                   = wp[p .. p + 3], wp[i] = w[i - 15 + o + padding] (0 outside the taps), o = -8 ceil(padding / 8),
-                                   NC = dw_t16_chunks = ceil((padding + 16 - o) / 32)  (plan.pack_dw_taps_t16) */
-  int32_t dw_t16_chunks;        /* NC of dw_taps_t16 (1..3); 0 = no image */
   const void* pw_w;             /* bf16 [c_out_pad32/32][c_in_pad64/16][64][8]  MFMA B-fragments of W*bn_scale */
   const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */
@@ -94,6 +89,22 @@ typedef struct ts_tcs_desc {
  * y: bf16 or f32 [B][c_out][pitch_out]. */
 int ts_tcs_subblock_fwd(const ts_tcs_desc* desc, const void* x, const int32_t* len_in, const void* x_res,
                         const int32_t* len_res, void* y, void* stream);
+
+/* A CHAIN of sub-blocks in ONE persistent launch: the R repeats of a QuartznetBlock / CitrinetBlock
+ * (quartznet/blocks.py:266-296, :317-338: `for layer in self.mconv` + the residual branch folded into the last repeat).
+ * Layer l reads x[l] and writes y[l]; x[l] == y[l-1] for l >= 1 (x[0] and every x_res[l] were written before the launch).
+ * Inside the launch a tile of layer l starts as soon as the (at most three) tiles of layer l-1 that cover its input frames
+ * (the tile and its K-1 halo) have been published through per-(layer, clip, time tile) counters in `workspace` -- no grid-wide
+ * barrier, no dependence on dispatch order or workgroup placement (write-through stores + agent-scope counters).
+ * Every layer: depthwise stride 1 / dilation 1, the same batch, kernel, padding, dw_ksteps, c_out, t_in == t_out, pitch_in ==
+ * pitch_out, c_in / c_res multiples of 64, both TS_TCS_IN_TAILZERO and TS_TCS_OUT_ZERO_TAIL set, dw_taps_raw given; `len` int32 [B]
+ * is the valid length of every tensor of the chain.  TS_EUNSUPPORTED otherwise (run the layers one by one with ts_tcs_subblock_fwd).
+ * workspace: ts_tcs_chain_workspace_bytes() bytes, any contents (the launch zeroes it with a memset node of its own); after the
+ * launch its last int32 is 0, or non-zero when a wait gave up (a workgroup of the launch was not resident: results invalid). */
+#define TS_TCS_CHAIN_MAX 16
+int64_t ts_tcs_chain_workspace_bytes(int32_t batch, int32_t t_out, int32_t n_layers);
+int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, const void* const* x, const void* const* x_res, void* const* y,
+                     const int32_t* len, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Squeeze-excite of the Citrinet blocks (eval): replaces SqueezeExcite.forward (citrinet/blocks.py:70-83: AdaptiveAvgPool1d

@@ -38,7 +38,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_library_loads_and_answers_version_queries():
     from thunder_speech_amd import _lib
     L = _lib.lib()
-    assert L.ts_abi_version() == _lib.ABI_VERSION == 5
+    assert L.ts_abi_version() == _lib.ABI_VERSION == 6
     assert L.ts_build_target() == b"gfx950"
     for t in (1, 127, 128, 129, 751, 1501, 2001):
         assert L.ts_time_pitch(t) == _lib.time_pitch(t) and _lib.time_pitch(t) % 128 == 0 and _lib.time_pitch(t) >= t
@@ -94,41 +94,6 @@ def test_pack_dw_taps_is_the_toeplitz_of_the_conv(k, stride, dil):
             got = (taps[:3, i].float() * win).sum(-1)
             np.testing.assert_allclose(got.numpy(), ref[:, t + i].numpy(), atol=1e-4)
     assert torch.all(taps[3:] == 0)
-
-
-@pytest.mark.parametrize("k", [5, 11, 17, 33, 39, 51, 63, 75])
-def test_pack_dw_taps_t16_windows_rebuild_the_toeplitz_fragments(k):
-    """plan.pack_dw_taps_t16: the sliding-window image of the merged kernel.  Rebuild, from the image alone, the A operand the
-    kernel hands to v_mfma_f32_16x16x32_bf16 -- lane (m, kg), chunk c, element j = window 8 kg - m + 15 + 32 c (+ 4), tap j % 4 --
-    and check that D = A x B with B_c[k][n] = x[16 n + o + 32 c + k] is the "same"-padded depthwise convolution."""
-    import torch.nn.functional as F
-    from thunder_speech_amd import plan
-    pad = k // 2
-    g = torch.Generator().manual_seed(k)
-    w = torch.randn(64, 1, k, generator=g).to(torch.bfloat16).float()
-    img, nc = plan.pack_dw_taps_t16(w, pad)
-    o, nc2 = plan.t16_geometry(k, pad)
-    assert nc == nc2 and 1 <= nc <= 3 and o % 8 == 0 and o <= -pad and o + 32 * nc >= 16 + pad
-    npos = 32 * nc + 16
-    assert img.shape == (1, 8, 8, npos * 8) and img.dtype == torch.uint8
-    win = img.reshape(64, npos * 8).view(torch.bfloat16).reshape(64, npos, 4).float()      # [channel][window][4 taps]
-    m = torch.arange(16).view(16, 1, 1, 1)
-    kg = torch.arange(4).view(1, 4, 1, 1)
-    c = torch.arange(nc).view(1, 1, nc, 1)
-    j = torch.arange(8).view(1, 1, 1, 8)
-    p = 8 * kg - m + 15 + 32 * c + 4 * (j // 4)                                          # window index per (m, kg, c, j)
-    a = win[:, p, j % 4]                                                                  # [ch, m, kg, c, j]
-    toep = a.permute(0, 1, 3, 2, 4).reshape(64, 16, nc * 32)                              # A[m][32 c + 8 kg + j]
-    t = 16 * 12
-    x = torch.randn(64, t + 400, generator=g)
-    x[:, :100] = 0; x[:, 100 + t:] = 0                                                    # zero outside the tile: "same" padding
-    n = torch.arange(12).view(12, 1)
-    kk = torch.arange(32 * nc).view(1, -1)
-    bmat = x[:, 100 + 16 * n + o + kk]                                                    # [ch, n, k]
-    d = torch.einsum("cmk,cnk->cnm", toep, bmat).reshape(64, t)                           # y[16 n + m]
-    ref = F.conv1d(x[None, :, 100 - pad: 100 + t + pad], w, groups=64)[0]
-    assert torch.allclose(d, ref, atol=1e-4)
-    assert plan.pack_dw_taps_t16(torch.randn(64, 1, 87), 43) == (None, 0)                  # 4 chunks: no image
 
 
 def test_tap_fragments_layout():

@@ -12,7 +12,7 @@ from typing import Optional
 from .build import lib_path
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 TCS_IN_TAILZERO = 1
 TCS_OUT_ZERO_TAIL = 2
 TCS_TAPS_PHASE = 4
@@ -20,7 +20,7 @@ TS_EUNSUPPORTED = -2
 GUARD_BYTES = 1024
 
 EXPORTED_SYMBOLS = [
-    "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd",
+    "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd", "ts_tcs_chain_fwd", "ts_tcs_chain_workspace_bytes",
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss", "ts_ctc_prepare",
     "ts_pack_activation", "ts_unpack_activation", "ts_lengths_map", "ts_im2col_time", "ts_fe_preemph", "ts_fe_dither", "ts_fe_power_spectrum", "ts_fe_stft", "ts_fe_mel", "ts_fe_normalize", "ts_gemm_nt_bf16", "ts_gemm_nt_pack_w", "ts_gemm_nt_bf16_packed", "ts_se_gate_fwd", "ts_se_apply_fwd",
@@ -47,7 +47,7 @@ class TcsDesc(C.Structure):
         ("depthwise", C.c_int32), ("relu", C.c_int32), ("out_fp32", C.c_int32),
         ("c_res", C.c_int32), ("pitch_res", C.c_int32), ("t_res", C.c_int32), ("res_stride", C.c_int32),
         ("dw_ksteps", C.c_int32), ("flags", C.c_int32),
-        ("dw_taps", C.c_void_p), ("dw_taps_raw", C.c_void_p), ("dw_taps_t16", C.c_void_p), ("dw_t16_chunks", C.c_int32), ("pw_w", C.c_void_p), ("res_w", C.c_void_p), ("bias", C.c_void_p),
+        ("dw_taps", C.c_void_p), ("dw_taps_raw", C.c_void_p), ("pw_w", C.c_void_p), ("res_w", C.c_void_p), ("bias", C.c_void_p),
     ]
 
 
@@ -87,6 +87,10 @@ def lib() -> C.CDLL:
     L.ts_time_pitch.restype = C.c_int
     L.ts_tcs_subblock_fwd.argtypes = [C.POINTER(TcsDesc), vp, vp, vp, vp, vp, vp]
     L.ts_tcs_subblock_fwd.restype = C.c_int
+    L.ts_tcs_chain_workspace_bytes.argtypes = [i32, i32, i32]
+    L.ts_tcs_chain_workspace_bytes.restype = i64
+    L.ts_tcs_chain_fwd.argtypes = [C.POINTER(TcsDesc), i32, vp, vp, vp, vp, vp, i64, vp]
+    L.ts_tcs_chain_fwd.restype = C.c_int
     L.ts_frontend_workspace_bytes.argtypes = [C.POINTER(FrontendDesc)]
     L.ts_frontend_workspace_bytes.restype = i64
     L.ts_mel_frontend_fwd.argtypes = [C.POINTER(FrontendDesc), vp, vp, vp, vp, vp, vp]

@@ -28,22 +28,11 @@
 //  * a lone wave issues an instruction only every ~8 cycles on this chip, so the steady state is kept almost VALU-free.
 #include "tcs_shared.hpp"
 
-#include <cstdlib>
 
 namespace ts {
 
-constexpr int NKP = 3;         // depthwise k-steps (of 4 samples) per pass
 constexpr int XMAX = 5;        // staged row length <= 64 * XMAX elements
 constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
-#ifndef TS_SPLIT_RING
-#define TS_SPLIT_RING 2
-#endif
-#ifndef TS_ROWS2
-#define TS_ROWS2 1            // producers request their rows TWO stages ahead (two register sets, counted vmcnt); 0: one stage, drain
-#endif
-#ifndef TS_WIN_DIST
-#define TS_WIN_DIST 1
-#endif
 constexpr int RING_BYTES = 8;   // weight-fragment prefetch depth: RING_BYTES KiB per wave in flight
 
 
@@ -61,20 +50,6 @@ struct DwTile {
   }
 };
 
-
-#ifdef TS_STAMP
-// Diagnostic build (tools/diag): stamps of workgroup 7, first tile only.  Never compiled into the product library.
-#define STAMP(slot) do { if (a.dbg && blockIdx.x == 7 && tile == 7 && lane == 0 && (slot) < 64) a.dbg[wave * 64 + (slot)] = clock64(); } while (0)
-#else
-#define STAMP(slot) do { } while (0)
-#endif
-#ifdef TS_STAMP
-#define PSTAMP(slot) do { if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) < 120) a.dbg[wave * 128 + (slot)] = clock64(); \
-    if (a.dbg && blockIdx.x == 7 && lane == 0 && (slot) == 0) { a.dbg[wave * 128 + 120] = __builtin_amdgcn_s_memrealtime(); a.dbg[wave * 128 + 121] = clock64(); } \
-    if (a.dbg && blockIdx.x == 7 && lane == 0) { a.dbg[wave * 128 + 122] = __builtin_amdgcn_s_memrealtime(); a.dbg[wave * 128 + 123] = clock64(); } } while (0)
-#else
-#define PSTAMP(slot) do { } while (0)
-#endif
 
 template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS, bool TZ, int XJ, int NPASS>
 __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
@@ -192,7 +167,6 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
         if constexpr (DW) {
           for (int s = 0; s < n_main; ++s, ++gs) {
             char* const dst = dwt + (gs & 1) * Tile::BYTES;
-            STAMP(1 + 5 * s);
             // taps of THIS stage straight into registers (NPASS is compile-time, so they are statically indexed
             // MFMA operands): they arrive from L2 while the staging writes below run -- no LDS round trip
             const unsigned short* tp = a.taps + (size_t)s * chunk_t + lane_t;
@@ -211,9 +185,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
                 d2[1] = u32x2{X[rr][j][2], X[rr][j][3]};
               }
             }
-            STAMP(2 + 5 * s);
             dw_issue();                                   // next depthwise stage (may belong to the next tile)
-            STAMP(3 + 5 * s);
             // depthwise FIR, LDS reads of pass p+1 issued before the MFMAs of pass p
             f32x4 d[M];
 #pragma unroll
@@ -249,9 +221,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
             for (int m = 0; m < M; ++m)
               *reinterpret_cast<u32x2*>(dst + Tile::addr(cw, q * RUN + 4 * m)) =
                   u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
-            STAMP(4 + 5 * s);
             stage_barrier();
-            STAMP(5 + 5 * s);
           }
         }
         for (int s = 0; s < n_id; ++s, ++gs) {
@@ -422,21 +392,15 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
             *reinterpret_cast<u32x2*>(dst + Tile::addr(cw, tl)) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
           }
         };
-        STAMP(0);
         issue_x(0);
         issue_t(0);
         for (int s = 0; s < n_main; ++s, ++gs) {
-          STAMP(1 + 5 * s);
           write_x();
           write_t();
-          STAMP(2 + 5 * s);
           if (s + 1 < n_main) { issue_x(s + 1); issue_t(s + 1); }
           else if (n_res > 0) issue_id(n_main);
-          STAMP(3 + 5 * s);
           depthwise(s, dwt + (gs & 1) * Tile::BYTES);
-          STAMP(4 + 5 * s);
           stage_barrier();
-          STAMP(5 + 5 * s);
         }
       } else {
         issue_id(0);
@@ -520,11 +484,8 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
 #pragma unroll
     for (int r = 0; r < RING; ++r) load_w(ring[r]);
 
-    STAMP(0);
     for (int s = 0; s < n_stage; ++s, ++gs) {
-      STAMP(1 + 2 * s);
       stage_barrier();
-      STAMP(2 + 2 * s);
       const char* src = dwt + (gs & 1) * Tile::BYTES;
       // A fragments of k-step ks+1 are read (transposed) from LDS before the MFMAs of k-step ks are issued
       s16x8 afA[MT], afB[MT];
@@ -549,18 +510,13 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       read_a(0, afA);
       read_a(1, afB);
       mfma_ks(0, afA);
-      STAMP(20 + 4 * s);
       read_a(2, afA);
       mfma_ks(1, afB);
-      STAMP(21 + 4 * s);
       read_a(3, afB);
       mfma_ks(2, afA);
-      STAMP(22 + 4 * s);
       mfma_ks(3, afB);
-      STAMP(23 + 4 * s);
     }
 
-    STAMP(60);
     // ---- epilogue (overlaps the producers' first stage of the next tile) -------------------------------
     if constexpr (OUT_F32) {
 #pragma unroll
@@ -642,550 +598,7 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
         }
       }
     }
-    STAMP(61);
   }
-}
-
-// ======================================================================================================
-// helpers of the split kernel
-// ======================================================================================================
-// ======================================================================================================
-// Split kernel: 12 waves = 8 consumer waves (pointwise GEMM, accumulators) + 4 producer waves (depthwise FIR).
-//
-// When the two jobs share an instruction stream they measurably do not overlap (skeleton + pointwise + depthwise times add
-// up: round 1's pipelined kernel).  Here they are different waves: every SIMD runs two consumer waves and one
-// producer wave, so the LDS-heavy depthwise stream issues while the consumers sit in their MFMA bursts.  Three waves
-// per SIMD leave 168 VGPRs each: enough for the 96 accumulators + ring + A fragments of a consumer, and for the
-// 16-channel windows of a producer.
-//   producer p (wave 8 + p): channels [16p, 16p + 16) of the stage, 16 MFMA blocks = 16 channels, 4 lane runs of TT/4
-//     frames, M = TT/16 steps per run (each tap fragment read feeds M MFMAs: 6 or 12, against 3 or 6 above);
-//     rows global -> registers (a stage ahead) -> wave-private LDS rows; taps global -> LDS by DMA, 2 k-steps per KiB.
-//   consumer w: output tile 96 frames x 64 channels.
-//   iteration i: producers write stage i into dwt[i & 1], consumers read stage i-1 out of dwt[(i-1) & 1]; one barrier.
-//   The epilogue runs after the barrier that ends the last stage of a tile, so the producers work through it.
-// ======================================================================================================
-// DIL == 2 (dilation-2 layers, K87 of QuartzNet): the even and the odd frames of a row are two independent dilation-1
-// sequences (y[2s+p] = sum_u w[u] x[2(s+u)+p - pad], pad even).  The producers stage each row as [even | odd] halves,
-// lane runs 0,1 filter the even half and 2,3 the odd half with dilation-1 tap fragments (no zero-stuffed Toeplitz rows:
-// 24 k-steps instead of 45), and lane pairs re-interleave their results on the way into the dw tile.
-template <int NPASS, int XJ, int MT, int WM, int DIL = 1>
-__global__ __launch_bounds__(768) void tcs_split_kernel(const TcsArgs a) {
-  constexpr int WN = 8 / WM, NT = 2;
-  constexpr int FW = 32 * MT;
-  constexpr int TT = FW * WM;
-  constexpr int M = TT / 16, RUN = TT / 4;        // producer: 4 runs of RUN frames per channel, M steps of 4 frames
-  constexpr int NK = NPASS * NKP;
-  constexpr int NP = NK + M - 1;
-  constexpr int ROWB = TT <= 128 ? 256 : 512;
-  constexpr int TILEB = KC * ROWB;
-  constexpr int EP = FW * 2 + 24;
-  constexpr int XP = 2 * XJ;                      // 16 rows x 128*XJ bytes per wave, 1 KiB per instruction
-  constexpr int IDP = (2 * TT + 63) / 64;         // identity rows: 16 rows x 2*TT bytes
-  // Depthwise taps: RAW, not as Toeplitz fragments.  Per channel two copies of the zero-padded tap array wp[n] = w[n - 3 - d]
-  // (copy 1 shifted by one element), their dwords interleaved (dword j of copy c at byte 8 j + 4 c), CST bytes per channel;
-  // Toeplitz row i of k-step k is wp[4k + 3 - i .. +3] = dwords 2k + (i < 2) and the next one of copy (i even): one
-  // ds_read2_b32.  CST = 16 (mod 32) bytes puts the 8 channels x 4 rows of a half-wave on 32 different banks.  Half the bytes of
-  // the pre-shifted fragments, so the taps of a 16-channel group fit TWICE: the image of the NEXT stage is fetched by DMA at
-  // the start of the running one (a whole stage ahead of its first use) and no DMA sits inside the MFMA passes any more.
-  constexpr int CST = (16 * NK + 16) % 32 == 16 ? 16 * NK + 16 : 16 * NK + 32;
-  constexpr int NTD = (16 * CST + 1023) / 1024;   // KiB (= DMA instructions) per 16-channel group and stage
-  constexpr int TAPB = NTD * 1024;
-  constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
-  constexpr int ER = (WM == 2 || DIL == 2) ? 16 : 32;   // output-channel rows of a consumer's epilogue tile
-  constexpr int PHW = 32 * XJ;                    // DIL == 2: frames of a staged half row
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef TS_EXP
-  if (a.exp & 32) return;
-#endif
-  char* const dwt = smem;                                             // [2][KC][ROWB]
-  char* const cons0 = smem + 2 * TILEB;                               // [8][32][EP] epilogue tiles
-  char* const prod0 = cons0 + 8 * ER * EP;                            // [4][XSB + 2 * TAPB]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n_main = a.c_in / KC;
-  const int n_res = a.c_res / KC;
-  const int n_stage = n_main + n_res;
-  // XCD-aware tile order: workgroup i runs on XCD i % 8, and each XCD has its own L2.  Give every XCD one
-  // contiguous range of tiles so that the input halos neighbouring time tiles share are fetched into ONE L2.
-  int tile0 = blockIdx.x, tile_step = gridDim.x, tile_end = a.n_tiles;
-  if (a.xcd) {
-    const int per = (a.n_tiles + 7) >> 3, xcd = blockIdx.x & 7;
-    tile0 = xcd * per + (blockIdx.x >> 3);
-    tile_step = gridDim.x >> 3;
-    tile_end = min(a.n_tiles, (xcd + 1) * per);
-    if (tile0 >= tile_end) return;
-  }
-  auto taddr = [](int c, int t) { return c * ROWB + ((((t >> 3) ^ ((c & 3) * 5))) << 4) + ((t & 7) << 1); };
-  constexpr int RSRC_FLAGS = 0x00020000;
-  auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
-  auto ld16 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); };
-  unsigned gs = 0;
-
-  if (wave >= 8) {
-    // ================================= PRODUCER =======================================================
-#ifdef TS_PROD_PRIO
-    __builtin_amdgcn_s_setprio(TS_PROD_PRIO);
-#endif
-    const int pw = wave - 8;
-    char* const xs = prod0 + (size_t)pw * (XSB + 2 * TAPB);
-    char* const tapl = xs + XSB;                   // two tap images: stage gs reads tapl[gs & 1]
-    const int xpitch = 64 * XJ + 4;
-    const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(a.x) - TS_GUARD_BYTES);
-    const i32x4 rt = raw_rsrc(a.taps_raw, (unsigned)n_main * (4 * TAPB));
-    const __amdgpu_buffer_rsrc_t ri = rsrc(n_res ? a.xres : a.x);
-    const int row = lane >> 2, sub = lane & 3;     // staging: row of the wave's 16 channels, 16-byte group sub + 4j
-    const int q = lane & 3;                        // depthwise: channel = row, time run q
-    char* const xw = xs + ((size_t)row * xpitch + sub * (DIL == 2 ? 4 : 8)) * 2;
-    const char* const xrow = DIL == 2 ? xs + ((size_t)row * xpitch + (q >> 1) * PHW + a.woff + (q & 1) * RUN) * 2
-                                      : xs + ((size_t)row * xpitch + a.woff + q * RUN) * 2;
-    // this lane's Toeplitz row inside a tap image: channel `row`, copy by the parity of q, one dword in for q < 2
-    const int tap_off = row * CST + ((lane & 1) ? 0 : 4) + ((lane & 3) < 2 ? 8 : 0);
-    int dw_out[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-      dw_out[m] = DIL == 2 ? taddr(pw * 16 + row, (q & 1) * 2 * RUN + 8 * m + 4 * (q >> 1)) : taddr(pw * 16 + row, q * RUN + 4 * m);
-    const int lane_x = ((pw * 16 + row) * a.pitch_in + sub * 8) * 2;
-    const int lane_t = pw * TAPB + lane * 16;      // [chunk][16-ch group][TAPB]
-    const int lane_i = ((pw * 16 + row) * a.pitch_res + sub * 8) * 2;
-    const int id_out = taddr(pw * 16 + row, sub * 8);
-    const int chunk_x = KC * a.pitch_in * 2;
-    const int chunk_t = 4 * TAPB;
-    const int chunk_i = KC * a.pitch_res * 2;
-
-    // ROWS2 (96-frame tiles, dilation 1, an even number of 64-channel stages): a stage's rows are requested TWO stages before it runs, into
-    // two register sets that alternate statically (the stage loop runs in pairs), and the stage start waits with a counted vmcnt instead of
-    // draining the queue -- the rows of the stage in between stay in flight.  A loaded HBM round trip is longer than one stage: the drain
-    // cost 950 of a stage's 5 500 stamped ticks (tools/diag/run_stamp_split.py).  Worth 1 % on the C2 step; the stage is then held by the rest
-    // of the producer chain.
-    constexpr bool ROWS2 = TS_ROWS2 && WM == 1 && DIL == 1;
-    const bool rows2 = ROWS2 && n_main > 0 && !(n_main & 1);
-    u32x4 X[ROWS2 ? 2 : 1][XP];
-    TilePos dwp;
-    dwp.init(tile0, tile_step, a.n_tt, a.n_z);
-    int dw_tile = tile0, dw_chunk = 0;
-    auto x_origin = [&](const TilePos& p) { return (p.b * a.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
-    int x_soff = x_origin(dwp);
-    auto dw_issue = [&](u32x4 (&X)[XP]) {
-#pragma unroll
-      for (int j = 0; j < XP; ++j) X[j] = ld16(rx, lane_x + j * 64, x_soff);
-      if (++dw_chunk == n_main) {
-        dw_chunk = 0;
-        if (dw_tile + tile_step < tile_end) { dw_tile += tile_step; dwp.advance(a.n_tt, a.n_z); }
-        x_soff = x_origin(dwp);
-      } else {
-        x_soff += chunk_x;
-      }
-    };
-    int t_next = (n_main > 1 ? 1 : 0) * chunk_t;
-    auto tap_dma = [&](int buf, int soff) {        // the whole image of a stage into tapl[buf]
-#pragma unroll
-      for (int h = 0; h < NTD; ++h) lds_dma16(rt, tapl + buf * TAPB + h * 1024, lane_t, soff + h * 1024);
-    };
-    auto tap_advance = [&]() { t_next = t_next + chunk_t == n_main * chunk_t ? 0 : t_next + chunk_t; };
-    u32x4 I[IDP], I2[IDP];                          // identity rows in flight: one stage ahead (two when n_res is even)
-    TilePos idp;
-    idp.init(tile0, tile_step, a.n_tt, a.n_z);
-    int id_tile = tile0, id_s = 0;
-    auto i_origin = [&](const TilePos& p) { return (p.b * a.c_res * a.pitch_res + p.tt * TT) * 2; };
-    int i_soff = i_origin(idp);
-    auto id_issue = [&](u32x4 (&I)[IDP]) {
-#pragma unroll
-      for (int j = 0; j < IDP; ++j) I[j] = ld16(ri, lane_i + j * 64, i_soff);
-      if (++id_s == n_res) {
-        id_s = 0;
-        if (id_tile + tile_step < tile_end) { id_tile += tile_step; idp.advance(a.n_tt, a.n_z); }
-        i_soff = i_origin(idp);
-      } else {
-        i_soff += chunk_i;
-      }
-    };
-
-    s16x4 P[NP];
-    u32x2 T[NK];
-    f32x4 d[M];
-    constexpr int WD = TS_WIN_DIST < NPASS ? TS_WIN_DIST : NPASS;
-    const char* trow = tapl + tap_off;             // re-pointed at the running stage's image at every stage start
-    auto xs_write = [&](const u32x4 (&X)[XP]) {
-#pragma unroll
-      for (int j = 0; j < XP; ++j) {
-        if constexpr (DIL == 2) {     // 8 frames -> 4 even + 4 odd (the staged span starts on an even frame)
-          *reinterpret_cast<u32x2*>(xw + j * 32) = u32x2{__builtin_amdgcn_perm(X[j][1], X[j][0], 0x05040100u),
-                                                         __builtin_amdgcn_perm(X[j][3], X[j][2], 0x05040100u)};
-          *reinterpret_cast<u32x2*>(xw + j * 32 + PHW * 2) = u32x2{__builtin_amdgcn_perm(X[j][1], X[j][0], 0x07060302u),
-                                                                   __builtin_amdgcn_perm(X[j][3], X[j][2], 0x07060302u)};
-        } else {
-          u32x2* d2 = reinterpret_cast<u32x2*>(xw + j * 64);
-          d2[0] = u32x2{X[j][0], X[j][1]};
-          d2[1] = u32x2{X[j][2], X[j][3]};
-        }
-      }
-    };
-    auto win_load = [&](int u) { P[u] = *reinterpret_cast<const s16x4*>(xrow + u * 8); };
-    auto tap_load = [&](int kk) {
-      T[kk] = u32x2{*reinterpret_cast<const unsigned*>(trow + kk * 16), *reinterpret_cast<const unsigned*>(trow + kk * 16 + 8)};
-    };
-    auto dw_begin = [&]() {
-#pragma unroll
-      for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < M - 1 + NKP * WD; ++u) win_load(u);
-#pragma unroll
-      for (int kk = 0; kk < NKP * WD; ++kk) tap_load(kk);
-    };
-    auto dw_pass = [&](auto pc) {
-      constexpr int p = decltype(pc)::value;
-      if constexpr (p + WD < NPASS) {
-#pragma unroll
-        for (int u = 0; u < NKP; ++u) win_load((p + WD) * NKP + M - 1 + u);
-#pragma unroll
-        for (int u = 0; u < NKP; ++u) tap_load((p + WD) * NKP + u);
-      }
-#pragma unroll
-      for (int kk = 0; kk < NKP; ++kk)
-#pragma unroll
-        for (int m = 0; m < M; ++m)
-          d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m], d[m], 0, 0, 0);
-    };
-
-    unsigned ds = 0;                               // depthwise stages started: selects the tap image
-    // prologue: rows and taps of the first stage (a pointwise-only layer has identity stages only: n_main == 0)
-    if (rows2) {
-      tap_dma(0, 0);
-      dw_issue(X[0]);                                // rows of stages 0 and 1
-      dw_issue(X[ROWS2 ? 1 : 0]);
-    } else if (n_main) {
-      dw_issue(X[0]);
-      tap_dma(0, 0);
-    }
-    // Identity rows are fetched TWO stages ahead when the stage count is even (register sets alternate, statically):
-    // an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
-    const bool id2 = WM == 1 && n_res && !(n_res & 1);      // (the 192-frame tiles have no registers to spare for a second set)
-    if (n_res) id_issue(I);
-    if (id2) id_issue(I2);
-    vm_wait<0>();
-    auto id_stage = [&](u32x4 (&R)[IDP], bool drain) {
-      char* const dst = dwt + (gs & 1) * TILEB;
-      if (drain) vm_wait<0>(); else vm_wait<IDP>();
-#pragma unroll
-      for (int j = 0; j < IDP; ++j) *reinterpret_cast<u32x4*>(dst + (id_out ^ (j << 6))) = R[j];
-      id_issue(R);
-      stage_barrier();
-      ++gs;
-    };
-    auto stage2 = [&](u32x4 (&XS)[XP]) {
-      // rows of this stage: requested two stages ago; its tap image: at the start of the previous stage, BEFORE that stage's row request -- so
-      // everything but the XP youngest loads (the next stage's rows) has to be there, and those stay in flight through this stage.  (Identity
-      // loads issued in between only make the wait stricter; there are never fewer than XP younger operations: dw_issue always issues.)
-      char* const dst = dwt + (gs & 1) * TILEB;
-      vm_wait<XP>();
-      trow = tapl + (ds & 1) * TAPB + tap_off;
-      xs_write(XS);
-      dw_begin();
-      tap_dma((ds + 1) & 1, t_next);                // the next stage's tap image first ...
-      dw_issue(XS);                                 // ... then the rows of the stage after next, into the set just consumed
-      tap_advance();
-      ++ds;
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int m = 0; m < M; ++m) *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
-      stage_barrier();
-      ++gs;
-    };
-    for (int tile = tile0; tile < tile_end; tile += tile_step) {
-      if (rows2) {
-        for (int s = 0; s < n_main; s += 2) {
-          stage2(X[0]);
-          stage2(X[ROWS2 ? 1 : 0]);
-        }
-      } else
-      for (int s = 0; s < n_main; ++s, ++gs) {
-        char* const dst = dwt + (gs & 1) * TILEB;
-        // Everything this wave has in flight -- the rows and the tap image of THIS stage -- was issued at the start of the
-        // previous stage: the drain is cheap.  (DMA-to-LDS loads and register loads retire out of order with respect to each
-        // other, so a counted vmcnt could not separate them anyway.)
-        PSTAMP(8 * gs);
-        vm_wait<0>();
-        PSTAMP(8 * gs + 1);
-        trow = tapl + (ds & 1) * TAPB + tap_off;
-#ifdef TS_EXP
-        if (!(a.exp & 16))
-#endif
-        xs_write(X[0]);
-        PSTAMP(8 * gs + 2);
-#ifdef TS_EXP
-        if (!(a.exp & 2))
-#endif
-        dw_begin();
-#ifdef TS_EXP
-        if (!(a.exp & 16)) {
-#endif
-        dw_issue(X[0]);                               // rows of the next depthwise stage (possibly of the next tile)
-        tap_dma((ds + 1) & 1, t_next);                // ... and its tap image, into the buffer the previous stage has finished with
-#ifdef TS_EXP
-        }
-#endif
-        tap_advance();
-        ++ds;
-        __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(8 * gs + 3);
-#ifdef TS_EXP
-        if (!(a.exp & 2))
-#endif
-        static_for<0, NPASS>([&](auto pc) { dw_pass(pc); __builtin_amdgcn_sched_barrier(0); });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PSTAMP(8 * gs + 4);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const unsigned m0 = pack_bf16(d[m][0], d[m][1]), m1 = pack_bf16(d[m][2], d[m][3]);
-          if constexpr (DIL == 2) {
-            // lanes q and q ^ 2 hold the even and the odd frames of the same 8-frame group: the even lane stores frames
-            // 0..3 (e0 o0 e1 o1), the odd lane frames 4..7 (e2 o2 e3 o3)
-            const unsigned t0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m0, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-            const unsigned t1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m1, 0x4E, 0xf, 0xf, true);
-            const bool odd = (q >> 1) != 0;
-            const unsigned ev = odd ? t1 : m0, od = odd ? m1 : t0;
-            *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{__builtin_amdgcn_perm(od, ev, 0x05040100u), __builtin_amdgcn_perm(od, ev, 0x07060302u)};
-          } else {
-            *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{m0, m1};
-          }
-        }
-        PSTAMP(8 * gs + 5);
-        stage_barrier();
-        PSTAMP(8 * gs + 6);
-      }
-      if (id2) {
-        // a tile that had depthwise stages drains once (tap DMAs and row loads are in the queue: counted waits cannot
-        // separate them); after that only identity loads are in flight and they retire in order
-        for (int s = 0; s < n_res; s += 2) {
-          id_stage(I, s == 0 && n_main != 0);
-          id_stage(I2, false);
-        }
-      } else {
-        for (int s = 0; s < n_res; ++s) id_stage(I, true);
-      }
-    }
-    vm_wait<0>();                                    // no tap DMA may still be heading for this workgroup's LDS when it is released
-    stage_barrier();                                 // pairs with the consumers' last stage
-    return;
-  }
-
-  // ================================= CONSUMER =========================================================
-#ifdef TS_CONS_HALF_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
-  char* const priv = cons0 + (size_t)wave * ER * EP;
-  const __amdgpu_buffer_rsrc_t rwm = rsrc(a.pw_w);
-  const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? a.res_w : a.pw_w);
-  const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
-  const int n_cot = (a.c_out + 31) >> 5;
-  const int h = lane >> 5;
-  const int gq = (lane >> 4) & 1;
-  const int q4 = (lane >> 2) & 3;
-  const int p4 = lane & 3;
-  int abase[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abase[mt] = taddr(8 * h + q4, wm * FW + 32 * mt + 16 * gq + 4 * p4);
-  const int rsub = lane >> 4, csub = lane & 15;
-  const unsigned floor2 = a.relu ? 0u : 0x80008000u;
-  const int lane_w = lane * 16;
-
-  constexpr int RING = TS_SPLIT_RING;             // weight-fragment ring depth in k-steps (4 = a whole stage ahead)
-  s16x8 ring[RING][NT];
-  TilePos wp;
-  wp.init(tile0, tile_step, a.n_tt, a.n_z);
-  int w_tile = tile0, w_s = 0;
-  __amdgpu_buffer_rsrc_t rwc = rwm, rwn = rwm;
-  int wc_soff[NT], wn_soff[NT];
-  auto w_seek = [&](bool res) {
-    rwn = res ? rwr : rwm;
-    const int kt = res ? a.kt_res : a.kt_main;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int cot = (wp.z * WN + wn) * NT + nt;
-      wn_soff[nt] = (cot < n_cot ? cot : n_cot - 1) * kt * 1024;
-    }
-  };
-  auto w_advance = [&]() {
-    rwc = rwn;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wc_soff[nt] = wn_soff[nt];
-    ++w_s;
-    if (w_s == n_stage) {
-      w_s = 0;
-      if (w_tile + tile_step < tile_end) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
-      w_seek(n_main == 0);
-    } else if (w_s == n_main) {
-      w_seek(true);
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wn_soff[nt] += 4096;
-    }
-  };
-  auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      slot[nt] = __builtin_bit_cast(s16x8, next ? ld16(rwn, lane_w + ks * 1024, wn_soff[nt]) : ld16(rwc, lane_w + ks * 1024, wc_soff[nt]));
-  };
-  f32x16 acc[MT][NT];
-  float bnext[NT];
-  auto bias_fetch = [&](const TilePos& p) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = ((p.z * WN + wn) * NT + nt) * 32 + (lane & 31);
-      bnext[nt] = a.bias[col < a.c_out ? col : 0];
-    }
-  };
-  s16x8 af[MT], afB[MT];
-  auto read_a = [&](const char* src, int ks, s16x8 (&f)[MT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB + 4 * ROWB));
-      f[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-  };
-  auto mfma_ks = [&](int ks, const s16x8 (&f)[MT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
-    load_w(ring[ks % RING], ks + RING >= 4, (ks + RING) & 3);
-  };
-
-  TilePos pos;
-  pos.init(tile0, tile_step, a.n_tt, a.n_z);
-  w_seek(n_main == 0);
-  w_advance();
-#pragma unroll
-  for (int r = 0; r < RING; ++r) load_w(ring[r], false, r);
-  bias_fetch(pos);
-  stage_barrier();                                   // stage 0 is in dwt[0]
-  for (int tile = tile0; tile < tile_end; tile += tile_step) {
-    const int b = pos.b, t0 = pos.tt * TT;
-    const int cot0 = (pos.z * WN + wn) * NT;
-    const int len_b = a.zero_tail ? a.len_in[b] : 0;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
-    for (int s = 0; s < n_stage; ++s, ++gs) {
-      const char* const src = dwt + (gs & 1) * TILEB;
-      PSTAMP(8 * gs);
-#ifdef TS_CONS_DELAY
-      __builtin_amdgcn_s_sleep(TS_CONS_DELAY);          // diagnostic: shift the consumers' burst behind the producers' memory phase
-#endif
-#ifdef TS_EXP
-      if (!(a.exp & 4)) {
-#endif
-      read_a(src, 0, af);
-      read_a(src, 1, afB);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(0, af);
-      read_a(src, 2, af);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(1, afB);
-      read_a(src, 3, afB);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(2, af);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ks(3, afB);
-#ifdef TS_EXP
-      }
-#endif
-      w_advance();
-      PSTAMP(8 * gs + 1);
-      stage_barrier();
-      PSTAMP(8 * gs + 2);
-    }
-    // ---- epilogue (the producers are already on the next tile)
-    pos.advance_if(tile + tile_step < tile_end, a.n_tt, a.n_z);
-    bias_fetch(pos);
-    unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
-    int len_out = 0x7fffffff;
-    if (a.zero_tail) len_out = conv_len(len_b, a.kernel, 1, a.padding, a.dilation);
-    const int tw = t0 + wm * FW;
-    const bool partial = tw + FW > len_out;
-    u32x4 keep = u32x4{~0u, ~0u, ~0u, ~0u};
-    if (partial) keep = keep_first(keep, len_out - (tw + csub * 8));
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#ifdef TS_EXP
-    if (!(a.exp & 8))
-#endif
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int cob = (cot0 + nt) * 32;
-      const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
-      u32x2 pk[MT * 4];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
-              pack_bf16_settled(acc[mt][nt][4 * rg + 0], acc[mt][nt][4 * rg + 1])), f2));
-          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
-              pack_bf16_settled(acc[mt][nt][4 * rg + 2], acc[mt][nt][4 * rg + 3])), f2));
-          pk[mt * 4 + rg] = u32x2{lo, hi};
-        }
-      // the LDS tile holds ER output-channel rows at a time (all 32, or 16 when the 192-frame dwt buffers leave less room)
-#pragma unroll
-      for (int half = 0; half < 32 / ER; ++half) {
-        if (((lane & 31) / ER) == half) {
-          char* const row = priv + (size_t)(lane & (ER - 1)) * EP + 8 * h;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) *reinterpret_cast<u32x2*>(row + (32 * mt + 8 * rg) * 2) = pk[mt * 4 + rg];
-        }
-        if (csub < FW / 8) {
-          unsigned short* const yrow = yb + (size_t)(b * a.c_out + cob + half * ER + rsub) * a.pitch_out + tw + csub * 8;
-          const char* const prow = priv + (size_t)rsub * EP + csub * 16;
-          u32x4 v[ER / 4];
-#pragma unroll
-          for (int i = 0; i < ER / 4; ++i) {
-            const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * i * EP);
-            v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
-          }
-#pragma unroll
-          for (int i = 0; i < ER / 4; ++i) {
-            if (partial) v[i] &= keep;
-#ifdef TS_EXP
-            if (!(a.exp & 1))
-#endif
-            if (cob + half * ER + 4 * i + rsub < a.c_out) *reinterpret_cast<u32x4*>(yrow + (size_t)(4 * i) * a.pitch_out) = v[i];
-          }
-        }
-      }
-    }
-  }
-}
-
-template <int NPASS, int XJ, int MT, int WM, int DIL = 1>
-static int launch_split(TcsArgs& a, hipStream_t stream) {
-  constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 64 * (8 / WM);
-  constexpr int ROWB = TT <= 128 ? 256 : 512;
-  constexpr int NK_ = NPASS * NKP, CST = (16 * NK_ + 16) % 32 == 16 ? 16 * NK_ + 16 : 16 * NK_ + 32, TAPB = (16 * CST + 1023) / 1024 * 1024;
-  a.n_tt = (a.t_out + TT - 1) / TT;
-  a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
-  a.n_tiles = a.batch * a.n_tt * a.n_z;
-  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) + (size_t)4 * (16 * (64 * XJ + 4) * 2 + 2 * TAPB);
-  if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = tcs_split_kernel<NPASS, XJ, MT, WM, DIL>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  const int n_cu = cu_count();
-  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-  static const bool no_xcd = getenv("TS_NO_XCD") != nullptr;
-  a.xcd = (grid % 8 == 0 && !no_xcd) ? 1 : 0;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, a);
-  return hip_status(hipGetLastError());
 }
 
 template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS = false, bool TZ = false, int XJ = 0, int NPASS = 0>
@@ -1213,6 +626,26 @@ static int launch(TcsArgs& a, hipStream_t stream) {
 
 extern "C" int ts_time_pitch(int T) { return ts::round_up((T < 1 ? 1 : T) + 384, 128); }
 
+// one layer through the split kernel (csrc/tcs_split.hip): a chain of one, no counters
+static int split_single(const ts::TcsArgs& w, int npass, int xe, int wm, int dil, hipStream_t stream) {
+  using namespace ts;
+  // 32-bit byte offsets inside the split kernel's buffer descriptors
+  const int64_t cmax = w.c_in > w.c_out ? w.c_in : w.c_out;
+  if ((int64_t)w.batch * cmax * (w.pitch_in > w.pitch_out ? w.pitch_in : w.pitch_out) * 2 + TS_GUARD_BYTES >= (1ll << 31)) return TS_EUNSUPPORTED;
+  if (w.c_res > 0 && (int64_t)w.batch * w.c_res * w.pitch_res * 2 >= (1ll << 31)) return TS_EUNSUPPORTED;
+  ChainArgs a{};
+  ChainLayer& L = a.layer[0];
+  L.x = w.x; L.xres = w.xres; L.y = static_cast<unsigned short*>(w.y);
+  L.taps_raw = w.taps_raw; L.pw_w = w.pw_w; L.res_w = w.res_w; L.bias = w.bias;
+  L.c_in = w.c_in; L.c_res = w.c_res; L.pitch_res = w.c_res > 0 ? w.pitch_res : w.pitch_in; L.relu = w.relu;
+  L.kt_main = w.kt_main; L.kt_res = w.kt_res; L.wait_in = 0;
+  a.len = w.len_in; a.flags = nullptr; a.n_layers = 1;
+  a.batch = w.batch; a.c_out = w.c_out; a.pitch_in = w.pitch_in; a.pitch_out = w.pitch_out; a.t_out = w.t_out;
+  a.kernel = w.kernel; a.padding = w.padding; a.dilation = w.dilation;
+  a.woff = w.woff; a.padl8 = w.padl8; a.zero_tail = w.zero_tail;
+  return launch_split_chain(a, npass, xe, wm, dil, stream);
+}
+
 extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const int32_t* len_in, const void* x_res,
                                    const int32_t* len_res, void* y, void* stream_) {
   using namespace ts;
@@ -1229,12 +662,6 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
 
   TcsArgs a{};
-#ifdef TS_STAMP
-  { const char* e = getenv("TS_DBG_PTR"); a.dbg = e ? (long long*)strtoull(e, nullptr, 10) : nullptr; }
-#endif
-#ifdef TS_EXP
-  { const char* e = getenv("TS_EXP"); a.exp = e ? atoi(e) : 0; }
-#endif
   a.x = static_cast<const unsigned short*>(x);
   a.xres = static_cast<const unsigned short*>(x_res);
   a.y = y;
@@ -1277,7 +704,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       const int n_ttp = (d->t_out + 95) / 96;
       const bool fits = a.npass == 8 && 24 + 4 * (5 + d->dw_ksteps) <= 160 && (n_ttp - 1) * 96 - w.padl8 + 320 <= d->pitch_in &&
                         d->pitch_in - d->t_in >= w.padl8 && d->pitch_out >= n_ttp * 96;
-      return (fits && d->dw_taps_raw) ? launch_split<8, 5, 3, 1, 2>(w, stream) : TS_EUNSUPPORTED;
+      return (fits && d->dw_taps_raw) ? split_single(w, 8, 320, 1, 2, stream) : TS_EUNSUPPORTED;
     }
     a.taps_lds = d->dw_ksteps <= NKMAX;
     const int padl4 = round_up(d->padding, 4);
@@ -1290,41 +717,17 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     a.xpitch = a.xe + 4;                              // row pitch == 8 (mod 16) bytes: conflict-free window reads
     const int xj = a.xe / 64;
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
-    if (tz && d->stride == 1 && d->dilation == 1 && d->dw_taps_t16 && d->dw_t16_chunks > 0) {
-      // merged kernel (csrc/tcs_v3.hip): 192-frame x 256-channel tiles, depthwise on v_mfma_f32_16x16x32_bf16
-      // Opt-in (TS_TCS_V3=1): parity-green but NOT faster on MI355X -- its tap image and whole-row loads put 2.75x the bytes of the
-      // split kernel's depthwise inputs through the CU's vector-memory path
-      const char* const v3_env = getenv("TS_TCS_V3");
-      const bool no_v3 = !(v3_env && v3_env[0] == '1');
-      TcsArgs w = a;
-      w.taps_t16 = static_cast<const unsigned char*>(d->dw_taps_t16);
-      w.t16_nc = d->dw_t16_chunks;
-      w.t16_o = -8 * ((d->padding + 7) / 8);
-      const int n_ttp = (d->t_out + 191) / 192;
-      const bool fits = d->padding + 16 - w.t16_o <= 32 * w.t16_nc && d->kernel == 2 * d->padding + 1 &&
-                        (n_ttp - 1) * 192 + w.t16_o + 272 <= d->pitch_in && d->pitch_in - d->t_in >= -w.t16_o &&
-                        d->pitch_out >= n_ttp * 192 && (d->c_res == 0 || d->pitch_res >= n_ttp * 192);
-      if (fits && !no_v3) {
-        const int st = launch_v3(w, stream);
-        if (st != TS_EUNSUPPORTED) return st;
-      }
-    }
-    if (tz && d->stride == 1 && a.npass <= 7) {
+    if (tz && d->stride == 1 && d->dilation == 1 && a.npass <= 7 && d->dw_taps_raw) {
       // split kernel: 96-frame granules, its own window geometry
-      TcsArgs w = a;
-      const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;
+      const int WM = split_tile_wm(d->c_out, d->batch, d->t_out);
       const int TTp = 96 * WM;
       const int n_ttp = (d->t_out + TTp - 1) / TTp;
-      w.xuse = w.woff + TTp + 4 * d->dw_ksteps;
-      w.xe = round_up(w.xuse, 64);
-      w.xpitch = w.xe + 4;
-      const bool fits = (n_ttp - 1) * TTp - w.padl8 + w.xe <= d->pitch_in && d->pitch_out >= n_ttp * TTp &&
+      const int xe = round_up(a.woff + TTp + 4 * d->dw_ksteps, 64);
+      const bool fits = (n_ttp - 1) * TTp - a.padl8 + xe <= d->pitch_in && d->pitch_out >= n_ttp * TTp &&
                         (d->c_res == 0 || d->pitch_res >= (n_ttp - 1) * TTp + round_up(TTp, 64));
-      if (fits && d->dw_taps_raw) {
-#define TS_PIPE(NP_, XJ_, WM_) if (w.npass == NP_ && w.xe == 64 * XJ_ && WM == WM_) return launch_split<NP_, XJ_, 3, WM_>(w, stream);
-        TS_PIPE(3, 4, 2) TS_PIPE(4, 4, 2) TS_PIPE(5, 3, 1) TS_PIPE(6, 3, 1) TS_PIPE(7, 3, 1)      /* QuartzNet: K 33..75 */
-        TS_PIPE(2, 2, 1) TS_PIPE(3, 3, 1) TS_PIPE(4, 3, 1) TS_PIPE(2, 4, 2)                         /* Citrinet: K 11..41 */
-#undef TS_PIPE
+      if (fits) {
+        const int st = split_single(a, a.npass, xe, WM, 1, stream);
+        if (st != TS_EUNSUPPORTED) return st;
       }
     }
     if (tz) {
@@ -1365,8 +768,10 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       const int n_ttp = (d->t_out + TTp - 1) / TTp;
       w.c_res = d->c_in; w.c_in = 0; w.xres = a.x; w.res_w = a.pw_w; w.kt_res = a.kt_main; w.pitch_res = d->pitch_in;
       w.len_res = a.len_in; w.woff = 0; w.padl8 = 0;
-      if (d->pitch_in >= (n_ttp - 1) * TTp + round_up(TTp, 64) && d->pitch_out >= n_ttp * TTp)
-        return WM == 2 ? launch_split<2, 4, 3, 2>(w, stream) : launch_split<2, 2, 3, 1>(w, stream);
+      if (d->pitch_in >= (n_ttp - 1) * TTp + round_up(TTp, 64) && d->pitch_out >= n_ttp * TTp) {
+        const int st = WM == 2 ? split_single(w, 2, 256, 2, 1, stream) : split_single(w, 2, 128, 1, 1, stream);
+        if (st != TS_EUNSUPPORTED) return st;
+      }
     }
     if (tz && d->pitch_in >= n_tt * TT)
       return wide ? launch<64, 4, 1, false, false, false, true, 0>(a, stream) : launch<128, 2, 1, false, false, false, true, 0>(a, stream);

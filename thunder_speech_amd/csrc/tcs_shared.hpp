@@ -1,4 +1,5 @@
-// Shared between the fused TCS kernels (csrc/tcs_kernel.hip: first design + split kernel; csrc/tcs_v3.hip: merged kernel).
+// Shared between the fused TCS kernels (csrc/tcs_kernel.hip: first design / generic kernel and the C-ABI dispatch; csrc/tcs_split.hip:
+// split kernel, single layers and chains).
 #pragma once
 #include "ts_common.hpp"
 
@@ -7,6 +8,7 @@
 namespace ts {
 
 constexpr int KC = 64;         // input channels per stage
+constexpr int NKP = 3;         // depthwise k-steps (of 4 samples) per pass
 
 struct TcsArgs {
   const unsigned short* x;     // [B][c_in][pitch_in]
@@ -16,8 +18,6 @@ struct TcsArgs {
   const int* len_res;
   const unsigned short* taps;  // [c_in_pad][4][4*nk]
   const unsigned short* taps_raw;  // split kernel: raw tap image, see plan.pack_dw_taps_raw
-  const unsigned char* taps_t16;   // merged kernel: sliding-window tap image, see plan.pack_dw_taps_t16
-  int t16_nc, t16_o;               // merged kernel: 32-frame chunks per output segment, first input frame of chunk 0 relative to the segment
   const unsigned short* pw_w;  // fragments
   const unsigned short* res_w;
   const float* bias;
@@ -38,13 +38,6 @@ struct TcsArgs {
   int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
   int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
   int xcd;                     // split kernel: 1 = XCD-contiguous tile order (grid is a multiple of 8)
-#ifdef TS_STAMP
-  long long* dbg;              // diagnostic build only: s_memtime stamps of one workgroup
-#endif
-#ifdef TS_EXP
-  int exp;                     // diagnostic build only (tools/variants.py): bit 0 no epilogue stores, 1 no depthwise FIR, 4 no producer loads,
-                               // 2 no pointwise k-loop, 3 no epilogue at all -- wrong results, timing experiments only
-#endif
 };
 
 __device__ __forceinline__ int conv_len(int len, int k, int s, int p, int d) {
@@ -111,8 +104,37 @@ struct TilePos {
 };
 
 
-// merged kernel (csrc/tcs_v3.hip): depthwise as Toeplitz x time segments on v_mfma_f32_16x16x32_bf16; TS_EUNSUPPORTED when the
-// geometry does not fit (the caller then takes the split kernel)
-int launch_v3(TcsArgs& a, hipStream_t stream);
+// ---- split kernel (csrc/tcs_split.hip) ------------------------------------------------------------------------------------
+// One launch runs a CHAIN of layers (ts_tcs_chain_fwd; a single layer is a chain of one).  What may differ between the layers of a
+// chain sits in ChainLayer; the geometry (tile grid, depthwise window, pitches, output channels) is common.
+struct ChainLayer {
+  const unsigned short* x;         // [B][c_in][pitch]; layer l >= 1: the previous layer's y
+  const unsigned short* xres;      // [B][c_res][pitch_res] residual input (written before the launch), or the input of a pointwise-only layer
+  unsigned short* y;               // [B][c_out][pitch]
+  const unsigned short* taps_raw;  // raw tap image (plan.pack_dw_taps_raw)
+  const unsigned short* pw_w;      // B fragments
+  const unsigned short* res_w;
+  const float* bias;
+  int c_in, c_res, pitch_res, relu;
+  int kt_main, kt_res;             // k-steps (16 channels) of the packed weights
+  int wait_in;                     // 1: x is produced by the previous layer of this launch -> its tiles are waited for
+  int pad_;
+};
+struct ChainArgs {
+  ChainLayer layer[TS_TCS_CHAIN_MAX];
+  const int* len;                  // int32 [B] valid frames (the same for every tensor of the chain)
+  unsigned* flags;                 // [n_layers][batch * n_tt] arrival counters + one status word; zeroed before the launch
+  int n_layers;
+  int batch, c_out, pitch_in, pitch_out, t_out;
+  int kernel, padding, dilation;
+  int woff, padl8;
+  int n_tt, n_z, n_tiles;
+  int zero_tail, xcd;
+};
+// TS_EUNSUPPORTED when no instantiation fits (npass = depthwise passes of 3 k-steps, xe = staged frames per row, a multiple of 64;
+// wm = 1: 96-frame x 512-channel tiles, 2: 192 x 256; dil = 1, or 2 for the phase-split form of a dilation-2 layer)
+int launch_split_chain(ChainArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream);
+// time-tile choice of the split kernel for a layer: 1 = 96 frames, 2 = 192 frames (c_out <= 256 only)
+int split_tile_wm(int c_out, int batch, int t_out);
 
 }  // namespace ts

@@ -84,34 +84,6 @@ def pack_dw_taps_raw(w: torch.Tensor, padding: int) -> torch.Tensor:
     return out.to(torch.bfloat16).reshape(cp // KC, 4, tapb // 2).contiguous()
 
 
-def t16_geometry(kernel: int, padding: int) -> Tuple[int, int]:
-    """(o, NC) of the merged kernel's depthwise (csrc/tcs_v3.hip): an output segment of 16 frames starting at frame t reads the
-    input frames [t + o, t + o + 32 NC); o is the first frame of chunk 0 (a multiple of 8: 16-byte aligned loads)."""
-    o = -8 * ((padding + 7) // 8)
-    nc = (padding + 16 - o + 31) // 32
-    return o, nc
-
-
-def pack_dw_taps_t16(w: torch.Tensor, padding: int) -> Tuple[Optional[torch.Tensor], int]:
-    """w: [C, 1, K] depthwise taps of a stride-1, dilation-1 "same" conv (K = 2 padding + 1) -> (image, NC): the sliding-window tap
-    image of the merged kernel, uint8 [C_pad64/64][8][8][(32 NC + 16) * 8] (stage, wave, channel of the wave, bytes), or (None, 0)
-    when the kernel is too long (NC > 3).  Per channel, window p (8 bytes) holds wp[p .. p + 3] as bf16, wp[i] = w[i - 15 + o +
-    padding] (0 outside the taps): the Toeplitz fragment A_c[m][8 kg + j] = w[o + padding + 32 c + 8 kg + j - m] of
-    v_mfma_f32_16x16x32_bf16 is then the windows 8 kg - m + 15 + 32 c and + 4 -- two aligned 8-byte LDS reads per lane."""
-    c, _, k = w.shape
-    o, nc = t16_geometry(k, padding)
-    if nc > 3 or k != 2 * padding + 1:
-        return None, 0
-    npos = 32 * nc + 16
-    cp = round_up(c, KC)
-    wp = torch.zeros(cp, npos + 3, dtype=torch.float32, device=w.device)
-    lo = 15 - o - padding                      # wp index of tap 0
-    wp[:c, lo: lo + k] = w[:, 0, :]
-    img = torch.stack([wp[:, j: j + npos] for j in range(4)], dim=2)          # [C, p, 4]
-    img = img.to(torch.bfloat16).contiguous().view(torch.uint8)               # [C, p, 8]
-    return img.reshape(cp // KC, 8, 8, npos * 8).contiguous(), nc
-
-
 def raw_tap_channel_stride(nk: int) -> int:
     """Bytes per channel of the raw tap image (mirror of CST in csrc/tcs_kernel.hip)."""
     return 16 * nk + 16 if (16 * nk + 16) % 32 == 16 else 16 * nk + 32
@@ -173,8 +145,6 @@ class TcsLayer:
     nk_phase: int = 0
     taps_raw: Optional[torch.Tensor] = None        # stride 1: raw tap image of the split kernel (pack_dw_taps_raw)
     taps_phase_raw: Optional[torch.Tensor] = None
-    taps_t16: Optional[torch.Tensor] = None        # stride 1, dilation 1, K <= 81: sliding-window tap image of the merged kernel
-    t16_chunks: int = 0
     # Convolutions without a fused kernel of their own (dense K > 1, depthwise stride > 2): `pre` = (K, stride, dilation, padding,
     # source channels, masked) describes an im2col pass (ts_im2col_time) in front of this -- then pointwise-only -- layer, whose c_in is
     # K * source channels.  masked: the reference re-masks between a depthwise and its pointwise conv, so the pointwise input counts as
@@ -186,6 +156,33 @@ class TcsLayer:
             k, s, d, p = self.pre[:4]
             return conv_out_size(t_in, k, s, p, d)
         return conv_out_size(t_in, self.kernel, self.stride, self.padding, self.dilation)
+
+    def desc(self, b: int, t_in: int, pitch_in: int, pitch_out: int, in_tail_zero: bool, zero_tail: bool,
+             pitch_res: int = 0, t_res: int = 0) -> "_lib.TcsDesc":
+        """struct ts_tcs_desc of this layer for a [b, c_in, pitch_in] input with t_in frames."""
+        d = _lib.TcsDesc()
+        d.batch, d.c_in, d.c_out, d.t_in, d.t_out = b, self.c_in, self.c_out, t_in, self.out_size(t_in) if self.pre is None else t_in
+        d.pitch_in, d.pitch_out = pitch_in, pitch_out
+        d.kernel, d.stride, d.dilation, d.padding = self.kernel, self.stride, self.dilation, self.padding
+        d.depthwise, d.relu, d.out_fp32 = int(self.depthwise), int(self.relu), int(self.out_fp32)
+        d.c_res = self.c_res
+        d.res_stride = self.res_stride
+        if self.c_res:
+            d.pitch_res, d.t_res = pitch_res, t_res
+            d.res_w = self.res_w.data_ptr()
+        d.dw_ksteps = self.nk
+        d.flags = (_lib.TCS_IN_TAILZERO if in_tail_zero else 0) | (_lib.TCS_OUT_ZERO_TAIL if zero_tail else 0)
+        d.dw_taps = self.taps.data_ptr() if self.taps is not None else None
+        d.dw_taps_raw = self.taps_raw.data_ptr() if self.taps_raw is not None else None
+        d.pw_w = self.pw.data_ptr()
+        d.bias = self.bias.data_ptr()
+        return d
+
+    def chainable(self) -> bool:
+        """Static part of what ts_tcs_chain_fwd asks of a layer (the library checks the geometry against the tensors)."""
+        return (self.pre is None and self.depthwise and self.stride == 1 and self.dilation == 1 and self.taps_raw is not None
+                and not self.out_fp32 and self.kernel == 2 * self.padding + 1 and self.c_in % KC == 0 and self.c_res % KC == 0
+                and self.res_stride == 1)
 
     def run(self, x: torch.Tensor, t_in: int, len_in: torch.Tensor, x_res: Optional[torch.Tensor] = None,
             t_res: int = 0, len_res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -213,24 +210,9 @@ class TcsLayer:
         if out is None:
             out = torch.empty(b, self.c_out, pitch_out, device=x.device,
                               dtype=torch.float32 if self.out_fp32 else torch.bfloat16)
-        d = _lib.TcsDesc()
-        d.batch, d.c_in, d.c_out, d.t_in, d.t_out = b, self.c_in, self.c_out, t_in, t_out
-        d.pitch_in, d.pitch_out = x.shape[2], out.shape[2]
-        d.kernel, d.stride, d.dilation, d.padding = self.kernel, self.stride, self.dilation, self.padding
-        d.depthwise, d.relu, d.out_fp32 = int(self.depthwise), int(self.relu), int(self.out_fp32)
-        d.c_res = self.c_res
-        d.res_stride = self.res_stride
-        if self.c_res:
-            d.pitch_res, d.t_res = x_res.shape[2], t_res
-            d.res_w = self.res_w.data_ptr()
-        d.dw_ksteps = self.nk
-        d.flags = (_lib.TCS_IN_TAILZERO if in_tail_zero else 0) | (_lib.TCS_OUT_ZERO_TAIL if zero_tail else 0)
-        d.dw_taps = self.taps.data_ptr() if self.taps is not None else None
-        d.dw_taps_raw = self.taps_raw.data_ptr() if self.taps_raw is not None else None
-        d.dw_taps_t16 = self.taps_t16.data_ptr() if self.taps_t16 is not None else None
-        d.dw_t16_chunks = self.t16_chunks
-        d.pw_w = self.pw.data_ptr()
-        d.bias = self.bias.data_ptr()
+        d = self.desc(b, t_in, x.shape[2], out.shape[2], in_tail_zero, zero_tail,
+                      pitch_res=x_res.shape[2] if self.c_res else 0, t_res=t_res)
+        d.t_out = t_out
         stream = torch.cuda.current_stream(x.device).cuda_stream
         args = (x.data_ptr(), len_in.data_ptr(), x_res.data_ptr() if self.c_res else None,
                 len_res.data_ptr() if self.c_res else None, out.data_ptr(), stream)
@@ -249,6 +231,73 @@ class TcsLayer:
         st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
         _lib.check(st, "ts_tcs_subblock_fwd")
         return out, t_out
+
+
+CHAIN = True          # True: chain where it pays (below); "force": wherever the library can (tests); False: one launch per sub-block (A/B timing)
+_CHAIN_WS = {}
+_N_CU = {}
+
+
+def _split_tiles(c_out: int, b: int, t: int, n_cu: int) -> int:
+    """Tiles per layer of the split kernel (mirror of split_tile_wm / launch_split in csrc/tcs_split.hip)."""
+    if round_up(c_out, 32) > 256:
+        return b * ((t + 95) // 96) * ((round_up(c_out, 32) + 511) // 512)
+    n192, n96 = b * ((t + 191) // 192), b * ((t + 95) // 96)
+    return n96 if (n192 < 2 * n_cu and n96 >= 2 * n_cu) else n192
+
+
+def run_chain(layers: Sequence["TcsLayer"], x: torch.Tensor, t: int, len_i32: torch.Tensor, outs: Sequence[torch.Tensor],
+              x_res: Optional[torch.Tensor] = None) -> bool:
+    """Consecutive sub-blocks of one block as ONE persistent launch (ts_tcs_chain_fwd): layer l reads outs[l - 1] (x for l = 0) and writes
+    outs[l]; `x_res` is the residual input of the layers that have one (the block input).  All tensors are tail-zero arena buffers
+    [B, C, pitch] with `t` valid frames at most.  Returns False -- nothing launched -- when the library has no chain kernel for the
+    geometry or the chain would not pay: the caller then runs the layers one by one.
+    When it pays (measured): with at least two tiles per workgroup and layer a tile's inputs were published a whole tile
+    earlier, so the hand-over is free and the launch gaps go; with a single tile per workgroup every layer boundary waits for the
+    workgroup's own epilogue AND its neighbours', which costs more than the kernel boundary it replaces (QuartzNet's 256-channel
+    blocks at 64 x 751 frames on 192-frame tiles: 110 -> 123 us per block)."""
+    n = len(layers)
+    if not CHAIN or n < 2 or n > 16 or not all(l.chainable() for l in layers):
+        return False
+    dev = x.device
+    if CHAIN != "force":
+        n_cu = _N_CU.get(dev.index)
+        if n_cu is None:
+            n_cu = _N_CU[dev.index] = torch.cuda.get_device_properties(dev).multi_processor_count
+        if _split_tiles(layers[0].c_out, x.shape[0], t, n_cu) < 2 * n_cu:
+            return False
+    L = _lib.lib()
+    b = x.shape[0]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    descs = (_lib.TcsDesc * n)()
+    xs, rs, ys = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    src = x
+    for i, layer in enumerate(layers):
+        d = layer.desc(b, t, src.shape[2], outs[i].shape[2], True, True, pitch_res=x_res.shape[2] if layer.c_res else 0, t_res=t)
+        C.memmove(C.byref(descs, i * C.sizeof(_lib.TcsDesc)), C.byref(d), C.sizeof(_lib.TcsDesc))
+        xs[i], ys[i] = src.data_ptr(), outs[i].data_ptr()
+        rs[i] = x_res.data_ptr() if layer.c_res else None
+        src = outs[i]
+    need = L.ts_tcs_chain_workspace_bytes(b, t, n)
+    key = (id(layers[0]), b, t, n, str(dev), stream)
+    ws = _CHAIN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _CHAIN_WS[key] = torch.zeros(need, dtype=torch.uint8, device=dev)
+    st = L.ts_tcs_chain_fwd(descs, n, xs, rs, ys, len_i32.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+    if st == _lib.TS_EUNSUPPORTED:
+        return False
+    _lib.check(st, "ts_tcs_chain_fwd")
+    return True
+
+
+def chain_status(layers: Sequence["TcsLayer"]) -> int:
+    """Status words of the chain launches that start at layers[0] (0 = every wait inside them ended normally); synchronises.
+    For tests and tools only."""
+    bad = 0
+    for key, ws in _CHAIN_WS.items():
+        if key[0] == id(layers[0]):
+            bad |= int(ws[:4].view(torch.int32)[0].item())
+    return bad
 
 
 def make_im2col_layer(device, *, w2: torch.Tensor, src_channels: int, kernel: int, stride: int, dilation: int, padding: int,
@@ -298,11 +347,8 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
     if dw_w is not None:
         taps, nk = pack_dw_taps(cpu(dw_w), stride, dilation, padding)
     taps_phase, nk_phase, taps_raw, taps_phase_raw = None, 0, None, None
-    taps_t16, t16_chunks = None, 0
     if dw_w is not None and stride == 1 and dilation == 1:
         taps_raw = pack_dw_taps_raw(cpu(dw_w), padding).to(device)
-        taps_t16, t16_chunks = pack_dw_taps_t16(cpu(dw_w), padding)
-        taps_t16 = None if taps_t16 is None else taps_t16.to(device)
     if dw_w is not None and stride == 1 and dilation == 2 and padding % 2 == 0 and res_w is None:
         taps_phase, nk_phase = pack_dw_taps(cpu(dw_w), 1, 1, padding // 2)
         taps_phase = tap_fragments(taps_phase).to(device)
@@ -318,4 +364,4 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
                     depthwise=dw_w is not None, relu=relu, taps=None if taps is None else tap_fragments(taps).to(device), nk=nk,
                     pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
                     res_stride=res_stride, out_fp32=out_fp32, taps_phase=taps_phase, nk_phase=nk_phase, taps_raw=taps_raw,
-                    taps_phase_raw=taps_phase_raw, taps_t16=taps_t16, t16_chunks=t16_chunks)
+                    taps_phase_raw=taps_phase_raw)
