@@ -61,12 +61,14 @@ def encoder_layers(module):
     return layers
 
 
-CPU_THREAD_SWEEP = {8: 117, 16: 167, 32: 104, 64: 73}     # audio-s/s of this oracle on the pool's 256-core host (tools/cpu_threads.py)
+# RECORDED in round 3 with tools/cpu_threads.py on one box of the pool (256-core host), NOT measured by this run: audio-s/s of the oracle
+# by torch thread count -- why `cpu_baseline` uses 16 threads
+CPU_THREAD_SWEEP_RECORDED = {8: 117, 16: 167, 32: 104, 64: 73}
 
 
 def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16, wav=None, keep_logits=False):
     """Oracle (port of the reference path) on the host cores, bounded sample.  16 threads is where torch-CPU
-    peaks for this model on the GPU box's 256-core host (CPU_THREAD_SWEEP, measured with tools/cpu_threads.py);
+    peaks for this model on the GPU box's 256-core host (CPU_THREAD_SWEEP_RECORDED, measured once with tools/cpu_threads.py);
     more threads only add synchronisation overhead, so `cores` reports the threads actually used and `host_cores` what the box has.
     `wav` (CPU, [clips, samples]): time the oracle on these clips -- bench.py passes the first clips of the GPU batch, so that the
     logits of the first pass double as the full-size parity check of the headline configuration."""
@@ -99,7 +101,9 @@ def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16, wav=None, ke
         run()
     dt = (time.perf_counter() - t0) / iters
     res = {"value": clips * seconds / dt, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
-           "kind": "port", "thread_sweep_audio_s_per_s": {str(k): v for k, v in CPU_THREAD_SWEEP.items()},
+           "kind": "port",
+           "thread_sweep_recorded_round3": {"note": "recorded once with tools/cpu_threads.py on a box of this pool, not measured in this run",
+                                            "audio_s_per_s_by_threads": {str(k): v for k, v in CPU_THREAD_SWEEP_RECORDED.items()}},
            "sample": f"QuartzNet15x5 fp32 oracle, {clips}x{seconds} s clips (the first {clips} of the GPU batch), {iters} timed passes "
                      "after 1 warm-up"}
     if keep_logits:
@@ -269,6 +273,7 @@ def main():
     # exception handler cannot -- a collective that never returns (e.g. because ONE rank failed): past the deadline rank 0 prints the
     # line with the error in place of the result and every rank leaves.
     c4_ddp = None
+    failed_extra = False
     if not args.no_extra and "c4" in args.extra.split(","):
         del module
         module = None
@@ -277,10 +282,13 @@ def main():
         deadline = float(os.environ.get("TS_BENCH_EXTRA_DEADLINE_S", "240"))
 
         def give_up():
+            # watchdog: a collective never returned (e.g. ONE rank failed).  Every rank says so on stderr and leaves with a NON-ZERO code (the
+            # launcher must see the failure); rank 0 flushes the headline line first, with the error in place of the result.
+            print(f"bench.py rank {rank}: extra c4_ddp gave no result within {deadline:.0f} s -- giving up", file=sys.stderr, flush=True)
             if rank == 0:
                 result.setdefault("extra", {})["c4_ddp"] = {"error": f"no result within {deadline:.0f} s (a rank failed or a collective did not return)"}
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(deadline, give_up)
         dog.daemon = True
@@ -291,24 +299,30 @@ def main():
             if world > 1:
                 dist.barrier()                       # every rank got through: only now is it safe to stop the watchdogs
         except Exception as e:
+            import traceback
+            print(f"bench.py rank {rank}: extra c4_ddp failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
             c4_ddp = {"error": f"{type(e).__name__}: {e}"}
-            if world > 1:                            # the other ranks may be waiting in a collective this rank will never enter
-                if rank == 0:
+            if world > 1:                            # the other ranks may be waiting in a collective this rank will never enter:
+                if rank == 0:                        # leave now (never re-exec), non-zero, after rank 0 has flushed the headline line
                     result.setdefault("extra", {})["c4_ddp"] = c4_ddp
                     print(json.dumps(result), flush=True)
-                os._exit(0)
+                os._exit(3)
+            failed_extra = True
         dog.cancel()
         torch.cuda.empty_cache()
     if rank == 0:
         if not args.no_extra and world == 1:
             from tools import bench_extra
             result["extra"] = bench_extra.run(device, tuple(n for n in args.extra.split(",") if n), check=not args.no_cpu_baseline)
+            failed_extra = failed_extra or any(isinstance(v, dict) and "error" in v for v in result["extra"].values())
         if c4_ddp is not None:
             result.setdefault("extra", {})["c4_ddp"] = c4_ddp
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed_extra:
+        sys.exit(3)                                  # the line above is complete, but an extra failed: the launcher must see it
 
 
 if __name__ == "__main__":

@@ -66,6 +66,10 @@ typedef struct ts_tcs_desc {
                                    second shifted by one element (plan.pack_dw_taps_raw).  With TS_TCS_TAPS_PHASE: the phase-split form. */
   const void* pw_w;             /* bf16 [c_out_pad32/32][c_in_pad64/16][64][8]  MFMA B-fragments of W*bn_scale */
   const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
+  const void* pw_w16;           /* the same weights as B fragments of v_mfma_f32_16x16x32_bf16: bf16 [c_out_pad32/16][c_in_pad64/32][64][8], lane l,
+                                   element j = W[16 tile + (l & 15)][32 kstep + 8 (l >> 4) + j] (plan.pack_pw_frags16).  May be NULL: the split kernel
+                                   (and with it ts_tcs_chain_fwd) then declines and the 4 + 4-wave kernel runs on pw_w */
+  const void* res_w16;          /* bf16 [c_out_pad32/16][c_res_pad64/32][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */
 } ts_tcs_desc;
 

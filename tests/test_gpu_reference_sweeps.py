@@ -131,6 +131,31 @@ def test_melscale_matches_oracle_and_guards_zero(sample_rate, n_fft, nfilt):
     assert torch.isfinite(zero).all() and torch.allclose(zero, torch.full_like(zero, math.log(ofe.LOG_FLOOR)))
 
 
+def test_filterbank_features_without_log_scale_matches_oracle():
+    """MelScale(log_scale=False) (reference transform.py:213, :253): the plain filterbank product goes into the normaliser.  The fused front
+    end has the log inside its kernel, so this configuration runs the module chain stage by stage -- it must not raise, and it must
+    match the oracle's stages with the log left out."""
+    from thunder_speech_amd.quartznet.transform import FilterbankFeatures
+    fbk = FilterbankFeatures().cuda().eval()
+    fbk[2].layer[0].log_scale = False
+    g = torch.Generator().manual_seed(9)
+    wav = 0.1 * torch.randn(3, 8000, generator=g)
+    lengths = torch.tensor([8000, 6000, 1234])
+    for b, n in enumerate(lengths.tolist()):
+        wav[b, n:] = 0
+    feats, flen = fbk(wav.cuda(), lengths.cuda())
+    cfg = ofe.FrontendConfig()
+    power = ofe.power_spectrum(ofe.preemphasis(wav, cfg.preemph), cfg)
+    fb = torch.from_numpy(ofe.slaney_mel_filterbank(cfg.n_freqs, cfg.nfilt, cfg.sample_rate))
+    mel = torch.matmul(fb.unsqueeze(0), power)
+    want_len = ofe.feature_lengths(lengths, cfg.n_window_stride)
+    ref = masked_normalize(mel, lengths_to_mask(want_len, mel.shape[-1]).unsqueeze(1), div_guard=1e-5)
+    assert torch.equal(flen.cpu(), want_len)
+    got = feats.float().cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("lens", [[137, 100, 1, 64], [137.0, 99.5, 20.0, 137.0]])
 def test_feature_batch_normalizer_matches_oracle(lens):
     from thunder_speech_amd.quartznet.transform import FeatureBatchNormalizer

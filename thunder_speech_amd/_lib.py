@@ -47,7 +47,7 @@ class TcsDesc(C.Structure):
         ("depthwise", C.c_int32), ("relu", C.c_int32), ("out_fp32", C.c_int32),
         ("c_res", C.c_int32), ("pitch_res", C.c_int32), ("t_res", C.c_int32), ("res_stride", C.c_int32),
         ("dw_ksteps", C.c_int32), ("flags", C.c_int32),
-        ("dw_taps", C.c_void_p), ("dw_taps_raw", C.c_void_p), ("pw_w", C.c_void_p), ("res_w", C.c_void_p), ("bias", C.c_void_p),
+        ("dw_taps", C.c_void_p), ("dw_taps_raw", C.c_void_p), ("pw_w", C.c_void_p), ("res_w", C.c_void_p), ("pw_w16", C.c_void_p), ("res_w16", C.c_void_p), ("bias", C.c_void_p),
     ]
 
 

@@ -47,7 +47,7 @@ def convolution_stft(input_data: Tensor, n_fft: int = 1024, hop_length: int = 51
     win[left:left + win_length] = window.detach().float().cpu()
     ang = 2.0 * math.pi * torch.arange(n_fft, dtype=torch.float64) / n_fft
     tw = torch.stack([torch.cos(ang), torch.sin(ang)], dim=1).to(torch.float32).contiguous()
-    frames = n // hop_length + 1
+    frames = 1 + (n + 2 * (n_fft // 2) - n_fft) // hop_length          # torch.stft(center=True); == n // hop + 1 for even n_fft
     out = torch.empty(b, n_fft // 2 + 1, frames, 2, dtype=torch.float32, device=x.device)
     win_d, tw_d = win.to(x.device), tw.to(x.device)          # named: they must outlive the launch
     st = _lib.lib().ts_fe_stft(x.data_ptr(), win_d.data_ptr(), tw_d.data_ptr(), out.data_ptr(), b, n, n_fft, hop_length,

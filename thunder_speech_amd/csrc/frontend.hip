@@ -82,9 +82,6 @@ struct FeArgs {
   float preemph;
   float dither;               // > 0: DitherAudio (transform.py:109-118, training only): x + dither * N(0, 1)
   unsigned long long seed;    // Philox key of the dither noise
-#ifdef TS_EXP
-  int exp;                    // diagnostic builds only: bit 0 no mel loop, 1 no split / power, 2 no FFT stages
-#endif
 };
 
 // Dither noise of sample `k` of clip `b`: a pure function of (seed, b, k), so every frame group (and the reflect padding)
@@ -183,9 +180,6 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   const int i = tid & 15;
   float* const Y = fr + fl * FSZ;
   float* const Z = Y;                 // written only after every lane of the workgroup has read its Y row
-#ifdef TS_EXP
-  if (!(a.exp & 4))
-#endif
   {
     C2 v[16];
     const float* s = sig + fl * a.hop;
@@ -201,9 +195,6 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   }
   __syncthreads();
   if (pre && gn < n_groups) commit();                // every lane has read its samples of group g
-#ifdef TS_EXP
-  if (!(a.exp & 4))
-#endif
   {
     C2 v[16];
 #pragma unroll
@@ -216,9 +207,6 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   __syncthreads();
   // ---- real-FFT split + power spectrum, bins k = i + 16 j (and bin 256 on lane 0) -> P (aliases Y) ------
   float* const P = Y;
-#ifdef TS_EXP
-  if (!(a.exp & 2))
-#endif
   {
     float pw[17];
     const f32x2 w_odd = (i & 1) ? f32x2{0.99992470183914454f, -0.012271538285719925f} : f32x2{1.f, 0.f};   // W_512^1
@@ -251,9 +239,6 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
     const int first = melo[2 * m], off = melo[2 * m + 1];
     const int cnt = melo[2 * m + 3] - off;
     float acc = 0.f;
-#ifdef TS_EXP
-    if (!(a.exp & 1))
-#endif
     for (int j = 0; j < cnt; ++j) acc = fmaf(melw[off + j], P[first + j], acc);
     const float lm = logf(acc + LOG_FLOOR);
     fr[fl * FSZ + RED0 + m] = lm;
@@ -407,9 +392,6 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   a.preemph = d->preemph;
   a.dither = d->dither;
   a.seed = d->dither_seed;
-#ifdef TS_EXP
-  { const char* e = getenv("TS_EXP"); a.exp = e ? atoi(e) : 0; }
-#endif
   if (d->n_masks < 0 || (d->n_masks > 0 && !d->masks)) return TS_EINVAL;
   a.mel_nnz = d->mel_nnz;
   a.batch = d->batch;

@@ -131,7 +131,7 @@ extern "C" int ts_fe_power_spectrum(const float* x, const float* window, const f
                                     int32_t n_fft, int32_t hop, void* stream) {
   if (!x || !window || !twiddle || !out || batch <= 0 || n <= 0 || n_fft < 2 || n_fft > 8192 || hop <= 0) return TS_EINVAL;
   if (n_fft / 2 >= n) return TS_EINVAL;            // reflect padding needs n_fft / 2 < n (torch.stft raises as well)
-  const int frames = n / hop + 1;
+  const int frames = 1 + (n + 2 * (n_fft / 2) - n_fft) / hop;      // torch.stft(center=True): n / hop + 1 for even n_fft, (n - 1) / hop + 1 for odd
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::fe_power_kernel<false>, dim3(frames, batch), dim3(256), (size_t)n_fft * sizeof(float), (hipStream_t)stream, x, window, twiddle,
                      out, n, n_fft, hop, frames);
@@ -142,7 +142,7 @@ extern "C" int ts_fe_stft(const float* x, const float* window, const float* twid
                           int32_t hop, void* stream) {
   if (!x || !window || !twiddle || !out || batch <= 0 || n <= 0 || n_fft < 2 || n_fft > 8192 || hop <= 0) return TS_EINVAL;
   if (n_fft / 2 >= n) return TS_EINVAL;
-  const int frames = n / hop + 1;
+  const int frames = 1 + (n + 2 * (n_fft / 2) - n_fft) / hop;      // torch.stft(center=True): n / hop + 1 for even n_fft, (n - 1) / hop + 1 for odd
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::fe_power_kernel<true>, dim3(frames, batch), dim3(256), (size_t)n_fft * sizeof(float), (hipStream_t)stream, x, window, twiddle,
                      out, n, n_fft, hop, frames);

@@ -48,9 +48,6 @@ struct GemmArgs {
   int M, N, K, act;                              // act bit 0: GELU
   int n_mt, n_nt;
   int blk_c;                                      // column tiles per block of the tile walk (divides n_nt)
-#ifdef TS_EXP
-  int exp;                                       // diagnostic builds: bit 0 no DMA in the loop, 1 no fragment reads, 2 no barriers, 3 no epilogue
-#endif
 };
 
 template <int N>
@@ -136,23 +133,13 @@ __global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2)
   // the DMAs of a half-stage in two halves (A rows, B rows): one half is issued in the LOAD phase, the other between the MFMAs of the
   // following MFMA phase -- all four in the LOAD phase made it longer than the partner's MFMA phase (measured), all four among the MFMAs
   // made that phase the longer one
-#ifdef TS_EXP
-#define KOFF(s) (((a.exp & 16) ? ((s) & 3) : (s)) * GKH * 2)      /* bit 4: every half-stage re-reads the first four (L2-hot operands) */
-#else
 #define KOFF(s) ((s) * GKH * 2)
-#endif
   auto issue_a = [&](int s) {
-#ifdef TS_EXP
-    if ((a.exp & 1) && s >= PD) return;
-#endif
     char* const st = smem + (s & (RINGN - 1)) * SLOTB;
 #pragma unroll
     for (int q = 0; q < 2; ++q) lds_dma16(ra, st + (32 * wave + 16 * q) * GROWB, offa[q], KOFF(s));
   };
   auto issue_b = [&](int s, int q) {
-#ifdef TS_EXP
-    if ((a.exp & 1) && s >= GRING - 1) return;
-#endif
     char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
     lds_dma16(rb, st + GHALFB + (32 * wave + 16 * q) * GROWB, offb[q], KOFF(s));
   };
@@ -182,9 +169,6 @@ __global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2)
   s16x8 fa[8], fb[4];
   auto load_phase = [&](int s) {
     const char* const st = smem + (s & (GRING - 1)) * GSTAGEB;
-#ifdef TS_EXP
-    if (!((a.exp & 2) && s > 0))
-#endif
     {
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const s16x8*>(st + fa0 + i * 16 * GROWB);
@@ -214,9 +198,6 @@ __global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2)
     __builtin_amdgcn_s_setprio(0);
   };
   auto phase_barrier = [&]() {
-#ifdef TS_EXP
-    if (a.exp & 4) return;
-#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -305,9 +286,6 @@ __global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2)
   // columns at a time, as f32 [128 rows][32 columns] in its own 16 KiB of the (now idle) operand ring and reads it back row-wise:
   // 16 bytes per lane for the residual load and the f32 store, 8 bytes per lane for the bf16 store.
   const size_t yoff = (size_t)bz * a.sy;
-#ifdef TS_EXP
-  if ((a.exp & 8) && acc[0][0][0] != 12345.678f) return;
-#endif
   __builtin_amdgcn_s_barrier();                    // every wave is done with the operand ring (all DMAs were drained in the loop)
   asm volatile("" ::: "memory");
   const int erow = lane >> 3;
@@ -413,13 +391,15 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
       (res && (ld_res % 4 || (reinterpret_cast<uintptr_t>(res) & 15))) || sy % (y16 ? 8 : 4))
     return TS_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (sx % 8)) return TS_EUNSUPPORTED;
-  if (M * lda * 2 >= (1ll << 31) || (long long)N * ldw * 2 >= (1ll << 31)) return TS_EUNSUPPORTED;    // 32-bit buffer offsets
-  static int attr = 0;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
+  // 32-bit buffer offsets: the last row reads up to ((M - 1) lda + K) elements (overlapping conv rows have K > lda)
+  if (((M - 1) * lda + K) * 2 >= (1ll << 31) - 1 || ((long long)(N - 1) * ldw + K) * 2 >= (1ll << 31) - 1) return TS_EUNSUPPORTED;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
+  static bool attr[64] = {};        // the attribute belongs to the (function, device) pair
+  if (!attr[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS) != hipSuccess)
       return TS_EUNSUPPORTED;
-    attr = 1;
+    attr[dev] = true;
   }
   if (wf && (reinterpret_cast<uintptr_t>(wf) & 15)) return TS_EUNSUPPORTED;
   GemmArgs a;
@@ -429,24 +409,19 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
   a.M = (int)M; a.N = N; a.K = K; a.act = gelu ? 1 : 0;
   a.n_mt = (int)((M + GM - 1) / GM); a.n_nt = (N + GN - 1) / GN;
   a.blk_c = a.n_nt % 4 == 0 ? 4 : (a.n_nt % 3 == 0 ? 3 : (a.n_nt % 2 == 0 ? 2 : 1));
-#ifdef TS_EXP
-  { const char* e = getenv("TS_EXP"); a.exp = e ? atoi(e) : 0; }
-#endif
   (void)hipGetLastError();
   const dim3 grid((unsigned)(a.n_mt * a.n_nt), (unsigned)batch);
-  static const int half_mode = getenv("TS_GEMM_HALF") ? atoi(getenv("TS_GEMM_HALF")) : 1;      // 128-row tiles for packed weights (0: the 256-row tile, for the A/B)
-  if (wf && half_mode) {
+  if (wf) {                                        // packed weights: 128-row tiles, two workgroups per CU
     constexpr int LDS_H = 4 * 128 * 144;
-    static int attr_h = 0;
-    if (!attr_h) {
+    static bool attr_h[64] = {};
+    if (!attr_h[dev]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H) != hipSuccess)
         return TS_EUNSUPPORTED;
-      attr_h = 1;
+      attr_h[dev] = true;
     }
     a.n_mt = (int)((M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), dim3((unsigned)(a.n_mt * a.n_nt), (unsigned)batch), dim3(256), LDS_H, stream, a);
-  } else if (wf) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(512), GEMM_LDS, stream, a);
-  else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(512), GEMM_LDS, stream, a);
+  } else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(512), GEMM_LDS, stream, a);
   return hip_status(hipGetLastError());
 }
 

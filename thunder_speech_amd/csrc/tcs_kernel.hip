@@ -636,7 +636,8 @@ static int split_single(const ts::TcsArgs& w, int npass, int xe, int wm, int dil
   ChainArgs a{};
   ChainLayer& L = a.layer[0];
   L.x = w.x; L.xres = w.xres; L.y = static_cast<unsigned short*>(w.y);
-  L.taps_raw = w.taps_raw; L.pw_w = w.pw_w; L.res_w = w.res_w; L.bias = w.bias;
+  if (!w.pw_w16 || (w.c_res > 0 && !w.res_w16)) return TS_EUNSUPPORTED;
+  L.taps_raw = w.taps_raw; L.pw_w = w.pw_w16; L.res_w = w.res_w16; L.bias = w.bias;
   L.c_in = w.c_in; L.c_res = w.c_res; L.pitch_res = w.c_res > 0 ? w.pitch_res : w.pitch_in; L.relu = w.relu;
   L.kt_main = w.kt_main; L.kt_res = w.kt_res; L.wait_in = 0;
   a.len = w.len_in; a.flags = nullptr; a.n_layers = 1;
@@ -671,6 +672,8 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   a.taps_raw = static_cast<const unsigned short*>(d->dw_taps_raw);
   a.pw_w = static_cast<const unsigned short*>(d->pw_w);
   a.res_w = static_cast<const unsigned short*>(d->res_w);
+  a.pw_w16 = static_cast<const unsigned short*>(d->pw_w16);
+  a.res_w16 = static_cast<const unsigned short*>(d->res_w16);
   a.bias = d->bias;
   a.batch = d->batch;
   a.c_in = d->c_in; a.c_out = d->c_out; a.c_res = d->c_res;
@@ -719,7 +722,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
     if (tz && d->stride == 1 && d->dilation == 1 && a.npass <= 7 && d->dw_taps_raw) {
       // split kernel: 96-frame granules, its own window geometry
-      const int WM = split_tile_wm(d->c_out, d->batch, d->t_out);
+      const int WM = split_tile_wm(d->c_out, d->batch, d->t_out, false);
       const int TTp = 96 * WM;
       const int n_ttp = (d->t_out + TTp - 1) / TTp;
       const int xe = round_up(a.woff + TTp + 4 * d->dw_ksteps, 64);
@@ -766,7 +769,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;
       const int TTp = 96 * WM;
       const int n_ttp = (d->t_out + TTp - 1) / TTp;
-      w.c_res = d->c_in; w.c_in = 0; w.xres = a.x; w.res_w = a.pw_w; w.kt_res = a.kt_main; w.pitch_res = d->pitch_in;
+      w.c_res = d->c_in; w.c_in = 0; w.xres = a.x; w.res_w = a.pw_w; w.res_w16 = a.pw_w16; w.kt_res = a.kt_main; w.pitch_res = d->pitch_in;
       w.len_res = a.len_in; w.woff = 0; w.padl8 = 0;
       if (d->pitch_in >= (n_ttp - 1) * TTp + round_up(TTp, 64) && d->pitch_out >= n_ttp * TTp) {
         const int st = WM == 2 ? split_single(w, 2, 256, 2, 1, stream) : split_single(w, 2, 128, 1, 1, stream);

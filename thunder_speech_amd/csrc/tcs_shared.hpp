@@ -18,8 +18,10 @@ struct TcsArgs {
   const int* len_res;
   const unsigned short* taps;  // [c_in_pad][4][4*nk]
   const unsigned short* taps_raw;  // split kernel: raw tap image, see plan.pack_dw_taps_raw
-  const unsigned short* pw_w;  // fragments
+  const unsigned short* pw_w;  // fragments (32x32x16 form)
   const unsigned short* res_w;
+  const unsigned short* pw_w16;   // fragments of the 16x16x32 form (split kernel)
+  const unsigned short* res_w16;
   const float* bias;
   int batch, c_in, c_out, c_res;
   int pitch_in, pitch_out, pitch_res;
@@ -112,7 +114,7 @@ struct ChainLayer {
   const unsigned short* xres;      // [B][c_res][pitch_res] residual input (written before the launch), or the input of a pointwise-only layer
   unsigned short* y;               // [B][c_out][pitch]
   const unsigned short* taps_raw;  // raw tap image (plan.pack_dw_taps_raw)
-  const unsigned short* pw_w;      // B fragments
+  const unsigned short* pw_w;      // B fragments of v_mfma_f32_16x16x32_bf16: [c_out / 16][c_in / 32][64][8]
   const unsigned short* res_w;
   const float* bias;
   int c_in, c_res, pitch_res, relu;
@@ -135,6 +137,6 @@ struct ChainArgs {
 // wm = 1: 96-frame x 512-channel tiles, 2: 192 x 256; dil = 1, or 2 for the phase-split form of a dilation-2 layer)
 int launch_split_chain(ChainArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream);
 // time-tile choice of the split kernel for a layer: 1 = 96 frames, 2 = 192 frames (c_out <= 256 only)
-int split_tile_wm(int c_out, int batch, int t_out);
+int split_tile_wm(int c_out, int batch, int t_out, bool chain);
 
 }  // namespace ts

@@ -36,7 +36,6 @@ namespace ts {
 
 namespace {
 
-constexpr int SPLIT_RING = 2;          // weight-fragment ring depth in k-steps
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -79,7 +78,11 @@ struct TileWait {
 // NT: 32-channel output tiles per consumer wave -- 2: a workgroup covers 512 (WM = 1) or 256 (WM = 2) output channels; 1 (WM = 1 only): 96 frames x
 // 256 channels, for layers of at most 256 output channels whose 192-frame tiling would leave a compute unit a single tile per layer (nothing
 // to overlap its prologue and epilogue with).
-template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2>
+// CHAIN: false -- ONE layer, known at compile time (no counters, plain loads and stores: the instantiation every single-layer launch takes);
+// true -- a.n_layers layers, sc1 activations, published tiles.  Two instantiations because the chain's bookkeeping costs registers in a kernel
+// that has none to spare: with the layer count a runtime value the single-layer launches of QuartzNet15x5 ran 6 % slower (11 spilled VGPRs in
+// the producers' stage loop), measured on one box.
+template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2, bool CHAIN = false>
 __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
   constexpr int WN = 8 / WM;
   constexpr int FW = 32 * MT;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
   constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
   constexpr int ER = (WM == 2 || DIL == 2) ? 16 : 32;   // output-channel rows of a consumer's epilogue tile
   constexpr int PHW = 32 * XJ;                    // DIL == 2: frames of a staged half row
-  constexpr int AUX_SC1 = 16;                     // cache-policy bit sc1 of the buffer instructions: write-through stores, L1-bypassing loads
+  constexpr int AUX_SC1 = CHAIN ? 16 : 0;         //                     // cache-policy bit sc1 of the buffer instructions: write-through stores, L1-bypassing loads
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const dwt = smem;                                             // [2][KC][ROWB]
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
   const int nct = a.batch * a.n_tt;               // counters per layer
   unsigned* const status = a.flags;               // word 0; the counters start 16 bytes in
   unsigned* const counters = a.flags + 4;
+  const int N_LAYERS = CHAIN ? a.n_layers : 1;
   unsigned gs = 0;
   if (tid == 0) *arrive = 0;                      // ordered before its first use by the barrier that opens layer 0
 
@@ -165,7 +169,11 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     // longer than one stage).
     constexpr bool ROWS2 = WM == 1 && DIL == 1;
     u32x4 X[ROWS2 ? 2 : 1][XP];
-    u32x4 I[IDP], I2[IDP];                          // identity rows in flight: one stage ahead (two when n_res is even)
+    // identity rows in flight: one stage ahead; TWO (a second register set, alternating statically) in the single-layer instantiation when the
+    // residual has an even number of stages -- an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
+    // The chain instantiation has no registers for the second set (it cost 20 spilled VGPRs in the stage loop there).
+    constexpr bool ID2 = !CHAIN && WM == 1;
+    u32x4 I[IDP], I2[ID2 ? IDP : 1];
     s16x4 P[NP];
     u32x2 T[NK];
     f32x4 d[M];
@@ -192,8 +200,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     };
     auto dw_begin = [&]() {
 #pragma unroll
-      for (int m = 0; m < M; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
       for (int u = 0; u < M - 1 + NKP * WD; ++u) win_load(u);
 #pragma unroll
       for (int kk = 0; kk < NKP * WD; ++kk) tap_load(kk);
@@ -209,13 +215,17 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
 #pragma unroll
       for (int kk = 0; kk < NKP; ++kk)
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-          d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m], d[m], 0, 0, 0);
+        for (int m = 0; m < M; ++m)      // the very first k-step starts from 0 (an inline constant: no register is zeroed)
+          d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m],
+                                                        (p == 0 && kk == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[m], 0, 0, 0);
     };
     auto dw_store = [&](char* dst) {
+      // ONE v_cvt_pk_bf16_f32 per pair (the plain cast lowers to two conversions and a v_perm_b32: 36 instead of 12 instructions in
+      // this wave's serial chain); hipcc adds no wait states for inline asm, so the last pass's results settle first
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        const unsigned m0 = pack_bf16(d[m][0], d[m][1]), m1 = pack_bf16(d[m][2], d[m][3]);
+        const unsigned m0 = pack_bf16_settled(d[m][0], d[m][1]), m1 = pack_bf16_settled(d[m][2], d[m][3]);
         if constexpr (DIL == 2) {
           // lanes q and q ^ 2 hold the even and the odd frames of the same 8-frame group: the even lane stores frames
           // 0..3 (e0 o0 e1 o1), the odd lane frames 4..7 (e2 o2 e3 o3)
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     };
 
     unsigned ds = 0;                               // depthwise stages started: selects the tap image
-    for (int l = 0; l < a.n_layers; ++l) {
+    for (int l = 0; l < N_LAYERS; ++l) {
       const ChainLayer& L = a.layer[l];
       const int n_main = L.c_in / KC;
       const int n_res = L.c_res / KC;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
       const int chunk_i = KC * L.pitch_res * 2;
       const bool rows2 = ROWS2 && n_main > 0 && !(n_main & 1);
       // tiles of the previous layer this layer's row loads wait for
-      const unsigned* const wflag = L.wait_in ? counters + (size_t)(l - 1) * nct : nullptr;
+      const unsigned* const wflag = (CHAIN && L.wait_in) ? counters + (size_t)(l - 1) * nct : nullptr;
       const unsigned need = (unsigned)a.n_z;
       TileWait tw;
       unsigned tw_seen = need;
@@ -314,11 +324,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
         dw_issue(X[0]);
         tap_dma(ds & 1, 0);
       }
-      // Identity rows are fetched TWO stages ahead when the stage count is even (register sets alternate, statically):
-      // an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
-      const bool id2 = WM == 1 && n_res && !(n_res & 1);      // (the 192-frame tiles have no registers to spare for a second set)
+      const bool id2 = ID2 && n_res && !(n_res & 1);
       if (n_res) id_issue(I);
-      if (id2) id_issue(I2);
+      if constexpr (ID2) { if (id2) id_issue(I2); }
       vm_wait<0>();
       auto id_stage = [&](u32x4 (&R)[IDP], bool drain) {
         char* const dst = dwt + (gs & 1) * TILEB;
@@ -376,12 +384,16 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
             stage_barrier();
           }
         }
-        if (id2) {
-          // a tile that had depthwise stages drains once (tap DMAs and row loads are in the queue: counted waits cannot
-          // separate them); after that only identity loads are in flight and they retire in order
-          for (int s = 0; s < n_res; s += 2) {
-            id_stage(I, s == 0 && n_main != 0);
-            id_stage(I2, false);
+        if constexpr (ID2) {
+          if (id2) {
+            // a tile that had depthwise stages drains once (tap DMAs and row loads are in the queue: counted waits cannot separate them);
+            // after that only identity loads are in flight and they retire in order
+            for (int s = 0; s < n_res; s += 2) {
+              id_stage(I, s == 0 && n_main != 0);
+              id_stage(I2, false);
+            }
+          } else {
+            for (int s = 0; s < n_res; ++s) id_stage(I, true);
           }
         } else {
           for (int s = 0; s < n_res; ++s) id_stage(I, true);
@@ -394,35 +406,36 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
   }
 
   // ================================= CONSUMER =========================================================
+  // v_mfma_f32_16x16x32_bf16: D[t][co] += dw[t][ci] W[co][ci] on 16-frame x 16-channel accumulators, 32 input channels per k-step.  The same
+  // matrix-core time as the 32x32x16 form this kernel used through round 3, but the chip holds a visibly higher clock on it (guide: DVFS
+  // give-back item 7) and a producer's 8-cycle 4x4x4 products queue behind 16-cycle instead of 32-cycle instructions: the stage loop without
+  // global memory takes 1.49 instead of 1.79 us (tools/diag/probe_stage.hip, profiles/round4_probe_stage.txt).
+  constexpr int MT16 = 2 * MT, NT16 = 2 * NT;       // 16-frame / 16-channel accumulator tiles per wave
   char* const priv = cons0 + (size_t)wave * ER * EP;
   const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
-  const int n_cot = (a.c_out + 31) >> 5;
-  const int h = lane >> 5;
-  const int gq = (lane >> 4) & 1;
+  const int n_c16 = ((a.c_out + 31) >> 5) * 2;      // 16-channel tiles in the packed weights (c_out padded to 32)
+  const int kg = lane >> 4;
   const int q4 = (lane >> 2) & 3;
   const int p4 = lane & 3;
-  int abase[MT];
+  // transposed A-operand reads: lane group kg reads channels 8 kg + q (lo) and + 4 (hi) of the k-step, lane 4q + p supplies frames 4p .. 4p + 3
+  int abase[MT16];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abase[mt] = taddr(8 * h + q4, wm * FW + 32 * mt + 16 * gq + 4 * p4);
+  for (int mt = 0; mt < MT16; ++mt) abase[mt] = taddr(8 * kg + q4, wm * FW + 16 * mt + 4 * p4);
   const int rsub = lane >> 4, csub = lane & 15;
   const int lane_w = lane * 16;
   const int lane_y = (rsub * a.pitch_out + csub * 8) * 2;
 
-  constexpr int RING = SPLIT_RING * 2 / NT;        // k-steps of weight fragments in flight: 2 (NT = 2) or 4 (NT = 1), 16 VGPRs either way
-  s16x8 ring[RING][NT];
-  f32x16 acc[MT][NT];
-  float bnext[NT];
-  s16x8 af[MT], afB[MT];
-  auto read_a = [&](const char* src, int ks, s16x8 (&f)[MT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 16 * ROWB + 4 * ROWB));
-      f[mt] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
+  s16x8 ring[NT16];                                  // B fragments of ONE k-step; a slot is refilled for the next k-step right after its last use
+  f32x4 acc[MT16][NT16];
+  float bnext[NT16];
+  s16x8 af[MT16];
+  auto read_a1 = [&](const char* src, int ks, int mt) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 32 * ROWB));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 32 * ROWB + 4 * ROWB));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
 
-  for (int l = 0; l < a.n_layers; ++l) {
+  for (int l = 0; l < N_LAYERS; ++l) {
     const ChainLayer& L = a.layer[l];
     const int n_main = L.c_in / KC;
     const int n_res = L.c_res / KC;
@@ -431,93 +444,98 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? L.res_w : L.pw_w);
     const __amdgpu_buffer_rsrc_t ry = rsrc(L.y);
     const unsigned floor2 = L.relu ? 0u : 0x80008000u;
-    const bool publish = l + 1 < a.n_layers;           // a later layer of this launch reads y
+    const bool publish = CHAIN && l + 1 < N_LAYERS;           // a later layer of this launch reads y
     unsigned* const pflag = counters + (size_t)l * nct;
 
+    // weight stream: fragments [c_out / 16][c_in / 32][64 lanes][8], walked k-step by k-step over (tile, main stages, residual stages);
+    // the pointers below always name the k-step AFTER the one being multiplied
     TilePos wp;
     wp.init(tile0, tile_step, a.n_tt, a.n_z);
-    int w_tile = tile0, w_s = 0;
-    __amdgpu_buffer_rsrc_t rwc = rwm, rwn = rwm;
-    int wc_soff[NT], wn_soff[NT];
+    int w_tile = tile0, w_k = 0;
+    const int nk_main = 2 * n_main, nk_all = 2 * n_stage;
+    __amdgpu_buffer_rsrc_t rwn = rwm;
+    int wn_soff[NT16];
     auto w_seek = [&](bool res) {
       rwn = res ? rwr : rwm;
-      const int kt = res ? L.kt_res : L.kt_main;
+      const int kt = (res ? L.kt_res : L.kt_main) >> 1;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int cot = (wp.z * WN + wn) * NT + nt;
-        wn_soff[nt] = (cot < n_cot ? cot : n_cot - 1) * kt * 1024;
+      for (int nt = 0; nt < NT16; ++nt) {
+        const int c16 = (wp.z * WN + wn) * NT16 + nt;
+        wn_soff[nt] = (c16 < n_c16 ? c16 : n_c16 - 1) * kt * 1024;
       }
     };
-    auto w_advance = [&]() {
-      rwc = rwn;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wc_soff[nt] = wn_soff[nt];
-      ++w_s;
-      if (w_s == n_stage) {
-        w_s = 0;
+    auto w_next = [&]() {
+      ++w_k;
+      if (w_k == nk_all) {
+        w_k = 0;
         if (w_tile + tile_step < tile_end) { w_tile += tile_step; wp.advance(a.n_tt, a.n_z); }
-        w_seek(n_main == 0);
-      } else if (w_s == n_main) {
+        w_seek(nk_main == 0);
+      } else if (w_k == nk_main) {
         w_seek(true);
       } else {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wn_soff[nt] += 4096;
+        for (int nt = 0; nt < NT16; ++nt) wn_soff[nt] += 1024;
       }
     };
-    auto load_w = [&](s16x8 (&slot)[NT], bool next, int ks) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        slot[nt] = __builtin_bit_cast(s16x8, next ? ld16(rwn, lane_w + ks * 1024, wn_soff[nt]) : ld16(rwc, lane_w + ks * 1024, wc_soff[nt]));
-    };
+    auto load_w = [&](int nt) { ring[nt] = __builtin_bit_cast(s16x8, ld16(rwn, lane_w, wn_soff[nt])); };
     auto bias_fetch = [&](const TilePos& p) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int col = ((p.z * WN + wn) * NT + nt) * 32 + (lane & 31);
+      for (int nt = 0; nt < NT16; ++nt) {
+        const int col = ((p.z * WN + wn) * NT16 + nt) * 16 + (lane & 15);
         bnext[nt] = L.bias[col < a.c_out ? col : 0];
       }
     };
-    auto mfma_ks = [&](int ks, const s16x8 (&f)[MT]) {
+    // one k-step: NT16 x MT16 products; `more_a`: the A fragments of the stage's second k-step replace the first one's as they retire
+    auto kstep = [&](const char* src, bool more_a) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int nt = 0; nt < NT16; ++nt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[mt], ring[ks % RING][nt], acc[mt][nt], 0, 0, 0);
-      load_w(ring[ks % RING], ks + RING >= 4, (ks + RING) & 3);
+        for (int mt = 0; mt < MT16; ++mt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], ring[nt], acc[mt][nt], 0, 0, 0);
+          if (more_a && nt == NT16 - 1) af[mt] = read_a1(src, 1, mt);
+        }
+        load_w(nt);
+      }
+      w_next();
     };
 
+    int pub_idx = -1;                                  // tile whose publication is pending (counter index), or -1
+    auto publish_tile = [&](unsigned* flag) {
+      unsigned old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add((TS_LDS unsigned*)arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if ((old & 7u) == 7u && lane == 0) __hip_atomic_fetch_add((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     TilePos pos;
     pos.init(tile0, tile_step, a.n_tt, a.n_z);
-    w_seek(n_main == 0);
-    w_advance();
+    w_seek(nk_main == 0);
 #pragma unroll
-    for (int r = 0; r < RING; ++r) load_w(ring[r], false, r);
+    for (int nt = 0; nt < NT16; ++nt) load_w(nt);
+    w_next();
     bias_fetch(pos);
     stage_barrier();                                   // stage 0 of the layer is in dwt[gs & 1]
     for (int tile = tile0; tile < tile_end; tile += tile_step) {
       const int b = pos.b, t0 = pos.tt * TT, tt = pos.tt;
-      const int cot0 = (pos.z * WN + wn) * NT;
+      const int c16_0 = (pos.z * WN + wn) * NT16;
       const int len_b = a.zero_tail ? a.len[b] : 0;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT16; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = bnext[j];
+        for (int i = 0; i < MT16; ++i) acc[i][j] = f32x4{bnext[j], bnext[j], bnext[j], bnext[j]};
       for (int s = 0; s < n_stage; ++s, ++gs) {
         const char* const src = dwt + (gs & 1) * TILEB;
-        read_a(src, 0, af);
-        read_a(src, 1, afB);
+#pragma unroll
+        for (int mt = 0; mt < MT16; ++mt) af[mt] = read_a1(src, 0, mt);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_ks(0, af);
-        read_a(src, 2, af);
+        kstep(src, true);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_ks(1, afB);
-        read_a(src, 3, afB);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_ks(2, af);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_ks(3, afB);
-        w_advance();
+        kstep(src, false);
+        if (pub_idx >= 0) {
+          // the previous tile's stores are older than the 2 NT16 weight loads of this stage: a counted wait covers exactly them
+          vm_wait<2 * NT16>();
+          publish_tile(pflag + pub_idx);
+          pub_idx = -1;
+        }
         stage_barrier();
       }
       // ---- epilogue (the producers are already on the next tile, or on the next layer's first stage)
@@ -530,30 +548,26 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
       u32x4 keep = u32x4{~0u, ~0u, ~0u, ~0u};
       if (partial) keep = keep_first(keep, len_out - (tw + csub * 8));
       asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+      const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
+      // 32 output channels (two accumulator columns) at a time through the wave-private LDS tile: lane (channel n = lane & 15, frame group
+      // kg) writes its 4 frames (8 bytes) of every 16-frame tile into row n (+ 16 for the second column), the rows leave as 16-byte segments
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int cob = (cot0 + nt) * 32;
-        const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
-        u32x2 pk[MT * 4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
-                pack_bf16_settled(acc[mt][nt][4 * rg + 0], acc[mt][nt][4 * rg + 1])), f2));
-            const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
-                pack_bf16_settled(acc[mt][nt][4 * rg + 2], acc[mt][nt][4 * rg + 3])), f2));
-            pk[mt * 4 + rg] = u32x2{lo, hi};
-          }
-        // the LDS tile holds ER output-channel rows at a time (all 32, or 16 when the 192-frame dwt buffers leave less room)
+      for (int np = 0; np < NT; ++np) {
+        const int cob = (c16_0 + 2 * np) * 16;
 #pragma unroll
         for (int half = 0; half < 32 / ER; ++half) {
-          if (((lane & 31) / ER) == half) {
-            char* const prow_w = priv + (size_t)(lane & (ER - 1)) * EP + 8 * h;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+          for (int sub = 0; sub < ER / 16; ++sub) {
+            const int nt = 2 * np + (ER == 16 ? half : sub);
+            char* const prow_w = priv + (size_t)(sub * 16 + (lane & 15)) * EP + 8 * kg;
 #pragma unroll
-              for (int rg = 0; rg < 4; ++rg) *reinterpret_cast<u32x2*>(prow_w + (32 * mt + 8 * rg) * 2) = pk[mt * 4 + rg];
+            for (int mt = 0; mt < MT16; ++mt) {
+              const unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+                  pack_bf16_settled(acc[mt][nt][0], acc[mt][nt][1])), f2));
+              const unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+                  pack_bf16_settled(acc[mt][nt][2], acc[mt][nt][3])), f2));
+              *reinterpret_cast<u32x2*>(prow_w + 32 * mt) = u32x2{lo, hi};
+            }
           }
           if (csub < FW / 8) {
             const int row0 = cob + half * ER;
@@ -576,15 +590,17 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
         }
       }
       if (publish) {
-        // every store of this wave has left (R1: each storing wave drains), then the wave checks in; the last of the eight
-        // to arrive signals for the tile.  An LDS counter, not the stage barrier: the producers may already be waiting for
-        // this very tile, and the barrier needs them.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add((TS_LDS unsigned*)arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if ((old & 7u) == 7u && lane == 0)
-          __hip_atomic_fetch_add((gu32*)(pflag + b * a.n_tt + tt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Publication (R1): every storing wave drains its stores, then checks in on an LDS counter -- not the stage barrier: the producers
+        // may already be waiting for this very tile, and the barrier needs them; the last of the eight to arrive signals for the tile.
+        // A tile that is followed by another one of this layer publishes one stage LATE (behind the first stage of the next tile, below):
+        // its write-through stores then complete under that stage's products instead of stalling the wave here, and with two tiles per
+        // workgroup nobody needs the tile that early.  The last tile of a layer publishes at once.
+        if (tile + tile_step < tile_end) {
+          pub_idx = b * a.n_tt + tt;
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          publish_tile(pflag + b * a.n_tt + tt);
+        }
       }
     }
   }
@@ -592,6 +608,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
 
 template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2>
 static int launch_split(ChainArgs& a, hipStream_t stream) {
+  const bool chain = a.n_layers > 1;
   constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 32 * NT * (8 / WM);
   constexpr int ROWB = TT <= 128 ? 256 : 512;
   constexpr int NK_ = NPASS * NKP, CST = (16 * NK_ + 16) % 32 == 16 ? 16 * NK_ + 16 : 16 * NK_ + 32, TAPB = (16 * CST + 1023) / 1024 * 1024;
@@ -601,19 +618,19 @@ static int launch_split(ChainArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) +
                      (size_t)4 * (16 * (64 * XJ + 4) * 2 + 2 * TAPB) + 16;
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT>;
-  static bool attr_set[64] = {};                       // per device (one process may drive several GPUs)
+  auto kern = chain ? tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, true> : tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, false>;
+  static bool attr_set[2][64] = {};                       // per device (one process may drive several GPUs)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
-  if (!attr_set[dev]) {
+  if (!attr_set[chain][dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set[dev] = true;
+    attr_set[chain][dev] = true;
   }
   const int n_cu = cu_count();
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
   a.xcd = grid % 8 == 0 ? 1 : 0;
-  if (a.n_layers > 1) {
+  if (chain) {
     // counters + status word of this launch: a memset node of its own, replayed with the launch
     const size_t bytes = (size_t)round_up((4 + a.n_layers * a.batch * a.n_tt) * 4, 16);
     hipError_t e = hipMemsetAsync(a.flags, 0, bytes, stream);
@@ -641,17 +658,15 @@ int launch_split_chain(ChainArgs& a, int npass, int xe, int wm, int dil, hipStre
 }
 
 // Frames of a time tile for a layer of c_out output channels: 96 (x 512 channels, or x 256 with one 32-channel tile per consumer wave), or 192
-// (x 256).  The 192-frame tiles have the cheaper stage loop, but a layer whose grid gives a workgroup fewer than two of them has nothing to
-// overlap a tile's prologue and epilogue with (QuartzNet's 256-channel layers at 64 x 751 frames: 256 tiles of 192 frames on 256 compute units).
-int split_tile_wm(int c_out, int batch, int t_out) {
+// (x 256).  The 192-frame tiles have the cheaper stage loop and are what every single-layer launch takes.  A CHAIN whose 192-frame grid gives a
+// workgroup a single tile per layer waits, at every layer boundary, for its own epilogue and its neighbours' (QuartzNet's 256-channel blocks at
+// 64 x 751 frames: 256 tiles on 256 compute units, 110 -> 123 us per block); on 96-frame tiles it has two, and the hand-over is free.
+int split_tile_wm(int c_out, int batch, int t_out, bool chain) {
   if (round_up(c_out, 32) > 256) return 1;
-#ifdef TS_NO_NARROW_TILES
-  return 2;
-#else
+  if (!chain) return 2;
   const int n192 = batch * ((t_out + 191) / 192), n96 = batch * ((t_out + 95) / 96);
   const int n_cu = cu_count();
   return (n192 < 2 * n_cu && n96 >= 2 * n_cu) ? 1 : 2;
-#endif
 }
 
 }  // namespace ts
@@ -675,8 +690,9 @@ extern "C" int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, cons
   ChainArgs a{};
   for (int l = 0; l < n_layers; ++l) {
     const ts_tcs_desc& d = descs[l];
-    if (!x[l] || !y[l] || !d.pw_w || !d.bias || !d.dw_taps_raw) return TS_EINVAL;
+    if (!x[l] || !y[l] || !d.pw_w || !d.bias) return TS_EINVAL;
     if (d.c_res > 0 && (!x_res || !x_res[l] || !d.res_w)) return TS_EINVAL;
+    if (!d.dw_taps_raw || !d.pw_w16 || (d.c_res > 0 && !d.res_w16)) return TS_EUNSUPPORTED;
     const bool same = d.batch == d0.batch && d.c_out == d0.c_out && d.t_in == d0.t_out && d.t_out == d0.t_out && d.pitch_in == d0.pitch_in &&
                       d.pitch_out == d0.pitch_in && d.kernel == d0.kernel && d.padding == d0.padding && d.dw_ksteps == d0.dw_ksteps;
     const bool shape = d.depthwise && d.stride == 1 && d.dilation == 1 && !d.out_fp32 && (d.flags & both) == both && !(d.flags & TS_TCS_TAPS_PHASE) &&
@@ -695,8 +711,8 @@ extern "C" int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, cons
     L.xres = d.c_res > 0 ? static_cast<const unsigned short*>(x_res[l]) : nullptr;
     L.y = static_cast<unsigned short*>(y[l]);
     L.taps_raw = static_cast<const unsigned short*>(d.dw_taps_raw);
-    L.pw_w = static_cast<const unsigned short*>(d.pw_w);
-    L.res_w = static_cast<const unsigned short*>(d.res_w);
+    L.pw_w = static_cast<const unsigned short*>(d.pw_w16);
+    L.res_w = static_cast<const unsigned short*>(d.res_w16);
     L.bias = d.bias;
     L.c_in = d.c_in; L.c_res = d.c_res; L.pitch_res = d.c_res > 0 ? d.pitch_res : d.pitch_in; L.relu = d.relu;
     L.kt_main = round_up(d.c_in, KC) / 16;
@@ -714,7 +730,7 @@ extern "C" int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, cons
   const int padl4 = round_up(d0.padding, 4);
   a.padl8 = round_up(padl4, 8);
   a.woff = a.padl8 - padl4;
-  const int WM = split_tile_wm(d0.c_out, d0.batch, d0.t_out);
+  const int WM = split_tile_wm(d0.c_out, d0.batch, d0.t_out, n_layers > 1);
   const int TTp = 96 * WM;
   const int n_ttp = (d0.t_out + TTp - 1) / TTp;
   const int xe = round_up(a.woff + TTp + 4 * d0.dw_ksteps, 64);

@@ -1150,8 +1150,7 @@ static int dwconv_fwd_impl(const void* x, const int32_t* len_in, const int32_t* 
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
   if (aff.part && !pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) return TS_EUNSUPPORTED;
   if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
-    static const bool no_mfma = getenv("TS_DW_NO_MFMA") != nullptr;                 // diagnostic switch
-    if (act == 1 && batch >= 17 && !no_mfma) {
+    if (act == 1 && batch >= 17) {
       // bf16 rows, enough clips to fill the MFMA's N dimension: the depthwise as Toeplitz x clips on the matrix cores
       const int pup = round_up(pad, 16), R = (k + 30 + pup - pad) / 16 + 1, NB = (R + 1) / 2;
       const int n_cg = (batch + 31) / 32, n_blk = (t_out + 31) / 32;

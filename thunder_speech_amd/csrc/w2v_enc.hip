@@ -16,7 +16,6 @@
 // accumulation, residual stream, normalisations and softmax stay fp32; every producer writes the bf16 copy its consumer
 // needs next to (or instead of) the fp32 result, so no separate cast pass exists.  Fused MFMA attention is the follow-up.
 #include "ts_blas.hpp"
-#include <hipblaslt/hipblaslt.h>
 #include <map>
 #include <tuple>
 
@@ -498,79 +497,6 @@ static int gemm_nt(rocblas_handle h, bool bf16, long long m, int n, int k, const
 int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
                  const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
                  int gelu, int batch, const void* wf);
-// TS_W2V_VENDOR_GEMM=1: the library GEMMs of rounds 1-2 instead (A/B timing; also what shapes our kernel declines fall back to)
-static bool vendor_gemm() {
-  static const bool v = [] { const char* e = getenv("TS_W2V_VENDOR_GEMM"); return e && e[0] == '1'; }();
-  return v;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// hipBLASLt GEMM with a fused epilogue (bias, or bias + GELU) and a bf16 result: used when the consumer of a linear layer is
-// another GEMM, so neither the f32 product nor a separate bias / activation pass ever touches HBM.  Plans (descriptor, layouts,
-// heuristic algorithm) are cached per shape.  Any failure returns false and the caller takes the rocBLAS + epilogue-kernel path.
-// ---------------------------------------------------------------------------------------------------------------------
-struct LtPlan {
-  hipblasLtMatmulDesc_t desc = nullptr;
-  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
-  hipblasLtMatmulAlgo_t algo;
-  size_t ws = 0;
-  bool ok = false;
-};
-
-static bool lt_linear(hipStream_t stream, const void* x, long long lda, const void* w, const float* bias, void* y16, long long rows, int n,
-                      int k, bool gelu) {
-  static hipblasLtHandle_t handle = nullptr;
-  static void* workspace = nullptr;
-  static const size_t WS = (size_t)32 << 20;
-  static std::map<std::tuple<long long, int, int, long long, int>, LtPlan> plans;
-  static const bool disabled = getenv("TS_W2V_NO_HIPBLASLT") != nullptr;     // diagnostic: rocBLAS + epilogue kernel everywhere
-  if (disabled) return false;
-  if (!handle) {
-    if (hipblasLtCreate(&handle) != HIPBLAS_STATUS_SUCCESS) { handle = nullptr; return false; }
-    if (hipMalloc(&workspace, WS) != hipSuccess) { workspace = nullptr; }     // one-time scratch of the library's own
-  }
-  const auto key = std::make_tuple(rows, n, k, lda, (gelu ? 1 : 0) | (bias ? 2 : 0));
-  auto it = plans.find(key);
-  if (it == plans.end()) {
-    LtPlan p;
-    bool ok = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
-    const int32_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
-    const uint32_t epi = bias ? (gelu ? HIPBLASLT_EPILOGUE_GELU_BIAS : HIPBLASLT_EPILOGUE_BIAS)
-                              : (gelu ? HIPBLASLT_EPILOGUE_GELU : HIPBLASLT_EPILOGUE_DEFAULT);
-    const int32_t bias_type = HIP_R_32F;
-    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type, sizeof(bias_type)) == HIPBLAS_STATUS_SUCCESS;
-    // column-major view: D^T [n x rows] = W(stored k x n, transposed) . X(stored k x rows)
-    ok = ok && hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, k, n, k) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, k, rows, lda) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatrixLayoutCreate(&p.d, HIP_R_16BF, n, rows, n) == HIPBLAS_STATUS_SUCCESS;
-    if (ok) {
-      // the bias pointer takes part in the heuristic query on some versions: set a placeholder now, the real one per call
-      if (bias) ok = hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
-      hipblasLtMatmulPreference_t pref = nullptr;
-      ok = ok && hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
-      const uint64_t max_ws = workspace ? WS : 0;
-      ok = ok && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)) == HIPBLAS_STATUS_SUCCESS;
-      hipblasLtMatmulHeuristicResult_t res[1];
-      int found = 0;
-      ok = ok && hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS &&
-           found > 0 && res[0].state == HIPBLAS_STATUS_SUCCESS;
-      if (ok) { p.algo = res[0].algo; p.ws = res[0].workspaceSize; }
-      if (pref) hipblasLtMatmulPreferenceDestroy(pref);
-    }
-    p.ok = ok;
-    it = plans.emplace(key, p).first;
-  }
-  LtPlan& p = it->second;
-  if (!p.ok) return false;
-  if (bias && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
-  const float one = 1.f, zero = 0.f;
-  return hipblasLtMatmul(handle, p.desc, &one, w, p.a, x, p.b, &zero, y16, p.d, y16, p.d, &p.algo, workspace, p.ws, stream) ==
-         HIPBLAS_STATUS_SUCCESS;
-}
-
 }  // namespace ts
 
 using namespace ts;
@@ -615,35 +541,26 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
   if (!x || !w_taps || !y || batch <= 0 || c_in <= 0 || c_out <= 0 || kernel <= 0 || stride <= 0 || t_in < kernel) return TS_EINVAL;
   if (c_out % 4 || precision < 0 || precision > 1 || act < 0 || act > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
-  rocblas_handle h;
-  if (int st = blas(stream, &h)) return st;
   const int t_out = conv_frames(t_in, kernel, stride);
   const size_t es = precision ? 2 : 4;
-  // bf16 operands and only the bf16 result wanted: ONE library GEMM per clip over all taps (K = kernel * c_in; the rows of the
-  // operand overlap when kernel > stride, which the GEMM kernels do not mind: they only ever use the row pitch) with the
-  // bias / GELU epilogue fused and a bf16 result -- no f32 accumulator in HBM, no epilogue pass.  Declined plans fall through.
-  static const bool overlap_ok = getenv("TS_W2V_NO_OVERLAP_GEMM") == nullptr;
-  if (precision && y_bf16 && overlap_ok && !vendor_gemm()) {
-    // ONE launch for all clips (grid.y = clip): rows of the operand overlap when kernel > stride, which a kernel that only ever uses
-    // the row pitch does not mind; bias + GELU in the epilogue, bf16 result only
-    const int st = gemm_nt_bf16(stream, x, (long long)stride * c_in, (long long)t_in * c_in, w_taps, (long long)kernel * c_in, bias, nullptr, 0,
-                                nullptr, 0, y_bf16, c_out, (long long)t_out * c_out, t_out, c_out, kernel * c_in, act != 0, batch, w_frag);
-    if (st != TS_EUNSUPPORTED) return st;
+  if (precision) {
+    // bf16 operands: OUR GEMM (csrc/gemm_nt.hip), ONE launch for all clips (grid.y = clip) over all taps, K = kernel * c_in.  Output frame t
+    // reads input rows stride t .. stride t + kernel - 1, contiguous in the time-major layout, so the im2col matrix IS the input with
+    // row pitch stride * c_in; its rows overlap when kernel > stride, which a kernel that only ever uses the pitch does not mind.  Bias +
+    // GELU in the epilogue; with y_bf16 only the bf16 result is written (the next layer's operand), else the f32 one (a LayerNorm
+    // follows).  A shape the kernel declines is an error here (TS_EUNSUPPORTED), not a reason to call a vendor library.
+    return gemm_nt_bf16(stream, x, (long long)stride * c_in, (long long)t_in * c_in, w_taps, (long long)kernel * c_in, bias, nullptr, 0,
+                        y_bf16 ? nullptr : y, c_out, y_bf16, c_out, (long long)t_out * c_out, t_out, c_out, kernel * c_in, act != 0, batch, w_frag);
   }
-  if (precision && y_bf16 && overlap_ok && c_in % 8 == 0 && c_out % 8 == 0) {
-    bool ok = true;
-    for (int b = 0; b < batch && ok; ++b)
-      ok = lt_linear(stream, static_cast<const char*>(x) + (size_t)b * t_in * c_in * 2, (long long)stride * c_in, w_taps, bias,
-                     static_cast<char*>(y_bf16) + (size_t)b * t_out * c_out * 2, t_out, c_out, kernel * c_in, act != 0);
-    if (ok) return hip_status(hipGetLastError());
-    if (hipGetLastError() != hipSuccess) return TS_EUNSUPPORTED;
-  }
+  // f32 mode (the reference's arithmetic): rocBLAS; its argument check wants lda >= K, so the taps go `stride` at a time
+  rocblas_handle h;
+  if (int st = blas(stream, &h)) return st;
   // Output frame t reads input rows stride*t .. stride*t + kernel - 1, which are CONTIGUOUS in the time-major layout: with a
   // row pitch of stride * c_in the first `stride` taps are one [t_out x stride*c_in] matrix, so taps go `stride` at a time
   // (k = 3, s = 2: taps {0, 1} in one GEMM with K = 2 c_in, tap 2 in a second one accumulating; k = 2, s = 2: one GEMM).
   for (int j = 0; j < kernel; j += stride) {
     const int nt = kernel - j < stride ? kernel - j : stride;
-    if (int st = gemm_nt(h, precision != 0, t_out, c_out, nt * c_in, static_cast<const char*>(x) + (size_t)j * c_in * es,
+    if (int st = gemm_nt(h, false, t_out, c_out, nt * c_in, static_cast<const char*>(x) + (size_t)j * c_in * es,
                          (long long)stride * c_in, (long long)t_in * c_in, static_cast<const char*>(w_taps) + (size_t)j * c_in * es,
                          (long long)kernel * c_in, 0, y, c_out, (long long)t_out * c_out, j ? 1.f : 0.f, batch))
       return st;
@@ -663,19 +580,15 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
   if (n % 4 || ldc % 4 || (res && ld_res % 4) || act < 0 || act > 3 || precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   if ((act & 2) && !y_bf16) return TS_EINVAL;
   TS_STREAM;
-  rocblas_handle h;
+  if (precision)
+    // bf16 operands: OUR GEMM with bias / GELU / residual in its epilogue; the f32 result is skipped when only the bf16 copy is wanted.
+    // A shape it declines is an error (TS_EUNSUPPORTED): no vendor library on the bf16 path.
+    return gemm_nt_bf16(stream, x, lda, 0, w, k, bias, res, ld_res, (act & 2) ? nullptr : y, ldc, y_bf16, n, 0, rows, n, k, act & 1, 1, w_frag);
+  rocblas_handle h;                 // f32 mode (the reference's arithmetic): rocBLAS + one epilogue pass
   if (int st = blas(stream, &h)) return st;
-  if (precision && !vendor_gemm()) {
-    // bf16 operands: our GEMM with bias / GELU / residual in its epilogue; the f32 result is skipped when only the bf16 copy is wanted
-    const int st = gemm_nt_bf16(stream, x, lda, 0, w, k, bias, res, ld_res, (act & 2) ? nullptr : y, ldc, y_bf16, n, 0, rows, n, k, act & 1, 1, w_frag);
-    if (st != TS_EUNSUPPORTED) return st;
-  }
-  // bf16 operands, only the bf16 copy of the result wanted, a bias to add: one library GEMM with the epilogue fused
-  if (precision && (act & 2) && bias && !res && n % 8 == 0 && k % 8 == 0 && lt_linear(stream, x, lda, w, bias, y_bf16, rows, n, k, (act & 1) != 0))
-    return hip_status(hipGetLastError());
   // res == y: accumulate into the residual stream in place (beta = 1 inside the GEMM) -- no separate add, no second tensor to read
   const bool inplace = res && static_cast<const void*>(res) == static_cast<const void*>(y) && ld_res == ldc;
-  if (int st = gemm_nt(h, precision != 0, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, inplace ? 1.f : 0.f, 1)) return st;
+  if (int st = gemm_nt(h, false, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, inplace ? 1.f : 0.f, 1)) return st;
   const float* res_e = inplace ? nullptr : res;
   if (bias || res_e || act || y_bf16)
     hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (n / 4))), dim3(256), 0, stream, y, bias, res_e, (long long)rows, n,
@@ -726,9 +639,8 @@ extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int3
   if (precision) hipLaunchKernelGGL(w2v_pad_rows_kernel<unsigned short>, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x,
                                     reinterpret_cast<unsigned short*>(xp), t, c, kernel);
   else hipLaunchKernelGGL(w2v_pad_rows_kernel<float>, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x, reinterpret_cast<float*>(xp), t, c, kernel);
-  static const bool no_mfma = getenv("TS_W2V_NO_POSCONV_MFMA") != nullptr;    // diagnostic: the per-tap GEMM path
   const size_t win_lds = (size_t)(PC_TT + kernel - 1) * PC_PITCH;
-  if (precision && cg == 64 && win_lds <= 64 * 1024 && !no_mfma) {
+  if (precision && cg == 64 && win_lds <= 64 * 1024) {
     PcArgs pa{};
     pa.xp = reinterpret_cast<const unsigned short*>(xp); pa.w = static_cast<const unsigned short*>(w_taps); pa.bias = bias; pa.x = x; pa.y = y;
     pa.t = t; pa.c = c; pa.k = kernel; pa.groups = groups;
@@ -761,8 +673,7 @@ extern "C" int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, i
   if (int st = blas(stream, &h)) return st;
   const int hd = c / heads;
   const bool bf = precision != 0;
-  static const bool no_fused = getenv("TS_W2V_NO_FUSED_ATTN") != nullptr;     // diagnostic: the GEMM + softmax + GEMM path
-  if (bf && hd == 64 && c % 8 == 0 && !no_fused) {
+  if (bf && hd == 64 && c % 8 == 0) {
     FaArgs f{};
     f.qkv = static_cast<const unsigned short*>(qkv); f.ctx = static_cast<unsigned short*>(ctx); f.key_len = key_len;
     f.t = t; f.c = c; f.scale_log2e = 1.4426950408889634f / sqrtf((float)hd);

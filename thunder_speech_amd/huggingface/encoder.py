@@ -107,7 +107,7 @@ class Wav2Vec2Plan:
     def _frag(self, w: torch.Tensor):
         """The bf16 GEMM weight `w` [n][k] in MFMA B-fragment order (ts_gemm_nt_pack_w), packed once per weight: the GEMM kernel then
         loads its B operand from L2 straight into registers.  None in fp32 mode or for shapes the packed kernel does not take."""
-        if not self.prec or os.environ.get("TS_W2V_NO_FRAG") == "1":          # (the switch is for A/B timing of the two operand paths)
+        if not self.prec:
             return None
         cache = self.__dict__.setdefault("_frags", {})
         key = w.data_ptr()

@@ -116,18 +116,23 @@ class BaseCTCModule(_Base):
             self.log("metrics/wer", self.validation_wer, on_epoch=True)
         return loss
 
-    def _update_special_optimizer_arg(self, original_kwargs: Dict) -> Dict:
-        updated_kwargs = original_kwargs.copy()
-        total_steps_arg = updated_kwargs.pop("total_steps_arg", None)
-        if total_steps_arg:
-            updated_kwargs[total_steps_arg] = self.trainer.estimated_stepping_batches
-        return updated_kwargs
+    def _resolve_builder_kwargs(self, kwargs: Dict) -> Dict:
+        """The reference's one magic key (module.py:165-171): {"total_steps_arg": name} means "pass the trainer's estimated number of
+        optimizer steps under `name`" (e.g. OneCycleLR's total_steps).  Everything else goes to the builder untouched."""
+        name = kwargs.get("total_steps_arg")
+        resolved = {k: v for k, v in kwargs.items() if k != "total_steps_arg"}
+        if name:
+            resolved[name] = self.trainer.estimated_stepping_batches
+        return resolved
+
+    # the reference's method name, kept for subclasses that override or call it
+    _update_special_optimizer_arg = _resolve_builder_kwargs
 
     def configure_optimizers(self) -> Union[torch.optim.Optimizer, Dict[str, Any]]:
-        optim_kwargs = self._update_special_optimizer_arg(self.optimizer_kwargs)
-        optimizer = self.optimizer_class(filter(lambda p: p.requires_grad, self.parameters()), **optim_kwargs)
-        if not self.lr_scheduler_class:
+        """Lightning contract (module.py:173-189): the optimizer over the trainable parameters, alone or with its scheduler entry."""
+        trainable = [p for p in self.parameters() if p.requires_grad]
+        optimizer = self.optimizer_class(trainable, **self._resolve_builder_kwargs(self.optimizer_kwargs))
+        if self.lr_scheduler_class is None:
             return optimizer
-        scheduler_kwargs = self._update_special_optimizer_arg(self.lr_scheduler_kwargs)
-        lr_scheduler = self.lr_scheduler_class(optimizer, **scheduler_kwargs)
-        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": lr_scheduler, "interval": self.lr_scheduler_interval}}
+        scheduler = self.lr_scheduler_class(optimizer, **self._resolve_builder_kwargs(self.lr_scheduler_kwargs))
+        return dict(optimizer=optimizer, lr_scheduler=dict(scheduler=scheduler, interval=self.lr_scheduler_interval))

@@ -112,6 +112,19 @@ def pack_pw_frags(wf: torch.Tensor) -> torch.Tensor:
     return fr.reshape(cop // 32, cip // 16, 64, 8).to(torch.bfloat16).contiguous()
 
 
+def pack_pw_frags16(wf: torch.Tensor) -> torch.Tensor:
+    """wf: [Cout, Cin] (already multiplied by the BN scale) -> bf16 [Cout_pad32/16, Cin_pad64/32, 64, 8].
+
+    Fragment (tile, ks), lane l (n = l & 15, g = l >> 4), element j  =  W[tile*16 + n][ks*32 + 8g + j]:
+    the B operand of v_mfma_f32_16x16x32_bf16 for D[t][co] += dw[t][ci] * W[co][ci] (the split kernel's consumers)."""
+    cout, cin = wf.shape
+    cop, cip = round_up(cout, 32), round_up(cin, KC)
+    wp = torch.zeros(cop, cip, dtype=torch.float32, device=wf.device)
+    wp[:cout, :cin] = wf
+    fr = wp.view(cop // 16, 16, cip // 32, 4, 8).permute(0, 2, 3, 1, 4)      # [tile][ks][g][n][j]
+    return fr.reshape(cop // 16, cip // 32, 64, 8).to(torch.bfloat16).contiguous()
+
+
 def pad_bias(b: torch.Tensor) -> torch.Tensor:
     out = torch.zeros(round_up(b.shape[0], 32), dtype=torch.float32, device=b.device)
     out[: b.shape[0]] = b
@@ -140,6 +153,8 @@ class TcsLayer:
     c_res: int = 0
     res_w: Optional[torch.Tensor] = None
     res_stride: int = 1
+    pw16: Optional[torch.Tensor] = None            # the pointwise / residual weights as 16x16x32 fragments (split kernel; pack_pw_frags16)
+    res_w16: Optional[torch.Tensor] = None
     out_fp32: bool = False
     taps_phase: Optional[torch.Tensor] = None      # dilation 2: the same taps packed for the phase-split kernel
     nk_phase: int = 0
@@ -170,17 +185,19 @@ class TcsLayer:
         if self.c_res:
             d.pitch_res, d.t_res = pitch_res, t_res
             d.res_w = self.res_w.data_ptr()
+            d.res_w16 = self.res_w16.data_ptr() if self.res_w16 is not None else None
         d.dw_ksteps = self.nk
         d.flags = (_lib.TCS_IN_TAILZERO if in_tail_zero else 0) | (_lib.TCS_OUT_ZERO_TAIL if zero_tail else 0)
         d.dw_taps = self.taps.data_ptr() if self.taps is not None else None
         d.dw_taps_raw = self.taps_raw.data_ptr() if self.taps_raw is not None else None
         d.pw_w = self.pw.data_ptr()
+        d.pw_w16 = self.pw16.data_ptr() if self.pw16 is not None else None
         d.bias = self.bias.data_ptr()
         return d
 
     def chainable(self) -> bool:
         """Static part of what ts_tcs_chain_fwd asks of a layer (the library checks the geometry against the tensors)."""
-        return (self.pre is None and self.depthwise and self.stride == 1 and self.dilation == 1 and self.taps_raw is not None
+        return (self.pre is None and self.depthwise and self.stride == 1 and self.dilation == 1 and self.taps_raw is not None and self.pw16 is not None
                 and not self.out_fp32 and self.kernel == 2 * self.padding + 1 and self.c_in % KC == 0 and self.c_res % KC == 0
                 and self.res_stride == 1)
 
@@ -233,7 +250,12 @@ class TcsLayer:
         return out, t_out
 
 
-CHAIN = True          # True: chain where it pays (below); "force": wherever the library can (tests); False: one launch per sub-block (A/B timing)
+# Chain launches (ts_tcs_chain_fwd: all repeats of a block in ONE persistent launch).  OFF by default: measured on one MI355X (round 4, C2 encoder,
+# same box, profiles/round4_chain_ab.txt + DESIGN.md 3.1): one launch per sub-block 2.87 ms, chains 3.00 ms.  The launch gaps a chain removes are worth
+# 6 %, but its bookkeeping costs registers in a kernel that has none to spare (+6 %: spills in the producers' stage loop) and its hand-over
+# needs write-through stores / L1-bypassing loads (+3.5 %).  True: chain where a workgroup has at least two tiles per layer; "force": wherever the
+# library can (tests, tools); False: one launch per sub-block.
+CHAIN = False
 _CHAIN_WS = {}
 _N_CU = {}
 
@@ -353,15 +375,17 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
         taps_phase, nk_phase = pack_dw_taps(cpu(dw_w), 1, 1, padding // 2)
         taps_phase = tap_fragments(taps_phase).to(device)
         taps_phase_raw = pack_dw_taps_raw(cpu(dw_w), padding // 2).to(device)
-    c_res, res_p = 0, None
+    c_res, res_p, res_p16 = 0, None, None
     if res_w is not None:
         r2 = cpu(res_w).reshape(res_w.shape[0], res_w.shape[1])
         rs, rsh = fold_bn(*[cpu(t) for t in res_bn])
         res_p = pack_pw_frags(r2 * rs[:, None]).to(device)
+        res_p16 = pack_pw_frags16(r2 * rs[:, None]).to(device)
         shift = shift + rsh
         c_res = r2.shape[1]
     return TcsLayer(c_in=cin, c_out=cout, kernel=kernel, stride=stride, dilation=dilation, padding=padding,
                     depthwise=dw_w is not None, relu=relu, taps=None if taps is None else tap_fragments(taps).to(device), nk=nk,
                     pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
                     res_stride=res_stride, out_fp32=out_fp32, taps_phase=taps_phase, nk_phase=nk_phase, taps_raw=taps_raw,
-                    taps_phase_raw=taps_phase_raw)
+                    taps_phase_raw=taps_phase_raw,
+                    pw16=None if out_fp32 else pack_pw_frags16(wf).to(device), res_w16=res_p16)

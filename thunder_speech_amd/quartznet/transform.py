@@ -139,7 +139,8 @@ class PowerSpectrum(nn.Module):
         if self.win_length > self.n_fft:
             raise RuntimeError(f"PowerSpectrum: win_length {self.win_length} > n_fft {self.n_fft} (torch.stft refuses it too)")
         win, tw = self._stft_tables(xf.device)
-        out = torch.empty(b, self.n_fft // 2 + 1, n // self.hop_length + 1, dtype=torch.float32, device=xf.device)
+        frames = 1 + (n + 2 * (self.n_fft // 2) - self.n_fft) // self.hop_length      # torch.stft(center=True): n // hop + 1 for even n_fft
+        out = torch.empty(b, self.n_fft // 2 + 1, frames, dtype=torch.float32, device=xf.device)
         st = _lib.lib().ts_fe_power_spectrum(xf.data_ptr(), win.data_ptr(), tw.data_ptr(), out.data_ptr(), b, n, self.n_fft, self.hop_length,
                                              _stream(xf))
         _lib.check(st, "ts_fe_power_spectrum")
@@ -197,7 +198,10 @@ class _FilterbankFeatures(MultiSequential):
         dither = float(self[0].layer[0].dither) if self[0].layer[0].training else 0.0
         ps, mel = self[1], self[2].layer[0]
         if not mel.log_scale:
-            raise NotImplementedError("MelScale(log_scale=False)")
+            # MelScale(log_scale=False) (reference transform.py:213, :253: the plain filterbank product, no log): no model of the reference is
+            # built this way and the fused kernel has the log inside its spectrum loop, so this configuration runs the reference's module
+            # chain stage by stage (MultiSequential.forward), every stage on its own HIP kernel (ts_fe_*)
+            return super().forward(audio, audio_lengths)
         x = audio.to(torch.float32).contiguous()
         b, n = x.shape
         win, mw, moff, nnz = self._tables(x.device)

@@ -147,7 +147,7 @@ def full_lengths(b: int, t: int, device) -> torch.Tensor:
 
 
 _KINDS = {torch.float32: 0, torch.int64: 1, torch.int32: 2}
-_NO_MAP = bool(os.environ.get("TS_NO_LENGTHS_MAP"))       # diagnostic switch: the plain torch expressions
+_NO_MAP = False        # tools may set this to time the plain torch expressions instead
 
 
 def lengths_map(lengths: torch.Tensor, add: int, div: int, plus: int, out_dtype=None) -> torch.Tensor:

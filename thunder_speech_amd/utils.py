@@ -60,15 +60,29 @@ def download_checkpoint(name: BaseCheckpoint, checkpoint_folder: str = None) -> 
     returned without touching the network."""
     folder = Path(checkpoint_folder) if checkpoint_folder is not None else get_default_cache_folder()
     url = str(name.value)
+    if "://" not in url:
+        # this package's checkpoint enums carry bare NeMo names (no network here), the reference's carry URLs: a bare name resolves to the
+        # cached `<name>.nemo`, the file name load_quartznet_checkpoint / load_citrinet_checkpoint look for
+        path = folder / (url if url.endswith(".nemo") else url + ".nemo")
+        if not path.exists():
+            raise FileNotFoundError(f"{path} not found and {url!r} is not a URL to fetch it from")
+        return path
     path = folder / url.split("/")[-1]
     if not path.exists():
-        if "://" not in url:
-            raise FileNotFoundError(f"{path} not found and {url!r} is not a URL to fetch it from")
+        import os
+        import tempfile
         import urllib.request
+        folder.mkdir(parents=True, exist_ok=True)
+        fd, tmp = tempfile.mkstemp(dir=folder, suffix=".part")       # an interrupted download must not leave a truncated file that
+        os.close(fd)                                                  # later counts as cached: fetch beside the target, then rename
         try:
-            urllib.request.urlretrieve(url, path)
+            urllib.request.urlretrieve(url, tmp)
+            os.replace(tmp, path)
         except OSError as e:
             raise RuntimeError(f"download_checkpoint: could not fetch {url} ({e}); place the file at {path}") from e
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return path
 
 

@@ -1,0 +1,33 @@
+"""Same-box A/B of library variants on the C2 encoder: python tools/ab_encoder.py variantA variantB ... ('' = product); each variant runs in
+its own process, interleaved twice."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = r'''
+import sys, os, torch
+sys.path.insert(0, %r)
+import bench
+from tools.bench_chain import time_graph
+dev = torch.device("cuda", 0)
+m = bench.build_model(dev)
+wav = (0.1 * torch.randn(64, 240000, generator=torch.Generator().manual_seed(1234))).to(dev)
+ln = torch.full((64,), 240000, dtype=torch.int32, device=dev)
+with torch.no_grad():
+    f, fl = m.audio_transform(wav, ln)
+    m.encoder(f, fl); torch.cuda.synchronize()
+    best = min(time_graph(lambda: m.encoder(f, fl), 40) for _ in range(3))
+print("RESULT %%.4f" %% best)
+''' % ROOT
+def main(names):
+    res = {n: [] for n in names}
+    for rep in range(2):
+        for n in names:
+            env = dict(os.environ, TS_LIB_VARIANT=n)
+            out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, cwd=ROOT)
+            line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+            res[n].append(float(line[0].split()[1]) if line else float("nan"))
+            if not line:
+                print(out.stderr[-2000:])
+    for n in names:
+        print(f"{n or 'product':12s} encoder ms: " + "  ".join(f"{v:.3f}" for v in res[n]), flush=True)
+if __name__ == "__main__":
+    main(sys.argv[1:] or [""])

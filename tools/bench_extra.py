@@ -320,7 +320,9 @@ def run(device, which=("c3", "c4", "c5"), check=True):
                 extra.update(c4(device))
             elif name == "c5":
                 extra["c5"] = c5(device, check=check)
-        except Exception as e:                      # an extra must never take the headline line down with it
+        except Exception as e:                      # an extra must never take the headline line down with it: recorded, reported on stderr,
+            import traceback                        # and bench.py exits non-zero after printing the (complete) line
+            print(f"bench_extra: {name} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
             extra[name] = {"error": f"{type(e).__name__}: {e}"}
         extra.setdefault("_wall_s", {})[name] = round(time.perf_counter() - t0, 1)
         torch.cuda.empty_cache()
