@@ -111,6 +111,20 @@ int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, const void* con
                      const int32_t* len, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * General f32-accumulating GEMM on the f32 matrix-core instruction (csrc/gemm_f32.hip): what the "reference arithmetic" modes run on -- the
+ * f32 1x1 convolutions of the training path (quartznet/blocks.py:181 computes in f32), wav2vec2's precision = "fp32" (transformers' f32
+ * linears, huggingface/compatibility.py:31-42) -- and the bf16-operand products without a kernel of their own.
+ *   C[z][m][n] = sum_{j < nkb} sum_{k < K} A(z, j; m, k) B(z, j; k, n) (+ C if beta) (+ bias[n])
+ *   A(m, k) at a + z sa + j ska + m a_rs + k a_cs, B(k, n) at b + z sb + j skb + k b_rs + n b_cs (ELEMENT strides): one of (a_rs, a_cs)
+ *   and one of (b_rs, b_cs) is 1; C row-major, ldc >= N.  Operands with a 16-byte aligned base (8 for bf16) and strides that are multiples of 4
+ *   are fetched with vector loads, others element by element.
+ * in_bf16: A and B are bf16 (widened exactly), else f32; out_bf16: C is bf16, else f32.  TS_EUNSUPPORTED when neither stride of an operand is 1.
+ * ---------------------------------------------------------------------------------------------- */
+int ts_gemm_f32(const void* a, int64_t a_rs, int64_t a_cs, int64_t sa, int64_t ska, const void* b, int64_t b_rs, int64_t b_cs, int64_t sb,
+                int64_t skb, void* c, int64_t ldc, int64_t sc, const float* bias, int32_t m, int32_t n, int32_t k, int32_t nkb, int32_t batch,
+                int32_t in_bf16, int32_t out_bf16, int32_t beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Squeeze-excite of the Citrinet blocks (eval): replaces SqueezeExcite.forward (citrinet/blocks.py:70-83: AdaptiveAvgPool1d
  * over ALL frames incl. padding -> Linear -> ReLU -> Linear -> sigmoid -> x * g) and the block tail
  * `out = relu(se(mconv(x)) + res(x))` (citrinet/blocks.py:186-196).

@@ -13,7 +13,6 @@
 
 #include <cstdlib>
 
-#include "ts_blas.hpp"
 
 namespace ts {
 
@@ -1373,14 +1372,11 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-// C = A . B through rocBLAS, strided-batched; in: operand type (f32 / bf16), out: result type (f32 / bf16), f32 accumulation
-static rocblas_status gemm_ex(rocblas_handle h, bool in_bf16, bool out_bf16, rocblas_operation ta, rocblas_operation tb, int m, int n, int k,
-                              const void* a, int lda, long long sa, const void* b, int ldb, long long sb, void* c, int ldc, long long sc, int batch) {
-  const float one = 1.f, zero = 0.f;
-  const rocblas_datatype in = in_bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
-  const rocblas_datatype out = out_bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
-  return rocblas_gemm_strided_batched_ex(h, ta, tb, m, n, k, &one, a, in, lda, sa, b, in, ldb, sb, &zero, c, out, ldc, sc, c, out, ldc, sc, batch,
-                                         rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+namespace ts {
+// f32-accumulating GEMM on the f32 matrix-core instruction, any operand layout (csrc/gemm_f32.hip)
+int gemm_f32(hipStream_t stream, bool in_bf16, const void* a, long long a_rs, long long a_cs, long long sa, long long ska, const void* b,
+             long long b_rs, long long b_cs, long long sb, long long skb, void* c, long long ldc, long long sc, bool out_bf16, const float* bias,
+             int M, int N, int K, int nkb, int batch, bool beta);
 }
 
 extern "C" int ts_train_cast_bf16(const float* x, void* y, int64_t n, void* stream_) {
@@ -1398,12 +1394,9 @@ extern "C" int ts_train_pwconv_fwd(const void* u, const void* w, void* v, int32_
   if (!u || !w || !v || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
   if (precision < 0 || precision > 2) return TS_EUNSUPPORTED;
   TS_STREAM;
-  rocblas_handle h;
-  if (int e = blas(stream, &h)) return e;
-  // row-major [c][pitch] == column-major [pitch][c]:  V(t x c_out) = U(t x c_in) . Wc(c_in x c_out)
-  const rocblas_status st = gemm_ex(h, precision != 0, precision == 2, rocblas_operation_none, rocblas_operation_none, t, c_out, c_in, u, pitch_u,
-                                    (long long)c_in * pitch_u, w, c_in, 0, v, pitch_v, (long long)c_out * pitch_v, batch);
-  return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
+  // per clip: V[c_out][t] = W[c_out][c_in] . U[c_in][t]  (W's contraction index contiguous, U's frame index contiguous)
+  return gemm_f32(stream, precision != 0, w, c_in, 1, 0, 0, u, pitch_u, 1, (long long)c_in * pitch_u, 0, v, pitch_v, (long long)c_out * pitch_v,
+                  precision == 2, nullptr, c_out, t, c_in, 1, batch, false);
 }
 
 // du[b] = W^T . dv[b];  dW = sum_b dv[b] . u[b]^T  (workspace: batch * c_out * c_in floats, f32 always); precision as above
@@ -1413,17 +1406,16 @@ extern "C" int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w,
   if (!dv || !u || !w || !du || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
   if (precision < 0 || precision > 2) return TS_EUNSUPPORTED;
   TS_STREAM;
-  rocblas_handle h;
-  if (int e = blas(stream, &h)) return e;
   const bool bf = precision != 0;
-  // dU(t x c_in) = dV(t x c_out) . Wc^T(c_out x c_in)
-  rocblas_status st = gemm_ex(h, bf, precision == 2, rocblas_operation_none, rocblas_operation_transpose, t, c_in, c_out, dv, pitch_v,
-                              (long long)c_out * pitch_v, w, c_in, 0, du, pitch_u, (long long)c_in * pitch_u, batch);
-  if (st != rocblas_status_success) return TS_EUNSUPPORTED;
-  // per clip: dWc_b(c_in x c_out) = U^T(c_in x t) . dV(t x c_out)
-  st = gemm_ex(h, bf, false, rocblas_operation_transpose, rocblas_operation_none, c_in, c_out, t, u, pitch_u, (long long)c_in * pitch_u, dv, pitch_v,
-               (long long)c_out * pitch_v, workspace, c_in, (long long)c_in * c_out, batch);
-  if (st != rocblas_status_success) return TS_EUNSUPPORTED;
+  // per clip: dU[c_in][t] = W^T . dV[c_out][t]  (A(m, k) = W[k][m]: W's output index is the contiguous one here)
+  if (int st = gemm_f32(stream, bf, w, 1, c_in, 0, 0, dv, pitch_v, 1, (long long)c_out * pitch_v, 0, du, pitch_u, (long long)c_in * pitch_u,
+                        precision == 2, nullptr, c_in, t, c_out, 1, batch, false))
+    return st;
+  // per clip: dW_b[c_out][c_in] = dV[c_out][t] . U[c_in][t]^T (both contract over their contiguous frame index) -> workspace, summed below.
+  // One partial per clip keeps every CU busy (16 tiles x 32 clips at 512 x 512); the pitch padding beyond t never enters (K = t).
+  if (int st = gemm_f32(stream, bf, dv, pitch_v, 1, (long long)c_out * pitch_v, 0, u, 1, pitch_u, (long long)c_in * pitch_u, 0, workspace, c_in,
+                        (long long)c_in * c_out, false, nullptr, c_out, c_in, t, 1, batch, false))
+    return st;
   const long long rows = (long long)c_in * c_out;
   hipLaunchKernelGGL(sum_parts_kernel, dim3(blocks(rows)), dim3(256), 0, stream, workspace, dw, rows, batch);
   return hip_status(hipGetLastError());

@@ -11,13 +11,11 @@
 //   ts_w2v_layernorm_fwd  y = LN(x [+ res])
 //   ts_w2v_posconv_fwd    y = x + gelu(grouped conv(x) + b): one batched GEMM per tap over a zero-padded copy
 //   ts_w2v_attention_fwd  softmax(q k^T * scale [keys >= len masked]) v per (clip, head)
-// The GEMMs are plain library calls (rocBLAS gemm_strided_batched_ex); everything else is hand-written here.
+// Every GEMM is this library's own: csrc/gemm_nt.hip (bf16 operands, token-major) and csrc/gemm_f32.hip (f32 mode, odd shapes).
 // precision 0: fp32 GEMMs (tight parity with the fp32 reference).  precision 1: the GEMM operands are bf16 (MFMA rate),
 // accumulation, residual stream, normalisations and softmax stay fp32; every producer writes the bf16 copy its consumer
 // needs next to (or instead of) the fp32 result, so no separate cast pass exists.  Fused MFMA attention is the follow-up.
-#include "ts_blas.hpp"
-#include <map>
-#include <tuple>
+#include "ts_common.hpp"
 
 namespace ts {
 
@@ -479,18 +477,17 @@ __global__ __launch_bounds__(256) void w2v_posconv_mfma_kernel(const PcArgs a) {
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
+// f32-accumulating GEMM on the f32 matrix-core instruction, any operand layout (csrc/gemm_f32.hip): the f32 mode and the shapes without a kernel of
+// their own
+int gemm_f32(hipStream_t stream, bool in_bf16, const void* a, long long a_rs, long long a_cs, long long sa, long long ska, const void* b,
+             long long b_rs, long long b_cs, long long sb, long long skb, void* c, long long ldc, long long sc, bool out_bf16, const float* bias,
+             int M, int N, int K, int nkb, int batch, bool beta);
+
 // row-major y[M][N] (ldc) = x[M][K] (lda) W[N][K]^T (ldw) + beta y, batched with element strides.  bf16 = x and W are bf16;
 // y is f32 (or bf16 when y16 is set), accumulation f32 either way.
-static int gemm_nt(rocblas_handle h, bool bf16, long long m, int n, int k, const void* x, long long lda, long long sx, const void* w,
+static int gemm_nt(hipStream_t stream, bool bf16, long long m, int n, int k, const void* x, long long lda, long long sx, const void* w,
                    long long ldw, long long sw, void* y, long long ldc, long long sy, float beta, int batch, bool y16 = false) {
-  const float one = 1.f;
-  const rocblas_datatype in = bf16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
-  const rocblas_datatype out = y16 ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
-  const rocblas_status st = rocblas_gemm_strided_batched_ex(h, rocblas_operation_transpose, rocblas_operation_none, n, (rocblas_int)m, k,
-                                                            &one, w, in, (rocblas_int)ldw, sw, x, in, (rocblas_int)lda, sx, &beta, y, out,
-                                                            (rocblas_int)ldc, sy, y, out, (rocblas_int)ldc, sy, batch,
-                                                            rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-  return st == rocblas_status_success ? TS_OK : TS_EUNSUPPORTED;
+  return gemm_f32(stream, bf16, x, lda, 1, sx, 0, w, 1, ldw, sw, 0, y, ldc, sy, y16, nullptr, (int)m, n, k, 1, batch, beta != 0.f);
 }
 
 // our own token-major bf16 GEMM with the fused epilogue (csrc/gemm_nt.hip): the default of the bf16 mode since round 3
@@ -552,15 +549,14 @@ extern "C" int ts_w2v_conv_fwd(const void* x, int32_t batch, int32_t t_in, int32
     return gemm_nt_bf16(stream, x, (long long)stride * c_in, (long long)t_in * c_in, w_taps, (long long)kernel * c_in, bias, nullptr, 0,
                         y_bf16 ? nullptr : y, c_out, y_bf16, c_out, (long long)t_out * c_out, t_out, c_out, kernel * c_in, act != 0, batch, w_frag);
   }
-  // f32 mode (the reference's arithmetic): rocBLAS; its argument check wants lda >= K, so the taps go `stride` at a time
-  rocblas_handle h;
-  if (int st = blas(stream, &h)) return st;
+  // f32 mode (the reference's arithmetic): the f32 matrix-core GEMM, taps `stride` at a time (rows stride t .. stride t + stride - 1 of the
+  // time-major input are one contiguous K = stride * c_in operand row)
   // Output frame t reads input rows stride*t .. stride*t + kernel - 1, which are CONTIGUOUS in the time-major layout: with a
   // row pitch of stride * c_in the first `stride` taps are one [t_out x stride*c_in] matrix, so taps go `stride` at a time
   // (k = 3, s = 2: taps {0, 1} in one GEMM with K = 2 c_in, tap 2 in a second one accumulating; k = 2, s = 2: one GEMM).
   for (int j = 0; j < kernel; j += stride) {
     const int nt = kernel - j < stride ? kernel - j : stride;
-    if (int st = gemm_nt(h, false, t_out, c_out, nt * c_in, static_cast<const char*>(x) + (size_t)j * c_in * es,
+    if (int st = gemm_nt(stream, false, t_out, c_out, nt * c_in, static_cast<const char*>(x) + (size_t)j * c_in * es,
                          (long long)stride * c_in, (long long)t_in * c_in, static_cast<const char*>(w_taps) + (size_t)j * c_in * es,
                          (long long)kernel * c_in, 0, y, c_out, (long long)t_out * c_out, j ? 1.f : 0.f, batch))
       return st;
@@ -584,11 +580,10 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
     // bf16 operands: OUR GEMM with bias / GELU / residual in its epilogue; the f32 result is skipped when only the bf16 copy is wanted.
     // A shape it declines is an error (TS_EUNSUPPORTED): no vendor library on the bf16 path.
     return gemm_nt_bf16(stream, x, lda, 0, w, k, bias, res, ld_res, (act & 2) ? nullptr : y, ldc, y_bf16, n, 0, rows, n, k, act & 1, 1, w_frag);
-  rocblas_handle h;                 // f32 mode (the reference's arithmetic): rocBLAS + one epilogue pass
-  if (int st = blas(stream, &h)) return st;
+  // f32 mode (the reference's arithmetic): the f32 matrix-core GEMM + one epilogue pass
   // res == y: accumulate into the residual stream in place (beta = 1 inside the GEMM) -- no separate add, no second tensor to read
   const bool inplace = res && static_cast<const void*>(res) == static_cast<const void*>(y) && ld_res == ldc;
-  if (int st = gemm_nt(h, false, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, inplace ? 1.f : 0.f, 1)) return st;
+  if (int st = gemm_nt(stream, false, rows, n, k, x, lda, 0, w, k, 0, y, ldc, 0, inplace ? 1.f : 0.f, 1)) return st;
   const float* res_e = inplace ? nullptr : res;
   if (bias || res_e || act || y_bf16)
     hipLaunchKernelGGL(w2v_bias_act_kernel, dim3(nblk(rows * (n / 4))), dim3(256), 0, stream, y, bias, res_e, (long long)rows, n,
@@ -628,8 +623,6 @@ extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int3
   if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   (void)y_bf16;
   TS_STREAM;
-  rocblas_handle h;
-  if (int st = blas(stream, &h)) return st;
   const int cg = c / groups;
   const long long prow = (long long)t + kernel;                       // padded rows per clip
   // workspace: yp f32 [B (t+k)][c] first, then the padded copy (f32 or bf16)
@@ -650,7 +643,7 @@ extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int3
   // all clips at once: output row r (over the padded row space) = sum_j xp[r + j] W_j^T, per group; rows between clips are waste
   const long long m = (long long)batch * prow - kernel;
   for (int j = 0; j < kernel; ++j) {
-    if (int st = gemm_nt(h, precision != 0, m, cg, cg, xp + (size_t)j * c * es, c, cg,
+    if (int st = gemm_nt(stream, precision != 0, m, cg, cg, xp + (size_t)j * c * es, c, cg,
                          static_cast<const char*>(w_taps) + (size_t)j * groups * cg * cg * es, cg, (long long)cg * cg, yp, c, cg,
                          j ? 1.f : 0.f, groups))
       return st;
@@ -669,8 +662,6 @@ extern "C" int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, i
   if (!qkv || !ctx || !workspace || batch <= 0 || t <= 0 || c <= 0 || heads <= 0 || c % heads) return TS_EINVAL;
   if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
   TS_STREAM;
-  rocblas_handle h;
-  if (int st = blas(stream, &h)) return st;
   const int hd = c / heads;
   const bool bf = precision != 0;
   if (bf && hd == 64 && c % 8 == 0) {
@@ -686,23 +677,18 @@ extern "C" int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, i
   for (int b = 0; b < batch; ++b) {
     const char* q = static_cast<const char*>(qkv) + (size_t)b * t * 3 * c * es;
     // scores[query][key] = q . k : batched over the heads (head h = columns [h hd, (h+1) hd) of each third of a qkv row)
-    if (int st = gemm_nt(h, bf, t, t, hd, q, 3LL * c, hd, q + (size_t)c * es, 3LL * c, hd, s + (size_t)b * heads * t * t, t,
+    if (int st = gemm_nt(stream, bf, t, t, hd, q, 3LL * c, hd, q + (size_t)c * es, 3LL * c, hd, s + (size_t)b * heads * t * t, t,
                          (long long)t * t, 0.f, heads))
       return st;
   }
   hipLaunchKernelGGL(w2v_softmax_kernel, dim3((unsigned)(((long long)heads * t + 3) / 4), batch), dim3(256), 0, stream, s, key_len, heads, t,
                      1.f / sqrtf((float)hd), p16);
-  const float one = 1.f, zero = 0.f;
-  const rocblas_datatype dt = bf ? rocblas_datatype_bf16_r : rocblas_datatype_f32_r;
   for (int b = 0; b < batch; ++b) {
     const char* v = static_cast<const char*>(qkv) + ((size_t)b * t * 3 * c + 2 * c) * es;
     const void* p = bf ? static_cast<const void*>(p16 + (size_t)b * heads * t * t) : static_cast<const void*>(s + (size_t)b * heads * t * t);
     void* out = static_cast<char*>(ctx) + (size_t)b * t * c * es;
-    // ctx[query][d] = sum_key p[query][key] v[key][d]   (column-major view: ctx^T = v^T p^T, no transposes); bf16 in -> bf16 out
-    const rocblas_status st = rocblas_gemm_strided_batched_ex(h, rocblas_operation_none, rocblas_operation_none, hd, t, t, &one, v, dt, 3 * c, hd,
-                                                              p, dt, t, (rocblas_stride)t * t, &zero, out, dt, c, hd, out, dt, c, hd, heads,
-                                                              rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-    if (st != rocblas_status_success) return TS_EUNSUPPORTED;
+    // ctx[query][d] = sum_key p[query][key] v[key][d], batched over the heads (head h = columns [h hd, (h+1) hd) of a v / ctx row); bf16 in -> bf16 out
+    if (int st = gemm_f32(stream, bf, p, t, 1, (long long)t * t, 0, v, 3LL * c, 1, hd, 0, out, c, hd, bf, nullptr, t, hd, t, 1, heads, false)) return st;
   }
   return hip_status(hipGetLastError());
 }
