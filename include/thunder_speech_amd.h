@@ -123,6 +123,34 @@ int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, const void* con
 int ts_gemm_f32(const void* a, int64_t a_rs, int64_t a_cs, int64_t sa, int64_t ska, const void* b, int64_t b_rs, int64_t b_cs, int64_t sb,
                 int64_t skb, void* c, int64_t ldc, int64_t sc, const float* bias, int32_t m, int32_t n, int32_t k, int32_t nkb, int32_t batch,
                 int32_t in_bf16, int32_t out_bf16, int32_t beta, void* stream);
+/* f32 operands and result, with a second batch level: grid z = z1 * batch2 + z2, operand offsets z1 s? + z2 s?2 (e.g. (clip, head)) */
+int ts_gemm_f32_b2(const void* a, int64_t a_rs, int64_t a_cs, int64_t sa, int64_t sa2, int64_t ska, const void* b, int64_t b_rs, int64_t b_cs,
+                   int64_t sb, int64_t sb2, int64_t skb, void* c, int64_t ldc, int64_t sc, int64_t sc2, const float* bias, int32_t m, int32_t n,
+                   int32_t k, int32_t nkb, int32_t batch, int32_t batch2, int32_t beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * wav2vec2 fine-tuning (csrc/w2v_train.hip): what the backward pass of transformers.Wav2Vec2Model needs besides GEMMs (the reference trains
+ * HuggingFace checkpoints through BaseCTCModule.training_step, module.py:102-127, with the conv feature extractor frozen,
+ * huggingface/compatibility.py:27-28).  f32 [rows][c] activations, rows = clips x frames.
+ *   ts_w2v_layernorm_bwd  y = LN(x (+ res)) gamma + beta: dx (= d res), dgamma += , dbeta += ; workspace ts_w2v_layernorm_bwd_workspace bytes
+ *   ts_w2v_colsum         out[j] += sum_r x[r ld + j]   (bias gradients)
+ *   ts_w2v_gelu_fwd/_bwd  y = gelu(z + bias[col]) (erf form; bias may be NULL) and dz = dy gelu'(z + bias[col])
+ *   ts_w2v_softmax_fwd    s [batch][heads][t][t] -> softmax(scale s) in place, keys >= key_len[clip] masked; _bwd: dp -> scale p (dp - <dp, p>)
+ *   ts_w2v_pad_rows       time-axis zero padding of [batch][t][c] (extract = 0) and its inverse (1)
+ *   ts_w2v_mask_embed     train-time masking: rows with mask != 0 <- embed (forward); backward: dembed += masked rows of dy, which become 0
+ *   ts_w2v_add            y = a + b
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ts_w2v_layernorm_bwd_workspace(int64_t rows, int32_t c);
+int ts_w2v_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* dy, float eps, int64_t rows, int32_t c, float* dx,
+                         float* dgamma, float* dbeta, void* workspace, void* stream);
+int ts_w2v_colsum(const float* x, int64_t rows, int32_t c, int64_t ld, float* out, void* stream);
+int ts_w2v_gelu_fwd(const float* z, const float* bias, int32_t c, float* y, int64_t n, void* stream);
+int ts_w2v_gelu_bwd(const float* z, const float* bias, int32_t c, const float* dy, float* dz, int64_t n, void* stream);
+int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, float scale, void* stream);
+int ts_w2v_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t t, float scale, void* stream);
+int ts_w2v_pad_rows(const float* src, float* dst, int32_t batch, int32_t t, int32_t t_dst, int32_t left, int32_t c, int32_t extract, void* stream);
+int ts_w2v_mask_embed(float* x, const uint8_t* mask, const float* embed, float* dembed, int64_t rows, int32_t c, void* stream);
+int ts_w2v_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Squeeze-excite of the Citrinet blocks (eval): replaces SqueezeExcite.forward (citrinet/blocks.py:70-83: AdaptiveAvgPool1d

@@ -1,0 +1,171 @@
+"""GPU parity of wav2vec2 FINE-TUNING (thunder_speech_amd/huggingface/train.py, csrc/w2v_train.hip, csrc/gemm_f32.hip) against the REAL
+`transformers.Wav2Vec2Model` in train mode with torch autograd on the CPU: the reference fine-tunes HuggingFace checkpoints through
+BaseCTCModule.training_step with the conv feature extractor frozen (/root/reference/tests/huggingface/test_module_huggingface.py:33-54,
+src/thunder/huggingface/compatibility.py:23-42).  Seeded random weights (pretrained ones need the network); transformers 5.15 in this image
+(the reference pins 4.21: same modelling code for these layers)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+transformers = pytest.importorskip("transformers")
+
+BASE = dict(vocab_size=32, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, conv_dim=(32, 32, 32),
+            conv_stride=(5, 2, 2), conv_kernel=(10, 3, 2), num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, hidden_dropout=0.0,
+            activation_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0, final_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0,
+            mask_feature_prob=0.0)
+FAMILIES = {"group_postln": dict(feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False),
+            "layer_preln": dict(feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)}
+
+
+def _model(family, seed=0, **over):
+    torch.manual_seed(seed)
+    cfg = transformers.Wav2Vec2Config(**{**BASE, **FAMILIES[family], **over})
+    m = transformers.Wav2Vec2Model(cfg)
+    with torch.no_grad():                       # default init leaves the positional conv and LayerNorms near-trivial: make every parameter matter
+        for n, p in m.named_parameters():
+            if p.dim() == 1 and "bias" in n:
+                p.add_(0.05 * torch.randn_like(p))
+            elif "layer_norm.weight" in n:
+                p.mul_(1.0 + 0.1 * torch.randn_like(p))
+        if hasattr(m, "masked_spec_embed"):           # created only with mask_time_prob / mask_feature_prob > 0
+            m.masked_spec_embed.copy_(torch.randn_like(m.masked_spec_embed))
+    return m
+
+
+def _pair(family, seed=0, **over):
+    """(reference model on the CPU, the same weights behind the HIP adapter on the GPU), both in train mode, feature extractor frozen."""
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    ref = _model(family, seed, **over)
+    ref.freeze_feature_encoder()
+    ref.train()
+    mine = _model(family, seed, **over)
+    mine.load_state_dict(ref.state_dict())
+    adapt = HuggingFaceEncoderAdapt(mine, mask_input=over.get("mask_input", False), precision="fp32").cuda().train()
+    return ref, adapt
+
+
+def _inputs(b=3, n=4000, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(b, n, generator=g)
+
+
+def _compare_grads(ref, adapt, tol=3e-3):
+    mine = dict(adapt.original_encoder.named_parameters())
+    worst = 0.0
+    checked = 0
+    # k_proj.bias has NO true gradient (it shifts every score of a query by the same amount, which the softmax ignores): both sides hold rounding
+    # noise there, so gradients are measured against the larger of their own norm and 1e-4 of the largest gradient norm of the model
+    floor = 1e-4 * max(float(p.grad.norm()) for p in ref.parameters() if p.grad is not None)
+    for name, p in ref.named_parameters():
+        q = mine[name]
+        if not p.requires_grad:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0, name        # frozen feature extractor: no gradient
+            continue
+        assert p.grad is not None and q.grad is not None, name
+        denom = max(float(p.grad.norm()), floor)
+        rel = float((q.grad.cpu() - p.grad).norm()) / denom
+        worst = max(worst, rel)
+        assert rel <= tol, (name, rel)
+        checked += 1
+    assert checked > 20
+    return worst
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("masked", [False, True])
+def test_training_forward_and_every_gradient_match_transformers_autograd(family, masked):
+    """All dropouts off: last_hidden_state (5e-4) and the gradient of EVERY trainable parameter (relative L2 3e-3) of a scalar loss, with and
+    without an attention mask (ragged clips).  Covers LayerNorm / linear / attention / GELU / positional conv (weight-norm g and v) backward."""
+    ref, adapt = _pair(family)
+    adapt.mask_input = masked
+    x = _inputs()
+    lengths = torch.tensor([4000, 3000, 2111])
+    if masked:
+        x = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
+    att = (torch.arange(x.shape[1])[None, :] < lengths[:, None]).long() if masked else None
+    out_ref = ref(x, attention_mask=att).last_hidden_state
+    probe = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(5))
+    (out_ref * probe).sum().backward()
+    feats, out_len = adapt(x.cuda(), lengths.cuda())
+    assert feats.shape == (3, 64, out_ref.shape[1])
+    got = feats.transpose(-1, -2)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), out_ref.detach().numpy(), atol=5e-4, rtol=1e-4)
+    (got * probe.cuda()).sum().backward()
+    _compare_grads(ref, adapt)
+
+
+def test_time_masking_follows_transformers_under_the_same_numpy_seed():
+    """mask_time_prob > 0 (Wav2Vec2Model._mask_hidden_states): the span geometry is transformers' `_compute_mask_indices` restated on numpy's
+    global RNG, so the same seed masks the same frames -- outputs and gradients (incl. masked_spec_embed's) match."""
+    ref, adapt = _pair("group_postln", mask_time_prob=0.3, mask_time_length=3, mask_time_min_masks=2)
+    x = _inputs(b=2, n=6000, seed=2)
+    np.random.seed(11)
+    out_ref = ref(x).last_hidden_state
+    probe = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(6))
+    (out_ref * probe).sum().backward()
+    np.random.seed(11)
+    feats, _ = adapt(x.cuda(), torch.tensor([6000, 6000]).cuda())
+    got = feats.transpose(-1, -2)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), out_ref.detach().numpy(), atol=5e-4, rtol=1e-4)
+    (got * probe.cuda()).sum().backward()
+    _compare_grads(ref, adapt)
+    assert float(adapt.original_encoder.masked_spec_embed.grad.abs().max()) > 0
+
+
+def test_layerdrop_skips_the_same_layers_as_transformers_under_the_same_torch_seed():
+    ref, adapt = _pair("group_postln", layerdrop=0.5, num_hidden_layers=4)
+    x = _inputs(b=2, n=3000, seed=3)
+    torch.manual_seed(21)
+    out_ref = ref(x).last_hidden_state
+    torch.manual_seed(21)
+    feats, _ = adapt(x.cuda(), torch.tensor([3000, 3000]).cuda())
+    np.testing.assert_allclose(feats.transpose(-1, -2).detach().cpu().numpy(), out_ref.detach().numpy(), atol=5e-4, rtol=1e-4)
+
+
+def test_dropouts_are_random_scaled_and_differentiable():
+    """hidden / activation / attention / feature-projection dropout on the device's Philox stream: two forwards differ, the mean over many
+    elements is preserved (1 / (1 - p) scaling), the backward runs and reaches every trainable parameter."""
+    _, adapt = _pair("group_postln", hidden_dropout=0.1, activation_dropout=0.1, attention_dropout=0.1, feat_proj_dropout=0.1)
+    x = _inputs(b=2, n=4000, seed=4).cuda()
+    ln = torch.tensor([4000, 4000]).cuda()
+    a, _ = adapt(x, ln)
+    b, _ = adapt(x, ln)
+    assert not torch.equal(a, b) and torch.isfinite(a).all()
+    adapt.eval()
+    with torch.no_grad():
+        e, _ = adapt(x, ln)
+    adapt.train()
+    assert float((a.detach() - e).abs().mean()) < 0.5                           # LayerNorm-ed outputs of unit scale: dropout perturbs, it does not destroy
+    a.square().mean().backward()
+    for name, p in adapt.original_encoder.named_parameters():
+        if p.requires_grad and "masked_spec_embed" not in name:
+            assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, name
+
+
+def test_ctc_training_step_through_the_module_updates_the_transformer_and_not_the_feature_extractor():
+    """The reference's fine-tuning loop in miniature (tests/huggingface/test_module_huggingface.py:33-54): BaseCTCModule.training_step on an
+    HF encoder + linear decoder, three AdamW steps: the loss falls, the feature extractor's weights stay, the transformer's move."""
+    from thunder_speech_amd.blocks import linear_decoder
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    from thunder_speech_amd.huggingface.transform import Wav2Vec2Preprocess
+    from thunder_speech_amd.module import BaseCTCModule
+    from thunder_speech_amd.text_processing.transform import BatchTextTransformer
+    enc = HuggingFaceEncoderAdapt(_model("group_postln", seed=3), precision="fp32")
+    tokens = [chr(97 + i) for i in range(26)] + [" "]
+    module = BaseCTCModule(enc, linear_decoder(64, len(tokens) + 1, 0.0), Wav2Vec2Preprocess(), BatchTextTransformer(tokens=tokens),
+                           optimizer_kwargs={"lr": 1e-3}).cuda().train()
+    before = {n: p.detach().clone() for n, p in enc.original_encoder.named_parameters()}
+    opt = module.configure_optimizers()
+    batch = (_inputs(b=2, n=8000, seed=7).cuda(), torch.tensor([8000.0, 6000.0]).cuda(), ["hello world", "abc"])
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = module.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))
+    moved = {n: float((p.detach() - before[n]).abs().max()) for n, p in enc.original_encoder.named_parameters()}
+    assert all(v == 0.0 for n, v in moved.items() if n.startswith("feature_extractor."))
+    assert moved["encoder.layers.1.attention.q_proj.weight"] > 0 and moved["feature_projection.projection.weight"] > 0

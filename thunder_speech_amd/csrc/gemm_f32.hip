@@ -26,7 +26,9 @@ struct GemmF32Args {
   const void* a; const void* b; void* c; const float* bias;
   long long a_rs, a_cs, b_rs, b_cs;
   long long ldc;
-  long long sa, sb, sc;                              // batch strides (grid.z)
+  long long sa, sb, sc;                              // batch strides: grid.z = z1 * nb2 + z2, operand offset z1 * s? + z2 * s?2
+  long long sa2, sb2, sc2;
+  int nb2;
   long long ska, skb;                                // strides of the outer contraction loop
   int M, N, K, nkb;
   int beta, out_bf16;
@@ -103,9 +105,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int n_nt = (g.N + BN - 1) / BN;
   const int m0 = (blockIdx.x / n_nt) * BM, n0 = (blockIdx.x % n_nt) * BN;
-  const long long z = blockIdx.z;
-  const char* const a0 = static_cast<const char*>(g.a) + z * g.sa * (BF ? 2 : 4);
-  const char* const b0 = static_cast<const char*>(g.b) + z * g.sb * (BF ? 2 : 4);
+  const long long z1 = blockIdx.z / g.nb2, z2 = blockIdx.z % g.nb2;
+  const char* const a0 = static_cast<const char*>(g.a) + (z1 * g.sa + z2 * g.sa2) * (BF ? 2 : 4);
+  const char* const b0 = static_cast<const char*>(g.b) + (z1 * g.sb + z2 * g.sb2) * (BF ? 2 : 4);
   const int nks = (g.K + BK - 1) / BK, total = nks * g.nkb;
 
   f32x16 acc[2][2];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
     __syncthreads();
   }
   // epilogue: accumulator (i, j), register r: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
-  char* const c0 = static_cast<char*>(g.c) + z * g.sc * (g.out_bf16 ? 2 : 4);
+  char* const c0 = static_cast<char*>(g.c) + (z1 * g.sc + z2 * g.sc2) * (g.out_bf16 ? 2 : 4);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -182,23 +184,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
 // Strides in ELEMENTS; exactly one of (a_rs, a_cs) and one of (b_rs, b_cs) must be 1 (TS_EUNSUPPORTED otherwise).  An operand whose base is 16-byte
 // aligned (8 for bf16) and whose other strides are all multiples of 4 is fetched with vector loads -- a load may then reach 3 elements past the
 // logical extent of the contiguous index, which stays inside the row pitch and is masked to 0 -- any other operand element by element.
-int gemm_f32(hipStream_t stream, bool in_bf16, const void* a, long long a_rs, long long a_cs, long long sa, long long ska, const void* b,
-             long long b_rs, long long b_cs, long long sb, long long skb, void* c, long long ldc, long long sc, bool out_bf16, const float* bias,
-             int M, int N, int K, int nkb, int batch, bool beta) {
-  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || nkb <= 0 || batch <= 0 || ldc < N) return TS_EINVAL;
+// Two batch levels: grid.z = batch x batch2, operand offsets z1 s? + z2 s?2 ((clip, head) of the attention products; (group, tap) of the
+// positional conv's weight gradient).
+int gemm_f32_b2(hipStream_t stream, bool in_bf16, const void* a, long long a_rs, long long a_cs, long long sa, long long ska, const void* b,
+                long long b_rs, long long b_cs, long long sb, long long skb, void* c, long long ldc, long long sc, bool out_bf16, const float* bias,
+                int M, int N, int K, int nkb, int batch, bool beta, int batch2, long long sa2, long long sb2, long long sc2) {
+  if (!a || !b || !c || M <= 0 || N <= 0 || K <= 0 || nkb <= 0 || batch <= 0 || batch2 <= 0 || ldc < N) return TS_EINVAL;
+  if ((long long)batch * batch2 > 65535) return TS_EUNSUPPORTED;
   const bool a_kc = a_cs == 1, b_kc = b_rs == 1;
   if ((!a_kc && a_rs != 1) || (!b_kc && b_cs != 1)) return TS_EUNSUPPORTED;
   const long long a_ld = a_kc ? a_rs : a_cs, b_ld = b_kc ? b_cs : b_rs;
   const uintptr_t al = in_bf16 ? 7 : 15;
-  const bool vec_a = !(a_ld % 4 || sa % 4 || ska % 4 || (reinterpret_cast<uintptr_t>(a) & al));
-  const bool vec_b = !(b_ld % 4 || sb % 4 || skb % 4 || (reinterpret_cast<uintptr_t>(b) & al));
+  const bool vec_a = !(a_ld % 4 || sa % 4 || sa2 % 4 || ska % 4 || (reinterpret_cast<uintptr_t>(a) & al));
+  const bool vec_b = !(b_ld % 4 || sb % 4 || sb2 % 4 || skb % 4 || (reinterpret_cast<uintptr_t>(b) & al));
   GemmF32Args g{};
   g.a = a; g.b = b; g.c = c; g.bias = bias;
   g.a_rs = a_rs; g.a_cs = a_cs; g.b_rs = b_rs; g.b_cs = b_cs; g.ldc = ldc;
   g.sa = sa; g.sb = sb; g.sc = sc; g.ska = ska; g.skb = skb;
+  g.sa2 = sa2; g.sb2 = sb2; g.sc2 = sc2; g.nb2 = batch2;
   g.M = M; g.N = N; g.K = K; g.nkb = nkb; g.beta = beta ? 1 : 0; g.out_bf16 = out_bf16 ? 1 : 0;
   g.vec_a = vec_a ? 1 : 0; g.vec_b = vec_b ? 1 : 0;
-  const dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), 1, (unsigned)batch);
+  const dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), 1, (unsigned)(batch * batch2));
   (void)hipGetLastError();
 #define TS_GF(AK, BK_, BF_) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, BF_>), grid, dim3(256), 0, stream, g)
   if (in_bf16) {
@@ -210,6 +216,12 @@ int gemm_f32(hipStream_t stream, bool in_bf16, const void* a, long long a_rs, lo
   return hip_status(hipGetLastError());
 }
 
+int gemm_f32(hipStream_t stream, bool in_bf16, const void* a, long long a_rs, long long a_cs, long long sa, long long ska, const void* b,
+             long long b_rs, long long b_cs, long long sb, long long skb, void* c, long long ldc, long long sc, bool out_bf16, const float* bias,
+             int M, int N, int K, int nkb, int batch, bool beta) {
+  return gemm_f32_b2(stream, in_bf16, a, a_rs, a_cs, sa, ska, b, b_rs, b_cs, sb, skb, c, ldc, sc, out_bf16, bias, M, N, K, nkb, batch, beta, 1, 0, 0, 0);
+}
+
 }  // namespace ts
 
 /* C-ABI form (tests, tools); see include/thunder_speech_amd.h */
@@ -218,4 +230,12 @@ extern "C" int ts_gemm_f32(const void* a, int64_t a_rs, int64_t a_cs, int64_t sa
                            int32_t batch, int32_t in_bf16, int32_t out_bf16, int32_t beta, void* stream) {
   return ts::gemm_f32(reinterpret_cast<hipStream_t>(stream), in_bf16 != 0, a, a_rs, a_cs, sa, ska, b, b_rs, b_cs, sb, skb, c, ldc, sc, out_bf16 != 0,
                       bias, m, n, k, nkb, batch, beta != 0);
+}
+
+/* the same with a second batch level: grid.z = batch x batch2, operand offsets z1 s? + z2 s?2 */
+extern "C" int ts_gemm_f32_b2(const void* a, int64_t a_rs, int64_t a_cs, int64_t sa, int64_t sa2, int64_t ska, const void* b, int64_t b_rs, int64_t b_cs,
+                              int64_t sb, int64_t sb2, int64_t skb, void* c, int64_t ldc, int64_t sc, int64_t sc2, const float* bias, int32_t m,
+                              int32_t n, int32_t k, int32_t nkb, int32_t batch, int32_t batch2, int32_t beta, void* stream) {
+  return ts::gemm_f32_b2(reinterpret_cast<hipStream_t>(stream), false, a, a_rs, a_cs, sa, ska, b, b_rs, b_cs, sb, skb, c, ldc, sc, false, bias, m, n, k,
+                         nkb, batch, beta != 0, batch2, sa2, sb2, sc2);
 }

@@ -1,0 +1,333 @@
+// wav2vec2 fine-tuning: the backward kernels (and the few forward ones training needs on their own) of the transformer encoder.
+//
+// The reference fine-tunes HuggingFace CTC models through the same training_step as QuartzNet (module.py:102-127) with the conv feature
+// extractor frozen (huggingface/compatibility.py:27-28 -> transformers' freeze_feature_encoder), i.e. autograd runs through
+// feature_projection, the positional conv and the transformer layers of transformers.Wav2Vec2Model (third-party; forward restated in
+// oracle/w2v.py).  Here every product of that backward pass is the f32 matrix-core GEMM (csrc/gemm_f32.hip: N / T forms, batched over
+// (clip, head), the tap loop of the grouped positional conv as its outer contraction loop), and this file holds the rest:
+//   LayerNorm backward (dx, and per-wave partial sums of d gamma / d beta)          ts_w2v_layernorm_bwd
+//   column sums (bias gradients; the finish of d gamma / d beta)                    ts_w2v_colsum
+//   GELU forward / backward on the erf form the inference kernels use              ts_w2v_gelu_fwd / _bwd
+//   softmax forward (scaled, key-masked; P is saved) / backward                     ts_w2v_softmax_fwd / _bwd
+//   row padding / un-padding of the time axis (positional conv)                     ts_w2v_pad_rows
+//   train-time masking with the learned embedding (mask_time_prob)                  ts_w2v_mask_embed_fwd / _bwd
+//   y = a + b                                                                      ts_w2v_add
+// Activations are f32 [rows][c], contiguous (the reference's arithmetic); rows = clips x frames.
+#include "ts_common.hpp"
+
+namespace ts {
+
+namespace {
+
+__device__ __forceinline__ float erf_as(float x) {          // Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 (the inference kernels' erf)
+  const float ax = fabsf(x);
+  const float t = 1.f / (1.f + 0.3275911f * ax);
+  const float y = 1.f - (((((1.061405429f * t - 1.453152027f) * t) + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t * __expf(-ax * ax);
+  return x < 0.f ? -y : y;
+}
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erf_as(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float z) {
+  return 0.5f * (1.f + erf_as(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// LayerNorm backward, one wave per row, the row in registers (NV float4 per lane: c <= 256 NV).  s = x (+ res); xhat = (s - mean) rstd;
+// g = dy gamma; dx = rstd (g - mean(g) - xhat mean(g xhat)).  Every wave keeps the sums of dy xhat and dy over ITS rows in registers and
+// writes them once: part[wave][0][c] (d gamma), part[wave][1][c] (d beta); ts_w2v_colsum adds the waves' partials.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ part, long long rows,
+                                                     int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  f32x4 dg[NV], db[NV], gm[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    dg[j] = db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col = 4 * (lane + 64 * j);
+    gm[j] = col < c ? *reinterpret_cast<const f32x4*>(gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long long r = wave; r < rows; r += n_waves) {
+    f32x4 s[NV], g[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int col = 4 * (lane + 64 * j);
+      s[j] = g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col < c) {
+        s[j] = *reinterpret_cast<const f32x4*>(x + r * c + col);
+        if (res) s[j] += *reinterpret_cast<const f32x4*>(res + r * c + col);
+        g[j] = *reinterpret_cast<const f32x4*>(dy + r * c + col);
+      }
+      sum += s[j][0] + s[j][1] + s[j][2] + s[j][3];
+    }
+    const float mean = wave_sum(sum) / c;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int col = 4 * (lane + 64 * j);
+      if (col < c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[j][i] -= mean; var += s[j][i] * s[j][i]; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(var) / c + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[j][i] *= rstd;                               // xhat
+        dg[j][i] += g[j][i] * s[j][i];
+        db[j][i] += g[j][i];
+        g[j][i] *= gm[j][i];
+        m1 += g[j][i];
+        m2 += g[j][i] * s[j][i];
+      }
+    }
+    m1 = wave_sum(m1) / c;
+    m2 = wave_sum(m2) / c;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int col = 4 * (lane + 64 * j);
+      if (col < c) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rstd * (g[j][i] - m1 - s[j][i] * m2);
+        *reinterpret_cast<f32x4*>(dx + r * c + col) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int col = 4 * (lane + 64 * j);
+    if (col < c) {
+      *reinterpret_cast<f32x4*>(part + (wave * 2 + 0) * c + col) = dg[j];
+      *reinterpret_cast<f32x4*>(part + (wave * 2 + 1) * c + col) = db[j];
+    }
+  }
+}
+
+// out[j] (+)= sum_r x[r][j]: 256 threads = 64 column lanes x 4 row groups per workgroup; grid.y strides the rows; atomics add the groups' sums
+// into the zeroed (or accumulating) output.  Small (bias-sized) outputs: the atomic traffic is c per workgroup.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows, int c, long long ld) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < c)
+    for (long long r = (long long)blockIdx.y * 4 + rg; r < rows; r += (long long)gridDim.y * 4) s += x[r * ld + col];
+  __shared__ float sm[4][64];
+  sm[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && col < c) atomicAdd(out + col, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// y = gelu(z + bias[col]) (dy == NULL) or dz = dy gelu'(z + bias[col]); bias may be NULL; c % 4 == 0 with a bias
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ z, const float* __restrict__ bias, int c, const float* __restrict__ dy,
+                                                   float* __restrict__ out, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + i);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + (i % c));
+    f32x4 o;
+    if (dy) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = g[k] * gelu_df(v[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = gelu_f(v[k]);
+    }
+    *reinterpret_cast<f32x4*>(out + i) = o;
+  } else {
+    for (long long k = i; k < n; ++k) {
+      const float v = z[k] + (bias ? bias[k % c] : 0.f);
+      out[k] = dy ? dy[k] * gelu_df(v) : gelu_f(v);
+    }
+  }
+}
+
+// In-place softmax over the keys of one (clip, head, query) row per wave: p = softmax(scale s), keys >= key_len[clip] get probability 0
+// (transformers adds finfo.min to them: the same after the softmax unless every key is padded, which a clip with at least one frame rules out).
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ s, const int* __restrict__ key_len, int heads, int t, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (row >= (long long)heads * t) return;
+  float* p = s + ((long long)b * heads * t + row) * t;
+  const int nk = key_len ? min(key_len[b], t) : t;
+  float mx = -3.0e38f;
+  for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, p[j] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int j = lane; j < nk; j += 64) sum += __expf(p[j] * scale - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int j = lane; j < t; j += 64) p[j] = j < nk ? __expf(p[j] * scale - mx) * inv : 0.f;
+}
+
+// ds = scale p (dp - sum_k dp_k p_k), in place over dp; one wave per row
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long long rows, int t, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pr = p + row * t;
+  float* dr = dp + row * t;
+  float dot = 0.f;
+  for (int j = lane; j < t; j += 64) dot += pr[j] * dr[j];
+  dot = wave_sum(dot);
+  for (int j = lane; j < t; j += 64) dr[j] = scale * pr[j] * (dr[j] - dot);
+}
+
+// dst[b][r + left][:] = src[b][r][:] for r < t, every other row of dst (t_dst rows per clip) = 0; with `extract` the other way round:
+// dst[b][r][:] (t rows) = src[b][r + left][:] (src has t_dst rows per clip)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int t, int t_dst, int left, int c, int extract) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int b = blockIdx.y;
+  const long long n = (long long)(extract ? t : t_dst) * c;
+  if (i >= n) return;
+  const int r = (int)(i / c), col = (int)(i % c);
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (extract) {
+    v = *reinterpret_cast<const f32x4*>(src + ((long long)b * t_dst + r + left) * c + col);
+    *reinterpret_cast<f32x4*>(dst + ((long long)b * t + r) * c + col) = v;
+  } else {
+    if (r >= left && r < left + t) v = *reinterpret_cast<const f32x4*>(src + ((long long)b * t + r - left) * c + col);
+    *reinterpret_cast<f32x4*>(dst + ((long long)b * t_dst + r) * c + col) = v;
+  }
+}
+
+// forward: rows with mask != 0 <- embed.  backward: dx = dy with those rows zeroed (in place over dy is fine), dembed += sum of dy over them.
+__global__ __launch_bounds__(256) void mask_embed_kernel(float* __restrict__ x, const unsigned char* __restrict__ mask, const float* __restrict__ embed,
+                                                         float* __restrict__ dembed, long long rows, int c) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= rows * c) return;
+  const long long r = i / c;
+  const int col = (int)(i % c);
+  if (!mask[r]) return;
+  float* px = x + i;
+  if (dembed) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { atomicAdd(dembed + col + k, px[k]); px[k] = 0.f; }
+  } else {
+    *reinterpret_cast<f32x4*>(px) = *reinterpret_cast<const f32x4*>(embed + col);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) *reinterpret_cast<f32x4*>(y + i) = *reinterpret_cast<const f32x4*>(a + i) + *reinterpret_cast<const f32x4*>(b + i);
+  else for (long long k = i; k < n; ++k) y[k] = a[k] + b[k];
+}
+
+inline unsigned blk4(long long n) { return (unsigned)(((n + 3) / 4 + 255) / 256); }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace ts
+
+using namespace ts;
+#define TS_STREAM hipStream_t stream = reinterpret_cast<hipStream_t>(stream_); (void)hipGetLastError()
+
+extern "C" int64_t ts_w2v_layernorm_bwd_workspace(int64_t rows, int32_t c) {
+  if (rows <= 0 || c <= 0) return TS_EINVAL;
+  const long long waves = (rows < 4096 ? (rows + 3) / 4 * 4 : 4096);
+  return (int64_t)waves * 2 * c * sizeof(float);
+}
+
+/* dx [rows][c]; dgamma, dbeta [c] are ADDED to (zero them, or pass the parameter's gradient); workspace: ts_w2v_layernorm_bwd_workspace bytes */
+extern "C" int ts_w2v_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* dy, float eps, int64_t rows, int32_t c, float* dx,
+                                    float* dgamma, float* dbeta, void* workspace, void* stream_) {
+  if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || c <= 0) return TS_EINVAL;
+  if (c % 4 || c > 4096 || !al16(x) || !al16(dy) || !al16(dx) || !al16(gamma) || (res && !al16(res)) || !al16(workspace)) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  const long long waves = (rows < 4096 ? (rows + 3) / 4 * 4 : 4096);
+  float* part = static_cast<float*>(workspace);
+  const dim3 grid((unsigned)(waves / 4));
+#define TS_LNB(NV_) hipLaunchKernelGGL(ln_bwd_kernel<NV_>, grid, dim3(256), 0, stream, x, res, gamma, dy, dx, part, (long long)rows, c, eps)
+  if (c <= 512) TS_LNB(2); else if (c <= 1024) TS_LNB(4); else if (c <= 2048) TS_LNB(8); else TS_LNB(16);
+#undef TS_LNB
+  // partials [waves][2][c]: even rows are d gamma, odd rows d beta
+  const dim3 cg((c + 63) / 64, 16);
+  hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, stream, part, dgamma, waves, c, (long long)2 * c);
+  hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, stream, part + c, dbeta, waves, c, (long long)2 * c);
+  return hip_status(hipGetLastError());
+}
+
+/* out[j] += sum_r x[r * ld + j], j < c */
+extern "C" int ts_w2v_colsum(const float* x, int64_t rows, int32_t c, int64_t ld, float* out, void* stream_) {
+  if (!x || !out || rows <= 0 || c <= 0 || ld < c) return TS_EINVAL;
+  TS_STREAM;
+  const unsigned gy = (unsigned)(rows >= 4096 ? 256 : (rows + 15) / 16);
+  hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, gy ? gy : 1), dim3(256), 0, stream, x, out, (long long)rows, c, (long long)ld);
+  return hip_status(hipGetLastError());
+}
+
+/* y = gelu(z + bias[col]) over [rows][c] (n = rows * c elements); bias may be NULL */
+extern "C" int ts_w2v_gelu_fwd(const float* z, const float* bias, int32_t c, float* y, int64_t n, void* stream_) {
+  if (!z || !y || n <= 0 || (bias && (c <= 0 || n % c))) return TS_EINVAL;
+  if (!al16(z) || !al16(y) || (bias && (c % 4 || !al16(bias)))) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  hipLaunchKernelGGL(gelu_kernel, dim3(blk4(n)), dim3(256), 0, stream, z, bias, c, (const float*)nullptr, y, (long long)n);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_gelu_bwd(const float* z, const float* bias, int32_t c, const float* dy, float* dz, int64_t n, void* stream_) {
+  if (!z || !dy || !dz || n <= 0 || (bias && (c <= 0 || n % c))) return TS_EINVAL;
+  if (!al16(z) || !al16(dy) || !al16(dz) || (bias && (c % 4 || !al16(bias)))) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  hipLaunchKernelGGL(gelu_kernel, dim3(blk4(n)), dim3(256), 0, stream, z, bias, c, dy, dz, (long long)n);
+  return hip_status(hipGetLastError());
+}
+
+/* s f32 [batch][heads][t][t] scores -> probabilities in place; key_len int32 [batch] or NULL */
+extern "C" int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, float scale, void* stream_) {
+  if (!s || batch <= 0 || heads <= 0 || t <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)(((long long)heads * t + 3) / 4), batch), dim3(256), 0, stream, s, key_len, heads, t, scale);
+  return hip_status(hipGetLastError());
+}
+
+/* dp [rows][t] -> d scores in place: scale p (dp - <dp, p>) */
+extern "C" int ts_w2v_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t t, float scale, void* stream_) {
+  if (!p || !dp || rows <= 0 || t <= 0) return TS_EINVAL;
+  TS_STREAM;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p, dp, (long long)rows, t, scale);
+  return hip_status(hipGetLastError());
+}
+
+/* extract = 0: dst [batch][t_dst][c] = src [batch][t][c] moved down by `left` rows, zeros around; 1: dst [batch][t][c] = rows left .. left + t of src */
+extern "C" int ts_w2v_pad_rows(const float* src, float* dst, int32_t batch, int32_t t, int32_t t_dst, int32_t left, int32_t c, int32_t extract,
+                               void* stream_) {
+  if (!src || !dst || batch <= 0 || t <= 0 || t_dst < t + left || left < 0 || c <= 0) return TS_EINVAL;
+  if (c % 4 || !al16(src) || !al16(dst)) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  const long long n = (long long)(extract ? t : t_dst) * c;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(blk4(n), batch), dim3(256), 0, stream, src, dst, t, t_dst, left, c, extract);
+  return hip_status(hipGetLastError());
+}
+
+/* forward (dembed NULL): x[r][:] = embed for every row with mask[r] != 0.  backward (embed NULL): x is dy: dembed += its masked rows, which become 0 */
+extern "C" int ts_w2v_mask_embed(float* x, const uint8_t* mask, const float* embed, float* dembed, int64_t rows, int32_t c, void* stream_) {
+  if (!x || !mask || (!embed == !dembed) || rows <= 0 || c <= 0) return TS_EINVAL;
+  if (c % 4 || !al16(x) || (embed && !al16(embed))) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  hipLaunchKernelGGL(mask_embed_kernel, dim3(blk4((long long)rows * c)), dim3(256), 0, stream, x, mask, embed, dembed, (long long)rows, c);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_add(const float* a, const float* b, float* y, int64_t n, void* stream_) {
+  if (!a || !b || !y || n <= 0) return TS_EINVAL;
+  if (!al16(a) || !al16(b) || !al16(y)) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  hipLaunchKernelGGL(add_kernel, dim3(blk4(n)), dim3(256), 0, stream, a, b, y, (long long)n);
+  return hip_status(hipGetLastError());
+}

@@ -5,7 +5,8 @@ src/thunder/huggingface/compatibility.py:31-42: `self.original_encoder(audio, at
 `last_hidden_state.transpose(-1, -2)` and `_get_feat_extract_output_lengths`).  Here the transformers module only OWNS the
 weights (same attribute name `original_encoder`, same state-dict keys, so checkpoints and fine-tuning code see no
 difference); the arithmetic runs in `Wav2Vec2Plan`, which keeps packed fp32 device copies of the weights and issues one C-ABI
-call per stage.  Group-norm / post-LN configurations only (wav2vec2-base-960h, -large-960h); no CPU fallback."""
+call per stage.  Both published families (group-norm / post-LN: wav2vec2-base-960h, -large-960h; layer-norm / pre-LN: -large-lv60, xlsr);
+training mode (fine-tuning with the conv feature extractor frozen) runs through huggingface/train.py; no CPU fallback."""
 from __future__ import annotations
 
 import os
@@ -276,11 +277,23 @@ class HuggingFaceEncoderAdapt(nn.Module):
         params = list(self.original_encoder.parameters())
         return self._cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, self.original_encoder.state_dict(), device, self.precision))
 
+    def _plan_frozen(self, device) -> Wav2Vec2Plan:
+        """The plan the training path runs the frozen conv feature extractor on: keyed on the feature extractor's parameters only, so an
+        optimizer step on the transformer does not re-pack anything."""
+        if not hasattr(self, "_fe_cache"):
+            self._fe_cache = _PackedCache()
+        params = list(self.original_encoder.feature_extractor.parameters())
+        return self._fe_cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, self.original_encoder.state_dict(), device, self.precision))
+
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "wav2vec2 encoder")
-        if self.training:
-            raise NotImplementedError("wav2vec2 HIP path: inference only (no backward kernels yet); call .eval()")
         x = audio.to(torch.float32).contiguous()
-        h = self._plan(x.device).forward(x, audio_lengths if self.mask_input else None)
+        if self.training:
+            # fine-tuning (module.py:102-127 through this adapter): transformers' training-mode forward -- frozen conv feature extractor, time
+            # masking, dropouts, LayerDrop -- as a chain of autograd nodes on the HIP kernels (huggingface/train.py), f32 arithmetic
+            from .train import train_forward
+            h = train_forward(self, x, audio_lengths if self.mask_input else None)
+        else:
+            h = self._plan(x.device).forward(x, audio_lengths if self.mask_input else None)
         cfg = self.original_encoder.config
         return h.transpose(-1, -2), feat_extract_output_lengths(cfg.conv_kernel, cfg.conv_stride, audio_lengths)

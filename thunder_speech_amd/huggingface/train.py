@@ -1,0 +1,437 @@
+"""wav2vec2 fine-tuning on the HIP kernels: the training-mode forward of `transformers.Wav2Vec2Model` as a chain of autograd nodes whose
+forward and backward are C-ABI launches (csrc/gemm_f32.hip for every product, csrc/w2v_train.hip for the rest).
+
+The reference fine-tunes HuggingFace CTC checkpoints through `BaseCTCModule.training_step` (src/thunder/module.py:102-127) with the conv feature
+extractor frozen (`_HuggingFaceEncoderAdapt.__init__`, src/thunder/huggingface/compatibility.py:27-28 -> `freeze_feature_encoder()`); autograd
+then runs through feature_projection, the train-time time masking (`mask_time_prob`), the weight-normalised positional conv and the transformer
+layers with their dropouts and LayerDrop (transformers' modeling_wav2vec2.py: Wav2Vec2Model.forward, Wav2Vec2Encoder /
+Wav2Vec2EncoderStableLayerNorm; forward restated for eval mode in oracle/w2v.py).  This module restates that training-mode forward on
+time-major f32 activations [B, T, C] (the reference's arithmetic) and owns the backward: PyTorch only chains the nodes and accumulates the
+parameters' .grad; no ATen kernel touches an activation.  The parameters stay the transformers module's own (`original_encoder`, reference
+state-dict keys), so optimizers and checkpoints see no difference.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _lib
+from ..rng import next_seed
+
+
+def _s(t: Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _f32c(t: Tensor) -> Tensor:
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
+def _gemm(a, a_rs, a_cs, b, b_rs, b_cs, c, ldc, m, n, k, *, sa=0, sa2=0, ska=0, sb=0, sb2=0, skb=0, sc=0, sc2=0, bias=None, nkb=1, batch=1,
+          batch2=1, beta=False, a_off=0, b_off=0, c_off=0):
+    """C (+)= A . B on ts_gemm_f32_b2 (element strides; *_off = element offsets into the tensors)."""
+    st = _lib.lib().ts_gemm_f32_b2(a.data_ptr() + 4 * a_off, a_rs, a_cs, sa, sa2, ska, b.data_ptr() + 4 * b_off, b_rs, b_cs, sb, sb2, skb,
+                                   c.data_ptr() + 4 * c_off, ldc, sc, sc2, bias.data_ptr() if bias is not None else None, m, n, k, nkb, batch, batch2,
+                                   int(beta), _s(c))
+    _lib.check(st, "ts_gemm_f32_b2")
+
+
+def _colsum(x: Tensor, rows: int, c: int) -> Tensor:
+    out = torch.zeros(c, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ts_w2v_colsum(x.data_ptr(), rows, c, c, out.data_ptr(), _s(x)), "ts_w2v_colsum")
+    return out
+
+
+class Linear(torch.autograd.Function):
+    """y = x W^T + b over the last axis (nn.Linear)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _f32c(x), _f32c(w)
+        n, k = w.shape
+        rows = x.numel() // k
+        y = torch.empty(*x.shape[:-1], n, dtype=torch.float32, device=x.device)
+        _gemm(x, k, 1, w, 1, k, y, n, rows, n, k, bias=_f32c(b) if b is not None else None)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, k = w.shape
+        rows = x.numel() // k
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gemm(dy, n, 1, w, k, 1, dx, k, rows, k, n)                     # dx[r][k] = sum_n dy[r][n] W[n][k]
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            _gemm(dy, 1, n, x, k, 1, dw, k, n, k, rows)                     # dW[n][k] = sum_r dy[r][n] x[r][k]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, rows, n)
+        return dx, dw, db
+
+
+class LayerNorm(torch.autograd.Function):
+    """y = LayerNorm(x (+ res)) over the last axis; the residual add rides in the launch (both inputs receive the same gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        x = _f32c(x)
+        res = _f32c(res) if res is not None else None
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = torch.empty_like(x)
+        st = _lib.lib().ts_w2v_layernorm_fwd(x.data_ptr(), res.data_ptr() if res is not None else None, None, gamma.data_ptr(), beta.data_ptr(), eps,
+                                             rows, c, 0, y.data_ptr(), None, _s(x))
+        _lib.check(st, "ts_w2v_layernorm_fwd")
+        ctx.save_for_backward(x, res, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, gamma = ctx.saved_tensors
+        dy = _f32c(dy)
+        c = x.shape[-1]
+        rows = x.numel() // c
+        L = _lib.lib()
+        dx = torch.empty_like(x)
+        dg = torch.zeros(c, dtype=torch.float32, device=x.device)
+        db = torch.zeros(c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.ts_w2v_layernorm_bwd_workspace(rows, c), dtype=torch.uint8, device=x.device)
+        st = L.ts_w2v_layernorm_bwd(x.data_ptr(), res.data_ptr() if res is not None else None, gamma.data_ptr(), dy.data_ptr(), ctx.eps, rows, c,
+                                    dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), _s(x))
+        _lib.check(st, "ts_w2v_layernorm_bwd")
+        return dx, (dx if res is not None else None), dg, db, None
+
+
+class BiasGelu(torch.autograd.Function):
+    """gelu(z + b), erf form; b may be None."""
+
+    @staticmethod
+    def forward(ctx, z, b):
+        z = _f32c(z)
+        c = z.shape[-1]
+        y = torch.empty_like(z)
+        _lib.check(_lib.lib().ts_w2v_gelu_fwd(z.data_ptr(), b.data_ptr() if b is not None else None, c, y.data_ptr(), z.numel(), _s(z)), "ts_w2v_gelu_fwd")
+        ctx.save_for_backward(z, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, b = ctx.saved_tensors
+        dy = _f32c(dy)
+        c = z.shape[-1]
+        dz = torch.empty_like(z)
+        _lib.check(_lib.lib().ts_w2v_gelu_bwd(z.data_ptr(), b.data_ptr() if b is not None else None, c, dy.data_ptr(), dz.data_ptr(), z.numel(), _s(z)),
+                   "ts_w2v_gelu_bwd")
+        db = _colsum(dz, z.numel() // c, c) if (b is not None and ctx.needs_input_grad[1]) else None
+        return dz, db
+
+
+class Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        y = torch.empty_like(a)
+        _lib.check(_lib.lib().ts_w2v_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _s(a)), "ts_w2v_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class Dropout(torch.autograd.Function):
+    """nn.Dropout on the device's Philox stream (ts_train_dropout): the backward re-draws the mask from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _f32c(x)
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        st = _lib.lib().ts_train_dropout(x.data_ptr(), y.data_ptr(), x.numel() // c, c, c, float(p), int(seed), None, 0, _s(x))
+        _lib.check(st, "ts_train_dropout")
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy)
+        c = dy.shape[-1]
+        dx = torch.empty_like(dy)
+        st = _lib.lib().ts_train_dropout(dy.data_ptr(), dx.data_ptr(), dy.numel() // c, c, c, float(ctx.p), int(ctx.seed), None, 0, _s(dy))
+        _lib.check(st, "ts_train_dropout")
+        return dx, None, None
+
+
+def dropout(x: Tensor, p: float) -> Tensor:
+    return Dropout.apply(x, p, next_seed()) if p > 0.0 else x
+
+
+class MaskRows(torch.autograd.Function):
+    """hidden_states[~attention_mask] = 0 (rows >= key_len[clip]); linear, so the backward is the same masking of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, key_len):
+        y = _f32c(x).clone()
+        b, t, c = y.shape
+        _lib.check(_lib.lib().ts_w2v_mask_rows(y.data_ptr(), b, t, c, key_len.data_ptr(), _s(y)), "ts_w2v_mask_rows")
+        ctx.save_for_backward(key_len)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (key_len,) = ctx.saved_tensors
+        dx = _f32c(dy).clone()
+        b, t, c = dx.shape
+        _lib.check(_lib.lib().ts_w2v_mask_rows(dx.data_ptr(), b, t, c, key_len.data_ptr(), _s(dx)), "ts_w2v_mask_rows")
+        return dx, None
+
+
+class MaskEmbed(torch.autograd.Function):
+    """hidden_states[mask_time_indices] = masked_spec_embed (Wav2Vec2Model._mask_hidden_states)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, embed):
+        y = _f32c(x).clone()
+        c = y.shape[-1]
+        _lib.check(_lib.lib().ts_w2v_mask_embed(y.data_ptr(), mask.data_ptr(), _f32c(embed).data_ptr(), None, y.numel() // c, c, _s(y)), "ts_w2v_mask_embed")
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dx = _f32c(dy).clone()
+        c = dx.shape[-1]
+        de = torch.zeros(c, dtype=torch.float32, device=dx.device)
+        _lib.check(_lib.lib().ts_w2v_mask_embed(dx.data_ptr(), mask.data_ptr(), None, de.data_ptr(), dx.numel() // c, c, _s(dx)), "ts_w2v_mask_embed")
+        return dx, None, de
+
+
+class Attention(torch.autograd.Function):
+    """Multi-head self-attention on a fused qkv tensor [B, T, 3C] (q | k | v thirds, head h = columns [h hd, (h + 1) hd) of each):
+    ctx = dropout(softmax(q k^T / sqrt(hd), keys >= key_len masked)) v.  The probabilities are kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_len, heads, p_drop, seed):
+        qkv = _f32c(qkv)
+        b, t, c3 = qkv.shape
+        c = c3 // 3
+        hd = c // heads
+        L = _lib.lib()
+        p = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
+        # scores[b][h][q][k] = q . k
+        _gemm(qkv, c3, 1, qkv, 1, c3, p, t, t, t, hd, sa=t * c3, sa2=hd, sb=t * c3, sb2=hd, sc=heads * t * t, sc2=t * t, batch=b, batch2=heads, b_off=c)
+        _lib.check(L.ts_w2v_softmax_fwd(p.data_ptr(), key_len.data_ptr() if key_len is not None else None, b, heads, t, hd ** -0.5, _s(p)),
+                   "ts_w2v_softmax_fwd")
+        pd = p
+        if p_drop > 0.0:
+            pd = torch.empty_like(p)
+            _lib.check(L.ts_train_dropout(p.data_ptr(), pd.data_ptr(), b * heads * t, t, t, float(p_drop), int(seed), None, 0, _s(p)), "ts_train_dropout")
+        out = torch.empty(b, t, c, dtype=torch.float32, device=qkv.device)
+        _gemm(pd, t, 1, qkv, c3, 1, out, c, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c3, sb2=hd, sc=t * c, sc2=hd, batch=b, batch2=heads, b_off=2 * c)
+        ctx.save_for_backward(qkv, p, pd if p_drop > 0.0 else None)
+        ctx.geom = (heads, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, p, pd = ctx.saved_tensors
+        heads, p_drop, seed = ctx.geom
+        dout = _f32c(dout)
+        b, t, c3 = qkv.shape
+        c = c3 // 3
+        hd = c // heads
+        L = _lib.lib()
+        pv = pd if pd is not None else p
+        dqkv = torch.empty_like(qkv)
+        bh = dict(batch=b, batch2=heads)
+        # dV[k][d] = sum_q P'[q][k] dout[q][d]
+        _gemm(pv, 1, t, dout, c, 1, dqkv, c3, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c, sb2=hd, sc=t * c3, sc2=hd, c_off=2 * c, **bh)
+        # dP'[q][k] = sum_d dout[q][d] v[k][d]
+        dp = torch.empty_like(p)
+        _gemm(dout, c, 1, qkv, 1, c3, dp, t, t, t, hd, sa=t * c, sa2=hd, sb=t * c3, sb2=hd, sc=heads * t * t, sc2=t * t, b_off=2 * c, **bh)
+        if p_drop > 0.0:
+            _lib.check(L.ts_train_dropout(dp.data_ptr(), dp.data_ptr(), b * heads * t, t, t, float(p_drop), int(seed), None, 0, _s(dp)), "ts_train_dropout")
+        _lib.check(L.ts_w2v_softmax_bwd(p.data_ptr(), dp.data_ptr(), b * heads * t, t, hd ** -0.5, _s(dp)), "ts_w2v_softmax_bwd")
+        # dQ[q][d] = sum_k dS[q][k] k[k][d];  dK[k][d] = sum_q dS[q][k] q[q][d]
+        _gemm(dp, t, 1, qkv, c3, 1, dqkv, c3, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c3, sb2=hd, sc=t * c3, sc2=hd, b_off=c, **bh)
+        _gemm(dp, 1, t, qkv, c3, 1, dqkv, c3, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c3, sb2=hd, sc=t * c3, sc2=hd, c_off=c, **bh)
+        return dqkv, None, None, None, None
+
+
+class PosConvGelu(torch.autograd.Function):
+    """y = x + gelu(grouped_conv1d(x, w, padding = k // 2)[..., :T] + b) (Wav2Vec2PositionalConvEmbedding + the residual add).
+    wk: the effective (weight-normalised) conv weight as [k][groups][out][in] f32 -- computed from (g, v) by torch ops on the PARAMETERS, so that
+    autograd carries d wk back through the weight norm; x [B, T, C] time-major.  The conv and both of its gradients are ONE GEMM launch each: the
+    tap loop is the GEMM's outer contraction loop (forward, data gradient) or its second batch level (weight gradient) over a zero-padded copy
+    of the rows."""
+
+    @staticmethod
+    def forward(ctx, x, wk, bias):
+        x, wk, bias = _f32c(x), _f32c(wk), _f32c(bias)
+        b, t, c = x.shape
+        k, g, cg, _ = wk.shape
+        L = _lib.lib()
+        tp = t + k
+        xp = torch.empty(b, tp, c, dtype=torch.float32, device=x.device)
+        _lib.check(L.ts_w2v_pad_rows(x.data_ptr(), xp.data_ptr(), b, t, tp, k // 2, c, 0, _s(x)), "ts_w2v_pad_rows")
+        m = b * tp - k                                                   # rows of the padded row space that have all k taps
+        zp = torch.zeros(b, tp, c, dtype=torch.float32, device=x.device)
+        # zp[r][g cg + o] = sum_j sum_i xp[r + j][g cg + i] wk[j][g][o][i]
+        _gemm(xp, c, 1, wk, 1, cg, zp, c, m, cg, cg, sa=cg, ska=c, sb=cg * cg, skb=g * cg * cg, sc=cg, nkb=k, batch=g)
+        z = torch.empty_like(x)
+        _lib.check(L.ts_w2v_pad_rows(zp.data_ptr(), z.data_ptr(), b, t, tp, 0, c, 1, _s(x)), "ts_w2v_pad_rows")
+        a = torch.empty_like(x)
+        _lib.check(L.ts_w2v_gelu_fwd(z.data_ptr(), bias.data_ptr(), c, a.data_ptr(), z.numel(), _s(x)), "ts_w2v_gelu_fwd")
+        y = torch.empty_like(x)
+        _lib.check(L.ts_w2v_add(x.data_ptr(), a.data_ptr(), y.data_ptr(), x.numel(), _s(x)), "ts_w2v_add")
+        ctx.save_for_backward(xp, z, wk, bias)
+        ctx.geom = (b, t, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, z, wk, bias = ctx.saved_tensors
+        b, t, c = ctx.geom
+        k, g, cg, _ = wk.shape
+        dy = _f32c(dy)
+        L = _lib.lib()
+        tp = t + k
+        m = b * tp - k
+        dz = torch.empty_like(dy)
+        _lib.check(L.ts_w2v_gelu_bwd(z.data_ptr(), bias.data_ptr(), c, dy.data_ptr(), dz.data_ptr(), dz.numel(), _s(dy)), "ts_w2v_gelu_bwd")
+        db = _colsum(dz, b * t, c) if ctx.needs_input_grad[2] else None
+        # d zp in the padded row space behind k - 1 zero rows: dbuf[k - 1 + r] = d zp[r]
+        dbuf = torch.empty((k - 1) + b * tp, c, dtype=torch.float32, device=dy.device)
+        dbuf[: k - 1].zero_()
+        dzp = dbuf[k - 1:].view(b, tp, c)
+        _lib.check(L.ts_w2v_pad_rows(dz.data_ptr(), dzp.data_ptr(), b, t, tp, 0, c, 0, _s(dy)), "ts_w2v_pad_rows")
+        dx = dwk = None
+        if ctx.needs_input_grad[0]:
+            # d xp[q][g cg + i] = sum_j' sum_o dbuf[q + j'][g cg + o] wk[k - 1 - j'][g][o][i]
+            dxp = torch.empty(b, tp, c, dtype=torch.float32, device=dy.device)
+            _gemm(dbuf, c, 1, wk, cg, 1, dxp, c, b * tp, cg, cg, sa=cg, ska=c, sb=cg * cg, skb=-g * cg * cg, sc=cg, nkb=k, batch=g,
+                  b_off=(k - 1) * g * cg * cg)
+            dconv = torch.empty_like(dy)
+            _lib.check(L.ts_w2v_pad_rows(dxp.data_ptr(), dconv.data_ptr(), b, t, tp, k // 2, c, 1, _s(dy)), "ts_w2v_pad_rows")
+            dx = torch.empty_like(dy)
+            _lib.check(L.ts_w2v_add(dy.data_ptr(), dconv.data_ptr(), dx.data_ptr(), dy.numel(), _s(dy)), "ts_w2v_add")
+        if ctx.needs_input_grad[1]:
+            # d wk[j][g][o][i] = sum_r d zp[r][g cg + o] xp[r + j][g cg + i]   (rows between the clips hold d zp = 0)
+            dwk = torch.empty_like(wk)
+            _gemm(dzp, 1, c, xp, c, 1, dwk, cg, cg, cg, m, sa=cg, sa2=0, sb=cg, sb2=c, sc=cg * cg, sc2=g * cg * cg, batch=g, batch2=k)
+        return dx, dwk, db
+
+
+def compute_mask_indices(batch: int, t: int, mask_prob: float, mask_length: int, lengths=None, min_masks: int = 0) -> np.ndarray:
+    """SpecAugment-style time masks of transformers' `_compute_mask_indices` (modeling_wav2vec2.py; the published algorithm, numpy's global
+    RNG like the original): per clip, `int(mask_prob * len / mask_length + eps)` spans (at least `min_masks`) of `mask_length` frames at distinct
+    random starts; clips with fewer spans repeat their first one.  Returns bool [batch, t]."""
+    if mask_length < 1:
+        raise ValueError("`mask_length` has to be bigger than 0.")
+    if mask_length > t:
+        raise ValueError(f"`mask_length` has to be smaller than `sequence_length`, but got `mask_length`: {mask_length} and `sequence_length`: {t}`")
+    eps = np.random.rand(1).item()
+
+    def n_spans(n):
+        k = max(int(mask_prob * n / mask_length + eps), min_masks)
+        if k * mask_length > t:
+            k = t // mask_length
+        if n - (mask_length - 1) < k:
+            k = max(n - (mask_length - 1), 0)
+        return k
+
+    lens = [t] * batch if lengths is None else [int(v) for v in lengths]
+    mask = np.zeros((batch, t), dtype=bool)
+    k_max = n_spans(t)
+    if k_max == 0:
+        return mask
+    for i, n in enumerate(lens):
+        k = n_spans(n)
+        starts = np.random.choice(np.arange(n - (mask_length - 1)), k, replace=False)
+        fill = t - 1 if len(starts) == 0 else starts[0]
+        starts = np.concatenate([starts, np.full(k_max - k, fill, dtype=np.int64)]).astype(np.int64)
+        idx = (starts[:, None] + np.arange(mask_length)[None, :]).reshape(-1)
+        mask[i, np.minimum(idx, t - 1)] = True
+    return mask
+
+
+def train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
+    """Training-mode Wav2Vec2Model.forward -> last_hidden_state [B, T', C] (f32, time-major).  `adapt`: the HuggingFaceEncoderAdapt module
+    (its `original_encoder` owns the parameters)."""
+    from .encoder import feat_extract_output_lengths
+    enc = adapt.original_encoder
+    cfg = enc.config
+    dev = audio.device
+    if float(getattr(cfg, "mask_feature_prob", 0.0)) > 0.0 and getattr(cfg, "apply_spec_augment", True):
+        raise NotImplementedError("wav2vec2 HIP training path: mask_feature_prob > 0 is not supported")
+    plan = adapt._plan_frozen(dev)
+    with torch.no_grad():                                   # frozen conv feature extractor (compatibility.py:27-28): the inference kernels
+        feats = plan.feature_extractor(audio)
+    b, t, _ = feats.shape
+    c, heads = int(cfg.hidden_size), int(cfg.num_attention_heads)
+    eps = float(cfg.layer_norm_eps)
+    fp, en = enc.feature_projection, enc.encoder
+    h = LayerNorm.apply(feats, None, fp.layer_norm.weight, fp.layer_norm.bias, eps)
+    h = Linear.apply(h, fp.projection.weight, fp.projection.bias)
+    h = dropout(h, float(cfg.feat_proj_dropout))
+    key_len = None
+    if lengths is not None:
+        key_len = feat_extract_output_lengths(cfg.conv_kernel, cfg.conv_stride, lengths.to(dev).long()).to(torch.int32).contiguous()
+    if getattr(cfg, "apply_spec_augment", True) and float(cfg.mask_time_prob) > 0.0:
+        m = compute_mask_indices(b, t, float(cfg.mask_time_prob), int(cfg.mask_time_length), None if key_len is None else key_len.tolist(),
+                                 int(getattr(cfg, "mask_time_min_masks", 2)))
+        if m.any():
+            h = MaskEmbed.apply(h, torch.from_numpy(m.astype(np.uint8)).to(dev), enc.masked_spec_embed)
+    if key_len is not None:
+        h = MaskRows.apply(h, key_len)
+    # positional conv: weight norm over dim 2 on the parameters (torch ops on [C][C/g][k] only), conv + GELU + residual on the kernels
+    conv = en.pos_conv_embed.conv
+    if hasattr(conv, "parametrizations"):
+        wg, wv = conv.parametrizations.weight.original0, conv.parametrizations.weight.original1
+    else:
+        wg, wv = conv.weight_g, conv.weight_v
+    g = int(cfg.num_conv_pos_embedding_groups)
+    kpos = int(cfg.num_conv_pos_embeddings)
+    w_eff = wg * wv / wv.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    wk = w_eff.view(g, c // g, c // g, kpos).permute(3, 0, 1, 2).contiguous()
+    h = PosConvGelu.apply(h, wk, conv.bias)
+    stable = bool(getattr(cfg, "do_stable_layer_norm", False))
+    p_hid, p_act, p_att = float(cfg.hidden_dropout), float(cfg.activation_dropout), float(cfg.attention_dropout)
+    if not stable:
+        h = LayerNorm.apply(h, None, en.layer_norm.weight, en.layer_norm.bias, eps)
+    h = dropout(h, p_hid)
+    for layer in en.layers:
+        if torch.rand([]).item() < float(cfg.layerdrop):            # LayerDrop: transformers draws torch.rand([]) per layer in training
+            continue
+        att, ff = layer.attention, layer.feed_forward
+        wqkv = torch.cat([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight], 0)
+        bqkv = torch.cat([att.q_proj.bias, att.k_proj.bias, att.v_proj.bias], 0)
+
+        def attend(x):
+            ctxt = Attention.apply(Linear.apply(x, wqkv, bqkv), key_len, heads, p_att, next_seed() if p_att > 0 else 0)
+            return dropout(Linear.apply(ctxt, att.out_proj.weight, att.out_proj.bias), p_hid)
+
+        def ffn(x):
+            z = Linear.apply(x, ff.intermediate_dense.weight, None)
+            a = dropout(BiasGelu.apply(z, ff.intermediate_dense.bias), p_act)
+            return dropout(Linear.apply(a, ff.output_dense.weight, ff.output_dense.bias), p_hid)
+
+        if stable:                                                  # pre-LN: h += attn(LN(h)); h += ffn(LN(h))
+            h = Add.apply(h, attend(LayerNorm.apply(h, None, layer.layer_norm.weight, layer.layer_norm.bias, eps)))
+            h = Add.apply(h, ffn(LayerNorm.apply(h, None, layer.final_layer_norm.weight, layer.final_layer_norm.bias, eps)))
+        else:                                                       # post-LN: h = LN(h + attn(h)); h = LN(h + ffn(h))
+            h = LayerNorm.apply(attend(h), h, layer.layer_norm.weight, layer.layer_norm.bias, eps)
+            h = LayerNorm.apply(ffn(h), h, layer.final_layer_norm.weight, layer.final_layer_norm.bias, eps)
+    if stable:
+        h = LayerNorm.apply(h, None, en.layer_norm.weight, en.layer_norm.bias, eps)
+    return h
