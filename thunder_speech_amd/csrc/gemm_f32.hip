@@ -57,29 +57,43 @@ __device__ __forceinline__ f32x4 load4(const void* base, long long off, bool vec
 }
 
 // One operand tile: `rows` = M (or N) extent, contraction extent K; KC: the contraction index is the contiguous one in memory.
-// Each thread fetches two 4-element vectors; `r0`, `k0` = tile origin.  Elements outside [0, rows) x [0, K) come back as 0.
+// Each thread fetches two 4-element vectors per stage.  The thread's element offsets at (j = 0, k0 = 0) are computed ONCE (`off`); rows beyond
+// the extent are redirected to row 0 -- what they fetch only ever reaches output rows / columns that are not stored -- so the main loop's fetch
+// is two unconditional loads and an add; only a stage that crosses K (or an operand without vector alignment) takes the guarded path.
 template <bool KC, bool BF>
 struct Stage {
   f32x4 v[2];
-  __device__ __forceinline__ void fetch(const void* base, long long rs, long long cs, int rows, int K, int r0, int k0, int tid, bool vec) {
+  long long off[2];
+  long long step;                                    // elements per stage (BK along the contraction index)
+  int kt[2], rr[2];                                  // this thread's k (relative to k0) and row of each vector (guarded path)
+  __device__ __forceinline__ void init(long long rs, long long cs, int rows, int r0, int tid) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if constexpr (KC) {
-        const int r = r0 + (tid >> 2) + 64 * p, k = k0 + 4 * (tid & 3);            // 4 lanes cover the 16 k of a row
-        v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (r < rows && k < K) {
-          v[p] = load4<BF>(base, (long long)r * rs + k, vec, K - k);
-#pragma unroll
-          for (int i = 1; i < 4; ++i) if (k + i >= K) v[p][i] = 0.f;
-        }
+        rr[p] = r0 + (tid >> 2) + 64 * p; kt[p] = 4 * (tid & 3);                     // 4 lanes cover the 16 k of a row
+        off[p] = (long long)(rr[p] < rows ? rr[p] : 0) * rs + kt[p];
       } else {
-        const int k = k0 + (tid >> 5) + 8 * p, r = r0 + 4 * (tid & 31);             // 32 lanes cover the 128 rows of a k
-        v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (k < K && r < rows) {
-          v[p] = load4<BF>(base, (long long)k * cs + r, vec, rows - r);
+        kt[p] = (tid >> 5) + 8 * p; rr[p] = r0 + 4 * (tid & 31);                     // 32 lanes cover the 128 rows of a k
+        off[p] = (long long)kt[p] * cs + (rr[p] < rows ? rr[p] : 0);
+      }
+    }
+    step = KC ? BK : BK * cs;
+  }
+  __device__ __forceinline__ void fetch_fast(const void* base, long long o) {
 #pragma unroll
-          for (int i = 1; i < 4; ++i) if (r + i >= rows) v[p][i] = 0.f;
-        }
+    for (int p = 0; p < 2; ++p) v[p] = load4<BF>(base, off[p] + o, true, 4);
+  }
+  // guarded: elements outside [0, rows) x [0, K) come back as 0
+  __device__ __forceinline__ void fetch_slow(const void* base, long long o, int rows, int K, int k0, bool vec) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int k = k0 + kt[p];
+      v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rr[p] < rows && k < K) {
+        const int nv = KC ? K - k : rows - rr[p];
+        v[p] = load4<BF>(base, off[p] + o, vec, nv);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (i >= nv) v[p][i] = 0.f;
       }
     }
   }
@@ -109,6 +123,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
   const char* const a0 = static_cast<const char*>(g.a) + (z1 * g.sa + z2 * g.sa2) * (BF ? 2 : 4);
   const char* const b0 = static_cast<const char*>(g.b) + (z1 * g.sb + z2 * g.sb2) * (BF ? 2 : 4);
   const int nks = (g.K + BK - 1) / BK, total = nks * g.nkb;
+  const bool vec = g.vec_a && g.vec_b;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -120,20 +135,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
 
   Stage<A_KC, BF> sa;
   Stage<B_KC, BF> sb;
-  auto fetch = [&](int s) {
-    const int j = s / nks, k0 = (s % nks) * BK;
-    sa.fetch(a0 + j * g.ska * (BF ? 2 : 4), g.a_rs, g.a_cs, g.M, g.K, m0, k0, tid, g.vec_a != 0);
-    // B(k, n): "rows" of the staging helper are n; KC: k contiguous (b_rs == 1), the row stride is b_cs
-    sb.fetch(b0 + j * g.skb * (BF ? 2 : 4), B_KC ? g.b_cs : 0, B_KC ? 0 : g.b_rs, g.N, g.K, n0, k0, tid, g.vec_b != 0);
+  sa.init(g.a_rs, g.a_cs, g.M, m0, tid);
+  // B(k, n): the "rows" of the staging helper are n; KC: k contiguous (b_rs == 1), the row stride is b_cs
+  sb.init(B_KC ? g.b_cs : 0, B_KC ? 0 : g.b_rs, g.N, n0, tid);
+  int sj = 0, sk = 0;                                 // (outer contraction step, stage inside it) of the next fetch
+  auto fetch = [&]() {
+    const int k0 = sk * BK;
+    const long long oa = sj * g.ska + sk * sa.step, ob = sj * g.skb + sk * sb.step;
+    if (vec && k0 + BK <= g.K) {                      // wave-uniform
+      sa.fetch_fast(a0, oa);
+      sb.fetch_fast(b0, ob);
+    } else {
+      sa.fetch_slow(a0, oa, g.M, g.K, k0, g.vec_a != 0);
+      sb.fetch_slow(b0, ob, g.N, g.K, k0, g.vec_b != 0);
+    }
+    if (++sk == nks) { sk = 0; ++sj; }
   };
-  fetch(0);
+  fetch();
   sa.store(lds[0][0], tid);
   sb.store(lds[0][1], tid);
   __syncthreads();
   const int fa = (lane >> 5) * LP + 64 * wm + (lane & 31), fb = (lane >> 5) * LP + 64 * wn + (lane & 31);
   for (int s = 0; s < total; ++s) {
     const int cur = s & 1;
-    if (s + 1 < total) fetch(s + 1);                                                // in flight under this tile's products
+    if (s + 1 < total) fetch();                                                     // in flight under this tile's products
     const float* const ta = lds[cur][0];
     const float* const tb = lds[cur][1];
 #pragma unroll
