@@ -269,3 +269,160 @@ def test_bf16_wire_reduce_scatter_all_gather_arithmetic_at_world_2():
     n_buckets = res[0][2]
     assert n_buckets >= 2 and res[0][1] == 2 * n_buckets                       # reduce-scatter + all-gather per bucket
     assert res[0][3] == res[1][3] and res[0][3] >= 2 * sum(shapes)             # bf16: two bytes per gradient element on the wire
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Segmented backward pass (train_graph.SegmentedBackward / segment_parameters / GradientSync(groups=...).launch): the mode
+# GraphedTrainStep(segments=S) replays from S hipGraphs so that bucket k's exchange runs under piece k + 1.  Plain torch
+# modules stand in for the encoder blocks here (same (x, lengths) -> (x, lengths) signature); the graphs themselves need a GPU
+# (tests/test_gpu_train_graph.py).
+# ----------------------------------------------------------------------------------------------------------------------
+class _Blk(torch.nn.Module):
+    def __init__(self, c_in, c_out, k, trainable=True):
+        super().__init__()
+        self.conv = torch.nn.Conv1d(c_in, c_out, k, padding=k // 2, bias=False)
+        self.bn = torch.nn.BatchNorm1d(c_out)
+        if not trainable:
+            for p in self.parameters():
+                p.requires_grad_(False)
+
+    def forward(self, x, lengths):
+        return torch.relu(self.bn(self.conv(x))), lengths
+
+
+class _Net(torch.nn.Module):
+    def __init__(self, seed=0, frozen_first=False):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.encoder = torch.nn.Sequential(_Blk(4, 8, 3, trainable=not frozen_first), _Blk(8, 8, 5), _Blk(8, 16, 3), _Blk(16, 16, 3), _Blk(16, 8, 1))
+        self.decoder = torch.nn.Conv1d(8, 5, 1)
+
+
+def _net_batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(3, 4, 24, generator=g), torch.tensor([24, 20, 11]), torch.randn(3, 5, 24, generator=g)
+
+
+def _net_head(net, target):
+    return lambda x, lengths: ((net.decoder(x) - target) ** 2).mean()
+
+
+def test_split_stages_balances_trainable_bytes_and_segment_parameters_orders_by_completion():
+    from thunder_speech_amd.train_graph import segment_parameters, split_stages
+    net = _Net()
+    blocks = list(net.encoder.children())
+    stages = split_stages(blocks, 3)
+    assert [b for st in stages for b in st] == blocks and len(stages) == 3 and all(st for st in stages)
+    groups = segment_parameters(net, 3)
+    assert len(groups) == 3
+    assert groups[0][0] is net.decoder.bias and groups[0][1] is net.decoder.weight           # the decoder's gradients land first
+    assert groups[-1][-1] is blocks[0].conv.weight                                               # the first layer's weight lands last
+    flat = [id(p) for g in groups for p in g]
+    assert sorted(flat) == sorted(id(p) for p in net.parameters()) and len(set(flat)) == len(flat)
+    # a frozen leading block joins the first stage that trains something; its parameters are in no group
+    net2 = _Net(frozen_first=True)
+    st2 = split_stages(list(net2.encoder.children()), 4)
+    assert st2[0][0] is net2.encoder[0] and len(st2[0]) >= 2 and all(any(p.requires_grad for b in st for p in b.parameters()) for st in st2)
+    assert all(p.requires_grad for g in segment_parameters(net2, 4) for p in g)
+    assert len(split_stages(blocks, 1)) == 1 and len(split_stages(blocks, 9)) == 5              # never more stages than trainable blocks
+
+
+def test_segmented_backward_equals_plain_backward():
+    from thunder_speech_amd.train_graph import SegmentedBackward, split_stages
+    net, ref = _Net(seed=1), _Net(seed=1)
+    x, lengths, target = _net_batch(5)
+    h = x
+    for blk in ref.encoder:
+        h, _ = blk(h, lengths)
+    _net_head(ref, target)(h, lengths).backward()
+    seg = SegmentedBackward(split_stages(list(net.encoder.children()), 3), _net_head(net, target))
+    loss = seg.forward(x, lengths)
+    with pytest.raises(RuntimeError):
+        seg.backward(2)                                       # pieces run from the back
+    done = []
+    for k in range(seg.n_pieces):
+        seg.backward(k)
+        done.append([n for n, p in net.named_parameters() if p.grad is not None])
+    assert len(done[0]) < len(done[1]) < len(done[2])         # each piece completes the gradients of one more stage
+    assert torch.isfinite(loss)
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7), n
+
+
+def _segment_worker(rank, world, port, out):
+    from thunder_speech_amd.parallel import GradientSync
+    from thunder_speech_amd.train_graph import SegmentedBackward, segment_parameters, split_stages
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        net = _Net(seed=2)
+        trainable = [p for p in net.parameters() if p.requires_grad]
+        sync = GradientSync(trainable, groups=segment_parameters(net, 3))
+        sync.hold(True)                                       # as under a graph replay: the hooks never start a collective
+        opt = torch.optim.SGD(trainable, lr=0.1)
+        log = []
+        for step in range(2):
+            x, lengths, target = _net_batch(50 + rank + 10 * step)
+            seg = SegmentedBackward(split_stages(list(net.encoder.children()), 3), _net_head(net, target))
+            sync.zero_grad()
+            seg.forward(x, lengths)
+            for k in range(seg.n_pieces):
+                seg.backward(k)
+                if k + 1 < seg.n_pieces:
+                    sync.launch(k)                            # bucket k goes out BEFORE piece k + 1 runs
+                log.append((k, list(sync._launched), sync.n_collectives))
+            sync.finish()
+            opt.step()
+        dist.barrier()
+        out.put((rank, {n: p.detach().numpy().copy() for n, p in net.named_parameters()}, len(sync.buckets), log, sync.n_collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_segmented_step_overlaps_bucket_k_with_piece_k_plus_1_and_averages_exactly():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_segment_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(2):
+        rank, state, n_buckets, log, n_coll = out.get(timeout=300)
+        results[rank] = (state, n_buckets, log, n_coll)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    torch.set_num_threads(1)
+    net = _Net(seed=2)
+    params = list(net.parameters())
+    opt = torch.optim.SGD(params, lr=0.1)
+    for step in range(2):
+        grads = [torch.zeros_like(p) for p in params]
+        for rank in range(2):
+            x, lengths, target = _net_batch(50 + rank + 10 * step)
+            for p in params:
+                p.grad = None
+            h = x
+            for blk in net.encoder:
+                h, _ = blk(h, lengths)
+            _net_head(net, target)(h, lengths).backward()
+            for g, p in zip(grads, params):
+                g += p.grad / 2
+        for g, p in zip(grads, params):
+            p.grad = g
+        opt.step()
+    for rank in (0, 1):
+        state, n_buckets, log, n_coll = results[rank]
+        assert n_buckets == 3 and n_coll == 2 * 3                      # one collective per bucket per step (gloo: all-reduce)
+        # after piece k of a step: buckets 0..k-1... launched exactly the ones whose piece is done, except the last (it goes out in finish())
+        for i, (k, launched, _) in enumerate(log):
+            assert launched == [j <= k and j < 2 for j in range(3)], (i, k, launched)
+        for n, p in net.named_parameters():
+            got = torch.from_numpy(state[n])
+            assert torch.allclose(got, p.detach(), rtol=1e-5, atol=1e-6), (rank, n, float((got - p.detach()).abs().max()))
+    for n in results[0][0]:
+        assert (results[0][0][n] == results[1][0][n]).all(), n

@@ -58,11 +58,16 @@ class GradientSync:
         loss.backward(); sync.finish(); optimizer.step(); optimizer.zero_grad(set_to_none=False)   # keep the views!
     """
 
-    def __init__(self, params, bucket_bytes: int = 32 << 20, wire_dtype=None, collective: str = None):
+    def __init__(self, params, bucket_bytes: int = 32 << 20, wire_dtype=None, collective: str = None, groups=None, loopback: bool = False):
+        """`groups` (optional): the buckets spelled out -- a list of parameter lists in the order their gradients become complete (the
+        pieces of a segmented backward pass, train_graph.segment_parameters): bucket k holds exactly groups[k], whatever `bucket_bytes` says.
+        `loopback`: with ONE rank, still run every bucket through its pack -> collective -> unpack sequence on the side stream (the
+        collective over a one-rank group moves no bytes over links): what bench_extra.c4_ddp times as the exchange's launch + pack cost."""
         import torch.distributed as dist
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradientSync: no trainable parameters")
+        self.loopback = bool(loopback)
         dev = self.params[0].device
         if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
             raise ValueError("GradientSync: fp32 parameters on one device only")
@@ -84,9 +89,22 @@ class GradientSync:
         self.buckets = []                       # (start, length, [param indices])
         self._bucket_of = {}
         offsets, off, cur, cur_start = {}, 0, [], 0
-        for idx in reversed(range(len(self.params))):
+        order, cuts = list(reversed(range(len(self.params)))), set()
+        if groups is not None:
+            index_of = {id(p): i for i, p in enumerate(self.params)}
+            order = []
+            for grp in groups:
+                members = [index_of[id(p)] for p in grp if p.requires_grad and id(p) in index_of]
+                if not members:
+                    raise ValueError("GradientSync: a group without trainable parameters")
+                if order:
+                    cuts.add(members[0])
+                order += members
+            if sorted(order) != list(range(len(self.params))):
+                raise ValueError("GradientSync: `groups` must cover every trainable parameter exactly once")
+        for idx in order:
             n = self.params[idx].numel()
-            if cur and (off - cur_start + n) * 4 > bucket_bytes:
+            if cur and (idx in cuts if groups is not None else (off - cur_start + n) * 4 > bucket_bytes):
                 off = -(-off // align) * align
                 self.buckets.append((cur_start, off - cur_start, cur))
                 cur, cur_start = [], off
@@ -138,7 +156,7 @@ class GradientSync:
     def _launch(self, b: int) -> None:
         import torch.distributed as dist
         self._launched[b] = True
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             return
         start, length, _ = self.buckets[b]
         seg = self.flat[start: start + length]
@@ -173,12 +191,14 @@ class GradientSync:
                 wire.copy_(torch.cat(parts))
                 self.n_collectives += 2
             elif self.collective == "reduce_scatter":
-                shard = wire.view(self.world, -1)[dist.get_rank()]
-                dist.reduce_scatter_tensor(shard, wire, op=dist.ReduceOp.SUM)
-                dist.all_gather_into_tensor(wire, shard)
-                self.n_collectives += 2
+                if dist.is_available() and dist.is_initialized():
+                    shard = wire.view(self.world, -1)[dist.get_rank()]
+                    dist.reduce_scatter_tensor(shard, wire, op=dist.ReduceOp.SUM)
+                    dist.all_gather_into_tensor(wire, shard)
+                self.n_collectives += 2                       # loop-back without a process group: pack + unpack only
             else:
-                dist.all_reduce(wire, op=dist.ReduceOp.SUM)
+                if dist.is_available() and dist.is_initialized():
+                    dist.all_reduce(wire, op=dist.ReduceOp.SUM)
                 self.n_collectives += 1
             if wire is not seg:
                 if seg.is_cuda:
@@ -187,6 +207,15 @@ class GradientSync:
                     _lib.check(st, "ts_grad_wire_unpack")
                 else:
                     seg.copy_(wire)
+
+    def launch(self, b: int) -> None:
+        """Start bucket `b`'s exchange now (side stream, behind everything the compute stream has been given so far).  The explicit form
+        of what the hooks do: for a backward pass replayed in pieces from hipGraphs (train_graph.GraphedTrainStep(segments=...)), where no
+        hook runs per step -- piece k has just been replayed, bucket k is complete, and piece k + 1 runs while it travels."""
+        if not 0 <= b < len(self.buckets):
+            raise IndexError(f"GradientSync.launch: no bucket {b}")
+        if not self._launched[b]:
+            self._launch(b)
 
     def hold(self, on: bool = True) -> None:
         """While held, the hooks only collect the gradients into the buckets and every collective waits for finish(): the mode of

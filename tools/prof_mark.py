@@ -1,6 +1,6 @@
 """Timed-region markers for profiled runs: with TS_PROF_MARK=1 every timed loop of bench.py / tools/bench_extra.py is bracketed by TWO
 back-to-back launches of a tiny library kernel (ts::counter_add_kernel via ts_counter_add; a single launch of it is also the
-replay-nonce bump at the head of a graphed training step, a pair is only ever a marker), so that tools/prof_round3_summary.py can
+replay-nonce bump at the head of a graphed training step, a pair is only ever a marker), so that tools/prof_round_summary.py can
 drop warm-up, graph-capture and one-time packing dispatches from the kernel trace and report per-step shares of the timed region only."""
 import os
 

@@ -1,9 +1,10 @@
-"""Condense the rocprofv3 outputs of tools/prof_round3.sh into the files that go under profiles/ (round3_*).  Per-kernel tables cover the
+"""Condense the rocprofv3 outputs of tools/prof_round.sh into the files that go under profiles/ (round<N>_*).  Per-kernel tables cover the
 TIMED REGION only: the dispatches between the two marker pairs (tools/prof_mark.py) that bracket each timed loop -- warm-up passes,
 graph capture and one-time weight packing are dropped, so the percentages are per-step shares."""
 import collections, csv, glob, json, os, sys
 
 O = sys.argv[1]
+R = sys.argv[2] if len(sys.argv) > 2 else "4"
 out = os.path.join(O, "profiles")
 os.makedirs(out, exist_ok=True)
 MARK = "counter_add_kernel"
@@ -26,7 +27,7 @@ def trace(name, anchor=None):
         agg[k] = (c + 1, t + d)
     table = sorted(({"Name": k, "Calls": c, "TotalDurationNs": t, "AverageNs": t / c} for k, (c, t) in agg.items()), key=lambda r: -r["TotalDurationNs"])
     span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) if rows else 0
-    with open(os.path.join(out, f"round3_{name}_kernel_stats.csv"), "w", newline="") as f:
+    with open(os.path.join(out, f"round{R}_{name}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
         tot = sum(r["TotalDurationNs"] for r in table)
@@ -52,13 +53,13 @@ def md_table(rows, top=18):
     return t, tot
 
 
-md = ["# Round 3 -- rocprofv3 summaries (tools/prof_round3.sh on one MI355X)", "",
+md = [f"# Round {R} -- rocprofv3 summaries (tools/prof_round.sh {R} on one MI355X)", "",
       "Tables cover the timed region of each run only (between the two marker pairs of tools/prof_mark.py).", ""]
 rows, span, _ = trace("bench")
 if rows:
     bj = last_json("bench")
     if bj:
-        json.dump(bj, open(os.path.join(out, "round3_bench.json"), "w"), indent=1)
+        json.dump(bj, open(os.path.join(out, f"round{R}_bench.json"), "w"), indent=1)
         md += ["## C2 headline: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 5 --no-extra --no-cpu-baseline`", "",
                f"bench line of the profiled run: value {bj['value']:.0f} {bj['unit']}, {bj['ms_per_step']:.3f} ms/step, encoder {bj['roofline']['encoder_ms']:.3f} ms, "
                f"avg_launch_us {bj['roofline']['avg_launch_us']:.1f} (HIP events), roofline.frac {bj['roofline']['frac']:.3f}", ""]
@@ -84,14 +85,16 @@ if pmc["fetch"][1] and pmc["write"][1]:
                "dispatches": pmc["fetch"][1], "fetch_size_kb_per_dispatch": fkb, "write_size_kb_per_dispatch": wkb,
                "gfx950_correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: 128-B requests tallied at 64 B); WRITE_SIZE exact",
                "traffic_bytes_per_launch": fkb * 1024 * 2 + wkb * 1024}
-    json.dump(traffic, open(os.path.join(out, "round3_traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(out, f"round{R}_traffic.json"), "w"), indent=1)
     md += [f"HBM-side traffic of the TCS launches (PMC, per launch): FETCH_SIZE {fkb:.0f} KB (x2 on gfx950 = {fkb * 2048 / 1e6:.1f} MB), WRITE_SIZE {wkb:.0f} KB "
-           f"({wkb * 1024 / 1e6:.1f} MB) -> {traffic['traffic_bytes_per_launch'] / 1e6:.1f} MB per launch (`round3_traffic.json`).", ""]
+           f"({wkb * 1024 / 1e6:.1f} MB) -> {traffic['traffic_bytes_per_launch'] / 1e6:.1f} MB per launch (`round{R}_traffic.json`).", ""]
 
 for name, title, key, anchor in (("c3", "C3 Citrinet-1024 inference 32 x 20 s (`tools/bench_extra.py c3`)", "c3", "stft_mel_kernel"),
                          ("c4p1", "C4 phase 1 as the reference schedule leaves the model: convolutions frozen, BatchNorm + decoder trainable, train-mode encoder "
                                   "(`TS_C4_ONLY=c4_phase1 tools/bench_extra.py c4`)", "c4_phase1", "ctc_kernel"),
                          ("c4p2", "C4 phase 2: everything trainable, bf16 activations, fwd + bwd from one hipGraph (`TS_C4_ONLY=c4_phase2 tools/bench_extra.py c4`)", "c4_phase2", "ctc_kernel"),
+                         ("c4p2f", "C4 phase 2 in fp32 (every GEMM on the f32 matrix-core kernel of csrc/gemm_f32.hip; no vendor library is linked) "
+                                   "(`TS_C4_ONLY=c4_phase2_fp32 tools/bench_extra.py c4`)", "c4_phase2_fp32", "ctc_kernel"),
                          ("c5", "C5 wav2vec2-large inference 16 x 20 s, own GEMM (`tools/bench_extra.py c5`)", "c5", "w2v_posconv_mfma_kernel")):
     rows, span, traced = trace(name, anchor)
     if not rows:
@@ -103,5 +106,5 @@ for name, title, key, anchor in (("c3", "C3 Citrinet-1024 inference 32 x 20 s (`
     t, tot = md_table(rows, top=22)
     md += t + ["", f"timed region: {sum(r['Calls'] for r in rows)} launches ({sum(r['Calls'] for r in rows) / steps:.0f} per step), kernel time {tot / 1e6 / steps:.2f} ms per step, "
                    f"{span / 1e6 / steps:.2f} ms wall per step in the trace.", ""]
-open(os.path.join(out, "round3_summary.md"), "w").write("\n".join(md) + "\n")
+open(os.path.join(out, f"round{R}_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md[:45]))
