@@ -253,33 +253,38 @@ def test_same_depthwise_pair_kernels_match_conv1d_autograd(act, batch, ch, t, k,
         assert err <= tol * max(float(ref.abs().max()), 1.0), (name, err, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("act,optimizer", [("fp32", "fused"), ("bf16", "fused"), ("bf16", "torch")])
-def test_graphed_training_step_follows_the_eager_step(act, optimizer):
+@pytest.mark.parametrize("act,optimizer,segments", [("fp32", "fused", 1), ("bf16", "fused", 1), ("bf16", "torch", 1), ("fp32", "fused", 3), ("bf16", "fused", 3)])
+def test_graphed_training_step_follows_the_eager_step(act, optimizer, segments):
     """train_graph.GraphedTrainStep (features -> encoder -> decoder -> CTC -> backward replayed from ONE hipGraph, front end /
     exchange / optimizer outside) against the same steps launched eagerly (module.py:102-113 + backward + GradientSync.finish +
     FusedAdamW): same seeds, so the dither draws are the same too; the first loss agrees to 1e-6 relative, the later ones to 1 % (fp32; the
     weight gradients of the depthwise convolutions leave through float atomics, whose order is not fixed, and the loss falls 5x in
     these 4 steps) / 5 % (bf16 activations), the 4-step parameter update to 20 % / 50 % in L2 (AdamW turns noise-level gradient entries into full +-lr steps), and the BatchNorm running statistics count exactly 4 steps: the warm-up and
-    capture passes leave no trace."""
+    capture passes leave no trace.
+    segments=3: the same step replayed as THREE graphs (backward pass cut at two block boundaries, train_graph.SegmentedBackward) with
+    GradientSync's buckets = the pieces and each bucket sent through its loop-back exchange (pack -> [one rank: no bytes move] -> unpack on
+    the side stream) while the next piece replays: same numbers (the bf16 wire rounds the gradients once, inside the bf16 tolerance)."""
     from thunder_speech_amd import train_ops
     from thunder_speech_amd.optim import FusedAdamW
     from thunder_speech_amd.parallel import GradientSync
     from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
-    from thunder_speech_amd.train_graph import GraphedTrainStep
+    from thunder_speech_amd.train_graph import GraphedTrainStep, segment_parameters
     arch = otcs.quartznet_arch(repeat_blocks=1)
     g = torch.Generator().manual_seed(9)
     wavs = [(0.1 * torch.randn(4, 24000, generator=g)).cuda() for _ in range(2)]
     lengths = torch.tensor([24000.0, 20000.0, 16000.0, 24000.0]).cuda()
     texts = [["abc", "hello", "data", "test"], ["speech", "to", "text x", "qrs"]]
 
-    def make():
+    def make(segmented=False):
         m = build_synthetic_quartznet(repeat_blocks=1, encoder_state=otcs.synth_encoder_state(arch, seed=0, calibrate=True),
                                       decoder_state=otcs.synth_decoder_state(1024, 29, seed=1)).cuda().train()
         params = [p for p in m.parameters() if p.requires_grad]
         # "torch": a plain torch optimizer -- the graph reads derived weight copies (MFMA fragments) that only FusedAdamW refreshes by
         # itself; GraphedTrainStep has to bring them up to date after ANY optimizer step
         opt = FusedAdamW(params, lr=1e-3, weight_decay=0.0) if optimizer == "fused" else torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0)
-        return m, opt, GradientSync(params)
+        if segmented:
+            return m, opt, GradientSync(params, groups=segment_parameters(m, segments), loopback=True)
+        return m, opt, GradientSync(params, loopback=segments > 1)      # the eager run rounds its gradients through the same wire
 
     train_ops.set_activation_dtype(act)
     try:
@@ -295,13 +300,17 @@ def test_graphed_training_step_follows_the_eager_step(act, optimizer):
             eager.append(float(loss.detach()))
         sync0.close()
         torch.manual_seed(5)
-        m1, opt1, sync1 = make()
-        step = GraphedTrainStep(m1, opt1, sync1, max_target_len=16)
+        m1, opt1, sync1 = make(segmented=segments > 1)
+        step = GraphedTrainStep(m1, opt1, sync1, max_target_len=16, segments=segments)
+        n_buckets = len(sync1.buckets)
         graphed = [float(step((wavs[i % 2], lengths, texts[i % 2]))) for i in range(4)]
         sync1.close()
     finally:
         train_ops.set_activation_dtype("fp32")
     assert step.replays == 4 and len(step._graphs) == 1
+    if segments > 1:
+        assert step.segments == segments == n_buckets and len(next(iter(step._graphs.values()))[0]) == segments
+        assert sync1.n_collectives == 4 * segments * (2 if sync1.collective == "reduce_scatter" else 1)      # every bucket went through its exchange
     # the first step sees identical parameters; afterwards the two runs drift apart through the atomics' summation order, amplified
     # by a loss that falls 5x in 4 steps
     assert abs(eager[0] - graphed[0]) <= (1e-3 if act == "bf16" else 1e-6) * abs(eager[0]), (eager, graphed)

@@ -237,35 +237,61 @@ def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
     return out
 
 
-def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8):
+XGMI_LINK_GBS_PER_DIRECTION = 76.5          # 7 point-to-point links per GPU, ~153 GB/s each counting both directions
+
+
+def _one_rank_group():
+    """A one-rank RCCL process group for the loop-back exchange of a single-GPU run (reduce-scatter / all-gather over one rank move no bytes
+    over links but cost their launches); None when a group already exists or RCCL cannot come up here."""
+    import socket
+    import torch.distributed as dist
+    if not dist.is_available() or dist.is_initialized():
+        return None
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        return True
+    except Exception as e:                                       # noqa: BLE001 -- recorded in the result, the pack / unpack legs are still timed
+        print(f"bench_extra.c4_ddp: no one-rank RCCL group ({type(e).__name__}: {e}); loop-back times pack + unpack only", file=sys.stderr, flush=True)
+        return None
+
+
+def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8, segments=3):
     """BASELINE.json configs[3] as the reference runs it (Trainer(strategy="ddp"), tests/quartznet/test_module_qn.py:33-53): QuartzNet15x5
     fine-tuning, everything trainable, GLOBAL batch 256 x 10 s split over the ranks (strong scaling: local batch 256 / world), one
     gradient exchange per step (parallel.GradientSync: bf16 wire, reduce-scatter + all-gather over RCCL), FusedAdamW, forward + backward
-    replayed from a hipGraph.  Every rank runs it; the time is the MAX over ranks between two barriers.  `exchange_ms_exposed` is the
-    step time minus the time of the same step with the exchange switched off (what the links cost after overlap)."""
+    replayed from `segments` hipGraphs (train_graph.GraphedTrainStep(segments=3): bucket k's exchange runs on the side stream under piece k + 1 of
+    the backward pass; only the last bucket is exposed).  Every rank runs it; the time is the MAX over ranks between two barriers.
+    `exchange_ms_exposed` is the step time minus the time of the same step with the exchange switched off (what the links cost after overlap).
+    With ONE rank the exchange runs in loop-back (pack -> collective over a one-rank RCCL group -> unpack: every launch of the real exchange, no
+    bytes over links) and the local-32 step -- what each of 8 ranks would run -- is timed the same way:
+    `projected_speedup_8 = t(local 256, no exchange) / (t(local 32) + exchange_ms_exposed(local 32) + link time of the exposed bucket)`."""
     from thunder_speech_amd import train_ops
     from thunder_speech_amd.optim import FusedAdamW
     from thunder_speech_amd.parallel import GradientSync, max_over_ranks
     from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
-    from thunder_speech_amd.train_graph import GraphedTrainStep
+    from thunder_speech_amd.train_graph import GraphedTrainStep, segment_parameters
     from thunder_speech_amd.utils import variance_preserving_init_
     import torch.distributed as dist
     if global_batch % world:
         raise ValueError(f"global batch {global_batch} does not split over {world} ranks")
-    local = global_batch // world
-    g = torch.Generator().manual_seed(1234 + rank)
-    wav = (0.1 * torch.randn(local, 16000 * seconds, generator=g)).to(device)
-    lengths = torch.full((local,), 16000.0 * seconds, device=device)
-    texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(60, 140, (local,), generator=g)]
-    torch.manual_seed(0)
-    m = build_synthetic_quartznet(repeat_blocks=3)
-    variance_preserving_init_(m.encoder, m.decoder, seed=0)          # same seed on every rank: replicas start identical
-    m = m.to(device).train()
-    train_ops.set_activation_dtype("bf16")
-    try:
+    own_group = _one_rank_group() if world == 1 else None
+
+    def measure(local, n_steps):
+        g = torch.Generator().manual_seed(1234 + rank)
+        wav = (0.1 * torch.randn(local, 16000 * seconds, generator=g)).to(device)
+        lengths = torch.full((local,), 16000.0 * seconds, device=device)
+        texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(60, 140, (local,), generator=g)]
+        torch.manual_seed(0)
+        m = build_synthetic_quartznet(repeat_blocks=3)
+        variance_preserving_init_(m.encoder, m.decoder, seed=0)          # same seed on every rank: replicas start identical
+        m = m.to(device).train()
         trainable = [p for p in m.parameters() if p.requires_grad]
-        opt, sync = FusedAdamW(trainable, lr=1e-3), GradientSync(trainable)
-        graphed = GraphedTrainStep(m, opt, sync, max_target_len=160)
+        opt = FusedAdamW(trainable, lr=1e-3)
+        sync = GradientSync(trainable, groups=segment_parameters(m, segments), loopback=(world == 1))
+        graphed = GraphedTrainStep(m, opt, sync, max_target_len=160, segments=segments)
         step = lambda: graphed((wav, lengths, texts))
 
         def timed(n):
@@ -284,28 +310,55 @@ def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8):
         for _ in range(2):
             step()
         c0, b0 = sync.n_collectives, sync.wire_bytes
-        dt = timed(steps)
-        n_coll, wire = (sync.n_collectives - c0) // steps, (sync.wire_bytes - b0) // steps
-        real_world, sync.world = sync.world, 1                        # exchange off: every rank steps on its local gradient
-        dt_local = timed(max(steps // 2, 2))
-        sync.world = real_world
+        dt = timed(n_steps)
+        n_coll, wire = (sync.n_collectives - c0) // n_steps, (sync.wire_bytes - b0) // n_steps
+        real_world, real_loop, sync.world, sync.loopback = sync.world, sync.loopback, 1, False       # exchange off: every rank steps on its local gradient
+        dt_local = timed(max(n_steps // 2, 2))
+        sync.world, sync.loopback = real_world, real_loop
         last = float(step())
+        out = {"dt": dt, "dt_local": dt_local, "first": first, "last": last, "n_coll": n_coll, "wire": wire, "wire_dtype": str(sync.wire_dtype).replace("torch.", ""),
+               "collective": sync.collective, "n_buckets": len(sync.buckets), "n_graphs": graphed.segments,
+               "bucket_bytes_on_wire": [length * (2 if sync.wire_dtype == torch.bfloat16 else 4) for (_, length, _) in sync.buckets]}
+        sync.close()
+        del m, opt, sync, graphed
+        torch.cuda.empty_cache()
+        return out
+
+    train_ops.set_activation_dtype("bf16")
+    try:
+        local = global_batch // world
+        r = measure(local, steps)
+        r32 = measure(global_batch // 8, 3 * steps) if world == 1 else None
     finally:
         train_ops.set_activation_dtype("fp32")
+        if own_group:
+            dist.destroy_process_group()
+    dt, dt_local = r["dt"], r["dt_local"]
     fwd_gflop = 4826.9 * global_batch * seconds / 2560.0
     res = {"workload": f"QuartzNet15x5 fine-tune step (CTC), GLOBAL batch {global_batch}x{seconds} s over {world} GPU(s) = local {local}, data-parallel, "
-                       "bf16 activations (mixed precision), forward + backward from one hipGraph, GradientSync + FusedAdamW (BASELINE.json configs[3])",
+                       f"bf16 activations (mixed precision), forward + backward from {r['n_graphs']} hipGraphs (bucket k's exchange under backward piece k + 1), "
+                       "GradientSync + FusedAdamW (BASELINE.json configs[3])",
            "n_gpus": world, "scaling": "strong", "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s",
-           "audio_seconds_per_s": global_batch * seconds / dt, "steps": steps, "loss_first_last": [first, last],
-           "n_collectives_per_step": n_coll, "wire_bytes_per_step_per_rank": wire, "wire_dtype": str(sync.wire_dtype).replace("torch.", ""),
-           "collective": sync.collective if world > 1 else "none (one rank)", "n_buckets": len(sync.buckets),
+           "audio_seconds_per_s": global_batch * seconds / dt, "steps": steps, "loss_first_last": [r["first"], r["last"]],
+           "n_collectives_per_step": r["n_coll"], "wire_bytes_per_step_per_rank": r["wire"], "wire_dtype": r["wire_dtype"],
+           "collective": r["collective"] if world > 1 else f"{r['collective']} in loop-back ({'one-rank RCCL group' if own_group else 'pack + unpack only'})",
+           "n_buckets": r["n_buckets"], "n_graphs": r["n_graphs"],
            "ms_per_step_without_exchange": dt_local * 1e3, "exchange_ms_exposed": max(dt - dt_local, 0.0) * 1e3,
            "roofline": {"bound": "mfma", "model": "3 x forward FLOPs of the global batch (BASELINE.md section 3) / (n_gpus x dense bf16 peak)",
                         "achieved": 3.0 * fwd_gflop / dt / 1e3, "peak": MFMA_BF16_PEAK_TF * world, "unit": "TFLOP/s",
                         "frac": 3.0 * fwd_gflop / dt / 1e3 / (MFMA_BF16_PEAK_TF * world)}}
-    sync.close()
-    del m, opt, sync, graphed
-    torch.cuda.empty_cache()
+    if r32 is not None:
+        # what the links add on an 8-GPU node: only the LAST bucket's reduce-scatter + all-gather is not hidden under a backward piece; direct
+        # (all-to-all shaped) exchange over 7 point-to-point links: every rank sends 1/8 of the bucket to each peer over its own link, twice
+        exposed_bucket = r32["bucket_bytes_on_wire"][-1]
+        link_ms = 2.0 * (exposed_bucket / 8.0) / (XGMI_LINK_GBS_PER_DIRECTION * 1e9) * 1e3
+        t32 = r32["dt"] * 1e3
+        res.update({"local32_ms_per_step": t32, "local32_ms_per_step_without_exchange": r32["dt_local"] * 1e3,
+                    "local32_exchange_ms_exposed_loopback": max(r32["dt"] - r32["dt_local"], 0.0) * 1e3,
+                    "exposed_bucket_bytes_on_wire": exposed_bucket, "exposed_link_ms_model": link_ms,
+                    "link_model": f"last bucket only; reduce-scatter + all-gather, each 1/8 of the bucket per peer link at {XGMI_LINK_GBS_PER_DIRECTION} GB/s per direction",
+                    "projected_speedup_8": dt_local * 1e3 / (t32 + link_ms),
+                    "projected_speedup_8_formula": "t(local 256, exchange off) / (t(local 32, loop-back exchange overlapped) + modelled link time of the exposed bucket)"})
     return res
 
 
