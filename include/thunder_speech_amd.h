@@ -375,11 +375,17 @@ int ts_train_pwconv_bwd(const void* dv, const void* u, const void* w, void* du, 
  *                               f32 partials in `workspace` (ts_train_pwconv_wgrad_workspace floats), summed onto dw by a second
  *                               launch.  len_u (may be NULL): frames >= len_u[b] of u count as zero -- the input mask of the MaskedConv1d
  *                               applied inside the product, so that the masked copy of u need not exist.  c_in, c_out multiples of 8, pitches multiples of 8 and >= round_up(T, 64), 16-byte aligned
- *                               bases; anything else returns TS_EUNSUPPORTED (callers fall back to ts_train_pwconv_bwd). */
+ *                               bases; anything else returns TS_EUNSUPPORTED (callers fall back to ts_train_pwconv_bwd).
+ *                               dw == NULL: the partials only ([n_parts][c_out][c_in], n_parts = workspace floats / (c_out * c_in)).
+ *   ts_train_wgrad_reduce_multi dws[e][i] += sum_p parts[e][p][i], i < n[e], p < n_parts[e], for `count` layers in ceil(count / 64) launches:
+ *                               a step replayed from a hipGraph parks every layer's partials and sums them once per backward piece instead
+ *                               of once per layer (93 launch-bound ~8 us launches for QuartzNet15x5).  The four arrays are HOST arrays of
+ *                               `count` entries, read at call time; n[e] % 4 == 0, 16-byte aligned pointers. */
 int ts_train_pack_pw_multi(const void* table, int32_t n_tensors, int64_t max_groups, void* stream);
 int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, int32_t c_out);
 int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const int32_t* len_u, float* dw, float* workspace, int32_t batch, int32_t c_in, int32_t c_out,
                                int32_t t, int32_t pitch_u, int32_t pitch_v, void* stream);
+int ts_train_wgrad_reduce_multi(const void* const* parts, void* const* dws, const int64_t* n, const int32_t* n_parts, int32_t count, void* stream);
 /* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
  * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */
 int ts_train_bn_fwd(const void* v, const float* gamma, const float* beta, void* y, float* mean_rstd, void* workspace, int32_t batch,

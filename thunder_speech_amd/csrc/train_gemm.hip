@@ -165,6 +165,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// the same for up to RM_MAX layers in one launch (blockIdx.y = layer): a graphed training step parks every layer's partials until the end of
+// its backward piece and sums them all at once -- 93 launches of ~8 us (launch-bound: 1-4 MB each) become one or two
+constexpr int RM_MAX = 64;
+struct ReduceMulti {
+  const float* part[RM_MAX];
+  float* dw[RM_MAX];
+  int n[RM_MAX];
+  int n_parts[RM_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceMulti a) {
+  const int e = blockIdx.y;
+  const long long n = a.n[e];
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float* const part = a.part[e];
+  float* const dw = a.dw[e];
+  const int n_parts = a.n_parts[e];
+  if (i + 4 <= n) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(dw + i);
+    for (int p = 0; p < n_parts; ++p) s += *reinterpret_cast<const f32x4*>(part + (size_t)p * n + i);
+    *reinterpret_cast<f32x4*>(dw + i) = s;
+  } else {
+    for (long long k = i; k < n; ++k) {
+      float s = dw[k];
+      for (int p = 0; p < n_parts; ++p) s += part[(size_t)p * n + k];
+      dw[k] = s;
+    }
+  }
+}
+
 // B-fragments of v_mfma_f32_32x32x16_bf16 for D[t][n] += X[k][t] * Wn[n][k] (tcs_kernel.hip, plan.pack_pw_frags): group (nt, ks, lane)
 // = 8 bf16: Wn[32 nt + lane % 32][16 ks + 8 (lane / 32) + 0..7], groups ordered [n_pad32 / 32][k_pad64 / 16][64].  Per layer two sets:
 // the forward one (Wn = W: n = c_out, k = c_in) and the backward one (Wn = W^T: n = c_in, k = c_out).  table rows: (W f32 ptr,
@@ -215,10 +245,10 @@ extern "C" int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, 
 /* dw += sum_b dv[b] . u[b]^T; see include/thunder_speech_amd.h */
 extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const int32_t* len_u, float* dw, float* workspace, int32_t batch, int32_t c_in,
                                           int32_t c_out, int32_t t, int32_t pitch_u, int32_t pitch_v, void* stream_) {
-  if (!dv || !u || !dw || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
+  if (!dv || !u || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
   const int tk_end = round_up(t, GK);
   if (c_out % 8 || c_in % 8 || pitch_u % 8 || pitch_v % 8 || pitch_u < tk_end || pitch_v < tk_end || !aligned16(u) || !aligned16(dv) ||
-      !aligned16(dw) || !aligned16(workspace) || ((size_t)c_out * c_in) % 4)
+      (dw && !aligned16(dw)) || !aligned16(workspace) || ((size_t)c_out * c_in) % 4)
     return TS_EUNSUPPORTED;
   if ((size_t)batch * c_out * pitch_v * 2 >= (1ull << 31) || (size_t)batch * c_in * pitch_u * 2 >= (1ull << 31)) return TS_EUNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
@@ -237,7 +267,30 @@ extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const i
   (void)hipGetLastError();
   hipLaunchKernelGGL(wgrad_gemm_kernel, dim3((unsigned)(g.n_mt * g.n_nt * split)), dim3(256), WD * WSTAGEB, stream, g);
   const long long n = (long long)c_out * c_in;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, workspace, dw, n, split);
+  // dw == NULL: partials only -- the caller sums them later, many layers at once (ts_train_wgrad_reduce_multi)
+  if (dw) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, workspace, dw, n, split);
+  return hip_status(hipGetLastError());
+}
+
+/* dw[e][i] += sum_p parts[e][p][i] for `count` layers; see include/thunder_speech_amd.h */
+extern "C" int ts_train_wgrad_reduce_multi(const void* const* parts, void* const* dws, const int64_t* n, const int32_t* n_parts, int32_t count,
+                                           void* stream_) {
+  if (!parts || !dws || !n || !n_parts || count <= 0) return TS_EINVAL;
+  for (int e = 0; e < count; ++e)
+    if (!parts[e] || !dws[e] || n[e] <= 0 || n[e] >= (1ll << 31) || n_parts[e] <= 0 || !aligned16(parts[e]) || !aligned16(dws[e]) || n[e] % 4) return TS_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  for (int base = 0; base < count; base += RM_MAX) {
+    ReduceMulti a;
+    const int m = count - base < RM_MAX ? count - base : RM_MAX;
+    long long max_n = 0;
+    for (int e = 0; e < RM_MAX; ++e) {
+      const int src = base + (e < m ? e : 0);
+      a.part[e] = static_cast<const float*>(parts[src]); a.dw[e] = static_cast<float*>(dws[src]); a.n[e] = (int)n[src]; a.n_parts[e] = n_parts[src];
+      if (e < m && n[src] > max_n) max_n = n[src];
+    }
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)((max_n / 4 + 255) / 256), (unsigned)m), dim3(256), 0, stream, a);
+  }
   return hip_status(hipGetLastError());
 }
 

@@ -166,7 +166,8 @@ class GraphedTrainStep:
         encoded, out_lengths = m.encoder(feats, flen)
         probabilities = m.decoder(encoded)
         loss = calculate_ctc(probabilities, y, out_lengths, ylen, m.text_transform.vocab.blank_idx)
-        loss.backward()
+        with train_ops.deferred_wgrad():         # no hook sends a bucket during a replay: the split-K partials of all layers are summed at once
+            loss.backward()
         return loss.detach()
 
     def _pieces(self, feats, flen, y, ylen):
@@ -184,10 +185,15 @@ class GraphedTrainStep:
             _t.require_gpu(feats, "encoder")
             with _t.lengths_scope():
                 box["loss"] = seg.forward(feats, flen)
-            seg.backward(0)
+            with train_ops.deferred_wgrad():     # summed once per piece, before the piece's bucket goes out
+                seg.backward(0)
             return box["loss"].detach()
 
-        return [first] + [(lambda k=k: seg.backward(k)) for k in range(1, seg.n_pieces)]
+        def later(k):
+            with train_ops.deferred_wgrad():
+                seg.backward(k)
+
+        return [first] + [(lambda k=k: later(k)) for k in range(1, seg.n_pieces)]
 
     def _capture_segments(self, feats, flen, y, ylen):
         dev = feats.device

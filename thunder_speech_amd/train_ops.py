@@ -152,13 +152,19 @@ def _g(dy: Tensor, like: Tensor) -> Tensor:
 _GRAD_VIEWS = {}
 
 
+_LAST_GRAD_OUT_IS_VIEW = False
+
+
 def grad_out(param, shape, zeroed: bool = False) -> Tensor:
     """f32 tensor of `shape` for the gradient of `param`: its registered flat-buffer view when it has one and `.grad` is unset
     (first -- and in the fine-tuning loop only -- contribution of the step), else a fresh tensor.  `zeroed`: the kernel about to
     receive it ACCUMULATES, so the tensor must hold zeros -- free for a bucket view (GradientSync.zero_grad cleared the whole
     buffer with one memset), one fill launch otherwise."""
+    global _LAST_GRAD_OUT_IS_VIEW
+    _LAST_GRAD_OUT_IS_VIEW = False
     ent = _GRAD_VIEWS.get(id(param)) if param is not None else None
     if ent is not None and param.grad is None and ent[1].claim(param):
+        _LAST_GRAD_OUT_IS_VIEW = True
         # (claim: a parameter that contributes twice in one backward -- tied weights, a module called twice -- gets the bucket view for
         # its first contribution only; the second one takes a fresh tensor and autograd adds the two)
         view, owner = ent
@@ -315,15 +321,65 @@ def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int
     _lib.check(st, "ts_tcs_subblock_fwd")
 
 
-def _wgrad(dv: Tensor, u: Tensor, dw: Tensor, len_u: Tensor = None) -> None:
-    """dw += sum_b dv[b] . mask(u[b], len_u)^T (csrc/train_gemm.hip); dv [B, c_out, T], u [B, c_in, T] bf16 rows, dw f32 [c_out, c_in]."""
+# Deferred split-K reduction of the pointwise weight gradients.  Eagerly, every layer's partial products are summed onto its gradient right
+# behind the product (GradientSync's hooks may send the bucket the moment autograd hands the gradient over).  A step replayed from hipGraphs
+# runs no hook, so train_graph.GraphedTrainStep opens `deferred_wgrad()` around each piece of its backward pass: the layers only leave their
+# partials (kept alive in the list below) and `flush_wgrad()` sums all of them in ONE launch per 64 layers at the end of the piece.
+_WGRAD_PENDING = None
+
+
+class deferred_wgrad:
+    """Context: park the split-K partials of every bf16 pointwise weight gradient computed inside; flush_wgrad() (called on exit too) sums them."""
+
+    def __enter__(self):
+        global _WGRAD_PENDING
+        self._outer = _WGRAD_PENDING
+        if _WGRAD_PENDING is None:
+            _WGRAD_PENDING = []
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_PENDING
+        try:
+            if exc[0] is None:
+                flush_wgrad()
+        finally:
+            if self._outer is None:
+                _WGRAD_PENDING = None
+        return False
+
+
+def flush_wgrad() -> int:
+    """Sum every parked partial onto its gradient (ts_train_wgrad_reduce_multi); returns the number of layers.  All on the current stream."""
+    import ctypes as C
+    pend = _WGRAD_PENDING
+    if not pend:
+        return 0
+    n = len(pend)
+    parts = (C.c_void_p * n)(*[ws.data_ptr() for ws, _, _ in pend])
+    dws = (C.c_void_p * n)(*[dw.data_ptr() for _, dw, _ in pend])
+    sizes = (C.c_int64 * n)(*[dw.numel() for _, dw, _ in pend])
+    nparts = (C.c_int32 * n)(*[k for _, _, k in pend])
+    st = _lib.lib().ts_train_wgrad_reduce_multi(parts, dws, sizes, nparts, n, _s(pend[0][1]))
+    pend.clear()
+    _lib.check(st, "ts_train_wgrad_reduce_multi")
+    return n
+
+
+def _wgrad(dv: Tensor, u: Tensor, dw: Tensor, len_u: Tensor = None, defer: bool = False) -> None:
+    """dw += sum_b dv[b] . mask(u[b], len_u)^T (csrc/train_gemm.hip); dv [B, c_out, T], u [B, c_in, T] bf16 rows, dw f32 [c_out, c_in].
+    `defer` (only inside deferred_wgrad()): leave the partials, flush_wgrad() sums them."""
     L = _lib.lib()
     b, c_out, t = dv.shape
     c_in = u.shape[1]
-    ws = torch.empty(L.ts_train_pwconv_wgrad_workspace(b, c_in, c_out), dtype=torch.float32, device=dv.device)
-    _lib.check(L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), len_u.data_ptr() if len_u is not None else None, dw.data_ptr(), ws.data_ptr(),
-                                            b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)),
+    n_ws = L.ts_train_pwconv_wgrad_workspace(b, c_in, c_out)
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dv.device)
+    park = defer and _WGRAD_PENDING is not None and (c_out * c_in) % 4 == 0
+    _lib.check(L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), len_u.data_ptr() if len_u is not None else None,
+                                            None if park else dw.data_ptr(), ws.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)),
                "ts_train_pwconv_wgrad_mfma")
+    if park:
+        _WGRAD_PENDING.append((ws, dw, n_ws // (c_out * c_in)))
 
 
 _LENS = {}
@@ -381,7 +437,9 @@ def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor, len_u: Tensor = No
             # through them to the BatchNorm parameters, callbacks.py): the data gradient is all that is needed
             return du, None
         dw = grad_out(param, (c_out, c_in), zeroed=True)
-        _wgrad(dv, u, dw, len_u)
+        # only a bucket view may wait for the end of the piece: a fresh tensor (a second contribution to the same parameter) is added to
+        # the first by autograd right away
+        _wgrad(dv, u, dw, len_u, defer=_LAST_GRAD_OUT_IS_VIEW)
         return du, dw
     if len_u is not None:
         raise RuntimeError("_pw_bwd: an unmasked input needs the kernels that mask inside")
