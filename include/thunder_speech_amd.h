@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 6
+#define TS_ABI_VERSION 7
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -71,6 +71,12 @@ typedef struct ts_tcs_desc {
                                    (and with it ts_tcs_chain_fwd) then declines and the 4 + 4-wave kernel runs on pw_w */
   const void* res_w16;          /* bf16 [c_out_pad32/16][c_res_pad64/32][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */
+  const void* se_y;             /* ABI v7, may be NULL.  Squeeze-excite tail of a CitrinetBlock (citrinet/blocks.py:186-196) in THIS launch's epilogue:
+                                   y = relu(se_gate[b][co] * se_y[b][co][t] + result), se_y = bf16 [B][c_out][pitch_out] (the main branch's output, tail-zero
+                                   rows, 16-byte aligned), the launch being the block's residual 1x1 conv + BatchNorm (depthwise = 0, kernel = 1, stride 1,
+                                   relu ignored, both TS_TCS_*TAIL* flags).  Replaces the separate ts_se_apply_fwd pass; any other configuration returns
+                                   TS_EUNSUPPORTED and the caller runs the launch without se_y followed by ts_se_apply_fwd. */
+  const float* se_gate;         /* f32 [B][c_out] from ts_se_gate_fwd */
 } ts_tcs_desc;
 
 /* ts_tcs_desc.flags

@@ -78,6 +78,36 @@ def test_citrinet_float_lengths_and_internal_chain():
     assert float((y.float().cpu() - ref).abs().max()) <= 0.05 * scale
 
 
+def test_squeeze_excite_tail_in_the_residual_launch_equals_the_separate_pass(monkeypatch):
+    """ABI v7 (ts_tcs_desc.se_y / se_gate): internal stride-1 blocks close with relu(gate * main + residual) inside the residual 1x1 launch's
+    epilogue instead of ts_se_apply_fwd over three tensors (citrinet/blocks.py:186-196).  Same arithmetic -- the residual rounded to bf16, one
+    fma, ReLU, one rounding -- so a 6-block encoder (512 / 1024 output channels: both tile shapes of the split kernel, ragged lengths, a strided
+    block in between that must keep the separate pass) gives identical bits either way; and the fused path is really taken."""
+    import thunder_speech_amd.citrinet.blocks as cb
+    filters, ks, strides = [512, 512, 1024, 1024], [11, 13, 15, 17], [1, 1, 2, 1]
+    arch = otcs.citrinet_arch(filters=filters, kernel_sizes=ks, strides=strides, feat_in=64)
+    sd = otcs.synth_encoder_state(arch, seed=7)
+    enc = cb.CitrinetEncoder(filters=filters, kernel_sizes=ks, strides=strides, feat_in=64)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    x = bf16_round(torch.randn(3, 64, 700, generator=g)).cuda()
+    lengths = torch.tensor([700, 433, 96]).cuda()
+    calls = []
+    real = cb.se_apply
+    monkeypatch.setattr(cb, "se_apply", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(cb, "FUSE_SE_TAIL", True)
+    y1, l1 = enc(x, lengths)
+    y1 = y1.clone()
+    fused_calls = len(calls)
+    monkeypatch.setattr(cb, "FUSE_SE_TAIL", False)
+    y0, l0 = enc(x, lengths)
+    n_se = sum(1 for m in enc.modules() if isinstance(m, cb.SqueezeExcite))
+    assert len(calls) - fused_calls == n_se                   # the separate pass, once per squeeze-excite block
+    assert 0 < fused_calls < n_se                            # fused: only strided / caller-visible blocks still take it
+    assert torch.equal(l0, l1) and torch.equal(y0, y1)
+
+
 def test_tiny_citrinet_matches_reference_fixture(golden):
     from thunder_speech_amd.citrinet.blocks import CitrinetEncoder
     g = golden("citrinet_tiny.npz")

@@ -12,7 +12,7 @@ from typing import Optional
 from .build import lib_path
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 TCS_IN_TAILZERO = 1
 TCS_OUT_ZERO_TAIL = 2
 TCS_TAPS_PHASE = 4
@@ -49,6 +49,7 @@ class TcsDesc(C.Structure):
         ("c_res", C.c_int32), ("pitch_res", C.c_int32), ("t_res", C.c_int32), ("res_stride", C.c_int32),
         ("dw_ksteps", C.c_int32), ("flags", C.c_int32),
         ("dw_taps", C.c_void_p), ("dw_taps_raw", C.c_void_p), ("pw_w", C.c_void_p), ("res_w", C.c_void_p), ("pw_w16", C.c_void_p), ("res_w16", C.c_void_p), ("bias", C.c_void_p),
+        ("se_y", C.c_void_p), ("se_gate", C.c_void_p),
     ]
 
 

@@ -19,6 +19,9 @@ from .. import _lib, plan as _plan, tensors as _t
 from ..blocks import Masked, MultiSequential, _PackedCache, get_same_padding
 from ..quartznet.blocks import EncoderSequential, _FusedBlockBase, _bn_tensors, _get_act_dropout_layer, _get_conv_bn_layer
 
+# the squeeze-excite tail inside the residual launch's epilogue (ABI v7); False = always the separate ts_se_apply_fwd pass (A/B, tests)
+FUSE_SE_TAIL = True
+
 __all__ = ["SqueezeExcite", "CitrinetBlock", "stem", "body", "CitrinetEncoder"]
 
 
@@ -156,6 +159,17 @@ class CitrinetBlock(_FusedBlockBase):
         gate = se_gate(se, h, lh, tail_y, th)
         r_buf = tail_r = None
         r_stride = 1
+        if res_layer is not None and internal and self.res[0].stride == 1 and x0_tz and FUSE_SE_TAIL:
+            # the block's tail relu(gate * main + residual) inside the residual 1x1 launch's epilogue (ts_tcs_desc.se_y): no residual tensor, no
+            # separate pass; blocks the library has no such kernel for (strided, caller-visible) take the three-tensor pass below
+            out = _t.arena(("enc", slot, "out"), b, c_out, th, dev)
+            if h.shape == out.shape:
+                y_f, t_res = res_layer.run(x0, t, len_in, out=out, in_tail_zero=True, zero_tail=True, se_y=h, se_gate=gate)
+                if y_f is not None:
+                    assert t_res == th
+                    y = out[:, :, :th]
+                    _t.tag_tail_zero(y)
+                    return y, out_lengths, was_internal
         if res_layer is not None:
             r_stride = self.res[0].stride
             r_buf = _t.arena(("enc", slot, "res"), b, c_out, t, dev)

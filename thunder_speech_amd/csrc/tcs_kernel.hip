@@ -640,6 +640,7 @@ static int split_single(const ts::TcsArgs& w, int npass, int xe, int wm, int dil
   L.taps_raw = w.taps_raw; L.pw_w = w.pw_w16; L.res_w = w.res_w16; L.bias = w.bias;
   L.c_in = w.c_in; L.c_res = w.c_res; L.pitch_res = w.c_res > 0 ? w.pitch_res : w.pitch_in; L.relu = w.relu;
   L.kt_main = w.kt_main; L.kt_res = w.kt_res; L.wait_in = 0;
+  L.se_y = w.se_y; L.se_gate = w.se_gate;
   a.len = w.len_in; a.flags = nullptr; a.n_layers = 1;
   a.batch = w.batch; a.c_out = w.c_out; a.pitch_in = w.pitch_in; a.pitch_out = w.pitch_out; a.t_out = w.t_out;
   a.kernel = w.kernel; a.padding = w.padding; a.dilation = w.dilation;
@@ -675,6 +676,13 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   a.pw_w16 = static_cast<const unsigned short*>(d->pw_w16);
   a.res_w16 = static_cast<const unsigned short*>(d->res_w16);
   a.bias = d->bias;
+  a.se_y = static_cast<const unsigned short*>(d->se_y);
+  a.se_gate = d->se_gate;
+  // the squeeze-excite tail lives in the split kernel's pointwise-only launch (tail-zero rows, stride 1, bf16 result, se_y at y's pitch);
+  // every other configuration answers TS_EUNSUPPORTED and the caller runs ts_se_apply_fwd as a separate pass
+  if (a.se_y && (!a.se_gate || d->depthwise || d->stride != 1 || d->out_fp32 || d->c_res > 0 || !(d->flags & TS_TCS_IN_TAILZERO) ||
+                 !(d->flags & TS_TCS_OUT_ZERO_TAIL) || d->c_in % KC || reinterpret_cast<uintptr_t>(a.se_y) % 16))
+    return TS_EUNSUPPORTED;
   a.batch = d->batch;
   a.c_in = d->c_in; a.c_out = d->c_out; a.c_res = d->c_res;
   a.pitch_in = d->pitch_in; a.pitch_out = d->pitch_out; a.pitch_res = d->pitch_res;
@@ -776,6 +784,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
         if (st != TS_EUNSUPPORTED) return st;
       }
     }
+    if (a.se_y) return TS_EUNSUPPORTED;
     if (tz && d->pitch_in >= n_tt * TT)
       return wide ? launch<64, 4, 1, false, false, false, true, 0>(a, stream) : launch<128, 2, 1, false, false, false, true, 0>(a, stream);
     return wide ? launch<64, 4, 1, false, false>(a, stream) : launch<128, 2, 1, false, false>(a, stream);

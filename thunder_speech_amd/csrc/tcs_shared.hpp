@@ -40,6 +40,8 @@ struct TcsArgs {
   int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
   int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
   int xcd;                     // split kernel: 1 = XCD-contiguous tile order (grid is a multiple of 8)
+  const unsigned short* se_y;  // squeeze-excite tail in the epilogue (pointwise-only split launches): see ChainLayer
+  const float* se_gate;
 };
 
 __device__ __forceinline__ int conv_len(int len, int k, int s, int p, int d) {
@@ -121,6 +123,10 @@ struct ChainLayer {
   int kt_main, kt_res;             // k-steps (16 channels) of the packed weights
   int wait_in;                     // 1: x is produced by the previous layer of this launch -> its tiles are waited for
   int pad_;
+  // squeeze-excite tail (SE instantiation only): y = relu(se_gate[b][co] * se_y[b][co][t] + this layer's result) -- the closing step of a
+  // CitrinetBlock (citrinet/blocks.py:186-196) in the residual 1x1 launch's epilogue; se_y has the pitch of y
+  const unsigned short* se_y;
+  const float* se_gate;
 };
 struct ChainArgs {
   ChainLayer layer[TS_TCS_CHAIN_MAX];

@@ -82,8 +82,11 @@ struct TileWait {
 // true -- a.n_layers layers, sc1 activations, published tiles.  Two instantiations because the chain's bookkeeping costs registers in a kernel
 // that has none to spare: with the layer count a runtime value the single-layer launches of QuartzNet15x5 ran 6 % slower (11 spilled VGPRs in
 // the producers' stage loop), measured on one box.
-template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2, bool CHAIN = false>
+// SE: the epilogue closes a CitrinetBlock -- y = relu(gate[b][co] * se_y[b][co][t] + result) with the main branch's output se_y read as 16-byte row
+// segments right where the result rows leave (single-layer launches only; what ts_se_apply_fwd did in a separate pass over three tensors).
+template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2, bool CHAIN = false, bool SE = false>
 __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
+  static_assert(!(SE && CHAIN), "the squeeze-excite tail exists for single-layer launches");
   constexpr int WN = 8 / WM;
   constexpr int FW = 32 * MT;
   constexpr int TT = FW * WM;
@@ -443,7 +446,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     const __amdgpu_buffer_rsrc_t rwm = rsrc(L.pw_w);
     const __amdgpu_buffer_rsrc_t rwr = rsrc(n_res ? L.res_w : L.pw_w);
     const __amdgpu_buffer_rsrc_t ry = rsrc(L.y);
-    const unsigned floor2 = L.relu ? 0u : 0x80008000u;
+    const __amdgpu_buffer_rsrc_t rse = rsrc(SE ? L.se_y : L.y);
+    const unsigned floor2 = (L.relu && !SE) ? 0u : 0x80008000u;        // SE: the ReLU follows the gate + add, in the row-segment stage
     const bool publish = CHAIN && l + 1 < N_LAYERS;           // a later layer of this launch reads y
     unsigned* const pflag = counters + (size_t)l * nct;
 
@@ -579,6 +583,34 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
               const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * i * EP);
               v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
             }
+            if constexpr (SE) {
+              // four rows at a time, requested here (after the result rows are back in registers): fetching them ahead of the LDS round trip, or
+              // a batch ahead, was measured slower -- the epilogue has no registers left for rows in flight (77-147 spilled VGPRs, C3 9.17 ms vs
+              // 9.04 with this form and 9.17 without the fusion)
+#pragma unroll
+              for (int i0 = 0; i0 < ER / 4; i0 += 4) {
+                u32x4 yv[4];
+                float gt[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const int row = row0 + 4 * (i0 + i) + rsub;
+                  const bool in = row < a.c_out;
+                  yv[i] = in ? __builtin_amdgcn_raw_buffer_load_b128(rse, lane_y, y_soff + 4 * (i0 + i) * a.pitch_out * 2, 0) : u32x4{0u, 0u, 0u, 0u};
+                  gt[i] = in ? L.se_gate[(size_t)b * a.c_out + row] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  u32x4 o;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    const float lo = fmaf(bf16_lo(yv[i][j]), gt[i], bf16_lo(v[i0 + i][j]));
+                    const float hi = fmaf(bf16_hi(yv[i][j]), gt[i], bf16_hi(v[i0 + i][j]));
+                    o[j] = pack_bf16(lo > 0.f ? lo : 0.f, hi > 0.f ? hi : 0.f);
+                  }
+                  v[i0 + i] = o;
+                }
+              }
+            }
 #pragma unroll
             for (int i = 0; i < ER / 4; ++i) {
               if (partial) v[i] &= keep;
@@ -606,9 +638,10 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
   }
 }
 
-template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2>
+template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2, bool SE = false>
 static int launch_split(ChainArgs& a, hipStream_t stream) {
   const bool chain = a.n_layers > 1;
+  if (SE && chain) return TS_EUNSUPPORTED;
   constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 32 * NT * (8 / WM);
   constexpr int ROWB = TT <= 128 ? 256 : 512;
   constexpr int NK_ = NPASS * NKP, CST = (16 * NK_ + 16) % 32 == 16 ? 16 * NK_ + 16 : 16 * NK_ + 32, TAPB = (16 * CST + 1023) / 1024 * 1024;
@@ -618,7 +651,8 @@ static int launch_split(ChainArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) +
                      (size_t)4 * (16 * (64 * XJ + 4) * 2 + 2 * TAPB) + 16;
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = chain ? tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, true> : tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, false>;
+  auto kern = SE ? tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, false, SE>
+                 : (chain ? tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, true> : tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, false>);
   static bool attr_set[2][64] = {};                       // per device (one process may drive several GPUs)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
@@ -642,6 +676,13 @@ static int launch_split(ChainArgs& a, hipStream_t stream) {
 }
 
 int launch_split_chain(ChainArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream) {
+  if (a.layer[0].se_y) {
+    // squeeze-excite tail: the pointwise-only launches of the Citrinet blocks (512 / 256 output channels per workgroup)
+    if (a.n_layers != 1 || !a.layer[0].se_gate || dil != 1 || npass != 2) return TS_EUNSUPPORTED;
+    if (xe == 128 && wm == 1) return launch_split<2, 2, 3, 1, 1, 2, true>(a, stream);
+    if (xe == 256 && wm == 2) return launch_split<2, 4, 3, 2, 1, 2, true>(a, stream);
+    return TS_EUNSUPPORTED;
+  }
   if (wm == 1 && dil == 1 && round_up(a.c_out, 32) <= 256) {
     // narrow layers on 96-frame tiles (split_tile_rows() chose them): 8 consumer waves x 32 output channels
 #define TS_PIPE1(NP_, XJ_) if (npass == NP_ && xe == 64 * XJ_) return launch_split<NP_, XJ_, 3, 1, 1, 1>(a, stream);

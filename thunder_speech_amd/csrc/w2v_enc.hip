@@ -51,60 +51,116 @@ struct Conv0Args {
   float eps;
 };
 
-template <bool APPLY>
+// One WAVE = 128 channels (a lane owns the pair 2l, 2l + 1 of its group: packed-f32 FMAs) x a run of frames; the 4 waves of a workgroup cover 512
+// channels of the same C0_FR frames.  The signal samples are wave-uniform, so they are SCALAR loads (index built from blockIdx and the loop counter
+// only) and enter the FMAs as SGPR operands: no LDS staging, no broadcast reads -- the first form of this kernel (samples in LDS, one lane per
+// channel, 10 broadcast ds_reads per output) was LDS-issue bound at 505 us (statistics) + 869 us (apply) for C5.
+typedef float c0v2 __attribute__((ext_vector_type(2)));
+// gelu_erf on a channel pair: the polynomial and the products as packed-f32 operations (v_pk_fma_f32 / v_pk_mul_f32), only the two reciprocals and
+// the two exponentials per pair stay scalar; the same arithmetic as gelu_erf element by element
+__device__ __forceinline__ c0v2 gelu_erf2(c0v2 x) {
+  const c0v2 z = x * 0.70710678118654752f;
+  const c0v2 az = c0v2{fabsf(z[0]), fabsf(z[1])};
+  const c0v2 d = __builtin_elementwise_fma(c0v2{0.3275911f, 0.3275911f}, az, c0v2{1.f, 1.f});
+  const c0v2 t = c0v2{__frcp_rn(d[0]), __frcp_rn(d[1])};
+  c0v2 p = __builtin_elementwise_fma(t, c0v2{1.061405429f, 1.061405429f}, c0v2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(t, p, c0v2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(t, p, c0v2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(t, p, c0v2{0.254829592f, 0.254829592f});
+  p = p * t;
+  const c0v2 m = -(az * az);
+  const c0v2 e = c0v2{__expf(m[0]), __expf(m[1])};
+  const c0v2 r = __builtin_elementwise_fma(-p, e, c0v2{1.f, 1.f});            // erf(|z|)
+  const c0v2 er = c0v2{copysignf(r[0], z[0]), copysignf(r[1], z[1])};
+  const c0v2 hx = x * 0.5f;
+  return __builtin_elementwise_fma(hx, er, hx);
+}
+constexpr int C0_FB = 8;            // frames per unrolled block
+typedef float __attribute__((address_space(4))) C0ConstF;
+
+// KT / ST: kernel size and stride as compile-time constants (10 / 5: every published wav2vec2), 0 = read them from the arguments
+template <bool APPLY, int KT, int ST>
 __global__ __launch_bounds__(256) void w2v_conv0_kernel(const Conv0Args a) {
-  extern __shared__ float sig[];                               // (C0_FR - 1) * s + k samples
+  const int kk = KT ? KT : a.k, ss = ST ? ST : a.s;
+  constexpr int KU = KT ? KT : C0_KMAX;
   const int b = blockIdx.y, chunk = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int f0 = chunk * C0_FR;
   const int nf = a.t0 - f0 < C0_FR ? a.t0 - f0 : C0_FR;
-  const int span = (nf - 1) * a.s + a.k;
-  const float* x = a.wave + (size_t)b * a.n + (size_t)f0 * a.s;
-  for (int i = threadIdx.x; i < span; i += 256) sig[i] = x[i];
-  __syncthreads();
-  for (int c = threadIdx.x; c < a.c; c += 256) {
-    float w[C0_KMAX];
+  const float* __restrict__ x = a.wave + (size_t)b * a.n + (size_t)f0 * ss;
+  for (int cg = wave * 128; cg < a.c; cg += 512) {
+    const int c = cg + 2 * lane;
+    const bool ok0 = c < a.c, ok1 = c + 1 < a.c;
+    c0v2 w[KU];
 #pragma unroll
-    for (int j = 0; j < C0_KMAX; ++j) w[j] = j < a.k ? a.w[(size_t)c * a.k + j] : 0.f;
+    for (int j = 0; j < KU; ++j)
+      w[j] = c0v2{(ok0 && j < kk) ? a.w[(size_t)c * kk + j] : 0.f, (ok1 && j < kk) ? a.w[(size_t)(c + 1) * kk + j] : 0.f};
+    c0v2 scale = c0v2{1.f, 1.f}, shift = c0v2{0.f, 0.f}, s1 = c0v2{0.f, 0.f}, s2 = c0v2{0.f, 0.f};
     if constexpr (APPLY) {
-      const float scale = a.plain ? 1.f : a.stats[((size_t)b * a.c + c) * 2];
-      const float shift = a.plain ? (a.beta ? a.beta[c] : 0.f) : a.stats[((size_t)b * a.c + c) * 2 + 1];
-      const size_t o0 = ((size_t)b * a.t0 + f0) * a.c + c;
-      for (int f = 0; f < nf; ++f) {
-        float v = 0.f;
-#pragma unroll
-        for (int j = 0; j < C0_KMAX; ++j) if (j < a.k) v = fmaf(w[j], sig[f * a.s + j], v);
-        v = fmaf(v, scale, shift);
-        if (!a.plain) v = gelu_erf(v);
-        if (a.y) a.y[o0 + (size_t)f * a.c] = v;
-        if (a.y16) a.y16[o0 + (size_t)f * a.c] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
+      if (a.plain) {
+        shift = c0v2{(ok0 && a.beta) ? a.beta[c] : 0.f, (ok1 && a.beta) ? a.beta[c + 1] : 0.f};
+      } else {
+        const float* st = a.stats + ((size_t)b * a.c + c) * 2;
+        scale = c0v2{ok0 ? st[0] : 0.f, ok1 ? st[2] : 0.f};
+        shift = c0v2{ok0 ? st[1] : 0.f, ok1 ? st[3] : 0.f};
       }
-    } else {
-      float s1 = 0.f, s2 = 0.f;
-      for (int f = 0; f < nf; ++f) {
-        float v = 0.f;
+    }
+    auto frame = [&](int f) {
+      // wave-uniform address in the CONSTANT address space: hipcc then issues scalar loads (a plain global pointer stays on the vector path because
+      // the stores below might alias it)
+      const C0ConstF* xs = (const C0ConstF*)(unsigned long long)(x + (size_t)f * ss);
+      c0v2 v = c0v2{0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < C0_KMAX; ++j) if (j < a.k) v = fmaf(w[j], sig[f * a.s + j], v);
+      for (int j = 0; j < KU; ++j)
+        if (KT || j < kk) { const float sj = xs[j]; v = __builtin_elementwise_fma(w[j], c0v2{sj, sj}, v); }
+      if constexpr (APPLY) {
+        v = __builtin_elementwise_fma(v, scale, shift);
+        if (!a.plain) v = gelu_erf2(v);
+        const size_t o = ((size_t)b * a.t0 + f0 + f) * a.c + c;
+        if (a.y) { if (ok1) *reinterpret_cast<c0v2*>(a.y + o) = v; else if (ok0) a.y[o] = v[0]; }
+        if (a.y16) {
+          const unsigned pk = pack_bf16(v[0], v[1]);
+          if (ok1) *reinterpret_cast<unsigned*>(a.y16 + o) = pk; else if (ok0) a.y16[o] = (unsigned short)(pk & 0xffffu);
+        }
+      } else {
         s1 += v;
-        s2 = fmaf(v, v, s2);
+        s2 = __builtin_elementwise_fma(v, v, s2);
       }
+    };
+    int f = 0;
+    for (; f + C0_FB <= nf; f += C0_FB) {
+#pragma unroll
+      for (int u = 0; u < C0_FB; ++u) frame(f + u);
+    }
+    for (; f < nf; ++f) frame(f);
+    if constexpr (!APPLY) {
       float* p = a.partial + (((size_t)b * a.chunks + chunk) * a.c + c) * 2;
-      p[0] = s1;
-      p[1] = s2;
+      if (ok0) { p[0] = s1[0]; p[1] = s2[0]; }
+      if (ok1) { p[2] = s1[1]; p[3] = s2[1]; }
     }
   }
 }
 
-// mean / biased variance over time per (clip, channel) in fp64 -> (scale, shift) of the affine normalisation
+// mean / biased variance over time per (clip, channel) in fp64 -> (scale, shift) of the affine normalisation.  Workgroup = 64 channels x 4 chunk
+// quarters (one channel per lane, its partials strided over the 4 waves), combined through LDS: the chunk loop of the first form (one thread per
+// channel walking all 250 chunks) took 63 us for 16 x 512 channels.
 __global__ __launch_bounds__(256) void w2v_conv0_finalize_kernel(const Conv0Args a) {
-  const int b = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.c) return;
+  __shared__ double red[4][64][2];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   double s1 = 0.0, s2 = 0.0;
-  for (int ch = 0; ch < a.chunks; ++ch) {
-    const float* p = a.partial + (((size_t)b * a.chunks + ch) * a.c + c) * 2;
-    s1 += (double)p[0];
-    s2 += (double)p[1];
-  }
+  if (c < a.c)
+    for (int ch = q; ch < a.chunks; ch += 4) {
+      const float* p = a.partial + (((size_t)b * a.chunks + ch) * a.c + c) * 2;
+      s1 += (double)p[0];
+      s2 += (double)p[1];
+    }
+  red[q][lane][0] = s1;
+  red[q][lane][1] = s2;
+  __syncthreads();
+  if (q || c >= a.c) return;
+  s1 = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
+  s2 = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
   const double mu = s1 / a.t0;
   double var = s2 / a.t0 - mu * mu;
   var = var < 0.0 ? 0.0 : var;
@@ -521,14 +577,15 @@ extern "C" int ts_w2v_conv0_fwd(const float* wave, int32_t batch, int64_t n_samp
   a.chunks = (a.t0 + C0_FR - 1) / C0_FR;
   a.partial = static_cast<float*>(workspace);
   a.stats = a.partial + (size_t)batch * a.chunks * c * 2;
-  const size_t lds = ((size_t)(C0_FR - 1) * stride + kernel) * sizeof(float);
-  if (lds > 64 * 1024) return TS_EUNSUPPORTED;
+  if ((c & 1) && (y_bf16 || y)) { /* odd channel counts: the last lane of a row stores a single element (handled in the kernel) */ }
   a.plain = gn_w ? 0 : 1;
   if (!a.plain) {
-    hipLaunchKernelGGL(w2v_conv0_kernel<false>, dim3(a.chunks, batch), dim3(256), lds, stream, a);
-    hipLaunchKernelGGL(w2v_conv0_finalize_kernel, dim3((c + 255) / 256, batch), dim3(256), 0, stream, a);
+    if (kernel == 10 && stride == 5) hipLaunchKernelGGL((w2v_conv0_kernel<false, 10, 5>), dim3(a.chunks, batch), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((w2v_conv0_kernel<false, 0, 0>), dim3(a.chunks, batch), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(w2v_conv0_finalize_kernel, dim3((c + 63) / 64, batch), dim3(256), 0, stream, a);
   }
-  hipLaunchKernelGGL(w2v_conv0_kernel<true>, dim3(a.chunks, batch), dim3(256), lds, stream, a);
+  if (kernel == 10 && stride == 5) hipLaunchKernelGGL((w2v_conv0_kernel<true, 10, 5>), dim3(a.chunks, batch), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((w2v_conv0_kernel<true, 0, 0>), dim3(a.chunks, batch), dim3(256), 0, stream, a);
   return hip_status(hipGetLastError());
 }
 

@@ -203,10 +203,13 @@ class TcsLayer:
 
     def run(self, x: torch.Tensor, t_in: int, len_in: torch.Tensor, x_res: Optional[torch.Tensor] = None,
             t_res: int = 0, len_res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-            in_tail_zero: bool = False, zero_tail: bool = False):
+            in_tail_zero: bool = False, zero_tail: bool = False, se_y: Optional[torch.Tensor] = None,
+            se_gate: Optional[torch.Tensor] = None):
         """x: bf16 [B, c_in, pitch]; len_in int32 [B].  Returns (y [B, c_out, pitch_out], t_out).
         in_tail_zero: x (and x_res) satisfy the tail-zero invariant (tensors.py) -> mask-free kernels;
-        zero_tail: store 0 for frames >= the output length so that y satisfies it too."""
+        zero_tail: store 0 for frames >= the output length so that y satisfies it too.
+        se_y / se_gate: the squeeze-excite tail in this launch's epilogue, y = relu(se_gate * se_y + result) (ts_tcs_desc.se_y); returns
+        (None, t_out) -- nothing launched -- when the library has no such kernel for the configuration."""
         if not x.is_cuda:
             raise RuntimeError("thunder_speech_amd kernels run on the GPU only (no CPU fallback)")
         L = _lib.lib()
@@ -233,6 +236,15 @@ class TcsLayer:
         stream = torch.cuda.current_stream(x.device).cuda_stream
         args = (x.data_ptr(), len_in.data_ptr(), x_res.data_ptr() if self.c_res else None,
                 len_res.data_ptr() if self.c_res else None, out.data_ptr(), stream)
+        if se_y is not None:
+            if se_gate is None or se_y.shape != out.shape or se_y.dtype != torch.bfloat16 or self.pre is not None:
+                return None, t_out
+            d.se_y, d.se_gate = se_y.data_ptr(), se_gate.data_ptr()
+            st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
+            if st == _lib.TS_EUNSUPPORTED:
+                return None, t_out
+            _lib.check(st, "ts_tcs_subblock_fwd")
+            return out, t_out
         if self.taps_phase is not None and in_tail_zero and zero_tail:
             # dilation 2: offer the phase-split fragments first; the library declines geometries it has no such kernel for
             d.flags |= _lib.TCS_TAPS_PHASE
