@@ -787,6 +787,10 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     if (a.se_y) return TS_EUNSUPPORTED;
     if (tz && d->pitch_in >= n_tt * TT)
       return wide ? launch<64, 4, 1, false, false, false, true, 0>(a, stream) : launch<128, 2, 1, false, false, false, true, 0>(a, stream);
+    // narrow layers whose 128-frame tiling leaves compute units idle (the training path's 32 clips x 501 frames: 128 tiles on 256 CUs) take
+    // 64-frame tiles: 9.2 -> 7.1 us at 256 -> 256 channels, 12.9 -> 9.5 at 512 -> 256 (tools/diag/pw_tile_bench.py); for the wide layers the
+    // same halving (64 x 256 tiles, two workgroups per CU) measured slower, 16.7 vs 15.4 us
+    if (!wide && (long long)d->batch * n_tt * ((round_up(d->c_out, 32) + 255) / 256) < cu_count()) return launch<64, 2, 1, false, false>(a, stream);
     return wide ? launch<64, 4, 1, false, false>(a, stream) : launch<128, 2, 1, false, false>(a, stream);
   }
   if (d->stride == 2)
