@@ -306,12 +306,14 @@ def _tcs_ok(bf: bool, k: int) -> bool:
 
 def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int) -> None:
     """y[b] = Wn . x[b] on the inference kernel's pointwise-only mode: x bf16 rows [B, K, T], frags = B-fragments of Wn [n_out, K],
-    y bf16 rows [B, n_out, T].  Frames beyond T inside the row pitch are read and written as scratch (every frame is independent)."""
+    y bf16 rows [B, n_out, T] -- or f32 rows (the decoder's logits: the kernel's fp32-output mode, what inference uses for them; through the f32
+    GEMM a 29-row product costs 113 us of mostly padding, here 20).  Frames beyond T inside the row pitch are read and written as scratch
+    (every frame is independent)."""
     import ctypes as C
     b, k, t = x.shape
     d = _lib.TcsDesc()
     d.batch, d.c_in, d.c_out, d.t_in, d.t_out, d.pitch_in, d.pitch_out = b, k, n_out, t, t, _pitch(x), _pitch(y)
-    d.kernel, d.stride, d.dilation, d.padding, d.depthwise, d.relu, d.out_fp32 = 1, 1, 1, 0, 0, 0, 0
+    d.kernel, d.stride, d.dilation, d.padding, d.depthwise, d.relu, d.out_fp32 = 1, 1, 1, 0, 0, 0, int(y.dtype == torch.float32)
     # no TS_TCS_IN_TAILZERO: with `lens` = the full length the generic kernel (4 producer + 4 consumer waves, 64 / 128-frame tiles) runs, which
     # at these sizes (32 x 501 frames) is 2 us per launch faster than the split kernel the flag would select (15.5 vs 17.5 us at 512^2,
     # 8.8 vs 10.8 at 256^2; tools/diag/gemm_bench.py) -- the split kernel's 96-frame tiles and 12 waves pay off at inference batch sizes
@@ -411,7 +413,7 @@ def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False, lens: T
     c_out = w2.shape[0]
     bf = u.dtype == torch.bfloat16
     v = alloc(b, c_out, t, u.device, torch.float32 if (f32_out or not bf) else torch.bfloat16)
-    if not f32_out and _tcs_ok(bf, c_in):
+    if _tcs_ok(bf, c_in):
         _tcs_pointwise(u, pw_frags(param, w2)[0], v, lens if lens is not None else _full_lengths(b, t, u.device), c_out)
     else:
         if lens is not None:
