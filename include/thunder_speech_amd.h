@@ -331,6 +331,10 @@ int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len
 int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* dx,
                         float* dw, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride,
                         int32_t dilation, int32_t padding, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);
+/* Kernel choice of ts_train_dwconv_bwd / ts_train_dwconv_bwd_bn for bf16 rows in the "same" geometry with channels % 16 == 0 and odd
+ * kernel <= 75: 1 (default) = both gradients on the matrix cores (v_mfma_f32_4x4x4_16b_bf16, taps rounded to bf16 like the forward's), 0 = the
+ * packed-f32 FIR kernel (what f32 rows and every other geometry always take).  Process-wide; returns the previous mode. */
+int ts_train_dwconv_bwd_select(int32_t mode);
 /* BatchNorm(train) [+ ReLU] between two repeats folded into the depthwise launches ("same" geometry only: stride 1, dilation 1, odd
  * kernel, padding (k-1)/2, even channel count; anything else TS_EUNSUPPORTED), so that the normalised tensor is never stored:
  *   ts_train_bn_stats       clip-group sums of v only (sums: 16*C doubles = [8][C][2] (sum v, sum v^2)), no apply pass

@@ -1,0 +1,103 @@
+"""GPU parity of the matrix-core depthwise backward (csrc/train_enc.hip dw_bwd_mfma_kernel, selected by ts_train_dwconv_bwd_select) -- the backward
+of the depthwise MaskedConv1d of a training-mode QuartznetBlock (/root/reference/src/thunder/quartznet/blocks.py:95-164, 317-338) on bf16 rows --
+against float64 autograd through F.conv1d on the same bf16 inputs, and against the packed-f32 FIR kernel it replaces.  Tolerances: dx is stored in
+bf16 (half an ulp = 0.4 % of a value; 6e-3 of the tensor's scale covers it), dw is an f32 sum of exact bf16 products (1e-5), the folded BatchNorm's
+sums are taken over the bf16-rounded gradient (4e-3)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(mode, b, ch, t, k, lens, bn, relu=True, no_dw=False):
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    old = L.ts_train_dwconv_bwd_select(mode)
+    try:
+        p = (k - 1) // 2
+        pitch = (t + 191) // 192 * 192 + 64
+        g = torch.Generator(device="cuda").manual_seed(1)
+        dy = torch.randn(b, ch, pitch, device="cuda", generator=g).bfloat16()
+        x = torch.randn(b, ch, pitch, device="cuda", generator=g).bfloat16()
+        x[:, :, t:] = float("nan")                      # columns >= T are scratch: nothing may leak out of them
+        dy[:, :, t:] = float("nan")
+        w = torch.randn(ch, k, device="cuda", generator=g) / k ** 0.5
+        li = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        dx = torch.full((b, ch, pitch), 7.0, device="cuda").bfloat16()
+        dw = torch.zeros(ch, k, device="cuda")
+        out = {}
+        if bn:
+            mr = torch.stack([0.1 * torch.randn(ch, device="cuda", generator=g), 1.0 + 0.2 * torch.rand(ch, device="cuda", generator=g)], 1).contiguous()
+            gamma = 1.0 + 0.1 * torch.randn(ch, device="cuda", generator=g)
+            beta = 0.1 * torch.randn(ch, device="cuda", generator=g)
+            dgam, dbet = torch.zeros(ch, device="cuda"), torch.zeros(ch, device="cuda")
+            rc = L.ts_train_dwconv_bwd_bn(dy.data_ptr(), x.data_ptr(), mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), int(relu), li.data_ptr(), li.data_ptr(),
+                                          w.data_ptr(), dx.data_ptr(), None if no_dw else dw.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), b, ch, t, k, p, pitch, 1, st)
+            out["dgamma"], out["dbeta"] = dgam, dbet
+        else:
+            rc = L.ts_train_dwconv_bwd(dy.data_ptr(), x.data_ptr(), li.data_ptr(), li.data_ptr(), w.data_ptr(), dx.data_ptr(), None if no_dw else dw.data_ptr(),
+                                       b, ch, t, t, k, 1, 1, p, pitch, pitch, 1, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        out["dx"], out["dw"] = dx[:, :, :t].float(), dw
+        mask = (torch.arange(t, device="cuda")[None, :] < li[:, None]).double()[:, None, :]
+        xd = torch.nan_to_num(x[:, :, :t].double())
+        dyd = torch.nan_to_num(dy[:, :, :t].double()) * mask
+        if bn:
+            sc = (gamma * mr[:, 1]).double()[None, :, None]
+            hs = (beta - mr[:, 0] * gamma * mr[:, 1]).double()[None, :, None]
+            pre = xd * sc + hs
+            yv = (torch.relu(pre) if relu else pre).bfloat16().double()
+        else:
+            yv = xd
+        xg = (yv * mask).requires_grad_(True)
+        wg = (w.bfloat16().double() if mode else w.double()).requires_grad_(True)      # the matrix-core kernel rounds the taps to bf16, like the forward
+        y = torch.nn.functional.conv1d(xg, wg[:, None, :], padding=p, groups=ch)
+        (y * dyd).sum().backward()
+        ref = {"dx": xg.grad * mask, "dw": wg.grad}
+        if bn:
+            gate = ((pre > 0).double() if relu else torch.ones_like(pre)) * mask
+            gref = ref["dx"] * gate
+            xhat = (xd - mr[:, 0].double()[None, :, None]) * mr[:, 1].double()[None, :, None]
+            ref = {"dx": gref, "dw": wg.grad, "dbeta": gref.sum((0, 2)), "dgamma": (gref * xhat).sum((0, 2))}
+        return out, ref
+    finally:
+        L.ts_train_dwconv_bwd_select(old)
+
+
+CASES = [(3, 32, 300, 33, [300, 211, 97]), (2, 16, 77, 5, [77, 40]), (5, 64, 501, 63, [501, 499, 3, 256, 257]), (2, 48, 700, 75, [700, 512]),
+         (4, 32, 256, 39, [256, 255, 1, 129]), (2, 16, 520, 51, [520, 260]), (1, 16, 128, 3, [128]), (2, 16, 1030, 21, [1030, 0])]
+
+
+@pytest.mark.parametrize("mode", [1, 2])                       # 128-frame tiles (two workgroups per CU) and 256-frame tiles
+@pytest.mark.parametrize("bn", [False, True])
+@pytest.mark.parametrize("b,ch,t,k,lens", CASES)
+def test_matrix_core_depthwise_backward_matches_float64_autograd(mode, bn, b, ch, t, k, lens):
+    out, ref = _run(mode, b, ch, t, k, lens, bn)
+    tol = {"dx": 6e-3, "dw": 1e-5, "dbeta": 4e-3, "dgamma": 4e-3}
+    for key, r in ref.items():
+        scale = max(float(r.abs().max()), 1e-6)
+        err = float((out[key].double() - r).abs().max()) / scale
+        assert torch.isfinite(out[key]).all() and err <= tol[key], (key, err)
+
+
+def test_frozen_weight_and_identity_affine_variants():
+    """dw == NULL (the reference's first fine-tuning phase freezes the convolutions): data gradient only, same values; a folded BatchNorm without
+    ReLU (block tails) gates nothing."""
+    full, _ = _run(1, 3, 32, 300, 33, [300, 211, 97], True)
+    part, _ = _run(1, 3, 32, 300, 33, [300, 211, 97], True, no_dw=True)
+    assert torch.equal(full["dx"], part["dx"]) and float(part["dw"].abs().max()) == 0.0
+    out, ref = _run(1, 3, 32, 300, 33, [300, 211, 97], True, relu=False)
+    for key, r in ref.items():
+        assert float((out[key].double() - r).abs().max()) <= 6e-3 * max(float(r.abs().max()), 1e-6), key
+
+
+def test_select_falls_back_to_the_fir_kernel_for_other_geometries():
+    """Channel counts that are not a multiple of 16 (and f32 rows, dilation, stride) keep the packed-f32 FIR kernel whatever the mode says."""
+    out1, ref = _run(1, 2, 24, 200, 11, [200, 150], False)
+    out0, _ = _run(0, 2, 24, 200, 11, [200, 150], False)
+    assert torch.equal(out1["dx"], out0["dx"])
+    assert float((out1["dw"].double() - _run(0, 2, 24, 200, 11, [200, 150], False)[1]["dw"]).abs().max()) <= 1e-4 * float(ref["dw"].abs().max())

@@ -844,6 +844,270 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
+// Depthwise backward on the matrix cores (bf16 rows, "same" geometry, channels % 16 == 0): v_mfma_f32_4x4x4_16b_bf16 = 16 independent
+// 4 x 4 x 4 products per instruction, the shape the inference kernel's depthwise producers use (csrc/tcs_split.hip).  A WAVE owns 16
+// consecutive channels and walks units = (clip, TT-frame tile); per unit it stages the dy and x windows [t0 - H, t0 + TT + H) of its 16
+// rows in wave-private LDS (zero outside the lengths; x through the previous repeat's BatchNorm + ReLU when that is folded in) and runs
+//   * the WEIGHT gradient  dw[c][j] += sum_u dym[t0 + u] xm[t0 + u + j - p],  u in [0, TT):
+//       block = (channel, group g of 16 taps), D[i][jj] += sum_k A[i][k] B[k][jj] with A[i][k] = dys[H + tau + k - i] (a 4-frame window of
+//       dy, shifted by the lane's i: three dwords + v_alignbit), B[k][jj] = xs[H - p4 + tau + k + 4 jj + 16 g]  ->  tap' = i + 4 jj + 16 g,
+//       tap = tap' - (p4 - p), p4 = round_up(p, 4).  B of (g, step s) is B of (g + 1, step s - 4): the windows slide through a register
+//       queue, ONE new 8-byte LDS read per step serves all G groups.  The first / last step of a tile mask the elements u < 0 / u >= TT.
+//   * the DATA gradient  dx[t0 + r] = sum_j w[c][j] dym[t0 + r + p - j]  as the inference producers' Toeplitz product: block = channel,
+//       column = one of 4 runs of TT / 4 frames, A = rows of the (flipped) tap Toeplitz slices out of a two-copy tap image built once per
+//       wave, B = 4-frame windows of dys sliding through registers; results leave through the (now free) x window as 16-byte row segments.
+// With a folded BatchNorm the data gradient's epilogue is that BatchNorm's backward first half (g = dx * (y > 0), sum g, sum g * xhat), as in
+// dw_bwd_pair_kernel.  Workgroup = 4 waves on the SAME 16 channels (different units): the weight gradient of the workgroup is combined in
+// LDS and leaves as one atomic per (channel, tap).  The VALU pair kernel this replaces spent 45 us per 512-channel K63 layer at 32 x 501
+// frames on 49 MB of traffic: FIR arithmetic, not memory.
+// ----------------------------------------------------------------------------------------------------------------------
+struct DwbArgs {
+  const bf16_t* dy; const bf16_t* x; const int* len_in; const int* len_out; const float* w;
+  bf16_t* dx; float* dw;
+  int batch, ch, t, k, p, pitch, n_tiles, upw;
+  PairAffine aff; float* in_dgamma; float* in_dbeta;
+};
+__host__ __device__ constexpr int dwb_pitch(int w_el, int mod_dw) {        // row pitch in elements: >= w_el, pitch / 2 == mod_dw (mod 64)
+  const int dwords = (w_el + 1) / 2;
+  return 2 * ((dwords + 63 - mod_dw) / 64 * 64 + mod_dw);
+}
+
+template <int TT, int NK, int G>
+__global__ __launch_bounds__(256, TT <= 128 ? 2 : 1) void dw_bwd_mfma_kernel(const DwbArgs a) {
+  constexpr int M = TT / 16, RUN = TT / 4, S = TT / 4;      // dx: M steps of 4 frames per run; dw: S + 1 steps of 4 frames
+  constexpr int HMAX = 40;                                  // halo for K <= 75 (round_up(37, 8))
+  constexpr int WY = TT + 2 * HMAX + 16, WX = TT + 2 * HMAX + 16;
+  constexpr int RPY = dwb_pitch(WY, 4), RPX = dwb_pitch(WX, 8);
+  constexpr int CST = (16 * NK + 16) % 32 == 16 ? 16 * NK + 16 : 16 * NK + 32;
+  constexpr int WAVEB = 16 * RPY * 2 + 16 * RPX * 2;
+  static_assert(16 * CST <= 16 * RPY * 2 && 16 * (4 * NK + 4) * 4 <= 16 * RPX * 2, "the tap image / tap rows borrow the windows' LDS");
+  extern __shared__ __attribute__((aligned(16))) char dwb_smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  char* const dys = dwb_smem + (size_t)wave * WAVEB;
+  char* const xs = dys + 16 * RPY * 2;
+  char* const tapl = dys;                                   // the tap image lives in registers (T) before the first window is staged
+  const int row = lane >> 2, q = lane & 3;                  // channel of the 16, and i / jj / run / staging sub-lane
+  const int c = blockIdx.x * 16 + row;
+  const int K = a.k, p = a.p, H = round_up(p, 8), p4 = round_up(p, 4), woff = H - p4, dl = p4 - p;
+  const bool need_dw = a.dw != nullptr;
+  // ---- tap image of this wave's 16 channels: wp[x] = w[K + 2 + dl - x] for x in [3 + dl, K + 2 + dl], two copies (the second shifted by one
+  // element), dwords interleaved: dword d of copy e at byte 8 d + 4 e
+  {
+    // the 16 tap rows first (coalesced, all loads in flight at once: 16 K floats = this wave's slice of w), flipped into wl[row][x] = wp[x]
+    float* const wl = reinterpret_cast<float*>(xs);                        // [16][4 NK + 4], free until the first unit is staged
+    constexpr int WLP = 4 * NK + 4, NWL = (16 * WLP + 63) / 64;
+    const float* const wg = a.w + (size_t)blockIdx.x * 16 * K;
+    float tv[NWL];
+#pragma unroll
+    for (int it = 0; it < NWL; ++it) {
+      const int idx = it * 64 + lane, rr = idx / WLP, x = idx % WLP, j = K + 2 + dl - x;
+      tv[it] = (rr < 16 && j >= 0 && j < K) ? wg[(size_t)rr * K + j] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NWL; ++it) { const int idx = it * 64 + lane; if (idx < 16 * WLP) wl[idx] = tv[it]; }
+    __builtin_amdgcn_wave_barrier();
+    const float* const wr = wl + row * WLP;
+#pragma unroll
+    for (int it = 0; it < (2 * NK + 2 + 3) / 4; ++it) {
+      const int d = q + 4 * it;
+      if (d <= 2 * NK + 1) {
+        const float w0 = wr[2 * d], w1 = wr[2 * d + 1], w2 = 2 * d + 2 < WLP ? wr[2 * d + 2] : 0.f;
+        unsigned* const o = reinterpret_cast<unsigned*>(tapl + row * CST + 8 * d);
+        o[0] = pack_bf16(w0, w1);
+        o[1] = pack_bf16(w1, w2);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  u32x2 T[NK];
+  {
+    const char* const trow = tapl + row * CST + ((lane & 1) ? 0 : 4) + ((lane & 3) < 2 ? 8 : 0);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk)
+      T[kk] = u32x2{*reinterpret_cast<const unsigned*>(trow + kk * 16), *reinterpret_cast<const unsigned*>(trow + kk * 16 + 8)};
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- folded BatchNorm of the input
+  const bool af = a.aff.mean_rstd != nullptr;
+  float sc = 1.f, hs = 0.f, mu = 0.f, rs = 0.f;
+  if (af) { mu = a.aff.mean_rstd[2 * c]; rs = a.aff.mean_rstd[2 * c + 1]; sc = a.aff.gamma[c] * rs; hs = a.aff.beta[c] - mu * sc; }
+  const bool relu = af && a.aff.relu != 0;
+  float s1 = 0.f, s2 = 0.f;
+  f32x4 E[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) E[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dw: masks of the first (u < 0) and last (u >= TT) step for this lane's shift i = q
+  const unsigned mF0 = q == 0 ? ~0u : (q == 1 ? 0xFFFF0000u : 0u), mF1 = q == 3 ? 0xFFFF0000u : ~0u;
+  const unsigned mL0 = q == 0 ? 0u : (q == 1 ? 0x0000FFFFu : ~0u), mL1 = q == 3 ? 0x0000FFFFu : 0u;
+  const unsigned ash = (q & 1) ? 16u : 0u;
+  const char* const arow = dys + (size_t)row * RPY * 2 + ((H - q - (q & 1)) >> 1) * 4;          // + 8 s per step
+  const char* const brow = xs + (size_t)row * RPX * 2 + (H - p4 + 4 * q) * 2;                   // + 8 s' per queue entry
+  const char* const xrow = dys + (size_t)row * RPY * 2 + (woff + q * RUN) * 2;                  // dx windows: + 8 u
+  const int unit0 = (blockIdx.y * 4 + wave) * a.upw, n_units = a.batch * a.n_tiles;
+  const int unit1 = unit0 + a.upw < n_units ? unit0 + a.upw : n_units;
+  // staging: 16-byte chunks, lane (row, q) takes chunks q, q + 4, ... of its row; the loads of unit n + 1 are issued (into registers) before the
+  // matrix work of unit n starts, the LDS writes follow when unit n is done
+  const int wxn = H - p4 + TT + 16 * G + 4 > TT + 2 * H ? H - p4 + TT + 16 * G + 4 : TT + 2 * H;
+  // (the data gradient's windows reach woff + TT + 4 NK frames into the dy rows whatever K is: a template NK larger than this K's k-steps meets
+  // zero taps there, and what they multiply must be staged zeros, not stale LDS)
+  const int wyn = woff + TT + 4 * NK > TT + 2 * H ? woff + TT + 4 * NK : TT + 2 * H;
+  const int ncy = (wyn + 7) / 8, ncx = (wxn + 7) / 8;
+  constexpr int NCQ = (WX / 8 + 3) / 4;
+  u32x4 gy[NCQ], gx[NCQ];
+  auto fetch = [&](int un) {
+    const int b = un / a.n_tiles, t0 = (un % a.n_tiles) * TT;
+    const int li = clamp_len(a.len_in, b, a.t), lo = a.len_out ? clamp_len(a.len_out, b, a.t) : a.t;
+    const size_t r0 = ((size_t)b * a.ch + c) * a.pitch;
+#pragma unroll
+    for (int it = 0; it < NCQ; ++it) {
+      const int ck = q + 4 * it, f = t0 - H + 8 * ck;
+      gy[it] = (ck < ncy && f >= 0 && f < lo) ? *reinterpret_cast<const u32x4*>(a.dy + r0 + f) : u32x4{0u, 0u, 0u, 0u};
+      gx[it] = (need_dw && ck < ncx && f >= 0 && f < li) ? *reinterpret_cast<const u32x4*>(a.x + r0 + f) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  if (unit0 < unit1) fetch(unit0);
+  for (int un = unit0; un < unit1; ++un) {
+    const int b = un / a.n_tiles, t0 = (un % a.n_tiles) * TT;
+    const int li = clamp_len(a.len_in, b, a.t), lo = a.len_out ? clamp_len(a.len_out, b, a.t) : a.t;
+    const size_t r0 = ((size_t)b * a.ch + c) * a.pitch;
+#pragma unroll
+    for (int it = 0; it < NCQ; ++it) {
+      const int ck = q + 4 * it, f = t0 - H + 8 * ck;
+      if (ck < ncy) {
+        u32x4 v = gy[it];
+        if (f < lo && f + 8 > lo) v = keep_first(v, lo - f);
+        *reinterpret_cast<u32x4*>(dys + (size_t)row * RPY * 2 + 16 * ck) = v;
+      }
+      if (need_dw && ck < ncx) {
+        u32x4 v = gx[it];
+        if (f >= 0 && f < li) {
+          if (af) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float y0 = fmaf(bf16_lo(v[j]), sc, hs), y1 = fmaf(bf16_hi(v[j]), sc, hs);
+              if (relu) { y0 = y0 > 0.f ? y0 : 0.f; y1 = y1 > 0.f ? y1 : 0.f; }
+              v[j] = pack_bf16(y0, y1);
+            }
+          }
+          if (f + 8 > li) v = keep_first(v, li - f);
+        }
+        *reinterpret_cast<u32x4*>(xs + (size_t)row * RPX * 2 + 16 * ck) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (un + 1 < unit1) fetch(un + 1);
+    // the raw input under this tile's output chunks, for the folded BatchNorm's backward in the epilogue: requested now, used after the products
+    constexpr int NOQ = TT / 32;
+    u32x4 vraw[NOQ];
+    if (af) {
+#pragma unroll
+      for (int it = 0; it < NOQ; ++it) {
+        const int f = t0 + 8 * (q + 4 * it);
+        vraw[it] = f < li ? *reinterpret_cast<const u32x4*>(a.x + r0 + f) : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int it = 0; it < NOQ; ++it) {                   // zero from the length on: the sums below then need no per-element guard
+        const int f = t0 + 8 * (q + 4 * it);
+        if (f < li && f + 8 > li) vraw[it] = keep_first(vraw[it], li - f);
+      }
+    }
+    // ---- weight gradient
+    if (need_dw) {
+      constexpr int QL = 4 * G;
+      s16x4 R[QL];
+#pragma unroll
+      for (int u = 0; u < 4 * (G - 1); ++u) R[u] = *reinterpret_cast<const s16x4*>(brow + 8 * u);
+#pragma unroll
+      for (int s_ = 0; s_ <= S; ++s_) {
+        R[(s_ + 4 * (G - 1)) % QL] = *reinterpret_cast<const s16x4*>(brow + 8 * (s_ + 4 * (G - 1)));
+        const unsigned* const ap = reinterpret_cast<const unsigned*>(arow + 8 * s_);
+        const unsigned d0 = ap[0], d1 = ap[1], d2 = ap[2];
+        unsigned a0 = __builtin_amdgcn_alignbit(d1, d0, ash), a1 = __builtin_amdgcn_alignbit(d2, d1, ash);
+        if (s_ == 0) { a0 &= mF0; a1 &= mF1; }
+        if (s_ == S) { a0 &= mL0; a1 &= mL1; }
+        const s16x4 av = __builtin_bit_cast(s16x4, u32x2{a0, a1});
+#pragma unroll
+        for (int g = 0; g < G; ++g) E[g] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av, R[(s_ + 4 * g) % QL], E[g], 0, 0, 0);
+      }
+    }
+    // ---- data gradient
+    f32x4 d[M];
+    {
+      s16x4 P[NK + M - 1];
+#pragma unroll
+      for (int u = 0; u < NK + M - 1; ++u) P[u] = *reinterpret_cast<const s16x4*>(xrow + 8 * u);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+          d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[kk]), P[kk + m], kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : d[m], 0, 0, 0);
+    }
+    // results -> the x window's LDS (free now) as bf16 [16 rows][TT], then out in 16-byte row segments
+    __builtin_amdgcn_wave_barrier();
+    char* const ot = xs;                                   // row pitch TT * 2 + 16 bytes
+    constexpr int OP = TT * 2 + 16;
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      *reinterpret_cast<u32x2*>(ot + (size_t)row * OP + (q * RUN + 4 * m) * 2) = u32x2{pack_bf16(d[m][0], d[m][1]), pack_bf16(d[m][2], d[m][3])};
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NOQ; ++it) {
+      const int ck = q + 4 * it, f = t0 + 8 * ck;
+      if (f >= a.pitch) break;
+      u32x4 v = *reinterpret_cast<const u32x4*>(ot + (size_t)row * OP + 16 * ck);
+      if (f >= li) v = u32x4{0u, 0u, 0u, 0u}; else if (f + 8 > li) v = keep_first(v, li - f);
+      if (af && f < li) {
+        // g = dx * (y > 0); s1 = sum g; s2 accumulates sum g * v here -- sum g * xhat = rstd * (sum g v - mean * sum g) is formed once per channel
+        const u32x4 vv = vraw[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = bf16_lo(vv[j]), v1 = bf16_hi(vv[j]);
+          float g0 = bf16_lo(v[j]), g1 = bf16_hi(v[j]);
+          if (relu) { g0 = fmaf(v0, sc, hs) > 0.f ? g0 : 0.f; g1 = fmaf(v1, sc, hs) > 0.f ? g1 : 0.f; }
+          s1 += g0 + g1;
+          s2 = fmaf(g0, v0, fmaf(g1, v1, s2));
+          if (relu) v[j] = pack_bf16(g0, g1);
+        }
+      }
+      *reinterpret_cast<u32x4*>(a.dx + r0 + f) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- flush: folded-BatchNorm sums (4 lanes per channel), then the workgroup's weight gradient
+  if (af) {
+    // one atomic per channel and WORKGROUP: 64 waves adding to the same address one by one cost 8 us per layer
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+    s2 = (s2 - mu * s1) * rs;
+    __syncthreads();
+    float* const rb = reinterpret_cast<float*>(dwb_smem) + 4 * 16 * 16 * G;     // behind the weight-gradient partials: [4 waves][16][2]
+    if (q == 0) { rb[(wave * 16 + row) * 2] = s1; rb[(wave * 16 + row) * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int rr = threadIdx.x >> 1, e = threadIdx.x & 1;
+      const float tot = rb[(0 * 16 + rr) * 2 + e] + rb[(1 * 16 + rr) * 2 + e] + rb[(2 * 16 + rr) * 2 + e] + rb[(3 * 16 + rr) * 2 + e];
+      atomicAdd((e ? a.in_dgamma : a.in_dbeta) + blockIdx.x * 16 + rr, tot);
+    }
+  }
+  if (need_dw) {
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(dwb_smem);                  // [4 waves][16 channels][16 G taps']
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[((size_t)wave * 16 + row) * (16 * G) + 16 * g + 4 * q + i] = E[g][i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * K; idx += 256) {
+      const int rr = idx / K, j = idx % K, tp = j + dl;
+      float tot = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) tot += red[((size_t)wv * 16 + rr) * (16 * G) + tp];
+      atomicAdd(a.dw + (size_t)(blockIdx.x * 16 + rr) * K + j, tot);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
 // Row-wise streaming kernels: one WAVE = one (row, 512-frame chunk) unit, 64 lanes x 8 elements (16 / 32 bytes per lane), four
 // units per 256-thread workgroup (a 10 s clip is 501 frames: with one workgroup per row three of its four waves had nothing to do).
 // Rows are pitched and 16-byte aligned, so every access is a whole vector; columns >= t are scratch and may be overwritten.
@@ -1215,6 +1479,56 @@ extern "C" int ts_train_dwconv_fwd_bn(const void* v, const void* in_sums, const 
                                   running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked)});
 }
 
+// the matrix-core depthwise backward (dw_bwd_mfma_kernel): bf16 rows, "same" geometry, channels % 16 == 0, odd K <= 75
+static int g_dw_bwd_mfma = 1, g_dw_bwd_tile = 128;
+/* 1 (default): bf16 depthwise backward on the matrix cores where the geometry allows; 0: always the VALU pair kernel (A/B, tests); 2: as 1 on
+   256-frame tiles (one workgroup per compute unit) */
+extern "C" int ts_train_dwconv_bwd_select(int32_t mode) {
+  const int old = g_dw_bwd_mfma ? (g_dw_bwd_tile == 256 ? 2 : 1) : 0;
+  g_dw_bwd_mfma = mode ? 1 : 0;
+  g_dw_bwd_tile = mode == 2 ? 256 : 128;
+  return old;
+}
+
+template <int TT, int NK, int G>
+static int dw_bwd_mfma_go(const DwbArgs& a, int n_cg, hipStream_t stream) {
+  constexpr int WY = TT + 96, WX = TT + 96;
+  const size_t lds = (size_t)4 * (16 * dwb_pitch(WY, 4) * 2 + 16 * dwb_pitch(WX, 8) * 2);
+  auto kern = dw_bwd_mfma_kernel<TT, NK, G>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TS_EUNSUPPORTED;
+    attr_set[dev] = true;
+  }
+  const int units = a.batch * a.n_tiles;
+  hipLaunchKernelGGL(kern, dim3(n_cg, (units + 4 * a.upw - 1) / (4 * a.upw)), dim3(256), lds, stream, a);
+  return hip_status(hipGetLastError());
+}
+
+static int dw_bwd_mfma_launch(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* dx, float* dw,
+                              int batch, int ch, int t, int k, int pad, int pitch, PairAffine aff, float* in_dgamma, float* in_dbeta, hipStream_t stream) {
+  if (ch % 16 || !(k & 1) || k > 75 || k < 3) return TS_EUNSUPPORTED;
+  const int p4 = round_up(pad, 4), dl = p4 - pad;
+  const int nk = (dl + k + 2) / 4 + 1, g = (dl + k + 15) / 16;
+  DwbArgs a;
+  a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.len_in = len_in; a.len_out = len_out; a.w = w; a.dx = (bf16_t*)dx; a.dw = dw;
+  a.batch = batch; a.ch = ch; a.t = t; a.k = k; a.p = pad; a.pitch = pitch; a.aff = aff; a.in_dgamma = in_dgamma; a.in_dbeta = in_dbeta;
+  // 128-frame tiles: 62 KiB of LDS per workgroup, two workgroups (8 waves) per compute unit
+  const int TT = g_dw_bwd_tile;
+  a.n_tiles = (t + TT - 1) / TT;
+  // units per wave: enough workgroups for every compute unit, as few atomics per (channel, tap) as that allows
+  const int n_cg = ch / 16, units = batch * a.n_tiles, wg_per_cu = TT <= 128 ? 2 : 1;
+  int upw = (int)(((long long)n_cg * units + 4LL * wg_per_cu * cu_count() - 1) / (4LL * wg_per_cu * cu_count()));
+  a.upw = upw < 1 ? 1 : upw;
+  (void)hipGetLastError();
+#define TS_DWB(NK_, G_) if (nk <= NK_ && g <= G_) return TT == 128 ? dw_bwd_mfma_go<128, NK_, G_>(a, n_cg, stream) : dw_bwd_mfma_go<256, NK_, G_>(a, n_cg, stream);
+  TS_DWB(9, 3) TS_DWB(11, 3) TS_DWB(15, 4) TS_DWB(17, 4) TS_DWB(21, 5)
+#undef TS_DWB
+  return TS_EUNSUPPORTED;
+}
+
 static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w,
                            void* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
                            int32_t stride, int32_t dil, int32_t pad, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_,
@@ -1225,6 +1539,10 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
   if (aff.mean_rstd && !pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) return TS_EUNSUPPORTED;
   if (pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
+    if (act == 1 && g_dw_bwd_mfma) {
+      const int st = dw_bwd_mfma_launch(dy, x, len_in, len_out, w, dx, dw, batch, ch, t_in, k, pad, pitch_in, aff, in_dgamma, in_dbeta, stream);
+      if (st != TS_EUNSUPPORTED) return st;
+    }
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + pair_gl(k, pad) + PAIR_TAPS) * sizeof(v2f);
     const int cpw = batch >= 16 ? (batch + 15) / 16 : 1;        // >= 2 clips per wave: the second clip's loads overlap the first one's FIR
     const dim3 grid2(ch / 2, (batch + 4 * cpw - 1) / (4 * cpw));
