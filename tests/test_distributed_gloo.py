@@ -325,6 +325,11 @@ def test_split_stages_balances_trainable_bytes_and_segment_parameters_orders_by_
     assert st2[0][0] is net2.encoder[0] and len(st2[0]) >= 2 and all(any(p.requires_grad for b in st for p in b.parameters()) for st in st2)
     assert all(p.requires_grad for g in segment_parameters(net2, 4) for p in g)
     assert len(split_stages(blocks, 1)) == 1 and len(split_stages(blocks, 9)) == 5              # never more stages than trainable blocks
+    # first_share: a small FIRST stage (its bucket is the one no backward piece overlaps), the rest split evenly
+    small = split_stages(blocks, 3, first_share=0.05)
+    assert small[0] == blocks[:1] and [b for st in small for b in st] == blocks and len(small) == 3
+    g_small = segment_parameters(net, 3, first_share=0.05)
+    assert sum(p.numel() for p in g_small[-1]) < sum(p.numel() for p in groups[-1])
 
 
 def test_segmented_backward_equals_plain_backward():

@@ -22,8 +22,8 @@ bucket k's reduce-scatter / all-gather on the side stream (`GradientSync.launch`
 LAST bucket's exchange (the first stage's parameters) is exposed.  `SegmentedBackward` is that logic without graphs (plain autograd, any device):
 the eager warm-up passes run it, and so do the CPU tests.
 
-    sync = GradientSync(trainable, groups=segment_parameters(module, 3))
-    step = GraphedTrainStep(module, optimizer, sync, segments=3)
+    sync = GradientSync(trainable, groups=segment_parameters(module, 3, first_share=0.1))
+    step = GraphedTrainStep(module, optimizer, sync, segments=3, first_share=0.1)      # the exposed (last) bucket: 10 % of the gradient
 
 Targets are padded to `max_target_len` labels (a longer transcript raises); batches of a new (batch, samples) shape capture a new
 graph.  The returned loss is the graph's own buffer: read it (`.item()`, `.clone()`) before the next call.
@@ -42,10 +42,12 @@ def _trainable_bytes(mod) -> int:
     return sum(p.numel() * p.element_size() for p in mod.parameters() if p.requires_grad)
 
 
-def split_stages(blocks: Sequence, n_stages: int) -> List[List]:
+def split_stages(blocks: Sequence, n_stages: int, first_share: float = None) -> List[List]:
     """Cut `blocks` (the encoder's children, in forward order) into at most `n_stages` contiguous stages of about equal TRAINABLE parameter
     bytes.  Every stage but the last must own a trainable parameter (its bucket would be empty otherwise), so frozen leading blocks join the
-    first stage that trains something; fewer stages come back when the blocks do not allow `n_stages`."""
+    first stage that trains something; fewer stages come back when the blocks do not allow `n_stages`.
+    `first_share` (0 < share < 1): the FIRST stage gets about that share of the bytes and the others split the rest evenly.  The first stage's
+    gradients complete last, so its bucket is the one whose exchange nothing overlaps: a small first stage keeps the exposed exchange small."""
     blocks = list(blocks)
     if n_stages < 1 or not blocks:
         raise ValueError("split_stages: need >= 1 stage and >= 1 block")
@@ -58,7 +60,10 @@ def split_stages(blocks: Sequence, n_stages: int) -> List[List]:
         left = n_stages - len(stages) - 1                      # stages still to be opened after the current one
         # close the stage once it has reached its share of what is left, as long as the remaining blocks can still fill the remaining stages
         rest = sum(1 for z in sizes[i + 1:] if z > 0)          # trainable blocks still ahead: each remaining stage needs one
-        if left > 0 and acc > 0 and rest >= left and (acc >= (total - done) / (left + 1) or rest == left):
+        want = (total - done) / (left + 1)
+        if first_share is not None and not stages and n_stages > 1:
+            want = float(first_share) * total
+        if left > 0 and acc > 0 and rest >= left and (acc >= want or rest == left):
             stages.append(cur)
             done, cur, acc = done + acc, [], 0
     if cur:
@@ -69,11 +74,11 @@ def split_stages(blocks: Sequence, n_stages: int) -> List[List]:
     return stages
 
 
-def segment_parameters(module, n_segments: int) -> List[List[torch.nn.Parameter]]:
+def segment_parameters(module, n_segments: int, first_share: float = None) -> List[List[torch.nn.Parameter]]:
     """The `groups` argument of parallel.GradientSync for `GraphedTrainStep(module, ..., segments=n_segments)`: group k = the trainable
     parameters whose gradients piece k of the segmented backward pass completes -- group 0 the decoder's and the last encoder stage's, the last
     group the first stage's -- each in reverse registration order (the order the gradients land in)."""
-    stages = split_stages(list(module.encoder.children()), n_segments)
+    stages = split_stages(list(module.encoder.children()), n_segments, first_share)
     seen, groups = set(), []
     for k, stage in enumerate(reversed(stages)):
         mods = ([module.decoder] if k == 0 else []) + list(reversed(stage))
@@ -133,12 +138,12 @@ class SegmentedBackward:
 
 
 class GraphedTrainStep:
-    def __init__(self, module, optimizer, sync, max_target_len: int = 512, warmup: int = 2, segments: int = 1):
+    def __init__(self, module, optimizer, sync, max_target_len: int = 512, warmup: int = 2, segments: int = 1, first_share: float = None):
         self.module, self.optimizer, self.sync = module, optimizer, sync
         self.segments = 1
         if int(segments) > 1:
-            stages = split_stages(list(module.encoder.children()), int(segments))
-            groups = segment_parameters(module, int(segments))
+            stages = split_stages(list(module.encoder.children()), int(segments), first_share)
+            groups = segment_parameters(module, int(segments), first_share)
             want = [sorted(id(p) for p in g) for g in groups]
             have = [sorted(id(sync.params[i]) for i in members) for (_, _, members) in sync.buckets]
             if want != have:
