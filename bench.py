@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--seconds", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / C5 measurements (extra.*)")
-    ap.add_argument("--extra", default="c3,c4,c5", help="which of c3,c4,c5 to measure at N = 1")
+    ap.add_argument("--extra", default="c3,c4,c5,c5_finetune", help="which of c3,c4,c5,c5_finetune to measure at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 

@@ -148,6 +148,54 @@ def c5(device, batch=16, seconds=20, steps=10, check=True):
     return res
 
 
+def c5_finetune(device, batch=8, seconds=10, steps=5):
+    """wav2vec2 fine-tuning as the reference runs it (BaseCTCModule.training_step on an HF encoder with the conv feature extractor frozen,
+    tests/huggingface/test_module_huggingface.py:33-54): wav2vec2-large geometry (random weights), f32, CTC loss, AdamW on the transformer --
+    forward, backward and the optimizer step, eager (autograd nodes over the library's f32 matrix-core GEMM, huggingface/train.py)."""
+    import transformers
+    from thunder_speech_amd.blocks import linear_decoder
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    from thunder_speech_amd.huggingface.transform import Wav2Vec2Preprocess
+    from thunder_speech_amd.module import BaseCTCModule
+    from thunder_speech_amd.optim import FusedAdamW
+    from thunder_speech_amd.text_processing.transform import BatchTextTransformer
+    torch.manual_seed(0)
+    cfg = transformers.Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, hidden_dropout=0.1,
+                                      activation_dropout=0.1, attention_dropout=0.1, feat_proj_dropout=0.1, layerdrop=0.0, mask_time_prob=0.05,
+                                      feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False, vocab_size=32)
+    enc = HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(cfg), precision="fp32")
+    tokens = [chr(97 + i) for i in range(26)] + [" "]
+    module = BaseCTCModule(enc, linear_decoder(1024, len(tokens) + 1, 0.0), Wav2Vec2Preprocess(), BatchTextTransformer(tokens=tokens),
+                           optimizer_class=FusedAdamW, optimizer_kwargs={"lr": 1e-5}).to(device).train()
+    opt = module.configure_optimizers()
+    opt = opt["optimizer"] if isinstance(opt, dict) else opt
+    g = torch.Generator().manual_seed(1234)
+    wav = (0.1 * torch.randn(batch, 16000 * seconds, generator=g)).to(device)
+    lengths = torch.full((batch,), 16000.0 * seconds, device=device)
+    texts = ["".join(chr(97 + int(c)) for c in torch.randint(0, 26, (int(n),), generator=g)) for n in torch.randint(40, 100, (batch,), generator=g)]
+
+    def step():
+        opt.zero_grad()
+        loss = module.training_step((wav, lengths, texts), 0)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    first = float(step())
+    step()
+    dt = _timed(step, steps)
+    last = float(step())
+    n_train = sum(p.numel() for p in module.parameters() if p.requires_grad)
+    t = 16000 * seconds // 320
+    c, ffn, L = 1024, 4096, 24
+    fwd = 2.0 * batch * t * L * (4 * c * c + 2 * c * ffn + 2 * t * c)               # transformer only: the feature extractor is frozen (forward once)
+    return {"workload": f"wav2vec2-large geometry fine-tune step (CTC, feature extractor frozen, dropouts + time masking on), batch {batch}x{seconds} s, f32, "
+                        "eager autograd over the own f32 GEMM + FusedAdamW", "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s",
+            "audio_seconds_per_s": batch * seconds / dt, "steps": steps, "trainable_parameters": n_train, "loss_first_last": [first, last],
+            "roofline": {"bound": "mfma", "model": "3 x transformer forward FLOPs / f32 matrix-core peak (157 TFLOP/s)", "achieved": 3.0 * fwd / dt / 1e12, "peak": 157.0,
+                         "unit": "TFLOP/s", "frac": 3.0 * fwd / dt / 1e12 / 157.0}}
+
+
 def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
     """QuartzNet15x5 fine-tuning, one rank's share of config C4 (global 256 x 10 s over 8 GPUs = local 32).  Phase 1 = the
     reference recipe's first epochs (FinetuneEncoderDecoder: encoder frozen), phase 2 = everything trainable."""
@@ -368,7 +416,7 @@ def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8, segme
     return res
 
 
-def run(device, which=("c3", "c4", "c5"), check=True):
+def run(device, which=("c3", "c4", "c5", "c5_finetune"), check=True):
     extra = {}
     for name in which:
         t0 = time.perf_counter()
@@ -379,6 +427,8 @@ def run(device, which=("c3", "c4", "c5"), check=True):
                 extra.update(c4(device))
             elif name == "c5":
                 extra["c5"] = c5(device, check=check)
+            elif name == "c5_finetune":
+                extra["c5_finetune"] = c5_finetune(device)
         except Exception as e:                      # an extra must never take the headline line down with it: recorded, reported on stderr,
             import traceback                        # and bench.py exits non-zero after printing the (complete) line
             print(f"bench_extra: {name} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
@@ -389,5 +439,5 @@ def run(device, which=("c3", "c4", "c5"), check=True):
 
 
 if __name__ == "__main__":
-    names = [a for a in sys.argv[1:] if not a.startswith("-")] or ["c3", "c4", "c5"]
+    names = [a for a in sys.argv[1:] if not a.startswith("-")] or ["c3", "c4", "c5", "c5_finetune"]
     print(json.dumps(run(torch.device("cuda", 0), names, check="--no-check" not in sys.argv)))
