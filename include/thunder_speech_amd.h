@@ -395,6 +395,15 @@ int ts_train_pack_pw_multi(const void* table, int32_t n_tensors, int64_t max_gro
 int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, int32_t c_out);
 int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const int32_t* len_u, float* dw, float* workspace, int32_t batch, int32_t c_in, int32_t c_out,
                                int32_t t, int32_t pitch_u, int32_t pitch_v, void* stream);
+/* One layer of ts_train_pwconv_wgrad_multi: the arguments of ts_train_pwconv_wgrad_mfma with dw = NULL (partials only, into `workspace`). */
+typedef struct ts_wgrad_item {
+  const void* dv; const void* u; const int32_t* len_u; float* workspace;
+  int32_t batch, c_in, c_out, t, pitch_u, pitch_v;
+} ts_wgrad_item;
+/* The split-K partial products of `count` layers in ceil(count / 32) launches (workgroup -> (layer, tile) through prefix sums in the kernel
+ * arguments): what a step replayed from hipGraphs launches once per backward piece, followed by ts_train_wgrad_reduce_multi.  `items` is a HOST
+ * array read at call time. */
+int ts_train_pwconv_wgrad_multi(const ts_wgrad_item* items, int32_t count, void* stream);
 int ts_train_wgrad_reduce_multi(const void* const* parts, void* const* dws, const int64_t* n, const int32_t* n_parts, int32_t count, void* stream);
 /* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
  * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */

@@ -379,3 +379,39 @@ def test_bf16_pointwise_products_match_a_float64_product(batch, c_in, c_out, t):
         T.set_pointwise_backend("mfma")
     assert float((v2.double() - v.double()).abs().max()) <= 8e-3 * float(ref.abs().max()) or not used_tcs
     assert float((dw2.double().cpu() - ref_dw).abs().max()) <= 2e-3 * float(ref_dw.abs().max())
+
+
+def test_grouped_weight_gradient_launch_equals_the_per_layer_launches():
+    """ts_train_pwconv_wgrad_multi (all layers of a backward piece in ceil(n / 32) launches, workgroup -> (layer, tile) through prefix sums) followed
+    by ts_train_wgrad_reduce_multi against one ts_train_pwconv_wgrad_mfma per layer: the same tiles, the same summation order -> identical bits.
+    40 layers (two launches of the grouped kernel) of mixed shapes, one with a length mask on its input."""
+    import ctypes as C
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(4, 64, 128, 300), (3, 256, 256, 501), (5, 128, 64, 77), (2, 512, 256, 192)] * 10
+    items = (_lib.WgradItem * len(shapes))()
+    keep, want, got, parts = [], [], [], []
+    for i, (b, ci, co, t) in enumerate(shapes):
+        p = (t + 191) // 192 * 192 + 64
+        dv = torch.randn(b, co, p, device="cuda", generator=g).bfloat16()
+        u = torch.randn(b, ci, p, device="cuda", generator=g).bfloat16()
+        lens = torch.randint(1, t + 1, (b,), device="cuda", generator=g).int() if i % 4 == 1 else None
+        n_ws = L.ts_train_pwconv_wgrad_workspace(b, ci, co)
+        ws1, ws2 = torch.empty(n_ws, device="cuda"), torch.empty(n_ws, device="cuda")
+        dw1, dw2 = torch.zeros(co, ci, device="cuda"), torch.zeros(co, ci, device="cuda")
+        assert L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), lens.data_ptr() if lens is not None else None, dw1.data_ptr(), ws1.data_ptr(),
+                                            b, ci, co, t, p, p, st) == 0
+        it = items[i]
+        it.dv, it.u, it.len_u, it.workspace = dv.data_ptr(), u.data_ptr(), (lens.data_ptr() if lens is not None else None), ws2.data_ptr()
+        it.batch, it.c_in, it.c_out, it.t, it.pitch_u, it.pitch_v = b, ci, co, t, p, p
+        keep += [dv, u, lens, ws1, ws2]
+        want.append(dw1); got.append(dw2); parts.append(n_ws // (co * ci))
+    assert L.ts_train_pwconv_wgrad_multi(items, len(shapes), st) == 0
+    n = len(shapes)
+    assert L.ts_train_wgrad_reduce_multi((C.c_void_p * n)(*[keep[5 * i + 4].data_ptr() for i in range(n)]), (C.c_void_p * n)(*[d.data_ptr() for d in got]),
+                                         (C.c_int64 * n)(*[d.numel() for d in got]), (C.c_int32 * n)(*parts), n, st) == 0
+    torch.cuda.synchronize()
+    for a, b_ in zip(want, got):
+        assert torch.equal(a, b_) and float(a.abs().max()) > 0

@@ -56,11 +56,11 @@ constexpr int WSTAGEB = 2 * WTILEB;
 // three K-steps of loads are in flight while one is multiplied: a K-step is only 512 MFMA cycles, far less than the load latency.
 // The swizzle is applied on the SOURCE address (the DMA's LDS image is lane-linear).  The pitch padding of the last K-step of a clip
 // (frames >= T: arbitrary bits) is zeroed in LDS by the wave that fetched those rows, between its own vmcnt wait and the barrier.
-__global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int block_id, int n_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  int id = xcd_tile(blockIdx.x, gridDim.x);              // the tiles of one clip group read the same rows of dv and u
+  int id = xcd_tile(block_id, n_blocks);                 // the tiles of one clip group read the same rows of dv and u
   const int nt_i = id % a.n_nt; id /= a.n_nt;
   const int mt_i = id % a.n_mt;
   const int sp = id / a.n_mt;
@@ -146,6 +146,28 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs a) {
         if (m < a.M && n < a.N) out[(size_t)m * a.N + n] = acc[i][j][r];
       }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs a) { wgrad_tile(a, blockIdx.x, gridDim.x); }
+
+// the same product for up to WM_MAX layers in ONE launch: workgroup -> (layer, tile) through the layers' tile-count prefix sums.  A graphed
+// training step hands over every layer of a backward piece at once (the weight gradients are off the critical path: nothing reads them before
+// the optimizer), so 93 launches of 17-20 us, each with its own launch latency, ramp and drain, become three.
+constexpr int WM_MAX = 32;
+struct WgradMulti {
+  const bf16_t* dv[WM_MAX]; const bf16_t* u[WM_MAX]; float* part[WM_MAX]; const int* len_u[WM_MAX];
+  int batch[WM_MAX], M[WM_MAX], N[WM_MAX], t[WM_MAX], pitch_v[WM_MAX], pitch_u[WM_MAX], n_mt[WM_MAX], n_nt[WM_MAX], cpw[WM_MAX];
+  int first[WM_MAX + 1];                                  // first workgroup of layer e; first[count] = grid size
+  int count;
+};
+__global__ __launch_bounds__(256) void wgrad_multi_kernel(const WgradMulti m) {
+  int e = 0;
+  for (int i = 1; i < m.count; ++i) e = (int)blockIdx.x >= m.first[i] ? i : e;
+  WgradArgs a;
+  a.dv = m.dv[e]; a.u = m.u[e]; a.part = m.part[e]; a.len_u = m.len_u[e];
+  a.batch = m.batch[e]; a.M = m.M[e]; a.N = m.N[e]; a.t = m.t[e]; a.pitch_v = m.pitch_v[e]; a.pitch_u = m.pitch_u[e];
+  a.n_mt = m.n_mt[e]; a.n_nt = m.n_nt[e]; a.clips_per_wg = m.cpw[e];
+  wgrad_tile(a, (int)blockIdx.x - m.first[e], m.first[e + 1] - m.first[e]);
 }
 
 // dw[i] += sum_p part[p][i]
@@ -269,6 +291,52 @@ extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const i
   const long long n = (long long)c_out * c_in;
   // dw == NULL: partials only -- the caller sums them later, many layers at once (ts_train_wgrad_reduce_multi)
   if (dw) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, workspace, dw, n, split);
+  return hip_status(hipGetLastError());
+}
+
+static int wgrad_check(const void* dv, const void* u, const float* workspace, int batch, int c_in, int c_out, int t, int pitch_u, int pitch_v) {
+  if (!dv || !u || !workspace || batch <= 0 || c_in <= 0 || c_out <= 0 || t <= 0 || pitch_u < t || pitch_v < t) return TS_EINVAL;
+  const int tk_end = round_up(t, GK);
+  if (c_out % 8 || c_in % 8 || pitch_u % 8 || pitch_v % 8 || pitch_u < tk_end || pitch_v < tk_end || !aligned16(u) || !aligned16(dv) ||
+      !aligned16(workspace) || ((size_t)c_out * c_in) % 4)
+    return TS_EUNSUPPORTED;
+  if ((size_t)batch * c_out * pitch_v * 2 >= (1ull << 31) || (size_t)batch * c_in * pitch_u * 2 >= (1ull << 31)) return TS_EUNSUPPORTED;
+  return TS_OK;
+}
+
+/* the partial products (ts_train_pwconv_wgrad_mfma with dw = NULL) of `count` layers in ceil(count / 32) launches; see include/thunder_speech_amd.h */
+extern "C" int ts_train_pwconv_wgrad_multi(const ts_wgrad_item* items, int32_t count, void* stream_) {
+  if (!items || count <= 0) return TS_EINVAL;
+  for (int e = 0; e < count; ++e) {
+    const ts_wgrad_item& it = items[e];
+    if (int st = wgrad_check(it.dv, it.u, it.workspace, it.batch, it.c_in, it.c_out, it.t, it.pitch_u, it.pitch_v)) return st;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  static int attr = 0;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WD * WSTAGEB) != hipSuccess)
+      return TS_EUNSUPPORTED;
+    attr = 1;
+  }
+  (void)hipGetLastError();
+  for (int base = 0; base < count; base += WM_MAX) {
+    WgradMulti m;
+    m.count = count - base < WM_MAX ? count - base : WM_MAX;
+    int grid = 0;
+    for (int e = 0; e < WM_MAX; ++e) {
+      const ts_wgrad_item& it = items[base + (e < m.count ? e : 0)];
+      m.dv[e] = (const bf16_t*)it.dv; m.u[e] = (const bf16_t*)it.u; m.part[e] = it.workspace; m.len_u[e] = it.len_u;
+      m.batch[e] = it.batch; m.M[e] = it.c_out; m.N[e] = it.c_in; m.t[e] = it.t; m.pitch_v[e] = it.pitch_v; m.pitch_u[e] = it.pitch_u;
+      m.n_mt[e] = (it.c_out + GTILE - 1) / GTILE; m.n_nt[e] = (it.c_in + GTILE - 1) / GTILE;
+      const int split = wgrad_split(it.batch, it.c_in, it.c_out);
+      m.cpw[e] = (it.batch + split - 1) / split;
+      m.first[e] = grid;
+      if (e < m.count) grid += m.n_mt[e] * m.n_nt[e] * split;
+    }
+    m.first[WM_MAX] = grid;
+    for (int e = m.count; e <= WM_MAX; ++e) m.first[e] = grid;
+    hipLaunchKernelGGL(wgrad_multi_kernel, dim3((unsigned)grid), dim3(256), WD * WSTAGEB, stream, m);
+  }
   return hip_status(hipGetLastError());
 }
 

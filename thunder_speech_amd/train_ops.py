@@ -325,9 +325,12 @@ def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int
 
 # Deferred split-K reduction of the pointwise weight gradients.  Eagerly, every layer's partial products are summed onto its gradient right
 # behind the product (GradientSync's hooks may send the bucket the moment autograd hands the gradient over).  A step replayed from hipGraphs
-# runs no hook, so train_graph.GraphedTrainStep opens `deferred_wgrad()` around each piece of its backward pass: the layers only leave their
-# partials (kept alive in the list below) and `flush_wgrad()` sums all of them in ONE launch per 64 layers at the end of the piece.
+# runs no hook, so train_graph.GraphedTrainStep opens `deferred_wgrad()` around each piece of its backward pass: the layers only REGISTER their
+# weight-gradient product (operands kept alive in the list below) and `flush_wgrad()` runs all of them at the end of the piece -- the split-K
+# products of up to 32 layers per launch (ts_train_pwconv_wgrad_multi), then ONE summation launch per 64 layers (ts_train_wgrad_reduce_multi).
+# Nothing reads a weight gradient before the optimizer, and every launch saved is ~5 us of latency, ramp and drain at this size.
 _WGRAD_PENDING = None
+GROUP_WGRAD = True          # False: inside deferred_wgrad() every layer still launches its own product at once and only the summation waits (A/B)
 
 
 class deferred_wgrad:
@@ -358,13 +361,23 @@ def flush_wgrad() -> int:
     if not pend:
         return 0
     n = len(pend)
-    parts = (C.c_void_p * n)(*[ws.data_ptr() for ws, _, _ in pend])
-    dws = (C.c_void_p * n)(*[dw.data_ptr() for _, dw, _ in pend])
-    sizes = (C.c_int64 * n)(*[dw.numel() for _, dw, _ in pend])
-    nparts = (C.c_int32 * n)(*[k for _, _, k in pend])
-    st = _lib.lib().ts_train_wgrad_reduce_multi(parts, dws, sizes, nparts, n, _s(pend[0][1]))
+    stream = _s(pend[0][1])
+    todo = [e for e in pend if e[3] is not None]                 # products not launched yet
+    items = (_lib.WgradItem * max(len(todo), 1))()
+    for it, (ws, dw, k, dv, u, len_u) in zip(items, todo):
+        b, c_out, t = dv.shape
+        it.dv, it.u, it.len_u, it.workspace = dv.data_ptr(), u.data_ptr(), (len_u.data_ptr() if len_u is not None else None), ws.data_ptr()
+        it.batch, it.c_in, it.c_out, it.t, it.pitch_u, it.pitch_v = b, u.shape[1], c_out, t, _pitch(u), _pitch(dv)
+    st, st2 = (_lib.lib().ts_train_pwconv_wgrad_multi(items, len(todo), stream) if todo else 0), 0
+    if st == 0:
+        parts = (C.c_void_p * n)(*[e[0].data_ptr() for e in pend])
+        dws = (C.c_void_p * n)(*[e[1].data_ptr() for e in pend])
+        sizes = (C.c_int64 * n)(*[e[1].numel() for e in pend])
+        nparts = (C.c_int32 * n)(*[e[2] for e in pend])
+        st2 = _lib.lib().ts_train_wgrad_reduce_multi(parts, dws, sizes, nparts, n, stream)
     pend.clear()
-    _lib.check(st, "ts_train_wgrad_reduce_multi")
+    _lib.check(st, "ts_train_pwconv_wgrad_multi")
+    _lib.check(st2, "ts_train_wgrad_reduce_multi")
     return n
 
 
@@ -376,12 +389,17 @@ def _wgrad(dv: Tensor, u: Tensor, dw: Tensor, len_u: Tensor = None, defer: bool 
     c_in = u.shape[1]
     n_ws = L.ts_train_pwconv_wgrad_workspace(b, c_in, c_out)
     ws = torch.empty(n_ws, dtype=torch.float32, device=dv.device)
-    park = defer and _WGRAD_PENDING is not None and (c_out * c_in) % 4 == 0
+    if defer and _WGRAD_PENDING is not None and (c_out * c_in) % 4 == 0:
+        if GROUP_WGRAD:
+            _WGRAD_PENDING.append((ws, dw, n_ws // (c_out * c_in), dv, u, len_u))   # operands stay alive until flush_wgrad()
+            return
+        _lib.check(L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), len_u.data_ptr() if len_u is not None else None, None, ws.data_ptr(),
+                                                b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)), "ts_train_pwconv_wgrad_mfma")
+        _WGRAD_PENDING.append((ws, dw, n_ws // (c_out * c_in), None, None, None))
+        return
     _lib.check(L.ts_train_pwconv_wgrad_mfma(dv.data_ptr(), u.data_ptr(), len_u.data_ptr() if len_u is not None else None,
-                                            None if park else dw.data_ptr(), ws.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)),
+                                            dw.data_ptr(), ws.data_ptr(), b, c_in, c_out, t, _pitch(u), _pitch(dv), _s(dv)),
                "ts_train_pwconv_wgrad_mfma")
-    if park:
-        _WGRAD_PENDING.append((ws, dw, n_ws // (c_out * c_in)))
 
 
 _LENS = {}
