@@ -404,6 +404,9 @@ typedef struct ts_wgrad_item {
  * arguments): what a step replayed from hipGraphs launches once per backward piece, followed by ts_train_wgrad_reduce_multi.  `items` is a HOST
  * array read at call time. */
 int ts_train_pwconv_wgrad_multi(const ts_wgrad_item* items, int32_t count, void* stream);
+/* partial [c_out][c_in] tiles per layer the grouped launch writes (its workspace needs that many x c_out x c_in floats; fewer than the single-layer
+ * launch, which must fill the chip with one layer's tiles): the n_parts to hand to ts_train_wgrad_reduce_multi */
+int32_t ts_train_pwconv_wgrad_multi_parts(int32_t batch, int32_t c_in, int32_t c_out);
 int ts_train_wgrad_reduce_multi(const void* const* parts, void* const* dws, const int64_t* n, const int32_t* n_parts, int32_t count, void* stream);
 /* running_mean / running_var (both or neither, f32 [C]) and num_batches_tracked (int64 scalar, may be NULL): the module's running
  * statistics, updated in the same launch as nn.BatchNorm1d does (momentum blend, unbiased batch variance, counter + 1). */

@@ -383,7 +383,7 @@ def test_bf16_pointwise_products_match_a_float64_product(batch, c_in, c_out, t):
 
 def test_grouped_weight_gradient_launch_equals_the_per_layer_launches():
     """ts_train_pwconv_wgrad_multi (all layers of a backward piece in ceil(n / 32) launches, workgroup -> (layer, tile) through prefix sums) followed
-    by ts_train_wgrad_reduce_multi against one ts_train_pwconv_wgrad_mfma per layer: the same tiles, the same summation order -> identical bits.
+    by ts_train_wgrad_reduce_multi against one ts_train_pwconv_wgrad_mfma per layer: the same products over fewer, longer clip groups (1e-5).
     40 layers (two launches of the grouped kernel) of mixed shapes, one with a length mask on its input."""
     import ctypes as C
     from thunder_speech_amd import _lib
@@ -407,11 +407,11 @@ def test_grouped_weight_gradient_launch_equals_the_per_layer_launches():
         it.dv, it.u, it.len_u, it.workspace = dv.data_ptr(), u.data_ptr(), (lens.data_ptr() if lens is not None else None), ws2.data_ptr()
         it.batch, it.c_in, it.c_out, it.t, it.pitch_u, it.pitch_v = b, ci, co, t, p, p
         keep += [dv, u, lens, ws1, ws2]
-        want.append(dw1); got.append(dw2); parts.append(n_ws // (co * ci))
+        want.append(dw1); got.append(dw2); parts.append(L.ts_train_pwconv_wgrad_multi_parts(b, ci, co))
     assert L.ts_train_pwconv_wgrad_multi(items, len(shapes), st) == 0
     n = len(shapes)
     assert L.ts_train_wgrad_reduce_multi((C.c_void_p * n)(*[keep[5 * i + 4].data_ptr() for i in range(n)]), (C.c_void_p * n)(*[d.data_ptr() for d in got]),
                                          (C.c_int64 * n)(*[d.numel() for d in got]), (C.c_int32 * n)(*parts), n, st) == 0
     torch.cuda.synchronize()
-    for a, b_ in zip(want, got):
-        assert torch.equal(a, b_) and float(a.abs().max()) > 0
+    for a, b_ in zip(want, got):                      # fewer, longer clip groups in the grouped launch: the same products, another summation order
+        assert torch.allclose(a, b_, rtol=1e-5, atol=1e-5 * float(a.abs().max())) and float(a.abs().max()) > 0

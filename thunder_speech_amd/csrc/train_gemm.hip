@@ -262,6 +262,21 @@ static int wgrad_split(int batch, int c_in, int c_out) {
   return (batch + cpw - 1) / cpw;
 }
 
+// the grouped launch fills the chip with the tiles of MANY layers, so a layer needs few clip groups: a quarter of the partial tiles to write and
+// to sum, four times the K-steps per workgroup behind one prologue and one 64-KiB result burst
+static int wgrad_split_group(int batch, int c_in, int c_out) {
+  const int s = wgrad_split(batch, c_in, c_out);
+  return s < 4 ? s : 4;
+}
+
+/* partial [c_out][c_in] tiles per layer that ts_train_pwconv_wgrad_multi leaves in its workspace (= n_parts of ts_train_wgrad_reduce_multi) */
+extern "C" int32_t ts_train_pwconv_wgrad_multi_parts(int32_t batch, int32_t c_in, int32_t c_out) {
+  if (batch <= 0 || c_in <= 0 || c_out <= 0) return TS_EINVAL;
+  const int split = wgrad_split_group(batch, c_in, c_out);
+  const int cpw = (batch + split - 1) / split;
+  return (batch + cpw - 1) / cpw;
+}
+
 /* floats of workspace ts_train_pwconv_wgrad_mfma needs: one [c_out][c_in] partial per clip group */
 extern "C" int64_t ts_train_pwconv_wgrad_workspace(int32_t batch, int32_t c_in, int32_t c_out) {
   if (batch <= 0 || c_in <= 0 || c_out <= 0) return TS_EINVAL;
@@ -332,10 +347,10 @@ extern "C" int ts_train_pwconv_wgrad_multi(const ts_wgrad_item* items, int32_t c
       m.dv[e] = (const bf16_t*)it.dv; m.u[e] = (const bf16_t*)it.u; m.part[e] = it.workspace; m.len_u[e] = it.len_u;
       m.batch[e] = it.batch; m.M[e] = it.c_out; m.N[e] = it.c_in; m.t[e] = it.t; m.pitch_v[e] = it.pitch_v; m.pitch_u[e] = it.pitch_u;
       m.n_mt[e] = (it.c_out + GTILE - 1) / GTILE; m.n_nt[e] = (it.c_in + GTILE - 1) / GTILE;
-      const int split = wgrad_split(it.batch, it.c_in, it.c_out);
+      const int split = wgrad_split_group(it.batch, it.c_in, it.c_out);
       m.cpw[e] = (it.batch + split - 1) / split;
       m.first[e] = grid;
-      if (e < m.count) grid += m.n_mt[e] * m.n_nt[e] * split;
+      if (e < m.count) grid += m.n_mt[e] * m.n_nt[e] * ((it.batch + m.cpw[e] - 1) / m.cpw[e]);
     }
     m.first[WM_MAX] = grid;
     for (int e = m.count; e <= WM_MAX; ++e) m.first[e] = grid;

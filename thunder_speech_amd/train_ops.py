@@ -387,6 +387,11 @@ def _wgrad(dv: Tensor, u: Tensor, dw: Tensor, len_u: Tensor = None, defer: bool 
     L = _lib.lib()
     b, c_out, t = dv.shape
     c_in = u.shape[1]
+    if defer and GROUP_WGRAD and _WGRAD_PENDING is not None and (c_out * c_in) % 4 == 0:
+        n_parts = L.ts_train_pwconv_wgrad_multi_parts(b, c_in, c_out)               # the grouped launch splits a layer over fewer clip groups
+        ws = torch.empty(n_parts * c_out * c_in, dtype=torch.float32, device=dv.device)
+        _WGRAD_PENDING.append((ws, dw, n_parts, dv, u, len_u))                      # operands stay alive until flush_wgrad()
+        return
     n_ws = L.ts_train_pwconv_wgrad_workspace(b, c_in, c_out)
     ws = torch.empty(n_ws, dtype=torch.float32, device=dv.device)
     if defer and _WGRAD_PENDING is not None and (c_out * c_in) % 4 == 0:
