@@ -64,7 +64,9 @@ constexpr int CTC_PF = 8;       // emission prefetch distance in time steps
 // lg[ext[s]][t] -- its address depends on (s, t) only -- arrives in chunks of CTC_PF steps requested a whole chunk ahead, the rows leave
 // in chunks too: no vector-memory operation and no vmcnt wait inside a chunk.  (__syncthreads() would drain vmcnt at every step;
 // a load under a condition becomes a phi the compiler waits on at once: both measured, 0.78 us per step before, 0.5 with them.)
-template <int SPT>
+// LSE_LDS: the per-frame log-sum-exp row is kept in LDS (n_frames floats: up to ~38 000 frames); false: clips longer than that read it back from the
+// global copy -- prefetched with the emissions, a chunk ahead, so the step loop still contains no vector-memory wait
+template <int SPT, bool LSE_LDS = true>
 __global__ __launch_bounds__(1024) void ctc_kernel(const CtcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L_MAX = a.lmax;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(1024) void ctc_kernel(const CtcArgs a) {
     }
     const float l = m + logf(sum);
     lse[t] = l;
-    lse_s[t] = l;
+    if constexpr (LSE_LDS) lse_s[t] = l;
   }
   __syncthreads();
   float* prev = row0 + 2;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(1024) void ctc_kernel(const CtcArgs a) {
   const int NT = blockDim.x;                       // round_up(lmax / SPT, 64) threads: state s = lane + i * NT
   bool act[NS], skip[NS], init[NS];
   const float* lrow[NS];
-  float own[NS], pf[2][CTC_PF][NS], out[CTC_PF][NS];
+  float own[NS], pf[2][CTC_PF][NS], out[CTC_PF][NS], lq[2][LSE_LDS ? 1 : CTC_PF];
   // step k of this direction looks at frame fr(k); emissions are requested a whole chunk of CTC_PF steps ahead, for lanes without a
   // state from the blank's row and with clamped frame indices (all loads unconditional, no vector-memory operation inside a chunk:
   // a load under a condition turns the ring slot into a phi and the compiler then waits for the load it has just issued)
@@ -134,13 +136,17 @@ __global__ __launch_bounds__(1024) void ctc_kernel(const CtcArgs a) {
     lrow[i] = lg + (size_t)e * a.pitch;
     own[i] = NEG_INF;
   }
-  auto fetch = [&](float (&buf)[CTC_PF][NS], int k0) {
+  auto fetch = [&](float (&buf)[CTC_PF][NS], float (&lb)[LSE_LDS ? 1 : CTC_PF], int k0) {
 #pragma unroll
     for (int j = 0; j < CTC_PF; ++j)
 #pragma unroll
       for (int i = 0; i < NS; ++i) buf[j][i] = lrow[i][fr(k0 + j)];
+    if constexpr (!LSE_LDS) {
+#pragma unroll
+      for (int j = 0; j < CTC_PF; ++j) lb[j] = lse[fr(k0 + j)];
+    }
   };
-  auto chunk = [&](float (&buf)[CTC_PF][NS], int k0) {
+  auto chunk = [&](float (&buf)[CTC_PF][NS], float (&lb)[LSE_LDS ? 1 : CTC_PF], int k0) {
 #pragma unroll
     for (int j = 0; j < CTC_PF; ++j) {
       const int k = k0 + j;
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(1024) void ctc_kernel(const CtcArgs a) {
           n1[i] = prev[s + d];
           n2[i] = prev[s + 2 * d];
         }
-        const float ls = lse_s[fr(k)];
+        float ls;
+        if constexpr (LSE_LDS) ls = lse_s[fr(k)]; else ls = lb[j];
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
           const float lpv = buf[j][i] - ls;
@@ -174,14 +181,14 @@ __global__ __launch_bounds__(1024) void ctc_kernel(const CtcArgs a) {
 #pragma unroll
       for (int i = 0; i < NS; ++i)
         rows[(size_t)(k0 + j < T ? fr(k0 + j) : a.n_frames) * a.rowp + lane + i * NT] = out[j][i];     // unpredicated: see rowp
-    fetch(buf, k0 + 2 * CTC_PF);
+    fetch(buf, lb, k0 + 2 * CTC_PF);
   };
   if (T > 0) {
-    fetch(pf[0], 0);
-    fetch(pf[1], CTC_PF);
+    fetch(pf[0], lq[0], 0);
+    fetch(pf[1], lq[1], CTC_PF);
     for (int k0 = 0; k0 < T; k0 += 2 * CTC_PF) {
-      chunk(pf[0], k0);
-      chunk(pf[1], k0 + CTC_PF);                   // (its steps are guarded by k < T; its loads and stores always run: exact vmcnt counts)
+      chunk(pf[0], lq[0], k0);
+      chunk(pf[1], lq[1], k0 + CTC_PF);                   // (its steps are guarded by k < T; its loads and stores always run: exact vmcnt counts)
     }
   }
   if (backward) return;
@@ -328,15 +335,23 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
   a.lse2 = a.alpha + (size_t)batch * (n_frames + 1) * a.rowp;
   a.beta = a.lse2 + (size_t)batch * n_frames;
   a.feasible = reinterpret_cast<int*>(a.beta + (size_t)batch * (n_frames + 1) * a.rowp);
-  const size_t lds = ((size_t)2 * (a.lmax + 4) + a.lmax + (size_t)n_frames) * sizeof(float);
+  size_t lds = ((size_t)2 * (a.lmax + 4) + a.lmax + (size_t)n_frames) * sizeof(float);
   const size_t lds_g = ((size_t)a.lmax + 4 * (size_t)n_classes) * sizeof(float);
-  // the per-frame log-sum-exp row lives in LDS next to the two state rows: 160 KiB hold about 38 000 frames (a 12-minute clip after the stem)
-  if (lds > 160 * 1024 || lds_g > 64 * 1024 || a.lmax > 4096) return TS_EUNSUPPORTED;            // ... or more than 2 047 labels in a transcript
+  // the per-frame log-sum-exp row lives in LDS next to the two state rows: 160 KiB hold about 38 000 frames (a 12-minute clip after the stem);
+  // longer clips take the instantiation that reads the row back from its global copy
+  const bool lse_lds = lds <= 160 * 1024;
+  if (!lse_lds) lds = ((size_t)2 * (a.lmax + 4) + a.lmax) * sizeof(float);
+  if (lds > 160 * 1024 || lds_g > 64 * 1024 || a.lmax > 4096) return TS_EUNSUPPORTED;            // more than 2 047 labels in a transcript
   (void)hipGetLastError();
   const dim3 grid(batch, grad ? 2 : 1);                                                          // alpha || beta
   const dim3 block((unsigned)ctc_threads(a.lmax));
   static bool big[3] = {false, false, false};                                                    // more than the default 64 KiB allowed, per instantiation
   const int which = spt == 1 ? 0 : (spt == 2 ? 1 : 2);
+  if (!lse_lds) {
+    if (which == 0) hipLaunchKernelGGL((ctc_kernel<1, false>), grid, block, lds, stream, a);
+    else if (which == 1) hipLaunchKernelGGL((ctc_kernel<2, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((ctc_kernel<4, false>), grid, block, lds, stream, a);
+  } else {
   if (lds > 64 * 1024 && !big[which]) {
     const void* fn = which == 0 ? reinterpret_cast<const void*>(ctc_kernel<1>)
                                 : (which == 1 ? reinterpret_cast<const void*>(ctc_kernel<2>) : reinterpret_cast<const void*>(ctc_kernel<4>));
@@ -346,6 +361,7 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
   if (which == 0) hipLaunchKernelGGL(ctc_kernel<1>, grid, block, lds, stream, a);
   else if (which == 1) hipLaunchKernelGGL(ctc_kernel<2>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(ctc_kernel<4>, grid, block, lds, stream, a);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (grad) hipLaunchKernelGGL(ctc_grad_kernel, dim3((n_frames + 3) / 4, batch), dim3(256), lds_g, stream, a);
