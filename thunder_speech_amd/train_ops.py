@@ -316,7 +316,7 @@ def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int
     d.kernel, d.stride, d.dilation, d.padding, d.depthwise, d.relu, d.out_fp32 = 1, 1, 1, 0, 0, 0, int(y.dtype == torch.float32)
     # no TS_TCS_IN_TAILZERO: with `lens` = the full length the generic kernel (4 producer + 4 consumer waves, 64 / 128-frame tiles) runs, which
     # at these sizes (32 x 501 frames) is 2 us per launch faster than the split kernel the flag would select (15.5 vs 17.5 us at 512^2,
-    # 8.8 vs 10.8 at 256^2; tools/diag/gemm_bench.py) -- the split kernel's 96-frame tiles and 12 waves pay off at inference batch sizes
+    # 8.8 vs 10.8 at 256^2; round-2 measurement, tools/diag/pw_tile_bench.py times the kernel now) -- the split kernel's 96-frame tiles and 12 waves pay off at inference batch sizes
     d.flags = 0
     d.pw_w, d.bias = frags.data_ptr(), _zero_bias(n_out, x.device).data_ptr()
     st = _lib.lib().ts_tcs_subblock_fwd(C.byref(d), x.data_ptr(), lens.data_ptr(), None, None, y.data_ptr(), _s(x))
