@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 7
+#define TS_ABI_VERSION 8
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -34,6 +34,8 @@ const char* ts_build_target(void);
 
 /* Time pitch (elements) used for an activation with T frames. */
 int ts_time_pitch(int T);
+/* frames per tile of the masked pointwise-only launch for this shape (see ts_tcs_desc.stats) */
+int ts_tcs_pointwise_tile_frames(int32_t batch, int32_t c_out, int32_t t_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused time-channel-separable sub-block (inference):
@@ -77,6 +79,10 @@ typedef struct ts_tcs_desc {
                                    relu ignored, both TS_TCS_*TAIL* flags).  Replaces the separate ts_se_apply_fwd pass; any other configuration returns
                                    TS_EUNSUPPORTED and the caller runs the launch without se_y followed by ts_se_apply_fwd. */
   const float* se_gate;         /* f32 [B][c_out] from ts_se_gate_fwd */
+  float* stats;                 /* ABI v8, may be NULL.  BatchNorm(train) statistics of the result, per TILE: f32 [c_out][batch * n_tiles][2] = (sum y, sum y^2)
+                                   over the tile's frames < t_out, n_tiles = ceil(t_out / ts_tcs_pointwise_tile_frames(batch, c_out, t_out)); written by the
+                                   masked pointwise-only launch (depthwise = 0, kernel 1, stride 1, bf16 result, no TS_TCS_IN_TAILZERO: what the training path's
+                                   1x1 forward is) out of its accumulators; ts_train_dwconv_fwd_bn_tiles sums the tiles.  Anything else: TS_EUNSUPPORTED. */
 } ts_tcs_desc;
 
 /* ts_tcs_desc.flags
@@ -349,6 +355,12 @@ int ts_train_dwconv_fwd_bn(const void* v, const void* in_sums, const float* in_g
                            float* in_mean_rstd, float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
                            const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch, int32_t channels,
                            int32_t t, int32_t kernel, int32_t padding, int32_t pitch, int32_t act, void* stream);
+/* ts_train_dwconv_fwd_bn with the statistics as the per-tile pairs a pointwise launch left (ts_tcs_desc.stats): in_tile_sums f32 [C][in_tiles][2].
+ * bf16 rows and >= 17 clips (the matrix-core depthwise forward, whose waves own a channel and sum its pairs cooperatively); else TS_EUNSUPPORTED. */
+int ts_train_dwconv_fwd_bn_tiles(const void* v, const float* in_tile_sums, int32_t in_tiles, const float* in_gamma, const float* in_beta, float in_eps,
+                                 int32_t in_relu, float* in_mean_rstd, float* running_mean, float* running_var, float momentum,
+                                 int64_t* num_batches_tracked, const int32_t* len_in, const int32_t* len_out, const float* w, void* y, int32_t batch,
+                                 int32_t channels, int32_t t, int32_t kernel, int32_t padding, int32_t pitch, int32_t act, void* stream);
 int ts_train_dwconv_bwd_bn(const void* dy, const void* v, const float* in_mean_rstd, const float* in_gamma, const float* in_beta,
                            int32_t in_relu, const int32_t* len_in, const int32_t* len_out, const float* w, void* g, float* dw,
                            float* in_dgamma, float* in_dbeta, int32_t batch, int32_t channels, int32_t t, int32_t kernel, int32_t padding,

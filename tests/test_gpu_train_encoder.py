@@ -415,3 +415,42 @@ def test_grouped_weight_gradient_launch_equals_the_per_layer_launches():
     torch.cuda.synchronize()
     for a, b_ in zip(want, got):                      # fewer, longer clip groups in the grouped launch: the same products, another summation order
         assert torch.allclose(a, b_, rtol=1e-5, atol=1e-5 * float(a.abs().max())) and float(a.abs().max()) > 0
+
+
+def test_tile_statistics_out_of_the_pointwise_epilogue_equal_the_separate_pass():
+    """ABI v8: between two repeats the BatchNorm statistics travel as per-tile (sum, sum of squares) pairs written by the 1x1 launch's epilogue
+    (ts_tcs_desc.stats) and summed by the next matrix-core depthwise launch (ts_train_dwconv_fwd_bn_tiles), instead of ts_train_bn_stats reading the
+    tensor back (quartznet/blocks.py:317-338 in train mode: BatchNorm over all B x T frames, quirk A4).  The pairs are formed from the f32 accumulators,
+    the pass from the bf16-stored values: outputs, every gradient and the running statistics of a 3-repeat block agree to bf16 accuracy, at 24 clips
+    (the matrix-core depthwise kernels need >= 17) with ragged lengths and a frame count that is no multiple of the tile."""
+    from thunder_speech_amd import train_ops
+    from thunder_speech_amd.quartznet.blocks import QuartznetBlock
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(24, 128, 333, generator=g).cuda()
+    lengths = torch.randint(100, 334, (24,), generator=g).cuda()
+    lengths[0] = 333
+    cot = torch.randn(24, 256, 333, generator=g).cuda()
+    res = {}
+    train_ops.set_activation_dtype("bf16")
+    try:
+        for mode in (True, False):
+            train_ops.TILE_STATS = mode
+            torch.manual_seed(3)
+            blk = QuartznetBlock(128, 256, repeat=3, kernel_size=(33,), separable=True).cuda().train()
+            for p in blk.parameters():
+                if p.dim() == 1:
+                    p.data.add_(0.1 * torch.randn_like(p))
+            y, _ = blk(x, lengths)
+            yf = train_ops.from_act(y) if train_ops.is_act(y) else y
+            (yf * cot).sum().backward()
+            res[mode] = (yf.detach().float().clone(), {n: p.grad.clone() for n, p in blk.named_parameters()},
+                         {n: b.clone() for n, b in blk.named_buffers() if "running" in n})
+    finally:
+        train_ops.TILE_STATS = True
+        train_ops.set_activation_dtype("fp32")
+    (y1, g1, r1), (y0, g0, r0) = res[True], res[False]
+    assert float((y1 - y0).abs().max()) <= 3e-2 * float(y0.abs().max())
+    for n in g0:            # three BatchNorm + ReLU layers deep, bf16 rounding boundaries and ReLU gates move with the last bits of the statistics
+        assert float((g1[n] - g0[n]).norm()) <= 8e-2 * max(float(g0[n].norm()), 1e-6), n
+    for n in r0:
+        assert torch.allclose(r1[n], r0[n], rtol=2e-3, atol=2e-4), n

@@ -555,6 +555,33 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       const bool partial = t0 + TT > len_out;
       // the accumulators were last written by MFMAs: let them settle before inline-asm readers (no auto wait states)
       asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+      if constexpr (!DW) {
+        if (a.stats) {
+          // BatchNorm(train) statistics of THIS tile, per output channel, out of the accumulators (frames < t_out; f32): the training path's
+          // next depthwise launch sums the tiles' pairs itself, so no pass over the stored tensor and no launch of its own is needed for them
+          const int nvf = a.t_out - t0;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float v = 32 * mt + 8 * (r >> 2) + 4 * h + (r & 3) < nvf ? acc[mt][nt][r] : 0.f;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+              }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            const int co = (cot0 + nt) * 32 + (lane & 31);
+            if (h == 0 && co < a.c_out) {
+              // channel-major: the consumer's wave owns a channel and reads its tiles as one contiguous run
+              float* const o = a.stats + ((size_t)co * (a.batch * a.n_tt) + (b * a.n_tt + tt)) * 2;
+              o[0] = s1; o[1] = s2;
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int cob = (cot0 + nt) * 32;
@@ -626,6 +653,16 @@ static int launch(TcsArgs& a, hipStream_t stream) {
 
 extern "C" int ts_time_pitch(int T) { return ts::round_up((T < 1 ? 1 : T) + 384, 128); }
 
+/* frames per tile of the masked pointwise-only launch (depthwise = 0, kernel 1, stride 1, no TS_TCS_IN_TAILZERO) for this shape: the tile grid of
+   ts_tcs_desc.stats is batch x ceil(t_out / this) */
+extern "C" int ts_tcs_pointwise_tile_frames(int32_t batch, int32_t c_out, int32_t t_out) {
+  using namespace ts;
+  if (batch <= 0 || c_out <= 0 || t_out <= 0) return TS_EINVAL;
+  if (round_up(c_out, 32) > 256) return 64;
+  const int n_tt = (t_out + 127) / 128;
+  return (long long)batch * n_tt * ((round_up(c_out, 32) + 255) / 256) < cu_count() ? 64 : 128;
+}
+
 // one layer through the split kernel (csrc/tcs_split.hip): a chain of one, no counters
 static int split_single(const ts::TcsArgs& w, int npass, int xe, int wm, int dil, hipStream_t stream) {
   using namespace ts;
@@ -678,6 +715,9 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   a.bias = d->bias;
   a.se_y = static_cast<const unsigned short*>(d->se_y);
   a.se_gate = d->se_gate;
+  a.stats = d->stats;
+  // per-tile BatchNorm statistics come out of the generic pointwise-only kernel's epilogue only (what the training path launches)
+  if (a.stats && (d->depthwise || d->out_fp32 || d->stride != 1 || d->c_res > 0 || (d->flags & TS_TCS_IN_TAILZERO))) return TS_EUNSUPPORTED;
   // the squeeze-excite tail lives in the split kernel's pointwise-only launch (tail-zero rows, stride 1, bf16 result, se_y at y's pitch);
   // every other configuration answers TS_EUNSUPPORTED and the caller runs ts_se_apply_fwd as a separate pass
   if (a.se_y && (!a.se_gate || d->depthwise || d->stride != 1 || d->out_fp32 || d->c_res > 0 || !(d->flags & TS_TCS_IN_TAILZERO) ||

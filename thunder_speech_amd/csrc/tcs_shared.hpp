@@ -42,6 +42,7 @@ struct TcsArgs {
   int xcd;                     // split kernel: 1 = XCD-contiguous tile order (grid is a multiple of 8)
   const unsigned short* se_y;  // squeeze-excite tail in the epilogue (pointwise-only split launches): see ChainLayer
   const float* se_gate;
+  float* stats;                // generic pointwise-only launches: per-tile (sum y, sum y^2) per output channel, f32 [c_out][batch * n_tt][2], or null
 };
 
 __device__ __forceinline__ int conv_len(int len, int k, int s, int p, int d) {

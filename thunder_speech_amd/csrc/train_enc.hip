@@ -343,7 +343,17 @@ struct PairAffine { const float* mean_rstd; const float* gamma; const float* bet
 struct PairBnIn {
   const double* part; const float* gamma; const float* beta; float eps; int relu; double n;
   float* mean_rstd; float* running_mean; float* running_var; float momentum; long long* nbt;
+  const float* tiles = nullptr; int n_tiles = 0;          // instead of `part`: per-tile (sum, sum of squares) pairs, f32 [ch][n_tiles][2] (ts_tcs_desc.stats)
 };
+// the channel's totals out of the per-tile pairs: the 64 lanes of a wave share the tiles, then combine (every lane of the wave must call this)
+__device__ __forceinline__ void bn_total_tiles(const float* __restrict__ tiles, int n_tiles, int ch, int c, int lane, double& s1, double& s2) {
+  double a1 = 0.0, a2 = 0.0;
+  const float* const row = tiles + (size_t)c * n_tiles * 2;
+  for (int p = lane; p < n_tiles; p += 64) { a1 += (double)row[2 * p]; a2 += (double)row[2 * p + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+  s1 = a1; s2 = a2;
+}
 
 __device__ __forceinline__ RowAffine row_affine(const PairAffine& p, int c) {
   RowAffine r{1.f, 0.f, 1.f, 0.f, false, false};
@@ -611,9 +621,9 @@ __global__ __launch_bounds__(256) void dw_fwd_mfma_kernel(const bf16_t* __restri
   // BatchNorm of the previous repeat on the fly (one channel: the pair helper on (c, c) would read c + 1 -> do it by hand)
   float sc = 1.f, hs = 0.f;
   bool aff_on = false, aff_relu = false;
-  if (aff.part) {
+  if (aff.part || aff.tiles) {
     double s1, s2;
-    bn_total(aff.part, ch, c, s1, s2);
+    if (aff.tiles) bn_total_tiles(aff.tiles, aff.n_tiles, ch, c, lane, s1, s2); else bn_total(aff.part, ch, c, s1, s2);
     const double mu = s1 / aff.n;
     double var = s2 / aff.n - mu * mu;
     var = var < 0.0 ? 0.0 : var;
@@ -1425,6 +1435,7 @@ static int dwconv_fwd_impl(const void* x, const int32_t* len_in, const int32_t* 
       TS_DWM(1) TS_DWM(2) TS_DWM(3) TS_DWM(4) TS_DWM(5)
 #undef TS_DWM
     }
+    if (aff.tiles) return TS_EUNSUPPORTED;                 // per-tile statistics: the matrix-core kernel only
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + PAIR_TAPS) * sizeof(v2f);
     // pairs per wave: 2 (the second pair's loads overlap the first one's FIR) once that still leaves >= 16 waves per CU
     const long long n_pairs = (long long)batch * ch / 2;
@@ -1469,6 +1480,19 @@ extern "C" int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const i
 
 // the same with x = relu?(BatchNorm(v)) formed on the fly from the previous repeat's un-normalised output v and the clip-group sums
 // ts_train_bn_stats left in `in_sums`; publishes in_mean_rstd (f32 [C][2], for the backward pass) and updates the running statistics
+extern "C" int ts_train_dwconv_fwd_bn_tiles(const void* v, const float* in_tile_sums, int32_t in_tiles, const float* in_gamma, const float* in_beta, float in_eps,
+                                            int32_t in_relu, float* in_mean_rstd, float* running_mean, float* running_var, float momentum,
+                                            int64_t* num_batches_tracked, const int32_t* len_in, const int32_t* len_out, const float* w, void* y,
+                                            int32_t batch, int32_t ch, int32_t t, int32_t k, int32_t pad, int32_t pitch, int32_t act, void* stream_) {
+  if (!in_tile_sums || in_tiles <= 0 || !in_gamma || !in_beta || !in_mean_rstd || (running_mean == nullptr) != (running_var == nullptr)) return TS_EINVAL;
+  // only the matrix-core kernel sums tile pairs (a wave per channel); dwconv_fwd_impl takes it for bf16 rows, >= 17 clips, "same" geometry
+  if (act != 1 || batch < 17 || !pair_geometry(ch, t, t, k, 1, 1, pad, pitch, pitch)) return TS_EUNSUPPORTED;
+  PairBnIn in{nullptr, in_gamma, in_beta, in_eps, in_relu, (double)batch * t, in_mean_rstd, running_mean, running_var, momentum,
+              reinterpret_cast<long long*>(num_batches_tracked)};
+  in.tiles = in_tile_sums; in.n_tiles = in_tiles;
+  return dwconv_fwd_impl(v, len_in, len_out, w, y, batch, ch, t, t, k, 1, 1, pad, pitch, pitch, act, stream_, in);
+}
+
 extern "C" int ts_train_dwconv_fwd_bn(const void* v, const void* in_sums, const float* in_gamma, const float* in_beta, float in_eps,
                                       int32_t in_relu, float* in_mean_rstd, float* running_mean, float* running_var, float momentum,
                                       int64_t* num_batches_tracked, const int32_t* len_in, const int32_t* len_out, const float* w, void* y,

@@ -255,7 +255,7 @@ class _FusedBlockBase(nn.Module):
             drop_p = drop.p if (drop is not None and drop.training) else 0.0
             # between two repeats the BatchNorm (+ ReLU) is folded into the next repeat's depthwise launches (train_ops.SubBlock)
             lazy = (fuse_tail and drop_p == 0.0) if last else (T._LAZY_BN and drop_p == 0.0 and T.same_depthwise(subs[r + 1][0]))
-            h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop_p, lazy_out=lazy)
+            h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop_p, lazy_out=lazy, tile_stats=not last)
         if self._has_se():
             se = self.mconv[len(self.mconv) - 1].layer[0]          # citrinet/blocks.py:154: SE closes the main branch
             h = T.SqueezeExciteTrain.apply(h, se.fc[0].weight, se.fc[2].weight)

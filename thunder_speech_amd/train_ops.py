@@ -304,7 +304,7 @@ def _tcs_ok(bf: bool, k: int) -> bool:
     return _OWN_GEMM and bf and k % 64 == 0
 
 
-def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int) -> None:
+def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int, stats: Tensor = None) -> None:
     """y[b] = Wn . x[b] on the inference kernel's pointwise-only mode: x bf16 rows [B, K, T], frags = B-fragments of Wn [n_out, K],
     y bf16 rows [B, n_out, T] -- or f32 rows (the decoder's logits: the kernel's fp32-output mode, what inference uses for them; through the f32
     GEMM a 29-row product costs 113 us of mostly padding, here 20).  Frames beyond T inside the row pitch are read and written as scratch
@@ -319,6 +319,8 @@ def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int
     # 8.8 vs 10.8 at 256^2; round-2 measurement, tools/diag/pw_tile_bench.py times the kernel now) -- the split kernel's 96-frame tiles and 12 waves pay off at inference batch sizes
     d.flags = 0
     d.pw_w, d.bias = frags.data_ptr(), _zero_bias(n_out, x.device).data_ptr()
+    if stats is not None:                # per-tile BatchNorm statistics of y out of the launch's epilogue (ts_tcs_desc.stats)
+        d.stats = stats.data_ptr()
     st = _lib.lib().ts_tcs_subblock_fwd(C.byref(d), x.data_ptr(), lens.data_ptr(), None, None, y.data_ptr(), _s(x))
     _lib.check(st, "ts_tcs_subblock_fwd")
 
@@ -429,7 +431,15 @@ def _pw_masks_inside(u_dtype, c_in: int, c_out: int) -> bool:
     return _tcs_ok(bf, c_in) and _tcs_ok(bf, c_out) and c_in % 8 == 0
 
 
-def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False, lens: Tensor = None) -> Tensor:
+def tile_stats_buffer(b: int, c_out: int, t: int, device) -> Tensor:
+    """f32 [c_out, batch * n_tiles, 2] for ts_tcs_desc.stats of the pointwise launch over b x t frames (every entry is written by the launch)."""
+    tt = _lib.lib().ts_tcs_pointwise_tile_frames(b, c_out, t)
+    if tt <= 0:
+        raise RuntimeError("ts_tcs_pointwise_tile_frames failed")
+    return torch.empty(c_out, b * ((t + tt - 1) // tt), 2, dtype=torch.float32, device=device)
+
+
+def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False, lens: Tensor = None, stats: Tensor = None) -> Tensor:
     """v[b] = W . u[b] for activation rows u [B, c_in, T]; w2 = f32 [c_out, c_in] view of `param`.  `lens` (only with
     _pw_masks_inside): u is NOT masked yet, frames >= lens[b] count as zero; otherwise u is masked already."""
     b, c_in, t = u.shape
@@ -437,8 +447,10 @@ def _pw_fwd(u: Tensor, param: Tensor, w2: Tensor, f32_out: bool = False, lens: T
     bf = u.dtype == torch.bfloat16
     v = alloc(b, c_out, t, u.device, torch.float32 if (f32_out or not bf) else torch.bfloat16)
     if _tcs_ok(bf, c_in):
-        _tcs_pointwise(u, pw_frags(param, w2)[0], v, lens if lens is not None else _full_lengths(b, t, u.device), c_out)
+        _tcs_pointwise(u, pw_frags(param, w2)[0], v, lens if lens is not None else _full_lengths(b, t, u.device), c_out, stats)
     else:
+        if stats is not None:
+            raise RuntimeError("_pw_fwd: per-tile statistics come out of the matrix-core pointwise kernel only")
         if lens is not None:
             raise RuntimeError("_pw_fwd: an unmasked input needs the kernels that mask inside")
         wk = _w_bf16(w2, param) if bf else w2
@@ -751,7 +763,7 @@ class SqueezeExciteTrain(torch.autograd.Function):
 class SubBlockCfg:
     """Non-tensor arguments of SubBlock (one per call)."""
     __slots__ = ("len_in", "len_out", "k", "stride", "dil", "pad", "eps", "relu", "running", "drop_p", "drop_seed",
-                 "lazy_in", "lazy_out", "out_sums", "bwd_mask")
+                 "lazy_in", "lazy_out", "out_sums", "bwd_mask", "tile_stats")
 
 
 # BatchNorm between two repeats folded into the neighbouring depthwise launches (no normalised tensor in memory): on by default
@@ -796,7 +808,21 @@ class SubBlock(torch.autograd.Function):
                 in_mr = torch.empty(c_in, 2, dtype=torch.float32, device=x.device)
                 sums, relu_in, eps_in, run_in = lazy
                 rm_i, rv_i, mom_i, nbt_i = run_in if run_in is not None else (None, None, 0.0, None)
-                _lib.check(L.ts_train_dwconv_fwd_bn(x.data_ptr(), sums.data_ptr(), g_in.data_ptr(), b_in.data_ptr(), float(eps_in), int(relu_in),
+                if sums.dtype == torch.float32:      # per-tile pairs out of the producing 1x1 launch's epilogue (tile_stats_buffer)
+                    st_t = L.ts_train_dwconv_fwd_bn_tiles(x.data_ptr(), sums.data_ptr(), sums.shape[1], g_in.data_ptr(), b_in.data_ptr(), float(eps_in), int(relu_in),
+                                                          in_mr.data_ptr(), rm_i.data_ptr() if rm_i is not None else None,
+                                                          rv_i.data_ptr() if rv_i is not None else None, float(mom_i),
+                                                          nbt_i.data_ptr() if nbt_i is not None else None,
+                                                          cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), mid.data_ptr(), b, c_in, t_in,
+                                                          cfg.k, cfg.pad, _pitch(x), code, st_)
+                    if st_t == _lib.TS_EUNSUPPORTED:  # a consumer without the tile reduction: fold the pairs into the clip-group layout (group 0 = all)
+                        folded = torch.zeros(8, c_in, 2, dtype=torch.float64, device=x.device)
+                        folded[0] = sums.to(torch.float64).sum(1)
+                        sums = folded
+                    else:
+                        _lib.check(st_t, "ts_train_dwconv_fwd_bn_tiles")
+                if sums.dtype != torch.float32:
+                  _lib.check(L.ts_train_dwconv_fwd_bn(x.data_ptr(), sums.data_ptr(), g_in.data_ptr(), b_in.data_ptr(), float(eps_in), int(relu_in),
                                                     in_mr.data_ptr(), rm_i.data_ptr() if rm_i is not None else None,
                                                     rv_i.data_ptr() if rv_i is not None else None, float(mom_i),
                                                     nbt_i.data_ptr() if nbt_i is not None else None,
@@ -819,12 +845,20 @@ class SubBlock(torch.autograd.Function):
         w_pw = pw_w.detach().to(torch.float32).contiguous().view(pw_w.shape[0], -1)
         c_out = w_pw.shape[0]
         inside = dw_w is None and mid is x
-        v = _pw_fwd(mid, pw_w, w_pw, lens=cfg.len_in if inside else None)
+        # statistics for a BatchNorm the NEXT repeat's matrix-core depthwise launch will fold in: per-tile pairs out of this launch's epilogue
+        # instead of a pass of their own over v (93 launches of 5.5 us per QuartzNet15x5 step at 32 x 501 frames)
+        tiles = None
+        if cfg.lazy_out and getattr(cfg, "tile_stats", False) and TILE_STATS and mid.dtype == torch.bfloat16 and b >= 17 and _tcs_ok(True, c_in):
+            tiles = tile_stats_buffer(b, c_out, t_out, x.device)
+        v = _pw_fwd(mid, pw_w, w_pw, lens=cfg.len_in if inside else None, stats=tiles)
         ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
         g, be = gamma.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
         mr = torch.empty(c_out, 2, dtype=torch.float32, device=x.device)
         rm, rv, mom, nbt = cfg.running if cfg.running is not None else (None, None, 0.0, None)
-        if cfg.lazy_out:
+        if cfg.lazy_out and tiles is not None:
+            cfg.out_sums = tiles
+            y, out = None, v
+        elif cfg.lazy_out:
             _lib.check(L.ts_train_bn_stats(v.data_ptr(), ws.data_ptr(), b, c_out, t_out, _pitch(v), code, st_), "ts_train_bn_stats")
             cfg.out_sums = ws
             y, out = None, v
@@ -905,12 +939,16 @@ class SubBlock(torch.autograd.Function):
         return dx, ddw, None if dpw is None else dpw.view(ctx.shapes[1]), dg, db, dg_in, db_in, None
 
 
+TILE_STATS = True           # False: every pending BatchNorm gets its statistics from ts_train_bn_stats (a pass over the tensor), as before ABI v8 (A/B)
+
+
 def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Tensor, len_out: Tensor, relu: bool, drop_p: float = 0.0,
-              lazy_out: bool = False, bwd_mask: bool = True) -> Tensor:
+              lazy_out: bool = False, bwd_mask: bool = True, tile_stats: bool = False) -> Tensor:
     """x -> [dropout](relu?(BN_train(pw(mask(dw(mask(x))))))): one repeat of a block.  dw_conv / pw_conv are the MaskedConv1d modules
     (dw_conv None for a non-separable 1x1 repeat), len_in / len_out int32 device lengths before / after the depthwise conv.
     `lazy_out` (only between two repeats, see SubBlock): the result is the UN-normalised 1x1 output carrying its pending BatchNorm
-    (`._ts_lazy`); hand it to the next sub_block call and to nothing else."""
+    (`._ts_lazy`); hand it to the next sub_block call and to nothing else.  `tile_stats` (with lazy_out, when the consumer is the next repeat's
+    depthwise launch and not a block tail): the statistics may travel as the per-tile pairs of the 1x1 launch (ts_tcs_desc.stats)."""
     cfg = SubBlockCfg()
     cfg.len_in, cfg.len_out, cfg.bwd_mask = len_in, len_out, bool(bwd_mask)   # bwd_mask False: x comes out of Fork(x, res_len), which masks the gradient
     if dw_conv is not None:
@@ -925,6 +963,7 @@ def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Ten
     pending = getattr(x, "_ts_lazy", None)              # (sums, relu, bn module, running buffers) of the previous repeat's BatchNorm
     cfg.lazy_in = (pending[0], pending[1], pending[2].eps, pending[3]) if pending is not None else None
     cfg.lazy_out, cfg.out_sums = bool(lazy_out) and cfg.drop_p == 0.0, None
+    cfg.tile_stats = bool(tile_stats)
     if pending is not None and not same_depthwise(dw_conv):
         raise RuntimeError("sub_block: the input carries a pending BatchNorm but this repeat cannot apply it")
     gamma_in, beta_in = (pending[2].weight, pending[2].bias) if pending is not None else (None, None)
