@@ -850,6 +850,8 @@ class SubBlock(torch.autograd.Function):
         tiles = None
         if cfg.lazy_out and getattr(cfg, "tile_stats", False) and TILE_STATS and mid.dtype == torch.bfloat16 and b >= 17 and _tcs_ok(True, c_in):
             tiles = tile_stats_buffer(b, c_out, t_out, x.device)
+            if tiles.shape[1] > 512:     # every consumer wave sums all the tiles of its channel: past ~512 the separate pass is cheaper
+                tiles = None             # (local batch 256 x 501 frames = 2 048 tiles: 54.2 vs 52.8 ms per step, measured)
         v = _pw_fwd(mid, pw_w, w_pw, lens=cfg.len_in if inside else None, stats=tiles)
         ws = torch.empty(16 * c_out, dtype=torch.float64, device=x.device)
         g, be = gamma.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
