@@ -101,3 +101,23 @@ def test_select_falls_back_to_the_fir_kernel_for_other_geometries():
     out0, _ = _run(0, 2, 24, 200, 11, [200, 150], False)
     assert torch.equal(out1["dx"], out0["dx"])
     assert float((out1["dw"].double() - _run(0, 2, 24, 200, 11, [200, 150], False)[1]["dw"]).abs().max()) <= 1e-4 * float(ref["dw"].abs().max())
+
+
+def test_random_geometries_sweep():
+    """60 random geometries (odd K in [3, 75], 16 / 32 / 48 channels, 8..900 frames, ragged lengths incl. empty and full clips, both tile sizes, with and
+    without the folded BatchNorm): the template with more k-steps / tap groups than a K needs, tiles that end exactly at T, clips shorter than the halo."""
+    import random
+    rnd = random.Random(2024)
+    tol = {"dx": 6e-3, "dw": 2e-5, "dbeta": 5e-3, "dgamma": 5e-3}
+    for case in range(60):
+        k = rnd.choice(range(3, 77, 2))
+        ch = rnd.choice([16, 32, 48])
+        t = rnd.choice([8, 64, 127, 128, 129, 255, 256, 257, 384, 500, 512, 640, 900]) if case % 3 else rnd.randint(8, 900)
+        b = rnd.randint(1, 4)
+        lens = [rnd.choice([0, 1, t, t, rnd.randint(0, t)]) for _ in range(b)]
+        bn, mode = bool(case & 1), 1 + (case >> 1 & 1)
+        out, ref = _run(mode, b, ch, t, k, lens, bn, relu=bool(case & 4) or not bn)
+        for key, r in ref.items():
+            scale = max(float(r.abs().max()), 1e-6)
+            err = float((out[key].double() - r).abs().max()) / scale
+            assert torch.isfinite(out[key]).all() and err <= tol[key], (case, (mode, b, ch, t, k, lens, bn), key, err)
