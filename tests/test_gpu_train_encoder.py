@@ -454,3 +454,30 @@ def test_tile_statistics_out_of_the_pointwise_epilogue_equal_the_separate_pass()
         assert float((g1[n] - g0[n]).norm()) <= 8e-2 * max(float(g0[n].norm()), 1e-6), n
     for n in r0:
         assert torch.allclose(r1[n], r0[n], rtol=2e-3, atol=2e-4), n
+
+
+@pytest.mark.parametrize("b,ci,co,t", [(17, 64, 256, 77), (32, 512, 512, 501), (20, 256, 1024, 128), (24, 128, 96, 333), (33, 64, 512, 64), (18, 192, 320, 1000)])
+def test_tile_statistics_of_the_pointwise_launch_sum_to_the_channel_moments(b, ci, co, t):
+    """ts_tcs_desc.stats: per (channel, tile) the launch leaves (sum y, sum y^2) over the tile's frames < T, taken from its f32 accumulators; summed over the
+    tiles they are the channel's moments over all B x T frames (nn.BatchNorm1d in train mode, quirk A4: padded frames count).  NaN in the rows' pitch padding
+    must not leak in; wide (64-frame tiles), narrow (128 / 64) and ragged (c_out % 32 != 0, T % tile != 0) shapes."""
+    from thunder_speech_amd import train_ops as T
+    g = torch.Generator(device="cuda").manual_seed(5)
+    p = (t + 191) // 192 * 192 + 64
+    u = torch.randn(b, ci, p, device="cuda", generator=g).bfloat16()
+    u[:, :, t:] = float("nan")
+    w = torch.randn(co, ci, device="cuda", generator=g) / ci ** 0.5
+    y = torch.empty(b, co, p, device="cuda", dtype=torch.bfloat16)
+    stats = T.tile_stats_buffer(b, co, t, "cuda")
+    stats.fill_(float("nan"))                                   # every entry is written by the launch
+    lens = torch.full((b,), t, dtype=torch.int32, device="cuda")
+    from thunder_speech_amd import plan
+    T._tcs_pointwise(u[:, :, :t].as_strided((b, ci, t), (ci * p, p, 1)), plan.pack_pw_frags(w), y[:, :, :t].as_strided((b, co, t), (co * p, p, 1)), lens, co, stats)
+    torch.cuda.synchronize()
+    ref = torch.einsum("oc,bct->bot", w.bfloat16().double(), u[:, :, :t].double())
+    got = stats.double().sum(1)
+    assert torch.isfinite(stats).all()
+    s1, s2 = ref.sum((0, 2)), (ref * ref).sum((0, 2))
+    assert float((got[:, 0] - s1).abs().max()) <= 1e-3 * max(float(s2.sqrt().max()), 1.0)
+    assert float((got[:, 1] - s2).abs().max()) <= 2e-3 * float(s2.max())
+    assert float((y[:, :, :t].double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
