@@ -345,7 +345,10 @@ extern "C" int ts_ctc_loss(const float* logits, int32_t batch, int32_t n_classes
   (void)hipGetLastError();
   const dim3 grid(batch, grad ? 2 : 1);                                                          // alpha || beta
   const dim3 block((unsigned)ctc_threads(a.lmax));
-  static bool big[3] = {false, false, false};                                                    // more than the default 64 KiB allowed, per instantiation
+  static bool big_all[64][3] = {};                                                               // more than the default 64 KiB allowed: per (device, instantiation)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
+  bool (&big)[3] = big_all[dev];
   const int which = spt == 1 ? 0 : (spt == 2 ? 1 : 2);
   if (!lse_lds) {
     if (which == 0) hipLaunchKernelGGL((ctc_kernel<1, false>), grid, block, lds, stream, a);

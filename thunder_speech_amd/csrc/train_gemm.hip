@@ -293,11 +293,13 @@ extern "C" int ts_train_pwconv_wgrad_mfma(const void* dv, const void* u, const i
     return TS_EUNSUPPORTED;
   if ((size_t)batch * c_out * pitch_v * 2 >= (1ull << 31) || (size_t)batch * c_in * pitch_u * 2 >= (1ull << 31)) return TS_EUNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  static int attr = 0;
-  if (!attr) {
+  static bool attr[64] = {};                              // per device (one process may drive several GPUs)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
+  if (!attr[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WD_SINGLE * WSTAGEB) != hipSuccess)
       return TS_EUNSUPPORTED;
-    attr = 1;
+    attr[dev] = true;
   }
   WgradArgs g;
   g.dv = (const bf16_t*)dv; g.u = (const bf16_t*)u; g.part = workspace; g.len_u = len_u;
@@ -331,11 +333,13 @@ extern "C" int ts_train_pwconv_wgrad_multi(const ts_wgrad_item* items, int32_t c
     if (int st = wgrad_check(it.dv, it.u, it.workspace, it.batch, it.c_in, it.c_out, it.t, it.pitch_u, it.pitch_v)) return st;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  static int attr = 0;
-  if (!attr) {
+  static bool attr[64] = {};                              // per device (one process may drive several GPUs)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
+  if (!attr[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WD_GROUP * WSTAGEB) != hipSuccess)
       return TS_EUNSUPPORTED;
-    attr = 1;
+    attr[dev] = true;
   }
   (void)hipGetLastError();
   for (int base = 0; base < count; base += WM_MAX) {
