@@ -854,7 +854,8 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
-// Depthwise backward on the matrix cores (bf16 rows, "same" geometry, channels % 16 == 0): v_mfma_f32_4x4x4_16b_bf16 = 16 independent
+// Depthwise backward on the matrix cores -- autograd's backward of the depthwise MaskedConv1d of a training-mode block (reference
+// quartznet/blocks.py:95-164 inside QuartznetBlock.forward, :317-338) -- for bf16 rows, "same" geometry, channels % 16 == 0: v_mfma_f32_4x4x4_16b_bf16 = 16 independent
 // 4 x 4 x 4 products per instruction, the shape the inference kernel's depthwise producers use (csrc/tcs_split.hip).  A WAVE owns 16
 // consecutive channels and walks units = (clip, TT-frame tile); per unit it stages the dy and x windows [t0 - H, t0 + TT + H) of its 16
 // rows in wave-private LDS (zero outside the lengths; x through the previous repeat's BatchNorm + ReLU when that is folded in) and runs

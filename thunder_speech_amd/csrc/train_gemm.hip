@@ -154,7 +154,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int block_id, int
 
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(WgradArgs a) { wgrad_tile<WD_SINGLE>(a, blockIdx.x, gridDim.x); }
 
-// the same product for up to WM_MAX layers in ONE launch: workgroup -> (layer, tile) through the layers' tile-count prefix sums.  A graphed
+// the same product (the weight gradient of the 1x1 MaskedConv1d of a block repeat, reference quartznet/blocks.py:169-182 with kernel_size = 1, as autograd
+// computes it) for up to WM_MAX layers in ONE launch: workgroup -> (layer, tile) through the layers' tile-count prefix sums.  A graphed
 // training step hands over every layer of a backward piece at once (the weight gradients are off the critical path: nothing reads them before
 // the optimizer), so 93 launches of 17-20 us, each with its own launch latency, ramp and drain, become three.
 constexpr int WM_MAX = 32;
