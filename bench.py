@@ -3,7 +3,7 @@
 configs[1]).  One "step" = mel front end -> 78 fused TCS launches -> decoder -> argmax + run-collapse, inputs
 resident in HBM, replayed from a hipGraph.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N ranks as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -148,10 +148,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # one command starts all ranks (the reference: Trainer(accelerator="gpu", devices=-1)): nothing above has touched the GPU, so start
+        # one CHILD process per GPU under torch.distributed.run, relay rank 0's line (inherited stdout) and leave with the launcher's code
+        from thunder_speech_amd.parallel import launch_ranks
+        rc = launch_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:], timeout_s=float(os.environ.get("TS_BENCH_LAUNCH_TIMEOUT_S", "1500")))
+        if rc != 0:
+            print(f"bench.py: the {args.gpus}-rank run failed (launcher exit code {rc})", file=sys.stderr)
+        sys.exit(rc)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (this benchmark has no CPU path)", file=sys.stderr)
         sys.exit(2)
@@ -161,6 +168,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)                      # a real RCCL all-reduce: its sum IS the number of ranks that took part
+        rccl_world = int(probe.item())
+        if rccl_world != dist.get_world_size():
+            raise RuntimeError(f"RCCL all-reduce saw {rccl_world} ranks, expected {dist.get_world_size()}")
+    else:
+        rccl_world = 1
 
     from thunder_speech_amd.module import greedy_decode
     from thunder_speech_amd.parallel import max_over_ranks
@@ -234,7 +248,7 @@ def main():
     traffic, traffic_source = pmc_traffic(B, S)
     result = {
         "metric": "audio-seconds/s (16 kHz) QuartzNet15x5 inference",
-        "value": value, "unit": "audio-seconds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "audio-seconds/s", "n_gpus": world, "rccl_world_size": rccl_world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"QuartzNet15x5 inference, batch {B}x{S} s per GPU, 16 kHz synthetic clips "

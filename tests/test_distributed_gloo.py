@@ -431,3 +431,68 @@ def test_two_rank_segmented_step_overlaps_bucket_k_with_piece_k_plus_1_and_avera
             assert torch.allclose(got, p.detach(), rtol=1e-5, atol=1e-6), (rank, n, float((got - p.detach()).abs().max()))
     for n in results[0][0]:
         assert (results[0][0][n] == results[1][0][n]).all(), n
+
+
+# ---- launch_ranks: one command starts all ranks (bench.py --gpus N without a launcher) -------------------------------------------------
+_STUB = '''
+import json, os, sys
+import torch, torch.distributed as dist
+mode = sys.argv[1]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if mode == "fail" and rank == 1:
+    print("stub: rank 1 has no GPU", file=sys.stderr); sys.exit(2)
+if mode == "hang":
+    import time; time.sleep(600)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+t = torch.ones(1); dist.all_reduce(t)
+if rank == 0:
+    print(json.dumps({"world_seen_by_all_reduce": int(t.item()), "argv": sys.argv[1:]}), flush=True)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run_launcher(tmp_path, mode, timeout_s=None):
+    """launch_ranks from a fresh interpreter (as bench.py calls it), stdout captured."""
+    import subprocess
+    import sys
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); from thunder_speech_amd.parallel import launch_ranks; "
+            f"sys.exit(launch_ranks({str(stub)!r}, 2, [{mode!r}, '--steps', 3], timeout_s={timeout_s!r}))")
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+
+
+def test_launch_ranks_starts_both_ranks_and_relays_rank0_line(tmp_path):
+    import json
+    r = _run_launcher(tmp_path, "ok")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got == {"world_seen_by_all_reduce": 2, "argv": ["ok", "--steps", "3"]}
+
+
+def test_launch_ranks_reports_a_failed_rank_with_a_nonzero_code_and_does_not_hang(tmp_path):
+    r = _run_launcher(tmp_path, "fail")
+    assert r.returncode != 0
+    assert "rank 1 has no GPU" in r.stderr
+
+
+def test_launch_ranks_stops_its_own_process_group_on_timeout(tmp_path):
+    r = _run_launcher(tmp_path, "hang", timeout_s=20)
+    assert r.returncode == 124
+    assert "ranks were stopped" in r.stderr
+
+
+def test_bench_gpus_2_without_a_launcher_fails_loudly_on_a_gpu_less_box():
+    """`python bench.py --gpus 2` starts two child ranks itself; without a GPU both say so and the command exits non-zero."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the real run is the driver's")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("no GPU visible") >= 1          # the launcher may stop the second rank before it has spoken

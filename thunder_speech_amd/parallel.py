@@ -37,6 +37,42 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return float(t.item())
 
 
+def launch_ranks(script: str, n_ranks: int, argv, timeout_s: float = None, env=None) -> int:
+    """Start `n_ranks` fresh processes of `script` (one per GPU of this node) under `torch.distributed.run` and return the launcher's
+    exit code -- what `pl.Trainer(accelerator="gpu", devices=-1)` does for the reference's users (docs/quick reference guide.md:74-79,
+    tests/quartznet/test_module_qn.py:46-53: one command starts all ranks).  The children inherit stdout / stderr, so rank 0's result
+    line is the caller's output; a failing rank makes the launcher tear the others down and return non-zero.
+    MUST be called before the calling process touches the GPU: the ranks are CHILD processes (never an exec of this one), and the
+    parent only waits."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if n_ranks < 1:
+        raise ValueError("launch_ranks: n_ranks must be >= 1")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:      # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + [str(a) for a in argv]
+    child_env = dict(os.environ if env is None else env)
+    child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this driver (RCCL across processes)
+    child_env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=child_env, start_new_session=True)
+    try:
+        return proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGTERM)                            # the exact process group this call started
+        try:
+            proc.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+        print(f"launch_ranks: {script} gave no result within {timeout_s:.0f} s; its {n_ranks} ranks were stopped", file=sys.stderr, flush=True)
+        return 124
+
+
 class GradientSync:
     """The one exchange step of data-parallel fine-tuning, overlapped with the backward pass.
 
