@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 8
+#define TS_ABI_VERSION 9
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -147,7 +147,8 @@ int ts_gemm_f32_b2(const void* a, int64_t a_rs, int64_t a_cs, int64_t sa, int64_
  *   ts_w2v_layernorm_bwd  y = LN(x (+ res)) gamma + beta: dx (= d res), dgamma += , dbeta += ; workspace ts_w2v_layernorm_bwd_workspace bytes
  *   ts_w2v_colsum         out[j] += sum_r x[r ld + j]   (bias gradients)
  *   ts_w2v_gelu_fwd/_bwd  y = gelu(z + bias[col]) (erf form; bias may be NULL) and dz = dy gelu'(z + bias[col])
- *   ts_w2v_softmax_fwd    s [batch][heads][t][t] -> softmax(scale s) in place, keys >= key_len[clip] masked; _bwd: dp -> scale p (dp - <dp, p>)
+ *   ts_w2v_softmax_fwd    s [batch][heads][t][pitch >= t] -> softmax(scale s) in place, keys >= key_len[clip] masked, columns t .. pitch zeroed
+ *                         (ABI v9: a pitch that is a multiple of 4 keeps the attention products on ts_gemm_f32's vector loads); _bwd: dp -> scale p (dp - <dp, p>)
  *   ts_w2v_pad_rows       time-axis zero padding of [batch][t][c] (extract = 0) and its inverse (1)
  *   ts_w2v_mask_embed     train-time masking: rows with mask != 0 <- embed (forward); backward: dembed += masked rows of dy, which become 0
  *   ts_w2v_add            y = a + b
@@ -158,8 +159,8 @@ int ts_w2v_layernorm_bwd(const float* x, const float* res, const float* gamma, c
 int ts_w2v_colsum(const float* x, int64_t rows, int32_t c, int64_t ld, float* out, void* stream);
 int ts_w2v_gelu_fwd(const float* z, const float* bias, int32_t c, float* y, int64_t n, void* stream);
 int ts_w2v_gelu_bwd(const float* z, const float* bias, int32_t c, const float* dy, float* dz, int64_t n, void* stream);
-int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, float scale, void* stream);
-int ts_w2v_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t t, float scale, void* stream);
+int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, int32_t pitch, float scale, void* stream);
+int ts_w2v_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t t, int32_t pitch, float scale, void* stream);
 int ts_w2v_pad_rows(const float* src, float* dst, int32_t batch, int32_t t, int32_t t_dst, int32_t left, int32_t c, int32_t extract, void* stream);
 int ts_w2v_mask_embed(float* x, const uint8_t* mask, const float* embed, float* dembed, int64_t rows, int32_t c, void* stream);
 int ts_w2v_add(const float* a, const float* b, float* y, int64_t n, void* stream);
@@ -444,11 +445,24 @@ int ts_train_subsample_mask(const void* x, const int32_t* len, void* y, int32_t 
  *   ts_train_se_pool   mean[row] = mean_t x[row][t]           (AdaptiveAvgPool1d(1) over ALL frames, quirk A3)
  *   ts_train_se_scale  y = x * gate[row] (+ add_mean[row] / t when add_mean != NULL: the pooled gradient, backward pass)
  *   ts_train_se_rowdot out[row] = sum_t a[row][t] * b[row][t]  (d gate = sum_t dy * x)
- * mean / gate / add_mean / out are f32 [rows].  The [B, C] bottleneck in between is a few tiny GEMMs on the caller's side. */
+ * mean / gate / add_mean / out are f32 [rows].
+ * The [B, C] bottleneck in between (citrinet/blocks.py:72-83: Linear(C, hidden, bias=False) -> ReLU -> Linear(hidden, C, bias=False) -> sigmoid;
+ * w1 f32 [hidden][C], w2 f32 [C][hidden]) and its autograd backward (ABI v9; these replace `mean @ w1.t()`, `h @ w2.t()` and the four
+ * products of their backward):
+ *   ts_train_se_gate_fwd  hid[b][j] = relu(sum_i w1[j][i] mean[b][i]) (stored when hid != NULL), gate[b][c] = sigmoid(sum_j w2[c][j] hid[b][j]);
+ *                         one launch, a workgroup per clip (ts_se_gate_fwd uses the same kernel behind its pooling pass)
+ *   ts_train_se_gate_bwd  dz = dgate * gate * (1 - gate); dhid = (hid > 0) * (dz . w2); dmean = dhid . w1; dw2 = dz^T . hid; dw1 = dhid^T . mean
+ *                         (dz_ws f32 [B][C], dhid_ws f32 [B][hidden]: workspaces; dw1 / dw2 are overwritten, not accumulated)
+ * TS_EUNSUPPORTED when C + hidden floats exceed the kernels' LDS budget (15 k). */
 int ts_train_se_pool(const void* x, float* mean, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_se_scale(const void* x, const float* gate, const float* add_mean, void* y, int64_t rows, int32_t t, int32_t pitch,
                       int32_t act, void* stream);
 int ts_train_se_rowdot(const void* a, const void* b, float* out, int64_t rows, int32_t t, int32_t pitch, int32_t act, void* stream);
+int ts_train_se_gate_fwd(const float* mean, const float* w1, const float* w2, float* hid, float* gate, int32_t batch, int32_t channels,
+                         int32_t hidden, void* stream);
+int ts_train_se_gate_bwd(const float* dgate, const float* gate, const float* hid, const float* mean, const float* w1, const float* w2,
+                         float* dz_ws, float* dhid_ws, float* dmean, float* dw1, float* dw2, int32_t batch, int32_t channels, int32_t hidden,
+                         void* stream);
 /* nn.Dropout in train mode on activation rows (quartznet/blocks.py:227-228, blocks.py:238): y = x * keep / (1 - p), keep ~
  * Bernoulli(1 - p) from the Philox stream (seed, element index row * t + i) -- independent of pitch and element type; the backward
  * pass is the same call on dy with the same seed.  x and y may alias.  `nonce` (device uint64, may be NULL) is added to the seed

@@ -169,3 +169,19 @@ def test_ctc_training_step_through_the_module_updates_the_transformer_and_not_th
     moved = {n: float((p.detach() - before[n]).abs().max()) for n, p in enc.original_encoder.named_parameters()}
     assert all(v == 0.0 for n, v in moved.items() if n.startswith("feature_extractor."))
     assert moved["encoder.layers.1.attention.q_proj.weight"] > 0 and moved["feature_projection.projection.weight"] > 0
+
+
+def test_unfrozen_feature_extractor_is_refused_and_the_frozen_plan_holds_only_its_weights():
+    """The reference freezes the conv feature extractor once, in __init__ (compatibility.py:27-28).  Flipping requires_grad back on afterwards would
+    make autograd train it in the reference; this path has no backward there and must say so rather than return no gradient."""
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    adapt = HuggingFaceEncoderAdapt(_model("group_postln", seed=5), precision="fp32").cuda().train()
+    x = _inputs(b=2, n=6000, seed=1).cuda()
+    adapt(x, torch.tensor([6000, 6000]).cuda())
+    plan = adapt._plan_frozen(x.device)
+    assert plan.feature_extractor_only and plan.layers == [] and not hasattr(plan, "fp_w")
+    with pytest.raises(RuntimeError):
+        plan.forward(x, None)
+    next(adapt.original_encoder.feature_extractor.parameters()).requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="feature extractor is frozen"):
+        adapt(x, torch.tensor([6000, 6000]).cuda())

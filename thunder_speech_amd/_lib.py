@@ -12,7 +12,7 @@ from typing import Optional
 from .build import lib_path
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 TCS_IN_TAILZERO = 1
 TCS_OUT_ZERO_TAIL = 2
 TCS_TAPS_PHASE = 4
@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "ts_w2v_attention_fwd",
     "ts_spec_masks_draw", "ts_spec_mask_apply", "ts_train_dropout", "ts_counter_add", "ts_train_add", "ts_train_act_import", "ts_train_act_export",
     "ts_audio_prep_workspace_bytes", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance", "ts_encode_chars",
-    "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot",
+    "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale", "ts_train_se_rowdot", "ts_train_se_gate_fwd", "ts_train_se_gate_bwd",
     "ts_grad_wire_pack", "ts_grad_wire_unpack",
 ]
 
@@ -186,6 +186,8 @@ def lib() -> C.CDLL:
     L.ts_train_se_pool.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     L.ts_train_se_scale.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp]
     L.ts_train_se_rowdot.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
+    L.ts_train_se_gate_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.ts_train_se_gate_bwd.argtypes = [vp] * 11 + [i32, i32, i32, vp]
     L.ts_train_dropout.argtypes = [vp, vp, i64, i32, i32, f32, u64, vp, i32, vp]
     L.ts_counter_add.argtypes = [vp, u64, vp]
     L.ts_lengths_map.argtypes = [vp, i32, vp, i32, vp, i32, i64, i64, i64, vp]
@@ -209,8 +211,8 @@ def lib() -> C.CDLL:
     L.ts_w2v_colsum.argtypes = [vp, i64, i32, i64, vp, vp]
     L.ts_w2v_gelu_fwd.argtypes = [vp, vp, i32, vp, i64, vp]
     L.ts_w2v_gelu_bwd.argtypes = [vp, vp, i32, vp, vp, i64, vp]
-    L.ts_w2v_softmax_fwd.argtypes = [vp, vp, i32, i32, i32, C.c_float, vp]
-    L.ts_w2v_softmax_bwd.argtypes = [vp, vp, i64, i32, C.c_float, vp]
+    L.ts_w2v_softmax_fwd.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, vp]
+    L.ts_w2v_softmax_bwd.argtypes = [vp, vp, i64, i32, i32, C.c_float, vp]
     L.ts_w2v_pad_rows.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.ts_w2v_mask_embed.argtypes = [vp, vp, vp, vp, i64, i32, vp]
     L.ts_w2v_add.argtypes = [vp, vp, vp, i64, vp]
@@ -227,7 +229,7 @@ def lib() -> C.CDLL:
     for fn in ("ts_train_act_import", "ts_train_act_export", "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_mask_time",
                "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_mfma", "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd",
                "ts_train_add_relu_fwd", "ts_train_relu_bwd", "ts_train_subsample_mask", "ts_train_se_pool", "ts_train_se_scale",
-               "ts_train_se_rowdot", "ts_train_dropout", "ts_counter_add", "ts_train_add"):
+               "ts_train_se_rowdot", "ts_train_se_gate_fwd", "ts_train_se_gate_bwd", "ts_train_dropout", "ts_counter_add", "ts_train_add"):
         getattr(L, fn).restype = C.c_int
     L.ts_spec_masks_draw.argtypes = [u64] + [i32] * 9 + [vp, vp]
     L.ts_spec_mask_apply.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp]

@@ -91,7 +91,7 @@ struct Stage {
       v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (rr[p] < rows && k < K) {
         const int nv = KC ? K - k : rows - rr[p];
-        v[p] = load4<BF>(base, off[p] + o, vec, nv);
+        v[p] = load4<BF>(base, off[p] + o, vec && nv >= 4, nv);     // a vector load never reaches past the operand's logical extent here
 #pragma unroll
         for (int i = 1; i < 4; ++i) if (i >= nv) v[p][i] = 0.f;
       }
@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
   const char* const a0 = static_cast<const char*>(g.a) + (z1 * g.sa + z2 * g.sa2) * (BF ? 2 : 4);
   const char* const b0 = static_cast<const char*>(g.b) + (z1 * g.sb + z2 * g.sb2) * (BF ? 2 : 4);
   const int nks = (g.K + BK - 1) / BK, total = nks * g.nkb;
-  const bool vec = g.vec_a && g.vec_b;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -142,13 +141,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
   auto fetch = [&]() {
     const int k0 = sk * BK;
     const long long oa = sj * g.ska + sk * sa.step, ob = sj * g.skb + sk * sb.step;
-    if (vec && k0 + BK <= g.K) {                      // wave-uniform
-      sa.fetch_fast(a0, oa);
-      sb.fetch_fast(b0, ob);
-    } else {
-      sa.fetch_slow(a0, oa, g.M, g.K, k0, g.vec_a != 0);
-      sb.fetch_slow(b0, ob, g.N, g.K, k0, g.vec_b != 0);
-    }
+    const bool full = k0 + BK <= g.K;                 // wave-uniform; the fast path is chosen PER OPERAND: one unaligned operand (e.g. attention
+    if (g.vec_a && full) sa.fetch_fast(a0, oa);       // probabilities with an odd frame count as their pitch) does not drag the other one down
+    else sa.fetch_slow(a0, oa, g.M, g.K, k0, g.vec_a != 0);
+    if (g.vec_b && full) sb.fetch_fast(b0, ob);
+    else sb.fetch_slow(b0, ob, g.N, g.K, k0, g.vec_b != 0);
     if (++sk == nks) { sk = 0; ++sj; }
   };
   fetch();
@@ -208,7 +205,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
 
 // Strides in ELEMENTS; exactly one of (a_rs, a_cs) and one of (b_rs, b_cs) must be 1 (TS_EUNSUPPORTED otherwise).  An operand whose base is 16-byte
 // aligned (8 for bf16) and whose other strides are all multiples of 4 is fetched with vector loads -- a load may then reach 3 elements past the
-// logical extent of the contiguous index, which stays inside the row pitch and is masked to 0 -- any other operand element by element.
+// logical extent of an M/N-contiguous operand's row, which stays inside the row pitch (a multiple of 4) and only feeds outputs that are not
+// stored; along K the last partial stage is fetched element by element -- any other operand element by element throughout.
 // Two batch levels: grid.z = batch x batch2, operand offsets z1 s? + z2 s?2 ((clip, head) of the attention products; (group, tap) of the
 // positional conv's weight gradient).
 int gemm_f32_b2(hipStream_t stream, bool in_bf16, const void* a, long long a_rs, long long a_cs, long long sa, long long ska, const void* b,

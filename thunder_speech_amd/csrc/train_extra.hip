@@ -3,7 +3,7 @@
 //   strided 1x1 MaskedConv1d (residual branch of a strided block, quartznet/blocks.py:301-311, citrinet/blocks.py:156-165):
 //     mask + subsample in one pass; the 1x1 conv itself is the pointwise GEMM that follows
 //   SqueezeExcite (citrinet/blocks.py:70-83) forward and backward: the two passes over the activation each way; the
-//     [B, C]-sized bottleneck (two bias-free linears, ReLU, sigmoid) is a handful of tiny GEMMs done by the caller
+//     [B, C]-sized bottleneck (two bias-free linears, ReLU, sigmoid) and its backward are one / two small launches (se_gate_*_kernel)
 //   nn.Dropout (quartznet/blocks.py:227-228, blocks.py:238): Philox mask re-drawn in the backward pass
 #include "ts_common.hpp"
 #include "ts_philox.hpp"
@@ -74,6 +74,106 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, 
     stf(y, row * pitch + i, fmaf(ldf(x, row * pitch + i), gr, ar));
 }
 
+// ---- the [B, C] bottleneck of SqueezeExcite (citrinet/blocks.py:72-83: Linear(C, C/r, bias=False) -> ReLU -> Linear(C/r, C, bias=False) -> sigmoid) ----
+// One workgroup of 16 waves per clip.  hid[j] = relu(sum_i w1[j][i] mean[i]): a wave per output, lanes over the contraction (coalesced rows);
+// gate[c] = sigmoid(sum_j w2[c][j] hid[j]): 16 lanes per output (the contraction is only C/r long), 4 outputs per wave at a time.
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__ mean, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                        float* __restrict__ hid_out, float* __restrict__ gate, int channels, int hidden) {
+  extern __shared__ float se_sm[];
+  float* xm = se_sm;
+  float* h = se_sm + channels;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < channels; i += 1024) xm[i] = mean[(size_t)b * channels + i];
+  __syncthreads();
+  for (int j = wave; j < hidden; j += 16) {
+    const float* wr = w1 + (size_t)j * channels;
+    float s = 0.f;
+    for (int i = lane; i < channels; i += 64) s = fmaf(wr[i], xm[i], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      s = s > 0.f ? s : 0.f;
+      h[j] = s;
+      if (hid_out) hid_out[(size_t)b * hidden + j] = s;
+    }
+  }
+  __syncthreads();
+  const int sub = lane & 15, q = lane >> 4;
+  for (int c0 = wave * 4; c0 < channels; c0 += 64) {
+    const int c = c0 + q;
+    float s = 0.f;
+    if (c < channels) {
+      const float* wr = w2 + (size_t)c * hidden;
+      for (int j = sub; j < hidden; j += 16) s = fmaf(wr[j], h[j], s);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (sub == 0 && c < channels) gate[(size_t)b * channels + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
+// backward through the bottleneck, per clip: dz = dgate * g (1 - g); dhid[j] = (hid[j] > 0) sum_c dz[c] w2[c][j]; dmean[i] = sum_j dhid[j] w1[j][i].
+// dz and dhid are kept ([B][C], [B][hidden]) for the weight gradients, which sum over the clips (se_gate_wgrad_kernel).
+__global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hid,
+                                                            const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ dz_out,
+                                                            float* __restrict__ dhid_out, float* __restrict__ dmean, int channels, int hidden) {
+  extern __shared__ float se_sm[];
+  float* dz = se_sm;                       // [channels]
+  float* dh = se_sm + channels;            // [hidden]
+  float* part = dh + hidden;               // [1024]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < channels; c += 1024) {
+    const float g = gate[(size_t)b * channels + c];
+    const float v = dgate[(size_t)b * channels + c] * g * (1.f - g);
+    dz[c] = v;
+    dz_out[(size_t)b * channels + c] = v;
+  }
+  __syncthreads();
+  int nj = 64;
+  while (nj < hidden && nj < 1024) nj <<= 1;             // threads = slices x nj: coalesced rows of w2, slices over the channels
+  const int slices = 1024 / nj, jl = tid % nj, cs = tid / nj;
+  for (int j0 = 0; j0 < hidden; j0 += nj) {
+    const int j = j0 + jl;
+    float s = 0.f;
+    if (j < hidden)
+      for (int c = cs; c < channels; c += slices) s = fmaf(dz[c], w2[(size_t)c * hidden + j], s);
+    part[tid] = s;
+    __syncthreads();
+    if (cs == 0 && j < hidden) {
+      for (int k = 1; k < slices; ++k) s += part[k * nj + jl];
+      s = hid[(size_t)b * hidden + j] > 0.f ? s : 0.f;
+      dh[j] = s;
+      dhid_out[(size_t)b * hidden + j] = s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < channels; i += 1024) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < hidden; ++j) s = fmaf(dh[j], w1[(size_t)j * channels + i], s);
+    dmean[(size_t)b * channels + i] = s;
+  }
+}
+
+// dw2[c][j] = sum_b dz[b][c] hid[b][j]  (first channels * hidden threads);  dw1[j][i] = sum_b dhid[b][j] mean[b][i]  (the rest)
+__global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ hid, const float* __restrict__ dhid,
+                                                             const float* __restrict__ mean, float* __restrict__ dw1, float* __restrict__ dw2, int batch,
+                                                             int channels, int hidden) {
+  const long long n = (long long)channels * hidden;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < n) {
+    const int c = (int)(idx / hidden), j = (int)(idx % hidden);
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) s = fmaf(dz[(size_t)b * channels + c], hid[(size_t)b * hidden + j], s);
+    dw2[idx] = s;
+  } else if (idx < 2 * n) {
+    idx -= n;
+    const int j = (int)(idx / channels), i = (int)(idx % channels);
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) s = fmaf(dhid[(size_t)b * hidden + j], mean[(size_t)b * channels + i], s);
+    dw1[idx] = s;
+  }
+}
+
 // element (row, i) draws word (e & 3) of Philox counter e >> 2, e = row * t + i: the mask depends on the LOGICAL index only
 template <class T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int t, int pitch, float p, float scale,
@@ -140,6 +240,31 @@ extern "C" int ts_train_se_scale(const void* x, const float* gate, const float* 
   TS_ACT(act,
          hipLaunchKernelGGL(se_scale_kernel<float>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const float*)x, gate, add_mean, 1.0f / (float)t, (float*)y, t, pitch),
          hipLaunchKernelGGL(se_scale_kernel<bf16_t>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gate, add_mean, 1.0f / (float)t, (bf16_t*)y, t, pitch));
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_se_gate_fwd(const float* mean, const float* w1, const float* w2, float* hid, float* gate, int32_t batch, int32_t channels,
+                                    int32_t hidden, void* stream) {
+  if (!mean || !w1 || !w2 || !gate || batch <= 0 || channels <= 0 || hidden <= 0) return TS_EINVAL;
+  const size_t lds = (size_t)(channels + hidden) * sizeof(float);
+  if (lds > 64 * 1024) return TS_EUNSUPPORTED;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(se_gate_kernel, dim3(batch), dim3(1024), lds, (hipStream_t)stream, mean, w1, w2, hid, gate, channels, hidden);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int ts_train_se_gate_bwd(const float* dgate, const float* gate, const float* hid, const float* mean, const float* w1, const float* w2,
+                                    float* dz_ws, float* dhid_ws, float* dmean, float* dw1, float* dw2, int32_t batch, int32_t channels, int32_t hidden,
+                                    void* stream) {
+  if (!dgate || !gate || !hid || !mean || !w1 || !w2 || !dz_ws || !dhid_ws || !dmean || !dw1 || !dw2) return TS_EINVAL;
+  if (batch <= 0 || channels <= 0 || hidden <= 0) return TS_EINVAL;
+  const size_t lds = (size_t)(channels + hidden + 1024) * sizeof(float);
+  if (lds > 64 * 1024) return TS_EUNSUPPORTED;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(batch), dim3(1024), lds, (hipStream_t)stream, dgate, gate, hid, w1, w2, dz_ws, dhid_ws, dmean, channels, hidden);
+  const long long n = 2ll * channels * hidden;
+  hipLaunchKernelGGL(se_gate_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz_ws, hid, dhid_ws, mean, dw1, dw2, batch,
+                     channels, hidden);
   return hip_status(hipGetLastError());
 }
 

@@ -155,12 +155,13 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ z, 
 
 // In-place softmax over the keys of one (clip, head, query) row per wave: p = softmax(scale s), keys >= key_len[clip] get probability 0
 // (transformers adds finfo.min to them: the same after the softmax unless every key is padded, which a clip with at least one frame rules out).
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ s, const int* __restrict__ key_len, int heads, int t, float scale) {
+// Rows of `pitch` >= t floats (a pitch that is a multiple of 4 keeps the attention GEMMs on their vector loads); columns t .. pitch are zeroed.
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ s, const int* __restrict__ key_len, int heads, int t, int pitch, float scale) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.y;
   if (row >= (long long)heads * t) return;
-  float* p = s + ((long long)b * heads * t + row) * t;
+  float* p = s + ((long long)b * heads * t + row) * pitch;
   const int nk = key_len ? min(key_len[b], t) : t;
   float mx = -3.0e38f;
   for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, p[j] * scale);
@@ -170,20 +171,20 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ s,
   for (int j = lane; j < nk; j += 64) sum += __expf(p[j] * scale - mx);
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
-  for (int j = lane; j < t; j += 64) p[j] = j < nk ? __expf(p[j] * scale - mx) * inv : 0.f;
+  for (int j = lane; j < pitch; j += 64) p[j] = j < nk ? __expf(p[j] * scale - mx) * inv : 0.f;
 }
 
 // ds = scale p (dp - sum_k dp_k p_k), in place over dp; one wave per row
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long long rows, int t, float scale) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long long rows, int t, int pitch, float scale) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* pr = p + row * t;
-  float* dr = dp + row * t;
+  const float* pr = p + row * pitch;
+  float* dr = dp + row * pitch;
   float dot = 0.f;
   for (int j = lane; j < t; j += 64) dot += pr[j] * dr[j];
   dot = wave_sum(dot);
-  for (int j = lane; j < t; j += 64) dr[j] = scale * pr[j] * (dr[j] - dot);
+  for (int j = lane; j < pitch; j += 64) dr[j] = j < t ? scale * pr[j] * (dr[j] - dot) : 0.f;
 }
 
 // dst[b][r + left][:] = src[b][r][:] for r < t, every other row of dst (t_dst rows per clip) = 0; with `extract` the other way round:
@@ -288,19 +289,19 @@ extern "C" int ts_w2v_gelu_bwd(const float* z, const float* bias, int32_t c, con
   return hip_status(hipGetLastError());
 }
 
-/* s f32 [batch][heads][t][t] scores -> probabilities in place; key_len int32 [batch] or NULL */
-extern "C" int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, float scale, void* stream_) {
-  if (!s || batch <= 0 || heads <= 0 || t <= 0) return TS_EINVAL;
+/* s f32 [batch][heads][t][pitch] scores -> probabilities in place; key_len int32 [batch] or NULL */
+extern "C" int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, int32_t pitch, float scale, void* stream_) {
+  if (!s || batch <= 0 || heads <= 0 || t <= 0 || pitch < t) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)(((long long)heads * t + 3) / 4), batch), dim3(256), 0, stream, s, key_len, heads, t, scale);
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)(((long long)heads * t + 3) / 4), batch), dim3(256), 0, stream, s, key_len, heads, t, pitch, scale);
   return hip_status(hipGetLastError());
 }
 
-/* dp [rows][t] -> d scores in place: scale p (dp - <dp, p>) */
-extern "C" int ts_w2v_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t t, float scale, void* stream_) {
-  if (!p || !dp || rows <= 0 || t <= 0) return TS_EINVAL;
+/* dp [rows][pitch] -> d scores in place: scale p (dp - <dp, p>) */
+extern "C" int ts_w2v_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t t, int32_t pitch, float scale, void* stream_) {
+  if (!p || !dp || rows <= 0 || t <= 0 || pitch < t) return TS_EINVAL;
   TS_STREAM;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p, dp, (long long)rows, t, scale);
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p, dp, (long long)rows, t, pitch, scale);
   return hip_status(hipGetLastError());
 }
 

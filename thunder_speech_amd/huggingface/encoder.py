@@ -50,7 +50,9 @@ class Wav2Vec2Plan:
     precision "fp32": every GEMM in fp32; "bf16": GEMM operands in bf16 (fp32 accumulation, fp32 residual stream /
     normalisations / softmax) -- each launch also writes the bf16 copy its consumer multiplies with."""
 
-    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device, precision: str = "bf16"):
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device, precision: str = "bf16", feature_extractor_only: bool = False):
+        """`feature_extractor_only`: pack the conv feature extractor's weights and nothing else -- the plan of the training path's frozen
+        front (huggingface/train.py); `forward` is then unavailable, `feature_extractor` works."""
         _check_config(cfg)
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
@@ -80,6 +82,10 @@ class Wav2Vec2Plan:
         # [c_out][c_in][k] -> [c_out][k][c_in]: consecutive taps are consecutive K columns of one GEMM
         self.conv_w = [gw(f(f"feature_extractor.conv_layers.{i}.conv.weight").permute(0, 2, 1))
                        for i in range(1, len(self.kernels))]
+        self.feature_extractor_only = bool(feature_extractor_only)
+        self.layers = []
+        if self.feature_extractor_only:
+            return
         self.fp_ln = (f("feature_projection.layer_norm.weight"), f("feature_projection.layer_norm.bias"))
         self.fp_w, self.fp_b = gw(f("feature_projection.projection.weight")), f("feature_projection.projection.bias")
         # weight_norm(dim=2): w[:, :, j] = g[j] v[:, :, j] / ||v[:, :, j]||
@@ -93,7 +99,6 @@ class Wav2Vec2Plan:
         self.pos_w = gw(w_eff.view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2))   # [k][g][out][in]
         self.pos_b = f(p + "bias")
         self.enc_ln = (f("encoder.layer_norm.weight"), f("encoder.layer_norm.bias"))
-        self.layers = []
         for i in range(self.n_layers):
             q = f"encoder.layers.{i}."
             self.layers.append(dict(
@@ -211,6 +216,8 @@ class Wav2Vec2Plan:
     def forward(self, audio: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
         """audio [B, n] fp32 on the GPU; lengths = samples per clip when the model was trained with an attention mask
         (`mask_input`), else None.  Returns last_hidden_state [B, T', C] fp32 (time-major)."""
+        if self.feature_extractor_only:
+            raise RuntimeError("this Wav2Vec2Plan holds the feature extractor's weights only (feature_extractor_only=True)")
         L = _lib.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         feats = self.feature_extractor(audio)
@@ -278,12 +285,16 @@ class HuggingFaceEncoderAdapt(nn.Module):
         return self._cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, self.original_encoder.state_dict(), device, self.precision))
 
     def _plan_frozen(self, device) -> Wav2Vec2Plan:
-        """The plan the training path runs the frozen conv feature extractor on: keyed on the feature extractor's parameters only, so an
-        optimizer step on the transformer does not re-pack anything."""
+        """The plan the training path runs the frozen conv feature extractor on: built from and keyed on the feature extractor's parameters
+        only, so an optimizer step on the transformer re-packs nothing and no transformer weight gets a device copy it never uses.  It runs
+        at `self.precision` -- with the default "bf16" the FROZEN convolutions multiply bf16 operands (f32 accumulation) while everything
+        trainable behind them is f32; pass precision="fp32" for f32 arithmetic throughout (what the parity tests use)."""
         if not hasattr(self, "_fe_cache"):
             self._fe_cache = _PackedCache()
-        params = list(self.original_encoder.feature_extractor.parameters())
-        return self._fe_cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, self.original_encoder.state_dict(), device, self.precision))
+        fe = self.original_encoder.feature_extractor
+        params = list(fe.parameters())
+        sd = {"feature_extractor." + k: v for k, v in fe.state_dict().items()}
+        return self._fe_cache.get(params, lambda: Wav2Vec2Plan(self.original_encoder.config, sd, device, self.precision, feature_extractor_only=True))
 
     def forward(self, audio: torch.Tensor, audio_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         _t.require_gpu(audio, "wav2vec2 encoder")

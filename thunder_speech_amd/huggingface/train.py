@@ -227,17 +227,18 @@ class Attention(torch.autograd.Function):
         c = c3 // 3
         hd = c // heads
         L = _lib.lib()
-        p = torch.empty(b, heads, t, t, dtype=torch.float32, device=qkv.device)
+        tp = (t + 3) // 4 * 4                       # row pitch of the score / probability rows: 16-byte rows keep every product on vector loads
+        p = torch.empty(b, heads, t, tp, dtype=torch.float32, device=qkv.device)
         # scores[b][h][q][k] = q . k
-        _gemm(qkv, c3, 1, qkv, 1, c3, p, t, t, t, hd, sa=t * c3, sa2=hd, sb=t * c3, sb2=hd, sc=heads * t * t, sc2=t * t, batch=b, batch2=heads, b_off=c)
-        _lib.check(L.ts_w2v_softmax_fwd(p.data_ptr(), key_len.data_ptr() if key_len is not None else None, b, heads, t, hd ** -0.5, _s(p)),
+        _gemm(qkv, c3, 1, qkv, 1, c3, p, tp, t, t, hd, sa=t * c3, sa2=hd, sb=t * c3, sb2=hd, sc=heads * t * tp, sc2=t * tp, batch=b, batch2=heads, b_off=c)
+        _lib.check(L.ts_w2v_softmax_fwd(p.data_ptr(), key_len.data_ptr() if key_len is not None else None, b, heads, t, tp, hd ** -0.5, _s(p)),
                    "ts_w2v_softmax_fwd")
         pd = p
         if p_drop > 0.0:
-            pd = torch.empty_like(p)
-            _lib.check(L.ts_train_dropout(p.data_ptr(), pd.data_ptr(), b * heads * t, t, t, float(p_drop), int(seed), None, 0, _s(p)), "ts_train_dropout")
+            pd = torch.empty_like(p)                 # its pitch columns are never multiplied into a stored output
+            _lib.check(L.ts_train_dropout(p.data_ptr(), pd.data_ptr(), b * heads * t, t, tp, float(p_drop), int(seed), None, 0, _s(p)), "ts_train_dropout")
         out = torch.empty(b, t, c, dtype=torch.float32, device=qkv.device)
-        _gemm(pd, t, 1, qkv, c3, 1, out, c, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c3, sb2=hd, sc=t * c, sc2=hd, batch=b, batch2=heads, b_off=2 * c)
+        _gemm(pd, tp, 1, qkv, c3, 1, out, c, t, hd, t, sa=heads * t * tp, sa2=t * tp, sb=t * c3, sb2=hd, sc=t * c, sc2=hd, batch=b, batch2=heads, b_off=2 * c)
         ctx.save_for_backward(qkv, p, pd if p_drop > 0.0 else None)
         ctx.geom = (heads, p_drop, seed)
         return out
@@ -250,21 +251,22 @@ class Attention(torch.autograd.Function):
         b, t, c3 = qkv.shape
         c = c3 // 3
         hd = c // heads
+        tp = p.shape[-1]
         L = _lib.lib()
         pv = pd if pd is not None else p
         dqkv = torch.empty_like(qkv)
         bh = dict(batch=b, batch2=heads)
         # dV[k][d] = sum_q P'[q][k] dout[q][d]
-        _gemm(pv, 1, t, dout, c, 1, dqkv, c3, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c, sb2=hd, sc=t * c3, sc2=hd, c_off=2 * c, **bh)
+        _gemm(pv, 1, tp, dout, c, 1, dqkv, c3, t, hd, t, sa=heads * t * tp, sa2=t * tp, sb=t * c, sb2=hd, sc=t * c3, sc2=hd, c_off=2 * c, **bh)
         # dP'[q][k] = sum_d dout[q][d] v[k][d]
         dp = torch.empty_like(p)
-        _gemm(dout, c, 1, qkv, 1, c3, dp, t, t, t, hd, sa=t * c, sa2=hd, sb=t * c3, sb2=hd, sc=heads * t * t, sc2=t * t, b_off=2 * c, **bh)
+        _gemm(dout, c, 1, qkv, 1, c3, dp, tp, t, t, hd, sa=t * c, sa2=hd, sb=t * c3, sb2=hd, sc=heads * t * tp, sc2=t * tp, b_off=2 * c, **bh)
         if p_drop > 0.0:
-            _lib.check(L.ts_train_dropout(dp.data_ptr(), dp.data_ptr(), b * heads * t, t, t, float(p_drop), int(seed), None, 0, _s(dp)), "ts_train_dropout")
-        _lib.check(L.ts_w2v_softmax_bwd(p.data_ptr(), dp.data_ptr(), b * heads * t, t, hd ** -0.5, _s(dp)), "ts_w2v_softmax_bwd")
+            _lib.check(L.ts_train_dropout(dp.data_ptr(), dp.data_ptr(), b * heads * t, t, tp, float(p_drop), int(seed), None, 0, _s(dp)), "ts_train_dropout")
+        _lib.check(L.ts_w2v_softmax_bwd(p.data_ptr(), dp.data_ptr(), b * heads * t, t, tp, hd ** -0.5, _s(dp)), "ts_w2v_softmax_bwd")
         # dQ[q][d] = sum_k dS[q][k] k[k][d];  dK[k][d] = sum_q dS[q][k] q[q][d]
-        _gemm(dp, t, 1, qkv, c3, 1, dqkv, c3, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c3, sb2=hd, sc=t * c3, sc2=hd, b_off=c, **bh)
-        _gemm(dp, 1, t, qkv, c3, 1, dqkv, c3, t, hd, t, sa=heads * t * t, sa2=t * t, sb=t * c3, sb2=hd, sc=t * c3, sc2=hd, c_off=c, **bh)
+        _gemm(dp, tp, 1, qkv, c3, 1, dqkv, c3, t, hd, t, sa=heads * t * tp, sa2=t * tp, sb=t * c3, sb2=hd, sc=t * c3, sc2=hd, b_off=c, **bh)
+        _gemm(dp, 1, tp, qkv, c3, 1, dqkv, c3, t, hd, t, sa=heads * t * tp, sa2=t * tp, sb=t * c3, sb2=hd, sc=t * c3, sc2=hd, c_off=c, **bh)
         return dqkv, None, None, None, None
 
 
@@ -374,6 +376,13 @@ def train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
     dev = audio.device
     if float(getattr(cfg, "mask_feature_prob", 0.0)) > 0.0 and getattr(cfg, "apply_spec_augment", True):
         raise NotImplementedError("wav2vec2 HIP training path: mask_feature_prob > 0 is not supported")
+    unfrozen = [n for n, p in enc.feature_extractor.named_parameters() if p.requires_grad]
+    if unfrozen:
+        # the reference freezes the conv feature extractor in __init__ (compatibility.py:27-28) and never trains it; autograd WOULD train it
+        # if a user flipped requires_grad afterwards -- this path has no backward for those convolutions, so say so instead of silently
+        # returning no gradient
+        raise NotImplementedError("wav2vec2 HIP training path: the conv feature extractor is frozen (freeze_feature_encoder); "
+                                  f"{len(unfrozen)} of its parameters have requires_grad=True (first: feature_extractor.{unfrozen[0]})")
     plan = adapt._plan_frozen(dev)
     with torch.no_grad():                                   # frozen conv feature extractor (compatibility.py:27-28): the inference kernels
         feats = plan.feature_extractor(audio)

@@ -125,14 +125,15 @@ class BaseCTCModule(_Base):
             resolved[name] = self.trainer.estimated_stepping_batches
         return resolved
 
-    # the reference's method name, kept for subclasses that override or call it
-    _update_special_optimizer_arg = _resolve_builder_kwargs
+    def _update_special_optimizer_arg(self, kwargs: Dict) -> Dict:
+        """The reference's hook name (module.py:165-171) and the one `configure_optimizers` calls: a subclass that overrides it is honoured."""
+        return self._resolve_builder_kwargs(kwargs)
 
     def configure_optimizers(self) -> Union[torch.optim.Optimizer, Dict[str, Any]]:
         """Lightning contract (module.py:173-189): the optimizer over the trainable parameters, alone or with its scheduler entry."""
         trainable = [p for p in self.parameters() if p.requires_grad]
-        optimizer = self.optimizer_class(trainable, **self._resolve_builder_kwargs(self.optimizer_kwargs))
+        optimizer = self.optimizer_class(trainable, **self._update_special_optimizer_arg(self.optimizer_kwargs))
         if self.lr_scheduler_class is None:
             return optimizer
-        scheduler = self.lr_scheduler_class(optimizer, **self._resolve_builder_kwargs(self.lr_scheduler_kwargs))
+        scheduler = self.lr_scheduler_class(optimizer, **self._update_special_optimizer_arg(self.lr_scheduler_kwargs))
         return dict(optimizer=optimizer, lr_scheduler=dict(scheduler=scheduler, interval=self.lr_scheduler_interval))

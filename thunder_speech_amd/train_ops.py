@@ -152,28 +152,26 @@ def _g(dy: Tensor, like: Tensor) -> Tensor:
 _GRAD_VIEWS = {}
 
 
-_LAST_GRAD_OUT_IS_VIEW = False
-
-
-def grad_out(param, shape, zeroed: bool = False) -> Tensor:
-    """f32 tensor of `shape` for the gradient of `param`: its registered flat-buffer view when it has one and `.grad` is unset
-    (first -- and in the fine-tuning loop only -- contribution of the step), else a fresh tensor.  `zeroed`: the kernel about to
-    receive it ACCUMULATES, so the tensor must hold zeros -- free for a bucket view (GradientSync.zero_grad cleared the whole
+def grad_out_ex(param, shape, zeroed: bool = False):
+    """(tensor, is_bucket_view): f32 tensor of `shape` for the gradient of `param` -- its registered flat-buffer view when it has one and
+    `.grad` is unset (first -- and in the fine-tuning loop only -- contribution of the step), else a fresh tensor.  `zeroed`: the kernel
+    about to receive it ACCUMULATES, so the tensor must hold zeros -- free for a bucket view (GradientSync.zero_grad cleared the whole
     buffer with one memset), one fill launch otherwise."""
-    global _LAST_GRAD_OUT_IS_VIEW
-    _LAST_GRAD_OUT_IS_VIEW = False
     ent = _GRAD_VIEWS.get(id(param)) if param is not None else None
     if ent is not None and param.grad is None and ent[1].claim(param):
-        _LAST_GRAD_OUT_IS_VIEW = True
         # (claim: a parameter that contributes twice in one backward -- tied weights, a module called twice -- gets the bucket view for
         # its first contribution only; the second one takes a fresh tensor and autograd adds the two)
         view, owner = ent
         out = view.view(shape)
         if zeroed and not owner.is_clean():
             out.zero_()
-        return out
+        return out, True
     dev = ent[0].device if ent is not None else param.device
-    return (torch.zeros if zeroed else torch.empty)(shape, dtype=torch.float32, device=dev)
+    return (torch.zeros if zeroed else torch.empty)(shape, dtype=torch.float32, device=dev), False
+
+
+def grad_out(param, shape, zeroed: bool = False) -> Tensor:
+    return grad_out_ex(param, shape, zeroed)[0]
 
 
 # bf16 operand copies of the weights (mixed precision).  One per parameter, reused while the parameter's version counter stands;
@@ -332,6 +330,7 @@ def _tcs_pointwise(x: Tensor, frags: Tensor, y: Tensor, lens: Tensor, n_out: int
 # products of up to 32 layers per launch (ts_train_pwconv_wgrad_multi), then ONE summation launch per 64 layers (ts_train_wgrad_reduce_multi).
 # Nothing reads a weight gradient before the optimizer, and every launch saved is ~5 us of latency, ramp and drain at this size.
 _WGRAD_PENDING = None
+MAX_PENDING_WGRAD = 32      # = the layers one grouped launch takes (ts_train_pwconv_wgrad_multi): flushing there costs no extra product launch
 GROUP_WGRAD = True          # False: inside deferred_wgrad() every layer still launches its own product at once and only the summation waits (A/B)
 
 
@@ -393,6 +392,8 @@ def _wgrad(dv: Tensor, u: Tensor, dw: Tensor, len_u: Tensor = None, defer: bool 
         n_parts = L.ts_train_pwconv_wgrad_multi_parts(b, c_in, c_out)               # the grouped launch splits a layer over fewer clip groups
         ws = torch.empty(n_parts * c_out * c_in, dtype=torch.float32, device=dv.device)
         _WGRAD_PENDING.append((ws, dw, n_parts, dv, u, len_u))                      # operands stay alive until flush_wgrad()
+        if len(_WGRAD_PENDING) >= MAX_PENDING_WGRAD:                               # bounds the memory parked operands hold (2 tensors per layer)
+            flush_wgrad()
         return
     n_ws = L.ts_train_pwconv_wgrad_workspace(b, c_in, c_out)
     ws = torch.empty(n_ws, dtype=torch.float32, device=dv.device)
@@ -473,10 +474,10 @@ def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor, len_u: Tensor = No
             # frozen weight (the first phase of the reference's fine-tuning schedule freezes the convolutions but still backpropagates
             # through them to the BatchNorm parameters, callbacks.py): the data gradient is all that is needed
             return du, None
-        dw = grad_out(param, (c_out, c_in), zeroed=True)
+        dw, is_view = grad_out_ex(param, (c_out, c_in), zeroed=True)
         # only a bucket view may wait for the end of the piece: a fresh tensor (a second contribution to the same parameter) is added to
         # the first by autograd right away
-        _wgrad(dv, u, dw, len_u, defer=_LAST_GRAD_OUT_IS_VIEW)
+        _wgrad(dv, u, dw, len_u, defer=is_view)
         return du, dw
     if len_u is not None:
         raise RuntimeError("_pw_bwd: an unmasked input needs the kernels that mask inside")
@@ -723,19 +724,25 @@ class SubsampleMask(torch.autograd.Function):
 
 class SqueezeExciteTrain(torch.autograd.Function):
     """SqueezeExcite.forward with autograd (citrinet/blocks.py:70-83): y = x * sigmoid(W2 relu(W1 mean_t(x))), the mean over ALL
-    frames (quirk A3).  The passes over the activation are HIP launches (csrc/train_extra.hip); the [B, C] bottleneck is four
-    tiny f32 GEMMs."""
+    frames (quirk A3).  Every step is a HIP launch (csrc/train_extra.hip): the passes over the activation and the [B, C] bottleneck
+    with its backward (ts_train_se_gate_fwd / _bwd); torch only allocates."""
 
     @staticmethod
     def forward(ctx, x, w1, w2):
         x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
-        w1, w2 = w1.detach().to(torch.float32), w2.detach().to(torch.float32)
+        w1, w2 = w1.detach(), w2.detach()
+        if w1.dtype != torch.float32 or w2.dtype != torch.float32 or not (w1.is_contiguous() and w2.is_contiguous()):
+            raise TypeError("SqueezeExciteTrain: contiguous f32 weights only (the reference's nn.Linear parameters)")
         b, c, t = x.shape
+        r = w1.shape[0]
+        if tuple(w1.shape) != (r, c) or tuple(w2.shape) != (c, r):
+            raise ValueError(f"SqueezeExciteTrain: weights {tuple(w1.shape)}, {tuple(w2.shape)} do not fit {c} channels")
         L = _lib.lib()
         mean = torch.empty(b, c, dtype=torch.float32, device=x.device)
+        h = torch.empty(b, r, dtype=torch.float32, device=x.device)
+        g = torch.empty(b, c, dtype=torch.float32, device=x.device)
         _lib.check(L.ts_train_se_pool(x.data_ptr(), mean.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)), "ts_train_se_pool")
-        h = torch.relu(mean @ w1.t())
-        g = torch.sigmoid(h @ w2.t()).contiguous()
+        _lib.check(L.ts_train_se_gate_fwd(mean.data_ptr(), w1.data_ptr(), w2.data_ptr(), h.data_ptr(), g.data_ptr(), b, c, r, _s(x)), "ts_train_se_gate_fwd")
         y = alloc_like(x)
         _lib.check(L.ts_train_se_scale(x.data_ptr(), g.data_ptr(), None, y.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)), "ts_train_se_scale")
         ctx.save_for_backward(x, w1, w2, mean, h, g)
@@ -746,14 +753,14 @@ class SqueezeExciteTrain(torch.autograd.Function):
         x, w1, w2, mean, h, g = ctx.saved_tensors
         dy = _g(dy, x)
         b, c, t = x.shape
+        r = w1.shape[0]
         L = _lib.lib()
-        dg = torch.empty(b, c, dtype=torch.float32, device=x.device)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        dg, dz, dmean = torch.empty(b, c, **f32), torch.empty(b, c, **f32), torch.empty(b, c, **f32)
+        dh, dw1, dw2 = torch.empty(b, r, **f32), torch.empty(r, c, **f32), torch.empty(c, r, **f32)
         _lib.check(L.ts_train_se_rowdot(dy.data_ptr(), x.data_ptr(), dg.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)), "ts_train_se_rowdot")
-        dz = dg * g * (1.0 - g)
-        dw2 = dz.t() @ h
-        dh = (dz @ w2) * (h > 0).to(dz.dtype)
-        dw1 = dh.t() @ mean
-        dmean = (dh @ w1).contiguous()
+        _lib.check(L.ts_train_se_gate_bwd(dg.data_ptr(), g.data_ptr(), h.data_ptr(), mean.data_ptr(), w1.data_ptr(), w2.data_ptr(), dz.data_ptr(),
+                                          dh.data_ptr(), dmean.data_ptr(), dw1.data_ptr(), dw2.data_ptr(), b, c, r, _s(x)), "ts_train_se_gate_bwd")
         dx = alloc_like(x)
         _lib.check(L.ts_train_se_scale(dy.data_ptr(), g.data_ptr(), dmean.data_ptr(), dx.data_ptr(), b * c, t, _pitch(x), _code(x), _s(x)),
                    "ts_train_se_scale")
