@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / C5 measurements (extra.*)")
     ap.add_argument("--extra", default="c3,c4,c5,c5_finetune", help="which of c3,c4,c5,c5_finetune to measure at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly from Python instead of replaying a hipGraph")
+    ap.add_argument("--weights", choices=("random", "trained"), default="random",
+                    help="random: random-init weights of the architecture (the contract's default); trained: QuartzNet15x5 trained on this box first "
+                         "(tools/train_margin_model.py, ~1 min) -- timing is the same, `check` then compares transcripts that mean something")
+    ap.add_argument("--no-trained-check", action="store_true", help="skip `check_trained` (training on the box + transcript identity vs the fp32 oracle)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,10 +183,18 @@ def main():
     from thunder_speech_amd.module import greedy_decode
     from thunder_speech_amd.parallel import max_over_ranks
     from thunder_speech_amd.utils import tcs_algorithmic_bytes
-    module = build_model(device)
     B, S = args.batch, args.seconds
-    g = torch.Generator().manual_seed(1234 + rank)
-    wav = (0.1 * torch.randn(B, 16000 * S, generator=g)).to(device)
+    trained_info = None
+    if args.weights == "trained":
+        from tools import train_margin_model as tmm
+        t_tr = time.perf_counter()
+        module, hist = tmm.train(device, verbose=False)
+        trained_info = {"train_seconds": time.perf_counter() - t_tr, "ctc_loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1}
+        wav = tmm.tone_clips(B, S, 4242 + rank, "cpu")[0].to(device)     # the task's own clips: transcripts of noise would mean nothing
+    else:
+        module = build_model(device)
+        g = torch.Generator().manual_seed(1234 + rank)
+        wav = (0.1 * torch.randn(B, 16000 * S, generator=g)).to(device)
     lengths = torch.full((B,), 16000 * S, dtype=torch.int32, device=device)
 
     def step():
@@ -255,7 +267,7 @@ def main():
                                "(BASELINE.json configs[1]); step = mel front end + 78 fused TCS launches + decoder + "
                                "greedy decode (argmax + collapse), hipGraph replay" if not args.no_graph else
                                f"QuartzNet15x5 inference, batch {B}x{S} s per GPU (eager launches)",
-                   "batch_per_gpu": B, "clip_seconds": S, "random_init": True},
+                   "batch_per_gpu": B, "clip_seconds": S, "random_init": args.weights == "random", "weights": args.weights, "trained": trained_info},
         "roofline": {"bound": "hbm", "kernel": "ts::tcs_split_kernel / ts::tcs_kernel (all fused TCS launches of one step)",
                      "launches_per_step": n_launch,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -282,6 +294,24 @@ def main():
             result["check"]["all_logits_finite"] = bool(torch.isfinite(logits).all())
             one = cpu_baseline(module, clips=2, seconds=15, iters=1, threads=1)
             result["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
+            if not args.no_trained_check:
+                # the transcript clause of north_star at this configuration's size, on weights that transcribe: QuartzNet15x5 trained on this box
+                # by the repository's own graphed CTC step (tools/train_margin_model.py), then HIP bf16 inference vs the fp32 oracle on 16 of
+                # 64 x 15 s clips -- collapsed label sequences, strings and every frame's argmax
+                try:
+                    from tools import train_margin_model as tmm
+                    if args.weights == "trained":
+                        m_tr, info = module, dict(trained_info)
+                    else:
+                        t_tr = time.perf_counter()
+                        m_tr, hist = tmm.train(device, verbose=False)
+                        info = {"train_seconds": time.perf_counter() - t_tr, "ctc_loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1}
+                    result["check_trained"] = dict(tmm.evaluate(m_tr, device, batch=B, seconds=S, n_check=n_chk), train=info)
+                    del m_tr
+                except Exception as e:                    # noqa: BLE001 -- recorded; the headline line must still come out
+                    import traceback
+                    print(f"bench.py: check_trained failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+                    result["check_trained"] = {"error": f"{type(e).__name__}: {e}"}
     # C4 as the reference runs it (DDP, strong scaling: global batch 256 x 10 s over the ranks), on EVERY N: all ranks take part.
     # An extra must never take the headline line down with it: exceptions are recorded, and a watchdog on every rank covers what an
     # exception handler cannot -- a collective that never returns (e.g. because ONE rank failed): past the deadline rank 0 prints the

@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Trained QuartzNet15x5 weights made ON THE BOX, for the transcript-identity clause of the headline configuration.
+
+`north_star` asks for "greedy transcriptions identical" to the reference path.  The reference pins that with a pretrained checkpoint
+(tests/quartznet/test_module_qn.py:17-30: `load_pretrained` + `predict` on a LibriSpeech clip), which needs the network; random weights
+leave near-tie frames that legitimately flip under bf16 rounding (profiles/round4_margin_study.txt).  So the weights are TRAINED here, with
+this repository's own fine-tuning path (train_graph.GraphedTrainStep: hipGraph-replayed forward + CTC + backward, FusedAdamW), on a task
+a CTC model learns to confident margins within seconds of GPU time:
+
+  * every one of the 28 labels of the reference's English vocabulary is a tone of its own frequency (280 Hz - 6.7 kHz, at least two mel filters
+    apart); the audio is built per ENCODER FRAME (20 ms): a frame carries its label's tone or silence, plus a little white noise.  The task proper
+    ("bursts"): per 200 ms slot one 60-120 ms burst (85 %) -- 3-6 frames, each another tone than the one before -- or silence, >= 40 ms of
+    silence between bursts; the transcript is the label sequence (~ 19 labels per second).  Every label has exactly ONE frame of evidence: with
+    several frames per label CTC is indifferent to how many of them carry it, which left 5-15 of 12 016 frames at burst edges within rounding
+    distance of a label / blank tie (measured, profiles/round5_trained_transcripts.md).
+  * training batches (32 x 10 s, the C4 shape) are drawn fresh every step from a seeded generator: half burst clips, a quarter "dense" clips
+    (every frame its own label) and a quarter "onoff" clips (one label in every other frame) -- the latter two admit a single CTC alignment, so
+    their loss is a per-frame cross-entropy that gets the training off CTC's all-blank plateau and keeps every frame's decision anchored;
+    evaluation clips (64 x 15 s, the C2 shape) are burst clips from their own seed.
+
+`evaluate()` then runs the HIP bf16 inference path and the fp32 CPU oracle on the same weights and the same clips and compares all-frame argmax,
+collapsed label sequences and decoded strings (module.py:88-100 `predict`).  Used by tests/test_gpu_trained_transcripts.py and by bench.py's
+`check_trained`.  The oracle is imported inside evaluate() only (checker, not product).
+
+    python tools/train_margin_model.py --out gpurun_out/qn15x5_tones.pt
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# one tone per label: 140 Hz apart below 1.7 kHz (the 320-sample Hann window resolves ~100 Hz), 8.5 % apart above (>= 2 mel filters)
+TONE_HZ = (280.0, 420.0, 560.0, 700.0, 840.0, 980.0, 1120.0, 1260.0, 1400.0, 1540.0, 1680.0, 1823.0, 1978.0, 2146.0, 2328.0, 2526.0, 2741.0, 2974.0,
+           3227.0, 3501.0, 3798.0, 4121.0, 4472.0, 4852.0, 5264.0, 5712.0, 6197.0, 6724.0)
+FRAME = 320                      # samples per encoder frame (hop 160, stride-2 stem): frame j is centred on sample 320 j
+SLOT_FRAMES = 10                 # burst clips: one burst (or silence) per 200 ms slot
+BURST_FRAMES = (3, 6)            # burst length: 60-120 ms
+
+
+def encoder_frames(n_samples: int) -> int:
+    """Output frames of QuartzNet for n_samples of audio: mel frames n // 160 + 1 (transform.py:182-184), halved by the stride-2 stem (blocks.py:149-155)."""
+    mel = n_samples // 160 + 1
+    return (mel + 2 * 16 - 32 - 1) // 2 + 1
+
+
+def frame_labels(batch: int, frames: int, kind: str, g: torch.Generator) -> torch.Tensor:
+    """int64 [batch, frames]: the label sounding in each encoder frame, -1 = silence.
+      "bursts": the task proper -- per 10-frame slot one burst (85 %) of 3-6 frames (60-120 ms), each frame of the burst another label than the
+                frame before (a little chirp of 3-6 tones), starting 1 .. 9 - d frames into the slot (>= 2 silent frames between bursts);
+      "dense" : every frame its own label, never the label of the frame before -> the transcript has exactly `frames` labels;
+      "onoff" : one label per clip, sounding in the even frames only -> the transcript repeats it (frames + 1) / 2 times, and CTC must put a blank
+                between equal labels, i.e. on every silent frame;
+      "warm"  : first half of the batch dense, second half onoff;   "mix": half bursts, a quarter dense, a quarter onoff.
+    dense and onoff transcripts admit exactly ONE CTC alignment: on them the loss is a per-frame cross-entropy over labels and blank."""
+    n_lab = len(TONE_HZ)
+    if kind in ("warm", "mix"):
+        cuts = (0, batch // 2, batch) if kind == "warm" else (0, batch // 2, batch // 2 + batch // 4, batch)
+        kinds = ("dense", "onoff") if kind == "warm" else ("bursts", "dense", "onoff")
+        return torch.cat([frame_labels(b - a, frames, k, g) for a, b, k in zip(cuts[:-1], cuts[1:], kinds) if b > a], 0)
+    if kind == "dense":
+        step = torch.randint(1, n_lab, (batch, frames), generator=g)                 # label[j] = label[j - 1] + step (mod 28), step != 0
+        step[:, 0] = torch.randint(0, n_lab, (batch,), generator=g)
+        return torch.cumsum(step, 1) % n_lab
+    if kind == "onoff":
+        lab = torch.randint(0, n_lab, (batch, 1), generator=g).expand(batch, frames).clone()
+        lab[:, 1::2] = -1
+        return lab
+    if kind != "bursts":
+        raise ValueError(f"frame_labels: unknown kind {kind!r}")
+    slots = frames // SLOT_FRAMES
+    present = torch.rand(batch, slots, generator=g) < 0.85
+    d = torch.randint(BURST_FRAMES[0], BURST_FRAMES[1] + 1, (batch, slots), generator=g)
+    a = 1 + (torch.rand(batch, slots, generator=g) * (SLOT_FRAMES - 1 - d).float()).floor().long()
+    step = torch.randint(1, n_lab, (batch, slots, SLOT_FRAMES), generator=g)         # inside a burst every frame moves on to another label
+    step[:, :, 0] = torch.randint(0, n_lab, (batch, slots), generator=g)
+    lab = torch.cumsum(step, 2) % n_lab
+    j = torch.arange(SLOT_FRAMES)[None, None, :]
+    inside = (j >= a[..., None]) & (j < (a + d)[..., None]) & present[..., None]
+    out = torch.full((batch, frames), -1, dtype=torch.int64)
+    out[:, : slots * SLOT_FRAMES] = torch.where(inside, lab, torch.full_like(lab, -1)).reshape(batch, -1)
+    return out
+
+
+def transcript(row) -> str:
+    """CTC reading of a frame-label row: a label is emitted where it starts (equal labels in adjacent frames are one emission, silence separates)."""
+    from thunder_speech_amd.quartznet.compatibility import ENGLISH_LABELS
+    row = np.asarray(row)
+    starts = (row >= 0) & (row != np.concatenate([[-2], row[:-1]]))
+    return "".join(ENGLISH_LABELS[int(l)] for l in row[starts])
+
+
+def tone_clips(batch: int, seconds: float, seed: int, device="cpu", kind: str = "bursts", noise: float = 0.005):
+    """(wav f32 [batch, 16000 * seconds], lengths f32 [batch], texts): the synthetic task.  Frame labels and phases are drawn on the CPU generator
+    (the same clips on any device), the audio is synthesised on `device`: encoder frame j (the 320 samples centred on sample 320 j) carries the
+    tone of its label at full amplitude with 2 ms fades at its borders and a random phase, or silence; a little white noise on top.  Every frame
+    is thus either a tone or silence -- no frame's label hangs on where inside the frame a burst happens to begin."""
+    n = int(round(16000 * seconds))
+    frames = encoder_frames(n)
+    g = torch.Generator().manual_seed(seed)
+    labels = frame_labels(batch, frames, kind, g)
+    phase = torch.rand(batch, frames, generator=g) * (2 * math.pi)
+    noise_seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=g))
+    texts = [transcript(r) for r in labels.numpy()]
+    dev = torch.device(device)
+    pos = torch.arange(n, device=dev)
+    seg = ((pos + FRAME // 2) // FRAME).clamp_(max=frames - 1)                               # sample -> the encoder frame centred nearest to it
+    lab_d = labels.to(dev)
+    freq = torch.tensor(TONE_HZ, device=dev)[lab_d.clamp(min=0)][:, seg]
+    ph = phase.to(dev)[:, seg]
+    rel = (pos - FRAME * seg).float()
+    edge = (0.5 - 0.5 * torch.cos(math.pi * ((rel + 160).clamp(0, 32) / 32))) * (0.5 - 0.5 * torch.cos(math.pi * ((160 - rel).clamp(0, 32) / 32)))
+    wav = 0.3 * torch.sin((2 * math.pi / 16000.0) * freq * rel[None, :] + ph) * edge[None, :] * (lab_d >= 0)[:, seg]
+    ng = torch.Generator(device=dev).manual_seed(noise_seed) if dev.type == "cuda" else torch.Generator().manual_seed(noise_seed)
+    wav = wav + noise * torch.randn(batch, n, generator=ng, device=dev)
+    return wav, torch.full((batch,), float(n), device=dev), texts
+
+
+def build_module(device, seed: int = 0):
+    """QuartzNet15x5 at the starting point of the training: variance-preserving random 1x1 convolutions (utils.variance_preserving_init_), but the
+    depthwise filters start as a unit tap at the centre plus a little noise.  With K = 33 ... 87 random taps per layer the untrained stack is a
+    temporal scrambler (every layer smears +-0.3 ... 0.9 s) and neither CTC nor a per-frame loss finds the tones for hundreds of steps (measured:
+    tools/diag/train_ab.py, CPU autograd and the HIP path alike); with centred taps each frame's features reach the decoder from step 0 and the
+    filters are learnt from there."""
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.utils import _is_depthwise, variance_preserving_init_
+    m = build_synthetic_quartznet(repeat_blocks=3)
+    variance_preserving_init_(m.encoder, m.decoder, seed=seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        for name, p in m.encoder.named_parameters():
+            if name.endswith("conv.weight") and p.shape[1] == 1 and _is_depthwise(m.encoder, name):
+                k = p.shape[2]
+                p.copy_(0.1 / math.sqrt(k) * torch.randn(p.shape, generator=g))
+                p[:, 0, k // 2] += 1.0
+        for p in m.decoder.parameters():          # start from near-uniform posteriors
+            p.mul_(0.1)
+        for mod in m.encoder.modules():           # running statistics start from the textbook state; training re-estimates them
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.zero_()
+                mod.running_var.fill_(1.0)
+    return m.to(device)
+
+
+# (steps, clips, seconds, kind of batch): the single-alignment warm-up first, then mixed batches.  On whole sentences of random labels CTC sits on its
+# all-blank plateau for thousands of steps (measured on this model, profiles/round5_trained_transcripts.md: 3 000 steps at 32 x 10 s never left it);
+# on "dense" / "onoff" clips the loss is a per-frame cross-entropy, the network tells tones and silence apart within ~100 steps, and the burst clips
+# then bring their free alignment.  The single-alignment clips stay in every batch: they keep every frame's decision anchored.
+DEFAULT_SCHEDULE = ((100, 32, 10, "warm"), (1900, 32, 10, "mix"))
+DEFAULT_LR = 2e-3
+
+
+def greedy_label_error(module, device, seed: int = 99, batch: int = 8, seconds: int = 10):
+    """Greedy label error rate of the HIP inference path against the ground truth on a small held-out batch (progress indicator)."""
+    from oracle import metrics as omet
+    wav, lengths, texts = tone_clips(batch, seconds, seed, device)
+    was_training = module.training
+    module.eval()
+    with torch.no_grad():
+        hyp = module.predict(wav)
+    module.train(was_training)
+    return float(omet.char_error_rate(hyp, texts))
+
+
+def train(device, schedule=DEFAULT_SCHEDULE, seed: int = 0, lr: float = DEFAULT_LR, log_every: int = 100, act: str = "bf16", verbose: bool = True):
+    """Fine-tune QuartzNet15x5 (everything trainable, bf16 activations, forward + backward replayed from one hipGraph per batch shape) on the
+    tone task.  Returns (module in eval mode, history)."""
+    from thunder_speech_amd import train_ops
+    from thunder_speech_amd.optim import FusedAdamW
+    from thunder_speech_amd.parallel import GradientSync
+    from thunder_speech_amd.train_graph import GraphedTrainStep
+    m = build_module(device, seed).train()
+    train_ops.set_activation_dtype(act)
+    hist = []
+    t0 = time.perf_counter()
+    try:
+        trainable = [p for p in m.parameters() if p.requires_grad]
+        opt, sync = FusedAdamW(trainable, lr=lr, weight_decay=1e-3), GradientSync(trainable)
+        step = GraphedTrainStep(m, opt, sync, max_target_len=max(encoder_frames(int(round(16000 * sec))) for _, _, sec, _ in schedule))
+        total = sum(st[0] for st in schedule)
+        warm = max(1, total // 20)
+        i = 0
+        for n_steps, batch, seconds, kind in schedule:
+            for _ in range(n_steps):
+                # linear warm-up, constant, cosine decay to 5 % over the last 30 % (settles the margins)
+                tail = int(0.7 * total)
+                scale = (i + 1) / warm if i < warm else (1.0 if i < tail else 0.05 + 0.95 * 0.5 * (1 + math.cos(math.pi * (i - tail) / max(1, total - tail))))
+                for grp in opt.param_groups:
+                    grp["lr"] = lr * scale
+                wav, lengths, texts = tone_clips(batch, seconds, seed * 1_000_003 + 17 + i, device, kind=kind)
+                loss = step((wav, lengths, texts))
+                if i % log_every == 0 or i == total - 1:
+                    v = float(loss)
+                    hist.append((i, v))
+                    if verbose:
+                        ler = greedy_label_error(m, device)
+                        print(f"  step {i:5d}  {batch:3d} x {seconds:4.1f} s {kind:6s}  ctc loss {v:8.4f}  lr {lr * scale:.2e}  held-out label error {ler:.3f}  "
+                              f"({time.perf_counter() - t0:.1f} s)", flush=True)
+                    if not math.isfinite(v):
+                        raise RuntimeError(f"training diverged at step {i}")
+                i += 1
+        torch.cuda.synchronize()
+        sync.close()
+    finally:
+        train_ops.set_activation_dtype("fp32")
+    return m.eval(), hist
+
+
+def evaluate(module, device, batch: int = 64, seconds: int = 15, n_check: int = 16, seed: int = 4242, threads: int = 16):
+    """HIP bf16 inference vs the fp32 oracle on the same trained weights, same clips: all-frame argmax, collapsed sequences, strings, and the
+    ground-truth label error of both.  Flipped frames are listed with the oracle's fp32 margin and its own bf16-ordered deviation there."""
+    from oracle import decode as odec, frontend as ofe, tcs as otcs
+    from oracle.primitives import bf16_round
+    from thunder_speech_amd.module import greedy_decode
+    wav, lengths, texts = tone_clips(batch, seconds, seed, "cpu")
+    wav_d = wav.to(device)
+    module = module.eval()
+    with torch.no_grad():
+        logits, out_len = module(wav_d, lengths.to(device))
+        ids, collapsed, counts = greedy_decode(logits)
+        strings = module.predict(wav_d)
+        torch.cuda.synchronize()
+    got = logits[:n_check].float().cpu().numpy()
+    dev_ids = ids[:n_check].cpu().numpy()
+    dev_seqs = [collapsed[i, : int(counts[i])].cpu().tolist() for i in range(n_check)]
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
+    arch = otcs.quartznet_arch(repeat_blocks=3)
+    sd = {k: v.detach().cpu() for k, v in module.encoder.state_dict().items()}
+    dsd = {k: v.detach().cpu() for k, v in module.decoder.state_dict().items()}
+    with torch.no_grad():
+        feats, fl = ofe.filterbank_features(wav[:n_check], lengths[:n_check].cpu())
+        enc, _ = otcs.encoder_forward(arch, sd, feats, fl)
+        ref = otcs.conv1d_decoder_forward(dsd, enc).numpy()
+    ref_ids = ref.argmax(1)
+    ref_seqs = [list(odec.collapse_repeats(r)) for r in ref_ids]
+    blank = module.text_transform.vocab.blank_idx
+    ref_strings = module.text_transform.decode_prediction(torch.from_numpy(ref_ids))
+    scale = float(np.abs(ref).max())
+    err = got - ref
+    flips = np.argwhere(dev_ids != ref_ids)
+    top2 = np.sort(ref, axis=1)[:, -2:, :]
+    margin = top2[:, 1] - top2[:, 0]
+    flipped = []
+    if len(flips):
+        # the oracle's own bf16-ordered evaluation on the flipped clips: how far bf16 storage moves the fp32 logits there
+        clips = sorted({int(c) for c, _ in flips})
+        with torch.no_grad():
+            e16, _ = otcs.encoder_forward(arch, sd, bf16_round(feats[clips]), fl[clips], emulate_bf16=True)
+            emu = otcs.conv1d_decoder_forward(dsd, e16, emulate_bf16=True).numpy()
+        for c, t in flips[:64]:
+            j = clips.index(int(c))
+            flipped.append({"clip": int(c), "frame": int(t), "oracle_label": int(ref_ids[c, t]), "device_label": int(dev_ids[c, t]),
+                            "fp32_margin": float(margin[c, t]), "device_err_at_frame": float(np.abs(err[c, :, t]).max()),
+                            "oracle_bf16_emulation_err_at_frame": float(np.abs(emu[j, :, t] - ref[c, :, t]).max())})
+
+    def label_errors(seqs):
+        from oracle import metrics as omet
+        tt = module.text_transform
+        hyp = ["".join(tt.vocab.itos[i] for i in s if i != blank) for s in seqs]
+        return float(omet.char_error_rate(hyp, texts[:n_check]))
+
+    return {
+        "vs": f"fp32 oracle on the same TRAINED weights, first {n_check} clips of a {batch}x{seconds} s batch, all {got.shape[2]} frames",
+        "collapsed_sequences_equal": int(sum(a == b for a, b in zip(dev_seqs, ref_seqs))), "collapsed_sequences_compared": n_check,
+        "strings_equal": int(sum(a == b for a, b in zip(strings[:n_check], ref_strings))),
+        "argmax_equal_all_frames_frac": float((dev_ids == ref_ids).mean()), "frames_compared": int(ref_ids.size), "frames_flipped": int(len(flips)),
+        "flipped_frames": flipped, "min_fp32_margin": float(margin.min()), "median_fp32_margin": float(np.median(margin)),
+        "max_err_over_scale": float(np.abs(err).max()) / scale, "rms_err_over_scale": float(np.sqrt(np.mean(err.astype(np.float64) ** 2))) / scale,
+        "logit_scale": scale, "label_error_rate_vs_ground_truth": {"device": label_errors(dev_seqs), "oracle": label_errors(ref_seqs)},
+        "example": {"device": strings[0][:60], "oracle": ref_strings[0][:60], "truth": texts[0][:60]},
+        "lengths_equal": bool(torch.equal(out_len[:n_check].cpu().long(), torch.full((n_check,), got.shape[2], dtype=torch.long))),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--schedule", default=None, help="steps:clips:seconds[:kind][,...] with kind in bursts|dense|onoff|warm|mix; default: 100 warm steps, then 1900 mix steps, at 32 x 10 s")
+    ap.add_argument("--lr", type=float, default=DEFAULT_LR)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--act", default="bf16")
+    ap.add_argument("--out", default=None, help="save the trained state dict here (torch.save)")
+    ap.add_argument("--n-check", type=int, default=16)
+    ap.add_argument("--log-every", type=int, default=100)
+    ap.add_argument("--no-eval", action="store_true", help="training log only (diagnostics)")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        print("train_margin_model: needs an MI355X (the repository's training path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    device = torch.device("cuda", 0)
+    schedule = DEFAULT_SCHEDULE if not args.schedule else tuple((int(q[0]), int(q[1]), float(q[2]), q[3] if len(q) > 3 else "bursts") for q in (part.split(":") for part in args.schedule.split(",")))
+    t0 = time.perf_counter()
+    module, hist = train(device, schedule=schedule, lr=args.lr, seed=args.seed, act=args.act, log_every=args.log_every)
+    t_train = time.perf_counter() - t0
+    if args.no_eval:
+        return
+    res = evaluate(module, device, n_check=args.n_check)
+    res["train"] = {"schedule": [list(x) for x in schedule], "seconds": t_train, "loss_first_last": [hist[0][1], hist[-1][1]], "lr": args.lr, "seed": args.seed,
+                    "act": args.act}
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        torch.save({"encoder": module.encoder.state_dict(), "decoder": module.decoder.state_dict()}, args.out)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
