@@ -374,6 +374,19 @@ int ts_train_bn2_add_relu_fwd(const void* va, const void* sums_a, const float* g
                               const void* vb, const void* sums_b, const float* gamma_b, const float* beta_b, float eps_b, float* mean_rstd_b,
                               float* running_mean_b, float* running_var_b, float momentum_b, int64_t* num_batches_tracked_b,
                               void* out, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
+/* The block tail in ONE launch each way (ABI v9): a workgroup owns a channel and keeps its batch x ceil(t / 512) row units of both branches in
+ * registers between the statistics and the apply step -- no clip-group sums, no second pass.  Forward = ts_train_bn_stats x 2 +
+ * ts_train_bn2_add_relu_fwd (quartznet/blocks.py:332-337 in train mode: batch statistics over all B * T frames, running-statistics update);
+ * backward = ts_train_bn_bwd(relu = 1) of both branches with the shared gate taken from `out` (dgamma / dbeta are overwritten).
+ * TS_EUNSUPPORTED when batch * ceil(t / 512) exceeds 32 (bf16 rows) / 16 (f32 rows): use the two-step entry points then. */
+int ts_train_bn2_add_relu_chan_fwd(const void* va, const float* gamma_a, const float* beta_a, float eps_a, float* mean_rstd_a,
+                                   float* running_mean_a, float* running_var_a, float momentum_a, int64_t* nbt_a, const void* vb,
+                                   const float* gamma_b, const float* beta_b, float eps_b, float* mean_rstd_b, float* running_mean_b,
+                                   float* running_var_b, float momentum_b, int64_t* nbt_b, void* out, int32_t batch, int32_t channels, int32_t t,
+                                   int32_t pitch, int32_t act, void* stream);
+int ts_train_bn2_chan_bwd(const void* dout, const void* out, const void* va, const void* vb, const float* gamma_a, const float* mean_rstd_a,
+                          const float* gamma_b, const float* mean_rstd_b, void* dva, void* dvb, float* dgamma_a, float* dbeta_a, float* dgamma_b,
+                          float* dbeta_b, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_bn_bwd_sums(const void* g, const void* v, const float* gamma, const float* mean_rstd, const float* dgamma, const float* dbeta,
                          void* dv, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_mask_time(const void* x, const int32_t* len, void* y, int32_t batch, int32_t channels, int32_t t, int32_t pitch_x,
@@ -450,7 +463,8 @@ int ts_train_subsample_mask(const void* x, const int32_t* len, void* y, int32_t 
  * w1 f32 [hidden][C], w2 f32 [C][hidden]) and its autograd backward (ABI v9; these replace `mean @ w1.t()`, `h @ w2.t()` and the four
  * products of their backward):
  *   ts_train_se_gate_fwd  hid[b][j] = relu(sum_i w1[j][i] mean[b][i]) (stored when hid != NULL), gate[b][c] = sigmoid(sum_j w2[c][j] hid[b][j]);
- *                         one launch, a workgroup per clip (ts_se_gate_fwd uses the same kernel behind its pooling pass)
+ *                         one launch, a workgroup per clip (inference keeps ts_se_gate_fwd's two wide launches: at 32 clips x 1024 channels the
+ *                         per-clip form is latency-bound, 31.7 us against 12.0)
  *   ts_train_se_gate_bwd  dz = dgate * gate * (1 - gate); dhid = (hid > 0) * (dz . w2); dmean = dhid . w1; dw2 = dz^T . hid; dw1 = dhid^T . mean
  *                         (dz_ws f32 [B][C], dhid_ws f32 [B][hidden]: workspaces; dw1 / dw2 are overwritten, not accumulated)
  * TS_EUNSUPPORTED when C + hidden floats exceed the kernels' LDS budget (15 k). */

@@ -14,7 +14,7 @@ def _ptr(t):
 @pytest.mark.parametrize("b,c,r", [(32, 1024, 128), (3, 24, 3), (5, 200, 25), (1, 64, 8), (7, 1536, 192)])
 def test_squeeze_excite_bottleneck_forward_and_backward_match_float64_autograd(b, c, r):
     """ts_train_se_gate_fwd / _bwd (citrinet/blocks.py:72-83: Linear -> ReLU -> Linear -> sigmoid, both bias-free) vs torch float64 autograd;
-    ts_se_gate_fwd's inference path runs the same forward kernel."""
+    the inference entry ts_se_gate_fwd keeps its own two launches (faster at 32 x 1024)."""
     from thunder_speech_amd import _lib
     L = _lib.lib()
     gen = torch.Generator().manual_seed(b * 1000 + c)
@@ -72,3 +72,72 @@ def test_squeeze_excite_train_node_uses_no_aten_matmul():
     for got, want in ((xd.grad, x64.grad), (w1d.grad, a64.grad), (w2d.grad, b64.grad)):
         s = max(float(want.abs().max()), 1e-6)
         assert float((got.cpu().double() - want).abs().max()) <= 1e-4 * s
+
+
+@pytest.mark.parametrize("act,b,c,t", [("bf16", 32, 40, 501), ("bf16", 5, 24, 37), ("bf16", 8, 16, 1300), ("fp32", 16, 24, 501), ("fp32", 3, 8, 700)])
+def test_block_tail_in_one_launch_each_way_matches_float64_autograd(act, b, c, t):
+    """ts_train_bn2_add_relu_chan_fwd / ts_train_bn2_chan_bwd (a workgroup per channel, rows in registers): out = relu(BN(va) + BN(vb)) with batch
+    statistics over all B * T frames (quartznet/blocks.py:332-337 in train mode), running-statistics update, and both BatchNorm backwards -- against
+    float64 autograd; NaN in the row padding must not leak."""
+    from thunder_speech_amd import _lib, train_ops as T
+    L = _lib.lib()
+    dt = torch.bfloat16 if act == "bf16" else torch.float32
+    gen = torch.Generator().manual_seed(b * 100 + c)
+    mk = lambda scale, shift: (scale * torch.randn(b, c, t, generator=gen) + shift).to(dt).float()
+    va, vb, dout = mk(2.0, 0.5), mk(0.7, -1.0), mk(1.0, 0.0)
+    ga, ba, gb, bb = (torch.randn(c, generator=gen) for _ in range(4))
+    eps = 1e-3
+    ref_in = [x.double().requires_grad_(True) for x in (va, vb, ga, ba, gb, bb)]
+
+    def bn(v, g, be):
+        mu = v.mean(dim=(0, 2), keepdim=True)
+        var = v.var(dim=(0, 2), unbiased=False, keepdim=True)
+        return (v - mu) / torch.sqrt(var + eps) * g[None, :, None] + be[None, :, None], mu.flatten(), var.flatten()
+
+    ya, mua, vara = bn(ref_in[0], ref_in[2], ref_in[3])
+    yb, mub, varb = bn(ref_in[1], ref_in[4], ref_in[5])
+    out64 = torch.relu(ya + yb)
+    (out64 * dout.double()).sum().backward()
+
+    def rows(x):
+        r = T.alloc(b, c, t, DEV, dt)
+        base = r.as_strided((b, c, r.stride(1)), r.stride())
+        base.fill_(float("nan"))
+        r.copy_(x.to(DEV))
+        return r
+
+    va_d, vb_d, dout_d = rows(va), rows(vb), rows(dout)
+    out_d = T.alloc(b, c, t, DEV, dt)
+    f = lambda x: x.to(DEV).float().contiguous()
+    ga_d, ba_d, gb_d, bb_d = f(ga), f(ba), f(gb), f(bb)
+    mra, mrb = torch.empty(c, 2, device=DEV), torch.empty(c, 2, device=DEV)
+    rma, rva, rmb, rvb = torch.zeros(c, device=DEV), torch.ones(c, device=DEV), torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    code, pitch = int(dt == torch.bfloat16), va_d.stride(1)
+    rc = L.ts_train_bn2_add_relu_chan_fwd(_ptr(va_d), _ptr(ga_d), _ptr(ba_d), eps, _ptr(mra), _ptr(rma), _ptr(rva), 0.1, _ptr(nbt),
+                                          _ptr(vb_d), _ptr(gb_d), _ptr(bb_d), eps, _ptr(mrb), _ptr(rmb), _ptr(rvb), 0.1, None, _ptr(out_d), b, c, t, pitch, code, st)
+    units = b * ((t + 511) // 512)
+    if units > (32 if act == "bf16" else 16):
+        assert rc == _lib.TS_EUNSUPPORTED
+        return
+    _lib.check(rc, "fwd")
+    tol = 2e-2 if act == "bf16" else 2e-5
+    scale = float(out64.abs().max())
+    assert float((out_d.float().cpu().double() - out64.detach()).abs().max()) <= tol * scale
+    n = b * t
+    np.testing.assert_allclose(mra[:, 0].cpu().numpy(), mua.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(mrb[:, 1].cpu().numpy(), (1.0 / torch.sqrt(varb + eps)).detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(rva.cpu().numpy(), (0.9 + 0.1 * vara * n / (n - 1)).detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(rmb.cpu().numpy(), (0.1 * mub).detach().numpy(), atol=1e-6)
+    assert int(nbt) == 1
+    # backward with the gate of the DEVICE output (the two paths may disagree on out > 0 where the sum is a rounding error away from 0)
+    dva, dvb = T.alloc(b, c, t, DEV, dt), T.alloc(b, c, t, DEV, dt)
+    dga, dba, dgb, dbb = (torch.full((c,), float("nan"), device=DEV) for _ in range(4))
+    out_ref = rows(out64.detach().float().to(dt).float())
+    _lib.check(L.ts_train_bn2_chan_bwd(_ptr(dout_d), _ptr(out_ref), _ptr(va_d), _ptr(vb_d), _ptr(ga_d), _ptr(mra), _ptr(gb_d), _ptr(mrb), _ptr(dva), _ptr(dvb),
+                                       _ptr(dga), _ptr(dba), _ptr(dgb), _ptr(dbb), b, c, t, pitch, code, st), "bwd")
+    for got, want in ((dva, ref_in[0].grad), (dvb, ref_in[1].grad), (dga, ref_in[2].grad), (dba, ref_in[3].grad), (dgb, ref_in[4].grad), (dbb, ref_in[5].grad)):
+        s_ = max(float(want.abs().max()), 1e-6)
+        assert torch.isfinite(got.float()).all()
+        assert float((got.float().cpu().double() - want).abs().max()) <= (2e-2 if act == "bf16" else 1e-4) * s_

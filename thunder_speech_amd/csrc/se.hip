@@ -33,6 +33,24 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const unsigned short* __re
   if (lane == 0) pool[row] = (s + (float)(t - l) * tail_y[c]) / (float)t;
 }
 
+// out[b, j] = act( sum_i w[j, i] * in[b, i] ): one wave per output, lanes over the contraction (coalesced weight rows);
+// ACT 0: ReLU (first linear), 1: sigmoid (second linear).  Grid: (ceil(n_out / 4), batch).
+template <int ACT>
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                     float* __restrict__ out, int n_in, int n_out) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (j >= n_out) return;
+  const float* x = in + (size_t)b * n_in;
+  const float* wr = w + (size_t)j * n_in;
+  float s = 0.f;
+  for (int i = lane; i < n_in; i += 64) s += wr[i] * x[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[(size_t)b * n_out + j] = ACT == 0 ? (s > 0.f ? s : 0.f) : 1.f / (1.f + __expf(-s));
+}
+
 // one thread per 8 frames (16 B)
 __global__ __launch_bounds__(256) void se_apply_kernel(const unsigned short* __restrict__ y, const unsigned short* __restrict__ r,
                                                         const float* __restrict__ gate, const int* __restrict__ len,
@@ -102,10 +120,12 @@ extern "C" int ts_se_gate_fwd(const void* y, const int32_t* len, const float* ta
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::se_pool_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, static_cast<const unsigned short*>(y), len,
                      tail_y, pool_ws, rows, channels, t, pitch);
-  const int st = ts::hip_status(hipGetLastError());
-  if (st != TS_OK) return st;
-  // both bias-free linears, ReLU and sigmoid in ONE launch (a workgroup per clip; csrc/train_extra.hip): the hidden vector stays in LDS
-  return ts_train_se_gate_fwd(pool_ws, w1, w2, nullptr, gate, batch, channels, hidden, stream_);
+  // two launches, (outputs / 4) x batch workgroups each: the one-launch form (a workgroup per clip, ts_train_se_gate_fwd) has 32 workgroups pull
+  // 1 MB of weights each through one CU's memory port -- 31.7 us against 12.0 us for this pair at 1024 / 128 channels (profiles/round5_c3_se.txt)
+  float* const hid = pool_ws + (size_t)batch * channels;           // workspace: [B][C] means, then [B][hidden]
+  hipLaunchKernelGGL(ts::se_fc_kernel<0>, dim3((hidden + 3) / 4, batch), dim3(256), 0, stream, pool_ws, w1, hid, channels, hidden);
+  hipLaunchKernelGGL(ts::se_fc_kernel<1>, dim3((channels + 3) / 4, batch), dim3(256), 0, stream, hid, w2, gate, hidden, channels);
+  return ts::hip_status(hipGetLastError());
 }
 
 extern "C" int ts_se_apply_fwd(const void* y, const void* r, const float* gate, const int32_t* len, const float* tail_y,

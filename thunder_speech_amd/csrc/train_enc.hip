@@ -1276,6 +1276,224 @@ __global__ __launch_bounds__(256) void bn2_add_relu_kernel(BnSide a, BnSide b, T
   store8(out + (size_t)row * pitch + i, x);
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Block tail in ONE launch each way (round 5): a workgroup owns a CHANNEL -- its batch x ceil(t / 512) row units of both branches live in
+// registers between the statistics and the apply step, so every tensor is read once and written once and no second launch has to wait for the
+// channel sums.  Replaces, per block, chan_sums<0> x 2 + bn2_add_relu (forward: 23 us -> one launch) and (chan_sums<1> + bn_bwd_apply) x 2
+// (backward: 38 us -> one launch) at 32 x 501 frames.  A wave holds up to CU_MAX units; larger batches keep the two-step kernels.
+// The variance is formed around the mean (two passes over the registers), not as E[x^2] - mean^2: f32 is then enough per lane, the sums across
+// lanes and waves run in f64 like the clip-group partials they replace.
+// ----------------------------------------------------------------------------------------------------------------------
+// rows stay in registers in their STORAGE form (bf16 rows: 4 VGPRs per 8 frames) and are widened where they are used
+template <class T> struct ChanRegs;
+template <> struct ChanRegs<bf16_t> {
+  static constexpr int UMAX = 8;
+  typedef u32x4 raw;
+  static __device__ __forceinline__ raw load(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+  static __device__ __forceinline__ void widen(const raw& r, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_lo(r[j]); v[2 * j + 1] = bf16_hi(r[j]); }
+  }
+  static __device__ __forceinline__ raw narrow(const float (&v)[8]) {        // exact for values that are bf16 already
+    return u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  }
+  // the compiler would rather keep the widened floats alive across the reduction than convert twice (256 VGPRs, one wave per SIMD): an opaque
+  // touch of the storage registers makes the second widening a new computation
+  static __device__ __forceinline__ void pin(raw& r) { asm volatile("" : "+v"(r)); }
+};
+template <> struct ChanRegs<float> {
+  static constexpr int UMAX = 4;
+  struct raw { f32x4 lo, hi; };
+  static __device__ __forceinline__ raw load(const float* p) { return raw{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)}; }
+  static __device__ __forceinline__ void widen(const raw& r, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = r.lo[j]; v[4 + j] = r.hi[j]; }
+  }
+  static __device__ __forceinline__ raw narrow(const float (&v)[8]) { return raw{f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}}; }
+  static __device__ __forceinline__ void pin(raw&) {}
+};
+
+__device__ __forceinline__ double chan_reduce(double v, double* red) {      // all 256 threads -> the sum, in every thread
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();                                                          // `red` may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+struct Bn2FwdArgs {
+  BnSide a, b;
+  void* out;
+  int batch, ch, t, pitch;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void bn2_fwd_chan_kernel(const Bn2FwdArgs g) {
+  typedef ChanRegs<T> R;
+  constexpr int UMAX = R::UMAX;
+  __shared__ double red[4];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cpr = (g.t + ROW_CHUNK - 1) / ROW_CHUNK, units = g.batch * cpr;
+  const T* const va = static_cast<const T*>(g.a.v);
+  const T* const vb = static_cast<const T*>(g.b.v);
+  typename R::raw xa[UMAX], xb[UMAX];
+  int off[UMAX], nval[UMAX];                       // element offsets fit 31 bits (checked by the launcher)
+#pragma unroll
+  for (int u = 0; u < UMAX; ++u) {
+    const int unit = wave + 4 * u;
+    const int b = unit / cpr, i = (unit % cpr) * ROW_CHUNK + lane * 8;
+    nval[u] = unit < units ? (g.t - i < 0 ? 0 : (g.t - i > 8 ? 8 : g.t - i)) : 0;
+    off[u] = nval[u] > 0 ? (b * g.ch + c) * g.pitch + i : 0;
+    xa[u] = R::load(va + off[u]);                  // idle lanes re-read element 0: in bounds, never used
+    xb[u] = R::load(vb + off[u]);
+  }
+  const double n = (double)g.batch * g.t;
+  float scs[2], hs[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const BnSide& sd = e == 0 ? g.a : g.b;
+    float p = 0.f;
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      float x[8];
+      R::widen(e == 0 ? xa[u] : xb[u], x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p += j < nval[u] ? x[j] : 0.f;
+    }
+    const double mu = chan_reduce((double)p, red) / n;
+    const float mf = (float)mu;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      float x[8];
+      R::pin(e == 0 ? xa[u] : xb[u]);
+      R::widen(e == 0 ? xa[u] : xb[u], x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = x[j] - mf;
+        q = j < nval[u] ? fmaf(d, d, q) : q;
+      }
+    }
+    double var = chan_reduce((double)q, red) / n;
+    var -= (mu - (double)mf) * (mu - (double)mf);              // the deviations were taken from the f32-rounded mean
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)sd.eps));
+    scs[e] = sd.gamma[c] * rstd; hs[e] = sd.beta[c] - mf * scs[e];
+    if (threadIdx.x == 0) {
+      sd.mean_rstd[2 * c] = mf; sd.mean_rstd[2 * c + 1] = rstd;
+      if (sd.running_mean) {
+        sd.running_mean[c] = (1.f - sd.momentum) * sd.running_mean[c] + sd.momentum * mf;
+        sd.running_var[c] = (1.f - sd.momentum) * sd.running_var[c] + sd.momentum * (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+        if (c == 0 && sd.nbt) *sd.nbt += 1;
+      }
+    }
+  }
+  const float sa = scs[0], sb = scs[1], ha = hs[0] + hs[1];
+  T* const out = static_cast<T*>(g.out);
+#pragma unroll
+  for (int u = 0; u < UMAX; ++u) {
+    if (nval[u] > 0) {
+      float x[8], z[8], o[8];
+      R::pin(xa[u]);
+      R::pin(xb[u]);
+      R::widen(xa[u], x);
+      R::widen(xb[u], z);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float r = fmaf(x[j], sa, fmaf(z[j], sb, ha));
+        o[j] = r > 0.f ? r : 0.f;
+      }
+      store8(out + off[u], o);
+    }
+  }
+}
+
+struct Bn2BwdArgs {
+  const void* dout; const void* out; const void* va; const void* vb;
+  const float* gamma_a; const float* mr_a; const float* gamma_b; const float* mr_b;
+  void* dva; void* dvb;
+  float* dgamma_a; float* dbeta_a; float* dgamma_b; float* dbeta_b;
+  int batch, ch, t, pitch;
+};
+
+// out = relu(BN_a(va) + BN_b(vb)):  g = dout * (out > 0);  dv_e = gamma_e rstd_e (g - mean(g) - xhat_e mean(g xhat_e)),  dbeta_e = sum g, dgamma_e = sum g xhat_e
+template <class T>
+__global__ __launch_bounds__(256) void bn2_bwd_chan_kernel(const Bn2BwdArgs g) {
+  typedef ChanRegs<T> R;
+  constexpr int UMAX = R::UMAX;
+  __shared__ double red[4];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cpr = (g.t + ROW_CHUNK - 1) / ROW_CHUNK, units = g.batch * cpr;
+  const float mua = g.mr_a[2 * c], rsa = g.mr_a[2 * c + 1], mub = g.mr_b[2 * c], rsb = g.mr_b[2 * c + 1];
+  typename R::raw gg[UMAX], xa[UMAX], xb[UMAX];    // the gated gradient and both un-normalised inputs, in storage form
+  int off[UMAX], nval[UMAX];
+  float p0 = 0.f, pa = 0.f, pb = 0.f;
+  // loads in batches of UB units (left alone the scheduler hoists all 4 UMAX row loads to the top: 256 VGPRs, one wave per SIMD)
+  constexpr int UB = UMAX < 4 ? UMAX : 4;
+#pragma unroll
+  for (int u0 = 0; u0 < UMAX; u0 += UB) {
+    typename R::raw dr[UB], orr[UB];
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+      const int u = u0 + k, unit = wave + 4 * u;
+      const int b = unit / cpr, i = (unit % cpr) * ROW_CHUNK + lane * 8;
+      nval[u] = unit < units ? (g.t - i < 0 ? 0 : (g.t - i > 8 ? 8 : g.t - i)) : 0;
+      off[u] = nval[u] > 0 ? (b * g.ch + c) * g.pitch + i : 0;
+      xa[u] = R::load(static_cast<const T*>(g.va) + off[u]);
+      xb[u] = R::load(static_cast<const T*>(g.vb) + off[u]);
+      dr[k] = R::load(static_cast<const T*>(g.dout) + off[u]);
+      orr[k] = R::load(static_cast<const T*>(g.out) + off[u]);
+    }
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {
+      const int u = u0 + k;
+      float d[8], o[8], x[8], z[8];
+      R::widen(dr[k], d);
+      R::widen(orr[k], o);
+      R::widen(xa[u], x);
+      R::widen(xb[u], z);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = j < nval[u];                       // columns >= t are scratch: they may hold anything, NaN included
+        d[j] = (in && o[j] > 0.f) ? d[j] : 0.f;
+        p0 += d[j];
+        pa = fmaf(d[j], in ? (x[j] - mua) * rsa : 0.f, pa);
+        pb = fmaf(d[j], in ? (z[j] - mub) * rsb : 0.f, pb);
+      }
+      gg[u] = R::narrow(d);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const double n = (double)g.batch * g.t;
+  const double s0 = chan_reduce((double)p0, red), sa = chan_reduce((double)pa, red), sb = chan_reduce((double)pb, red);
+  if (threadIdx.x == 0) {
+    g.dbeta_a[c] = (float)s0; g.dgamma_a[c] = (float)sa;
+    g.dbeta_b[c] = (float)s0; g.dgamma_b[c] = (float)sb;
+  }
+  const float mg = (float)(s0 / n), mga = (float)(sa / n), mgb = (float)(sb / n);
+  const float ka = g.gamma_a[c] * rsa, kb = g.gamma_b[c] * rsb;
+#pragma unroll
+  for (int u = 0; u < UMAX; ++u) {
+    if (nval[u] > 0) {
+      float d[8], x[8], z[8], da[8], db[8];
+      R::pin(gg[u]);
+      R::pin(xa[u]);
+      R::pin(xb[u]);
+      R::widen(gg[u], d);
+      R::widen(xa[u], x);
+      R::widen(xb[u], z);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        da[j] = ka * (d[j] - mg - (x[j] - mua) * rsa * mga);
+        db[j] = kb * (d[j] - mg - (z[j] - mub) * rsb * mgb);
+      }
+      store8(static_cast<T*>(g.dva) + off[u], da);
+      store8(static_cast<T*>(g.dvb) + off[u], db);
+    }
+  }
+}
+
 // dv = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (y > 0) when relu,  xhat = (v - mean) * rstd
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ v,
@@ -1658,6 +1876,45 @@ extern "C" int ts_train_bn2_add_relu_fwd(const void* va, const void* sums_a, con
   TS_ACT(act,
          hipLaunchKernelGGL(bn2_add_relu_kernel<float>, rg, dim3(256), 0, stream, a, b, (float*)out, batch, ch, t, pitch),
          hipLaunchKernelGGL(bn2_add_relu_kernel<bf16_t>, rg, dim3(256), 0, stream, a, b, (bf16_t*)out, batch, ch, t, pitch));
+  return hip_status(hipGetLastError());
+}
+
+/* Block tail forward without separate statistics passes (one workgroup per channel, rows in registers); TS_EUNSUPPORTED when the batch does not
+ * fit the register budget (callers then run ts_train_bn_stats x 2 + ts_train_bn2_add_relu_fwd).  See include/thunder_speech_amd.h */
+extern "C" int ts_train_bn2_add_relu_chan_fwd(const void* va, const float* gamma_a, const float* beta_a, float eps_a, float* mean_rstd_a,
+                                              float* running_mean_a, float* running_var_a, float momentum_a, int64_t* nbt_a, const void* vb,
+                                              const float* gamma_b, const float* beta_b, float eps_b, float* mean_rstd_b, float* running_mean_b,
+                                              float* running_var_b, float momentum_b, int64_t* nbt_b, void* out, int32_t batch, int32_t ch, int32_t t,
+                                              int32_t pitch, int32_t act, void* stream_) {
+  if (!va || !vb || !gamma_a || !beta_a || !gamma_b || !beta_b || !mean_rstd_a || !mean_rstd_b || !out) return TS_EINVAL;
+  if (batch <= 0 || ch <= 0 || t <= 0 || pitch < t || pitch % 8 || act < 0 || act > 1) return TS_EINVAL;
+  const int units = batch * ((t + ROW_CHUNK - 1) / ROW_CHUNK);
+  if (units > 4 * (act ? ChanRegs<bf16_t>::UMAX : ChanRegs<float>::UMAX) || (long long)batch * ch * pitch >= (1ll << 31)) return TS_EUNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  Bn2FwdArgs g{};
+  g.a = BnSide{va, nullptr, gamma_a, beta_a, eps_a, mean_rstd_a, running_mean_a, running_var_a, momentum_a, (long long*)nbt_a};
+  g.b = BnSide{vb, nullptr, gamma_b, beta_b, eps_b, mean_rstd_b, running_mean_b, running_var_b, momentum_b, (long long*)nbt_b};
+  g.out = out; g.batch = batch; g.ch = ch; g.t = t; g.pitch = pitch;
+  (void)hipGetLastError();
+  TS_ACT(act, hipLaunchKernelGGL(bn2_fwd_chan_kernel<float>, dim3(ch), dim3(256), 0, stream, g),
+         hipLaunchKernelGGL(bn2_fwd_chan_kernel<bf16_t>, dim3(ch), dim3(256), 0, stream, g));
+  return hip_status(hipGetLastError());
+}
+
+/* Backward of the block tail, both branches, one launch (same budget rule) */
+extern "C" int ts_train_bn2_chan_bwd(const void* dout, const void* out, const void* va, const void* vb, const float* gamma_a, const float* mean_rstd_a,
+                                     const float* gamma_b, const float* mean_rstd_b, void* dva, void* dvb, float* dgamma_a, float* dbeta_a,
+                                     float* dgamma_b, float* dbeta_b, int32_t batch, int32_t ch, int32_t t, int32_t pitch, int32_t act, void* stream_) {
+  if (!dout || !out || !va || !vb || !gamma_a || !gamma_b || !mean_rstd_a || !mean_rstd_b || !dva || !dvb || !dgamma_a || !dbeta_a || !dgamma_b || !dbeta_b)
+    return TS_EINVAL;
+  if (batch <= 0 || ch <= 0 || t <= 0 || pitch < t || pitch % 8 || act < 0 || act > 1) return TS_EINVAL;
+  const int units = batch * ((t + ROW_CHUNK - 1) / ROW_CHUNK);
+  if (units > 4 * (act ? ChanRegs<bf16_t>::UMAX : ChanRegs<float>::UMAX) || (long long)batch * ch * pitch >= (1ll << 31)) return TS_EUNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const Bn2BwdArgs g{dout, out, va, vb, gamma_a, mean_rstd_a, gamma_b, mean_rstd_b, dva, dvb, dgamma_a, dbeta_a, dgamma_b, dbeta_b, batch, ch, t, pitch};
+  (void)hipGetLastError();
+  TS_ACT(act, hipLaunchKernelGGL(bn2_bwd_chan_kernel<float>, dim3(ch), dim3(256), 0, stream, g),
+         hipLaunchKernelGGL(bn2_bwd_chan_kernel<bf16_t>, dim3(ch), dim3(256), 0, stream, g));
   return hip_status(hipGetLastError());
 }
 

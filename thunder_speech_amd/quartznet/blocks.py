@@ -255,7 +255,7 @@ class _FusedBlockBase(nn.Module):
             drop_p = drop.p if (drop is not None and drop.training) else 0.0
             # between two repeats the BatchNorm (+ ReLU) is folded into the next repeat's depthwise launches (train_ops.SubBlock)
             lazy = (fuse_tail and drop_p == 0.0) if last else (T._LAZY_BN and drop_p == 0.0 and T.same_depthwise(subs[r + 1][0]))
-            h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop_p, lazy_out=lazy, tile_stats=not last)
+            h = T.sub_block(h, dw, pw, bn, lh_in, lh, relu=not last, drop_p=drop_p, lazy_out=lazy, tile_stats=not last, defer_stats=last)
         if self._has_se():
             se = self.mconv[len(self.mconv) - 1].layer[0]          # citrinet/blocks.py:154: SE closes the main branch
             h = T.SqueezeExciteTrain.apply(h, se.fc[0].weight, se.fc[2].weight)
@@ -266,7 +266,7 @@ class _FusedBlockBase(nn.Module):
                 r_in = T.SubsampleMask.apply(x_res, len_in, rc.stride, (x_res.shape[2] - 1) // rc.stride + 1)
                 r_out = T.batch_norm_train(rbn, T.PointwiseConv.apply(r_in, rc.conv.weight), relu=False)
             else:                    # mask -> 1x1 -> BatchNorm as one node, like a repeat without depthwise conv and ReLU
-                r_out = T.sub_block(x_res, None, rc, rbn, len_in, len_in, relu=False, lazy_out=fuse_tail, bwd_mask=False)
+                r_out = T.sub_block(x_res, None, rc, rbn, len_in, len_in, relu=False, lazy_out=fuse_tail, bwd_mask=False, defer_stats=True)
         out = T.block_tail(h, r_out) if (fuse_tail and getattr(h, "_ts_lazy", None) is not None) else T.AddRelu.apply(h, r_out)
         return T.dropout(out, out_drop.p, out_drop.training), out_lengths
 

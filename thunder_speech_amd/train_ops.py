@@ -770,7 +770,7 @@ class SqueezeExciteTrain(torch.autograd.Function):
 class SubBlockCfg:
     """Non-tensor arguments of SubBlock (one per call)."""
     __slots__ = ("len_in", "len_out", "k", "stride", "dil", "pad", "eps", "relu", "running", "drop_p", "drop_seed",
-                 "lazy_in", "lazy_out", "out_sums", "bwd_mask", "tile_stats")
+                 "lazy_in", "lazy_out", "out_sums", "bwd_mask", "tile_stats", "defer_stats")
 
 
 # BatchNorm between two repeats folded into the neighbouring depthwise launches (no normalised tensor in memory): on by default
@@ -867,6 +867,9 @@ class SubBlock(torch.autograd.Function):
         if cfg.lazy_out and tiles is not None:
             cfg.out_sums = tiles
             y, out = None, v
+        elif cfg.lazy_out and getattr(cfg, "defer_stats", False) and chan_fits(b, t_out, v.dtype):
+            cfg.out_sums = None      # the block tail's one-launch kernel forms the statistics itself (ts_train_bn2_add_relu_chan_fwd)
+            y, out = None, v
         elif cfg.lazy_out:
             _lib.check(L.ts_train_bn_stats(v.data_ptr(), ws.data_ptr(), b, c_out, t_out, _pitch(v), code, st_), "ts_train_bn_stats")
             cfg.out_sums = ws
@@ -952,7 +955,7 @@ TILE_STATS = True           # False: every pending BatchNorm gets its statistics
 
 
 def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Tensor, len_out: Tensor, relu: bool, drop_p: float = 0.0,
-              lazy_out: bool = False, bwd_mask: bool = True, tile_stats: bool = False) -> Tensor:
+              lazy_out: bool = False, bwd_mask: bool = True, tile_stats: bool = False, defer_stats: bool = False) -> Tensor:
     """x -> [dropout](relu?(BN_train(pw(mask(dw(mask(x))))))): one repeat of a block.  dw_conv / pw_conv are the MaskedConv1d modules
     (dw_conv None for a non-separable 1x1 repeat), len_in / len_out int32 device lengths before / after the depthwise conv.
     `lazy_out` (only between two repeats, see SubBlock): the result is the UN-normalised 1x1 output carrying its pending BatchNorm
@@ -973,6 +976,7 @@ def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Ten
     cfg.lazy_in = (pending[0], pending[1], pending[2].eps, pending[3]) if pending is not None else None
     cfg.lazy_out, cfg.out_sums = bool(lazy_out) and cfg.drop_p == 0.0, None
     cfg.tile_stats = bool(tile_stats)
+    cfg.defer_stats = bool(defer_stats)          # `lazy_out` towards block_tail: leave the statistics to its one-launch kernel when the batch fits
     if pending is not None and not same_depthwise(dw_conv):
         raise RuntimeError("sub_block: the input carries a pending BatchNorm but this repeat cannot apply it")
     gamma_in, beta_in = (pending[2].weight, pending[2].bias) if pending is not None else (None, None)
@@ -986,10 +990,20 @@ def sub_block(x: Tensor, dw_conv, pw_conv, bn: torch.nn.BatchNorm1d, len_in: Ten
     return y
 
 
+CHAN_TAIL = True            # False: block tails keep the two-step kernels (clip-group sums + apply passes), as before ABI v9 (A/B)
+
+
+def chan_fits(batch: int, t: int, dtype) -> bool:
+    """Whether the one-workgroup-per-channel block-tail kernels hold a channel of this batch in registers (csrc/train_enc.hip ChanRegs)."""
+    return CHAN_TAIL and batch * ((t + 511) // 512) <= (32 if dtype == torch.bfloat16 else 16)
+
+
 class BlockTail(torch.autograd.Function):
-    """out = relu(BatchNorm(v_main) + BatchNorm(v_res)) (quartznet/blocks.py:332-337) as ONE pass over the two un-normalised tensors
-    (both branches end in a `lazy_out` sub_block, which left their clip-group sums); backward = the two BatchNorm backwards with the
-    shared ReLU's gate taken from `out`."""
+    """out = relu(BatchNorm(v_main) + BatchNorm(v_res)) (quartznet/blocks.py:332-337) over the two un-normalised tensors (both branches end
+    in a `lazy_out` sub_block).  When neither branch brought statistics (`defer_stats`, the batch fits): ONE launch forward
+    (ts_train_bn2_add_relu_chan_fwd: statistics + both normalisations + add + ReLU, every tensor read once) and ONE launch backward
+    (ts_train_bn2_chan_bwd: both BatchNorm backwards with the shared ReLU's gate taken from `out`); otherwise one apply pass over the
+    clip-group sums forward and two (sums + apply) pairs backward."""
 
     @staticmethod
     def forward(ctx, va, gamma_a, beta_a, vb, gamma_b, beta_b, cfg):
@@ -999,12 +1013,19 @@ class BlockTail(torch.autograd.Function):
         ga, ba = gamma_a.detach().to(torch.float32).contiguous(), beta_a.detach().to(torch.float32).contiguous()
         gb, bb = gamma_b.detach().to(torch.float32).contiguous(), beta_b.detach().to(torch.float32).contiguous()
         mra, mrb = (torch.empty(c, 2, dtype=torch.float32, device=va.device) for _ in range(2))
+        chan = cfg[0][0] is None and cfg[1][0] is None and chan_fits(b, t, va.dtype)
         args = []
         for v, sums, g, be, eps, mr, run in ((va, cfg[0][0], ga, ba, cfg[0][1], mra, cfg[0][2]), (vb, cfg[1][0], gb, bb, cfg[1][1], mrb, cfg[1][2])):
             rm, rv, mom, nbt = run if run is not None else (None, None, 0.0, None)
-            args += [v.data_ptr(), sums.data_ptr(), g.data_ptr(), be.data_ptr(), float(eps), mr.data_ptr(), rm.data_ptr() if rm is not None else None,
-                     rv.data_ptr() if rv is not None else None, float(mom), nbt.data_ptr() if nbt is not None else None]
-        _lib.check(L.ts_train_bn2_add_relu_fwd(*args, out.data_ptr(), b, c, t, _pitch(va), _code(va), _s(va)), "ts_train_bn2_add_relu_fwd")
+            if not chan and sums is None:         # one branch came without statistics: the pass it skipped
+                sums = torch.empty(16 * c, dtype=torch.float64, device=v.device)
+                _lib.check(L.ts_train_bn_stats(v.data_ptr(), sums.data_ptr(), b, c, t, _pitch(v), _code(v), _s(v)), "ts_train_bn_stats")
+            args += [v.data_ptr()] + ([] if chan else [sums.data_ptr()]) + [g.data_ptr(), be.data_ptr(), float(eps), mr.data_ptr(),
+                     rm.data_ptr() if rm is not None else None, rv.data_ptr() if rv is not None else None, float(mom), nbt.data_ptr() if nbt is not None else None]
+        if chan:
+            _lib.check(L.ts_train_bn2_add_relu_chan_fwd(*args, out.data_ptr(), b, c, t, _pitch(va), _code(va), _s(va)), "ts_train_bn2_add_relu_chan_fwd")
+        else:
+            _lib.check(L.ts_train_bn2_add_relu_fwd(*args, out.data_ptr(), b, c, t, _pitch(va), _code(va), _s(va)), "ts_train_bn2_add_relu_fwd")
         ctx.save_for_backward(va, vb, out, ga, gb, mra, mrb)
         ctx.params = (gamma_a, beta_a, gamma_b, beta_b)
         return out
@@ -1015,6 +1036,14 @@ class BlockTail(torch.autograd.Function):
         va, vb, out, ga, gb, mra, mrb = ctx.saved_tensors
         b, c, t = va.shape
         dout = _g(dout, out)
+        if chan_fits(b, t, va.dtype):
+            dva, dvb = alloc_like(va), alloc_like(vb)
+            dga, dba = grad_out(ctx.params[0], (c,)), grad_out(ctx.params[1], (c,))
+            dgb, dbb = grad_out(ctx.params[2], (c,)), grad_out(ctx.params[3], (c,))
+            _lib.check(L.ts_train_bn2_chan_bwd(dout.data_ptr(), out.data_ptr(), va.data_ptr(), vb.data_ptr(), ga.data_ptr(), mra.data_ptr(), gb.data_ptr(),
+                                               mrb.data_ptr(), dva.data_ptr(), dvb.data_ptr(), dga.data_ptr(), dba.data_ptr(), dgb.data_ptr(), dbb.data_ptr(),
+                                               b, c, t, _pitch(va), _code(va), _s(va)), "ts_train_bn2_chan_bwd")
+            return dva, dga, dba, dvb, dgb, dbb, None
         grads = []
         for v, g, mr, (gp, bp) in ((va, ga, mra, ctx.params[:2]), (vb, gb, mrb, ctx.params[2:])):
             dv = alloc_like(v)
