@@ -306,12 +306,14 @@ def _one_rank_group():
         return None
 
 
-def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8, segments=3, first_share=0.1):
+def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8, segments=2, first_share=0.1):
     """BASELINE.json configs[3] as the reference runs it (Trainer(strategy="ddp"), tests/quartznet/test_module_qn.py:33-53): QuartzNet15x5
     fine-tuning, everything trainable, GLOBAL batch 256 x 10 s split over the ranks (strong scaling: local batch 256 / world), one
     gradient exchange per step (parallel.GradientSync: bf16 wire, reduce-scatter + all-gather over RCCL), FusedAdamW, forward + backward
-    replayed from `segments` hipGraphs (train_graph.GraphedTrainStep(segments=3, first_share=0.1): bucket k's exchange runs on the side stream under
-    piece k + 1 of the backward pass; only the last bucket -- the first encoder stage's parameters, cut to ~10 % of the gradient bytes -- is exposed).  Every rank runs it; the time is the MAX over ranks between two barriers.
+    replayed from `segments` hipGraphs (train_graph.GraphedTrainStep(segments=2, first_share=0.1): bucket k's exchange runs on the side stream under
+    piece k + 1 of the backward pass; only the last bucket -- the first encoder stage's parameters, cut to ~10 % of the gradient bytes -- is exposed;
+    two pieces since round 5: the first stage's backward, ~0.9 ms, is longer than the 34 MB bucket needs on the links, and every extra graph costs
+    ~0.1 ms of replay gaps -- profiles/round5_c4_segments.txt).  Every rank runs it; the time is the MAX over ranks between two barriers.
     `exchange_ms_exposed` is the step time minus the time of the same step with the exchange switched off (what the links cost after overlap).
     With ONE rank the exchange runs in loop-back (pack -> collective over a one-rank RCCL group -> unpack: every launch of the real exchange, no
     bytes over links) and the local-32 step -- what each of 8 ranks would run -- is timed the same way:
@@ -429,6 +431,8 @@ def run(device, which=("c3", "c4", "c5", "c5_finetune"), check=True):
                 extra["c5"] = c5(device, check=check)
             elif name == "c5_finetune":
                 extra["c5_finetune"] = c5_finetune(device)
+            elif name == "c4_ddp":                   # stand-alone A/B of the segmented step: TS_C4_SEGMENTS / TS_C4_FIRST_SHARE (bench.py runs the defaults)
+                extra["c4_ddp"] = c4_ddp(device, segments=int(os.environ.get("TS_C4_SEGMENTS", "2")), first_share=float(os.environ.get("TS_C4_FIRST_SHARE", "0.1")))
         except Exception as e:                      # an extra must never take the headline line down with it: recorded, reported on stderr,
             import traceback                        # and bench.py exits non-zero after printing the (complete) line
             print(f"bench_extra: {name} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
