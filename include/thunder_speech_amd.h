@@ -70,7 +70,7 @@ typedef struct ts_tcs_desc {
   const void* res_w;            /* bf16 [c_out_pad32/32][c_res_pad64/16][64][8] */
   const void* pw_w16;           /* the same weights as B fragments of v_mfma_f32_16x16x32_bf16: bf16 [c_out_pad32/16][c_in_pad64/32][64][8], lane l,
                                    element j = W[16 tile + (l & 15)][32 kstep + 8 (l >> 4) + j] (plan.pack_pw_frags16).  May be NULL: the split kernel
-                                   (and with it ts_tcs_chain_fwd) then declines and the 4 + 4-wave kernel runs on pw_w */
+                                   then declines and the 4 + 4-wave kernel runs on pw_w */
   const void* res_w16;          /* bf16 [c_out_pad32/16][c_res_pad64/32][64][8] */
   const float* bias;            /* f32  [c_out_pad32]  bn_shift (+ residual bn_shift) */
   const void* se_y;             /* ABI v7, may be NULL.  Squeeze-excite tail of a CitrinetBlock (citrinet/blocks.py:186-196) in THIS launch's epilogue:
@@ -106,21 +106,6 @@ typedef struct ts_tcs_desc {
 int ts_tcs_subblock_fwd(const ts_tcs_desc* desc, const void* x, const int32_t* len_in, const void* x_res,
                         const int32_t* len_res, void* y, void* stream);
 
-/* A CHAIN of sub-blocks in ONE persistent launch: the R repeats of a QuartznetBlock / CitrinetBlock
- * (quartznet/blocks.py:266-296, :317-338: `for layer in self.mconv` + the residual branch folded into the last repeat).
- * Layer l reads x[l] and writes y[l]; x[l] == y[l-1] for l >= 1 (x[0] and every x_res[l] were written before the launch).
- * Inside the launch a tile of layer l starts as soon as the (at most three) tiles of layer l-1 that cover its input frames
- * (the tile and its K-1 halo) have been published through per-(layer, clip, time tile) counters in `workspace` -- no grid-wide
- * barrier, no dependence on dispatch order or workgroup placement (write-through stores + agent-scope counters).
- * Every layer: depthwise stride 1 / dilation 1, the same batch, kernel, padding, dw_ksteps, c_out, t_in == t_out, pitch_in ==
- * pitch_out, c_in / c_res multiples of 64, both TS_TCS_IN_TAILZERO and TS_TCS_OUT_ZERO_TAIL set, dw_taps_raw given; `len` int32 [B]
- * is the valid length of every tensor of the chain.  TS_EUNSUPPORTED otherwise (run the layers one by one with ts_tcs_subblock_fwd).
- * workspace: ts_tcs_chain_workspace_bytes() bytes, any contents (the launch zeroes it with a memset node of its own); after the
- * launch its last int32 is 0, or non-zero when a wait gave up (a workgroup of the launch was not resident: results invalid). */
-#define TS_TCS_CHAIN_MAX 16
-int64_t ts_tcs_chain_workspace_bytes(int32_t batch, int32_t t_out, int32_t n_layers);
-int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, const void* const* x, const void* const* x_res, void* const* y,
-                     const int32_t* len, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * General f32-accumulating GEMM on the f32 matrix-core instruction (csrc/gemm_f32.hip): what the "reference arithmetic" modes run on -- the

@@ -141,3 +141,32 @@ def test_block_tail_in_one_launch_each_way_matches_float64_autograd(act, b, c, t
         s_ = max(float(want.abs().max()), 1e-6)
         assert torch.isfinite(got.float()).all()
         assert float((got.float().cpu().double() - want).abs().max()) <= (2e-2 if act == "bf16" else 1e-4) * s_
+
+
+@pytest.mark.parametrize("b,c_in,c_out,t,relu,ragged", [(64, 1024, 29, 751, False, False), (3, 256, 11, 37, True, True), (5, 128, 32, 300, False, True),
+                                                         (2, 640, 1025 % 33, 129, False, True), (4, 1024, 29, 128, False, False)])
+def test_logits_kernel_matches_float64(b, c_in, c_out, t, relu, ragged):
+    """csrc/pw_logits.hip behind ts_tcs_subblock_fwd(depthwise = 0, out_fp32 = 1, c_out <= 32): the CTC decoders' 1x1 conv + bias with f32 logits
+    (reference blocks.py:199-216) -- vs a float64 product of the same bf16 operands; input frames >= len count as 0, NaN in the row padding beyond the
+    last tile must not matter; c_in = 640 is not a multiple of 128 and takes the generic kernel (same answer)."""
+    from thunder_speech_amd import _lib, plan
+    gen = torch.Generator().manual_seed(b * 7 + t)
+    x = torch.randn(b, c_in, t, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(c_out, c_in, generator=gen) / c_in ** 0.5)
+    bias = torch.randn(c_out, generator=gen)
+    lens = torch.tensor([t - (5 * i) % max(t // 2, 1) if ragged else t for i in range(b)], dtype=torch.int32)
+    layer = plan.make_tcs_layer(torch.device(DEV), dw_w=None, pw_w=w, bn=None, kernel=1, stride=1, dilation=1, padding=0, relu=relu, bias_extra=bias,
+                                out_fp32=True)
+    pitch = _lib.time_pitch(t)
+    xb = torch.full((b, c_in, pitch), float("nan"), dtype=torch.bfloat16, device=DEV)
+    xb[:, :, :t] = x.to(DEV)
+    n_tt = (t + 127) // 128
+    xb[:, :, t:min(n_tt * 128, pitch)] = 0                      # what the tile may read beyond t stays finite (the library's buffers hold zeros there)
+    y, t_out = layer.run(xb, t, lens.to(DEV))
+    assert t_out == t and y.dtype == torch.float32
+    mask = (torch.arange(t)[None, :] < lens[:, None]).double()
+    ref = torch.einsum("vc,bct->bvt", w.to(torch.bfloat16).double(), x.double() * mask[:, None, :]) + bias.double()[None, :, None]
+    if relu:
+        ref = ref.clamp_min(0)
+    got = y[:, :, :t].cpu().double()
+    assert float((got - ref).abs().max()) <= 2e-4 * max(float(ref.abs().max()), 1.0)

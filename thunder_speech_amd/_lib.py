@@ -20,7 +20,7 @@ TS_EUNSUPPORTED = -2
 GUARD_BYTES = 1024
 
 EXPORTED_SYMBOLS = [
-    "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd", "ts_tcs_chain_fwd", "ts_tcs_chain_workspace_bytes",
+    "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd",
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss", "ts_ctc_prepare",
     "ts_pack_activation", "ts_unpack_activation", "ts_lengths_map", "ts_im2col_time", "ts_fe_preemph", "ts_fe_dither", "ts_fe_power_spectrum", "ts_fe_stft", "ts_fe_mel", "ts_fe_normalize", "ts_gemm_nt_bf16", "ts_gemm_nt_pack_w", "ts_gemm_nt_bf16_packed", "ts_gemm_f32", "ts_gemm_f32_b2", "ts_w2v_layernorm_bwd_workspace", "ts_w2v_layernorm_bwd", "ts_w2v_colsum", "ts_w2v_gelu_fwd", "ts_w2v_gelu_bwd",
@@ -95,10 +95,6 @@ def lib() -> C.CDLL:
     L.ts_time_pitch.restype = C.c_int
     L.ts_tcs_subblock_fwd.argtypes = [C.POINTER(TcsDesc), vp, vp, vp, vp, vp, vp]
     L.ts_tcs_subblock_fwd.restype = C.c_int
-    L.ts_tcs_chain_workspace_bytes.argtypes = [i32, i32, i32]
-    L.ts_tcs_chain_workspace_bytes.restype = i64
-    L.ts_tcs_chain_fwd.argtypes = [C.POINTER(TcsDesc), i32, vp, vp, vp, vp, vp, i64, vp]
-    L.ts_tcs_chain_fwd.restype = C.c_int
     L.ts_frontend_workspace_bytes.argtypes = [C.POINTER(FrontendDesc)]
     L.ts_frontend_workspace_bytes.restype = i64
     L.ts_mel_frontend_fwd.argtypes = [C.POINTER(FrontendDesc), vp, vp, vp, vp, vp, vp]

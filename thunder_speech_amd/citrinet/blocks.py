@@ -139,12 +139,7 @@ class CitrinetBlock(_FusedBlockBase):
         h, th, lh, h_tz = x0, t, len_in, x0_tz
         out_lengths = lengths
         subs = list(self._sub_blocks())
-        first = 0
-        if len(convs) >= 2 and x0_tz and all(l.chainable() for l in convs):     # every repeat in ONE launch (stride-1 blocks)
-            outs = [_t.arena(("enc", slot, r % 2), b, convs[r].c_out, t, dev) for r in range(len(convs))]
-            if _plan.run_chain(convs, x0, t, len_in, outs):
-                h, first = outs[-1], len(convs)
-        for r in range(first, len(convs)):
+        for r in range(len(convs)):
             layer = convs[r]
             geom = subs[r][0] if subs[r][0] is not None else subs[r][1]
             out = _t.arena(("enc", slot, r % 2), b, layer.c_out, layer.out_size(th), dev)

@@ -663,26 +663,26 @@ extern "C" int ts_tcs_pointwise_tile_frames(int32_t batch, int32_t c_out, int32_
   return (long long)batch * n_tt * ((round_up(c_out, 32) + 255) / 256) < cu_count() ? 64 : 128;
 }
 
-// one layer through the split kernel (csrc/tcs_split.hip): a chain of one, no counters
+// one layer through the split kernel (csrc/tcs_split.hip)
 static int split_single(const ts::TcsArgs& w, int npass, int xe, int wm, int dil, hipStream_t stream) {
   using namespace ts;
   // 32-bit byte offsets inside the split kernel's buffer descriptors
   const int64_t cmax = w.c_in > w.c_out ? w.c_in : w.c_out;
   if ((int64_t)w.batch * cmax * (w.pitch_in > w.pitch_out ? w.pitch_in : w.pitch_out) * 2 + TS_GUARD_BYTES >= (1ll << 31)) return TS_EUNSUPPORTED;
   if (w.c_res > 0 && (int64_t)w.batch * w.c_res * w.pitch_res * 2 >= (1ll << 31)) return TS_EUNSUPPORTED;
-  ChainArgs a{};
-  ChainLayer& L = a.layer[0];
+  SplitArgs a{};
+  SplitLayer& L = a.layer;
   L.x = w.x; L.xres = w.xres; L.y = static_cast<unsigned short*>(w.y);
   if (!w.pw_w16 || (w.c_res > 0 && !w.res_w16)) return TS_EUNSUPPORTED;
   L.taps_raw = w.taps_raw; L.pw_w = w.pw_w16; L.res_w = w.res_w16; L.bias = w.bias;
   L.c_in = w.c_in; L.c_res = w.c_res; L.pitch_res = w.c_res > 0 ? w.pitch_res : w.pitch_in; L.relu = w.relu;
-  L.kt_main = w.kt_main; L.kt_res = w.kt_res; L.wait_in = 0;
+  L.kt_main = w.kt_main; L.kt_res = w.kt_res;
   L.se_y = w.se_y; L.se_gate = w.se_gate;
-  a.len = w.len_in; a.flags = nullptr; a.n_layers = 1;
+  a.len = w.len_in;
   a.batch = w.batch; a.c_out = w.c_out; a.pitch_in = w.pitch_in; a.pitch_out = w.pitch_out; a.t_out = w.t_out;
   a.kernel = w.kernel; a.padding = w.padding; a.dilation = w.dilation;
   a.woff = w.woff; a.padl8 = w.padl8; a.zero_tail = w.zero_tail;
-  return launch_split_chain(a, npass, xe, wm, dil, stream);
+  return launch_split_layer(a, npass, xe, wm, dil, stream);
 }
 
 extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const int32_t* len_in, const void* x_res,
@@ -770,7 +770,7 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
     tz = tz && (n_tt - 1) * TT * d->stride - a.padl8 + a.xe <= d->pitch_in && d->pitch_in - d->t_in >= a.padl8;
     if (tz && d->stride == 1 && d->dilation == 1 && a.npass <= 7 && d->dw_taps_raw) {
       // split kernel: 96-frame granules, its own window geometry
-      const int WM = split_tile_wm(d->c_out, d->batch, d->t_out, false);
+      const int WM = split_tile_wm(d->c_out);
       const int TTp = 96 * WM;
       const int n_ttp = (d->t_out + TTp - 1) / TTp;
       const int xe = round_up(a.woff + TTp + 4 * d->dw_ksteps, 64);
@@ -805,6 +805,8 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
   // pointwise only: `stride` is handled by the staging (generic gather when > 1)
   if (d->out_fp32) {
     if (d->stride != 1) return TS_EUNSUPPORTED;
+    const int st = launch_pw_logits(a, stream);          // the decoders: few output channels, a pure read stream (csrc/pw_logits.hip)
+    if (st != TS_EUNSUPPORTED) return st;
     return launch<128, 2, 1, false, true>(a, stream);
   }
   if (d->stride == 1) {

@@ -1,5 +1,5 @@
 // Shared between the fused TCS kernels (csrc/tcs_kernel.hip: first design / generic kernel and the C-ABI dispatch; csrc/tcs_split.hip:
-// split kernel, single layers and chains).
+// split kernel).
 #pragma once
 #include "ts_common.hpp"
 
@@ -40,7 +40,7 @@ struct TcsArgs {
   int n_tt, n_z, n_tiles;      // tile grid: time tiles, output-channel splits, total
   int zero_tail;               // 1: store 0 for frames >= the output length (keeps the tail-zero invariant)
   int xcd;                     // split kernel: 1 = XCD-contiguous tile order (grid is a multiple of 8)
-  const unsigned short* se_y;  // squeeze-excite tail in the epilogue (pointwise-only split launches): see ChainLayer
+  const unsigned short* se_y;  // squeeze-excite tail in the epilogue (pointwise-only split launches): see SplitLayer
   const float* se_gate;
   float* stats;                // generic pointwise-only launches: per-tile (sum y, sum y^2) per output channel, f32 [c_out][batch * n_tt][2], or null
 };
@@ -110,11 +110,9 @@ struct TilePos {
 
 
 // ---- split kernel (csrc/tcs_split.hip) ------------------------------------------------------------------------------------
-// One launch runs a CHAIN of layers (ts_tcs_chain_fwd; a single layer is a chain of one).  What may differ between the layers of a
-// chain sits in ChainLayer; the geometry (tile grid, depthwise window, pitches, output channels) is common.
-struct ChainLayer {
-  const unsigned short* x;         // [B][c_in][pitch]; layer l >= 1: the previous layer's y
-  const unsigned short* xres;      // [B][c_res][pitch_res] residual input (written before the launch), or the input of a pointwise-only layer
+struct SplitLayer {
+  const unsigned short* x;         // [B][c_in][pitch]
+  const unsigned short* xres;      // [B][c_res][pitch_res] residual input, or the input of a pointwise-only layer
   unsigned short* y;               // [B][c_out][pitch]
   const unsigned short* taps_raw;  // raw tap image (plan.pack_dw_taps_raw)
   const unsigned short* pw_w;      // B fragments of v_mfma_f32_16x16x32_bf16: [c_out / 16][c_in / 32][64][8]
@@ -122,18 +120,14 @@ struct ChainLayer {
   const float* bias;
   int c_in, c_res, pitch_res, relu;
   int kt_main, kt_res;             // k-steps (16 channels) of the packed weights
-  int wait_in;                     // 1: x is produced by the previous layer of this launch -> its tiles are waited for
-  int pad_;
   // squeeze-excite tail (SE instantiation only): y = relu(se_gate[b][co] * se_y[b][co][t] + this layer's result) -- the closing step of a
   // CitrinetBlock (citrinet/blocks.py:186-196) in the residual 1x1 launch's epilogue; se_y has the pitch of y
   const unsigned short* se_y;
   const float* se_gate;
 };
-struct ChainArgs {
-  ChainLayer layer[TS_TCS_CHAIN_MAX];
-  const int* len;                  // int32 [B] valid frames (the same for every tensor of the chain)
-  unsigned* flags;                 // [n_layers][batch * n_tt] arrival counters + one status word; zeroed before the launch
-  int n_layers;
+struct SplitArgs {
+  SplitLayer layer;
+  const int* len;                  // int32 [B] valid frames
   int batch, c_out, pitch_in, pitch_out, t_out;
   int kernel, padding, dilation;
   int woff, padl8;
@@ -142,8 +136,10 @@ struct ChainArgs {
 };
 // TS_EUNSUPPORTED when no instantiation fits (npass = depthwise passes of 3 k-steps, xe = staged frames per row, a multiple of 64;
 // wm = 1: 96-frame x 512-channel tiles, 2: 192 x 256; dil = 1, or 2 for the phase-split form of a dilation-2 layer)
-int launch_split_chain(ChainArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream);
+int launch_split_layer(SplitArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream);
+// pointwise layer with <= 32 output channels and f32 results (csrc/pw_logits.hip); TS_EUNSUPPORTED when the shape is not its
+int launch_pw_logits(const TcsArgs& w, hipStream_t stream);
 // time-tile choice of the split kernel for a layer: 1 = 96 frames, 2 = 192 frames (c_out <= 256 only)
-int split_tile_wm(int c_out, int batch, int t_out, bool chain);
+int split_tile_wm(int c_out);
 
 }  // namespace ts

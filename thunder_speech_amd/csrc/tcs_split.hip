@@ -1,12 +1,11 @@
 // Split kernel of the fused time-channel-separable sub-block (gfx950): 12 waves = 8 pointwise consumers + 4 depthwise
-// producers, 96 / 192-frame tiles, persistent workgroups -- and, since round 4, a whole CHAIN of sub-blocks per launch.
+// producers, 96 / 192-frame tiles, persistent workgroups, one sub-block per launch.
 //
 //   y_l[b, co, t] = act( sum_ci Wf_l[co, ci] * dw_l[b, ci, t] + bias_l[co] + sum_cr Wr_l[co, cr] * xres_l[b, cr, t] )
 //   dw_l[b, ci, t] = sum_u taps_l[ci, u] * x_l[b, ci, t + u - pad],   x_l = y_(l-1) for l >= 1
 //
 // Replaces the reference's per-sub-block ATen chain (quartznet/blocks.py:166-182 masked_fill + conv1d(groups=C) + masked_fill +
-// conv1d(k=1), :222 batch_norm, :332-337 residual add + relu), and with n_layers > 1 the `for layer in self.mconv` loop of a whole
-// block (quartznet/blocks.py:317-338) in ONE launch.  DESIGN.md section 3.1 has the measurements behind each step.
+// conv1d(k=1), :222 batch_norm, :332-337 residual add + relu).  DESIGN.md section 3.1 has the measurements behind each step.
 //
 // Roles (every SIMD holds two consumer waves and one producer wave, 168 VGPRs each):
 //   producer p (wave 8 + p): channels [16p, 16p + 16) of a 64-channel stage.  Rows global -> registers (two stages ahead) ->
@@ -19,57 +18,13 @@
 //   iteration i: producers write stage i into dwt[i & 1], consumers read stage i-1; ONE s_barrier per stage; the stream runs on
 //   across tile boundaries, the epilogue of a tile sits behind the barrier that ends it, so the producers work through it.
 //
-// Chains (round 4).  Layer l + 1 reads what layer l wrote, and a tile (clip, time tile tt) of layer l + 1 needs the tiles tt - 1,
-// tt, tt + 1 of layer l (its own frames + the K - 1 halo).  Every workgroup walks its tiles layer by layer; a consumer wave drains
-// its (write-through, sc1) output stores, the eighth one to arrive on an LDS counter adds 1 to the tile's agent-scope counter,
-// and the producers of the workgroup that needs the tile read that counter (sc1 load, requested a stage before its first use) in
-// front of their first row load -- which is an sc1 load too, so no cache of the reading CU can serve stale bytes
-// (cdna_hip_programming.md Guideline 16, R1 with the payload loads as sc1 loads; MI355X_MICROARCH.md "Valid forms", row 1).
-// No grid-wide barrier, no assumption about dispatch order or workgroup placement; correctness needs only that every workgroup of
-// the launch becomes resident (grid <= compute units, one workgroup per CU) and waits are bounded (status word).
-// Deadlock freedom: a workgroup only ever waits for tiles of the PREVIOUS layer, and it enters a wait for layer l's tiles only
-// after its producers have handed over every stage of its own layer l-1 tiles (the barrier that ends a layer comes first), so
-// its own layer l-1 epilogues complete without it; by induction over the layers every wait ends.
+// Round 4 also ran all repeats of a block as ONE persistent launch of this kernel (a chain: per-tile arrival counters, write-through stores,
+// L1-bypassing loads).  It was bit-identical and removed the launch gaps, but lost more than that to the sc1 traffic and to register pressure
+// (2.98-3.00 vs 2.87 ms per encoder pass, profiles/round4_chain_ab.txt, round4_tcs_same_box.txt) and never shipped switched on; round 5 took it out
+// of the product (git history: commit 4a86010 has the full kernel, ts_tcs_chain_fwd and its tests).
 #include "tcs_shared.hpp"
 
 namespace ts {
-
-namespace {
-
-constexpr unsigned SPIN_LIMIT = 1u << 21;
-
-typedef __attribute__((address_space(1))) unsigned gu32;
-
-__device__ __forceinline__ unsigned flag_load(const unsigned* p) {
-  return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// the tiles (b, tt - 1 .. tt + 1) of the previous layer: lanes 0..2 hold one counter each (index < 0: lane takes no part)
-struct TileWait {
-  int idx;
-  __device__ __forceinline__ void aim(int b, int tt, int n_tt, int lane) {
-    const int t = tt - 1 + lane;
-    idx = (lane < 3 && t >= 0 && t < n_tt) ? b * n_tt + t : -1;
-  }
-  __device__ __forceinline__ unsigned peek(const unsigned* layer_flags, unsigned need) const {
-    return idx >= 0 ? flag_load(layer_flags + idx) : need;
-  }
-  // blocking form: poll (relaxed, one wave-instruction per round) until all three counters have reached `need`
-  __device__ __forceinline__ void block(const unsigned* layer_flags, unsigned need, unsigned* status, int lane) const {
-    for (unsigned spins = 0;; ++spins) {
-      const unsigned v = peek(layer_flags, need);
-      if (__all(v >= need)) break;
-      if (spins > SPIN_LIMIT) {                       // a workgroup of the launch never became resident: give up loudly
-        if (lane == 0) __hip_atomic_store((gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // compiler-only: no load of the tile may move above the poll
-  }
-};
-
-}  // namespace
 
 // DIL == 2 (dilation-2 layers, K87 of QuartzNet): the even and the odd frames of a row are two independent dilation-1
 // sequences (y[2s+p] = sum_u w[u] x[2(s+u)+p - pad], pad even).  The producers stage each row as [even | odd] halves,
@@ -78,15 +33,10 @@ struct TileWait {
 // NT: 32-channel output tiles per consumer wave -- 2: a workgroup covers 512 (WM = 1) or 256 (WM = 2) output channels; 1 (WM = 1 only): 96 frames x
 // 256 channels, for layers of at most 256 output channels whose 192-frame tiling would leave a compute unit a single tile per layer (nothing
 // to overlap its prologue and epilogue with).
-// CHAIN: false -- ONE layer, known at compile time (no counters, plain loads and stores: the instantiation every single-layer launch takes);
-// true -- a.n_layers layers, sc1 activations, published tiles.  Two instantiations because the chain's bookkeeping costs registers in a kernel
-// that has none to spare: with the layer count a runtime value the single-layer launches of QuartzNet15x5 ran 6 % slower (11 spilled VGPRs in
-// the producers' stage loop), measured on one box.
 // SE: the epilogue closes a CitrinetBlock -- y = relu(gate[b][co] * se_y[b][co][t] + result) with the main branch's output se_y read as 16-byte row
-// segments right where the result rows leave (single-layer launches only; what ts_se_apply_fwd did in a separate pass over three tensors).
-template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2, bool CHAIN = false, bool SE = false>
-__global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
-  static_assert(!(SE && CHAIN), "the squeeze-excite tail exists for single-layer launches");
+// segments right where the result rows leave (what ts_se_apply_fwd did in a separate pass over three tensors).
+template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2, bool SE = false>
+__global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
   constexpr int WN = 8 / WM;
   constexpr int FW = 32 * MT;
   constexpr int TT = FW * WM;
@@ -110,13 +60,11 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
   constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
   constexpr int ER = (WM == 2 || DIL == 2) ? 16 : 32;   // output-channel rows of a consumer's epilogue tile
   constexpr int PHW = 32 * XJ;                    // DIL == 2: frames of a staged half row
-  constexpr int AUX_SC1 = CHAIN ? 16 : 0;         //                     // cache-policy bit sc1 of the buffer instructions: write-through stores, L1-bypassing loads
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const dwt = smem;                                             // [2][KC][ROWB]
   char* const cons0 = smem + 2 * TILEB;                               // [8][ER][EP] epilogue tiles
   char* const prod0 = cons0 + 8 * ER * EP;                            // [4][XSB + 2 * TAPB]
-  unsigned* const arrive = reinterpret_cast<unsigned*>(prod0 + 4 * (XSB + 2 * TAPB));   // consumer waves done with their stores
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,18 +78,17 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     tile_end = min(a.n_tiles, (xcd + 1) * per);
     if (tile0 >= tile_end) return;
   }
-  auto taddr = [](int c, int t) { return c * ROWB + ((((t >> 3) ^ ((c & 3) * 5))) << 4) + ((t & 7) << 1); };
+  // dw tile [ci][t]: rows of ROWB bytes (a whole number of 256-byte bank rows, so every row starts on bank 0) with the 16-byte chunk index
+  // XOR-ed by a per-row key.  The consumers' transposed reads take 8 rows per half-wave -- channels 8 kg + q (+ 4), kg = 0, 1 -- and two 8-byte
+  // halves of 2 chunks each per row: the key's bits 1.. must differ for all eight rows.  (c & 3) * 5 alone repeats for rows c and c + 8: a
+  // 2-way conflict on EVERY A-fragment read, which the round-5 SQ counter pass showed (SQ_LDS_BANK_CONFLICT = 44 % of SQ_LDS_IDX_ACTIVE at K63;
+  // profiles/round5_tcs_sq_counters.md); bit 3 of the row folded into bit 1 of the key makes the eight rows' keys 0, 5, 10, 15, 2, 7, 8, 13.
+  auto taddr = [](int c, int t) { return c * ROWB + ((((t >> 3) ^ ((c & 3) * 5) ^ (((c >> 3) & 1) << 1))) << 4) + ((t & 7) << 1); };
   constexpr int RSRC_FLAGS = 0x00020000;
   auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, RSRC_FLAGS); };
   auto ld16 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); };
-  // activations another workgroup of this launch may have written: every load of them bypasses this CU's L1
-  auto ld16_sc1 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX_SC1)); };
-  const int nct = a.batch * a.n_tt;               // counters per layer
-  unsigned* const status = a.flags;               // word 0; the counters start 16 bytes in
-  unsigned* const counters = a.flags + 4;
-  const int N_LAYERS = CHAIN ? a.n_layers : 1;
+  const SplitLayer& L = a.layer;
   unsigned gs = 0;
-  if (tid == 0) *arrive = 0;                      // ordered before its first use by the barrier that opens layer 0
 
   if (wave >= 8) {
     // ================================= PRODUCER =======================================================
@@ -172,10 +119,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     // longer than one stage).
     constexpr bool ROWS2 = WM == 1 && DIL == 1;
     u32x4 X[ROWS2 ? 2 : 1][XP];
-    // identity rows in flight: one stage ahead; TWO (a second register set, alternating statically) in the single-layer instantiation when the
-    // residual has an even number of stages -- an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
-    // The chain instantiation has no registers for the second set (it cost 20 spilled VGPRs in the stage loop there).
-    constexpr bool ID2 = !CHAIN && WM == 1;
+    // identity rows in flight: one stage ahead; TWO (a second register set, alternating statically) when the residual has an even number of
+    // stages -- an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
+    constexpr bool ID2 = WM == 1;
     u32x4 I[IDP], I2[ID2 ? IDP : 1];
     s16x4 P[NP];
     u32x2 T[NK];
@@ -244,8 +190,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     };
 
     unsigned ds = 0;                               // depthwise stages started: selects the tap image
-    for (int l = 0; l < N_LAYERS; ++l) {
-      const ChainLayer& L = a.layer[l];
+    {
       const int n_main = L.c_in / KC;
       const int n_res = L.c_res / KC;
       const __amdgpu_buffer_rsrc_t rx = rsrc(reinterpret_cast<const char*>(L.x) - TS_GUARD_BYTES);
@@ -254,12 +199,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
       const int lane_i = ((pw * 16 + row) * L.pitch_res + sub * 8) * 2;
       const int chunk_i = KC * L.pitch_res * 2;
       const bool rows2 = ROWS2 && n_main > 0 && !(n_main & 1);
-      // tiles of the previous layer this layer's row loads wait for
-      const unsigned* const wflag = (CHAIN && L.wait_in) ? counters + (size_t)(l - 1) * nct : nullptr;
-      const unsigned need = (unsigned)a.n_z;
-      TileWait tw;
-      unsigned tw_seen = need;
-      bool tw_pending = false;
 
       TilePos dwp;
       dwp.init(tile0, tile_step, a.n_tt, a.n_z);
@@ -267,22 +206,13 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
       auto x_origin = [&](const TilePos& p) { return (p.b * L.c_in * a.pitch_in + p.tt * TT - a.padl8) * 2 + TS_GUARD_BYTES; };
       int x_soff = x_origin(dwp);
       auto dw_issue = [&](u32x4 (&XS)[XP]) {
-        if (tw_pending) {                            // first rows of a new tile: its counters were requested a stage ago
-          if (!__all(tw_seen >= need)) tw.block(wflag, need, status, lane);
-          tw_pending = false;
-        }
         const bool last_chunk = dw_chunk + 1 == n_main;
         if (last_chunk && dw_tile + tile_step < tile_end) {
           dw_tile += tile_step;
           dwp.advance(a.n_tt, a.n_z);
-          if (wflag) {                               // the counters of the NEXT tile, in front of this stage's row loads
-            tw.aim(dwp.b, dwp.tt, a.n_tt, lane);
-            tw_seen = tw.peek(wflag, need);
-            tw_pending = true;
-          }
         }
 #pragma unroll
-        for (int j = 0; j < XP; ++j) XS[j] = ld16_sc1(rx, lane_x + j * 64, x_soff);
+        for (int j = 0; j < XP; ++j) XS[j] = ld16(rx, lane_x + j * 64, x_soff);
         if (last_chunk) {
           dw_chunk = 0;
           x_soff = x_origin(dwp);
@@ -314,11 +244,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
         }
       };
 
-      // prologue of the layer: rows and taps of its first stage (a pointwise-only layer has identity stages only: n_main == 0)
-      if (wflag && n_main) {
-        tw.aim(dwp.b, dwp.tt, a.n_tt, lane);
-        tw.block(wflag, need, status, lane);
-      }
+      // prologue: rows and taps of the first stage (a pointwise-only layer has identity stages only: n_main == 0)
       if (rows2) {
         tap_dma(ds & 1, 0);
         dw_issue(X[0]);                              // rows of stages 0 and 1
@@ -402,8 +328,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
           for (int s = 0; s < n_res; ++s) id_stage(I, true);
         }
       }
-      vm_wait<0>();                                    // no tap DMA may still be heading for the LDS when the layer (the workgroup) ends
-      stage_barrier();                                 // pairs with the consumers' last stage of the layer
+      vm_wait<0>();                                    // no tap DMA may still be heading for the LDS when the workgroup ends
+      stage_barrier();                                 // pairs with the consumers' last stage
     }
     return;
   }
@@ -438,8 +364,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
 
-  for (int l = 0; l < N_LAYERS; ++l) {
-    const ChainLayer& L = a.layer[l];
+  {
     const int n_main = L.c_in / KC;
     const int n_res = L.c_res / KC;
     const int n_stage = n_main + n_res;
@@ -448,8 +373,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     const __amdgpu_buffer_rsrc_t ry = rsrc(L.y);
     const __amdgpu_buffer_rsrc_t rse = rsrc(SE ? L.se_y : L.y);
     const unsigned floor2 = (L.relu && !SE) ? 0u : 0x80008000u;        // SE: the ReLU follows the gate + add, in the row-segment stage
-    const bool publish = CHAIN && l + 1 < N_LAYERS;           // a later layer of this launch reads y
-    unsigned* const pflag = counters + (size_t)l * nct;
 
     // weight stream: fragments [c_out / 16][c_in / 32][64 lanes][8], walked k-step by k-step over (tile, main stages, residual stages);
     // the pointers below always name the k-step AFTER the one being multiplied
@@ -503,13 +426,6 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
       w_next();
     };
 
-    int pub_idx = -1;                                  // tile whose publication is pending (counter index), or -1
-    auto publish_tile = [&](unsigned* flag) {
-      unsigned old = 0;
-      if (lane == 0) old = __hip_atomic_fetch_add((TS_LDS unsigned*)arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      old = __builtin_amdgcn_readfirstlane(old);
-      if ((old & 7u) == 7u && lane == 0) __hip_atomic_fetch_add((gu32*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
     TilePos pos;
     pos.init(tile0, tile_step, a.n_tt, a.n_z);
     w_seek(nk_main == 0);
@@ -517,9 +433,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
     for (int nt = 0; nt < NT16; ++nt) load_w(nt);
     w_next();
     bias_fetch(pos);
-    stage_barrier();                                   // stage 0 of the layer is in dwt[gs & 1]
+    stage_barrier();                                   // stage 0 is in dwt[gs & 1]
     for (int tile = tile0; tile < tile_end; tile += tile_step) {
-      const int b = pos.b, t0 = pos.tt * TT, tt = pos.tt;
+      const int b = pos.b, t0 = pos.tt * TT;
       const int c16_0 = (pos.z * WN + wn) * NT16;
       const int len_b = a.zero_tail ? a.len[b] : 0;
 #pragma unroll
@@ -534,15 +450,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
         kstep(src, true);
         __builtin_amdgcn_sched_barrier(0);
         kstep(src, false);
-        if (pub_idx >= 0) {
-          // the previous tile's stores are older than the 2 NT16 weight loads of this stage: a counted wait covers exactly them
-          vm_wait<2 * NT16>();
-          publish_tile(pflag + pub_idx);
-          pub_idx = -1;
-        }
         stage_barrier();
       }
-      // ---- epilogue (the producers are already on the next tile, or on the next layer's first stage)
+      // ---- epilogue (the producers are already on the next tile)
       pos.advance_if(tile + tile_step < tile_end, a.n_tt, a.n_z);
       bias_fetch(pos);
       int len_out = 0x7fffffff;
@@ -614,24 +524,10 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
 #pragma unroll
             for (int i = 0; i < ER / 4; ++i) {
               if (partial) v[i] &= keep;
-              // write-through (sc1): what a later layer of this launch reads must not sit dirty in this XCD's L2
               if (row0 + 4 * i + rsub < a.c_out)
-                __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * i * a.pitch_out * 2, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * i * a.pitch_out * 2, 0);
             }
           }
-        }
-      }
-      if (publish) {
-        // Publication (R1): every storing wave drains its stores, then checks in on an LDS counter -- not the stage barrier: the producers
-        // may already be waiting for this very tile, and the barrier needs them; the last of the eight to arrive signals for the tile.
-        // A tile that is followed by another one of this layer publishes one stage LATE (behind the first stage of the next tile, below):
-        // its write-through stores then complete under that stage's products instead of stalling the wave here, and with two tiles per
-        // workgroup nobody needs the tile that early.  The last tile of a layer publishes at once.
-        if (tile + tile_step < tile_end) {
-          pub_idx = b * a.n_tt + tt;
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          publish_tile(pflag + b * a.n_tt + tt);
         }
       }
     }
@@ -639,9 +535,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const ChainArgs a) {
 }
 
 template <int NPASS, int XJ, int MT, int WM, int DIL = 1, int NT = 2, bool SE = false>
-static int launch_split(ChainArgs& a, hipStream_t stream) {
-  const bool chain = a.n_layers > 1;
-  if (SE && chain) return TS_EUNSUPPORTED;
+static int launch_split(SplitArgs& a, hipStream_t stream) {
   constexpr int FW = 32 * MT, TT = FW * WM, CO_WG = 32 * NT * (8 / WM);
   constexpr int ROWB = TT <= 128 ? 256 : 512;
   constexpr int NK_ = NPASS * NKP, CST = (16 * NK_ + 16) % 32 == 16 ? 16 * NK_ + 16 : 16 * NK_ + 32, TAPB = (16 * CST + 1023) / 1024 * 1024;
@@ -649,36 +543,29 @@ static int launch_split(ChainArgs& a, hipStream_t stream) {
   a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
   a.n_tiles = a.batch * a.n_tt * a.n_z;
   const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) +
-                     (size_t)4 * (16 * (64 * XJ + 4) * 2 + 2 * TAPB) + 16;
+                     (size_t)4 * (16 * (64 * XJ + 4) * 2 + 2 * TAPB);
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
-  auto kern = SE ? tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, false, SE>
-                 : (chain ? tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, true> : tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, false>);
-  static bool attr_set[2][64] = {};                       // per device (one process may drive several GPUs)
+  auto kern = tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, SE>;
+  static bool attr_set[64] = {};                          // per device (one process may drive several GPUs)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TS_EINVAL;
-  if (!attr_set[chain][dev]) {
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set[chain][dev] = true;
+    attr_set[dev] = true;
   }
   const int n_cu = cu_count();
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
   a.xcd = grid % 8 == 0 ? 1 : 0;
-  if (chain) {
-    // counters + status word of this launch: a memset node of its own, replayed with the launch
-    const size_t bytes = (size_t)round_up((4 + a.n_layers * a.batch * a.n_tt) * 4, 16);
-    hipError_t e = hipMemsetAsync(a.flags, 0, bytes, stream);
-    if (e != hipSuccess) return (int)e;
-  }
   (void)hipGetLastError();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, a);
   return hip_status(hipGetLastError());
 }
 
-int launch_split_chain(ChainArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream) {
-  if (a.layer[0].se_y) {
+int launch_split_layer(SplitArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream) {
+  if (a.layer.se_y) {
     // squeeze-excite tail: the pointwise-only launches of the Citrinet blocks (512 / 256 output channels per workgroup)
-    if (a.n_layers != 1 || !a.layer[0].se_gate || dil != 1 || npass != 2) return TS_EUNSUPPORTED;
+    if (!a.layer.se_gate || dil != 1 || npass != 2) return TS_EUNSUPPORTED;
     if (xe == 128 && wm == 1) return launch_split<2, 2, 3, 1, 1, 2, true>(a, stream);
     if (xe == 256 && wm == 2) return launch_split<2, 4, 3, 2, 1, 2, true>(a, stream);
     return TS_EUNSUPPORTED;
@@ -698,86 +585,8 @@ int launch_split_chain(ChainArgs& a, int npass, int xe, int wm, int dil, hipStre
   return TS_EUNSUPPORTED;
 }
 
-// Frames of a time tile for a layer of c_out output channels: 96 (x 512 channels, or x 256 with one 32-channel tile per consumer wave), or 192
-// (x 256).  The 192-frame tiles have the cheaper stage loop and are what every single-layer launch takes.  A CHAIN whose 192-frame grid gives a
-// workgroup a single tile per layer waits, at every layer boundary, for its own epilogue and its neighbours' (QuartzNet's 256-channel blocks at
-// 64 x 751 frames: 256 tiles on 256 compute units, 110 -> 123 us per block); on 96-frame tiles it has two, and the hand-over is free.
-int split_tile_wm(int c_out, int batch, int t_out, bool chain) {
-  if (round_up(c_out, 32) > 256) return 1;
-  if (!chain) return 2;
-  const int n192 = batch * ((t_out + 191) / 192), n96 = batch * ((t_out + 95) / 96);
-  const int n_cu = cu_count();
-  return (n192 < 2 * n_cu && n96 >= 2 * n_cu) ? 1 : 2;
-}
+// Frames of a time tile for a layer of c_out output channels: 96 (x 512 channels) above 256 channels, else 192 (x 256): the 192-frame tiles have
+// the cheaper stage loop.  (96 x 256 tiles, NT = 1, exist for callers that ask for them through the tile rows of ts_tcs_desc.)
+int split_tile_wm(int c_out) { return round_up(c_out, 32) > 256 ? 1 : 2; }
 
 }  // namespace ts
-
-extern "C" int64_t ts_tcs_chain_workspace_bytes(int32_t batch, int32_t t_out, int32_t n_layers) {
-  if (batch <= 0 || t_out <= 0 || n_layers <= 0) return 0;
-  const int64_t n_tt = (t_out + 95) / 96;              // the finer of the two tile grids
-  return ((4 + (int64_t)n_layers * batch * n_tt) * 4 + 15) / 16 * 16;
-}
-
-extern "C" int ts_tcs_chain_fwd(const ts_tcs_desc* descs, int32_t n_layers, const void* const* x, const void* const* x_res,
-                                void* const* y, const int32_t* len, void* workspace, int64_t workspace_bytes, void* stream_) {
-  using namespace ts;
-  if (!descs || !x || !y || !len || n_layers < 1) return TS_EINVAL;
-  if (n_layers > TS_TCS_CHAIN_MAX) return TS_EUNSUPPORTED;
-  const ts_tcs_desc& d0 = descs[0];
-  if (d0.batch <= 0 || d0.c_out <= 0 || d0.t_out <= 0) return TS_EINVAL;
-  if (n_layers > 1 && (!workspace || workspace_bytes < ts_tcs_chain_workspace_bytes(d0.batch, d0.t_out, n_layers))) return TS_EINVAL;
-  if (reinterpret_cast<uintptr_t>(workspace) % 16) return TS_EINVAL;
-  const int both = TS_TCS_IN_TAILZERO | TS_TCS_OUT_ZERO_TAIL;
-  ChainArgs a{};
-  for (int l = 0; l < n_layers; ++l) {
-    const ts_tcs_desc& d = descs[l];
-    if (!x[l] || !y[l] || !d.pw_w || !d.bias) return TS_EINVAL;
-    if (d.c_res > 0 && (!x_res || !x_res[l] || !d.res_w)) return TS_EINVAL;
-    if (!d.dw_taps_raw || !d.pw_w16 || (d.c_res > 0 && !d.res_w16)) return TS_EUNSUPPORTED;
-    const bool same = d.batch == d0.batch && d.c_out == d0.c_out && d.t_in == d0.t_out && d.t_out == d0.t_out && d.pitch_in == d0.pitch_in &&
-                      d.pitch_out == d0.pitch_in && d.kernel == d0.kernel && d.padding == d0.padding && d.dw_ksteps == d0.dw_ksteps;
-    const bool shape = d.depthwise && d.stride == 1 && d.dilation == 1 && !d.out_fp32 && (d.flags & both) == both && !(d.flags & TS_TCS_TAPS_PHASE) &&
-                       d.kernel == 2 * d.padding + 1 && d.c_in > 0 && d.c_in % KC == 0 && d.c_res % KC == 0 && d.dw_ksteps % NKP == 0 &&
-                       (d.c_res == 0 || d.res_stride <= 1);
-    if (!same || !shape) return TS_EUNSUPPORTED;
-    if (l > 0 && (x[l] != y[l - 1] || d.c_in != d0.c_out)) return TS_EUNSUPPORTED;
-    for (int j = 0; j <= l; ++j)                       // a residual input written inside the launch would need its own wait
-      if (d.c_res > 0 && x_res[l] == y[j]) return TS_EUNSUPPORTED;
-    // 32-bit byte offsets inside the buffer descriptors
-    const int64_t cmax = d.c_in > d.c_out ? d.c_in : d.c_out;
-    if ((int64_t)d.batch * cmax * d.pitch_in * 2 + TS_GUARD_BYTES >= (1ll << 31)) return TS_EUNSUPPORTED;
-    if (d.c_res > 0 && (int64_t)d.batch * d.c_res * d.pitch_res * 2 >= (1ll << 31)) return TS_EUNSUPPORTED;
-    ChainLayer& L = a.layer[l];
-    L.x = static_cast<const unsigned short*>(x[l]);
-    L.xres = d.c_res > 0 ? static_cast<const unsigned short*>(x_res[l]) : nullptr;
-    L.y = static_cast<unsigned short*>(y[l]);
-    L.taps_raw = static_cast<const unsigned short*>(d.dw_taps_raw);
-    L.pw_w = static_cast<const unsigned short*>(d.pw_w16);
-    L.res_w = static_cast<const unsigned short*>(d.res_w16);
-    L.bias = d.bias;
-    L.c_in = d.c_in; L.c_res = d.c_res; L.pitch_res = d.c_res > 0 ? d.pitch_res : d.pitch_in; L.relu = d.relu;
-    L.kt_main = round_up(d.c_in, KC) / 16;
-    L.kt_res = round_up(d.c_res > 0 ? d.c_res : 1, KC) / 16;
-    L.wait_in = l > 0 ? 1 : 0;
-  }
-  a.len = len;
-  a.flags = static_cast<unsigned*>(workspace);
-  a.n_layers = n_layers;
-  a.batch = d0.batch; a.c_out = d0.c_out; a.pitch_in = d0.pitch_in; a.pitch_out = d0.pitch_out; a.t_out = d0.t_out;
-  a.kernel = d0.kernel; a.padding = d0.padding; a.dilation = 1;
-  a.zero_tail = 1;
-  const int npass = d0.dw_ksteps / NKP;
-  if (npass > 7) return TS_EUNSUPPORTED;
-  const int padl4 = round_up(d0.padding, 4);
-  a.padl8 = round_up(padl4, 8);
-  a.woff = a.padl8 - padl4;
-  const int WM = split_tile_wm(d0.c_out, d0.batch, d0.t_out, n_layers > 1);
-  const int TTp = 96 * WM;
-  const int n_ttp = (d0.t_out + TTp - 1) / TTp;
-  const int xe = round_up(a.woff + TTp + 4 * d0.dw_ksteps, 64);
-  bool fits = (n_ttp - 1) * TTp - a.padl8 + xe <= d0.pitch_in && d0.pitch_in - d0.t_in >= a.padl8 && d0.pitch_out >= n_ttp * TTp;
-  for (int l = 0; l < n_layers; ++l)
-    if (descs[l].c_res > 0 && descs[l].pitch_res < (n_ttp - 1) * TTp + round_up(TTp, 64)) fits = false;
-  if (!fits) return TS_EUNSUPPORTED;
-  return launch_split_chain(a, npass, xe, WM, 1, reinterpret_cast<hipStream_t>(stream_));
-}

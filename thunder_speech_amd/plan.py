@@ -195,12 +195,6 @@ class TcsLayer:
         d.bias = self.bias.data_ptr()
         return d
 
-    def chainable(self) -> bool:
-        """Static part of what ts_tcs_chain_fwd asks of a layer (the library checks the geometry against the tensors)."""
-        return (self.pre is None and self.depthwise and self.stride == 1 and self.dilation == 1 and self.taps_raw is not None and self.pw16 is not None
-                and not self.out_fp32 and self.kernel == 2 * self.padding + 1 and self.c_in % KC == 0 and self.c_res % KC == 0
-                and self.res_stride == 1)
-
     def run(self, x: torch.Tensor, t_in: int, len_in: torch.Tensor, x_res: Optional[torch.Tensor] = None,
             t_res: int = 0, len_res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
             in_tail_zero: bool = False, zero_tail: bool = False, se_y: Optional[torch.Tensor] = None,
@@ -260,78 +254,6 @@ class TcsLayer:
         st = L.ts_tcs_subblock_fwd(C.byref(d), *args)
         _lib.check(st, "ts_tcs_subblock_fwd")
         return out, t_out
-
-
-# Chain launches (ts_tcs_chain_fwd: all repeats of a block in ONE persistent launch).  OFF by default: measured on one MI355X (round 4, C2 encoder,
-# same box, profiles/round4_chain_ab.txt + DESIGN.md 3.1): one launch per sub-block 2.87 ms, chains 3.00 ms.  The launch gaps a chain removes are worth
-# 6 %, but its bookkeeping costs registers in a kernel that has none to spare (+6 %: spills in the producers' stage loop) and its hand-over
-# needs write-through stores / L1-bypassing loads (+3.5 %).  True: chain where a workgroup has at least two tiles per layer; "force": wherever the
-# library can (tests, tools); False: one launch per sub-block.
-CHAIN = False
-_CHAIN_WS = {}
-_N_CU = {}
-
-
-def _split_tiles(c_out: int, b: int, t: int, n_cu: int) -> int:
-    """Tiles per layer of the split kernel (mirror of split_tile_wm / launch_split in csrc/tcs_split.hip)."""
-    if round_up(c_out, 32) > 256:
-        return b * ((t + 95) // 96) * ((round_up(c_out, 32) + 511) // 512)
-    n192, n96 = b * ((t + 191) // 192), b * ((t + 95) // 96)
-    return n96 if (n192 < 2 * n_cu and n96 >= 2 * n_cu) else n192
-
-
-def run_chain(layers: Sequence["TcsLayer"], x: torch.Tensor, t: int, len_i32: torch.Tensor, outs: Sequence[torch.Tensor],
-              x_res: Optional[torch.Tensor] = None) -> bool:
-    """Consecutive sub-blocks of one block as ONE persistent launch (ts_tcs_chain_fwd): layer l reads outs[l - 1] (x for l = 0) and writes
-    outs[l]; `x_res` is the residual input of the layers that have one (the block input).  All tensors are tail-zero arena buffers
-    [B, C, pitch] with `t` valid frames at most.  Returns False -- nothing launched -- when the library has no chain kernel for the
-    geometry or the chain would not pay: the caller then runs the layers one by one.
-    When it pays (measured): with at least two tiles per workgroup and layer a tile's inputs were published a whole tile
-    earlier, so the hand-over is free and the launch gaps go; with a single tile per workgroup every layer boundary waits for the
-    workgroup's own epilogue AND its neighbours', which costs more than the kernel boundary it replaces (QuartzNet's 256-channel
-    blocks at 64 x 751 frames on 192-frame tiles: 110 -> 123 us per block)."""
-    n = len(layers)
-    if not CHAIN or n < 2 or n > 16 or not all(l.chainable() for l in layers):
-        return False
-    dev = x.device
-    if CHAIN != "force":
-        n_cu = _N_CU.get(dev.index)
-        if n_cu is None:
-            n_cu = _N_CU[dev.index] = torch.cuda.get_device_properties(dev).multi_processor_count
-        if _split_tiles(layers[0].c_out, x.shape[0], t, n_cu) < 2 * n_cu:
-            return False
-    L = _lib.lib()
-    b = x.shape[0]
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    descs = (_lib.TcsDesc * n)()
-    xs, rs, ys = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
-    src = x
-    for i, layer in enumerate(layers):
-        d = layer.desc(b, t, src.shape[2], outs[i].shape[2], True, True, pitch_res=x_res.shape[2] if layer.c_res else 0, t_res=t)
-        C.memmove(C.byref(descs, i * C.sizeof(_lib.TcsDesc)), C.byref(d), C.sizeof(_lib.TcsDesc))
-        xs[i], ys[i] = src.data_ptr(), outs[i].data_ptr()
-        rs[i] = x_res.data_ptr() if layer.c_res else None
-        src = outs[i]
-    need = L.ts_tcs_chain_workspace_bytes(b, t, n)
-    key = (id(layers[0]), b, t, n, str(dev), stream)
-    ws = _CHAIN_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _CHAIN_WS[key] = torch.zeros(need, dtype=torch.uint8, device=dev)
-    st = L.ts_tcs_chain_fwd(descs, n, xs, rs, ys, len_i32.data_ptr(), ws.data_ptr(), ws.numel(), stream)
-    if st == _lib.TS_EUNSUPPORTED:
-        return False
-    _lib.check(st, "ts_tcs_chain_fwd")
-    return True
-
-
-def chain_status(layers: Sequence["TcsLayer"]) -> int:
-    """Status words of the chain launches that start at layers[0] (0 = every wait inside them ended normally); synchronises.
-    For tests and tools only."""
-    bad = 0
-    for key, ws in _CHAIN_WS.items():
-        if key[0] == id(layers[0]):
-            bad |= int(ws[:4].view(torch.int32)[0].item())
-    return bad
 
 
 def make_im2col_layer(device, *, w2: torch.Tensor, src_channels: int, kernel: int, stride: int, dilation: int, padding: int,
@@ -400,4 +322,4 @@ def make_tcs_layer(device, *, dw_w: Optional[torch.Tensor], pw_w: torch.Tensor, 
                     pw=pack_pw_frags(wf).to(device), bias=pad_bias(shift).to(device), c_res=c_res, res_w=res_p,
                     res_stride=res_stride, out_fp32=out_fp32, taps_phase=taps_phase, nk_phase=nk_phase, taps_raw=taps_raw,
                     taps_phase_raw=taps_phase_raw,
-                    pw16=None if out_fp32 else pack_pw_frags16(wf).to(device), res_w16=res_p16)
+                    pw16=pack_pw_frags16(wf).to(device), res_w16=res_p16)

@@ -289,15 +289,7 @@ class _FusedBlockBase(nn.Module):
         out_lengths = lengths
         subs = list(self._sub_blocks())
         n = len(layers)
-        # the repeats whose output stays inside the library (all of an internal block, all but the last of a caller-visible one) as ONE
-        # persistent launch when the library has a chain kernel for the geometry (ts_tcs_chain_fwd: stride-1 "same" depthwise layers)
-        n_chain = n if internal else n - 1
-        first = 0
-        if n_chain >= 2 and x0_tz and all(l.chainable() for l in layers[:n_chain]):
-            outs = [_t.arena(("enc", slot, r % 2), b, layers[r].c_out, t, xi.device) for r in range(n_chain)]
-            if _plan.run_chain(layers[:n_chain], x0, t, len_in, outs, x_res=x0):
-                h, th, h_tz, first = outs[-1], t, True, n_chain
-        for r in range(first, n):
+        for r in range(n):
             layer = layers[r]
             geom = subs[r][0] if subs[r][0] is not None else subs[r][1]
             last = r == n - 1

@@ -6,7 +6,19 @@ CODE = r'''
 import sys, os, torch
 sys.path.insert(0, %r)
 import bench
-from tools.bench_chain import time_graph
+def time_graph(fn, steps):
+    side = torch.cuda.Stream(); g = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+        with torch.cuda.graph(g, stream=side):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
 dev = torch.device("cuda", 0)
 m = bench.build_model(dev)
 wav = (0.1 * torch.randn(64, 240000, generator=torch.Generator().manual_seed(1234))).to(dev)

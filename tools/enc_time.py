@@ -24,11 +24,4 @@ def time_graph(fn, steps):
 with torch.no_grad():
     f, fl = m.audio_transform(wav, ln)
     m.encoder(f, fl); torch.cuda.synchronize()
-    from thunder_speech_amd import plan
-    res = []
-    for chain in (True, False):
-        if hasattr(plan, "CHAIN"):
-            plan.CHAIN = chain
-        m.encoder(f, fl); torch.cuda.synchronize()
-        res.append(f"chain={chain}: " + " ".join(f"{time_graph(lambda: m.encoder(f, fl), 40):.3f}" for _ in range(2)))
-    print("encoder ms:", " | ".join(res), "tree", ROOT, os.environ.get("TS_LIB_VARIANT", ""))
+    print("encoder ms:", " ".join(f"{time_graph(lambda: m.encoder(f, fl), 40):.3f}" for _ in range(3)), "tree", ROOT, os.environ.get("TS_LIB_VARIANT", ""))
