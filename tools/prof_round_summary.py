@@ -60,7 +60,7 @@ if rows:
     bj = last_json("bench")
     if bj:
         json.dump(bj, open(os.path.join(out, f"round{R}_bench.json"), "w"), indent=1)
-        md += ["## C2 headline: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 5 --no-extra --no-cpu-baseline`", "",
+        md += ["## C2 headline: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 5 --no-extra --no-cpu-baseline --no-trained-check`", "",
                f"bench line of the profiled run: value {bj['value']:.0f} {bj['unit']}, {bj['ms_per_step']:.3f} ms/step, encoder {bj['roofline']['encoder_ms']:.3f} ms, "
                f"avg_launch_us {bj['roofline']['avg_launch_us']:.1f} (HIP events), roofline.frac {bj['roofline']['frac']:.3f}", ""]
     t, tot = md_table(rows)
@@ -81,7 +81,7 @@ for name in ("fetch", "write"):
     pmc[name] = (agg, cnt)
 if pmc["fetch"][1] and pmc["write"][1]:
     fkb = pmc["fetch"][0] / pmc["fetch"][1]; wkb = pmc["write"][0] / pmc["write"][1]
-    traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline`, all ts::tcs_* dispatches",
+    traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-trained-check`, all ts::tcs_* dispatches",
                "dispatches": pmc["fetch"][1], "fetch_size_kb_per_dispatch": fkb, "write_size_kb_per_dispatch": wkb,
                "gfx950_correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: 128-B requests tallied at 64 B); WRITE_SIZE exact",
                "traffic_bytes_per_launch": fkb * 1024 * 2 + wkb * 1024}
@@ -95,7 +95,8 @@ for name, title, key, anchor in (("c3", "C3 Citrinet-1024 inference 32 x 20 s (`
                          ("c4p2", "C4 phase 2: everything trainable, bf16 activations, fwd + bwd from one hipGraph (`TS_C4_ONLY=c4_phase2 tools/bench_extra.py c4`)", "c4_phase2", "ctc_kernel"),
                          ("c4p2f", "C4 phase 2 in fp32 (every GEMM on the f32 matrix-core kernel of csrc/gemm_f32.hip; no vendor library is linked) "
                                    "(`TS_C4_ONLY=c4_phase2_fp32 tools/bench_extra.py c4`)", "c4_phase2_fp32", "ctc_kernel"),
-                         ("c5", "C5 wav2vec2-large inference 16 x 20 s, own GEMM (`tools/bench_extra.py c5`)", "c5", "w2v_posconv_mfma_kernel")):
+                         ("c5", "C5 wav2vec2-large inference 16 x 20 s, own GEMM (`tools/bench_extra.py c5`)", "c5", "w2v_posconv_mfma_kernel"),
+                         ("c5ft", "wav2vec2-large fine-tuning step 8 x 10 s, f32, eager launches (`tools/bench_extra.py c5_finetune`)", "c5_finetune", "w2v_conv0_finalize_kernel")):
     rows, span, traced = trace(name, anchor)
     if not rows:
         md += [f"## {title}", "", "(no trace)", ""]
