@@ -86,7 +86,8 @@ def test_c5_wav2vec2_large_16x20s_clip0_matches_oracle():
     assert float(err.max()) <= 0.1 and float(err.pow(2).mean().sqrt()) <= 0.015, (float(err.max()), float(err.pow(2).mean().sqrt()))
 
 
-BF16_LOSS_TOL, BF16_DEC_TOL, BF16_BLK_TOL = 1.0, 1.0, 1.0          # provisional: set from the first measurement
+# bf16 rows: measured 6.4e-4 / 1.7e-2 / 6.7e-2 on this case (round 5); the tolerances are ~3x that
+BF16_LOSS_TOL, BF16_DEC_TOL, BF16_BLK_TOL = 3e-3, 5e-2, 2e-1
 # tolerances: (loss, relative), (decoder gradients, relative L2), (last block's gradients, relative L2)
 C4_TOL = {"fp32": (1e-4, 2e-3, 1e-2), "bf16": (BF16_LOSS_TOL, BF16_DEC_TOL, BF16_BLK_TOL)}
 

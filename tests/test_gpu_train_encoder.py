@@ -304,6 +304,10 @@ def test_graphed_training_step_follows_the_eager_step(act, optimizer, segments):
         step = GraphedTrainStep(m1, opt1, sync1, max_target_len=16, segments=segments)
         n_buckets = len(sync1.buckets)
         graphed = [float(step((wavs[i % 2], lengths, texts[i % 2]))) for i in range(4)]
+        if optimizer == "fused":
+            # a segmented step updates bucket k's parameters on the side stream right behind bucket k's exchange: every parameter still takes exactly
+            # one optimizer step per training step
+            assert all(opt1.state[p]["step"] == 4 for grp in opt1.param_groups for p in grp["params"])
         sync1.close()
     finally:
         train_ops.set_activation_dtype("fp32")

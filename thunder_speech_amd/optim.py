@@ -22,8 +22,12 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    supports_subset = True       # step(only=...) updates a subset of the parameters (train_graph: a bucket's update behind its exchange)
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, only=None):
+        """`only`: a set of id(parameter) -- update just those (each parameter still takes exactly one update per training step: the caller
+        partitions the parameters over its calls).  Runs on the CURRENT stream."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -33,7 +37,7 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             todo = []
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only is not None and id(p) not in only):
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdamW: contiguous fp32 GPU parameters only (no CPU fallback)")
