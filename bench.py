@@ -189,7 +189,8 @@ def main():
         from tools import train_margin_model as tmm
         t_tr = time.perf_counter()
         module, hist = tmm.train(device, verbose=False)
-        trained_info = {"train_seconds": time.perf_counter() - t_tr, "ctc_loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1}
+        trained_info = {"train_seconds": time.perf_counter() - t_tr, "ctc_loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1,
+                        "validation_margin": hist[-1][2]}
         wav = tmm.tone_clips(B, S, 4242 + rank, "cpu")[0].to(device)     # the task's own clips: transcripts of noise would mean nothing
     else:
         module = build_model(device)
@@ -305,7 +306,8 @@ def main():
                     else:
                         t_tr = time.perf_counter()
                         m_tr, hist = tmm.train(device, verbose=False)
-                        info = {"train_seconds": time.perf_counter() - t_tr, "ctc_loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1}
+                        info = {"train_seconds": time.perf_counter() - t_tr, "ctc_loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1,
+                        "validation_margin": hist[-1][2]}
                     result["check_trained"] = dict(tmm.evaluate(m_tr, device, batch=B, seconds=S, n_check=n_chk), train=info)
                     del m_tr
                 except Exception as e:                    # noqa: BLE001 -- recorded; the headline line must still come out

@@ -2,7 +2,7 @@
 
 The reference pins `predict()` with a pretrained checkpoint (tests/quartznet/test_module_qn.py:17-30), which needs the network.  Here the
 QuartzNet15x5 weights are trained on this box by the repository's own fine-tuning path (tools/train_margin_model.py: hipGraph-replayed CTC
-training on a synthetic two-tone-burst task, ~25 s of GPU time), then the HIP bf16 inference path and the fp32 CPU oracle transcribe the same
+training on a synthetic tone task, ~25 s of GPU time), then the HIP bf16 inference path and the fp32 CPU oracle transcribe the same
 64 x 15 s batch (BASELINE.json configs[1]); 16 clips are compared on every frame."""
 import pytest
 import torch

@@ -58,7 +58,8 @@ def frame_labels(batch: int, frames: int, kind: str, g: torch.Generator) -> torc
     """int64 [batch, frames]: the label sounding in each encoder frame, -1 = silence.
       "bursts": the task proper -- per 10-frame slot one burst (85 %) of 3-6 frames (60-120 ms), each frame of the burst another label than the
                 frame before (a little chirp of 3-6 tones), starting 1 .. 9 - d frames into the slot (>= 2 silent frames between bursts);
-      "dense" : every frame its own label, never the label of the frame before -> the transcript has exactly `frames` labels;
+      "dense" : every frame its own label, never the label of the frame before nor its neighbour in frequency (the 20 ms analysis window that
+                straddles two frames sees both tones) -> the transcript has exactly `frames` labels;
       "onoff" : one label per clip, sounding in the even frames only -> the transcript repeats it (frames + 1) / 2 times, and CTC must put a blank
                 between equal labels, i.e. on every silent frame;
       "warm"  : first half of the batch dense, second half onoff;   "mix": half bursts, a quarter dense, a quarter onoff.
@@ -69,8 +70,8 @@ def frame_labels(batch: int, frames: int, kind: str, g: torch.Generator) -> torc
         kinds = ("dense", "onoff") if kind == "warm" else ("bursts", "dense", "onoff")
         return torch.cat([frame_labels(b - a, frames, k, g) for a, b, k in zip(cuts[:-1], cuts[1:], kinds) if b > a], 0)
     if kind == "dense":
-        step = torch.randint(1, n_lab, (batch, frames), generator=g)                 # label[j] = label[j - 1] + step (mod 28), step != 0
-        step[:, 0] = torch.randint(0, n_lab, (batch,), generator=g)
+        step = torch.randint(2, n_lab - 1, (batch, frames), generator=g)             # label[j] = label[j - 1] + step (mod 28), 2 <= step <= 26:
+        step[:, 0] = torch.randint(0, n_lab, (batch,), generator=g)                  # never the same tone, never the neighbouring one
         return torch.cumsum(step, 1) % n_lab
     if kind == "onoff":
         lab = torch.randint(0, n_lab, (batch, 1), generator=g).expand(batch, frames).clone()
@@ -82,7 +83,7 @@ def frame_labels(batch: int, frames: int, kind: str, g: torch.Generator) -> torc
     present = torch.rand(batch, slots, generator=g) < 0.85
     d = torch.randint(BURST_FRAMES[0], BURST_FRAMES[1] + 1, (batch, slots), generator=g)
     a = 1 + (torch.rand(batch, slots, generator=g) * (SLOT_FRAMES - 1 - d).float()).floor().long()
-    step = torch.randint(1, n_lab, (batch, slots, SLOT_FRAMES), generator=g)         # inside a burst every frame moves on to another label
+    step = torch.randint(2, n_lab - 1, (batch, slots, SLOT_FRAMES), generator=g)     # inside a burst every frame moves on by 2 .. 26 tones (mod 28)
     step[:, :, 0] = torch.randint(0, n_lab, (batch, slots), generator=g)
     lab = torch.cumsum(step, 2) % n_lab
     j = torch.arange(SLOT_FRAMES)[None, None, :]
@@ -156,7 +157,7 @@ def build_module(device, seed: int = 0):
 # all-blank plateau for thousands of steps (measured on this model, profiles/round5_trained_transcripts.md: 3 000 steps at 32 x 10 s never left it);
 # on "dense" / "onoff" clips the loss is a per-frame cross-entropy, the network tells tones and silence apart within ~100 steps, and the burst clips
 # then bring their free alignment.  The single-alignment clips stay in every batch: they keep every frame's decision anchored.
-DEFAULT_SCHEDULE = ((100, 32, 10, "warm"), (1900, 32, 10, "mix"))
+DEFAULT_SCHEDULE = ((100, 32, 10, "warm"), (2400, 32, 10, "mix"))
 DEFAULT_LR = 2e-3
 
 
@@ -170,6 +171,19 @@ def greedy_label_error(module, device, seed: int = 99, batch: int = 8, seconds: 
         hyp = module.predict(wav)
     module.train(was_training)
     return float(omet.char_error_rate(hyp, texts))
+
+
+def validation_margin(module, device, batch: int = 64, seconds: int = 15, seed: int = 31337) -> float:
+    """Smallest top-1 / top-2 logit margin of the HIP inference path over every frame of a validation batch (device only)."""
+    wav, lengths, _ = tone_clips(batch, seconds, seed, device)
+    was_training = module.training
+    module.eval()
+    with torch.no_grad():
+        logits, _ = module(wav, lengths)
+        top2 = logits.float().topk(2, dim=1).values
+        margin = float((top2[:, 0] - top2[:, 1]).min())
+    module.train(was_training)
+    return margin
 
 
 def train(device, schedule=DEFAULT_SCHEDULE, seed: int = 0, lr: float = DEFAULT_LR, log_every: int = 100, act: str = "bf16", verbose: bool = True):
@@ -209,6 +223,10 @@ def train(device, schedule=DEFAULT_SCHEDULE, seed: int = 0, lr: float = DEFAULT_
                     if not math.isfinite(v):
                         raise RuntimeError(f"training diverged at step {i}")
                 i += 1
+        # reported, not steered by: the smallest top-1 / top-2 logit margin of the HIP inference path over a validation batch of the evaluation
+        # shape (its own seed, no oracle involved).  "Train until that margin is >= 2" was tried and dropped: the minimum over 48 000 frames moves
+        # between 0.1 and 1.9 from one 400-step round to the next at any learning rate (profiles/round5_trained_transcripts.md)
+        hist.append((i - 1, float(hist[-1][1]), validation_margin(m, device)))
         torch.cuda.synchronize()
         sync.close()
     finally:
@@ -284,7 +302,7 @@ def evaluate(module, device, batch: int = 64, seconds: int = 15, n_check: int = 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--schedule", default=None, help="steps:clips:seconds[:kind][,...] with kind in bursts|dense|onoff|warm|mix; default: 100 warm steps, then 1900 mix steps, at 32 x 10 s")
+    ap.add_argument("--schedule", default=None, help="steps:clips:seconds[:kind][,...] with kind in bursts|dense|onoff|warm|mix; default: 100 warm steps, then 2400 mix steps, at 32 x 10 s")
     ap.add_argument("--lr", type=float, default=DEFAULT_LR)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--act", default="bf16")
@@ -304,7 +322,7 @@ def main():
     if args.no_eval:
         return
     res = evaluate(module, device, n_check=args.n_check)
-    res["train"] = {"schedule": [list(x) for x in schedule], "seconds": t_train, "loss_first_last": [hist[0][1], hist[-1][1]], "lr": args.lr, "seed": args.seed,
+    res["train"] = {"schedule": [list(x) for x in schedule], "seconds": t_train, "loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1, "validation_margin": hist[-1][2], "lr": args.lr, "seed": args.seed,
                     "act": args.act}
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
