@@ -362,14 +362,16 @@ int ts_train_bn2_add_relu_fwd(const void* va, const void* sums_a, const float* g
 /* The block tail in ONE launch each way (ABI v9): a workgroup owns a channel and keeps its batch x ceil(t / 512) row units of both branches in
  * registers between the statistics and the apply step -- no clip-group sums, no second pass.  Forward = ts_train_bn_stats x 2 +
  * ts_train_bn2_add_relu_fwd (quartznet/blocks.py:332-337 in train mode: batch statistics over all B * T frames, running-statistics update);
- * backward = ts_train_bn_bwd(relu = 1) of both branches with the shared gate taken from `out` (dgamma / dbeta are overwritten).
+ * backward = ts_train_bn_bwd(relu = 1) of both branches with the shared gate taken from `out` (dgamma / dbeta are overwritten); `dout2` (may be NULL):
+ * a second gradient of `out`, added to `dout` for frames < len2[clip] (len2 NULL: all frames) -- the sum ts_train_add would form when the block's
+ * output feeds the next block's main and residual branch.
  * TS_EUNSUPPORTED when batch * ceil(t / 512) exceeds 32 (bf16 rows) / 16 (f32 rows): use the two-step entry points then. */
 int ts_train_bn2_add_relu_chan_fwd(const void* va, const float* gamma_a, const float* beta_a, float eps_a, float* mean_rstd_a,
                                    float* running_mean_a, float* running_var_a, float momentum_a, int64_t* nbt_a, const void* vb,
                                    const float* gamma_b, const float* beta_b, float eps_b, float* mean_rstd_b, float* running_mean_b,
                                    float* running_var_b, float momentum_b, int64_t* nbt_b, void* out, int32_t batch, int32_t channels, int32_t t,
                                    int32_t pitch, int32_t act, void* stream);
-int ts_train_bn2_chan_bwd(const void* dout, const void* out, const void* va, const void* vb, const float* gamma_a, const float* mean_rstd_a,
+int ts_train_bn2_chan_bwd(const void* dout, const void* dout2, const int32_t* len2, const void* out, const void* va, const void* vb, const float* gamma_a, const float* mean_rstd_a,
                           const float* gamma_b, const float* mean_rstd_b, void* dva, void* dvb, float* dgamma_a, float* dbeta_a, float* dgamma_b,
                           float* dbeta_b, int32_t batch, int32_t channels, int32_t t, int32_t pitch, int32_t act, void* stream);
 int ts_train_bn_bwd_sums(const void* g, const void* v, const float* gamma, const float* mean_rstd, const float* dgamma, const float* dbeta,

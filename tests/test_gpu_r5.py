@@ -135,12 +135,28 @@ def test_block_tail_in_one_launch_each_way_matches_float64_autograd(act, b, c, t
     dva, dvb = T.alloc(b, c, t, DEV, dt), T.alloc(b, c, t, DEV, dt)
     dga, dba, dgb, dbb = (torch.full((c,), float("nan"), device=DEV) for _ in range(4))
     out_ref = rows(out64.detach().float().to(dt).float())
-    _lib.check(L.ts_train_bn2_chan_bwd(_ptr(dout_d), _ptr(out_ref), _ptr(va_d), _ptr(vb_d), _ptr(ga_d), _ptr(mra), _ptr(gb_d), _ptr(mrb), _ptr(dva), _ptr(dvb),
+    _lib.check(L.ts_train_bn2_chan_bwd(_ptr(dout_d), None, None, _ptr(out_ref), _ptr(va_d), _ptr(vb_d), _ptr(ga_d), _ptr(mra), _ptr(gb_d), _ptr(mrb), _ptr(dva), _ptr(dvb),
                                        _ptr(dga), _ptr(dba), _ptr(dgb), _ptr(dbb), b, c, t, pitch, code, st), "bwd")
     for got, want in ((dva, ref_in[0].grad), (dvb, ref_in[1].grad), (dga, ref_in[2].grad), (dba, ref_in[3].grad), (dgb, ref_in[4].grad), (dbb, ref_in[5].grad)):
         s_ = max(float(want.abs().max()), 1e-6)
         assert torch.isfinite(got.float()).all()
         assert float((got.float().cpu().double() - want).abs().max()) <= (2e-2 if act == "bf16" else 1e-4) * s_
+    # the same gradient arriving as TWO tensors (the block output fed the next block's main and residual branch): dout = d1 + mask(d2, len2) is
+    # formed inside the kernel -- equal to the one-tensor call on the pre-added sum
+    lens2 = torch.tensor([t - (7 * i) % max(t // 3, 1) for i in range(b)], dtype=torch.int32)
+    d2 = mk(1.0, 0.0)
+    keep = (torch.arange(t)[None, None, :] < lens2[:, None, None]).float()
+    summed = rows((dout + d2 * keep).to(dt).float())
+    d2_d = rows(d2)
+    outs = []
+    for first, second, ln in ((summed, None, None), (dout_d, d2_d, lens2.to(DEV))):
+        o = [T.alloc(b, c, t, DEV, dt), T.alloc(b, c, t, DEV, dt)] + [torch.empty(c, device=DEV) for _ in range(4)]
+        _lib.check(L.ts_train_bn2_chan_bwd(_ptr(first), _ptr(second) if second is not None else None, _ptr(ln) if ln is not None else None, _ptr(out_ref),
+                                           _ptr(va_d), _ptr(vb_d), _ptr(ga_d), _ptr(mra), _ptr(gb_d), _ptr(mrb), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3]),
+                                           _ptr(o[4]), _ptr(o[5]), b, c, t, pitch, code, st), "bwd2")
+        outs.append(o)
+    for x1, x2 in zip(*outs):
+        assert torch.equal(x1, x2) if act == "bf16" else float((x1 - x2).abs().max()) <= 1e-5 * max(float(x1.abs().max()), 1e-6)
 
 
 @pytest.mark.parametrize("b,c_in,c_out,t,relu,ragged", [(64, 1024, 29, 751, False, False), (3, 256, 11, 37, True, True), (5, 128, 32, 300, False, True),

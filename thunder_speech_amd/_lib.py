@@ -165,7 +165,7 @@ def lib() -> C.CDLL:
     L.ts_train_bn_bwd_sums.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ts_train_bn2_add_relu_fwd.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, f32, vp] * 2 + [vp, i32, i32, i32, i32, i32, vp]
     L.ts_train_bn2_add_relu_chan_fwd.argtypes = [vp, vp, vp, f32, vp, vp, vp, f32, vp] * 2 + [vp, i32, i32, i32, i32, i32, vp]
-    L.ts_train_bn2_chan_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, i32, vp]
+    L.ts_train_bn2_chan_bwd.argtypes = [vp] * 16 + [i32, i32, i32, i32, i32, vp]
     L.ts_train_bn2_add_relu_chan_fwd.restype = L.ts_train_bn2_chan_bwd.restype = C.c_int
     L.ts_train_pack_pw_multi.argtypes = [vp, i32, i64, vp]
     L.ts_train_pwconv_wgrad_workspace.argtypes = [i32, i32, i32]

@@ -1410,7 +1410,8 @@ __global__ __launch_bounds__(256) void bn2_fwd_chan_kernel(const Bn2FwdArgs g) {
 }
 
 struct Bn2BwdArgs {
-  const void* dout; const void* out; const void* va; const void* vb;
+  const void* dout; const void* dout2; const int* len2;     // dout2 (may be NULL): a second gradient of `out`, counted for frames < len2[clip] only
+  const void* out; const void* va; const void* vb;
   const float* gamma_a; const float* mr_a; const float* gamma_b; const float* mr_b;
   void* dva; void* dvb;
   float* dgamma_a; float* dbeta_a; float* dgamma_b; float* dbeta_b;
@@ -1444,6 +1445,17 @@ __global__ __launch_bounds__(256) void bn2_bwd_chan_kernel(const Bn2BwdArgs g) {
       xb[u] = R::load(static_cast<const T*>(g.vb) + off[u]);
       dr[k] = R::load(static_cast<const T*>(g.dout) + off[u]);
       orr[k] = R::load(static_cast<const T*>(g.out) + off[u]);
+      if (g.dout2) {
+        // the block's output fed two consumers (the next block's main and residual branch): their gradients are added HERE instead of in a pass
+        // of their own (Fork.backward's ts_train_add); the residual branch's input mask zeroes its share from the clip's length on
+        float d1[8], d2[8];
+        R::widen(dr[k], d1);
+        R::widen(R::load(static_cast<const T*>(g.dout2) + off[u]), d2);
+        const int l2 = g.len2 ? g.len2[b] : 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d1[j] += i + j < l2 ? d2[j] : 0.f;
+        dr[k] = R::narrow(d1);                     // bf16 rows: rounded like the stored sum of the separate pass
+      }
     }
 #pragma unroll
     for (int k = 0; k < UB; ++k) {
@@ -1902,7 +1914,7 @@ extern "C" int ts_train_bn2_add_relu_chan_fwd(const void* va, const float* gamma
 }
 
 /* Backward of the block tail, both branches, one launch (same budget rule) */
-extern "C" int ts_train_bn2_chan_bwd(const void* dout, const void* out, const void* va, const void* vb, const float* gamma_a, const float* mean_rstd_a,
+extern "C" int ts_train_bn2_chan_bwd(const void* dout, const void* dout2, const int32_t* len2, const void* out, const void* va, const void* vb, const float* gamma_a, const float* mean_rstd_a,
                                      const float* gamma_b, const float* mean_rstd_b, void* dva, void* dvb, float* dgamma_a, float* dbeta_a,
                                      float* dgamma_b, float* dbeta_b, int32_t batch, int32_t ch, int32_t t, int32_t pitch, int32_t act, void* stream_) {
   if (!dout || !out || !va || !vb || !gamma_a || !gamma_b || !mean_rstd_a || !mean_rstd_b || !dva || !dvb || !dgamma_a || !dbeta_a || !dgamma_b || !dbeta_b)
@@ -1911,7 +1923,7 @@ extern "C" int ts_train_bn2_chan_bwd(const void* dout, const void* out, const vo
   const int units = batch * ((t + ROW_CHUNK - 1) / ROW_CHUNK);
   if (units > 4 * (act ? ChanRegs<bf16_t>::UMAX : ChanRegs<float>::UMAX) || (long long)batch * ch * pitch >= (1ll << 31)) return TS_EUNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  const Bn2BwdArgs g{dout, out, va, vb, gamma_a, mean_rstd_a, gamma_b, mean_rstd_b, dva, dvb, dgamma_a, dbeta_a, dgamma_b, dbeta_b, batch, ch, t, pitch};
+  const Bn2BwdArgs g{dout, dout2, len2, out, va, vb, gamma_a, mean_rstd_a, gamma_b, mean_rstd_b, dva, dvb, dgamma_a, dbeta_a, dgamma_b, dbeta_b, batch, ch, t, pitch};
   (void)hipGetLastError();
   TS_ACT(act, hipLaunchKernelGGL(bn2_bwd_chan_kernel<float>, dim3(ch), dim3(256), 0, stream, g),
          hipLaunchKernelGGL(bn2_bwd_chan_kernel<bf16_t>, dim3(ch), dim3(256), 0, stream, g));

@@ -264,6 +264,12 @@ class GradientSync:
         zeros), then make the compute stream wait for the exchange.  Resets the per-step bookkeeping.  `exchange=False` does the
         bookkeeping only (warm-up / capture passes of a graphed step, whose gradients are discarded)."""
         self._clean = False
+        from . import train_ops
+        if train_ops._PENDING_ADD:
+            # Fork.backward parked a pair of gradients for a block tail whose backward never ran: the sum would be missing from the step
+            n = len(train_ops._PENDING_ADD)
+            train_ops._PENDING_ADD.clear()
+            raise RuntimeError(f"GradientSync.finish: {n} parked gradient pair(s) were never consumed (train_ops.DEFER_FORK_ADD)")
         for p, view in zip(self.params, self._views):
             if p.grad is None:
                 if not self._zeroed:
@@ -285,6 +291,8 @@ class GradientSync:
         kernels of the training path then write their result straight into the bucket views and autograd adopts those tensors
         as `.grad` (train_ops.grad_out) -- no accumulate kernel, no copy.  Parameters that receive no gradient keep the zeros."""
         self.flat.zero_()
+        from . import train_ops
+        train_ops._PENDING_ADD.clear()                 # gradient pairs a previous, interrupted backward pass may have left parked
         self._clean = True
         self._zeroed = True
         self._claimed.clear()

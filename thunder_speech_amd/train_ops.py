@@ -490,6 +490,21 @@ def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor, len_u: Tensor = No
     return du, dw
 
 
+# Gradients of a block output that feeds the next block's main AND residual branch: Fork.backward parks the pair here instead of adding them
+# (ts_train_add, 9 us x 15 per QuartzNet15x5 step) when the tensor came out of a one-launch block tail, whose backward kernel reads both
+# (ts_train_bn2_chan_bwd's dout2).  Entries live from one autograd node to the next of the same backward pass; GradientSync clears leftovers.
+DEFER_FORK_ADD = True
+_PENDING_ADD = {}
+
+
+def take_pending_add(dout: Tensor):
+    """(second gradient, its length mask) parked for `dout` by Fork.backward, or (None, None)."""
+    ent = _PENDING_ADD.pop(dout.data_ptr(), None)
+    if ent is None or ent[0] is not dout and ent[0].data_ptr() != dout.data_ptr():
+        return None, None
+    return ent[1], ent[2]
+
+
 class Fork(torch.autograd.Function):
     """x -> (x, x) for a tensor with two consumers (a block input: main branch + residual branch).  The backward pass adds the two
     gradients with one kernel on activation rows; autograd's own accumulation (an ATen add) leaves the row layout, which costs a
@@ -498,6 +513,8 @@ class Fork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res_len=None):
         ctx.res_len = res_len          # int32 lengths: the second output feeds a MaskedConv1d whose input mask's backward is applied HERE
+        # x is the output of a one-launch block tail (block_tail tags it): its backward kernel adds the two gradients itself
+        ctx.defer_add = bool(getattr(x, "_ts_tail_out", False)) and DEFER_FORK_ADD
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
@@ -508,6 +525,11 @@ class Fork(torch.autograd.Function):
             return (g1 if g2 is None else g2), None
         dtype = g1.dtype if is_act(g1) else (g2.dtype if is_act(g2) else _ACT_DTYPE)
         g1, g2 = _import(g1, dtype), _import(g2, dtype)
+        if ctx.defer_add and chan_fits(g1.shape[0], g1.shape[2], g1.dtype):
+            # the consumer is BlockTail.backward of the previous block: hand it both gradients (keyed by the first one's address; the entry keeps
+            # the tensors alive, so the address cannot be reused while it is pending)
+            _PENDING_ADD[g1.data_ptr()] = (g1, g2, ctx.res_len)
+            return g1, None
         out = alloc_like(g1)
         ln = ctx.res_len
         st = _lib.lib().ts_train_add(g1.data_ptr(), g2.data_ptr(), ln.data_ptr() if ln is not None else None, g1.shape[1], out.data_ptr(),
@@ -1035,12 +1057,19 @@ class BlockTail(torch.autograd.Function):
         L = _lib.lib()
         va, vb, out, ga, gb, mra, mrb = ctx.saved_tensors
         b, c, t = va.shape
+        d2, len2 = take_pending_add(dout)
         dout = _g(dout, out)
+        if d2 is not None and not chan_fits(b, t, va.dtype):      # cannot happen (Fork checks the same condition); kept correct anyway
+            summed = alloc_like(dout)
+            _lib.check(L.ts_train_add(dout.data_ptr(), d2.data_ptr(), len2.data_ptr() if len2 is not None else None, c, summed.data_ptr(), b * c, t,
+                                      _pitch(dout), _code(dout), _s(dout)), "ts_train_add")
+            dout, d2 = summed, None
         if chan_fits(b, t, va.dtype):
             dva, dvb = alloc_like(va), alloc_like(vb)
             dga, dba = grad_out(ctx.params[0], (c,)), grad_out(ctx.params[1], (c,))
             dgb, dbb = grad_out(ctx.params[2], (c,)), grad_out(ctx.params[3], (c,))
-            _lib.check(L.ts_train_bn2_chan_bwd(dout.data_ptr(), out.data_ptr(), va.data_ptr(), vb.data_ptr(), ga.data_ptr(), mra.data_ptr(), gb.data_ptr(),
+            _lib.check(L.ts_train_bn2_chan_bwd(dout.data_ptr(), d2.data_ptr() if d2 is not None else None, len2.data_ptr() if (d2 is not None and len2 is not None) else None,
+                                               out.data_ptr(), va.data_ptr(), vb.data_ptr(), ga.data_ptr(), mra.data_ptr(), gb.data_ptr(),
                                                mrb.data_ptr(), dva.data_ptr(), dvb.data_ptr(), dga.data_ptr(), dba.data_ptr(), dgb.data_ptr(), dbb.data_ptr(),
                                                b, c, t, _pitch(va), _code(va), _s(va)), "ts_train_bn2_chan_bwd")
             return dva, dga, dba, dvb, dgb, dbb, None
@@ -1062,6 +1091,8 @@ def block_tail(h: Tensor, r: Tensor) -> Tensor:
         raise RuntimeError("block_tail: both inputs must carry a pending BatchNorm without ReLU")
     cfg = ((ph[0], ph[2].eps, ph[3]), (pr[0], pr[2].eps, pr[3]))
     out = BlockTail.apply(h, ph[2].weight, ph[2].bias, r, pr[2].weight, pr[2].bias, cfg)
+    if cfg[0][0] is None and cfg[1][0] is None and chan_fits(h.shape[0], h.shape[2], h.dtype):
+        out._ts_tail_out = True          # a Fork that takes this tensor may leave the sum of its two gradients to this tail's backward kernel
     _bump_running(ph[2], ph[3])
     _bump_running(pr[2], pr[3])
     return out
