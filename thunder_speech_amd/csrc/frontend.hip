@@ -69,6 +69,12 @@ __device__ __forceinline__ void fft16(C2 (&a)[16]) {
   }
 }
 
+// A frame's 16 lanes live in ONE wave (4 frames per wave) and its scratch tile is private to them, so the exchanges inside a frame need no
+// workgroup barrier: LDS operations of a wave complete in issue order; this only stops the compiler from moving accesses across the hand-over.
+// (Round 5: five of the seven workgroup barriers per frame group became this; front end 121.5 -> 113 us on the same box.  A per-clip finalize
+// kernel for the normaliser's statistics -- instead of every normalize workgroup re-reducing the partial sums -- measured neutral and is not here.)
+__device__ __forceinline__ void frame_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 struct FeArgs {
   const float* wave;
   const int* wave_len;
@@ -193,18 +199,17 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
     for (int k1 = 0; k1 < 16; ++k1)
       *reinterpret_cast<f32x2*>(Y + (k1 * 17 + i) * 2) = cmul(v[k1], *reinterpret_cast<const f32x2*>(&tw256[(i * k1) & (NC - 1)]));
   }
-  __syncthreads();
-  if (pre && gn < n_groups) commit();                // every lane has read its samples of group g
+  frame_sync();
   {
     C2 v[16];
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) v[n2] = *reinterpret_cast<const f32x2*>(Y + (i * 17 + n2) * 2);
-    __syncthreads();
+    frame_sync();
     fft16(v);                                    // over n2 -> k2; bin = i + 16 k2
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<f32x2*>(Z + (i + 16 * k2) * 2) = v[k2];
   }
-  __syncthreads();
+  frame_sync();
   // ---- real-FFT split + power spectrum, bins k = i + 16 j (and bin 256 on lane 0) -> P (aliases Y) ------
   float* const P = Y;
   {
@@ -227,12 +232,12 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
         pw[j] = xr * xr + xi * xi;
       }
     }
-    __syncthreads();                              // all lanes of the frame are done reading Y/Z rows
+    frame_sync();                                 // all lanes of the frame are done reading Y/Z rows
 #pragma unroll
     for (int j = 0; j < 17; ++j)
       if (j < 16 || i == 0) P[i + 16 * j] = pw[j];
   }
-  __syncthreads();
+  frame_sync();
   // ---- sparse mel filters + log -------------------------------------------------------------------------
   const int f = f0 + fl;
   for (int m = i; m < a.n_mels; m += 16) {
@@ -244,7 +249,8 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
     fr[fl * FSZ + RED0 + m] = lm;
     if (f < a.n_frames) a.logmel[((size_t)b * a.n_frames + f) * a.n_mels + m] = lm;
   }
-  __syncthreads();
+  __syncthreads();                                   // every wave has long read its samples of group g and staged its frames' log-mel
+  if (pre && gn < n_groups) commit();                // the next group's samples (prefetched into registers above)
   // ---- partial statistics over the valid frames of this workgroup -----------------------------------------
   const int flen = a.wave_len[b] / a.hop + 1;      // floor(len / hop) + 1  (transform.py:182-184)
   if (tid == 0 && grp == 0) a.feat_len[b] = flen;
