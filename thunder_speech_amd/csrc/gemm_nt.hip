@@ -78,18 +78,12 @@ __device__ __forceinline__ float gelu_g(float x) { return 0.5f * x * (1.f + erf_
 // WMR: wave rows.  2: the 256 x 256 tile above, 8 waves.  1 (packed weights only): a 128 x 256 tile on 4 waves and 72 KiB of LDS, so that TWO
 // workgroups share a CU: they fall out of step by themselves, one's epilogue and cold prologue run under the other's k-loop, and the matrix
 // core is handed back and forth between the two waves of a SIMD without the stagger barriers.
-#ifndef TS_HALF_TWO_BARRIERS
-#define TS_HALF_TWO_BARRIERS 0
-#endif
 template <bool PB, int WMR = 2>
 __global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_kernel(const GemmArgs a) {
   static_assert(WMR == 2 || PB, "the half tile exists for packed weights only");
   constexpr int GMT = 128 * WMR;                                             // rows of this instantiation's tile
   constexpr int SLOTB = (PB && WMR == 1) ? GMT * GROWB : GSTAGEB;            // bytes of a ring slot (the half tile stages A only)
-#ifndef TS_HALF_RING
-#define TS_HALF_RING 4
-#endif
-  constexpr int RINGN = (PB && WMR == 1) ? TS_HALF_RING : GRING;             // half tile: 8 KiB slots; eight of them (distance 7) measured no better than four
+  constexpr int RINGN = (PB && WMR == 1) ? 4 : GRING;             // half tile: 8 KiB slots; eight of them (distance 7) measured no better than four
   constexpr int PD = RINGN - 1;                                              // A is requested PD half-stages ahead
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,7 +252,7 @@ __global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2)
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], cur[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (WMR == 2 || TS_HALF_TWO_BARRIERS) phase_barrier();   // one wave row: the barrier after LOAD already orders ring reads, DMA waits and refills
+      if (WMR == 2) phase_barrier();   // one wave row: the barrier after LOAD already orders ring reads, DMA waits and refills
     };
     int s = 0;
     for (; s + 2 <= S_; s += 2) {

@@ -555,11 +555,7 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
       v2f acc[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) acc[m] = v2f{0.f, 0.f};
-#ifndef DWV_NO_FIR
       fir_pair(xs + ((t8 >> 3) << 1), q, 0, k8, tp, acc);
-#else
-      acc[0] = xs[lane];
-#endif
       if (PH) store_phase(ya, acc, t0 + t8, lo); else store_pair(ya, ya + pitch, acc, t0 + t8, lo);
     }
     __builtin_amdgcn_wave_barrier();
@@ -776,7 +772,6 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
       __builtin_amdgcn_wave_barrier();
       const int nt = te - t0 < PT ? te - t0 : PT;
       const int i8 = 8 * lane;
-#ifndef DWV_NO_DX
       if (i8 < nt) {
         v2f acc[8];
 #pragma unroll
@@ -797,8 +792,6 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
         }
         if (PH) store_phase(dx + r0, acc, t0 + i8, li); else store_pair(dx + r0, dx + r0 + pitch, acc, t0 + i8, li);
       }
-#endif
-#ifndef DWV_NO_DW
       if (active) {
         const int per = round_up((nt + nq - 1) / nq, 8);
         const int lo_t = sl * per < nt ? sl * per : nt, hi_t = lo_t + per < nt ? lo_t + per : nt;
@@ -818,7 +811,6 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
           }
         }
       }
-#endif
       __builtin_amdgcn_wave_barrier();
     }
   }
