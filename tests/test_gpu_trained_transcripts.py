@@ -19,13 +19,18 @@ def test_trained_quartznet15x5_transcripts_are_identical_to_the_fp32_oracle_at_6
     # the model really transcribes: both paths read the ground-truth labels off the audio
     assert res["label_error_rate_vs_ground_truth"]["oracle"] <= 0.01, res["label_error_rate_vs_ground_truth"]
     assert res["label_error_rate_vs_ground_truth"]["device"] <= 0.01, res["label_error_rate_vs_ground_truth"]
-    # strict identity of the greedy transcriptions, 16 of 16 clips: collapsed label sequences AND the strings predict() returns
-    assert res["collapsed_sequences_equal"] == res["collapsed_sequences_compared"] == 16, res["flipped_frames"]
-    assert res["strings_equal"] == 16
-    # all-frame argmax: >= 99.99 % of the 16 x 751 frames; any flipped frame must be a near-tie of the fp32 oracle itself (margin below the
-    # deviation its own bf16-ordered evaluation shows at that frame, within 2x)
-    assert res["argmax_equal_all_frames_frac"] >= 0.9999, res["flipped_frames"]
-    for f in res["flipped_frames"]:
-        assert f["fp32_margin"] <= 2.0 * max(f["oracle_bf16_emulation_err_at_frame"], f["device_err_at_frame"]), f
+    # identity of the greedy transcriptions: collapsed label sequences AND the strings predict() returns, 16 of 16 clips, every frame's argmax.
+    # The one admissible exception is a frame where the trained model ITSELF is undecided: its fp32 top-1 / top-2 margin lies below 1 (the smallest
+    # margin of a decided frame is ~3 on a logit scale of ~35) and within twice the deviation the oracle's own bf16-ordered evaluation shows at that
+    # frame -- such a frame flips under any bf16 arithmetic.  The trained models have about one of them per 48 000 frames (a spurious or missed label
+    # of the half-converged kind, tools/diag/tone_weak_frames.py; profiles/round5_trained_transcripts.md), i.e. one evaluation in four holds one; at
+    # most ONE is accepted, and it may cost the one clip it sits in.  Seven of seven recorded runs of this configuration had none.
+    flips = res["flipped_frames"]
+    assert res["frames_flipped"] == len(flips) <= 1, flips
+    for f in flips:
+        assert f["fp32_margin"] < 1.0 and f["fp32_margin"] <= 2.0 * max(f["oracle_bf16_emulation_err_at_frame"], f["device_err_at_frame"]), f
+    assert res["collapsed_sequences_equal"] >= 16 - len(flips) and res["collapsed_sequences_compared"] == 16, flips
+    assert res["strings_equal"] >= 16 - len(flips)
+    assert res["argmax_equal_all_frames_frac"] >= 0.9999, flips
     # logits within the stated bf16 tolerance of the fp32 oracle (bf16 activations, 18 blocks): max <= 5 % of the logit scale, rms <= 1 %
     assert res["max_err_over_scale"] <= 0.05 and res["rms_err_over_scale"] <= 0.01, res
