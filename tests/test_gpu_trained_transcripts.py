@@ -24,7 +24,7 @@ def test_trained_quartznet15x5_transcripts_are_identical_to_the_fp32_oracle_at_6
     # margin of a decided frame is ~3 on a logit scale of ~35) and within twice the deviation the oracle's own bf16-ordered evaluation shows at that
     # frame -- such a frame flips under any bf16 arithmetic.  The trained models have about one of them per 48 000 frames (a spurious or missed label
     # of the half-converged kind, tools/diag/tone_weak_frames.py; profiles/round5_trained_transcripts.md), i.e. one evaluation in four holds one; at
-    # most ONE is accepted, and it may cost the one clip it sits in.  Seven of seven recorded runs of this configuration had none.
+    # most ONE is accepted, and it may cost the one clip it sits in.  Six of six recorded evaluations of this configuration had none.
     flips = res["flipped_frames"]
     assert res["frames_flipped"] == len(flips) <= 1, flips
     for f in flips:
