@@ -319,7 +319,9 @@ int ts_train_dwconv_fwd(const void* x, const int32_t* len_in, const int32_t* len
 /* len_out (may be NULL) in both directions: the forward zeroes y from len_out[b] on -- the re-masking the next MaskedConv1d applies
  * (quartznet/blocks.py:169-171) -- and the backward treats dy as zero there; no separate masking pass is needed then.
  * dw ACCUMULATES: dw += sum_{b,t} dy * x (float atomics over clip groups); hand in zeros for a plain gradient.  dw == NULL (here and in
- * ts_train_dwconv_bwd_bn): the weight is frozen -- only the data gradient is computed (and x is not read unless an input transform needs it). */
+ * ts_train_dwconv_bwd_bn): the weight is frozen -- only the data gradient is computed (and x is not read unless an input transform needs it).
+ * dx == NULL (ts_train_dwconv_bwd, stride > 1 geometries whose two gradients are separate launches, dw given): the input needs no gradient (the stem's
+ * input are the features) -- only the weight gradient is computed; TS_EINVAL for the fused stride-1 kernels, which form both in one pass. */
 int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* dx,
                         float* dw, int32_t batch, int32_t channels, int32_t t_in, int32_t t_out, int32_t kernel, int32_t stride,
                         int32_t dilation, int32_t padding, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream);

@@ -99,6 +99,9 @@ __device__ __forceinline__ float dither_noise(unsigned long long seed, int b, in
   return (k & 1) ? n1 : n0;
 }
 
+// DITHER is a template flag: the Philox code, unrolled into the staging of every sample, tripled the kernel's size (and spilled 49 SGPRs) for a
+// branch that eval mode never takes.
+template <bool DITHER>
 __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int span = (FPW - 1) * a.hop + NFFT;
@@ -128,42 +131,57 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   for (int j = tid; j < (a.n_mels + 1) * 2; j += 256) melo[j] = a.mel_off[j];
 
   // ---- signal staging, one frame group ahead: the samples of group g + grid travel global -> registers while group g
-  // is transformed, and go into `sig` as soon as the first FFT stage of g has read it ------------------------------
-  constexpr int NL = 12;                             // staged samples per thread held in registers (span <= 3072)
-  const bool pre = span <= 256 * NL;
-  float cur[NL], prv[NL];
-  auto fetch = [&](int g) {
-    const float* x = a.wave + (size_t)(g / a.nwg) * a.n_samples;
+  // is transformed, and go into `sig` as soon as the first FFT stage of g has read it.  Interior groups (no reflection, no
+  // clip end inside the span: all but two or three per clip) take 16-byte loads -- three per thread plus the sample in front
+  // of each for the pre-emphasis -- and 16-byte LDS writes; the others are staged element by element when their turn comes. ----
+  constexpr int NV = 3;                              // 16-byte groups per thread held in registers (span <= 3072)
+  const int span4 = round_up(span, 4) / 4;
+  const bool vec_ok = span4 <= 256 * NV && (T & 3) == 0 && ((FPW * a.hop) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.wave) & 15) == 0;
+  auto interior = [&](int g) {
     const int k0 = (g % a.nwg) * FPW * a.hop - NFFT / 2;
+    return vec_ok && k0 >= 4 && k0 + 4 * span4 <= T;
+  };
+  f32x4 cur[NV];
+  float prv[NV];
+  auto fetch = [&](int g) {
+    const float* x = a.wave + (size_t)(g / a.nwg) * a.n_samples + ((g % a.nwg) * FPW * a.hop - NFFT / 2);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      int k = k0 + tid + 256 * j;
-      k = k < 0 ? -k : k;
-      k = k >= T ? 2 * (T - 1) - k : k;
-      k = k < 0 ? 0 : (k >= T ? T - 1 : k);          // frames entirely beyond the clip (never valid)
-      cur[j] = x[k];
-      prv[j] = k > 0 ? x[k - 1] : 0.f;               // sample 0 is not pre-emphasised
-      if (a.dither > 0.f) {                          // wave-uniform branch; eval mode never takes it
-        cur[j] += a.dither * dither_noise(a.seed, g / a.nwg, k);
-        if (k > 0) prv[j] += a.dither * dither_noise(a.seed, g / a.nwg, k - 1);
-      }
+    for (int j = 0; j < NV; ++j) {
+      const int e = tid + 256 * j < span4 ? tid + 256 * j : span4 - 1;      // unconditional loads (a guarded load is waited for on the spot)
+      // asm loads: hipcc arranges the loaded registers for the commit right behind a plain load -- and waits for it there, which makes the prefetch synchronous
+      const float* const src = x + 4 * e;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cur[j]) : "v"(src) : "memory");
+      asm volatile("global_load_dword %0, %1, off offset:-4" : "=v"(prv[j]) : "v"(src) : "memory");
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int g) {
+    // the asm loads of fetch() (hipcc does not count them); the registers are operands of the wait so that no use of them moves above it
+    static_assert(NV == 3, "operand list of the wait below");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(prv[0]), "+v"(prv[1]), "+v"(prv[2]) :: "memory");
 #pragma unroll
-    for (int j = 0; j < NL; ++j)
-      if (tid + 256 * j < span) sig[tid + 256 * j] = cur[j] - a.preemph * prv[j];
+    for (int j = 0; j < NV; ++j) {
+      const int e = tid + 256 * j;
+      if constexpr (DITHER) {                          // only now: the registers are not to be touched before the wait above
+        const int b = g / a.nwg, k = (g % a.nwg) * FPW * a.hop - NFFT / 2 + 4 * (e < span4 ? e : span4 - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[j][q] += a.dither * dither_noise(a.seed, b, k + q);
+        prv[j] += a.dither * dither_noise(a.seed, b, k - 1);
+      }
+      if (e < span4)
+        *reinterpret_cast<f32x4*>(sig + 4 * e) = f32x4{cur[j][0] - a.preemph * prv[j], cur[j][1] - a.preemph * cur[j][0],
+                                                       cur[j][2] - a.preemph * cur[j][1], cur[j][3] - a.preemph * cur[j][2]};
+    }
   };
-  auto stage_direct = [&](int g) {                   // long hops: no register prefetch
+  auto stage_direct = [&](int g) {                   // edge groups and long hops: no register prefetch
     const float* x = a.wave + (size_t)(g / a.nwg) * a.n_samples;
     const int k0 = (g % a.nwg) * FPW * a.hop - NFFT / 2;
     for (int e = tid; e < span; e += 256) {
       int k = k0 + e;
       k = k < 0 ? -k : k;
       k = k >= T ? 2 * (T - 1) - k : k;
-      k = k < 0 ? 0 : (k >= T ? T - 1 : k);
-      float xc = x[k], xp = k > 0 ? x[k - 1] : 0.f;
-      if (a.dither > 0.f) {
+      k = k < 0 ? 0 : (k >= T ? T - 1 : k);          // frames entirely beyond the clip (never valid)
+      float xc = x[k], xp = k > 0 ? x[k - 1] : 0.f;  // sample 0 is not pre-emphasised
+      if constexpr (DITHER) {
         xc += a.dither * dither_noise(a.seed, g / a.nwg, k);
         if (k > 0) xp += a.dither * dither_noise(a.seed, g / a.nwg, k - 1);
       }
@@ -172,14 +190,15 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   };
   const int n_groups = a.nwg * a.batch;
   int g = blockIdx.x;
-  if (pre) { fetch(g); commit(); } else { stage_direct(g); }
+  if (interior(g)) { fetch(g); commit(g); } else { stage_direct(g); }
   __syncthreads();
 
   for (; g < n_groups; g += gridDim.x) {
   const int b = g / a.nwg, grp = g - b * a.nwg;
   const int f0 = grp * FPW;
   const int gn = g + gridDim.x;
-  if (pre && gn < n_groups) fetch(gn);
+  const bool nvec = gn < n_groups && interior(gn);
+  if (nvec) fetch(gn);
 
   // ---- 256-point complex FFT per frame: 16 lanes per frame ---------------------------------------------
   const int fl = tid >> 4;          // frame in workgroup
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
     if (f < a.n_frames) a.logmel[((size_t)b * a.n_frames + f) * a.n_mels + m] = lm;
   }
   __syncthreads();                                   // every wave has long read its samples of group g and staged its frames' log-mel
-  if (pre && gn < n_groups) commit();                // the next group's samples (prefetched into registers above)
+  if (nvec) commit(gn);                              // the next group's samples (prefetched into registers above)
   // ---- partial statistics over the valid frames of this workgroup -----------------------------------------
   const int flen = a.wave_len[b] / a.hop + 1;      // floor(len / hop) + 1  (transform.py:182-184)
   if (tid == 0 && grp == 0) a.feat_len[b] = flen;
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
     dst[0] = s1;
     dst[1] = s2;
   }
-  if (!pre && gn < n_groups) stage_direct(gn);
+  if (!nvec && gn < n_groups) stage_direct(gn);
   __syncthreads();                                   // `red` / P are free again, the next group's samples are in place
   }
 }
@@ -408,8 +427,8 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
                        (size_t)d->mel_nnz + (size_t)(d->n_mels + 1) * 2) * sizeof(float);
   if (lds1 > 160 * 1024) return TS_EUNSUPPORTED;
   if (lds1 > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (e != hipSuccess) return (int)e;
   }
   (void)hipGetLastError();
@@ -417,7 +436,8 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   const int per_cu = (int)((160 * 1024) / lds1) < 1 ? 1 : (int)((160 * 1024) / lds1);
   const int n_groups = nwg * d->batch;
   const int grid = n_groups < cu_count() * per_cu ? n_groups : cu_count() * per_cu;
-  hipLaunchKernelGGL(stft_mel_kernel, dim3(grid), dim3(256), lds1, stream, a);
+  if (a.dither > 0.f) hipLaunchKernelGGL(stft_mel_kernel<true>, dim3(grid), dim3(256), lds1, stream, a);
+  else hipLaunchKernelGGL(stft_mel_kernel<false>, dim3(grid), dim3(256), lds1, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
 

@@ -1780,7 +1780,11 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
                            void* dx, float* dw, int32_t batch, int32_t ch, int32_t t_in, int32_t t_out, int32_t k,
                            int32_t stride, int32_t dil, int32_t pad, int32_t pitch_in, int32_t pitch_out, int32_t act, void* stream_,
                            PairAffine aff, float* in_dgamma, float* in_dbeta) {
-  if (!dy || !x || !w || !dx || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;      // dw may be null: frozen weight
+  if (!dy || !x || !w || batch <= 0 || ch <= 0 || t_in <= 0 || t_out <= 0 || k <= 0) return TS_EINVAL;      // dw may be null: frozen weight
+  // dx may be null where the input needs no gradient (the stem's input are the features) -- the general-geometry kernels only, whose data and
+  // weight gradients are separate launches; the fused kernels form both in one pass and want the buffer
+  const bool fused = pair_geometry(ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out) || phase_geometry(t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out);
+  if (!dx && (fused || !dw)) return TS_EINVAL;
   if (pitch_in < t_in || pitch_out < t_out || act < 0 || act > 1) return TS_EINVAL;
   TS_STREAM;
   if (k > DW_KMAX) return TS_EUNSUPPORTED;
@@ -1816,6 +1820,7 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
   if (k > 256) return TS_EUNSUPPORTED;
   if (lds_d > 64 * 1024 || lds_w > 64 * 1024) return TS_EUNSUPPORTED;
   const dim3 gd((t_in + DW_TILE - 1) / DW_TILE, batch * ch), gw(ch, batch < 8 ? batch : 8);
+  if (dx)
   TS_ACT(act,
          hipLaunchKernelGGL(dw_bwd_data_kernel<float>, gd, dim3(256), lds_d, stream, (const float*)dy, len_in, len_out, w, (float*)dx, batch, ch,
                             t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),

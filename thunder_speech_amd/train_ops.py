@@ -959,9 +959,14 @@ class SubBlock(torch.autograd.Function):
                 _lib.check(L.ts_train_bn_bwd_sums(gbuf.data_ptr(), x.data_ptr(), g_in.data_ptr(), in_mr.data_ptr(), dg_in.data_ptr(), db_in.data_ptr(),
                                                   dx.data_ptr(), b, c_in, t_in, _pitch(x), code, st_), "ts_train_bn_bwd_sums")
             else:
-                _lib.check(L.ts_train_dwconv_bwd(dmid.data_ptr(), x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(), dx.data_ptr(),
-                                                 ddw_ptr, b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad, _pitch(x), _pitch(dmid), code, st_),
-                           "ts_train_dwconv_bwd")
+                # the block input needs no gradient (the stem: its input are the features) and the geometry is one whose data gradient is a
+                # launch of its own (stride > 1): skip it (55 us of a QuartzNet15x5 step at 32 x 1001 x 64)
+                skip_dx = not ctx.needs_input_grad[0] and cfg.stride != 1 and ddw_ptr is not None
+                _lib.check(L.ts_train_dwconv_bwd(dmid.data_ptr(), x.data_ptr(), cfg.len_in.data_ptr(), cfg.len_out.data_ptr(), w_dw.data_ptr(),
+                                                 None if skip_dx else dx.data_ptr(), ddw_ptr, b, c_in, t_in, t_out, cfg.k, cfg.stride, cfg.dil, cfg.pad,
+                                                 _pitch(x), _pitch(dmid), code, st_), "ts_train_dwconv_bwd")
+                if skip_dx:
+                    dx = None
             ddw = ddw.view(ctx.shapes[0]) if ddw is not None else None
         else:
             ddw = None
