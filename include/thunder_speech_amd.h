@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 9
+#define TS_ABI_VERSION 10
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -538,6 +538,12 @@ int ts_w2v_mask_rows(float* x, int32_t batch, int32_t t, int32_t c, const int32_
 int64_t ts_w2v_posconv_workspace_bytes(int32_t batch, int32_t t, int32_t c, int32_t kernel);
 int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias, int32_t kernel,
                        int32_t groups, int32_t precision, float* y, void* y_bf16, void* workspace, void* stream);
+/* the conv of ONE layer of Data2VecAudioPositionalConvEmbedding (transformers modeling_data2vec_audio.py, reached from
+ * huggingface/compatibility.py:31-42 when the checkpoint is a data2vec-audio one -- tests/huggingface/test_module_huggingface.py:107-110):
+ * y = Conv1d(c, c, kernel, padding = kernel / 2, groups)(x) + bias, last frame of an even kernel dropped; its LayerNorm (no affine) + GELU
+ * are ts_w2v_layernorm_fwd(act = 1) with unit weights.  Arguments and workspace as ts_w2v_posconv_fwd. */
+int ts_w2v_groupconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias, int32_t kernel,
+                         int32_t groups, int32_t precision, float* y, void* workspace, void* stream);
 /* self-attention core: qkv [B][t][3c] (q | k | v, heads are contiguous column blocks), softmax(q k^T / sqrt(c / heads)) v
  * -> ctx [B][t][c]; qkv and ctx are f32 (precision 0) or bf16 (precision 1), scores and softmax f32.
  * key_len int32 [B] or NULL: keys >= key_len[b] get probability 0 (the reference's additive mask). */

@@ -1,4 +1,4 @@
-"""Generates tests/golden/w2v_tiny.npz / w2v_tiny_layer.npz / w2v_mid.npz from the REAL transformers Wav2Vec2Model (run in the
+"""Generates tests/golden/w2v_tiny.npz / w2v_tiny_layer.npz / w2v_mid.npz / hubert_tiny.npz / d2v_tiny.npz from the REAL transformers Wav2Vec2Model, HubertModel and Data2VecAudioModel (run in the
 build container only): small configurations with seeded random weights, one unmasked and one masked forward pass each.
 w2v_mid has head_dim 64 and 64 channels per positional-conv group, the geometry at which the HIP path takes its fused
 attention / MFMA positional-conv kernels (the tiny ones exercise the fallback kernels).  Its 1 M-element positional-conv
@@ -6,7 +6,7 @@ direction tensor is not stored: it is drawn from a seeded torch generator here a
 (same torch build on both sides; a stored checksum guards against generator drift)."""
 import numpy as np
 import torch
-from transformers import Wav2Vec2Config, Wav2Vec2Model
+from transformers import Data2VecAudioConfig, Data2VecAudioModel, HubertConfig, HubertModel, Wav2Vec2Config, Wav2Vec2Model
 
 CFG = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, feat_extract_norm="group",
            do_stable_layer_norm=False, vocab_size=32, conv_dim=(32,) * 7, conv_kernel=(10, 3, 3, 3, 3, 2, 2),
@@ -16,12 +16,18 @@ CFG = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermedi
 LAYER = dict(CFG, feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)
 MID = dict(CFG, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_conv_pos_embeddings=128,
            num_conv_pos_embedding_groups=2)
+# HubertModel without the feature projection's LayerNorm (hubert-base); Data2VecAudioModel with its stacked positional convs
+HUBERT = dict(CFG, feat_proj_layer_norm=False, model_type="hubert")
+D2V = dict({k: v for k, v in CFG.items() if k not in ("feat_extract_norm", "do_stable_layer_norm")}, num_conv_pos_embeddings=5,
+           conv_pos_kernel_size=19, model_type="data2vec-audio")
+MODELS = {"wav2vec2": (Wav2Vec2Config, Wav2Vec2Model), "hubert": (HubertConfig, HubertModel), "data2vec-audio": (Data2VecAudioConfig, Data2VecAudioModel)}
 REGEN_SEED, REGEN_SCALE = 4321, 0.05
 
 
 def main(cfg=CFG, name="w2v_tiny.npz", regen=()):
     torch.manual_seed(0)
-    model = Wav2Vec2Model(Wav2Vec2Config(**cfg)).eval()
+    config_cls, model_cls = MODELS[cfg.get("model_type", "wav2vec2")]
+    model = model_cls(config_cls(**{k: v for k, v in cfg.items() if k != "model_type"})).eval()
     with torch.no_grad():                      # make the norms / biases non-trivial
         for k, v in model.state_dict().items():
             if k.endswith("layer_norm.weight"):
@@ -58,3 +64,5 @@ if __name__ == "__main__":
     main()
     main(LAYER, "w2v_tiny_layer.npz")
     main(MID, "w2v_mid.npz", regen=("pos_conv_embed.conv.parametrizations.weight.original1", "pos_conv_embed.conv.weight_v"))
+    main(HUBERT, "hubert_tiny.npz")
+    main(D2V, "d2v_tiny.npz")

@@ -57,6 +57,56 @@ def test_unsupported_configurations_fail_loudly():
         enc(torch.zeros(1, 4000), torch.tensor([4000]))
 
 
+def test_the_other_ctc_families_are_accepted_or_refused_by_name():
+    """AutoModelForCTC families (huggingface/compatibility.py:77): hubert and data2vec-audio (tests/huggingface/test_module_huggingface.py:107-110)
+    have a HIP path; a family whose layers this library has no kernels for says so when the adapter is built, not at the first forward."""
+    from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
+    small = {k: v for k, v in CFG.items() if k not in ("feat_extract_norm", "do_stable_layer_norm")}
+    HuggingFaceEncoderAdapt(transformers.HubertModel(transformers.HubertConfig(**{**CFG, "feat_proj_layer_norm": False})))
+    HuggingFaceEncoderAdapt(transformers.Data2VecAudioModel(transformers.Data2VecAudioConfig(**{**small, "num_conv_pos_embeddings": 2})))
+    with pytest.raises(NotImplementedError, match="wavlm"):
+        HuggingFaceEncoderAdapt(transformers.WavLMModel(transformers.WavLMConfig(**CFG)))
+    with pytest.raises(NotImplementedError, match="conv_pos_batch_norm"):
+        HuggingFaceEncoderAdapt(transformers.HubertModel(transformers.HubertConfig(**{**CFG, "conv_pos_batch_norm": True})))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["hubert", "hubert-large-style", "data2vec-audio"])
+def test_other_ctc_families_match_transformers_through_the_loader_path(family):
+    """module_from_huggingface on a randomly initialised HubertForCTC / Data2VecAudioForCTC: encoder output and logits of the HIP path (fp32 mode)
+    against the transformers forward pass of the same module."""
+    from thunder_speech_amd.huggingface.compatibility import module_from_huggingface
+    torch.manual_seed(3)
+    small = {k: v for k, v in CFG.items() if k not in ("feat_extract_norm", "do_stable_layer_norm")}
+    if family == "hubert":
+        model = transformers.HubertForCTC(transformers.HubertConfig(**{**CFG, "feat_proj_layer_norm": False}))
+    elif family == "hubert-large-style":
+        model = transformers.HubertForCTC(transformers.HubertConfig(**{**CFG, "feat_extract_norm": "layer", "do_stable_layer_norm": True,
+                                                                       "conv_bias": True, "feat_proj_layer_norm": True}))
+    else:
+        model = transformers.Data2VecAudioForCTC(transformers.Data2VecAudioConfig(**{**small, "num_conv_pos_embeddings": 3, "conv_pos_kernel_size": 19}))
+    model = model.eval()
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith(".bias"):
+                v.copy_(0.1 * torch.randn_like(v))
+    x = torch.randn(2, 6000)
+    with torch.no_grad():
+        want_h = model.base_model(x).last_hidden_state
+        want_logits = model(x).logits
+    fe = transformers.Wav2Vec2FeatureExtractor(return_attention_mask=False)
+    m = module_from_huggingface(model, fe, None)
+    m.encoder.precision = "fp32"
+    m = m.cuda()
+    with torch.no_grad():
+        h, out_len = m.encoder(x.cuda(), torch.tensor([6000, 6000]).cuda())
+    np.testing.assert_allclose(h.transpose(1, 2).cpu().numpy(), want_h.numpy(), atol=5e-4, rtol=1e-4)
+    assert out_len.tolist() == [want_h.shape[1]] * 2
+    with torch.no_grad():
+        logits = torch.nn.functional.linear(h.transpose(1, 2).cpu(), model.lm_head.weight, model.lm_head.bias)
+    np.testing.assert_allclose(logits.numpy(), want_logits.numpy(), atol=2e-3, rtol=1e-3)
+
+
 @pytest.mark.gpu
 def test_logits_and_transcripts_match_the_oracle(checkpoint_dir):
     from oracle import w2v as ow

@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # group-norm / post-LN and layer-norm / stable-LN families at toy size (fallback kernels on the GPU), and a mid-size group-norm
 # configuration with head_dim 64 and 64 channels per positional-conv group (fused attention / MFMA positional conv on the GPU)
-FIXTURES = ["w2v_tiny.npz", "w2v_tiny_layer.npz", "w2v_mid.npz"]
+# + HubertModel without the feature projection's LayerNorm, Data2VecAudioModel (five stacked positional convs)
+FIXTURES = ["w2v_tiny.npz", "w2v_tiny_layer.npz", "w2v_mid.npz", "hubert_tiny.npz", "d2v_tiny.npz"]
 
 
 def load_fixture(name="w2v_tiny.npz"):
@@ -30,7 +31,11 @@ def load_fixture(name="w2v_tiny.npz"):
                        intermediate_size=int(c["intermediate_size"]), num_conv_pos_embeddings=int(c["num_conv_pos_embeddings"]),
                        num_conv_pos_embedding_groups=int(c["num_conv_pos_embedding_groups"]),
                        feat_extract_norm=str(z["cfgs/feat_extract_norm"]) if "cfgs/feat_extract_norm" in z.files else "group",
-                       do_stable_layer_norm=bool(c.get("do_stable_layer_norm", False)), conv_bias=bool(c.get("conv_bias", False)))
+                       do_stable_layer_norm=bool(c.get("do_stable_layer_norm", False)), conv_bias=bool(c.get("conv_bias", False)),
+                       model_type=str(z["cfgs/model_type"]) if "cfgs/model_type" in z.files else "wav2vec2",
+                       feat_proj_layer_norm=bool(c.get("feat_proj_layer_norm", True)), conv_pos_kernel_size=int(c.get("conv_pos_kernel_size", 19)))
+    if cfg.model_type == "data2vec-audio":
+        cfg.feat_extract_norm = "layer"                  # Data2VecAudioConvLayer: always conv -> LayerNorm -> GELU
     return z, sd, cfg
 
 

@@ -10,6 +10,7 @@
 //   ts_w2v_linear_fwd     y = act(x W^T + b [+ res])
 //   ts_w2v_layernorm_fwd  y = LN(x [+ res])
 //   ts_w2v_posconv_fwd    y = x + gelu(grouped conv(x) + b): one batched GEMM per tap over a zero-padded copy
+//   ts_w2v_groupconv_fwd  y = grouped conv(x) + b, same padding: a layer of data2vec-audio's stacked positional convs
 //   ts_w2v_attention_fwd  softmax(q k^T * scale [keys >= len masked]) v per (clip, head)
 // Every GEMM is this library's own: csrc/gemm_nt.hip (bf16 operands, token-major) and csrc/gemm_f32.hip (f32 mode, odd shapes).
 // precision 0: fp32 GEMMs (tight parity with the fp32 reference).  precision 1: the GEMM operands are bf16 (MFMA rate),
@@ -275,6 +276,9 @@ __global__ __launch_bounds__(256) void w2v_pad_rows_kernel(const float* __restri
   else xp[(size_t)b * total + idx] = v;
 }
 
+// PLAIN: y = conv + bias (a layer of Data2VecAudioPositionalConvEmbedding: its LayerNorm + GELU follow in ts_w2v_layernorm_fwd); else the wav2vec2 /
+// hubert embedding y = x + gelu(conv + bias)
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void w2v_posconv_finish_kernel(const float* __restrict__ x, const float* __restrict__ yp,
                                                                  const float* __restrict__ bias, float* __restrict__ y, int t,
                                                                  int c, int k) {
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256) void w2v_posconv_finish_kernel(const float* __
   const int col = (int)(idx % c);
   // conv output frame r of clip b was accumulated at padded row b (T + k) + r
   const float v = yp[(size_t)b * (t + k) * c + idx] + bias[col];
-  y[(size_t)b * t * c + idx] = x[(size_t)b * t * c + idx] + gelu_erf(v);
+  y[(size_t)b * t * c + idx] = PLAIN ? v : x[(size_t)b * t * c + idx] + gelu_erf(v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -673,12 +677,27 @@ extern "C" int64_t ts_w2v_posconv_workspace_bytes(int32_t batch, int32_t t, int3
   return (int64_t)2 * batch * (t + kernel) * c * sizeof(float);
 }
 
+namespace ts {
+static int posconv_impl(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias, int32_t kernel, int32_t groups,
+                        int32_t precision, float* y, void* workspace, void* stream_, bool plain);
+}
+
 extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias,
                                   int32_t kernel, int32_t groups, int32_t precision, float* y, void* y_bf16, void* workspace,
                                   void* stream_) {
+  (void)y_bf16;
+  return ts::posconv_impl(x, batch, t, c, w_taps, bias, kernel, groups, precision, y, workspace, stream_, false);
+}
+
+extern "C" int ts_w2v_groupconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias,
+                                    int32_t kernel, int32_t groups, int32_t precision, float* y, void* workspace, void* stream_) {
+  return ts::posconv_impl(x, batch, t, c, w_taps, bias, kernel, groups, precision, y, workspace, stream_, true);
+}
+
+static int ts::posconv_impl(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias, int32_t kernel,
+                            int32_t groups, int32_t precision, float* y, void* workspace, void* stream_, bool plain) {
   if (!x || !w_taps || !bias || !y || !workspace || batch <= 0 || t <= 0 || c <= 0 || kernel <= 0 || groups <= 0 || c % groups) return TS_EINVAL;
   if (precision < 0 || precision > 1) return TS_EUNSUPPORTED;
-  (void)y_bf16;
   TS_STREAM;
   const int cg = c / groups;
   const long long prow = (long long)t + kernel;                       // padded rows per clip
@@ -690,7 +709,7 @@ extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int3
                                     reinterpret_cast<unsigned short*>(xp), t, c, kernel);
   else hipLaunchKernelGGL(w2v_pad_rows_kernel<float>, dim3(nblk(prow * c), batch), dim3(256), 0, stream, x, reinterpret_cast<float*>(xp), t, c, kernel);
   const size_t win_lds = (size_t)(PC_TT + kernel - 1) * PC_PITCH;
-  if (precision && cg == 64 && win_lds <= 64 * 1024) {
+  if (!plain && precision && cg == 64 && win_lds <= 64 * 1024) {           // the fused kernel's epilogue is the wav2vec2 one
     PcArgs pa{};
     pa.xp = reinterpret_cast<const unsigned short*>(xp); pa.w = static_cast<const unsigned short*>(w_taps); pa.bias = bias; pa.x = x; pa.y = y;
     pa.t = t; pa.c = c; pa.k = kernel; pa.groups = groups;
@@ -705,7 +724,8 @@ extern "C" int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int3
                          j ? 1.f : 0.f, groups))
       return st;
   }
-  hipLaunchKernelGGL(w2v_posconv_finish_kernel, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, yp, bias, y, t, c, kernel);
+  if (plain) hipLaunchKernelGGL(w2v_posconv_finish_kernel<true>, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, yp, bias, y, t, c, kernel);
+  else hipLaunchKernelGGL(w2v_posconv_finish_kernel<false>, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, yp, bias, y, t, c, kernel);
   return hip_status(hipGetLastError());
 }
 

@@ -31,8 +31,20 @@ def feat_extract_output_lengths(conv_kernel, conv_stride, lengths: torch.Tensor)
     return out
 
 
+# AutoModelForCTC families with a HIP path (the reference loads any of them, huggingface/compatibility.py:77): wav2vec2 (both published
+# families), hubert (the same layers; the feature projection's LayerNorm is optional) and data2vec-audio (the reference's own test,
+# tests/huggingface/test_module_huggingface.py:107-110: layer-norm conv feature extractor, post-LN encoder, the positional embedding as a
+# stack of grouped convs each followed by an affine-free LayerNorm and GELU).  Others (wavlm's gated relative-position attention, sew's
+# squeezed encoder, wav2vec2-conformer ...) have layers this library holds no kernels for and raise.
+SUPPORTED_MODEL_TYPES = ("wav2vec2", "hubert", "data2vec-audio")
+
+
 def _check_config(cfg) -> None:
     bad = []
+    if getattr(cfg, "model_type", "wav2vec2") not in SUPPORTED_MODEL_TYPES:
+        bad.append(f"model_type={cfg.model_type!r} (supported: {', '.join(SUPPORTED_MODEL_TYPES)})")
+    if getattr(cfg, "conv_pos_batch_norm", False):
+        bad.append("conv_pos_batch_norm=True")
     if getattr(cfg, "feat_extract_norm", "group") not in ("group", "layer"):
         bad.append(f"feat_extract_norm={cfg.feat_extract_norm!r}")
     if getattr(cfg, "add_adapter", False):
@@ -69,8 +81,12 @@ class Wav2Vec2Plan:
         self.kpos = int(cfg.num_conv_pos_embeddings)
         self.groups = int(cfg.num_conv_pos_embedding_groups)
         self.eps = float(cfg.layer_norm_eps)
-        self.layer_norm_convs = getattr(cfg, "feat_extract_norm", "group") == "layer"      # lv60 / xlsr family
+        self.model_type = getattr(cfg, "model_type", "wav2vec2")
+        self.d2v = self.model_type == "data2vec-audio"
+        # lv60 / xlsr family; Data2VecAudioConvLayer is always conv -> LayerNorm -> GELU and its config carries no feat_extract_norm
+        self.layer_norm_convs = self.d2v or getattr(cfg, "feat_extract_norm", "group") == "layer"
         self.stable_ln = bool(getattr(cfg, "do_stable_layer_norm", False))
+        self.fp_has_ln = bool(getattr(cfg, "feat_proj_layer_norm", True))                  # HubertFeatureProjection
         opt = lambda k: f(k) if k in sd else None
         self.conv_b = [opt(f"feature_extractor.conv_layers.{i}.conv.bias") if getattr(cfg, "conv_bias", False) else None
                        for i in range(len(self.kernels))]
@@ -86,18 +102,28 @@ class Wav2Vec2Plan:
         self.layers = []
         if self.feature_extractor_only:
             return
-        self.fp_ln = (f("feature_projection.layer_norm.weight"), f("feature_projection.layer_norm.bias"))
+        self.fp_ln = (f("feature_projection.layer_norm.weight"), f("feature_projection.layer_norm.bias")) if self.fp_has_ln else None
         self.fp_w, self.fp_b = gw(f("feature_projection.projection.weight")), f("feature_projection.projection.bias")
-        # weight_norm(dim=2): w[:, :, j] = g[j] v[:, :, j] / ||v[:, :, j]||
-        p = "encoder.pos_conv_embed.conv."
-        if p + "parametrizations.weight.original0" in sd:
-            g, v = f(p + "parametrizations.weight.original0"), f(p + "parametrizations.weight.original1")
-        else:
-            g, v = f(p + "weight_g"), f(p + "weight_v")
-        w_eff = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()                    # [C][C/g][k]
         cg = self.hidden // self.groups
-        self.pos_w = gw(w_eff.view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2))   # [k][g][out][in]
-        self.pos_b = f(p + "bias")
+        if self.d2v:
+            # Data2VecAudioPositionalConvEmbedding: num_conv_pos_embeddings LAYERS of conv_pos_kernel_size taps, plain weights
+            self.pos_layers = int(cfg.num_conv_pos_embeddings)
+            self.kpos = int(cfg.conv_pos_kernel_size)
+            self.pos_stack = []
+            for i in range(self.pos_layers):
+                q = f"encoder.pos_conv_embed.layers.{i}.conv."
+                self.pos_stack.append((gw(f(q + "weight").view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2)), f(q + "bias")))
+            self.unit_ln = (torch.ones(self.hidden, device=self.device), torch.zeros(self.hidden, device=self.device))   # elementwise_affine=False
+        else:
+            # weight_norm(dim=2): w[:, :, j] = g[j] v[:, :, j] / ||v[:, :, j]||
+            p = "encoder.pos_conv_embed.conv."
+            if p + "parametrizations.weight.original0" in sd:
+                g, v = f(p + "parametrizations.weight.original0"), f(p + "parametrizations.weight.original1")
+            else:
+                g, v = f(p + "weight_g"), f(p + "weight_v")
+            w_eff = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()                    # [C][C/g][k]
+            self.pos_w = gw(w_eff.view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2))   # [k][g][out][in]
+            self.pos_b = f(p + "bias")
         self.enc_ln = (f("encoder.layer_norm.weight"), f("encoder.layer_norm.bias"))
         for i in range(self.n_layers):
             q = f"encoder.layers.{i}."
@@ -167,6 +193,10 @@ class Wav2Vec2Plan:
 
     def feature_extractor(self, audio: torch.Tensor) -> torch.Tensor:
         """[B, n] fp32 -> [B, T', C_last] fp32 (time-major)."""
+        return self._feature_extractor(audio)[0]
+
+    def _feature_extractor(self, audio: torch.Tensor, want_op: bool = False):
+        """-> (features fp32, their GEMM-operand copy when `want_op`: a feature projection without LayerNorm multiplies them as they are)."""
         L = _lib.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         b, n = audio.shape
@@ -181,7 +211,7 @@ class Wav2Vec2Plan:
             h = self._buf(b, t, c0)
             _lib.check(L.ts_w2v_conv0_fwd(audio.data_ptr(), b, n, self.w0.data_ptr(), None, self._ptr(self.conv_b[0]), c0, k0, s0, 1e-5,
                                           h.data_ptr(), None, ws.data_ptr(), stream), "ts_w2v_conv0_fwd")
-            h, x_op = self._ln(L, stream, h, self.conv_ln[0], act=1, eps=1e-5, want_op=n_conv > 1)
+            h, x_op = self._ln(L, stream, h, self.conv_ln[0], act=1, eps=1e-5, want_op=n_conv > 1 or want_op)
             for i, w in enumerate(self.conv_w, start=1):
                 k, s = self.kernels[i], self.strides[i]
                 t_out = (t - k) // s + 1
@@ -190,9 +220,9 @@ class Wav2Vec2Plan:
                 y = self._buf(b, t_out, self.dims[i])
                 _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self._ptr(self.conv_b[i]), self.dims[i],
                                              k, s, 0, self.prec, y.data_ptr(), None, self._ptr(self._frag(w)), stream), "ts_w2v_conv_fwd")
-                h, x_op = self._ln(L, stream, y, self.conv_ln[i], act=1, eps=1e-5, want_op=i < n_conv - 1)
+                h, x_op = self._ln(L, stream, y, self.conv_ln[i], act=1, eps=1e-5, want_op=i < n_conv - 1 or want_op)
                 t = t_out
-            return h
+            return h, x_op
         last = n_conv == 1
         h = self._buf(b, t, c0) if (not self.prec or last) else None       # bf16 mode: the next conv only reads the bf16 copy
         h_op = self._op(b, t, c0)
@@ -206,12 +236,12 @@ class Wav2Vec2Plan:
                 raise RuntimeError("wav2vec2: input too short for the conv feature extractor")
             last = i == n_conv - 1
             y = self._buf(b, t_out, self.dims[i])
-            y_op = None if last else self._op(b, t_out, self.dims[i])
+            y_op = None if (last and not want_op) else self._op(b, t_out, self.dims[i])
             _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self._ptr(self.conv_b[i]), self.dims[i], k, s,
                                          1, self.prec, y.data_ptr(), self._ptr(y_op), self._ptr(self._frag(w)), stream), "ts_w2v_conv_fwd")
             h, t = y, t_out
             x_op = y_op if self.prec else y
-        return h
+        return h, x_op
 
     def forward(self, audio: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
         """audio [B, n] fp32 on the GPU; lengths = samples per clip when the model was trained with an attention mask
@@ -220,10 +250,11 @@ class Wav2Vec2Plan:
             raise RuntimeError("this Wav2Vec2Plan holds the feature extractor's weights only (feature_extractor_only=True)")
         L = _lib.lib()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        feats = self.feature_extractor(audio)
+        feats, ln_op = self._feature_extractor(audio, want_op=not self.fp_has_ln)
         b, t, _ = feats.shape
         c = self.hidden
-        _, ln_op = self._ln(L, stream, feats, self.fp_ln)
+        if self.fp_has_ln:
+            _, ln_op = self._ln(L, stream, feats, self.fp_ln)
         h, _ = self._linear(L, stream, ln_op, self.fp_w, self.fp_b)
         key_len = None
         if lengths is not None:
@@ -231,8 +262,18 @@ class Wav2Vec2Plan:
             _lib.check(L.ts_w2v_mask_rows(h.data_ptr(), b, t, c, key_len.data_ptr(), stream), "ts_w2v_mask_rows")
         ws = self._buf(L.ts_w2v_posconv_workspace_bytes(b, t, c, self.kpos), dtype=torch.uint8)
         hp = torch.empty_like(h)
-        _lib.check(L.ts_w2v_posconv_fwd(h.data_ptr(), b, t, c, self.pos_w.data_ptr(), self.pos_b.data_ptr(), self.kpos, self.groups,
-                                        self.prec, hp.data_ptr(), None, ws.data_ptr(), stream), "ts_w2v_posconv_fwd")
+        if self.d2v:
+            # pos = (GELU . LayerNorm_no_affine . conv)^n (h); the encoder's LayerNorm below takes h as its residual: LN(pos + h)
+            pos = h
+            for w_taps, bias in self.pos_stack:
+                _lib.check(L.ts_w2v_groupconv_fwd(pos.data_ptr(), b, t, c, w_taps.data_ptr(), bias.data_ptr(), self.kpos, self.groups, self.prec,
+                                                  hp.data_ptr(), ws.data_ptr(), stream), "ts_w2v_groupconv_fwd")
+                pos, _ = self._ln(L, stream, hp, self.unit_ln, act=1, eps=1e-5, want_op=False)
+            hp, pos_res = pos, h
+        else:
+            pos_res = None                             # the wav2vec2 / hubert launch adds its input itself: hp = h + gelu(conv(h) + b)
+            _lib.check(L.ts_w2v_posconv_fwd(h.data_ptr(), b, t, c, self.pos_w.data_ptr(), self.pos_b.data_ptr(), self.kpos, self.groups,
+                                            self.prec, hp.data_ptr(), None, ws.data_ptr(), stream), "ts_w2v_posconv_fwd")
         del ws
         att_ws = self._buf(L.ts_w2v_attention_workspace_bytes(b, t, self.heads, self.prec), dtype=torch.uint8)
 
@@ -245,6 +286,7 @@ class Wav2Vec2Plan:
 
         if self.stable_ln:
             # pre-LN family: h += attn(LN(h)); h += ffn(LN(h)); one LayerNorm after the last layer
+            assert pos_res is None
             h = hp
             for lw in self.layers:
                 _, x_op = self._ln(L, stream, h, lw["ln1"])
@@ -255,7 +297,7 @@ class Wav2Vec2Plan:
             h, _ = self._ln(L, stream, h, self.enc_ln, want_op=False)
             return h
         # post-LN family: LayerNorm before the layers, after each residual add inside them
-        h, h_op = self._ln(L, stream, hp, self.enc_ln)
+        h, h_op = self._ln(L, stream, hp, self.enc_ln, res=pos_res)
         for lw in self.layers:
             # the projections accumulate into the residual stream inside the GEMM; their biases ride in the LayerNorm launch
             self._linear(L, stream, attention(h_op), lw["wo"], None, into=h)
