@@ -103,10 +103,14 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
                                       : xs + ((size_t)row * xpitch + a.woff + q * RUN) * 2;
     // this lane's Toeplitz row inside a tap image: channel `row`, copy by the parity of q, one dword in for q < 2
     const int tap_off = row * CST + ((lane & 1) ? 0 : 4) + ((lane & 3) < 2 ? 8 : 0);
-    int dw_out[M];
+    // dilation 1: steps 2h and 2h + 1 of a run write the two halves of ONE 16-byte chunk (RUN is a multiple of 8 frames), so M / 2 addresses and an
+    // immediate offset do -- three registers fewer in a wave that has none to spare (the K 15..75 instantiations spilled eight without them)
+    static_assert(DIL == 2 || (RUN % 8 == 0 && M % 2 == 0), "chunk pairs of the depthwise result");
+    constexpr int NDO = DIL == 2 ? M : M / 2;
+    int dw_out[NDO];
 #pragma unroll
-    for (int m = 0; m < M; ++m)
-      dw_out[m] = DIL == 2 ? taddr(pw * 16 + row, (q & 1) * 2 * RUN + 8 * m + 4 * (q >> 1)) : taddr(pw * 16 + row, q * RUN + 4 * m);
+    for (int m = 0; m < NDO; ++m)
+      dw_out[m] = DIL == 2 ? taddr(pw * 16 + row, (q & 1) * 2 * RUN + 8 * m + 4 * (q >> 1)) : taddr(pw * 16 + row, q * RUN + 8 * m);
     const int lane_x = ((pw * 16 + row) * a.pitch_in + sub * 8) * 2;
     const int lane_t = pw * TAPB + lane * 16;      // [chunk][16-ch group][TAPB]
     const int id_out = taddr(pw * 16 + row, sub * 8);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
           const unsigned ev = odd ? t1 : m0, od = odd ? m1 : t0;
           *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{__builtin_amdgcn_perm(od, ev, 0x05040100u), __builtin_amdgcn_perm(od, ev, 0x07060302u)};
         } else {
-          *reinterpret_cast<u32x2*>(dst + dw_out[m]) = u32x2{m0, m1};
+          *reinterpret_cast<u32x2*>(dst + dw_out[m >> 1] + 8 * (m & 1)) = u32x2{m0, m1};
         }
       }
     };
@@ -483,49 +487,53 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
               *reinterpret_cast<u32x2*>(prow_w + 32 * mt) = u32x2{lo, hi};
             }
           }
+          // the rows leave in batches of four per lane (eight at once are 32 registers on top of the accumulators and the next tile's first weight
+          // fragments: the squeeze-excite instantiation spilled 21 registers with them, 12 now)
+          constexpr int RB = 4, NB = ER / 4 / RB;
+          static_assert(NB * RB * 4 == ER, "row batches");
           if (csub < FW / 8) {
             const int row0 = cob + half * ER;
             const int y_soff = ((b * a.c_out + row0) * a.pitch_out + tw) * 2;
             const char* const prow = priv + (size_t)rsub * EP + csub * 16;
-            u32x4 v[ER / 4];
 #pragma unroll
-            for (int i = 0; i < ER / 4; ++i) {
-              const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * i * EP);
-              v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
-            }
-            if constexpr (SE) {
-              // four rows at a time, requested here (after the result rows are back in registers): fetching them ahead of the LDS round trip, or
-              // a batch ahead, was measured slower -- the epilogue has no registers left for rows in flight (77-147 spilled VGPRs, C3 9.17 ms vs
-              // 9.04 with this form and 9.17 without the fusion)
+            for (int bt = 0; bt < NB; ++bt) {
+              u32x4 v[RB];
 #pragma unroll
-              for (int i0 = 0; i0 < ER / 4; i0 += 4) {
-                u32x4 yv[4];
-                float gt[4];
+              for (int i = 0; i < RB; ++i) {
+                const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * (RB * bt + i) * EP);
+                v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
+              }
+              if constexpr (SE) {
+                // four rows at a time, requested here (after the result rows are back in registers): fetching them ahead of the LDS round trip, or
+                // a batch ahead, was measured slower -- the epilogue has no registers left for rows in flight (77-147 spilled VGPRs, C3 9.17 ms vs
+                // 9.04 with this form and 9.17 without the fusion)
+                u32x4 yv[RB];
+                float gt[RB];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  const int row = row0 + 4 * (i0 + i) + rsub;
+                for (int i = 0; i < RB; ++i) {
+                  const int row = row0 + 4 * (RB * bt + i) + rsub;
                   const bool in = row < a.c_out;
-                  yv[i] = in ? __builtin_amdgcn_raw_buffer_load_b128(rse, lane_y, y_soff + 4 * (i0 + i) * a.pitch_out * 2, 0) : u32x4{0u, 0u, 0u, 0u};
+                  yv[i] = in ? __builtin_amdgcn_raw_buffer_load_b128(rse, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, 0) : u32x4{0u, 0u, 0u, 0u};
                   gt[i] = in ? L.se_gate[(size_t)b * a.c_out + row] : 0.f;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < RB; ++i) {
                   u32x4 o;
 #pragma unroll
                   for (int j = 0; j < 4; ++j) {
-                    const float lo = fmaf(bf16_lo(yv[i][j]), gt[i], bf16_lo(v[i0 + i][j]));
-                    const float hi = fmaf(bf16_hi(yv[i][j]), gt[i], bf16_hi(v[i0 + i][j]));
+                    const float lo = fmaf(bf16_lo(yv[i][j]), gt[i], bf16_lo(v[i][j]));
+                    const float hi = fmaf(bf16_hi(yv[i][j]), gt[i], bf16_hi(v[i][j]));
                     o[j] = pack_bf16(lo > 0.f ? lo : 0.f, hi > 0.f ? hi : 0.f);
                   }
-                  v[i0 + i] = o;
+                  v[i] = o;
                 }
               }
-            }
 #pragma unroll
-            for (int i = 0; i < ER / 4; ++i) {
-              if (partial) v[i] &= keep;
-              if (row0 + 4 * i + rsub < a.c_out)
-                __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * i * a.pitch_out * 2, 0);
+              for (int i = 0; i < RB; ++i) {
+                if (partial) v[i] &= keep;
+                if (row0 + 4 * (RB * bt + i) + rsub < a.c_out)
+                  __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, 0);
+              }
             }
           }
         }
