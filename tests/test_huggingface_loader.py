@@ -71,7 +71,7 @@ def test_the_other_ctc_families_are_accepted_or_refused_by_name():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("family", ["hubert", "hubert-large-style", "data2vec-audio"])
+@pytest.mark.parametrize("family", ["hubert", "hubert-large-style", "data2vec-audio", "unispeech", "unispeech-sat"])
 def test_other_ctc_families_match_transformers_through_the_loader_path(family):
     """module_from_huggingface on a randomly initialised HubertForCTC / Data2VecAudioForCTC: encoder output and logits of the HIP path (fp32 mode)
     against the transformers forward pass of the same module."""
@@ -83,6 +83,10 @@ def test_other_ctc_families_match_transformers_through_the_loader_path(family):
     elif family == "hubert-large-style":
         model = transformers.HubertForCTC(transformers.HubertConfig(**{**CFG, "feat_extract_norm": "layer", "do_stable_layer_norm": True,
                                                                        "conv_bias": True, "feat_proj_layer_norm": True}))
+    elif family == "unispeech":
+        model = transformers.UniSpeechForCTC(transformers.UniSpeechConfig(**CFG))
+    elif family == "unispeech-sat":
+        model = transformers.UniSpeechSatForCTC(transformers.UniSpeechSatConfig(**{**CFG, "feat_extract_norm": "layer", "do_stable_layer_norm": True, "conv_bias": True}))
     else:
         model = transformers.Data2VecAudioForCTC(transformers.Data2VecAudioConfig(**{**small, "num_conv_pos_embeddings": 3, "conv_pos_kernel_size": 19}))
     model = model.eval()

@@ -65,3 +65,39 @@ def test_forward_matches_transformers_masked_and_lengths(name):
     out, key_len = ow.forward(cfg, sd, xm, lengths)
     np.testing.assert_array_equal(key_len.numpy(), z["out_lengths"])
     np.testing.assert_allclose(out.numpy(), z["out_masked"], atol=5e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("family", ["unispeech", "unispeech-sat"])
+@pytest.mark.parametrize("style", ["group", "layer"])
+def test_unispeech_models_run_the_wav2vec2_arithmetic(family, style):
+    """UniSpeechModel / UniSpeechSatModel (other AutoModelForCTC families the reference's loader accepts, huggingface/compatibility.py:77) against the
+    wav2vec2 restatement on THEIR state dict: same keys, same forward pass -- which is why the HIP adapter takes them on the wav2vec2 plan."""
+    transformers = pytest.importorskip("transformers")
+    z, _, base = load_fixture("w2v_tiny.npz")
+    kw = dict(hidden_size=base.hidden_size, num_hidden_layers=base.num_hidden_layers, num_attention_heads=base.num_attention_heads,
+              intermediate_size=base.intermediate_size, vocab_size=32, conv_dim=tuple(base.conv_dim), conv_kernel=tuple(base.conv_kernel),
+              conv_stride=tuple(base.conv_stride), num_conv_pos_embeddings=base.num_conv_pos_embeddings,
+              num_conv_pos_embedding_groups=base.num_conv_pos_embedding_groups, feat_extract_norm=style, do_stable_layer_norm=style == "layer",
+              conv_bias=style == "layer")
+    config_cls, model_cls = {"unispeech": (transformers.UniSpeechConfig, transformers.UniSpeechModel),
+                             "unispeech-sat": (transformers.UniSpeechSatConfig, transformers.UniSpeechSatModel)}[family]
+    torch.manual_seed(0)
+    model = model_cls(config_cls(**kw)).eval()
+    assert model.config.model_type == family
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith(".bias"):
+                v.copy_(0.1 * torch.randn_like(v))
+    x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
+    mask = (torch.arange(x.shape[1])[None, :] < lengths[:, None]).int()
+    with torch.no_grad():
+        want = model(x).last_hidden_state
+        want_masked = model(x * mask, attention_mask=mask).last_hidden_state
+    cfg = ow.W2VConfig(**{**base.__dict__, "feat_extract_norm": style, "do_stable_layer_norm": style == "layer", "conv_bias": style == "layer",
+                          "layer_norm_eps": float(model.config.layer_norm_eps)})
+    sd = {k: v for k, v in model.state_dict().items()}
+    got, _ = ow.forward(cfg, sd, x)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=5e-5, rtol=1e-5)
+    got_m, key_len = ow.forward(cfg, sd, x * mask, lengths)
+    np.testing.assert_array_equal(key_len.numpy(), z["out_lengths"])
+    np.testing.assert_allclose(got_m.numpy(), want_masked.numpy(), atol=5e-5, rtol=1e-5)

@@ -34,9 +34,10 @@ def feat_extract_output_lengths(conv_kernel, conv_stride, lengths: torch.Tensor)
 # AutoModelForCTC families with a HIP path (the reference loads any of them, huggingface/compatibility.py:77): wav2vec2 (both published
 # families), hubert (the same layers; the feature projection's LayerNorm is optional) and data2vec-audio (the reference's own test,
 # tests/huggingface/test_module_huggingface.py:107-110: layer-norm conv feature extractor, post-LN encoder, the positional embedding as a
-# stack of grouped convs each followed by an affine-free LayerNorm and GELU).  Others (wavlm's gated relative-position attention, sew's
+# stack of grouped convs each followed by an affine-free LayerNorm and GELU); unispeech / unispeech-sat (UniSpeechModel / UniSpeechSatModel run the wav2vec2
+# encoder arithmetic unchanged: tests/test_oracle_w2v.py checks the oracle against both).  Others (wavlm's gated relative-position attention, sew's
 # squeezed encoder, wav2vec2-conformer ...) have layers this library holds no kernels for and raise.
-SUPPORTED_MODEL_TYPES = ("wav2vec2", "hubert", "data2vec-audio")
+SUPPORTED_MODEL_TYPES = ("wav2vec2", "hubert", "data2vec-audio", "unispeech", "unispeech-sat")
 
 
 def _check_config(cfg) -> None:
