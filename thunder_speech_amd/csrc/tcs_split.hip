@@ -578,13 +578,7 @@ int launch_split_layer(SplitArgs& a, int npass, int xe, int wm, int dil, hipStre
     if (xe == 256 && wm == 2) return launch_split<2, 4, 3, 2, 1, 2, true>(a, stream);
     return TS_EUNSUPPORTED;
   }
-  if (wm == 1 && dil == 1 && round_up(a.c_out, 32) <= 256) {
-    // narrow layers on 96-frame tiles (split_tile_rows() chose them): 8 consumer waves x 32 output channels
-#define TS_PIPE1(NP_, XJ_) if (npass == NP_ && xe == 64 * XJ_) return launch_split<NP_, XJ_, 3, 1, 1, 1>(a, stream);
-    TS_PIPE1(3, 3) TS_PIPE1(4, 3) TS_PIPE1(2, 2) TS_PIPE1(2, 3)
-#undef TS_PIPE1
-    return TS_EUNSUPPORTED;
-  }
+  if (wm == 1 && round_up(a.c_out, 32) <= 256) return TS_EUNSUPPORTED;       // narrow layers run on the 192-frame tiles only (split_tile_wm)
 #define TS_PIPE(NP_, XJ_, WM_, DIL_) if (npass == NP_ && xe == 64 * XJ_ && wm == WM_ && dil == DIL_) return launch_split<NP_, XJ_, 3, WM_, DIL_>(a, stream);
   TS_PIPE(3, 4, 2, 1) TS_PIPE(4, 4, 2, 1) TS_PIPE(5, 3, 1, 1) TS_PIPE(6, 3, 1, 1) TS_PIPE(7, 3, 1, 1)      /* QuartzNet: K 33..75 */
   TS_PIPE(2, 2, 1, 1) TS_PIPE(3, 3, 1, 1) TS_PIPE(4, 3, 1, 1) TS_PIPE(2, 4, 2, 1)                         /* Citrinet: K 11..41; pointwise only */
@@ -594,7 +588,8 @@ int launch_split_layer(SplitArgs& a, int npass, int xe, int wm, int dil, hipStre
 }
 
 // Frames of a time tile for a layer of c_out output channels: 96 (x 512 channels) above 256 channels, else 192 (x 256): the 192-frame tiles have
-// the cheaper stage loop.  (96 x 256 tiles, NT = 1, exist for callers that ask for them through the tile rows of ts_tcs_desc.)
+// the cheaper stage loop.  96 x 256 tiles (two per workgroup, eight consumer waves of 32 channels) were built for the chain launch of round 4 and
+// measured again on single launches in round 5: C2 encoder 2.89 against 2.85 ms on the same box (profiles/round5_session2/wm1_ab.log); their instantiations are gone.
 int split_tile_wm(int c_out) { return round_up(c_out, 32) > 256 ? 1 : 2; }
 
 }  // namespace ts
