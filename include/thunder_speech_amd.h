@@ -544,6 +544,10 @@ int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, cons
  * are ts_w2v_layernorm_fwd(act = 1) with unit weights.  Arguments and workspace as ts_w2v_posconv_fwd. */
 int ts_w2v_groupconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias, int32_t kernel,
                          int32_t groups, int32_t precision, float* y, void* workspace, void* stream);
+/* Wav2Vec2Adapter (config.add_adapter: transformers modeling_wav2vec2.py Wav2Vec2Adapter / Wav2Vec2AdapterLayer, behind the encoder in the forward
+ * pass that huggingface/compatibility.py:31-42 calls): each layer is Conv1d(c, 2c, kernel, stride, padding = 1) -- ts_w2v_pad_rows + ts_w2v_conv_fwd --
+ * followed by GLU over the channels: y[r][j] = x[r][j] * sigmoid(x[r][c + j]), x f32 [rows][2c], y f32 [rows][c], y_bf16 optional copy. */
+int ts_w2v_glu_fwd(const float* x, int64_t rows, int32_t c, float* y, void* y_bf16, void* stream);
 /* self-attention core: qkv [B][t][3c] (q | k | v, heads are contiguous column blocks), softmax(q k^T / sqrt(c / heads)) v
  * -> ctx [B][t][c]; qkv and ctx are f32 (precision 0) or bf16 (precision 1), scores and softmax f32.
  * key_len int32 [B] or NULL: keys >= key_len[b] get probability 0 (the reference's additive mask). */

@@ -20,6 +20,8 @@ MID = dict(CFG, hidden_size=128, num_attention_heads=2, intermediate_size=256, n
 HUBERT = dict(CFG, feat_proj_layer_norm=False, model_type="hubert")
 D2V = dict({k: v for k, v in CFG.items() if k not in ("feat_extract_norm", "do_stable_layer_norm")}, num_conv_pos_embeddings=5,
            conv_pos_kernel_size=19, model_type="data2vec-audio")
+# Wav2Vec2Adapter behind the encoder: projection + LayerNorm to 48 channels, two strided conv + GLU layers
+ADAPTER = dict(CFG, add_adapter=True, num_adapter_layers=2, adapter_kernel_size=3, adapter_stride=2, output_hidden_size=48)
 MODELS = {"wav2vec2": (Wav2Vec2Config, Wav2Vec2Model), "hubert": (HubertConfig, HubertModel), "data2vec-audio": (Data2VecAudioConfig, Data2VecAudioModel)}
 REGEN_SEED, REGEN_SCALE = 4321, 0.05
 
@@ -66,3 +68,4 @@ if __name__ == "__main__":
     main(MID, "w2v_mid.npz", regen=("pos_conv_embed.conv.parametrizations.weight.original1", "pos_conv_embed.conv.weight_v"))
     main(HUBERT, "hubert_tiny.npz")
     main(D2V, "d2v_tiny.npz")
+    main(ADAPTER, "w2v_tiny_adapter.npz")

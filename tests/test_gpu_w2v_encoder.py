@@ -20,7 +20,9 @@ def _hf_cfg(cfg: ow.W2VConfig):
                            num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups, layer_norm_eps=cfg.layer_norm_eps,
                            feat_extract_norm=cfg.feat_extract_norm, do_stable_layer_norm=cfg.do_stable_layer_norm,
                            conv_bias=cfg.conv_bias, hidden_act="gelu", feat_extract_activation="gelu", model_type=cfg.model_type,
-                           feat_proj_layer_norm=cfg.feat_proj_layer_norm, conv_pos_kernel_size=cfg.conv_pos_kernel_size)
+                           feat_proj_layer_norm=cfg.feat_proj_layer_norm, conv_pos_kernel_size=cfg.conv_pos_kernel_size,
+                           add_adapter=cfg.add_adapter, adapter_kernel_size=cfg.adapter_kernel_size, adapter_stride=cfg.adapter_stride,
+                           num_adapter_layers=cfg.num_adapter_layers, output_hidden_size=cfg.output_hidden_size)
 
 
 def _plan(precision="fp32", name="w2v_tiny.npz"):

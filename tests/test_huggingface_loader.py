@@ -48,9 +48,11 @@ def test_loader_builds_the_reference_module_layout(checkpoint_dir):
 
 def test_unsupported_configurations_fail_loudly():
     from thunder_speech_amd.huggingface.encoder import HuggingFaceEncoderAdapt
-    cfg = transformers.Wav2Vec2Config(**{**CFG, "add_adapter": True})
-    with pytest.raises(NotImplementedError):
+    cfg = transformers.Wav2Vec2Config(**{**CFG, "hidden_act": "relu"})
+    with pytest.raises(NotImplementedError, match="gelu"):
         HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(cfg))
+    # the adapter behind the encoder is inference-only: building the module is fine, fine-tuning it says so
+    HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(**{**CFG, "add_adapter": True, "num_adapter_layers": 1})))
     enc = HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(**CFG)))
     enc.train()
     with pytest.raises(RuntimeError):        # training mode runs on the HIP kernels too (huggingface/train.py); CPU tensors have no path at all
@@ -71,7 +73,7 @@ def test_the_other_ctc_families_are_accepted_or_refused_by_name():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("family", ["hubert", "hubert-large-style", "data2vec-audio", "unispeech", "unispeech-sat"])
+@pytest.mark.parametrize("family", ["hubert", "hubert-large-style", "data2vec-audio", "unispeech", "unispeech-sat", "wav2vec2-adapter"])
 def test_other_ctc_families_match_transformers_through_the_loader_path(family):
     """module_from_huggingface on a randomly initialised HubertForCTC / Data2VecAudioForCTC: encoder output and logits of the HIP path (fp32 mode)
     against the transformers forward pass of the same module."""
@@ -83,6 +85,8 @@ def test_other_ctc_families_match_transformers_through_the_loader_path(family):
     elif family == "hubert-large-style":
         model = transformers.HubertForCTC(transformers.HubertConfig(**{**CFG, "feat_extract_norm": "layer", "do_stable_layer_norm": True,
                                                                        "conv_bias": True, "feat_proj_layer_norm": True}))
+    elif family == "wav2vec2-adapter":            # Wav2Vec2Adapter behind the encoder: projection to 48 channels, two conv + GLU layers; the head sits on 48
+        model = transformers.Wav2Vec2ForCTC(transformers.Wav2Vec2Config(**{**CFG, "add_adapter": True, "num_adapter_layers": 2, "output_hidden_size": 48}))
     elif family == "unispeech":
         model = transformers.UniSpeechForCTC(transformers.UniSpeechConfig(**CFG))
     elif family == "unispeech-sat":
@@ -105,7 +109,7 @@ def test_other_ctc_families_match_transformers_through_the_loader_path(family):
     with torch.no_grad():
         h, out_len = m.encoder(x.cuda(), torch.tensor([6000, 6000]).cuda())
     np.testing.assert_allclose(h.transpose(1, 2).cpu().numpy(), want_h.numpy(), atol=5e-4, rtol=1e-4)
-    assert out_len.tolist() == [want_h.shape[1]] * 2
+    assert out_len.tolist() == [want_h.shape[1]] * 2 and m.encoder_final_dimension == want_h.shape[2]
     with torch.no_grad():
         logits = torch.nn.functional.linear(h.transpose(1, 2).cpu(), model.lm_head.weight, model.lm_head.bias)
     np.testing.assert_allclose(logits.numpy(), want_logits.numpy(), atol=2e-3, rtol=1e-3)

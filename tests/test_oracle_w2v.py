@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # group-norm / post-LN and layer-norm / stable-LN families at toy size (fallback kernels on the GPU), and a mid-size group-norm
 # configuration with head_dim 64 and 64 channels per positional-conv group (fused attention / MFMA positional conv on the GPU)
 # + HubertModel without the feature projection's LayerNorm, Data2VecAudioModel (five stacked positional convs)
-FIXTURES = ["w2v_tiny.npz", "w2v_tiny_layer.npz", "w2v_mid.npz", "hubert_tiny.npz", "d2v_tiny.npz"]
+# + Wav2Vec2Model with its adapter (projection + LayerNorm + two strided conv / GLU layers behind the encoder)
+FIXTURES = ["w2v_tiny.npz", "w2v_tiny_layer.npz", "w2v_mid.npz", "hubert_tiny.npz", "d2v_tiny.npz", "w2v_tiny_adapter.npz"]
 
 
 def load_fixture(name="w2v_tiny.npz"):
@@ -33,7 +34,10 @@ def load_fixture(name="w2v_tiny.npz"):
                        feat_extract_norm=str(z["cfgs/feat_extract_norm"]) if "cfgs/feat_extract_norm" in z.files else "group",
                        do_stable_layer_norm=bool(c.get("do_stable_layer_norm", False)), conv_bias=bool(c.get("conv_bias", False)),
                        model_type=str(z["cfgs/model_type"]) if "cfgs/model_type" in z.files else "wav2vec2",
-                       feat_proj_layer_norm=bool(c.get("feat_proj_layer_norm", True)), conv_pos_kernel_size=int(c.get("conv_pos_kernel_size", 19)))
+                       feat_proj_layer_norm=bool(c.get("feat_proj_layer_norm", True)), conv_pos_kernel_size=int(c.get("conv_pos_kernel_size", 19)),
+                       add_adapter=bool(c.get("add_adapter", False)), adapter_kernel_size=int(c.get("adapter_kernel_size", 3)),
+                       adapter_stride=int(c.get("adapter_stride", 2)), num_adapter_layers=int(c.get("num_adapter_layers", 3)),
+                       output_hidden_size=int(c["output_hidden_size"]) if "output_hidden_size" in c else None)
     if cfg.model_type == "data2vec-audio":
         cfg.feat_extract_norm = "layer"                  # Data2VecAudioConvLayer: always conv -> LayerNorm -> GELU
     return z, sd, cfg
@@ -63,7 +67,8 @@ def test_forward_matches_transformers_masked_and_lengths(name):
     x, lengths = torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"])
     xm = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
     out, key_len = ow.forward(cfg, sd, xm, lengths)
-    np.testing.assert_array_equal(key_len.numpy(), z["out_lengths"])
+    np.testing.assert_array_equal(ow.output_lengths(cfg, lengths, cfg.add_adapter).numpy(), z["out_lengths"])
+    assert cfg.add_adapter or np.array_equal(key_len.numpy(), z["out_lengths"])
     np.testing.assert_allclose(out.numpy(), z["out_masked"], atol=5e-5, rtol=1e-5)
 
 

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
     "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_fwd_bn_tiles", "ts_tcs_pointwise_tile_frames", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_bn2_add_relu_chan_fwd", "ts_train_bn2_chan_bwd",
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
-    "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_groupconv_fwd", "ts_w2v_attention_workspace_bytes",
+    "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_groupconv_fwd", "ts_w2v_glu_fwd", "ts_w2v_attention_workspace_bytes",
     "ts_w2v_attention_fwd",
     "ts_spec_masks_draw", "ts_spec_mask_apply", "ts_train_dropout", "ts_counter_add", "ts_train_add", "ts_train_act_import", "ts_train_act_export",
     "ts_audio_prep_workspace_bytes", "ts_audio_prep", "ts_collate_pad", "ts_edit_distance", "ts_encode_chars",
@@ -139,11 +139,12 @@ def lib() -> C.CDLL:
     L.ts_w2v_posconv_workspace_bytes.restype = i64
     L.ts_w2v_posconv_fwd.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.ts_w2v_groupconv_fwd.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.ts_w2v_glu_fwd.argtypes = [vp, i64, i32, vp, vp, vp]
     L.ts_w2v_attention_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.ts_w2v_attention_workspace_bytes.restype = i64
     L.ts_w2v_attention_fwd.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     for fn in ("ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd", "ts_w2v_mask_rows",
-               "ts_w2v_posconv_fwd", "ts_w2v_groupconv_fwd", "ts_w2v_attention_fwd"):
+               "ts_w2v_posconv_fwd", "ts_w2v_groupconv_fwd", "ts_w2v_glu_fwd", "ts_w2v_attention_fwd"):
         getattr(L, fn).restype = C.c_int
     L.ts_train_act_import.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     L.ts_train_act_export.argtypes = [vp, vp, i64, i32, i32, i32, vp]

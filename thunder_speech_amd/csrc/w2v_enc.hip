@@ -11,6 +11,7 @@
 //   ts_w2v_layernorm_fwd  y = LN(x [+ res])
 //   ts_w2v_posconv_fwd    y = x + gelu(grouped conv(x) + b): one batched GEMM per tap over a zero-padded copy
 //   ts_w2v_groupconv_fwd  y = grouped conv(x) + b, same padding: a layer of data2vec-audio's stacked positional convs
+//   ts_w2v_glu_fwd        y = x[:, :c] * sigmoid(x[:, c:]): the activation of the adapter layers behind the encoder (config.add_adapter)
 //   ts_w2v_attention_fwd  softmax(q k^T * scale [keys >= len masked]) v per (clip, head)
 // Every GEMM is this library's own: csrc/gemm_nt.hip (bf16 operands, token-major) and csrc/gemm_f32.hip (f32 mode, odd shapes).
 // precision 0: fp32 GEMMs (tight parity with the fp32 reference).  precision 1: the GEMM operands are bf16 (MFMA rate),
@@ -669,6 +670,35 @@ extern "C" int ts_w2v_mask_rows(float* x, int32_t batch, int32_t t, int32_t c, c
   if (!x || !len || batch <= 0 || t <= 0 || c <= 0) return TS_EINVAL;
   TS_STREAM;
   hipLaunchKernelGGL(w2v_mask_rows_kernel, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, len, t, c);
+  return hip_status(hipGetLastError());
+}
+
+namespace ts {
+// GLU over the channel halves of a row: y[r][j] = x[r][j] * sigmoid(x[r][c + j]) -- the activation of Wav2Vec2AdapterLayer (Conv1d to 2c channels, then
+// nn.functional.glu over them); four channels per thread, f32 result and optional bf16 copy
+__global__ __launch_bounds__(256) void w2v_glu_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned short* __restrict__ y16, long long rows, int c) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int q = c >> 2;
+  if (idx >= rows * q) return;
+  const long long r = idx / q;
+  const int j = (int)(idx - r * q) * 4;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * 2 * c + j);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(x + r * 2 * c + c + j);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = a[i] / (1.f + __expf(-g[i]));
+  *reinterpret_cast<f32x4*>(y + r * c + j) = o;
+  if (y16) *reinterpret_cast<u32x2*>(y16 + r * c + j) = u32x2{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+}
+}  // namespace ts
+
+extern "C" int ts_w2v_glu_fwd(const float* x, int64_t rows, int32_t c, float* y, void* y_bf16, void* stream_) {
+  if (!x || !y || rows <= 0 || c <= 0) return TS_EINVAL;
+  if (c % 4 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (y_bf16 && (reinterpret_cast<uintptr_t>(y_bf16) & 7))) return TS_EUNSUPPORTED;
+  using namespace ts;
+  TS_STREAM;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(w2v_glu_kernel, dim3(nblk(rows * (c / 4))), dim3(256), 0, stream, x, y, static_cast<unsigned short*>(y_bf16), (long long)rows, c);
   return hip_status(hipGetLastError());
 }
 

@@ -48,7 +48,9 @@ def text_transform_from_tokenizer(tokenizer) -> BatchTextTransformer:
 def module_from_huggingface(model, feature_extractor, tokenizer=None) -> BaseCTCModule:
     """Assemble the module from already-loaded transformers objects (what `load_huggingface_checkpoint` does after the
     three `from_pretrained` calls; also the offline entry point for randomly initialised models)."""
-    hidden = model.base_model.config.hidden_size
+    cfg = model.base_model.config
+    # Wav2Vec2ForCTC puts its head on output_hidden_size when the adapter is on (modeling_wav2vec2.py)
+    hidden = cfg.output_hidden_size if getattr(cfg, "add_adapter", False) else cfg.hidden_size
     text_transform, decoder = None, None
     if tokenizer is not None:
         text_transform = text_transform_from_tokenizer(tokenizer)

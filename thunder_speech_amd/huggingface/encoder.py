@@ -23,11 +23,14 @@ from ..blocks import _PackedCache
 __all__ = ["Wav2Vec2Plan", "HuggingFaceEncoderAdapt", "feat_extract_output_lengths"]
 
 
-def feat_extract_output_lengths(conv_kernel, conv_stride, lengths: torch.Tensor) -> torch.Tensor:
-    """transformers' `_get_feat_extract_output_lengths`: floor((len - k) / s) + 1 per conv layer (integer tensor in, out)."""
+def feat_extract_output_lengths(conv_kernel, conv_stride, lengths: torch.Tensor, adapter_layers: int = 0, adapter_stride: int = 2) -> torch.Tensor:
+    """transformers' `_get_feat_extract_output_lengths`: floor((len - k) / s) + 1 per conv layer (integer tensor in, out); with an adapter behind the
+    encoder (config.add_adapter) also floor((len - 1) / adapter_stride) + 1 per adapter layer."""
     out = lengths
     for k, s in zip(conv_kernel, conv_stride):
         out = torch.div(out - k, s, rounding_mode="floor") + 1
+    for _ in range(adapter_layers):
+        out = torch.div(out - 1, adapter_stride, rounding_mode="floor") + 1
     return out
 
 
@@ -48,8 +51,6 @@ def _check_config(cfg) -> None:
         bad.append("conv_pos_batch_norm=True")
     if getattr(cfg, "feat_extract_norm", "group") not in ("group", "layer"):
         bad.append(f"feat_extract_norm={cfg.feat_extract_norm!r}")
-    if getattr(cfg, "add_adapter", False):
-        bad.append("add_adapter=True")
     if getattr(cfg, "hidden_act", "gelu") != "gelu" or getattr(cfg, "feat_extract_activation", "gelu") != "gelu":
         bad.append("activation != gelu")
     if getattr(cfg, "position_embeddings_type", None) not in (None, "absolute") and hasattr(cfg, "position_embeddings_type"):
@@ -126,6 +127,16 @@ class Wav2Vec2Plan:
             self.pos_w = gw(w_eff.view(self.groups, cg, cg, self.kpos).permute(3, 0, 1, 2))   # [k][g][out][in]
             self.pos_b = f(p + "bias")
         self.enc_ln = (f("encoder.layer_norm.weight"), f("encoder.layer_norm.bias"))
+        # Wav2Vec2Adapter behind the encoder (config.add_adapter): optional projection + LayerNorm, then strided conv (padding 1, 2x channels) + GLU layers.
+        # Its projection and convolutions run on the f32 GEMM in both precision modes (three short layers at an eighth of the frame rate and below).
+        self.adapter = bool(getattr(cfg, "add_adapter", False))
+        if self.adapter:
+            self.ad_k, self.ad_s = int(cfg.adapter_kernel_size), int(cfg.adapter_stride)
+            self.ad_proj = None
+            if "adapter.proj.weight" in sd:
+                self.ad_proj = (f("adapter.proj.weight"), f("adapter.proj.bias"), (f("adapter.proj_layer_norm.weight"), f("adapter.proj_layer_norm.bias")))
+            self.ad_layers = [(f(f"adapter.layers.{i}.conv.weight").permute(0, 2, 1).contiguous(), f(f"adapter.layers.{i}.conv.bias"))
+                              for i in range(int(cfg.num_adapter_layers))]
         for i in range(self.n_layers):
             q = f"encoder.layers.{i}."
             self.layers.append(dict(
@@ -296,7 +307,7 @@ class Wav2Vec2Plan:
                 _, f1_op = self._linear(L, stream, x_op, lw["w1"], lw["b1"], act=1, want_op=True)
                 self._linear(L, stream, f1_op, lw["w2"], lw["b2"], into=h)
             h, _ = self._ln(L, stream, h, self.enc_ln, want_op=False)
-            return h
+            return self._adapter(L, stream, h) if self.adapter else h
         # post-LN family: LayerNorm before the layers, after each residual add inside them
         h, h_op = self._ln(L, stream, hp, self.enc_ln, res=pos_res)
         for lw in self.layers:
@@ -306,6 +317,31 @@ class Wav2Vec2Plan:
             _, f1_op = self._linear(L, stream, h_op, lw["w1"], lw["b1"], act=1, want_op=True)
             self._linear(L, stream, f1_op, lw["w2"], None, into=h)
             h, h_op = self._ln(L, stream, h, lw["ln2"], xbias=lw["b2"])
+        return self._adapter(L, stream, h) if self.adapter else h
+
+    def _adapter(self, L, stream, h: torch.Tensor) -> torch.Tensor:
+        """Wav2Vec2Adapter.forward (eval): [B, T, C] -> [B, T'', output_hidden_size]."""
+        if self.ad_proj is not None:
+            w, bias, ln = self.ad_proj
+            b0, t0, c0 = h.shape
+            y = self._buf(b0, t0, w.shape[0])
+            _lib.check(L.ts_w2v_linear_fwd(h.data_ptr(), c0, w.data_ptr(), bias.data_ptr(), None, w.shape[0], y.data_ptr(), w.shape[0], None,
+                                           b0 * t0, w.shape[0], c0, 0, 0, None, stream), "ts_w2v_linear_fwd")       # f32 operands (precision 0)
+            h, _ = self._ln(L, stream, y, ln, want_op=False, eps=1e-5)
+        b, t, c = h.shape
+        for w, bias in self.ad_layers:
+            t_pad = t + 2                                          # Conv1d(padding = 1)
+            t_out = (t_pad - self.ad_k) // self.ad_s + 1
+            if t_out < 1:
+                raise RuntimeError("wav2vec2: input too short for the adapter layers")
+            hp = self._buf(b, t_pad, c)
+            _lib.check(L.ts_w2v_pad_rows(h.data_ptr(), hp.data_ptr(), b, t, t_pad, 1, c, 0, stream), "ts_w2v_pad_rows")
+            y = self._buf(b, t_out, 2 * c)
+            _lib.check(L.ts_w2v_conv_fwd(hp.data_ptr(), b, t_pad, c, w.data_ptr(), bias.data_ptr(), 2 * c, self.ad_k, self.ad_s, 0, 0, y.data_ptr(),
+                                         None, None, stream), "ts_w2v_conv_fwd")
+            h = self._buf(b, t_out, c)
+            _lib.check(L.ts_w2v_glu_fwd(y.data_ptr(), b * t_out, c, h.data_ptr(), None, stream), "ts_w2v_glu_fwd")
+            t = t_out
         return h
 
 
@@ -350,4 +386,5 @@ class HuggingFaceEncoderAdapt(nn.Module):
         else:
             h = self._plan(x.device).forward(x, audio_lengths if self.mask_input else None)
         cfg = self.original_encoder.config
-        return h.transpose(-1, -2), feat_extract_output_lengths(cfg.conv_kernel, cfg.conv_stride, audio_lengths)
+        n_ad = int(cfg.num_adapter_layers) if getattr(cfg, "add_adapter", False) else 0
+        return h.transpose(-1, -2), feat_extract_output_lengths(cfg.conv_kernel, cfg.conv_stride, audio_lengths, n_ad, int(getattr(cfg, "adapter_stride", 2)))

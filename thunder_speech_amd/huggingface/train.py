@@ -378,6 +378,8 @@ def train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
         # hubert / data2vec-audio run the inference path (huggingface/encoder.py); their training-mode forward (no feature-projection LayerNorm,
         # stacked positional convs) has no autograd nodes here
         raise NotImplementedError(f"HIP fine-tuning path: model_type={cfg.model_type!r} is inference-only (wav2vec2 checkpoints fine-tune)")
+    if getattr(cfg, "add_adapter", False):
+        raise NotImplementedError("HIP fine-tuning path: add_adapter=True is inference-only (the adapter layers have no backward here)")
     if float(getattr(cfg, "mask_feature_prob", 0.0)) > 0.0 and getattr(cfg, "apply_spec_augment", True):
         raise NotImplementedError("wav2vec2 HIP training path: mask_feature_prob > 0 is not supported")
     unfrozen = [n for n, p in enc.feature_extractor.named_parameters() if p.requires_grad]
