@@ -432,8 +432,26 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
     if (e != hipSuccess) return (int)e;
   }
   (void)hipGetLastError();
-  // persistent workgroups: as many as fit at once (LDS-limited), each walks frame groups g, g + grid, ...
-  const int per_cu = (int)((160 * 1024) / lds1) < 1 ? 1 : (int)((160 * 1024) / lds1);
+  // persistent workgroups: as many as are resident at once, each walks frame groups g, g + grid, ...  (LDS allows three per CU; the dither instantiation's
+  // registers only two -- a third would start when the first two have finished their share)
+  int per_cu = (int)((160 * 1024) / lds1) < 1 ? 1 : (int)((160 * 1024) / lds1);
+  {
+    static int occ_cache[64][2] = {};          // per (device, instantiation); the query depends on lds1 too, which the two model families share
+    static size_t occ_lds[64][2] = {};
+    int dev = 0;
+    const int di = a.dither > 0.f ? 1 : 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (occ_lds[dev][di] != lds1) {
+        int occ = 0;
+        const hipError_t oe = di ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, stft_mel_kernel<true>, 256, lds1)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, stft_mel_kernel<false>, 256, lds1);
+        (void)hipGetLastError();
+        occ_cache[dev][di] = (oe == hipSuccess && occ > 0) ? occ : per_cu;
+        occ_lds[dev][di] = lds1;
+      }
+      if (occ_cache[dev][di] < per_cu) per_cu = occ_cache[dev][di];
+    }
+  }
   const int n_groups = nwg * d->batch;
   const int grid = n_groups < cu_count() * per_cu ? n_groups : cu_count() * per_cu;
   if (a.dither > 0.f) hipLaunchKernelGGL(stft_mel_kernel<true>, dim3(grid), dim3(256), lds1, stream, a);
