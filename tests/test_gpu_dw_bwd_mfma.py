@@ -121,3 +121,39 @@ def test_random_geometries_sweep():
             scale = max(float(r.abs().max()), 1e-6)
             err = float((out[key].double() - r).abs().max()) / scale
             assert torch.isfinite(out[key]).all() and err <= tol[key], (case, (mode, b, ch, t, k, lens, bn), key, err)
+
+
+def test_strided_depthwise_backward_without_a_data_gradient():
+    """ts_train_dwconv_bwd(dx = NULL): the stem's input are the features and need no gradient (blocks.py:317-338 under module.py:102-127) -- on the strided
+    geometries, whose two gradients are separate launches, only the weight gradient is formed, and it is the one the full call gives; the fused stride-1
+    kernels and a call that asks for nothing refuse."""
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    b, ch, t_in, k, stride = 3, 64, 401, 33, 2
+    pad = (k - 1) // 2
+    t_out = (t_in + 2 * pad - (k - 1) - 1) // stride + 1
+    pin, pout = (t_in + 191) // 192 * 192 + 64, (t_out + 191) // 192 * 192 + 64
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(b, ch, pin, device="cuda", generator=g).bfloat16()
+    dy = torch.randn(b, ch, pout, device="cuda", generator=g).bfloat16()
+    w = torch.randn(ch, k, device="cuda", generator=g) / k ** 0.5
+    li = torch.tensor([t_in, 300, 77], dtype=torch.int32, device="cuda")
+    lo = ((li + 2 * pad - (k - 1) - 1) // stride + 1).to(torch.int32)
+    dx = torch.zeros(b, ch, pin, device="cuda").bfloat16()
+    dw_full, dw_only = torch.zeros(ch, k, device="cuda"), torch.zeros(ch, k, device="cuda")
+    args = lambda dxp, dwp: (dy.data_ptr(), x.data_ptr(), li.data_ptr(), lo.data_ptr(), w.data_ptr(), dxp, dwp, b, ch, t_in, t_out, k, stride, 1, pad, pin, pout, 1, st)
+    assert L.ts_train_dwconv_bwd(*args(dx.data_ptr(), dw_full.data_ptr())) == 0
+    assert L.ts_train_dwconv_bwd(*args(None, dw_only.data_ptr())) == 0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dw_only, dw_full, rtol=1e-5, atol=1e-5)        # float atomics over clip groups: the same sum in another order
+    assert float(dw_full.abs().max()) > 0
+    TS_EINVAL = -1
+    assert L.ts_train_dwconv_bwd(*args(None, None)) == TS_EINVAL                           # nothing asked for
+    # a fused stride-1 geometry forms both gradients in one pass and wants the buffer
+    t = 300
+    p1 = (t + 191) // 192 * 192 + 64
+    x1, dy1 = torch.randn(2, 64, p1, device="cuda", generator=g).bfloat16(), torch.randn(2, 64, p1, device="cuda", generator=g).bfloat16()
+    l1 = torch.tensor([t, 200], dtype=torch.int32, device="cuda")
+    rc = L.ts_train_dwconv_bwd(dy1.data_ptr(), x1.data_ptr(), l1.data_ptr(), l1.data_ptr(), w.data_ptr(), None, dw_only.data_ptr(), 2, 64, t, t, k, 1, 1, pad, p1, p1, 1, st)
+    assert rc == TS_EINVAL
