@@ -10,8 +10,10 @@ resident in HBM, replayed from a hipGraph.
 Prints ONE JSON line on rank 0.  Inference shards by clip (independent units, no collective on the data path):
 every rank runs its own 64-clip batch, scaling is "weak".  `roofline` is for the dominant kernel family
 (ts::tcs_split_kernel / ts::tcs_kernel, all 78 launches of a step): algorithmic bytes (ideal fusion, SURVEY 8d) / HIP-event time of the
-encoder segment.  `cpu_baseline` times the CPU oracle (a port of the reference path, fp32 torch-CPU ops) on a
-bounded sample of the same workload on this box's host cores (16 threads, where torch-CPU peaks, plus a 1-thread figure).
+encoder segment.  `cpu_baseline` times the CPU oracle (a port of the reference path, fp32 torch-CPU ops) on a bounded sample of the same
+workload on this box's host cores: P worker processes x 16 torch threads over disjoint clips, P swept IN THIS RUN (1, 4, 16 where the host has
+the cores), best aggregate reported with `processes`, `threads`, `host_cores` (started before this process touches the GPU).  The timed steps
+rotate through 5 distinct 64 x 15 s waveform batches (307 MB > the 256 MB Infinity Cache), so the front end reads its input from HBM.
 At N = 1 the same JSON object also carries `extra`: the other BASELINE.json configurations (C3, C4 phases 1 and 2, C5) measured by
 tools/bench_extra.py in the same process, each with its own roofline (and oracle check where affordable); --no-extra skips them.
 """
@@ -61,54 +63,158 @@ def encoder_layers(module):
     return layers
 
 
-# RECORDED in round 3 with tools/cpu_threads.py on one box of the pool (256-core host), NOT measured by this run: audio-s/s of the oracle
-# by torch thread count -- why `cpu_baseline` uses 16 threads
-CPU_THREAD_SWEEP_RECORDED = {8: 117, 16: 167, 32: 104, 64: 73}
+def cpu_baseline_sweep(seconds=15, budget_s=40.0, repeat_blocks=3):
+    """`cpu_baseline`, measured in this run: the oracle (port of the reference path, fp32 torch-CPU ops) as P processes x T threads over
+    disjoint clips of the workload (tools/cpu_oracle_worker.py), P swept over (1, 4, 16) as far as the host has P * T cores (T = 16, where one
+    torch-CPU process peaks for this model: more threads only add synchronisation), plus a 1-process x 1-thread point.  Every
+    configuration: the workers build the model, run one warm-up pass, wait at a common start line, run `iters` timed passes; the
+    configuration's rate is (all clips x seconds x iters) / (the slowest worker's time).  The best rate is the value.  MUST run before this
+    process initialises the GPU (the workers are child processes)."""
+    import subprocess
+    host = os.cpu_count() or 1
+    threads = min(16, host)
+    t_start = time.perf_counter()
+    worker = os.path.join(ROOT, "tools", "cpu_oracle_worker.py")
+    points = []
+
+    def run_config(procs, thr, clips_each, iters):
+        env = dict(os.environ, OMP_NUM_THREADS=str(thr), MKL_NUM_THREADS=str(thr))
+        ps = [subprocess.Popen([sys.executable, worker, "--first", str(i * clips_each), "--clips", str(clips_each), "--threads", str(thr),
+                                "--iters", str(iters), "--seconds", str(seconds), "--repeat-blocks", str(repeat_blocks)],
+                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env) for i in range(procs)]
+        try:
+            for p in ps:
+                line = p.stdout.readline().strip()
+                if line != "READY":
+                    raise RuntimeError(f"cpu_oracle_worker said {line!r}")
+            for p in ps:                                  # common start line
+                p.stdin.write("GO\n")
+                p.stdin.flush()
+            res = [json.loads(p.stdout.readline()) for p in ps]
+            for p in ps:
+                p.wait(timeout=30)
+        finally:
+            for p in ps:
+                if p.poll() is None:
+                    p.kill()                              # the exact processes this call started
+        slowest = max(r["seconds"] for r in res)
+        return {"processes": procs, "threads": thr, "clips_per_process": clips_each, "iters": iters,
+                "value": procs * clips_each * seconds * iters / slowest, "slowest_worker_s": slowest}
+
+    for procs in (1, 4, 16):
+        if procs > 1 and procs * threads > host:
+            break
+        if time.perf_counter() - t_start > 0.7 * budget_s:
+            break
+        try:
+            points.append(run_config(procs, threads, max(2, 16 // procs), 3))
+        except Exception as e:                            # noqa: BLE001 -- recorded; the headline line must still come out
+            points.append({"processes": procs, "threads": threads, "error": f"{type(e).__name__}: {e}"})
+    one = None
+    if time.perf_counter() - t_start < 0.8 * budget_s:
+        try:
+            one = run_config(1, 1, 2, 1)
+        except Exception as e:                            # noqa: BLE001
+            one = {"error": f"{type(e).__name__}: {e}"}
+    good = [p for p in points if "value" in p]
+    if not good:
+        return {"error": "no CPU configuration finished", "sweep": points}
+    best = max(good, key=lambda p: p["value"])
+    return {"value": best["value"], "unit": "audio-seconds/s", "cores": best["processes"] * best["threads"], "processes": best["processes"],
+            "threads": best["threads"], "host_cores": host, "kind": "port",
+            "sample": f"QuartzNet15x5 fp32 oracle, {best['processes']} process(es) x {best['threads']} threads, {best['clips_per_process']} x {seconds} s clips each "
+                      f"(disjoint clips of the workload), {best['iters']} timed passes after 1 warm-up, common start line",
+            "sweep": points, "one_thread": one, "measured_in_this_run": True, "sweep_wall_s": round(time.perf_counter() - t_start, 1)}
 
 
-def cpu_baseline(module, clips=16, seconds=15, iters=4, threads=16, wav=None, keep_logits=False):
-    """Oracle (port of the reference path) on the host cores, bounded sample.  16 threads is where torch-CPU
-    peaks for this model on the GPU box's 256-core host (CPU_THREAD_SWEEP_RECORDED, measured once with tools/cpu_threads.py);
-    more threads only add synchronisation overhead, so `cores` reports the threads actually used and `host_cores` what the box has.
-    `wav` (CPU, [clips, samples]): time the oracle on these clips -- bench.py passes the first clips of the GPU batch, so that the
-    logits of the first pass double as the full-size parity check of the headline configuration."""
+def oracle_logits(module, wav, seconds, threads=16):
+    """fp32 oracle logits [n, V, T'] of `wav` (CPU): the checker of the headline configuration's full-size parity statement."""
     from oracle import frontend as ofe
     from oracle import tcs as otcs
-    from oracle import decode as odec
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     arch = otcs.quartznet_arch(repeat_blocks=3)
     sd = {k: v.detach().cpu() for k, v in module.encoder.state_dict().items()}
     dsd = {k: v.detach().cpu() for k, v in module.decoder.state_dict().items()}
-    if wav is None:
-        g = torch.Generator().manual_seed(1234)
-        wav = 0.1 * torch.randn(clips, 16000 * seconds, generator=g)
-    clips = wav.shape[0]
-    lengths = torch.full((clips,), 16000 * seconds)
-    kept = {}
+    lengths = torch.full((wav.shape[0],), 16000 * seconds)
+    with torch.no_grad():
+        feats, fl = ofe.filterbank_features(wav, lengths)
+        enc, _ = otcs.encoder_forward(arch, sd, feats, fl)
+        return otcs.conv1d_decoder_forward(dsd, enc)
 
-    def run():
-        with torch.no_grad():
-            feats, fl = ofe.filterbank_features(wav, lengths)
-            enc, _ = otcs.encoder_forward(arch, sd, feats, fl)
-            logits = otcs.conv1d_decoder_forward(dsd, enc)
-            ids = logits.argmax(1).numpy()
-            if keep_logits and not kept:
-                kept["logits"] = logits
-            return [odec.collapse_repeats(r) for r in ids]
-    run()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        run()
-    dt = (time.perf_counter() - t0) / iters
-    res = {"value": clips * seconds / dt, "unit": "audio-seconds/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
-           "kind": "port",
-           "thread_sweep_recorded_round3": {"note": "recorded once with tools/cpu_threads.py on a box of this pool, not measured in this run",
-                                            "audio_s_per_s_by_threads": {str(k): v for k, v in CPU_THREAD_SWEEP_RECORDED.items()}},
-           "sample": f"QuartzNet15x5 fp32 oracle, {clips}x{seconds} s clips (the first {clips} of the GPU batch), {iters} timed passes "
-                     "after 1 warm-up"}
-    if keep_logits:
-        res["_logits"] = kept["logits"]
-    return res
+
+def predict_api(module, wavs, batch, seconds, headline_value):
+    """What a drop-in user gets: wall time of `module.predict(wav)` (reference module.py:88-100) per call -- input copy into the module's
+    replayed graph, the ~90 launches, D2H of the collapsed ids and the host string join included -- with the module's inference graph on
+    (the default) and off (eager launches from Python), at the headline size (C2) and at C1's named size (QuartzNet5x5, 4 x 10 s)."""
+    from thunder_speech_amd.quartznet.compatibility import build_synthetic_quartznet
+    from thunder_speech_amd.utils import variance_preserving_init_
+
+    def timed(mod, inputs, n):
+        for i in range(3):
+            strings = mod.predict(inputs[i % len(inputs)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            strings = mod.predict(inputs[i % len(inputs)])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, strings
+
+    def both(mod, inputs, n, audio_s):
+        res = {}
+        for tag, flag in (("graph_on", None), ("graph_off", False)):
+            mod.graph_inference = flag
+            mod.reset_inference_graphs()
+            dt, strings = timed(mod, inputs, n)
+            res[tag] = {"ms_per_call": dt * 1e3, "audio_seconds_per_s": audio_s / dt, "mean_chars_per_string": sum(map(len, strings)) / len(strings)}
+        return res
+
+    out = {"what": "wall time per module.predict(wav) call incl. input copy, D2H and the host string join; graph_on = the module's per-signature "
+                   "hipGraph (default in eval mode under no_grad), graph_off = eager launches from Python; inputs rotate like the headline's"}
+    with torch.no_grad():
+        dev = wavs[0].device
+        c2 = both(module, wavs, 20, batch * seconds)
+        c2["workload"] = f"QuartzNet15x5, {batch}x{seconds} s (BASELINE.json configs[1])"
+        c2["graph_on_vs_headline"] = c2["graph_on"]["audio_seconds_per_s"] / headline_value
+        out["c2"] = c2
+        m5 = build_synthetic_quartznet(repeat_blocks=1)
+        variance_preserving_init_(m5.encoder, m5.decoder, seed=0)
+        m5 = m5.to(dev).eval()
+        g = torch.Generator().manual_seed(77)
+        w5 = [(0.1 * torch.randn(4, 160000, generator=g)).to(dev) for _ in range(3)]
+        c1 = both(m5, w5, 50, 40.0)
+        c1["workload"] = "QuartzNet5x5, 4x10 s (BASELINE.json configs[0] at its named size, on the GPU)"
+        out["c1"] = c1
+    module.graph_inference = False
+    module.reset_inference_graphs()
+    return out
+
+
+def scaling_block(result, c4_ddp):
+    """Per-N summary for the driver's 1 / 2 / 4 / 8 runs: this run's N, audio-s/s, c4_ddp step/s, and the speed-up against the N = 1 line a
+    previous run of this checkout stored (gpurun_out/bench_n1.json; written by every N = 1 run).  Efficiency is the driver's to compute."""
+    store = os.path.join(ROOT, "gpurun_out", "bench_n1.json")
+    n = result["n_gpus"]
+    cur = {"n_gpus": n, "audio_seconds_per_s": result["value"],
+           "c4_ddp_step_per_s": (c4_ddp or {}).get("value"), "c4_ddp_ms_per_step": (c4_ddp or {}).get("ms_per_step")}
+    blk = dict(cur, inference_scaling="weak (64 x 15 s per GPU)", c4_ddp_scaling="strong (global batch 256 x 10 s)")
+    if n == 1:
+        try:
+            os.makedirs(os.path.dirname(store), exist_ok=True)
+            with open(store, "w") as f:
+                json.dump(cur, f)
+        except OSError:
+            pass
+        blk["vs_n1"] = {"audio_seconds_per_s": 1.0, "c4_ddp_step_per_s": 1.0 if cur["c4_ddp_step_per_s"] else None, "n1_source": "this run"}
+    else:
+        try:
+            with open(store) as f:
+                n1 = json.load(f)
+            blk["vs_n1"] = {"audio_seconds_per_s": cur["audio_seconds_per_s"] / n1["audio_seconds_per_s"],
+                            "c4_ddp_step_per_s": (cur["c4_ddp_step_per_s"] / n1["c4_ddp_step_per_s"]) if (cur["c4_ddp_step_per_s"] and n1.get("c4_ddp_step_per_s")) else None,
+                            "n1_source": "gpurun_out/bench_n1.json (the N = 1 run of this checkout)", "n1": n1}
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
+            blk["vs_n1"] = None                      # no N = 1 line stored on this box
+    return blk
 
 
 def parity_check(gpu_logits, ref_logits, gpu_ids, labels_blank=28):
@@ -147,6 +253,8 @@ def main():
                     help="random: random-init weights of the architecture (the contract's default); trained: QuartzNet15x5 trained on this box first "
                          "(tools/train_margin_model.py, ~1 min) -- timing is the same, `check` then compares transcripts that mean something")
     ap.add_argument("--no-trained-check", action="store_true", help="skip `check_trained` (training on the box + transcript identity vs the fp32 oracle)")
+    ap.add_argument("--no-predict-api", action="store_true", help="skip `predict_api` (module.predict() wall time, graph on / off, C2 and C1 sizes)")
+    ap.add_argument("--input-batches", type=int, default=5, help="distinct waveform batches the timed steps rotate through (5 x 61 MB > the 256 MB Infinity Cache)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,12 +271,19 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    # the CPU baseline runs FIRST: its worker processes are children of a process that has not touched the GPU yet
+    cpu_sweep = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_sweep = cpu_baseline_sweep(seconds=args.seconds)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (this benchmark has no CPU path)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (WORLD_SIZE set) -- with ANY number of ranks, one included -- the RCCL group comes up and every
+    # collective of the multi-rank path runs (probe all-reduce, barriers, max-over-ranks, the gradient exchange of c4_ddp)
+    dist_on = "WORLD_SIZE" in os.environ
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -191,15 +306,19 @@ def main():
         module, hist = tmm.train(device, verbose=False)
         trained_info = {"train_seconds": time.perf_counter() - t_tr, "ctc_loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1,
                         "validation_margin": hist[-1][2]}
-        wav = tmm.tone_clips(B, S, 4242 + rank, "cpu")[0].to(device)     # the task's own clips: transcripts of noise would mean nothing
+        wavs = [tmm.tone_clips(B, S, 4242 + rank + 1000 * i, "cpu")[0].to(device) for i in range(max(args.input_batches, 1))]   # the task's own clips
     else:
         module = build_model(device)
         g = torch.Generator().manual_seed(1234 + rank)
-        wav = (0.1 * torch.randn(B, 16000 * S, generator=g)).to(device)
+        wavs = [(0.1 * torch.randn(B, 16000 * S, generator=g)).to(device) for _ in range(max(args.input_batches, 1))]
+    # the timed steps rotate through `wavs`: 5 x 61.4 MB of distinct samples do not fit the 256 MB Infinity Cache, so every step's front end
+    # reads its waveforms from HBM (one replayed graph per input buffer: no copy inside the timed region)
+    wav = wavs[0]
     lengths = torch.full((B,), 16000 * S, dtype=torch.int32, device=device)
+    module.graph_inference = False          # the headline times the launch sequence under bench.py's own graphs; `predict_api` below times the module's
 
-    def step():
-        logits, _ = module(wav, lengths)
+    def step(w=None):
+        logits, _ = module(wav if w is None else w, lengths)
         return greedy_decode(logits)
 
     def encoder_only(feats, fl):
@@ -212,36 +331,38 @@ def main():
         feats, fl = module.audio_transform(wav, lengths)
         side = torch.cuda.Stream(device)
         if args.no_graph:
-            run_step = step
+            run_steps = [(lambda w=w: step(w)) for w in wavs]
             run_enc = lambda: encoder_only(feats, fl)
         else:
-            g_step, g_enc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            g_steps, g_enc = [torch.cuda.CUDAGraph() for _ in wavs], torch.cuda.CUDAGraph()
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
                 step()                          # the library's arena buffers are per stream: let this stream's exist (and be zeroed once)
                 encoder_only(feats, fl)         # before the capture, or their one-time zero fill would be replayed with every step
-                with torch.cuda.graph(g_step, stream=side):
-                    out = step()
+                for gs_, w in zip(g_steps, wavs):
+                    with torch.cuda.graph(gs_, stream=side):
+                        out = step(w)
                 with torch.cuda.graph(g_enc, stream=side):
                     enc_out = encoder_only(feats, fl)
-            run_step, run_enc = g_step.replay, g_enc.replay
+            run_steps, run_enc = [gs_.replay for gs_ in g_steps], g_enc.replay
+        n_in = len(run_steps)
 
         def barrier():
-            if world > 1:
+            if dist_on:
                 dist.barrier()
 
         from tools import prof_mark
-        for _ in range(args.warmup):
-            run_step()
+        for i in range(args.warmup):
+            run_steps[i % n_in]()
         barrier(); torch.cuda.synchronize()
         prof_mark.mark(device)                      # profiled runs (TS_PROF_MARK=1): brackets the timed region in the kernel trace
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run_step()
+        for i in range(args.steps):
+            run_steps[i % n_in]()
         torch.cuda.synchronize(); barrier()
         dt = time.perf_counter() - t0
         prof_mark.mark(device)
-        dt = max_over_ranks(dt, device)
+        dt = max_over_ranks(dt, device, force=dist_on)
 
         # dominant kernel family: the fused TCS launches of the encoder, timed with HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -261,13 +382,15 @@ def main():
     traffic, traffic_source = pmc_traffic(B, S)
     result = {
         "metric": "audio-seconds/s (16 kHz) QuartzNet15x5 inference",
-        "value": value, "unit": "audio-seconds/s", "n_gpus": world, "rccl_world_size": rccl_world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "audio-seconds/s", "n_gpus": world, "rccl_world_size": rccl_world,
+        "process_group": "nccl (RCCL), size from a real all-reduce" if dist_on else None, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"QuartzNet15x5 inference, batch {B}x{S} s per GPU, 16 kHz synthetic clips "
                                "(BASELINE.json configs[1]); step = mel front end + 78 fused TCS launches + decoder + "
                                "greedy decode (argmax + collapse), hipGraph replay" if not args.no_graph else
                                f"QuartzNet15x5 inference, batch {B}x{S} s per GPU (eager launches)",
+                   "input_batches_rotated": len(wavs), "input_bytes_rotated": len(wavs) * B * 16000 * S * 4,
                    "batch_per_gpu": B, "clip_seconds": S, "random_init": args.weights == "random", "weights": args.weights, "trained": trained_info},
         "roofline": {"bound": "hbm", "kernel": "ts::tcs_split_kernel / ts::tcs_kernel (all fused TCS launches of one step)",
                      "launches_per_step": n_launch,
@@ -280,8 +403,8 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             n_chk = min(16, B)
-            result["cpu_baseline"] = cpu_baseline(module, seconds=S, wav=wav[:n_chk].cpu(), keep_logits=True)
-            ref_logits = result["cpu_baseline"].pop("_logits")
+            result["cpu_baseline"] = cpu_sweep
+            ref_logits = oracle_logits(module, wav[:n_chk].cpu(), S)      # the checker: fp32 oracle on the first clips of the GPU batch
             with torch.no_grad():
                 logits, _ = module(wav, lengths)
                 ids, collapsed, counts = greedy_decode(logits)
@@ -293,8 +416,6 @@ def main():
             result["check"]["collapsed_sequences_equal"] = sum(int(a == b) for a, b in zip(ref_seqs, dev_seqs))
             result["check"]["collapsed_sequences_compared"] = n_chk
             result["check"]["all_logits_finite"] = bool(torch.isfinite(logits).all())
-            one = cpu_baseline(module, clips=2, seconds=15, iters=1, threads=1)
-            result["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
             if not args.no_trained_check:
                 # the transcript clause of north_star at this configuration's size, on weights that transcribe: QuartzNet15x5 trained on this box
                 # by the repository's own graphed CTC step (tools/train_margin_model.py), then HIP bf16 inference vs the fp32 oracle on 16 of
@@ -314,13 +435,21 @@ def main():
                     import traceback
                     print(f"bench.py: check_trained failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
                     result["check_trained"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.no_predict_api:
+        try:
+            result["predict_api"] = predict_api(module, wavs, B, S, value)
+        except Exception as e:                            # noqa: BLE001 -- recorded; the headline line must still come out
+            import traceback
+            print(f"bench.py: predict_api failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+            result["predict_api"] = {"error": f"{type(e).__name__}: {e}"}
     # C4 as the reference runs it (DDP, strong scaling: global batch 256 x 10 s over the ranks), on EVERY N: all ranks take part.
     # An extra must never take the headline line down with it: exceptions are recorded, and a watchdog on every rank covers what an
     # exception handler cannot -- a collective that never returns (e.g. because ONE rank failed): past the deadline rank 0 prints the
     # line with the error in place of the result and every rank leaves.
     c4_ddp = None
     failed_extra = False
-    if not args.no_extra and "c4" in args.extra.split(","):
+    extras = [n for n in args.extra.split(",") if n]
+    if not args.no_extra and ("c4" in extras or "c4_ddp" in extras):
         del module
         module = None
         torch.cuda.empty_cache()
@@ -342,7 +471,7 @@ def main():
         from tools import bench_extra
         try:
             c4_ddp = bench_extra.c4_ddp(device, world=world, rank=rank)
-            if world > 1:
+            if dist_on:
                 dist.barrier()                       # every rank got through: only now is it safe to stop the watchdogs
         except Exception as e:
             import traceback
@@ -359,12 +488,13 @@ def main():
     if rank == 0:
         if not args.no_extra and world == 1:
             from tools import bench_extra
-            result["extra"] = bench_extra.run(device, tuple(n for n in args.extra.split(",") if n), check=not args.no_cpu_baseline)
+            result["extra"] = bench_extra.run(device, tuple(n for n in extras if n != "c4_ddp"), check=not args.no_cpu_baseline)
             failed_extra = failed_extra or any(isinstance(v, dict) and "error" in v for v in result["extra"].values())
         if c4_ddp is not None:
             result.setdefault("extra", {})["c4_ddp"] = c4_ddp
+        result["scaling_block"] = scaling_block(result, c4_ddp)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if failed_extra:

@@ -244,7 +244,8 @@ int ts_spec_mask_apply(void* features, int32_t elem_bytes, int32_t batch, int32_
 /* ------------------------------------------------------------------------------------------------
  * Greedy CTC decode: argmax over classes then run-collapse (torch.unique_consecutive), replaces
  * module.py:100 + text_processing/transform.py:107-110.  logits f32 [B][V][pitch]; ids int32 [B][T]
- * (argmax per frame, lowest index wins ties); collapsed int32 [B][T] + counts int32 [B].
+ * (argmax per frame, lowest index wins ties); collapsed int32 [B][T] + counts int32 [B]; collapsed[b][i] = 0
+ * for i >= counts[b] (the host's token-table lookup runs over whole rows).
  * ---------------------------------------------------------------------------------------------- */
 int ts_greedy_decode(const float* logits, int32_t batch, int32_t n_classes, int32_t n_frames, int32_t pitch,
                      int32_t* ids, int32_t* collapsed, int32_t* counts, void* stream);

@@ -227,3 +227,32 @@ def test_a_subclass_override_of_update_special_optimizer_arg_is_honoured():
 
     m = Custom(torch.nn.Linear(4, 4), torch.nn.Linear(4, 3), torch.nn.Identity(), BatchTextTransformer(tokens=["a", "b"]), optimizer_kwargs={"lr": 0.25})
     assert m.configure_optimizers().defaults["lr"] == 0.5
+
+
+def test_decode_collapsed_join_plans_equal_the_reference_join():
+    """decode_collapsed's three join plans (character table / token table / per-id loop) against the reference semantics restated in
+    `_ids_to_text` (text_processing/transform.py:107-120: join, "▁" and "|" -> " ", special-token STRINGS removed), incl. vocabularies whose
+    ordinary tokens could spell a special string (they must not take the character plan) and an out-of-vocabulary id (IndexError)."""
+    import torch
+    from thunder_speech_amd.text_processing.transform import BatchTextTransformer
+    labels = [" "] + [chr(ord("a") + i) for i in range(26)] + ["'"]
+    cases = [(labels, {}, "chars"), (labels + ["|", "▁", "é", "ß"], dict(start_token="<s>", end_token="</s>"), "chars"),
+             (labels + ["€"], {}, "chars"),
+             (labels + ["<"], {}, "table"),                          # "<" + "blank>"-like spellings: the removal pass must see the joined text
+             (["▁the", "▁", "a", "b|", "<", "blank", ">", "é", "ab▁c"], {}, "table"),
+             (labels, dict(unknown_token="<unk>"), "table"), (["a", "b\x00"], {}, "loop")]
+    g = torch.Generator().manual_seed(0)
+    for toks, kw, want_plan in cases:
+        tt = BatchTextTransformer(tokens=list(toks), **kw)
+        assert tt._decode_plan()[0] == want_plan, (toks[-3:], tt._decode_plan()[0])
+        v = len(tt.vocab.itos)
+        rows = torch.randint(0, v, (9, 203), generator=g, dtype=torch.int32)
+        counts = torch.randint(0, 204, (9,), generator=g, dtype=torch.int32)
+        counts[0], counts[1] = 0, 203
+        for i in range(9):
+            rows[i, int(counts[i]):] = 0                              # what ts_greedy_decode leaves beyond the count
+        assert tt.decode_collapsed(rows, counts) == [tt._ids_to_text(rows[i, : int(counts[i])].tolist()) for i in range(9)]
+        rows[3, 0] = v
+        counts[3] = max(int(counts[3]), 1)
+        with pytest.raises(IndexError):
+            tt.decode_collapsed(rows, counts)

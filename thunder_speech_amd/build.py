@@ -46,6 +46,15 @@ def build(force: bool = False, verbose: bool = True, only=None) -> str:
     procs = []
     variant = os.environ.get("TS_LIB_VARIANT", "")
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    if not variant:
+        # a product build leaves only its own objects behind: variant objects of past A/B runs (tools/variants.py) and objects of sources that
+        # no longer exist would otherwise travel to the GPU box with every snapshot
+        keep = {os.path.basename(src) + ".o" for src in sources()}
+        for name in os.listdir(os.path.join(PKG, "build")):
+            if name.endswith(".o") and name not in keep:
+                os.remove(os.path.join(PKG, "build", name))
+        for stale in glob.glob(os.path.join(PKG, LIB_NAME.replace(".so", ".*.so"))):
+            os.remove(stale)
     for src in sources():
         # a variant build recompiles only the sources named in `only` and links the product objects of the rest
         own = not variant or only is None or os.path.basename(src) in only

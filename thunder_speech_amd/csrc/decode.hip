@@ -102,6 +102,8 @@ __global__ __launch_bounds__(GTH) void greedy_kernel(const float* __restrict__ l
     }
     __syncthreads();
   }
+  // entries beyond the row's count: 0 (a valid id), so that the host's table lookup over the whole [B, T'] buffer needs no mask
+  for (int i = carry_s + tid; i < n_frames; i += GTH) collapsed[(size_t)b * n_frames + i] = 0;
   if (tid == 0) counts[b] = carry_s;
 }
 

@@ -63,8 +63,99 @@ class BaseCTCModule(_Base):
         self.validation_cer, self.validation_wer = CharErrorRate(), WordErrorRate()
         self.example_input_array = (torch.randn((10, 16000)), torch.randint(100, 16000, (10,)))
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # Inference as users call it (`module(x, lengths)` / `module.predict(x)` in eval mode under no_grad): the ~90 launches of a forward are
+    # replayed from a hipGraph per input signature instead of being issued from Python one by one (no reference counterpart; the reference's
+    # forward is module.py:74-86).  `graph_inference`: None = automatic (on for the model families whose whole forward is capture-safe: the
+    # mel front end + QuartzNet / Citrinet encoder + this package's decoders), True / False = forced on / off.
+    graph_inference: Optional[bool] = None
+    MAX_INFERENCE_GRAPHS = 4             # input signatures kept (each owns its static input copy and the launch arena of its stream)
+
+    def _inference_graph_ok(self, x: Tensor) -> bool:
+        if not x.is_cuda or self.training or torch.is_grad_enabled() or self.graph_inference is False:
+            return False
+        if torch.cuda.is_current_stream_capturing():          # the caller is recording its own graph: launch into it
+            return False
+        if getattr(self, "_frozen_graph", None) is not None:  # graph_frozen_encoder() replays its own graph inside the forward
+            return False
+        auto = getattr(self, "_graph_auto", None)
+        if auto is None:
+            from .blocks import _Conv1dDecoder, _LinearDecoder
+            from .quartznet.blocks import EncoderSequential
+            from .quartznet.transform import FilterbankFeatures
+            auto = self._graph_auto = (isinstance(self.encoder, EncoderSequential) and isinstance(self.audio_transform, FilterbankFeatures)
+                                       and isinstance(self.decoder, (_Conv1dDecoder, _LinearDecoder)))
+        if not (self.graph_inference or auto):
+            return False
+        return not any(m.training for m in (self.encoder, self.decoder, self.audio_transform))
+
+    def _weights_stamp(self):
+        """Changes whenever a parameter / buffer of the model is written in place (optimizer step, load_state_dict, manual edits): the sum
+        of the tensors' version counters.  The tensor list is rebuilt on train() / _apply() (.to, .half ...) / load_state_dict; code that
+        REPLACES a Parameter object calls reset_inference_graphs()."""
+        ts = getattr(self, "_stamp_tensors", None)
+        if ts is None:
+            ts = self._stamp_tensors = [t for m in (self.audio_transform, self.encoder, self.decoder)
+                                        for t in list(m.parameters()) + list(m.buffers())]
+        return sum(t._version for t in ts)
+
+    def reset_inference_graphs(self) -> None:
+        self.__dict__.pop("_stamp_tensors", None)
+        self.__dict__.pop("_infer_graphs", None)
+        self.__dict__.pop("_graph_auto", None)
+
+    def train(self, mode: bool = True):
+        self.reset_inference_graphs()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.reset_inference_graphs()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.reset_inference_graphs()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _graphed_inference(self, x: Tensor, lengths: Tensor):
+        """(logits, out_lengths, ids, collapsed, counts) -- the graph's OWN output buffers, overwritten by the next call of this signature --
+        or None: this input signature has no graph (yet).  A signature is captured the SECOND time it is seen (a shape that never repeats
+        would pay three forward passes for nothing) and at most MAX_INFERENCE_GRAPHS signatures are kept; everything else runs eagerly.
+        All captures of a module record on ONE side stream, so that re-captures (after a weight update) find the launch arena of the
+        previous ones instead of growing a new one (tensors.arena is keyed by stream)."""
+        from .utils import GraphedForward
+        graphs = self.__dict__.get("_infer_graphs")
+        stamp = self._weights_stamp()
+        if graphs is None or graphs[0] != stamp:
+            def run(xx, ll):
+                logits, out_lengths = self._forward_eager(xx, ll)
+                return (logits, out_lengths) + greedy_decode(logits)
+            streams = self.__dict__.setdefault("_infer_streams", {})
+            side = streams.get(str(x.device))
+            if side is None:
+                side = streams[str(x.device)] = torch.cuda.Stream(device=x.device)
+            graphs = self.__dict__["_infer_graphs"] = (stamp, GraphedForward(run, stream=side), {})
+        _, gf, seen = graphs
+        if lengths.device != x.device:
+            lengths = lengths.to(x.device)
+        key = gf.signature(x, lengths)
+        if not gf.has(key):
+            n = seen.get(key, 0)
+            if n < 1 or gf.count() >= self.MAX_INFERENCE_GRAPHS:
+                if len(seen) > 256:
+                    seen.clear()
+                seen[key] = n + 1
+                return None
+        return gf(x, lengths)
+
     def forward(self, x: Tensor, lengths: Tensor) -> Tuple[Tensor, Optional[Tensor]]:
         """[batch, time] audio -> (logits [batch, vocab, time'] BEFORE softmax, output lengths)."""
+        if self._inference_graph_ok(x):
+            out = self._graphed_inference(x, lengths)
+            if out is not None:
+                return out[0].clone(), out[1].clone()      # the caller may keep them across calls: never hand out the graph's buffers
+        return self._forward_eager(x, lengths)
+
+    def _forward_eager(self, x: Tensor, lengths: Tensor) -> Tuple[Tensor, Optional[Tensor]]:
         graphed = getattr(self, "_frozen_graph", None)
         if graphed is not None and x.is_cuda and not self.encoder.training and \
                 not any(p.requires_grad for p in self.encoder.parameters()):
@@ -87,8 +178,12 @@ class BaseCTCModule(_Base):
     def predict(self, x: Tensor) -> List[str]:
         """Greedy transcription; every clip is treated as full length (module.py:98)."""
         audio_lengths = torch.full((x.shape[0],), x.shape[-1], dtype=torch.int32, device=x.device)
-        pred, _ = self(x, audio_lengths)
-        _, collapsed, counts = greedy_decode(pred)
+        out = self._graphed_inference(x, audio_lengths) if self._inference_graph_ok(x) else None
+        if out is not None:
+            collapsed, counts = out[3], out[4]             # consumed right here: no copies
+        else:
+            pred, _ = self._forward_eager(x, audio_lengths)
+            _, collapsed, counts = greedy_decode(pred)
         return self.text_transform.decode_collapsed(collapsed, counts)
 
     def training_step(self, batch, batch_idx: int) -> torch.Tensor:

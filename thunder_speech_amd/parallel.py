@@ -27,48 +27,75 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def max_over_ranks(seconds: float, device=None) -> float:
-    """MAX all-reduce of a host-side duration (RCCL when `device` is a GPU, gloo on CPU)."""
+def max_over_ranks(seconds: float, device=None, force: bool = False) -> float:
+    """MAX all-reduce of a host-side duration (RCCL when `device` is a GPU, gloo on CPU).  A one-rank group skips the collective unless
+    `force` (bench.py under torch.distributed.run with ONE rank: the multi-rank code path, collective included, on the hardware at hand)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def launch_ranks(script: str, n_ranks: int, argv, timeout_s: float = None, env=None) -> int:
+def _descendants(pid: int):
+    """pids of every live descendant of `pid` (children first), read from /proc: torch's elastic agent starts its workers in their own
+    sessions, so a killpg on the launcher's group does not reach them."""
+    import os
+    kids = {}
+    for name in os.listdir("/proc"):
+        if not name.isdigit():
+            continue
+        try:
+            with open(f"/proc/{name}/stat") as f:
+                fields = f.read().rsplit(")", 1)[1].split()
+            kids.setdefault(int(fields[1]), []).append(int(name))
+        except (OSError, IndexError, ValueError):
+            continue
+    out, todo = [], [pid]
+    while todo:
+        for k in kids.get(todo.pop(), []):
+            out.append(k)
+            todo.append(k)
+    return out
+
+
+def launch_ranks(script: str, n_ranks: int, argv, timeout_s: float = None, env=None, stdout=None, stderr=None) -> int:
     """Start `n_ranks` fresh processes of `script` (one per GPU of this node) under `torch.distributed.run` and return the launcher's
     exit code -- what `pl.Trainer(accelerator="gpu", devices=-1)` does for the reference's users (docs/quick reference guide.md:74-79,
-    tests/quartznet/test_module_qn.py:46-53: one command starts all ranks).  The children inherit stdout / stderr, so rank 0's result
-    line is the caller's output; a failing rank makes the launcher tear the others down and return non-zero.
-    MUST be called before the calling process touches the GPU: the ranks are CHILD processes (never an exec of this one), and the
-    parent only waits."""
+    tests/quartznet/test_module_qn.py:46-53: one command starts all ranks).  The children inherit stdout / stderr (or write to the files
+    given as `stdout` / `stderr`), so rank 0's result line is the caller's output; a failing rank makes the launcher tear the others down
+    and return non-zero.  The ranks are CHILD processes (never an exec of this one), and the parent only waits; the rendezvous is a c10d
+    store on a port the launcher picks itself (--rdzv-endpoint 127.0.0.1:0), so concurrent launches cannot collide on a pre-probed port."""
     import os
-    import socket
+    import signal
     import subprocess
     import sys
     if n_ranks < 1:
         raise ValueError("launch_ranks: n_ranks must be >= 1")
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:      # a free rendezvous port on the loop-back interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script] + [str(a) for a in argv]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr=127.0.0.1", script] + [str(a) for a in argv]
     child_env = dict(os.environ if env is None else env)
     child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this driver (RCCL across processes)
     child_env.setdefault("OMP_NUM_THREADS", "4")
-    proc = subprocess.Popen(cmd, env=child_env, start_new_session=True)
+    proc = subprocess.Popen(cmd, env=child_env, start_new_session=True, stdout=stdout, stderr=stderr)
     try:
         return proc.wait(timeout=timeout_s)
     except subprocess.TimeoutExpired:
-        import signal
-        os.killpg(proc.pid, signal.SIGTERM)                            # the exact process group this call started
+        # SIGTERM to the agent (it forwards it to its workers and reaps them), a grace period, then SIGKILL to whatever is left of the
+        # exact process tree this call started -- the workers live in their own sessions, so they are found through /proc, not the group
+        tree = _descendants(proc.pid)
+        os.killpg(proc.pid, signal.SIGTERM)
         try:
-            proc.wait(timeout=15)
+            proc.wait(timeout=30)
         except subprocess.TimeoutExpired:
-            os.killpg(proc.pid, signal.SIGKILL)
-            proc.wait()
+            pass
+        for pid in tree + [proc.pid]:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        proc.wait()
         print(f"launch_ranks: {script} gave no result within {timeout_s:.0f} s; its {n_ranks} ranks were stopped", file=sys.stderr, flush=True)
         return 124
 

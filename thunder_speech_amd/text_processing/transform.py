@@ -87,10 +87,69 @@ class BatchTextTransformer(nn.Module):
             out_list.append(self._ids_to_text(element.tolist()))
         return out_list
 
+    def _decode_plan(self):
+        """How decode_collapsed joins tokens, decided once per vocabulary:
+          ("chars", table[V] uint8/uint32, codec): every ordinary token is ONE character and no ordinary token contains the first character of
+              a removable special string (blank / pad / start / end), so those strings can only come from their own token: the table maps an
+              id straight to its final character ("▁", "|" -> " ", removable specials -> NUL, dropped) and the reference's replace / remove
+              passes (text_processing/transform.py:107-120, vocab.py:124-130) cannot do anything else to the text;
+          ("table", table[V + 2, L], codec, sep): any other vocabulary with tokens of <= 32 characters (BPE pieces): code-point table, one
+              lookup for the batch, the reference's passes on every joined row;
+          ("loop",): tokens containing NUL / the separator, or very long ones."""
+        import numpy as np
+        plan = getattr(self, "_dec_plan", None)
+        if plan is not None and plan[0] == tuple(self.vocab.itos):
+            return plan[1]
+        voc = self.vocab
+        toks = list(voc.itos)
+        removable = {t for t in (voc.blank_token, voc.pad_token, voc.start_token, voc.end_token) if t}
+        ordinary = [t for t in toks if t not in removable]
+        width = max((len(t) for t in toks), default=1) or 1
+        sep = "\x01"
+        if any("\x00" in t or sep in t for t in toks) or any(len(t) == 0 for t in removable):
+            out = ("loop",)
+        elif (all(len(t) == 1 for t in ordinary) and not any(("▁" in r) or ("|" in r) for r in removable)
+              and not any(r[0] in t for r in removable for t in ordinary)):
+            final = [("\x00" if t in removable else (" " if t in ("▁", "|") else t)) for t in toks]
+            narrow = all(ord(ch) < 256 for ch in final)
+            out = ("chars", np.array([ord(ch) for ch in final], dtype=np.uint8 if narrow else np.uint32), "latin-1" if narrow else "utf-32-le")
+        elif width <= 32:
+            narrow = all(ord(ch) < 256 for t in toks for ch in t)
+            arr = np.zeros((len(toks) + 2, width), dtype=np.uint8 if narrow else np.uint32)
+            for i, t in enumerate(toks):
+                arr[i, : len(t)] = [ord(ch) for ch in t]
+            arr[len(toks) + 1, 0] = ord(sep)
+            out = ("table", arr, "latin-1" if narrow else "utf-32-le", sep)
+        else:
+            out = ("loop",)
+        self._dec_plan = (tuple(toks), out)
+        return out
+
     def decode_collapsed(self, collapsed: torch.Tensor, counts: torch.Tensor) -> List[str]:
-        """Strings from the output of the greedy-decode kernel (run-collapsed ids + per-row counts)."""
-        rows, n = collapsed.detach().to("cpu"), counts.detach().to("cpu").tolist()
-        return [self._ids_to_text(rows[i, : n[i]].tolist()) for i in range(len(n))]
+        """Strings from the output of the greedy-decode kernel (run-collapsed ids + per-row counts): `decode_prediction`'s token join for the
+        whole batch as ONE table lookup + one bytes -> str decode (the per-id Python loop costs more than the GPU's whole forward pass at
+        64 x 751 frames); same strings as `_ids_to_text` row by row (tests/test_host_r2.py compares the three plans with it)."""
+        import numpy as np
+        rows, n = collapsed.detach().to("cpu").numpy(), counts.detach().to("cpu").numpy()
+        plan = self._decode_plan()
+        v = len(self.vocab.itos)
+        if plan[0] == "loop" or rows.size == 0:
+            return [self._ids_to_text(rows[i, : n[i]].tolist()) for i in range(len(n))]
+        b, t = rows.shape
+        if plan[0] == "chars":
+            # entries beyond a row's count are 0 (ts_greedy_decode fills them): the lookup validates every id (IndexError, as the reference's
+            # itos[id] would raise), the slice cuts the row at its count
+            text = np.take(plan[1], rows).tobytes().decode(plan[2])
+            return [text[i * t: i * t + int(n[i])].replace("\x00", "") for i in range(b)]
+        _, table, codec, sep = plan
+        if int(rows.max(initial=0)) >= v or int(rows.min(initial=0)) < 0:       # (entries beyond a row's count are 0: ts_greedy_decode fills them)
+            raise IndexError("decode_collapsed: id outside the vocabulary")
+        ids = np.where(np.arange(t)[None, :] < n[:, None], rows, v)              # beyond the row's count: the empty token
+        ids = np.concatenate([ids, np.full((b, 1), v + 1, dtype=ids.dtype)], axis=1)
+        chars = table[ids].reshape(-1)
+        text = chars[chars != 0].tobytes().decode(codec)
+        voc = self.vocab
+        return [voc.remove_special_tokens(part.replace("▁", " ").replace("|", " ")) for part in text.split(sep)[:b]]
 
     @classmethod
     def from_sentencepiece(cls, output_dir: str) -> "BatchTextTransformer":

@@ -495,6 +495,21 @@ def _pw_bwd(dv: Tensor, u: Tensor, param: Tensor, w2: Tensor, len_u: Tensor = No
 # (ts_train_bn2_chan_bwd's dout2).  Entries live from one autograd node to the next of the same backward pass; GradientSync clears leftovers.
 DEFER_FORK_ADD = True
 _PENDING_ADD = {}
+_PENDING_CHECK_QUEUED = False
+
+
+def _check_pending_add() -> None:
+    """End-of-backward callback (queued by Fork.backward the first time it parks a pair in a backward pass): every parked pair must have
+    been taken by a BlockTail.backward.  A leftover means the block output had ANOTHER consumer besides the Fork (a forward hook, an
+    auxiliary / intermediate-CTC loss, a retained clone): autograd then summed the first gradient with the other consumer's into a new
+    buffer, the key missed, and the residual-branch gradient would be silently missing from the step -- fail instead."""
+    global _PENDING_CHECK_QUEUED
+    _PENDING_CHECK_QUEUED = False
+    if _PENDING_ADD:
+        n = len(_PENDING_ADD)
+        _PENDING_ADD.clear()
+        raise RuntimeError(f"train_ops.Fork: {n} parked gradient pair(s) were never consumed -- a block output that feeds the next block has a second "
+                           "consumer (hook / auxiliary loss); set train_ops.DEFER_FORK_ADD = False for such graphs")
 
 
 def take_pending_add(dout: Tensor):
@@ -512,6 +527,8 @@ class Fork(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res_len=None):
+        global _PENDING_CHECK_QUEUED
+        _PENDING_CHECK_QUEUED = False  # a new forward pass: whatever an interrupted backward left behind is over (its callbacks never ran)
         ctx.res_len = res_len          # int32 lengths: the second output feeds a MaskedConv1d whose input mask's backward is applied HERE
         # x is the output of a one-launch block tail (block_tail tags it): its backward kernel adds the two gradients itself
         ctx.defer_add = bool(getattr(x, "_ts_tail_out", False)) and DEFER_FORK_ADD
@@ -528,7 +545,13 @@ class Fork(torch.autograd.Function):
         if ctx.defer_add and chan_fits(g1.shape[0], g1.shape[2], g1.dtype):
             # the consumer is BlockTail.backward of the previous block: hand it both gradients (keyed by the first one's address; the entry keeps
             # the tensors alive, so the address cannot be reused while it is pending)
+            global _PENDING_CHECK_QUEUED
             _PENDING_ADD[g1.data_ptr()] = (g1, g2, ctx.res_len)
+            if not _PENDING_CHECK_QUEUED:
+                # once per backward pass: when the engine has run every node, nothing may be left parked (works for a plain
+                # loss.backward() + optimizer.step() loop too, which never calls GradientSync.finish / zero_grad)
+                torch.autograd.Variable._execution_engine.queue_callback(_check_pending_add)
+                _PENDING_CHECK_QUEUED = True
             return g1, None
         out = alloc_like(g1)
         ln = ctx.res_len

@@ -150,15 +150,27 @@ class GraphedForward:
     into the graph's static buffers before each replay; the RETURNED TENSORS ARE THE GRAPH'S OWN OUTPUT BUFFERS and are
     overwritten by the next call with the same signature -- consume them (or clone them) before calling again."""
 
-    def __init__(self, fn, warmup: int = 2):
-        self.fn, self.warmup, self._graphs = fn, warmup, {}
+    def __init__(self, fn, warmup: int = 2, stream=None):
+        # `stream`: record every capture on this side stream (default: a fresh one per signature).  The library's launch arena is keyed by
+        # stream (tensors.arena), so an owner that re-captures -- BaseCTCModule after a weight update -- passes one stream and reuses it.
+        self.fn, self.warmup, self._graphs, self._stream = fn, warmup, {}, stream
+
+    @staticmethod
+    def signature(*args: torch.Tensor):
+        return tuple((tuple(a.shape), a.dtype, str(a.device)) for a in args)
+
+    def has(self, key) -> bool:
+        return key in self._graphs
+
+    def count(self) -> int:
+        return len(self._graphs)
 
     def __call__(self, *args: torch.Tensor):
-        key = tuple((tuple(a.shape), a.dtype, str(a.device)) for a in args)
+        key = self.signature(*args)
         entry = self._graphs.get(key)
         if entry is None:
             static_in = [a.detach().clone() for a in args]
-            side = torch.cuda.Stream(device=args[0].device)
+            side = self._stream if self._stream is not None else torch.cuda.Stream(device=args[0].device)
             side.wait_stream(torch.cuda.current_stream(args[0].device))
             with torch.no_grad(), torch.cuda.stream(side):
                 for _ in range(self.warmup):                     # packs weights, sizes arena buffers, sets kernel attributes

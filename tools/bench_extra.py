@@ -328,6 +328,9 @@ def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8, segme
     if global_batch % world:
         raise ValueError(f"global batch {global_batch} does not split over {world} ranks")
     own_group = _one_rank_group() if world == 1 else None
+    # a process group is up: bench.py's own (launched under torch.distributed.run, any number of ranks incl. ONE) or the one-rank group above.
+    # Then every barrier / max-over-ranks / reduce-scatter / all-gather of the multi-rank path runs, whatever the world size
+    group_up = dist.is_available() and dist.is_initialized()
 
     def measure(local, n_steps):
         g = torch.Generator().manual_seed(1234 + rank)
@@ -346,15 +349,15 @@ def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8, segme
 
         def timed(n):
             torch.cuda.synchronize()
-            if world > 1:
+            if group_up:
                 dist.barrier()
             t0 = time.perf_counter()
             for _ in range(n):
                 step()
             torch.cuda.synchronize()
-            if world > 1:
+            if group_up:
                 dist.barrier()
-            return max_over_ranks((time.perf_counter() - t0) / n, device)
+            return max_over_ranks((time.perf_counter() - t0) / n, device, force=group_up)
 
         first = float(step())
         for _ in range(4):
@@ -397,7 +400,10 @@ def c4_ddp(device, world=1, rank=0, global_batch=256, seconds=10, steps=8, segme
            "n_gpus": world, "scaling": "strong", "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s",
            "audio_seconds_per_s": global_batch * seconds / dt, "steps": steps, "loss_first_last": [r["first"], r["last"]],
            "n_collectives_per_step": r["n_coll"], "wire_bytes_per_step_per_rank": r["wire"], "wire_dtype": r["wire_dtype"],
-           "collective": r["collective"] if world > 1 else f"{r['collective']} in loop-back ({'one-rank RCCL group' if own_group else 'pack + unpack only'})",
+           "collective": r["collective"] if world > 1 else (f"{r['collective']} over a ONE-rank RCCL group ("
+                                                           + ("bench.py's own, launched under torch.distributed.run" if (group_up and not own_group) else "created for this measurement")
+                                                           + "): every launch of the real exchange, no bytes over links" if group_up else f"{r['collective']} in loop-back (pack + unpack only)"),
+           "process_group": ("torch.distributed.run" if (group_up and not own_group) else ("own one-rank group" if own_group else None)),
            "n_buckets": r["n_buckets"], "n_graphs": r["n_graphs"],
            "ms_per_step_without_exchange": dt_local * 1e3, "exchange_ms_exposed": max(dt - dt_local, 0.0) * 1e3,
            "roofline": {"bound": "mfma", "model": "3 x forward FLOPs of the global batch (BASELINE.md section 3) / (n_gpus x dense bf16 peak)",
