@@ -82,7 +82,7 @@ class BaseCTCModule(_Base):
         if auto is None:
             from .blocks import _Conv1dDecoder, _LinearDecoder
             from .quartznet.blocks import EncoderSequential
-            from .quartznet.transform import FilterbankFeatures
+            from .quartznet.transform import _FilterbankFeatures as FilterbankFeatures
             auto = self._graph_auto = (isinstance(self.encoder, EncoderSequential) and isinstance(self.audio_transform, FilterbankFeatures)
                                        and isinstance(self.decoder, (_Conv1dDecoder, _LinearDecoder)))
         if not (self.graph_inference or auto):

@@ -15,7 +15,7 @@ timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r6a_bench.json 2>
 echo "bench rc $?"; tail -5 gpurun_out/r6a_bench.err
 python - <<'PY'
 import json
-d = json.loads(open("gpurun_out/r6a_bench.json").read().strip().splitlines()[-1])
+d = json.loads([l for l in open("gpurun_out/r6a_bench.json").read().splitlines() if l.startswith("{")][-1])
 print({k: d[k] for k in ("value", "ms_per_step")}, d["roofline"]["frac"], d["roofline"]["encoder_ms"])
 print("cpu", {k: d["cpu_baseline"].get(k) for k in ("value", "processes", "threads", "host_cores", "sweep_wall_s")}, [ (p.get("processes"), p.get("value")) for p in d["cpu_baseline"]["sweep"]])
 print("predict_api", json.dumps(d.get("predict_api"))[:1500])
