@@ -26,7 +26,7 @@ extern "C" {
 #define TS_EINVAL (-1)       /* bad argument / unsupported shape */
 #define TS_EUNSUPPORTED (-2) /* valid reference configuration this build has no kernel for */
 
-#define TS_ABI_VERSION 10
+#define TS_ABI_VERSION 11
 
 /* Library identification: ABI version and the gfx target the code objects were built for. */
 int ts_abi_version(void);
@@ -330,6 +330,13 @@ int ts_train_dwconv_bwd(const void* dy, const void* x, const int32_t* len_in, co
  * kernel <= 75: 1 (default) = both gradients on the matrix cores (v_mfma_f32_4x4x4_16b_bf16, taps rounded to bf16 like the forward's), 0 = the
  * packed-f32 FIR kernel (what f32 rows and every other geometry always take).  Process-wide; returns the previous mode. */
 int ts_train_dwconv_bwd_select(int32_t mode);
+/* Deterministic gradients (no reference counterpart; torch.use_deterministic_algorithms is the nearest notion): with a workspace set, the depthwise
+ * backward kernels (ts_train_dwconv_bwd / _bwd_bn, every geometry with a fused data + weight gradient) store their per-workgroup sums of dw,
+ * in_dbeta, in_dgamma there instead of adding them with float atomics, and a second launch adds them to the destinations in workgroup order: the
+ * gradients of a step are then the same bits on every run.  workspace: f32 [n_floats] on the device, at least (workgroup rows of a launch) x
+ * channels x (kernel + 2) for the largest layer (TS_EINVAL from the backward call otherwise); NULL switches the mode off.  Process-wide; the
+ * workspace is reused by every launch, in stream order. */
+int ts_train_set_deterministic(float* workspace, int64_t n_floats);
 /* BatchNorm(train) [+ ReLU] between two repeats folded into the depthwise launches ("same" geometry only: stride 1, dilation 1, odd
  * kernel, padding (k-1)/2, even channel count; anything else TS_EUNSUPPORTED), so that the normalised tensor is never stored:
  *   ts_train_bn_stats       clip-group sums of v only (sums: 16*C doubles = [8][C][2] (sum v, sum v^2)), no apply pass

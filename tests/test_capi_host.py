@@ -38,7 +38,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_library_loads_and_answers_version_queries():
     from thunder_speech_amd import _lib
     L = _lib.lib()
-    assert L.ts_abi_version() == _lib.ABI_VERSION == 10
+    assert L.ts_abi_version() == _lib.ABI_VERSION == 11
     assert L.ts_build_target() == b"gfx950"
     for t in (1, 127, 128, 129, 751, 1501, 2001):
         assert L.ts_time_pitch(t) == _lib.time_pitch(t) and _lib.time_pitch(t) % 128 == 0 and _lib.time_pitch(t) >= t

@@ -12,7 +12,7 @@ from typing import Optional
 from .build import lib_path
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 10
+ABI_VERSION = 11
 TCS_IN_TAILZERO = 1
 TCS_OUT_ZERO_TAIL = 2
 TCS_TAPS_PHASE = 4
@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "ts_pack_activation", "ts_unpack_activation", "ts_lengths_map", "ts_im2col_time", "ts_fe_preemph", "ts_fe_dither", "ts_fe_power_spectrum", "ts_fe_stft", "ts_fe_mel", "ts_fe_normalize", "ts_gemm_nt_bf16", "ts_gemm_nt_pack_w", "ts_gemm_nt_bf16_packed", "ts_gemm_f32", "ts_gemm_f32_b2", "ts_w2v_layernorm_bwd_workspace", "ts_w2v_layernorm_bwd", "ts_w2v_colsum", "ts_w2v_gelu_fwd", "ts_w2v_gelu_bwd",
     "ts_w2v_softmax_fwd", "ts_w2v_softmax_bwd", "ts_w2v_pad_rows", "ts_w2v_mask_embed", "ts_w2v_add", "ts_se_gate_fwd", "ts_se_apply_fwd",
     "ts_decoder_bwd", "ts_adamw_step", "ts_adamw_multi_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
-    "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_dwconv_bwd_select", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_workspace", "ts_train_pwconv_wgrad_mfma", "ts_train_pwconv_wgrad_multi", "ts_train_pwconv_wgrad_multi_parts", "ts_train_wgrad_reduce_multi",
+    "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_dwconv_bwd_select", "ts_train_set_deterministic", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_workspace", "ts_train_pwconv_wgrad_mfma", "ts_train_pwconv_wgrad_multi", "ts_train_pwconv_wgrad_multi_parts", "ts_train_wgrad_reduce_multi",
     "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
     "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_fwd_bn_tiles", "ts_tcs_pointwise_tile_frames", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_bn2_add_relu_chan_fwd", "ts_train_bn2_chan_bwd",
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
@@ -152,6 +152,8 @@ def lib() -> C.CDLL:
     L.ts_train_dwconv_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [i32] * 11 + [vp]
     L.ts_train_dwconv_bwd_select.argtypes = [i32]
     L.ts_train_dwconv_bwd_select.restype = C.c_int
+    L.ts_train_set_deterministic.argtypes = [vp, i64]
+    L.ts_train_set_deterministic.restype = C.c_int
     L.ts_train_mask_time.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_pwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_cast_bf16.argtypes = [vp, vp, i64, vp]

@@ -194,7 +194,7 @@ template <class T>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const int* __restrict__ len_in, const int* __restrict__ len_out,
                                                             float* __restrict__ dw, int batch, int ch, int t_in, int t_out, int k, int s,
-                                                            int d, int p, int pitch_in, int pitch_out) {
+                                                            int d, int p, int pitch_in, int pitch_out, float* __restrict__ det_part) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* const gs = sm;                       // [t_out], zero-padded to the 8-frame steps of the slices
   const int gpad = round_up(t_out + 16, 4);
@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict_
     const int j = threadIdx.x, gj = j / TG, jj = j % TG;
     double tot = 0.0;
     for (int r = 0; r < nq; ++r) tot += red[(r * ng + gj) * TG + jj];
-    atomicAdd(dw + (size_t)c * k + j, (float)tot);       // dw accumulates (zero on entry for a plain gradient); clips are split over blockIdx.y
+    // dw accumulates (zero on entry for a plain gradient); clips are split over blockIdx.y (deterministic mode: ordered partials, see det_reduce_kernel)
+    if (det_part) det_part[((size_t)blockIdx.y * ch + c) * (k + 2) + j] = (float)tot;
+    else atomicAdd(dw + (size_t)c * k + j, (float)tot);
   }
 }
 
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
                                                           const int* __restrict__ len_out, const float* __restrict__ w, T* __restrict__ dx,
                                                           float* __restrict__ dw, int batch, int ch, int t, int k, int p, int pitch,
                                                           int clips_per_wave, PairAffine aff, float* __restrict__ in_dgamma,
-                                                          float* __restrict__ in_dbeta) {
+                                                          float* __restrict__ in_dbeta, float* __restrict__ det_part) {
   extern __shared__ __attribute__((aligned(16))) v2f sm2[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int sh = (-p) & 7;                                 // x is staged from the 8-aligned frame t0 - p - sh: tap j sits at window offset j + sh
@@ -827,7 +829,8 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
         const v2f e = red[((wv * 64) + r * ng + gj) * 8 + jj];
         tot += PH ? e[0] + e[1] : e[sel];                  // phase split: both phases of the row feed the same tap
       }
-    atomicAdd(dw + (size_t)(c + sel) * k + j, tot);
+    if (det_part) det_part[((size_t)blockIdx.y * ch + c + sel) * (k + 2) + j] = tot;
+    else atomicAdd(dw + (size_t)(c + sel) * k + j, tot);
   }
   if (af.on) {
 #pragma unroll
@@ -840,7 +843,8 @@ __global__ __launch_bounds__(256) void dw_bwd_pair_kernel(const T* __restrict__ 
     __syncthreads();
     if (threadIdx.x < 4) {
       const float tot = rs[threadIdx.x] + rs[4 + threadIdx.x] + rs[8 + threadIdx.x] + rs[12 + threadIdx.x];
-      atomicAdd((threadIdx.x < 2 ? in_dbeta : in_dgamma) + c + (threadIdx.x & 1), tot);
+      if (det_part) det_part[((size_t)blockIdx.y * ch + c + (threadIdx.x & 1)) * (k + 2) + k + (threadIdx.x < 2 ? 0 : 1)] = tot;
+      else atomicAdd((threadIdx.x < 2 ? in_dbeta : in_dgamma) + c + (threadIdx.x & 1), tot);
     }
   }
 }
@@ -869,6 +873,7 @@ struct DwbArgs {
   bf16_t* dx; float* dw;
   int batch, ch, t, k, p, pitch, n_tiles, upw;
   PairAffine aff; float* in_dgamma; float* in_dbeta;
+  float* part;        // deterministic mode (ts_train_set_deterministic): [gridDim.y][ch][k + 2] partials instead of atomics, summed in order by det_reduce_kernel
 };
 __host__ __device__ constexpr int dwb_pitch(int w_el, int mod_dw) {        // row pitch in elements: >= w_el, pitch / 2 == mod_dw (mod 64)
   const int dwords = (w_el + 1) / 2;
@@ -1089,7 +1094,8 @@ __global__ __launch_bounds__(256, TT <= 128 ? 2 : 1) void dw_bwd_mfma_kernel(con
     if (threadIdx.x < 32) {
       const int rr = threadIdx.x >> 1, e = threadIdx.x & 1;
       const float tot = rb[(0 * 16 + rr) * 2 + e] + rb[(1 * 16 + rr) * 2 + e] + rb[(2 * 16 + rr) * 2 + e] + rb[(3 * 16 + rr) * 2 + e];
-      atomicAdd((e ? a.in_dgamma : a.in_dbeta) + blockIdx.x * 16 + rr, tot);
+      if (a.part) a.part[((size_t)blockIdx.y * a.ch + blockIdx.x * 16 + rr) * (K + 2) + K + e] = tot;
+      else atomicAdd((e ? a.in_dgamma : a.in_dbeta) + blockIdx.x * 16 + rr, tot);
     }
   }
   if (need_dw) {
@@ -1105,7 +1111,8 @@ __global__ __launch_bounds__(256, TT <= 128 ? 2 : 1) void dw_bwd_mfma_kernel(con
       float tot = 0.f;
 #pragma unroll
       for (int wv = 0; wv < 4; ++wv) tot += red[((size_t)wv * 16 + rr) * (16 * G) + tp];
-      atomicAdd(a.dw + (size_t)(blockIdx.x * 16 + rr) * K + j, tot);
+      if (a.part) a.part[((size_t)blockIdx.y * a.ch + blockIdx.x * 16 + rr) * (K + 2) + j] = tot;
+      else atomicAdd(a.dw + (size_t)(blockIdx.x * 16 + rr) * K + j, tot);
     }
   }
 }
@@ -1737,8 +1744,41 @@ extern "C" int ts_train_dwconv_bwd_select(int32_t mode) {
   return old;
 }
 
+// Deterministic mode (ts_train_set_deterministic): the depthwise backward kernels' per-workgroup sums go to a caller-provided workspace
+// [n_parts][ch][k + 2] (taps, then dbeta, dgamma) instead of float atomics, and this kernel adds them to their destinations in workgroup order --
+// the step's gradients are then a pure function of its inputs (same bits on every run and box), at one extra launch per layer.
+static float* g_det_ws = nullptr;
+static long long g_det_floats = 0;
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int n_parts, int ch, int k, float* __restrict__ dw,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ch * (k + 2)) return;
+  const int c = idx / (k + 2), j = idx % (k + 2);
+  float* dst = j < k ? (dw ? dw + (size_t)c * k + j : nullptr) : (j == k ? (dbeta ? dbeta + c : nullptr) : (dgamma ? dgamma + c : nullptr));
+  if (!dst) return;
+  float tot = 0.f;
+  for (int y = 0; y < n_parts; ++y) tot += part[((size_t)y * ch + c) * (k + 2) + j];
+  *dst += tot;
+}
+// workspace for a launch of n_parts x ch x (k + 2) partials, or null (not in deterministic mode); *st = TS_EINVAL when the workspace is too small
+static float* det_workspace(int n_parts, int ch, int k, int* st) {
+  if (!g_det_ws) return nullptr;
+  if ((long long)n_parts * ch * (k + 2) > g_det_floats) { *st = TS_EINVAL; return nullptr; }
+  return g_det_ws;
+}
+static int det_reduce(const float* part, int n_parts, int ch, int k, float* dw, float* dgamma, float* dbeta, hipStream_t stream) {
+  hipLaunchKernelGGL(det_reduce_kernel, dim3((ch * (k + 2) + 255) / 256), dim3(256), 0, stream, part, n_parts, ch, k, dw, dgamma, dbeta);
+  return hip_status(hipGetLastError());
+}
+extern "C" int ts_train_set_deterministic(float* workspace, int64_t n_floats) {
+  if (workspace && n_floats <= 0) return TS_EINVAL;
+  g_det_ws = workspace;
+  g_det_floats = workspace ? n_floats : 0;
+  return TS_OK;
+}
+
 template <int TT, int NK, int G>
-static int dw_bwd_mfma_go(const DwbArgs& a, int n_cg, hipStream_t stream) {
+static int dw_bwd_mfma_go(DwbArgs& a, int n_cg, hipStream_t stream) {
   constexpr int WY = TT + 96, WX = TT + 96;
   const size_t lds = (size_t)4 * (16 * dwb_pitch(WY, 4) * 2 + 16 * dwb_pitch(WX, 8) * 2);
   auto kern = dw_bwd_mfma_kernel<TT, NK, G>;
@@ -1749,9 +1789,14 @@ static int dw_bwd_mfma_go(const DwbArgs& a, int n_cg, hipStream_t stream) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TS_EUNSUPPORTED;
     attr_set[dev] = true;
   }
-  const int units = a.batch * a.n_tiles;
-  hipLaunchKernelGGL(kern, dim3(n_cg, (units + 4 * a.upw - 1) / (4 * a.upw)), dim3(256), lds, stream, a);
-  return hip_status(hipGetLastError());
+  const int units = a.batch * a.n_tiles, ny = (units + 4 * a.upw - 1) / (4 * a.upw);
+  int st = TS_OK;
+  a.part = det_workspace(ny, a.ch, a.k, &st);
+  if (st != TS_OK) return st;
+  hipLaunchKernelGGL(kern, dim3(n_cg, ny), dim3(256), lds, stream, a);
+  st = hip_status(hipGetLastError());
+  if (st == TS_OK && a.part) st = det_reduce(a.part, ny, a.ch, a.k, a.dw, a.aff.mean_rstd ? a.in_dgamma : nullptr, a.aff.mean_rstd ? a.in_dbeta : nullptr, stream);
+  return st;
 }
 
 static int dw_bwd_mfma_launch(const void* dy, const void* x, const int32_t* len_in, const int32_t* len_out, const float* w, void* dx, float* dw,
@@ -1797,23 +1842,33 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + pair_gl(k, pad) + PAIR_TAPS) * sizeof(v2f);
     const int cpw = batch >= 16 ? (batch + 15) / 16 : 1;        // >= 2 clips per wave: the second clip's loads overlap the first one's FIR
     const dim3 grid2(ch / 2, (batch + 4 * cpw - 1) / (4 * cpw));
+    int dst = TS_OK;
+    float* const part = det_workspace((int)grid2.y, ch, k, &dst);
+    if (dst != TS_OK) return dst;
     TS_ACT(act,
            hipLaunchKernelGGL(dw_bwd_pair_kernel<float>, grid2, dim3(256), lds2, stream, (const float*)dy, (const float*)x, len_in, len_out, w,
-                              (float*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta),
+                              (float*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta, part),
            hipLaunchKernelGGL(dw_bwd_pair_kernel<bf16_t>, grid2, dim3(256), lds2, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, w,
-                              (bf16_t*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta));
-    return hip_status(hipGetLastError());
+                              (bf16_t*)dx, dw, batch, ch, t_in, k, pad, pitch_in, cpw, aff, in_dgamma, in_dbeta, part));
+    dst = hip_status(hipGetLastError());
+    if (dst == TS_OK && part) dst = det_reduce(part, (int)grid2.y, ch, k, dw, aff.mean_rstd ? in_dgamma : nullptr, aff.mean_rstd ? in_dbeta : nullptr, stream);
+    return dst;
   }
   if (phase_geometry(t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out)) {
     const size_t lds2 = 4 * (size_t)(pair_xl(round_up(k + 7, 8)) + pair_gl(k, pad / 2) + PAIR_TAPS) * sizeof(v2f);
     const int cpw = batch >= 16 ? (batch + 15) / 16 : 1;
     const dim3 grid2(ch, (batch + 4 * cpw - 1) / (4 * cpw));
+    int dst = TS_OK;
+    float* const part = det_workspace((int)grid2.y, ch, k, &dst);
+    if (dst != TS_OK) return dst;
     TS_ACT(act,
            { hipLaunchKernelGGL((dw_bwd_pair_kernel<float, true>), grid2, dim3(256), lds2, stream, (const float*)dy, (const float*)x, len_in, len_out, w,
-                               (float*)dx, dw, batch, ch, t_in, k, pad / 2, pitch_in, cpw, aff, in_dgamma, in_dbeta); },
+                               (float*)dx, dw, batch, ch, t_in, k, pad / 2, pitch_in, cpw, aff, in_dgamma, in_dbeta, part); },
            { hipLaunchKernelGGL((dw_bwd_pair_kernel<bf16_t, true>), grid2, dim3(256), lds2, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, w,
-                               (bf16_t*)dx, dw, batch, ch, t_in, k, pad / 2, pitch_in, cpw, aff, in_dgamma, in_dbeta); });
-    return hip_status(hipGetLastError());
+                               (bf16_t*)dx, dw, batch, ch, t_in, k, pad / 2, pitch_in, cpw, aff, in_dgamma, in_dbeta, part); });
+    dst = hip_status(hipGetLastError());
+    if (dst == TS_OK && part) dst = det_reduce(part, (int)grid2.y, ch, k, dw, nullptr, nullptr, stream);
+    return dst;
   }
   const size_t lds_d = (DW_KMAX + (size_t)(DW_TILE + (k - 1) * dil) / stride + 2 + 48) * sizeof(float);
   const size_t lds_w = (size_t)(round_up(t_out + 16, 4) + round_up(t_in + 2 * pad + 48, 2)) * sizeof(float) + 256 * 8 * sizeof(double);
@@ -1826,12 +1881,21 @@ static int dwconv_bwd_impl(const void* dy, const void* x, const int32_t* len_in,
                             t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
          hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, gd, dim3(256), lds_d, stream, (const bf16_t*)dy, len_in, len_out, w, (bf16_t*)dx, batch, ch,
                             t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out));
-  if (dw)
-  TS_ACT(act,
-         hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, gw, dim3(256), lds_w, stream, (const float*)dy, (const float*)x, len_in, len_out, dw, batch,
-                            ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out),
-         hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, gw, dim3(256), lds_w, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, dw, batch,
-                            ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out));
+  if (dw) {
+    int dst = TS_OK;
+    float* const part = det_workspace((int)gw.y, ch, k, &dst);
+    if (dst != TS_OK) return dst;
+    TS_ACT(act,
+           hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, gw, dim3(256), lds_w, stream, (const float*)dy, (const float*)x, len_in, len_out, dw, batch,
+                              ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out, part),
+           hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, gw, dim3(256), lds_w, stream, (const bf16_t*)dy, (const bf16_t*)x, len_in, len_out, dw, batch,
+                              ch, t_in, t_out, k, stride, dil, pad, pitch_in, pitch_out, part));
+    if (part) {
+      dst = hip_status(hipGetLastError());
+      if (dst != TS_OK) return dst;
+      return det_reduce(part, (int)gw.y, ch, k, dw, nullptr, nullptr, stream);
+    }
+  }
   return hip_status(hipGetLastError());
 }
 

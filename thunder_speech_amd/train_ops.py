@@ -31,6 +31,25 @@ def activation_dtype() -> torch.dtype:
     return _ACT_DTYPE
 
 
+_DET_WS = {}
+
+
+def set_deterministic(on: bool, device=None, workspace_floats: int = 8 << 20) -> None:
+    """Deterministic gradients (the notion of torch.use_deterministic_algorithms for this library's training kernels): the depthwise backward
+    kernels then leave their per-workgroup sums of the weight / BatchNorm-parameter gradients in a workspace and a second launch adds them in a
+    fixed order, instead of float atomics -- every other kernel of the step already sums in a fixed order (split-K partials + ordered reduce,
+    per-tile statistics, one workgroup per channel).  A training run started from the same seeds is then bit-reproducible, at one extra tiny
+    launch per depthwise layer.  Process-wide (ts_train_set_deterministic); the workspace (32 MiB by default) lives until the mode is switched off."""
+    if on:
+        dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        ws = torch.empty(int(workspace_floats), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().ts_train_set_deterministic(ws.data_ptr(), ws.numel()), "ts_train_set_deterministic")
+        _DET_WS["ws"] = ws
+    else:
+        _lib.check(_lib.lib().ts_train_set_deterministic(None, 0), "ts_train_set_deterministic")
+        _DET_WS.clear()
+
+
 def set_gemm_precision(precision: str) -> None:
     """Round-1 name of the mixed-precision switch: "bf16" now selects bf16 activations (and with them bf16 GEMM operands)."""
     set_activation_dtype(precision)

@@ -186,15 +186,35 @@ def validation_margin(module, device, batch: int = 64, seconds: int = 15, seed: 
     return margin
 
 
-def train(device, schedule=DEFAULT_SCHEDULE, seed: int = 0, lr: float = DEFAULT_LR, log_every: int = 100, act: str = "bf16", verbose: bool = True):
+CHECKSUM_FILE = os.path.join(ROOT, "tests", "golden", "trained_tones.json")
+
+
+def weights_checksum(module) -> str:
+    """sha256 over the bytes of every encoder / decoder state-dict tensor (in key order): names the trained weights bit for bit."""
+    import hashlib
+    h = hashlib.sha256()
+    for part in (module.encoder, module.decoder):
+        for k, v in sorted(part.state_dict().items()):
+            h.update(k.encode())
+            h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def train(device, schedule=DEFAULT_SCHEDULE, seed: int = 0, lr: float = DEFAULT_LR, log_every: int = 100, act: str = "bf16", verbose: bool = True,
+          deterministic: bool = True):
     """Fine-tune QuartzNet15x5 (everything trainable, bf16 activations, forward + backward replayed from one hipGraph per batch shape) on the
-    tone task.  Returns (module in eval mode, history)."""
+    tone task.  Returns (module in eval mode, history).  `deterministic` (default): train_ops.set_deterministic -- ordered partial sums instead of
+    float atomics in the depthwise backward kernels -- and the host generator seeded (dither seeds), so that the SAME weights come out of every
+    run (`weights_checksum`): the transcript comparison that follows is then a fixed known answer, not a draw."""
     from thunder_speech_amd import train_ops
     from thunder_speech_amd.optim import FusedAdamW
     from thunder_speech_amd.parallel import GradientSync
     from thunder_speech_amd.train_graph import GraphedTrainStep
     m = build_module(device, seed).train()
     train_ops.set_activation_dtype(act)
+    if deterministic:
+        torch.manual_seed(1_000_003 * seed + 12345)          # rng.next_seed draws the dither seeds from torch's CPU generator
+        train_ops.set_deterministic(True, device)
     hist = []
     t0 = time.perf_counter()
     try:
@@ -231,6 +251,9 @@ def train(device, schedule=DEFAULT_SCHEDULE, seed: int = 0, lr: float = DEFAULT_
         sync.close()
     finally:
         train_ops.set_activation_dtype("fp32")
+        if deterministic:
+            torch.cuda.synchronize()
+            train_ops.set_deterministic(False)
     return m.eval(), hist
 
 
@@ -310,6 +333,8 @@ def main():
     ap.add_argument("--n-check", type=int, default=16)
     ap.add_argument("--log-every", type=int, default=100)
     ap.add_argument("--no-eval", action="store_true", help="training log only (diagnostics)")
+    ap.add_argument("--write-checksum", action="store_true", help="record the trained weights' sha256 + the evaluation's outcome in tests/golden/trained_tones.json (the known "
+                                                                   "answer tests/test_gpu_trained_transcripts.py pins; refresh it whenever a training kernel changes the bits)")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         print("train_margin_model: needs an MI355X (the repository's training path has no CPU fallback)", file=sys.stderr)
@@ -322,8 +347,16 @@ def main():
     if args.no_eval:
         return
     res = evaluate(module, device, n_check=args.n_check)
+    res["weights_sha256"] = weights_checksum(module)
     res["train"] = {"schedule": [list(x) for x in schedule], "seconds": t_train, "loss_first_last": [hist[0][1], hist[-1][1]], "steps": hist[-1][0] + 1, "validation_margin": hist[-1][2], "lr": args.lr, "seed": args.seed,
                     "act": args.act}
+    if args.write_checksum:
+        with open(CHECKSUM_FILE, "w") as f:
+            json.dump({"weights_sha256": res["weights_sha256"], "seed": args.seed, "schedule": [list(x) for x in schedule], "lr": args.lr, "act": args.act,
+                       "frames_flipped": res["frames_flipped"], "collapsed_sequences_equal": res["collapsed_sequences_equal"], "strings_equal": res["strings_equal"],
+                       "min_fp32_margin": res["min_fp32_margin"], "validation_margin": res["train"]["validation_margin"],
+                       "note": "deterministic training (train_ops.set_deterministic) of tools/train_margin_model.py on an MI355X; refresh with --write-checksum "
+                               "whenever a kernel of the training step changes its rounding"}, f, indent=1)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         torch.save({"encoder": module.encoder.state_dict(), "decoder": module.decoder.state_dict()}, args.out)
