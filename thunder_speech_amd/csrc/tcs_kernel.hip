@@ -36,21 +36,6 @@ constexpr int NKMAX = 24;      // taps are cached in LDS up to this many k-steps
 constexpr int RING_BYTES = 8;   // weight-fragment prefetch depth: RING_BYTES KiB per wave in flight
 
 
-// [ci][t] bf16 tile of the depthwise output / identity input, 16-byte chunks XOR-swizzled so that both
-// the 8-byte row writes and the transposed reads spread over the banks.
-template <int TT>
-struct DwTile {
-  static constexpr int ROWB = TT * 2;
-  static constexpr int BYTES = KC * ROWB;
-  __device__ static __forceinline__ int sw(int c) {
-    return TT == 128 ? (c & 3) * 5 : ((((c >> 1) & 1) << 2) | (c & 3));
-  }
-  __device__ static __forceinline__ int addr(int c, int t) {
-    return c * ROWB + ((((t >> 3) ^ sw(c))) << 4) + ((t & 7) << 1);
-  }
-};
-
-
 template <int TT, int NT, int STRIDE, bool DW, bool OUT_F32, bool TLDS, bool TZ, int XJ, int NPASS>
 __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
   constexpr int MT = TT / 32;     // 32-frame MFMA row tiles

@@ -109,6 +109,20 @@ struct TilePos {
 };
 
 
+// [ci][t] bf16 tile of the depthwise output / identity input, 16-byte chunks XOR-swizzled so that both
+// the 8-byte row writes and the transposed reads spread over the banks.
+template <int TT>
+struct DwTile {
+  static constexpr int ROWB = TT * 2;
+  static constexpr int BYTES = KC * ROWB;
+  __device__ static __forceinline__ int sw(int c) {
+    return TT == 128 ? (c & 3) * 5 : ((((c >> 1) & 1) << 2) | (c & 3));
+  }
+  __device__ static __forceinline__ int addr(int c, int t) {
+    return c * ROWB + ((((t >> 3) ^ sw(c))) << 4) + ((t & 7) << 1);
+  }
+};
+
 // ---- split kernel (csrc/tcs_split.hip) ------------------------------------------------------------------------------------
 struct SplitLayer {
   const unsigned short* x;         // [B][c_in][pitch]

@@ -24,6 +24,10 @@
 // of the product (git history: commit 4a86010 has the full kernel, ts_tcs_chain_fwd and its tests).
 #include "tcs_shared.hpp"
 
+#ifndef TS_SPLIT_STORE_AUX
+#define TS_SPLIT_STORE_AUX 0      // cache policy of the result stores (raw buffer aux: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+
 namespace ts {
 
 // DIL == 2 (dilation-2 layers, K87 of QuartzNet): the even and the odd frames of a row are two independent dilation-1
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
               for (int i = 0; i < RB; ++i) {
                 if (partial) v[i] &= keep;
                 if (row0 + 4 * (RB * bt + i) + rsub < a.c_out)
-                  __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, 0);
+                  __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, TS_SPLIT_STORE_AUX);
               }
             }
           }

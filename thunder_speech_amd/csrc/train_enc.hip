@@ -38,12 +38,32 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) { v[2 * j] = bf16_lo(a[j]); v[2 * j + 1] = bf16_hi(a[j]); }
 }
+// Activation rows leave with streaming (nontemporal) stores: a training launch writes 8-16 MB that the NEXT launch reads, possibly on another
+// XCD, so the lines have to reach memory anyway -- streaming them out while the kernel runs beats leaving them dirty in the XCD's L2 for the
+// end-of-kernel write-back the next launch waits for (measured on the 1x1 products: -10 % per launch, profiles/round6_pw_tile.txt).
+#ifndef TS_TRAIN_NT
+#define TS_TRAIN_NT 0
+#endif
+__device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
+#if TS_TRAIN_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st16(f32x4* p, f32x4 v) {
+#if TS_TRAIN_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
-  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  st16(reinterpret_cast<f32x4*>(p), f32x4{v[0], v[1], v[2], v[3]});
+  st16(reinterpret_cast<f32x4*>(p + 4), f32x4{v[4], v[5], v[6], v[7]});
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
-  *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  st16(reinterpret_cast<u32x4*>(p), u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])});
 }
 
 constexpr int DW_TILE = 1024;      // output frames per workgroup (forward) / input frames per workgroup (backward-data)
@@ -697,7 +717,7 @@ __global__ __launch_bounds__(256) void dw_fwd_mfma_kernel(const bf16_t* __restri
             u32x4 v = h ? u32x4{g0, g1, m0, m1} : u32x4{m0, m1, g0, g1};            // frames f .. f + 3 come from the h = 0 lane
             if (clip_on && f < pitch) {
               if (f + 8 > lo) v = keep_first(v, lo - f);
-              *reinterpret_cast<u32x4*>(yr + f) = v;
+              st16(reinterpret_cast<u32x4*>(yr + f), v);
             }
           }
         }
@@ -1077,7 +1097,7 @@ __global__ __launch_bounds__(256, TT <= 128 ? 2 : 1) void dw_bwd_mfma_kernel(con
           if (relu) v[j] = pack_bf16(g0, g1);
         }
       }
-      *reinterpret_cast<u32x4*>(a.dx + r0 + f) = v;
+      st16(reinterpret_cast<u32x4*>(a.dx + r0 + f), v);
     }
     __builtin_amdgcn_wave_barrier();
   }
