@@ -1,5 +1,5 @@
 """GPU parity: wav2vec2 encoder (csrc/w2v_enc.hip through the C ABI) vs the oracle and the transformers-generated fixture.
-fp32 activations, fp32 rocBLAS GEMMs: tolerances are fp32 summation-order noise."""
+fp32 activations, fp32 GEMMs on the library's own matrix-core kernel (csrc/gemm_f32.hip): tolerances are fp32 summation-order noise."""
 from types import SimpleNamespace
 
 import numpy as np

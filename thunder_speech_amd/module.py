@@ -31,8 +31,10 @@ def greedy_decode(logits: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     if lg.dtype != torch.float32 or lg.stride(2) != 1 or lg.stride(0) != v * lg.stride(1):
         lg = lg.to(torch.float32).contiguous()
     ids = torch.empty(b, t, dtype=torch.int32, device=lg.device)
-    collapsed = torch.empty(b, t, dtype=torch.int32, device=lg.device)
-    counts = torch.empty(b, dtype=torch.int32, device=lg.device)
+    # collapsed ids and their per-row counts share ONE buffer, so that the host takes them in a single device -> host copy
+    # (BatchTextTransformer.decode_collapsed); the views behave like separate tensors for everyone else
+    packed = torch.empty(b * t + b, dtype=torch.int32, device=lg.device)
+    collapsed, counts = packed[: b * t].view(b, t), packed[b * t:]
     st = _lib.lib().ts_greedy_decode(lg.data_ptr(), b, v, t, lg.stride(1), ids.data_ptr(), collapsed.data_ptr(),
                                      counts.data_ptr(), torch.cuda.current_stream(lg.device).cuda_stream)
     _lib.check(st, "ts_greedy_decode")

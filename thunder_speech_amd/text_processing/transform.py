@@ -130,7 +130,15 @@ class BatchTextTransformer(nn.Module):
         whole batch as ONE table lookup + one bytes -> str decode (the per-id Python loop costs more than the GPU's whole forward pass at
         64 x 751 frames); same strings as `_ids_to_text` row by row (tests/test_host_r2.py compares the three plans with it)."""
         import numpy as np
-        rows, n = collapsed.detach().to("cpu").numpy(), counts.detach().to("cpu").numpy()
+        b_, t_ = collapsed.shape
+        if (collapsed.is_cuda and counts.is_cuda and collapsed.dtype == counts.dtype == torch.int32 and collapsed.is_contiguous() and counts.is_contiguous()
+                and collapsed.untyped_storage().data_ptr() == counts.untyped_storage().data_ptr()
+                and counts.storage_offset() == collapsed.storage_offset() + b_ * t_ and counts.numel() == b_):
+            # greedy_decode's packed layout: one device -> host copy (and one synchronisation) for both
+            host = torch.as_strided(collapsed, (b_ * t_ + b_,), (1,), collapsed.storage_offset()).detach().to("cpu").numpy()
+            rows, n = host[: b_ * t_].reshape(b_, t_), host[b_ * t_:]
+        else:
+            rows, n = collapsed.detach().to("cpu").numpy(), counts.detach().to("cpu").numpy()
         plan = self._decode_plan()
         v = len(self.vocab.itos)
         if plan[0] == "loop" or rows.size == 0:

@@ -239,7 +239,7 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             keep = [b.clone() for b in self._touched]
-            for _ in range(self.warmup):         # eager passes: rocBLAS picks its kernels, the allocator reaches its steady state
+            for _ in range(self.warmup):         # eager passes: weight copies get packed, the allocator reaches its steady state
                 self._body(*static)
                 self.sync.finish(exchange=False)
             for b, k in zip(self._touched, keep):   # the warm-up passes must not count as training steps: running statistics back

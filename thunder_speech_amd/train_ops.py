@@ -226,15 +226,16 @@ def _w_bf16(w2: Tensor, param: Tensor = None) -> Tensor:
 
 
 # bf16 pointwise convolutions: forward and data gradient on the inference kernel's pointwise-only mode (ts_tcs_subblock_fwd), weight
-# gradient on csrc/train_gemm.hip; set_pointwise_backend("rocblas") routes all three to the library's strided-batched GEMMs instead
-# (the f32 path always uses those).
+# gradient on csrc/train_gemm.hip; set_pointwise_backend("gemm_f32") routes all three to this library's general GEMM (csrc/gemm_f32.hip, bf16
+# operands) instead -- what the f32 path always uses; an A/B and fallback switch.  ("rocblas", the name from the rounds when that path was the
+# vendor's strided-batched call, is still accepted: no vendor library has been linked since round 4.)
 _OWN_GEMM = True
 
 
 def set_pointwise_backend(name: str) -> None:
     global _OWN_GEMM
-    if name not in ("mfma", "rocblas"):
-        raise ValueError("pointwise backend must be 'mfma' or 'rocblas'")
+    if name not in ("mfma", "gemm_f32", "rocblas"):
+        raise ValueError("pointwise backend must be 'mfma' or 'gemm_f32'")
     _OWN_GEMM = name == "mfma"
 
 
@@ -642,7 +643,7 @@ class MaskTime(torch.autograd.Function):
 
 
 class PointwiseConv(torch.autograd.Function):
-    """1x1 conv without bias on an already masked input: v[b] = W . u[b] (rocBLAS), du = W^T dv, dW = sum_b dv u^T.
+    """1x1 conv without bias on an already masked input: v[b] = W . u[b], du = W^T dv, dW = sum_b dv u^T.
     f32 activations: f32 GEMMs.  bf16 activations: bf16 operands, f32 accumulation; the result is bf16 too, except with
     `f32_out` (the decoder's logits feed the CTC kernel in f32)."""
 
