@@ -195,3 +195,61 @@ def test_decode_fixture_matches_reference(golden):
     assert tt.decode_prediction(pred, remove_repeated=False) == [str(s) for s in g["strings_norep"]]
     ids, lens = tt.encode([str(s) for s in g["texts"]])
     assert np.array_equal(ids.numpy(), g["enc_ids"]) and np.array_equal(lens.numpy(), g["enc_len"])
+
+
+_ASAN_DRIVER = r'''
+import ctypes as C, sys
+L = C.CDLL(sys.argv[1])
+i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
+assert L.ts_abi_version() == 11
+L.ts_build_target.restype = C.c_char_p
+assert L.ts_build_target() == b"gfx950"
+assert [L.ts_time_pitch(t) for t in (1, 128, 751, 1501)] == [512, 512, 1152, 1920]
+# argument validation returns before any launch: null pointers, non-positive sizes, misaligned pitches (TS_EINVAL = -1, TS_EUNSUPPORTED = -2)
+class Desc(C.Structure):
+    _fields_ = [(n, i32) for n in ("batch", "c_in", "c_out", "t_in", "t_out", "pitch_in", "pitch_out", "kernel", "stride", "dilation", "padding", "depthwise",
+                                   "relu", "out_fp32", "c_res", "pitch_res", "t_res", "res_stride", "dw_ksteps", "flags")] + \
+               [(n, vp) for n in ("dw_taps", "dw_taps_raw", "pw_w", "res_w", "pw_w16", "res_w16", "bias", "se_y", "se_gate", "stats")]
+d = Desc()
+L.ts_tcs_subblock_fwd.argtypes = [C.POINTER(Desc), vp, vp, vp, vp, vp, vp]
+assert L.ts_tcs_subblock_fwd(None, None, None, None, None, None, None) == -1
+buf = (C.c_char * 4096)()
+d.batch, d.c_in, d.c_out, d.t_out, d.pitch_in, d.pitch_out, d.kernel, d.stride, d.dilation = 1, 64, 64, 100, 513, 512, 1, 1, 1
+d.pw_w = d.bias = C.addressof(buf)
+assert L.ts_tcs_subblock_fwd(C.byref(d), buf, buf, None, None, buf, None) == -1              # pitch_in % 8
+d.pitch_in, d.stride, d.dilation = 512, 2, 2
+assert L.ts_tcs_subblock_fwd(C.byref(d), buf, buf, None, None, buf, None) == -1              # stride AND dilation
+d.stride, d.dilation, d.kernel = 1, 1, 5
+assert L.ts_tcs_subblock_fwd(C.byref(d), buf, buf, None, None, buf, None) == -2              # dense K > 1
+L.ts_tcs_pointwise_tile_frames.argtypes = [i32, i32, i32]
+assert L.ts_tcs_pointwise_tile_frames(32, 512, 501) == 64 and L.ts_tcs_pointwise_tile_frames(0, 512, 501) == -1
+L.ts_greedy_decode.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp]
+assert L.ts_greedy_decode(None, 1, 1, 1, 1, None, None, None, None) == -1
+assert L.ts_greedy_decode(buf, 2, 29, 100, 64, buf, buf, buf, None) == -1                     # pitch < frames
+L.ts_train_set_deterministic.argtypes = [vp, i64]
+assert L.ts_train_set_deterministic(buf, 0) == -1 and L.ts_train_set_deterministic(None, 0) == 0
+L.ts_train_pwconv_wgrad_workspace.argtypes = [i32, i32, i32]
+L.ts_train_pwconv_wgrad_workspace.restype = i64
+assert L.ts_train_pwconv_wgrad_workspace(32, 512, 512) >= 512 * 512
+L.ts_train_pwconv_wgrad_multi_parts.argtypes = [i32, i32, i32]
+assert 1 <= L.ts_train_pwconv_wgrad_multi_parts(32, 512, 512) <= 32
+L.ts_train_dwconv_bwd.argtypes = [vp] * 7 + [i32] * 11 + [vp]
+assert L.ts_train_dwconv_bwd(None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, 8, 8, 0, None) == -1
+L.ts_ctc_workspace_bytes.restype = i64
+L.ts_ctc_workspace_bytes.argtypes = [i32, i32, i32, i32]
+assert L.ts_ctc_workspace_bytes(32, 501, 160, 29) > 0
+print("ASAN-DRIVER-OK")
+'''
+
+
+def test_host_code_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """`python -m thunder_speech_amd.build --asan`: the extern "C" launchers compiled host-only with -fsanitize=address,undefined and driven through
+    the paths that return before a launch (version queries, argument validation, workspace arithmetic).  Any sanitizer report aborts the child."""
+    from thunder_speech_amd import build as b
+    path = b.build_asan(verbose=False)
+    driver = tmp_path / "asan_driver.py"
+    driver.write_text(_ASAN_DRIVER)
+    env = dict(os.environ, LD_PRELOAD=b.asan_runtime(), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    import sys
+    r = subprocess.run([sys.executable, str(driver), path], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ASAN-DRIVER-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
