@@ -192,6 +192,8 @@ typedef struct ts_frontend_desc {
   const int32_t* masks;          /* int32 [n_masks][4] = (f0, f1, t0, t1): features[b][f0:f1][t0:t1] = 0 for every clip */
   uint64_t dither_seed;          /* Philox key of the dither noise */
   float dither;                  /* > 0: DitherAudio (quartznet/transform.py:109-118): x + dither * N(0, 1) before pre-emphasis */
+  int64_t* feat_len64;           /* optional (ABI v11): the frame lengths once more as int64 [B] -- what PowerSpectrum.get_sequence_length returns
+                                    (quartznet/transform.py:182-184, .long()) -- so that the caller needs no launch of its own for them */
 } ts_frontend_desc;
 
 /* Stage 1: logmel f32 [B][n_frames][n_mels] (frame-major scratch) + per-(b, mel) partial sums.

@@ -74,7 +74,7 @@ def test_inference_graph_matches_eager_is_invalidated_by_weight_updates_and_neve
         assert module._infer_graphs[1].count() == 1
         assert torch.equal(a0, ref_logits) and torch.equal(a1, ref_logits) and torch.equal(l1, ref_len)
         x2 = (0.5 * x).contiguous()
-        b1, _ = module(x2, lens)                                           # same signature, other samples: replay with the input copied in
+        b1, _ = module(x2, lens)                                           # same signature at another address: not this graph's input
         assert torch.equal(a1, ref_logits), "a returned tensor was overwritten by the next call"
         module.graph_inference = False
         b_ref, _ = module(x2, lens)
@@ -87,6 +87,18 @@ def test_inference_graph_matches_eager_is_invalidated_by_weight_updates_and_neve
         module.graph_inference = False
         c_ref, _ = module(x, lens)
         assert torch.equal(c0, c_ref) and torch.equal(c1, c_ref) and not torch.equal(c_ref, ref_logits)
+        # the same shape arriving at NEW addresses every time: from the fourth sighting on, one copying graph serves them all
+        module.graph_inference = None
+        module.reset_inference_graphs()
+        keep, outs = [], []
+        for k in range(6):
+            xk = (x * (1.0 + 0.1 * k)).contiguous()
+            keep.append(xk)                                                # held, so that every call sees a fresh address
+            outs.append(module(xk, lens)[0])
+        assert module._infer_graphs[1].count() == 0 and module._infer_graphs[2].count() == 1
+        module.graph_inference = False
+        for xk, got in zip(keep, outs):
+            assert torch.equal(got, module(xk, lens)[0])
     # under autograd / in train mode the graph path is never taken
     module.graph_inference = None
     module.reset_inference_graphs()

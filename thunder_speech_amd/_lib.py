@@ -66,7 +66,7 @@ class FrontendDesc(C.Structure):
         ("win_length", C.c_int32), ("n_mels", C.c_int32), ("preemph", C.c_float), ("n_frames", C.c_int32),
         ("pitch_out", C.c_int32),
         ("window", C.c_void_p), ("mel_weights", C.c_void_p), ("mel_offsets", C.c_void_p), ("mel_nnz", C.c_int32),
-        ("n_masks", C.c_int32), ("masks", C.c_void_p), ("dither_seed", C.c_uint64), ("dither", C.c_float),
+        ("n_masks", C.c_int32), ("masks", C.c_void_p), ("dither_seed", C.c_uint64), ("dither", C.c_float), ("feat_len64", C.c_void_p),
     ]
 
 

@@ -84,6 +84,7 @@ struct FeArgs {
   float* logmel;              // [B][F][n_mels]
   float* partial;             // [B][nwg][n_mels][2]
   int* feat_len;
+  long long* feat_len64;      // optional int64 copy of feat_len (the lengths the Python side returns)
   int n_samples, hop, n_mels, n_frames, nwg, mel_nnz, batch;
   float preemph;
   float dither;               // > 0: DitherAudio (transform.py:109-118, training only): x + dither * N(0, 1)
@@ -272,7 +273,10 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const FeArgs a) {
   if (nvec) commit(gn);                              // the next group's samples (prefetched into registers above)
   // ---- partial statistics over the valid frames of this workgroup -----------------------------------------
   const int flen = a.wave_len[b] / a.hop + 1;      // floor(len / hop) + 1  (transform.py:182-184)
-  if (tid == 0 && grp == 0) a.feat_len[b] = flen;
+  if (tid == 0 && grp == 0) {
+    a.feat_len[b] = flen;
+    if (a.feat_len64) a.feat_len64[b] = flen;
+  }
   for (int m = tid; m < a.n_mels; m += 256) {
     float s1 = 0.f, s2 = 0.f;
     for (int q = 0; q < FPW; ++q) {
@@ -413,6 +417,7 @@ extern "C" int ts_mel_frontend_fwd(const ts_frontend_desc* d, const float* wave,
   a.logmel = static_cast<float*>(workspace);
   a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + fe_logmel_bytes(d));
   a.feat_len = feat_len;
+  a.feat_len64 = reinterpret_cast<long long*>(d->feat_len64);
   a.n_samples = d->n_samples; a.hop = d->hop; a.n_mels = d->n_mels; a.n_frames = d->n_frames; a.nwg = nwg;
   a.preemph = d->preemph;
   a.dither = d->dither;

@@ -230,11 +230,20 @@ class _FilterbankFeatures(MultiSequential):
         feats = _t.arena(("feat", id(self)), b, d.n_mels, d.n_frames, x.device)   # normalize_kernel zeroes frames >= length up to the pitch
         flen = torch.empty(b, dtype=torch.int32, device=x.device)
         wl = _t.lengths_i32(audio_lengths, x.device)
+        # the lengths this forward returns (PowerSpectrum.get_sequence_length: floor(len / hop) + 1 as int64) come out of the same launch; the
+        # kernel's arithmetic -- floor(len) to int32 first, then the integer division -- equals the reference's float expression for len >= 0
+        fused_len = audio_lengths.is_cuda and audio_lengths.dtype in (torch.float32, torch.int64, torch.int32) and not _t._NO_MAP
+        flen64 = torch.empty(b, dtype=torch.int64, device=x.device) if fused_len else None
+        if flen64 is not None:
+            d.feat_len64 = flen64.data_ptr()
         st = L.ts_mel_frontend_fwd(C.byref(d), x.data_ptr(), wl.data_ptr(), feats.data_ptr(), flen.data_ptr(),
                                    ws.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(st, "ts_mel_frontend_fwd")
         self._last_logmel = ws[: b * d.n_frames * d.n_mels * 4].view(torch.float32).view(b, d.n_frames, d.n_mels)
-        return _t.tag_tail_zero(feats[:, :, :d.n_frames]), ps.get_sequence_length(audio_lengths)
+        if flen64 is None:
+            return _t.tag_tail_zero(feats[:, :, :d.n_frames]), ps.get_sequence_length(audio_lengths)
+        _t.remember_i32(flen64, flen)        # the encoder's kernels take the int32 copy the same launch wrote
+        return _t.tag_tail_zero(feats[:, :, :d.n_frames]), flen64
 
     def last_logmel(self) -> torch.Tensor:
         """Parity hook: un-normalised log-mel [B, frames, n_mels] of the last forward (kernel-1 output)."""

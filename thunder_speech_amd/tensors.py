@@ -169,6 +169,12 @@ def lengths_map(lengths: torch.Tensor, add: int, div: int, plus: int, out_dtype=
     return out
 
 
+def remember_i32(lengths: torch.Tensor, i32: torch.Tensor) -> None:
+    """`i32` IS the int32 copy of `lengths` (written by the launch that produced both): lengths_i32 hands it out inside the current lengths_scope."""
+    if _LEN_SCOPE is not None:
+        _LEN_SCOPE[id(lengths)] = (lengths, lengths._version, i32)
+
+
 def lengths_i32(lengths: torch.Tensor, device) -> torch.Tensor:
     """Reference lengths may be float or int (A5); the kernels take floor()ed int32 on the device."""
     if lengths.dtype == torch.int32 and lengths.device == torch.device(device) and lengths.is_contiguous():

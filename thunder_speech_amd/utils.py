@@ -150,14 +150,18 @@ class GraphedForward:
     into the graph's static buffers before each replay; the RETURNED TENSORS ARE THE GRAPH'S OWN OUTPUT BUFFERS and are
     overwritten by the next call with the same signature -- consume them (or clone them) before calling again."""
 
-    def __init__(self, fn, warmup: int = 2, stream=None):
+    def __init__(self, fn, warmup: int = 2, stream=None, alias_first: bool = False):
         # `stream`: record every capture on this side stream (default: a fresh one per signature).  The library's launch arena is keyed by
         # stream (tensors.arena), so an owner that re-captures -- BaseCTCModule after a weight update -- passes one stream and reuses it.
-        self.fn, self.warmup, self._graphs, self._stream = fn, warmup, {}, stream
+        # `alias_first`: the graph reads the FIRST argument where the caller's tensor lives instead of a static copy (no copy per replay); the
+        # signature then includes its address, and a replay only ever happens for a tensor of that shape AT that address -- whatever was
+        # allocated there since.  No reference to the caller's tensor is kept (a held tensor would pin the address the caller's allocator
+        # would otherwise hand out again for the next batch).
+        self.fn, self.warmup, self._graphs, self._stream, self.alias_first = fn, warmup, {}, stream, alias_first
 
-    @staticmethod
-    def signature(*args: torch.Tensor):
-        return tuple((tuple(a.shape), a.dtype, str(a.device)) for a in args)
+    def signature(self, *args: torch.Tensor):
+        sig = tuple((tuple(a.shape), a.dtype, str(a.device)) for a in args)
+        return sig + ((args[0].data_ptr(), tuple(args[0].stride())),) if self.alias_first else sig
 
     def has(self, key) -> bool:
         return key in self._graphs
@@ -169,7 +173,7 @@ class GraphedForward:
         key = self.signature(*args)
         entry = self._graphs.get(key)
         if entry is None:
-            static_in = [a.detach().clone() for a in args]
+            static_in = [a if (self.alias_first and i == 0) else a.detach().clone() for i, a in enumerate(args)]
             side = self._stream if self._stream is not None else torch.cuda.Stream(device=args[0].device)
             side.wait_stream(torch.cuda.current_stream(args[0].device))
             with torch.no_grad(), torch.cuda.stream(side):
@@ -179,9 +183,12 @@ class GraphedForward:
                 with torch.cuda.graph(graph, stream=side):
                     out = self.fn(*static_in)
             torch.cuda.current_stream(args[0].device).wait_stream(side)
+            if self.alias_first:
+                static_in[0] = None                              # the address is in the key; the tensor is the caller's
             entry = self._graphs[key] = (graph, static_in, out)
         graph, static_in, out = entry
         for dst, src in zip(static_in, args):
-            dst.copy_(src)                                       # bumps dst._version: host-side caches keyed on it go stale
+            if dst is not None:
+                dst.copy_(src)                                   # bumps dst._version: host-side caches keyed on it go stale
         graph.replay()
         return out

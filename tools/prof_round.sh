@@ -8,9 +8,9 @@ export TS_PROF_MARK=1
 R=${1:-5}
 O=gpurun_out/prof_r$R
 rm -rf $O && mkdir -p $O
-timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 bench.py --steps 100 --warmup 5 --no-extra --no-cpu-baseline --no-trained-check > $O/bench.log 2>&1
-timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-trained-check > $O/fetch.log 2>&1
-timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-trained-check > $O/write.log 2>&1
+timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 bench.py --steps 100 --warmup 5 --no-extra --no-cpu-baseline --no-trained-check --no-predict-api > $O/bench.log 2>&1
+timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-trained-check --no-predict-api > $O/fetch.log 2>&1
+timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline --no-trained-check --no-predict-api > $O/write.log 2>&1
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python3 tools/bench_extra.py c3 --no-check > $O/c3.log 2>&1
 export TS_C4_ONLY=c4_phase1
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4p1 -- python3 tools/bench_extra.py c4 > $O/c4p1.log 2>&1
