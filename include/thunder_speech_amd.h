@@ -142,6 +142,12 @@ int64_t ts_w2v_layernorm_bwd_workspace(int64_t rows, int32_t c);
 int ts_w2v_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* dy, float eps, int64_t rows, int32_t c, float* dx,
                          float* dgamma, float* dbeta, void* workspace, void* stream);
 int ts_w2v_colsum(const float* x, int64_t rows, int32_t c, int64_t ld, float* out, void* stream);
+/* Operand casts of the MIXED-PRECISION fine-tuning products (ABI v11; the reference under Lightning's precision="bf16-mixed": f32 master weights,
+ * f32 gradients, bf16 GEMM operands): x f32 [rows][c] (pitch ldx) -> y bf16 [rows][c] (pitch ldy) and / or yt bf16 [c][rows_pad] (pitch ldt), the
+ * transposed copy with its rows index zero-padded to rows_pad (a multiple of 32: ts_gemm_nt_bf16's contraction index).  Either output may be NULL. */
+int ts_w2v_cast_bf16_t(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad, void* stream);
+/* out[i] = sum_p parts[p * n + i], p in order (n % 4 == 0): the reduction behind ts_gemm_nt_bf16_splitk */
+int ts_w2v_sum_parts(const float* parts, float* out, int64_t n, int32_t n_parts, void* stream);
 int ts_w2v_gelu_fwd(const float* z, const float* bias, int32_t c, float* y, int64_t n, void* stream);
 int ts_w2v_gelu_bwd(const float* z, const float* bias, int32_t c, const float* dy, float* dz, int64_t n, void* stream);
 int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, int32_t pitch, float scale, void* stream);
@@ -528,6 +534,11 @@ int ts_gemm_nt_bf16(const void* x, int64_t lda, const void* w, int64_t ldw, cons
 /* The same product with the (static) weights additionally supplied as MFMA B fragments, w_frag[n / 16][k / 32][64][8] bf16 written by
  * ts_gemm_nt_pack_w (n * k elements; n % 16 == 0, k % 32 == 0): the B operand then goes from L2 straight to registers instead of through LDS. */
 int ts_gemm_nt_pack_w(const void* w, int64_t ldw, int32_t n, int32_t k, void* w_frag, void* stream);
+/* Split-K form (ABI v11) for products with few 256 x 256 output tiles and a long contraction -- the weight gradients of mixed-precision fine-tuning
+ * (1024 x 1024 outputs over 4 000 rows = 16 tiles on 256 compute units): split z of `splits` multiplies columns [z k / splits, (z + 1) k / splits) of
+ * both operands into parts[z] (f32 [rows][n], pitch n); (k / splits) % 32 == 0.  ts_w2v_sum_parts adds the parts in a fixed order. */
+int ts_gemm_nt_bf16_splitk(const void* x, int64_t lda, const void* w, int64_t ldw, float* parts, int64_t rows, int32_t n, int32_t k, int32_t splits,
+                           void* stream);
 int ts_gemm_nt_bf16_packed(const void* x, int64_t lda, const void* w, int64_t ldw, const void* w_frag, const float* bias, const float* res,
                            int64_t ld_res, float* y, int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k, int32_t gelu,
                            void* stream);

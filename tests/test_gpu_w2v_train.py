@@ -185,3 +185,81 @@ def test_unfrozen_feature_extractor_is_refused_and_the_frozen_plan_holds_only_it
     next(adapt.original_encoder.feature_extractor.parameters()).requires_grad_(True)
     with pytest.raises(NotImplementedError, match="feature extractor is frozen"):
         adapt(x, torch.tensor([6000, 6000]).cuda())
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+def test_mixed_precision_training_matches_transformers_autograd_within_bf16_tolerance(family):
+    """train_precision="bf16" (huggingface/train.py LinearMixed: bf16 operands + f32 accumulation in the linear layers' forward, data-gradient and
+    weight-gradient products on csrc/gemm_nt.hip; everything else f32) -- the reference under Lightning's precision="bf16-mixed".  Stated
+    tolerance against f32 autograd through the real transformers model: last_hidden_state within 3e-2 of its unit scale, every parameter
+    gradient within 4e-2 relative L2 (bf16 operands carry 2^-9 relative rounding through 2 layers x 6 products); the f32 mode's 3e-3 / 5e-4
+    are checked above.  The ragged (attention-masked) form is the one run here; the forward is bit-reproducible."""
+    ref, adapt = _pair(family)
+    adapt.train_precision = "bf16"
+    adapt.mask_input = True
+    x = _inputs()
+    lengths = torch.tensor([4000, 3000, 2111])
+    x = x * (torch.arange(x.shape[1])[None, :] < lengths[:, None])
+    att = (torch.arange(x.shape[1])[None, :] < lengths[:, None]).long()
+    out_ref = ref(x, attention_mask=att).last_hidden_state
+    probe = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(5))
+    (out_ref * probe).sum().backward()
+    feats, _ = adapt(x.cuda(), lengths.cuda())
+    got = feats.transpose(-1, -2)
+    err = float((got.detach().cpu() - out_ref.detach()).abs().max())
+    assert err <= 3e-2 * max(1.0, float(out_ref.abs().max())), err
+    assert err > 1e-6, "the mixed-precision path did not run (bit-level agreement with f32 is not what bf16 operands give)"
+    (got * probe.cuda()).sum().backward()
+    worst = _compare_grads(ref, adapt, tol=4e-2)
+    assert worst > 1e-5
+    with torch.no_grad():
+        adapt.train()
+        feats2, _ = adapt(x.cuda(), lengths.cuda())
+    assert torch.equal(feats2, feats)
+
+
+def test_cast_bf16_t_writes_the_plain_and_the_zero_padded_transposed_copy():
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    for rows, c in ((597, 64), (70, 96), (1, 32), (130, 200)):
+        x = torch.randn(rows, c, device="cuda")
+        rp = (rows + 31) // 32 * 32
+        y = torch.full((rows, c), 7.0, dtype=torch.bfloat16, device="cuda")
+        yt = torch.full((c, rp), 7.0, dtype=torch.bfloat16, device="cuda")
+        _lib.check(L.ts_w2v_cast_bf16_t(x.data_ptr(), c, rows, c, y.data_ptr(), c, yt.data_ptr(), rp, rp, torch.cuda.current_stream().cuda_stream), "cast")
+        assert torch.equal(y, x.to(torch.bfloat16))
+        assert torch.equal(yt[:, :rows], x.to(torch.bfloat16).t()) and float(yt[:, rows:].float().abs().sum()) == 0.0
+
+
+def test_vectorised_dropout_draws_the_oracles_philox_stream():
+    """huggingface/train.py Dropout on f32 [rows, c] tensors takes ts_train_dropout's four-elements-per-thread form (c % 4 == 0): one Philox block per
+    four elements -- the same keep mask as the oracle's per-element definition (word e & 3 of block e >> 2, e = row * c + i), bit for bit; an odd width
+    takes the scalar form and agrees with the oracle too."""
+    from oracle import philox as ph
+    from thunder_speech_amd.huggingface.train import Dropout
+    for rows, c, p in ((37, 1024, 0.1), (5, 4096, 0.5), (9, 1023, 0.3)):
+        x = torch.randn(rows, c, device="cuda") + 3.0
+        y = Dropout.apply(x, p, 424242)
+        keep = torch.from_numpy(ph.dropout_keep(424242, rows * c, p)).view(rows, c).cuda()
+        assert torch.equal(y != 0, keep)
+        torch.testing.assert_close(y[keep], x[keep] / (1.0 - p), rtol=1e-6, atol=0)
+
+
+def test_split_k_product_equals_the_single_launch():
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for rows, n, k, splits in ((1024, 1024, 4096, 8), (512, 256, 2048, 4), (96, 64, 1024, 2)):
+        a = torch.randn(rows, k, device="cuda", generator=g).to(torch.bfloat16)
+        w = torch.randn(n, k, device="cuda", generator=g).to(torch.bfloat16)
+        one = torch.empty(rows, n, device="cuda")
+        _lib.check(L.ts_gemm_nt_bf16(a.data_ptr(), k, w.data_ptr(), k, None, None, 0, one.data_ptr(), n, None, 0, rows, n, k, 0, st), "gemm")
+        parts = torch.empty(splits, rows, n, device="cuda")
+        out = torch.empty(rows, n, device="cuda")
+        _lib.check(L.ts_gemm_nt_bf16_splitk(a.data_ptr(), k, w.data_ptr(), k, parts.data_ptr(), rows, n, k, splits, st), "splitk")
+        _lib.check(L.ts_w2v_sum_parts(parts.data_ptr(), out.data_ptr(), rows * n, splits, st), "sum")
+        ref = a.float() @ w.float().t()
+        scale = float(ref.abs().max())
+        assert float((one - ref).abs().max()) <= 2e-3 * scale and float((out - ref).abs().max()) <= 2e-3 * scale
+        assert L.ts_gemm_nt_bf16_splitk(a.data_ptr(), k, w.data_ptr(), k, parts.data_ptr(), rows, n, k, 3, st) != 0      # k / 3 is not a multiple of 32

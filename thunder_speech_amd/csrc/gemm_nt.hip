@@ -45,6 +45,7 @@ struct GemmArgs {
   unsigned short* y16;
   long long lda, ldw, ld_res, ldc, ld16;
   long long sx, sy;                              // batch strides (elements) of x and of y / y16 / res
+  long long sw;                                  // batch stride of w (0: shared by the batch; split-K: both operands step along the contraction)
   int M, N, K, act;                              // act bit 0: GELU
   int n_mt, n_nt;
   int blk_c;                                      // column tiles per block of the tile walk (divides n_nt)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256 * WMR) __attribute__((amdgpu_waves_per_eu(2, 2)
   const unsigned short* const xb = a.x + (size_t)bz * a.sx;
 
   const i32x4 ra = raw_rsrc(xb, 0x7fffffffu);
-  const i32x4 rb = raw_rsrc(a.w, 0x7fffffffu);
+  const i32x4 rb = raw_rsrc(a.w + (size_t)bz * a.sw, 0x7fffffffu);
   // DMA geometry: one instruction = 16 rows x 64 bytes; lane -> (row lane >> 2, LDS slot lane & 3); the slot holds source chunk
   // slot ^ ((row >> 2) & 3).  Wave w fetches rows [32 w, 32 w + 32) of both tiles (two instructions each).
   const int lrow = lane >> 2, lslot = lane & 3;
@@ -376,9 +377,9 @@ int gemm_nt_pack_w(hipStream_t stream, const void* w, long long ldw, int N, int 
 }
 
 // wf: w in fragment order (gemm_nt_pack_w) or null
-int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
-                 const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
-                 int gelu, int batch, const void* wf) {
+static int gemm_nt_bf16_sw(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
+                           const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
+                           int gelu, int batch, const void* wf, long long sw) {
   if (!x || !w || (!y && !y16) || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return TS_EINVAL;
   if (N % 32 || K % GKH || lda % 8 || ldw % 8 || ldw < K) return TS_EUNSUPPORTED;
   if ((y && (ldc % 4 || (reinterpret_cast<uintptr_t>(y) & 15))) || (y16 && (ld16 % 8 || (reinterpret_cast<uintptr_t>(y16) & 15))) ||
@@ -399,7 +400,7 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
   GemmArgs a;
   a.x = static_cast<const unsigned short*>(x); a.w = static_cast<const unsigned short*>(w); a.wf = static_cast<const unsigned short*>(wf); a.bias = bias; a.res = res; a.y = y;
   a.y16 = static_cast<unsigned short*>(y16);
-  a.lda = lda; a.ldw = ldw; a.ld_res = ld_res; a.ldc = ldc; a.ld16 = ld16; a.sx = sx; a.sy = sy;
+  a.lda = lda; a.ldw = ldw; a.ld_res = ld_res; a.ldc = ldc; a.ld16 = ld16; a.sx = sx; a.sy = sy; a.sw = sw;
   a.M = (int)M; a.N = N; a.K = K; a.act = gelu ? 1 : 0;
   a.n_mt = (int)((M + GM - 1) / GM); a.n_nt = (N + GN - 1) / GN;
   a.blk_c = a.n_nt % 4 == 0 ? 4 : (a.n_nt % 3 == 0 ? 3 : (a.n_nt % 2 == 0 ? 2 : 1));
@@ -419,6 +420,12 @@ int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx,
   return hip_status(hipGetLastError());
 }
 
+int gemm_nt_bf16(hipStream_t stream, const void* x, long long lda, long long sx, const void* w, long long ldw, const float* bias,
+                 const float* res, long long ld_res, float* y, long long ldc, void* y16, long long ld16, long long sy, long long M, int N, int K,
+                 int gelu, int batch, const void* wf) {
+  return gemm_nt_bf16_sw(stream, x, lda, sx, w, ldw, bias, res, ld_res, y, ldc, y16, ld16, sy, M, N, K, gelu, batch, wf, 0);
+}
+
 }  // namespace ts
 
 /* C-ABI form (tests, tools): y[m][n] = act(sum_k x[m][k] w[n][k] + bias[n]) + res[m][n]; see include/thunder_speech_amd.h */
@@ -426,6 +433,17 @@ extern "C" int ts_gemm_nt_bf16(const void* x, int64_t lda, const void* w, int64_
                                float* y, int64_t ldc, void* y_bf16, int64_t ld16, int64_t rows, int32_t n, int32_t k, int32_t gelu, void* stream) {
   if (lda < 0 || ldw < k || (y && ldc < n) || (y_bf16 && ld16 < n) || (res && ld_res < n)) return TS_EINVAL;
   return ts::gemm_nt_bf16((hipStream_t)stream, x, lda, 0, w, ldw, bias, res, ld_res, y, ldc, y_bf16, ld16, 0, rows, n, k, gelu, 1, nullptr);
+}
+
+/* split-K form for products with few output tiles and a long contraction (the weight gradients of mixed-precision fine-tuning: 1024 x 1024 outputs
+   = 16 tiles of 256 x 256 over 4 000 rows): `splits` launches-in-one (grid.y), split z multiplies columns [z k / splits, (z + 1) k / splits) of both
+   operands into parts[z] (f32 [rows][n], pitch n); ts_w2v_sum_parts adds the parts in order. */
+extern "C" int ts_gemm_nt_bf16_splitk(const void* x, int64_t lda, const void* w, int64_t ldw, float* parts, int64_t rows, int32_t n, int32_t k, int32_t splits,
+                                      void* stream) {
+  if (splits < 1 || k % splits || (k / splits) % 32 || lda < k || ldw < k) return TS_EINVAL;
+  const long long ks = k / splits;
+  if ((ks % 8) != 0) return TS_EUNSUPPORTED;
+  return ts::gemm_nt_bf16_sw((hipStream_t)stream, x, lda, ks, w, ldw, nullptr, nullptr, 0, parts, n, nullptr, 0, (long long)rows * n, rows, n, (int)ks, 0, splits, nullptr, ks);
 }
 
 /* the same product with the weights ALSO given in fragment order (ts_gemm_nt_pack_w): the B operand then bypasses LDS */

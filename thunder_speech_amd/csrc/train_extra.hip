@@ -193,17 +193,43 @@ __global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float* __restr
   }
 }
 
-// element (row, i) draws word (e & 3) of Philox counter e >> 2, e = row * t + i: the mask depends on the LOGICAL index only
+// element (row, i) draws word (e & 3) of Philox counter e >> 2, e = row * t + i: the mask depends on the LOGICAL index only.  A thread owns one
+// Philox block = four consecutive logical elements (which may straddle a row end when t % 4 != 0: the address is formed per element).
 template <class T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int t, int pitch, float p, float scale,
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n_el, int t, int pitch, float p, float scale,
+                                                       unsigned long long seed, const unsigned long long* __restrict__ nonce) {
+  if (nonce) seed += *nonce;                             // replay counter of a captured training step (hipGraph): a new mask per replay
+  const unsigned long long e0 = 4ull * ((unsigned long long)blockIdx.x * 256 + threadIdx.x);
+  if (e0 >= (unsigned long long)n_el) return;
+  const Philox4 r = philox(seed, PHILOX_DROPOUT, e0 >> 2);
+  long long row = (long long)(e0 / (unsigned)t);
+  int i = (int)(e0 - (unsigned long long)row * t);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (e0 + q < (unsigned long long)n_el) {
+      const size_t at = (size_t)row * pitch + i;
+      stf(y, at, u01(r.v[q]) >= p ? ldf(x, at) * scale : 0.f);
+      if (++i == t) { i = 0; ++row; }
+    }
+  }
+}
+
+// the same masks four elements at a time (f32 rows, t and pitch multiples of 4, 16-byte aligned rows): element e = row * t + i with i % 4 == 0 starts
+// Philox block e >> 2, whose four words are the draws of elements i .. i + 3 -- ONE block and one 16-byte load / store per thread instead of four
+// blocks and four scalar accesses (wav2vec2 fine-tuning: 196 launches x 57 us -> see profiles/round6_c5_finetune.md)
+__global__ __launch_bounds__(256) void dropout4_kernel(const float* __restrict__ x, float* __restrict__ y, int t, int pitch, float p, float scale,
                                                        unsigned long long seed, const unsigned long long* __restrict__ nonce) {
   const long long row = blockIdx.x;
-  if (nonce) seed += *nonce;                             // replay counter of a captured training step (hipGraph): a new mask per replay
-  for (int i = blockIdx.y * 1024 + threadIdx.x; i < t && i < (int)(blockIdx.y + 1) * 1024; i += 256) {
-    const unsigned long long e = (unsigned long long)row * t + i;
-    const Philox4 r = philox(seed, PHILOX_DROPOUT, e >> 2);
-    stf(y, row * pitch + i, u01(r.v[e & 3]) >= p ? ldf(x, row * pitch + i) * scale : 0.f);
-  }
+  if (nonce) seed += *nonce;
+  const int i = blockIdx.y * 1024 + threadIdx.x * 4;
+  if (i >= t) return;
+  const unsigned long long e = (unsigned long long)row * t + i;
+  const Philox4 r = philox(seed, PHILOX_DROPOUT, e >> 2);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * pitch + i);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = u01(r.v[j]) >= p ? v[j] * scale : 0.f;
+  *reinterpret_cast<f32x4*>(y + row * pitch + i) = o;
 }
 
 static inline dim3 rgrid(long long rows, int t) { return dim3((unsigned)rows, (unsigned)((t + 1023) / 1024)); }
@@ -301,10 +327,17 @@ extern "C" int ts_train_dropout(const void* x, void* y, int64_t rows, int32_t t,
   if (!x || !y || rows <= 0 || t <= 0 || pitch < t || !(p >= 0.f) || p > 1.f || act < 0 || act > 1) return TS_EINVAL;
   const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
   (void)hipGetLastError();
+  if (act == 0 && t % 4 == 0 && pitch % 4 == 0 && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(y) & 15)) {
+    hipLaunchKernelGGL(dropout4_kernel, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, t, pitch, p, scale, (unsigned long long)seed,
+                       (const unsigned long long*)nonce);
+    return hip_status(hipGetLastError());
+  }
+  const long long n_el = (long long)rows * t;
+  const dim3 fgrid((unsigned)((n_el + 1023) / 1024));
   TS_ACT(act,
-         hipLaunchKernelGGL(dropout_kernel<float>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, t, pitch, p, scale, (unsigned long long)seed,
+         hipLaunchKernelGGL(dropout_kernel<float>, fgrid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n_el, t, pitch, p, scale, (unsigned long long)seed,
                             (const unsigned long long*)nonce),
-         hipLaunchKernelGGL(dropout_kernel<bf16_t>, rgrid(rows, t), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, t, pitch, p, scale, (unsigned long long)seed,
+         hipLaunchKernelGGL(dropout_kernel<bf16_t>, fgrid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n_el, t, pitch, p, scale, (unsigned long long)seed,
                             (const unsigned long long*)nonce));
   return hip_status(hipGetLastError());
 }

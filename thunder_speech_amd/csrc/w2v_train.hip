@@ -238,6 +238,66 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 using namespace ts;
 #define TS_STREAM hipStream_t stream = reinterpret_cast<hipStream_t>(stream_); (void)hipGetLastError()
 
+namespace ts {
+// f32 rows -> bf16 copy and / or TRANSPOSED bf16 copy, the operands of the mixed-precision fine-tuning products (huggingface/train.py LinearMixed):
+//   y[r][j] = bf16(x[r][j]);   yt[j][r] = bf16(x[r][j]) for r < rows, 0 for rows <= r < rows_pad
+// (the transposed copy's contraction index -- the rows -- is padded with zeros to a multiple of 32, what ts_gemm_nt_bf16 wants).  64 x 64 tiles
+// through LDS: 256-byte row reads, 128-byte writes in both layouts.
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ x, long long ldx, int rows, int c, unsigned short* __restrict__ y,
+                                                          long long ldy, unsigned short* __restrict__ yt, long long ldt, int rows_pad) {
+  __shared__ unsigned short tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, cc = c0 + tx;
+    unsigned short v = 0;
+    if (r < rows && cc < c) {
+      v = (unsigned short)(pack_bf16(x[(size_t)r * ldx + cc], 0.f) & 0xffffu);
+      if (y) y[(size_t)r * ldy + cc] = v;
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (yt) {
+    for (int i = ty; i < 64; i += 4) {
+      const int cc = c0 + i, r = r0 + tx;
+      if (cc < c && r < rows_pad) yt[(size_t)cc * ldt + r] = tile[tx][i];
+    }
+  }
+}
+}  // namespace ts
+
+namespace ts {
+__global__ __launch_bounds__(256) void w2v_sum_parts_kernel(const float* __restrict__ parts, float* __restrict__ out, long long n4, int n_parts, long long stride4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 acc = reinterpret_cast<const f32x4*>(parts)[i];
+  for (int p = 1; p < n_parts; ++p) acc += reinterpret_cast<const f32x4*>(parts)[(long long)p * stride4 + i];      // fixed order: deterministic
+  reinterpret_cast<f32x4*>(out)[i] = acc;
+}
+}  // namespace ts
+
+extern "C" int ts_w2v_sum_parts(const float* parts, float* out, int64_t n, int32_t n_parts, void* stream_) {
+  if (!parts || !out || n <= 0 || n % 4 || n_parts < 1 || (reinterpret_cast<uintptr_t>(parts) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return TS_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::w2v_sum_parts_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), parts, out, (long long)(n / 4), (int)n_parts,
+                     (long long)(n / 4));
+  return ts::hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_cast_bf16_t(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad,
+                                  void* stream_) {
+  if (!x || (!y && !yt) || rows <= 0 || c <= 0 || ldx < c || rows >= (1ll << 31)) return TS_EINVAL;
+  if (y && ldy < c) return TS_EINVAL;
+  if (yt && (rows_pad < rows || ldt < rows_pad || rows_pad >= (1ll << 31))) return TS_EINVAL;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const long long rp = yt ? rows_pad : rows;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::cast_bf16_t_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)((rp + 63) / 64)), dim3(256), 0, stream, x, (long long)ldx, (int)rows, (int)c,
+                     static_cast<unsigned short*>(y), (long long)ldy, static_cast<unsigned short*>(yt), (long long)ldt, (int)rows_pad);
+  return ts::hip_status(hipGetLastError());
+}
+
 extern "C" int64_t ts_w2v_layernorm_bwd_workspace(int64_t rows, int32_t c) {
   if (rows <= 0 || c <= 0) return TS_EINVAL;
   const long long waves = (rows < 4096 ? (rows + 3) / 4 * 4 : 4096);

@@ -349,9 +349,14 @@ class HuggingFaceEncoderAdapt(nn.Module):
     """Same constructor, attributes and return convention as the reference's `_HuggingFaceEncoderAdapt`
     (huggingface/compatibility.py:23-42): `(audio [B, n], lengths) -> (features [B, C, T'], lengths')`."""
 
-    def __init__(self, encoder, mask_input: bool = False, precision: str = "bf16"):
+    def __init__(self, encoder, mask_input: bool = False, precision: str = "bf16", train_precision: str = "fp32"):
+        if train_precision not in ("fp32", "bf16"):
+            raise ValueError(f"train_precision must be 'fp32' or 'bf16', got {train_precision!r}")
         super().__init__()
         self.precision = precision
+        # arithmetic of the TRAINABLE part in train mode (huggingface/train.py): "fp32" = the reference's, "bf16" = mixed precision (bf16 operands in the
+        # linear layers' three products, everything else f32) -- the reference under Lightning's precision="bf16-mixed"
+        self.train_precision = train_precision
         self.original_encoder = encoder
         if hasattr(self.original_encoder, "freeze_feature_encoder"):
             self.original_encoder.freeze_feature_encoder()

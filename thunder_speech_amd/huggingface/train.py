@@ -77,6 +77,98 @@ class Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+def _pad32(n: int) -> int:
+    """Padded length of a contraction index: a multiple of 32 (ts_gemm_nt_bf16), of 256 for long ones so that split-K has powers of two to choose from."""
+    return (n + 255) // 256 * 256 if n > 1024 else (n + 31) // 32 * 32
+
+
+def _cast(x2: Tensor, rows: int, c: int, plain: bool, transposed: bool):
+    """(bf16 copy [rows][c] or None, transposed bf16 copy [c][pad32(rows)] or None) of the f32 matrix x2 (contiguous [rows][c]): ONE launch."""
+    dev = x2.device
+    y = torch.empty(rows, c, dtype=torch.bfloat16, device=dev) if plain else None
+    rp = _pad32(rows)
+    yt = torch.empty(c, rp, dtype=torch.bfloat16, device=dev) if transposed else None
+    st = _lib.lib().ts_w2v_cast_bf16_t(x2.data_ptr(), c, rows, c, y.data_ptr() if plain else None, c, yt.data_ptr() if transposed else None, rp, rp, _s(x2))
+    _lib.check(st, "ts_w2v_cast_bf16_t")
+    return y, yt
+
+
+def _gemm_nt(a16: Tensor, lda: int, w16: Tensor, ldw: int, out: Tensor, rows: int, n: int, k: int, bias: Optional[Tensor] = None):
+    """out[r][j] = sum_i a16[r][i] w16[j][i] (+ bias[j]) on the bf16 matrix-core GEMM (csrc/gemm_nt.hip), f32 accumulation and result."""
+    st = _lib.lib().ts_gemm_nt_bf16(a16.data_ptr(), lda, w16.data_ptr(), ldw, bias.data_ptr() if bias is not None else None, None, 0, out.data_ptr(), n,
+                                    None, 0, rows, n, k, 0, _s(out))
+    _lib.check(st, "ts_gemm_nt_bf16")
+
+
+def _gemm_nt_splitk(a16: Tensor, lda: int, w16: Tensor, ldw: int, out: Tensor, rows: int, n: int, k: int):
+    """The same product for FEW output tiles and a LONG contraction (the weight gradients: 1024 x 1024 outputs are 16 tiles of 256 x 256 on 256 compute
+    units): split-K into f32 partials (ts_gemm_nt_bf16_splitk) + an ordered sum (ts_w2v_sum_parts), splits chosen for ~128 workgroups."""
+    tiles = ((rows + 255) // 256) * ((n + 255) // 256)
+    splits = 1
+    while tiles * splits < 128 and k % (64 * splits) == 0 and k // (2 * splits) >= 256:
+        splits *= 2
+    if splits == 1 or (rows * n) % 4:
+        return _gemm_nt(a16, lda, w16, ldw, out, rows, n, k)
+    parts = torch.empty(splits, rows, n, dtype=torch.float32, device=out.device)
+    L = _lib.lib()
+    _lib.check(L.ts_gemm_nt_bf16_splitk(a16.data_ptr(), lda, w16.data_ptr(), ldw, parts.data_ptr(), rows, n, k, splits, _s(out)), "ts_gemm_nt_bf16_splitk")
+    _lib.check(L.ts_w2v_sum_parts(parts.data_ptr(), out.data_ptr(), rows * n, splits, _s(out)), "ts_w2v_sum_parts")
+
+
+class LinearMixed(torch.autograd.Function):
+    """nn.Linear in mixed precision (what Lightning's precision="bf16-mixed" gives the reference's training_step, module.py:102-127): bf16 operands,
+    f32 accumulation, f32 activations / master weights / gradients.  All three products are the NT form of csrc/gemm_nt.hip:
+        y  = x16 . w16^T                    x16 [M][K], w16 [N][K]
+        dx = dy16 . (w16^T)^T               dy16 [M][N], wT16 [K][N]
+        dW = dyT16 . (xT16)^T               dyT16 [N][Mp], xT16 [K][Mp]   (Mp = M padded to 32 with zeros: the contraction index)
+    The transposed copies come out of the same cast launch as the plain ones; the node keeps xT16 (half the bytes of the f32 input) and wT16."""
+
+    @staticmethod
+    def supported(n: int, k: int) -> bool:
+        return n % 32 == 0 and k % 32 == 0
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _f32c(x), _f32c(w)
+        n, k = w.shape
+        rows = x.numel() // k
+        x16, xt16 = _cast(x.view(rows, k), rows, k, True, ctx.needs_input_grad[1])
+        w16, wt16 = _cast(w, n, k, True, ctx.needs_input_grad[0])
+        y = torch.empty(*x.shape[:-1], n, dtype=torch.float32, device=x.device)
+        _gemm_nt(x16, k, w16, k, y, rows, n, k, _f32c(b) if b is not None else None)
+        ctx.save_for_backward(xt16, wt16)
+        ctx.has_bias, ctx.geom = b is not None, (rows, n, k, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xt16, wt16 = ctx.saved_tensors
+        rows, n, k, xshape = ctx.geom
+        dy = _f32c(dy)
+        dy16, dyt16 = _cast(dy.view(rows, n), rows, n, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
+            _gemm_nt(dy16, n, wt16, _pad32(n), dx, rows, k, n)                    # (n % 32 == 0: wT16's pitch is n)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
+            rp = _pad32(rows)
+            _gemm_nt_splitk(dyt16, rp, xt16, rp, dw, n, k, rp)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, rows, n)
+        return dx, dw, db
+
+
+_MIXED = False
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """nn.Linear of the training path in the current precision mode (`train_forward(..., mixed=...)`)."""
+    if _MIXED and LinearMixed.supported(w.shape[0], w.shape[1]):
+        return LinearMixed.apply(x, w, b)
+    return Linear.apply(x, w, b)
+
+
 class LayerNorm(torch.autograd.Function):
     """y = LayerNorm(x (+ res)) over the last axis; the residual add rides in the launch (both inputs receive the same gradient)."""
 
@@ -369,7 +461,18 @@ def compute_mask_indices(batch: int, t: int, mask_prob: float, mask_length: int,
 
 def train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
     """Training-mode Wav2Vec2Model.forward -> last_hidden_state [B, T', C] (f32, time-major).  `adapt`: the HuggingFaceEncoderAdapt module
-    (its `original_encoder` owns the parameters)."""
+    (its `original_encoder` owns the parameters).  `adapt.train_precision`: "fp32" (default: the reference's arithmetic, every product on the f32
+    matrix-core GEMM) or "bf16" (mixed precision: the linear layers -- 92 % of the step's FLOPs -- multiply bf16 operands with f32 accumulation,
+    LinearMixed; attention, positional conv, LayerNorm, GELU, dropout, master weights and all gradients stay f32)."""
+    global _MIXED
+    _MIXED = getattr(adapt, "train_precision", "fp32") == "bf16"
+    try:
+        return _train_forward(adapt, audio, lengths)
+    finally:
+        _MIXED = False
+
+
+def _train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
     from .encoder import feat_extract_output_lengths
     enc = adapt.original_encoder
     cfg = enc.config
@@ -397,7 +500,7 @@ def train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
     eps = float(cfg.layer_norm_eps)
     fp, en = enc.feature_projection, enc.encoder
     h = LayerNorm.apply(feats, None, fp.layer_norm.weight, fp.layer_norm.bias, eps)
-    h = Linear.apply(h, fp.projection.weight, fp.projection.bias)
+    h = linear(h, fp.projection.weight, fp.projection.bias)
     h = dropout(h, float(cfg.feat_proj_dropout))
     key_len = None
     if lengths is not None:
@@ -433,13 +536,13 @@ def train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
         bqkv = torch.cat([att.q_proj.bias, att.k_proj.bias, att.v_proj.bias], 0)
 
         def attend(x):
-            ctxt = Attention.apply(Linear.apply(x, wqkv, bqkv), key_len, heads, p_att, next_seed() if p_att > 0 else 0)
-            return dropout(Linear.apply(ctxt, att.out_proj.weight, att.out_proj.bias), p_hid)
+            ctxt = Attention.apply(linear(x, wqkv, bqkv), key_len, heads, p_att, next_seed() if p_att > 0 else 0)
+            return dropout(linear(ctxt, att.out_proj.weight, att.out_proj.bias), p_hid)
 
         def ffn(x):
-            z = Linear.apply(x, ff.intermediate_dense.weight, None)
+            z = linear(x, ff.intermediate_dense.weight, None)
             a = dropout(BiasGelu.apply(z, ff.intermediate_dense.bias), p_act)
-            return dropout(Linear.apply(a, ff.output_dense.weight, ff.output_dense.bias), p_hid)
+            return dropout(linear(a, ff.output_dense.weight, ff.output_dense.bias), p_hid)
 
         if stable:                                                  # pre-LN: h += attn(LN(h)); h += ffn(LN(h))
             h = Add.apply(h, attend(LayerNorm.apply(h, None, layer.layer_norm.weight, layer.layer_norm.bias, eps)))

@@ -149,7 +149,7 @@ def c5(device, batch=16, seconds=20, steps=10, check=True):
     return res
 
 
-def c5_finetune(device, batch=8, seconds=10, steps=5):
+def c5_finetune(device, batch=8, seconds=10, steps=5, train_precision="fp32"):
     """wav2vec2 fine-tuning as the reference runs it (BaseCTCModule.training_step on an HF encoder with the conv feature extractor frozen,
     tests/huggingface/test_module_huggingface.py:33-54): wav2vec2-large geometry (random weights), f32, CTC loss, AdamW on the transformer --
     forward, backward and the optimizer step, eager (autograd nodes over the library's f32 matrix-core GEMM, huggingface/train.py)."""
@@ -164,7 +164,7 @@ def c5_finetune(device, batch=8, seconds=10, steps=5):
     cfg = transformers.Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, hidden_dropout=0.1,
                                       activation_dropout=0.1, attention_dropout=0.1, feat_proj_dropout=0.1, layerdrop=0.0, mask_time_prob=0.05,
                                       feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False, vocab_size=32)
-    enc = HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(cfg), precision="fp32")
+    enc = HuggingFaceEncoderAdapt(transformers.Wav2Vec2Model(cfg), precision="fp32" if train_precision == "fp32" else "bf16", train_precision=train_precision)
     tokens = [chr(97 + i) for i in range(26)] + [" "]
     module = BaseCTCModule(enc, linear_decoder(1024, len(tokens) + 1, 0.0), Wav2Vec2Preprocess(), BatchTextTransformer(tokens=tokens),
                            optimizer_class=FusedAdamW, optimizer_kwargs={"lr": 1e-5}).to(device).train()
@@ -190,11 +190,15 @@ def c5_finetune(device, batch=8, seconds=10, steps=5):
     t = 16000 * seconds // 320
     c, ffn, L = 1024, 4096, 24
     fwd = 2.0 * batch * t * L * (4 * c * c + 2 * c * ffn + 2 * t * c)               # transformer only: the feature extractor is frozen (forward once)
-    return {"workload": f"wav2vec2-large geometry fine-tune step (CTC, feature extractor frozen, dropouts + time masking on), batch {batch}x{seconds} s, f32, "
-                        "eager autograd over the own f32 GEMM + FusedAdamW", "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s",
+    how = ("f32, eager autograd over the own f32 GEMM + FusedAdamW" if train_precision == "fp32" else
+           "mixed precision (bf16 operands / f32 accumulation in the linear layers' three products on the own bf16 GEMM; attention, positional conv, LayerNorm, "
+           "master weights, gradients f32), eager autograd + FusedAdamW")
+    return {"workload": f"wav2vec2-large geometry fine-tune step (CTC, feature extractor frozen, dropouts + time masking on), batch {batch}x{seconds} s, " + how,
+            "train_precision": train_precision, "ms_per_step": dt * 1e3, "value": 1.0 / dt, "unit": "step/s",
             "audio_seconds_per_s": batch * seconds / dt, "steps": steps, "trainable_parameters": n_train, "loss_first_last": [first, last],
-            "roofline": {"bound": "mfma", "model": "3 x transformer forward FLOPs / f32 matrix-core peak (157 TFLOP/s)", "achieved": 3.0 * fwd / dt / 1e12, "peak": 157.0,
-                         "unit": "TFLOP/s", "frac": 3.0 * fwd / dt / 1e12 / 157.0}}
+            "roofline": {"bound": "mfma", "model": "3 x transformer forward FLOPs / " + ("f32 matrix-core peak (157 TFLOP/s)" if train_precision == "fp32" else "dense bf16 peak"),
+                         "achieved": 3.0 * fwd / dt / 1e12, "peak": 157.0 if train_precision == "fp32" else MFMA_BF16_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": 3.0 * fwd / dt / 1e12 / (157.0 if train_precision == "fp32" else MFMA_BF16_PEAK_TF)}}
 
 
 def c4(device, local_batch=32, seconds=10, steps1=30, steps2=30):
@@ -437,7 +441,11 @@ def run(device, which=("c3", "c4", "c5", "c5_finetune"), check=True):
             elif name == "c5":
                 extra["c5"] = c5(device, check=check)
             elif name == "c5_finetune":
-                extra["c5_finetune"] = c5_finetune(device)
+                only = os.environ.get("TS_C5FT_ONLY")            # profiled runs: one variant per process
+                if only != "bf16":
+                    extra["c5_finetune"] = c5_finetune(device)
+                if only != "fp32":
+                    extra["c5_finetune_bf16"] = c5_finetune(device, train_precision="bf16")
             elif name == "c4_ddp":                   # stand-alone A/B of the segmented step: TS_C4_SEGMENTS / TS_C4_FIRST_SHARE (bench.py runs the defaults)
                 extra["c4_ddp"] = c4_ddp(device, segments=int(os.environ.get("TS_C4_SEGMENTS", "2")), first_share=float(os.environ.get("TS_C4_FIRST_SHARE", "0.1")))
         except Exception as e:                      # an extra must never take the headline line down with it: recorded, reported on stderr,
