@@ -192,3 +192,34 @@ def test_block_output_with_a_second_consumer_fails_loudly_instead_of_dropping_th
             continue
         w = (pm if pm is not None else 0) + (pa if pa is not None else 0)
         assert float((pb - w).abs().max()) <= 5e-4 * max(float(torch.as_tensor(w).abs().max()), 1e-3)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_front_end_register_prefetch_equals_the_direct_staging_bit_for_bit(train):
+    """stft_mel_kernel prefetches the next frame group's samples with `asm volatile` loads whose wait the compiler does not track
+    (csrc/frontend.hip fetch / commit); a toolchain that re-coloured those registers in between would produce silently wrong features.  The same
+    samples at a 4-byte-misaligned address make every group take the plain `stage_direct` path instead: the two feature tensors must be
+    IDENTICAL, in eval mode and in train mode (dither drawn from the same seed)."""
+    from thunder_speech_amd import rng
+    from thunder_speech_amd.quartznet.transform import FilterbankFeatures
+    fb = FilterbankFeatures().cuda()
+    fb.train(train)
+    n = 16000 * 7
+    g = torch.Generator().manual_seed(9)
+    base = torch.zeros(3 * n + 8, device="cuda")
+    wav = (0.1 * torch.randn(3, n, generator=g)).cuda()
+    aligned = wav.clone()
+    shifted = base[1: 1 + 3 * n].view(3, n)
+    shifted.copy_(wav)
+    assert aligned.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+    lengths = torch.tensor([n, n - 1234, n // 2], device="cuda", dtype=torch.int32)
+    outs = []
+    for x in (aligned, shifted):
+        if train:
+            torch.manual_seed(77)                      # rng.next_seed draws the dither seed from torch's CPU generator
+        feats, flen = fb(x, lengths)
+        outs.append((feats.clone(), flen.clone(), fb.last_logmel().clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2]), "log-mel differs between the prefetching and the direct staging path"
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].dtype == torch.int64 and outs[0][1].tolist() == [n // 160 + 1, (n - 1234) // 160 + 1, (n // 2) // 160 + 1]

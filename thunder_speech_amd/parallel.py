@@ -280,6 +280,11 @@ class GradientSync:
         if not self._launched[b]:
             self._launch(b)
 
+    def side_stream(self):
+        """The stream the exchange runs on (None on CPU): callers that put more work behind a bucket's exchange -- train_graph.GraphedTrainStep's
+        early per-bucket optimizer step -- queue it here."""
+        return self._side
+
     def hold(self, on: bool = True) -> None:
         """While held, the hooks only collect the gradients into the buckets and every collective waits for finish(): the mode of
         a backward pass that is captured into / replayed from a hipGraph (train_graph.GraphedTrainStep), where the host-side hooks

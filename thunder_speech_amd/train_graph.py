@@ -150,6 +150,23 @@ class GraphedTrainStep:
                 raise ValueError("GraphedTrainStep(segments=S): build the GradientSync with groups=segment_parameters(module, S) -- "
                                  f"its {len(have)} buckets are not the {len(want)} pieces of the segmented backward pass")
             self.segments, self._stages = len(stages), stages
+            # The early per-bucket optimizer step (__call__) updates bucket k's parameters -- and rewrites their bf16 / fragment copies -- on the
+            # side stream while graph k + 1 is running.  That is only sound if NO later piece reads a parameter of an earlier bucket: every
+            # parameter of bucket k must belong to modules of stage S-1-k (or, for bucket 0, the decoder) and to nothing else.  A parameter shared
+            # between stages (tied weights), or one outside encoder / decoder (`extra`, folded into bucket 0), switches the early step off.
+            owner = {}
+            for si, stage in enumerate(stages):
+                for blk in stage:
+                    for p in blk.parameters():
+                        owner.setdefault(id(p), set()).add(si)
+            for p in module.decoder.parameters():
+                owner.setdefault(id(p), set()).add(len(stages) - 1)              # the decoder's backward is part of piece 0 = the last stage's
+            self._early_ok = True
+            for k, grp in enumerate(groups):
+                want_stage = len(stages) - 1 - k
+                for p in grp:
+                    if owner.get(id(p)) != {want_stage}:
+                        self._early_ok = False
         if int(warmup) < 1:
             # the eager passes are what creates the per-stream arena buffers, packs the weight fragments and fills the length caches OUTSIDE
             # the graph's private memory pool; a capture without them would bake one-time work (and pool-owned cache entries) into the graph
@@ -271,8 +288,8 @@ class GraphedTrainStep:
             s.copy_(v, non_blocking=True)
         early = None
         if self.segments > 1:
-            side = getattr(self.sync, "_side", None)
-            if side is not None and getattr(self.optimizer, "supports_subset", False):
+            side = self.sync.side_stream() if hasattr(self.sync, "side_stream") else None
+            if side is not None and getattr(self.optimizer, "supports_subset", False) and getattr(self, "_early_ok", False):
                 early = set()
             for k, g in enumerate(graph):
                 g.replay()

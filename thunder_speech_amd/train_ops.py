@@ -795,9 +795,10 @@ class SqueezeExciteTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w2):
         x = _import(x, x.dtype if is_act(x) else _ACT_DTYPE)
-        w1, w2 = w1.detach(), w2.detach()
-        if w1.dtype != torch.float32 or w2.dtype != torch.float32 or not (w1.is_contiguous() and w2.is_contiguous()):
-            raise TypeError("SqueezeExciteTrain: contiguous f32 weights only (the reference's nn.Linear parameters)")
+        # any floating dtype / stride is accepted, as nn.Linear's own matmul would (the kernels take contiguous f32: a copy when needed; the
+        # gradients come back in f32 and autograd casts them to the parameters' dtype).  A bottleneck too wide for the gate kernels' LDS
+        # (C + hidden > 16 K floats; Citrinet-1024 has 1 152) raises NotImplementedError from _lib.check -- loudly, there is no ATen path.
+        w1, w2 = w1.detach().to(torch.float32).contiguous(), w2.detach().to(torch.float32).contiguous()
         b, c, t = x.shape
         r = w1.shape[0]
         if tuple(w1.shape) != (r, c) or tuple(w2.shape) != (c, r):
