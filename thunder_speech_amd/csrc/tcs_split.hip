@@ -25,7 +25,10 @@
 #include "tcs_shared.hpp"
 
 #ifndef TS_SPLIT_STORE_AUX
-#define TS_SPLIT_STORE_AUX 0      // cache policy of the result stores (raw buffer aux: 1 = sc0, 2 = nt, 16 = sc1)
+// cache policy of the result stores (raw buffer aux: 1 = sc0, 2 = nt, 16 = sc1).  sc1 = write-through at system scope: the rows do not wait dirty in the
+// XCD's L2 for the end-of-kernel write-back; same-box A/B of the C2 encoder, 4 interleaved runs each: 2.812 2.792 2.801 2.801 ms (plain) vs 2.788 2.783
+// 2.791 2.789 (sc1); nt (streaming) costs +3 % -- it also evicts what the next launch would hit (profiles/round6_c4_pointwise.md section 3)
+#define TS_SPLIT_STORE_AUX 16
 #endif
 
 namespace ts {
