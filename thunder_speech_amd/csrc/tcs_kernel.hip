@@ -28,6 +28,10 @@
 //  * a lone wave issues an instruction only every ~8 cycles on this chip, so the steady state is kept almost VALU-free.
 #include "tcs_shared.hpp"
 
+#ifndef TS_TCS_STORE_AUX
+#define TS_TCS_STORE_AUX 0       // experiment: cache policy of the generic kernel's bf16 result stores (raw buffer aux: 16 = sc1); see profiles/round6_c4_pointwise.md
+#endif
+
 
 namespace ts {
 
@@ -528,6 +532,9 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
       // 32-channel output tile so that the global stores are whole 16-B-per-lane row segments (the accumulator
       // layout gives 8 B per lane in 64 different rows per instruction, which is TA-issue-bound).
       unsigned short* const yb = reinterpret_cast<unsigned short*>(a.y);
+#if TS_TCS_STORE_AUX
+      const __amdgpu_buffer_rsrc_t ry_out = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0x7fffffff, 0x00020000);
+#endif
       // ReLU as a packed signed-16-bit max against `floor`: 0 clamps negative bf16 to +0, 0x8000 is a no-op
       const unsigned floor2 = a.relu ? 0u : 0x80008000u;
       // frames >= the output length are stored as 0 when the caller asks for the tail-zero invariant
@@ -605,8 +612,13 @@ __global__ __launch_bounds__(512, 2) void tcs_kernel(const TcsArgs a) {
           const int co = cob + rl;
           const int t = t0 + csub * 8;
           const u32x4 v = *reinterpret_cast<const u32x4*>(et + (size_t)rl * EP + csub * 16);
-          if (co < a.c_out && t < a.pitch_out)
+          if (co < a.c_out && t < a.pitch_out) {
+#if TS_TCS_STORE_AUX
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry_out, (int)(((size_t)(b * a.c_out + co) * a.pitch_out + t) * 2), 0, TS_TCS_STORE_AUX);
+#else
             *reinterpret_cast<u32x4*>(yb + (size_t)(b * a.c_out + co) * a.pitch_out + t) = v;
+#endif
+          }
         }
       }
     }
