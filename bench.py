@@ -106,6 +106,12 @@ def cpu_baseline_sweep(seconds=15, budget_s=40.0, repeat_blocks=3):
             break
         if time.perf_counter() - t_start > 0.7 * budget_s:
             break
+        good_so_far = [p for p in points if "value" in p]
+        if len(good_so_far) >= 2 and good_so_far[-1]["value"] < 1.25 * good_so_far[-2]["value"]:
+            # four times the processes did not even buy 25 %: the host is out of memory bandwidth (or of CPU quota), sixteen would only cost the
+            # run another ~25 s (measured on the pool's boxes: 243 / 185 / 66 audio-s/s at 1 / 4 / 16 processes) -- recorded as skipped
+            points.append({"processes": procs, "threads": threads, "skipped": "the previous step of the sweep scaled by less than 1.25x"})
+            break
         try:
             points.append(run_config(procs, threads, max(2, 16 // procs), 3))
         except Exception as e:                            # noqa: BLE001 -- recorded; the headline line must still come out
