@@ -24,6 +24,15 @@
 // of the product (git history: commit 4a86010 has the full kernel, ts_tcs_chain_fwd and its tests).
 #include "tcs_shared.hpp"
 
+#ifndef TS_SPLIT_SWITCH_OFF
+#define TS_SPLIT_SWITCH_OFF 0
+#endif
+#ifndef TS_SPLIT_RING
+#define TS_SPLIT_RING 2            // consumer weight fragments: k-steps in flight (see the consumer's `ring`; 1 = the round 4-5 loop, kept for A/B builds)
+#endif
+#ifndef TS_SPLIT_SWITCH_WM
+#define TS_SPLIT_SWITCH_WM 2         // which tiling the switch-off applies to: 2 = 192 x 256 (c_out <= 256), 1 = 96 x 512
+#endif
 #ifndef TS_SPLIT_STORE_AUX
 // cache policy of the result stores (raw buffer aux: 1 = sc0, 2 = nt, 16 = sc1).  sc1 = write-through at system scope: the rows do not wait dirty in the
 // XCD's L2 for the end-of-kernel write-back; same-box A/B of the C2 encoder, 4 interleaved runs each: 2.812 2.792 2.801 2.801 ms (plain) vs 2.788 2.783
@@ -167,17 +176,27 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
     auto dw_pass = [&](auto pc) {
       constexpr int p = decltype(pc)::value;
       if constexpr (p + WD < NPASS) {
+#if TS_SPLIT_SWITCH_OFF == 2
+        if (WM != TS_SPLIT_SWITCH_WM) {
+#endif
 #pragma unroll
         for (int u = 0; u < NKP; ++u) win_load((p + WD) * NKP + M - 1 + u);
 #pragma unroll
         for (int u = 0; u < NKP; ++u) tap_load((p + WD) * NKP + u);
+#if TS_SPLIT_SWITCH_OFF == 2
+        }
+#endif
       }
 #pragma unroll
       for (int kk = 0; kk < NKP; ++kk)
 #pragma unroll
-        for (int m = 0; m < M; ++m)      // the very first k-step starts from 0 (an inline constant: no register is zeroed)
+        for (int m = 0; m < M; ++m) {    // the very first k-step starts from 0 (an inline constant: no register is zeroed)
+#if TS_SPLIT_SWITCH_OFF >= 1             // diagnostic builds only (tools/variants.py): the producers' matrix work switched off -- WRONG results, a lower bound
+          if (WM == TS_SPLIT_SWITCH_WM && !(p == 0 && kk == 0 && m < M)) continue;       // of what ANY faster depthwise producer could buy those launches
+#endif
           d[m] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, T[p * NKP + kk]), P[p * NKP + kk + m],
                                                         (p == 0 && kk == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d[m], 0, 0, 0);
+        }
     };
     auto dw_store = [&](char* dst) {
       // ONE v_cvt_pk_bf16_f32 per pair (the plain cast lowers to two conversions and a v_perm_b32: 36 instead of 12 instructions in
@@ -365,10 +384,13 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
   const int lane_w = lane * 16;
   const int lane_y = (rsub * a.pitch_out + csub * 8) * 2;
 
-  s16x8 ring[NT16];                                  // B fragments of ONE k-step; a slot is refilled for the next k-step right after its last use
+  // B fragments: TS_SPLIT_RING sets of one k-step each; a slot is refilled right after its last use with the fragment of the k-step RING ahead
+  constexpr int RD = TS_SPLIT_RING;
+  s16x8 ring[RD][NT16];
   f32x4 acc[MT16][NT16];
   float bnext[NT16];
-  s16x8 af[MT16];
+  s16x8 af[TS_SPLIT_RING == 1 ? MT16 : 3];
+  static_assert(TS_SPLIT_RING == 1 || MT16 % 3 == 0, "three rotating A-fragment registers");
   auto read_a1 = [&](const char* src, int ks, int mt) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 32 * ROWB));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)src + abase[mt] + ks * 32 * ROWB + 4 * ROWB));
@@ -403,6 +425,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
       }
     };
     auto w_next = [&]() {
+#if TS_SPLIT_SWITCH_OFF == 5            // diagnostic build 5: the weight loads are issued but never advance (always the same, cache-hot fragments; WRONG results)
+      return;
+#endif
       ++w_k;
       if (w_k == nk_all) {
         w_k = 0;
@@ -415,7 +440,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
         for (int nt = 0; nt < NT16; ++nt) wn_soff[nt] += 1024;
       }
     };
-    auto load_w = [&](int nt) { ring[nt] = __builtin_bit_cast(s16x8, ld16(rwn, lane_w, wn_soff[nt])); };
+    auto load_w = [&](int set, int nt) { ring[set][nt] = __builtin_bit_cast(s16x8, ld16(rwn, lane_w, wn_soff[nt])); };
     auto bias_fetch = [&](const TilePos& p) {
 #pragma unroll
       for (int nt = 0; nt < NT16; ++nt) {
@@ -423,26 +448,55 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
         bnext[nt] = L.bias[col < a.c_out ? col : 0];
       }
     };
-    // one k-step: NT16 x MT16 products; `more_a`: the A fragments of the stage's second k-step replace the first one's as they retire
+    // one k-step: MT16 x NT16 products.
+#if TS_SPLIT_RING == 1
+    // `more_a`: the A fragments of the stage's second k-step replace the first one's as they retire
     auto kstep = [&](const char* src, bool more_a) {
 #pragma unroll
       for (int nt = 0; nt < NT16; ++nt) {
 #pragma unroll
         for (int mt = 0; mt < MT16; ++mt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], ring[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], ring[0][nt], acc[mt][nt], 0, 0, 0);
           if (more_a && nt == NT16 - 1) af[mt] = read_a1(src, 1, mt);
         }
-        load_w(nt);
+#if TS_SPLIT_SWITCH_OFF != 4            // diagnostic build 4: the consumers' weight stream switched off (stale fragments, WRONG results): what the stream costs
+        load_w(0, nt);
+#endif
       }
       w_next();
     };
+#else
+    // Frame-tile-major order: the four weight fragments of the k-step stay put while the A fragments stream through THREE registers (the one being
+    // multiplied, the next, and the one after that in flight from LDS) instead of six -- the 12 registers that frees, plus slack, hold a SECOND set of
+    // weight fragments, so that a fragment is requested two k-steps (a whole stage) before its first use instead of one: the round-6 switch-off
+    // runs priced the consumers' weight stream at 16 % of the encoder (10 % even with cache-hot fragments: latency, not bandwidth).
+    auto kstep = [&](const char* src, bool more_a) {
+      const int set = more_a ? 0 : 1;                      // a stage is two k-steps: the set follows the k-step's parity (static after inlining)
+#pragma unroll
+      for (int mt = 0; mt < MT16; ++mt) {
+        if (mt + 2 < MT16) af[(mt + 2) % 3] = read_a1(src, more_a ? 0 : 1, mt + 2);
+        else if (more_a) af[(mt + 2) % 3] = read_a1(src, 1, mt + 2 - MT16);
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt % 3], ring[set][nt], acc[mt][nt], 0, 0, 0);
+#if TS_SPLIT_SWITCH_OFF != 4
+          if (mt == MT16 - 1) load_w(set, nt);
+#endif
+        }
+      }
+      w_next();
+    };
+#endif
 
     TilePos pos;
     pos.init(tile0, tile_step, a.n_tt, a.n_z);
     w_seek(nk_main == 0);
 #pragma unroll
-    for (int nt = 0; nt < NT16; ++nt) load_w(nt);
-    w_next();
+    for (int set = 0; set < RD; ++set) {
+#pragma unroll
+      for (int nt = 0; nt < NT16; ++nt) load_w(set, nt);
+      w_next();
+    }
     bias_fetch(pos);
     stage_barrier();                                   // stage 0 is in dwt[gs & 1]
     for (int tile = tile0; tile < tile_end; tile += tile_step) {
@@ -456,7 +510,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
       for (int s = 0; s < n_stage; ++s, ++gs) {
         const char* const src = dwt + (gs & 1) * TILEB;
 #pragma unroll
-        for (int mt = 0; mt < MT16; ++mt) af[mt] = read_a1(src, 0, mt);
+        for (int mt = 0; mt < (TS_SPLIT_RING == 1 ? MT16 : 2); ++mt) af[mt] = read_a1(src, 0, mt);
         __builtin_amdgcn_sched_barrier(0);
         kstep(src, true);
         __builtin_amdgcn_sched_barrier(0);
