@@ -474,11 +474,17 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
       const int set = more_a ? 0 : 1;                      // a stage is two k-steps: the set follows the k-step's parity (static after inlining)
 #pragma unroll
       for (int mt = 0; mt < MT16; ++mt) {
+#if TS_SPLIT_SWITCH_OFF != 6            // diagnostic build 6: the consumers' A-fragment LDS reads inside the k-step switched off (stale fragments)
         if (mt + 2 < MT16) af[(mt + 2) % 3] = read_a1(src, more_a ? 0 : 1, mt + 2);
         else if (more_a) af[(mt + 2) % 3] = read_a1(src, 1, mt + 2 - MT16);
+#endif
 #pragma unroll
         for (int nt = 0; nt < NT16; ++nt) {
+#if TS_SPLIT_SWITCH_OFF == 7            // diagnostic build 7: the consumers' matrix instructions switched off (operands still fetched and kept alive)
+          asm volatile("" :: "v"(af[mt % 3]), "v"(ring[set][nt]));
+#else
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt % 3], ring[set][nt], acc[mt][nt], 0, 0, 0);
+#endif
 #if TS_SPLIT_SWITCH_OFF != 4
           if (mt == MT16 - 1) load_w(set, nt);
 #endif
@@ -593,7 +599,11 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
               for (int i = 0; i < RB; ++i) {
                 if (partial) v[i] &= keep;
                 if (row0 + 4 * (RB * bt + i) + rsub < a.c_out)
+#if TS_SPLIT_SWITCH_OFF == 8            // diagnostic build 8: the result stores switched off
+                  asm volatile("" :: "v"(v[i]));
+#else
                   __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, TS_SPLIT_STORE_AUX);
+#endif
               }
             }
           }
