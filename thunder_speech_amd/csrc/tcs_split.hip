@@ -36,7 +36,8 @@
 #ifndef TS_SPLIT_STORE_AUX
 // cache policy of the result stores (raw buffer aux: 1 = sc0, 2 = nt, 16 = sc1).  sc1 = write-through at system scope: the rows do not wait dirty in the
 // XCD's L2 for the end-of-kernel write-back; same-box A/B of the C2 encoder, 4 interleaved runs each: 2.812 2.792 2.801 2.801 ms (plain) vs 2.788 2.783
-// 2.791 2.789 (sc1); nt (streaming) costs +3 % -- it also evicts what the next launch would hit (profiles/round6_c4_pointwise.md section 3)
+// 2.791 2.789 (sc1); nt (streaming) costs +3 % -- it also evicts what the next launch would hit (profiles/round6_c4_pointwise.md section 3).
+// Layers of up to 512 output channels only: on Citrinet-1024 (C3) plain stores measured 0.6 % faster (8.64 vs 8.69 ms, twice).
 #define TS_SPLIT_STORE_AUX 16
 #endif
 
@@ -602,7 +603,10 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
 #if TS_SPLIT_SWITCH_OFF == 8            // diagnostic build 8: the result stores switched off
                   asm volatile("" :: "v"(v[i]));
 #else
-                  __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, TS_SPLIT_STORE_AUX);
+                  if (TS_SPLIT_STORE_AUX != 0 && a.c_out <= 512)      // (wave-uniform) -- see TS_SPLIT_STORE_AUX
+                    __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, TS_SPLIT_STORE_AUX);
+                  else
+                    __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, 0);
 #endif
               }
             }
