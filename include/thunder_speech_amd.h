@@ -36,6 +36,10 @@ const char* ts_build_target(void);
 int ts_time_pitch(int T);
 /* frames per tile of the masked pointwise-only launch for this shape (see ts_tcs_desc.stats) */
 int ts_tcs_pointwise_tile_frames(int32_t batch, int32_t c_out, int32_t t_out);
+/* Tile shape of the tail-zero pointwise-only launches with more than 256 output channels (Citrinet's residual 1x1 convs, QuartzNet's last block):
+ * 0 = 96 frames x 512 channels per workgroup, consumer waves of 96 x 64; 1 = 192 x 256 per workgroup, consumer waves of 192 frames x 32
+ * channels (half the weight-fragment loads per matrix instruction).  Same results bit for bit.  Process-wide; returns the previous mode. */
+int ts_tcs_pointwise_wide(int32_t on);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused time-channel-separable sub-block (inference):

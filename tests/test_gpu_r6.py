@@ -223,3 +223,37 @@ def test_front_end_register_prefetch_equals_the_direct_staging_bit_for_bit(train
     assert torch.equal(outs[0][2], outs[1][2]), "log-mel differs between the prefetching and the direct staging path"
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1].dtype == torch.int64 and outs[0][1].tolist() == [n // 160 + 1, (n - 1234) // 160 + 1, (n // 2) // 160 + 1]
+
+
+@pytest.mark.parametrize("b,ci,co,t", [(4, 512, 1024, 751), (3, 512, 640, 333)])
+def test_wide_frame_pointwise_tile_equals_the_default_tile_bit_for_bit(b, ci, co, t):
+    """ts_tcs_pointwise_wide(1): consumer waves of 192 frames x 32 channels for the tail-zero pointwise-only launches (measured: no faster,
+    profiles/round6_tcs_256.txt, so the default stays 0) -- same accumulation order, so the same bits."""
+    from thunder_speech_amd import _lib, plan, tensors as TS
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(b * 1000 + co)
+    w = torch.randn(co, ci, 1, generator=g) / ci ** 0.5
+    bn = [torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, torch.rand(co, generator=g) + 0.5]
+    layer = plan.make_tcs_layer("cuda", dw_w=None, pw_w=w, bn=bn, kernel=1, stride=1, dilation=1, padding=0, relu=True)
+    lens = torch.randint(t // 2, t + 1, (b,), generator=g).to(torch.int32).cuda()
+    lens[0] = t
+    xb = TS.arena(("wide_x", 0), b, ci, t, "cuda")
+    xb.zero_()
+    xb[:, :, :t] = torch.randn(b, ci, t, generator=g).to(torch.bfloat16).cuda()
+    for i in range(b):
+        xb[i, :, int(lens[i]):] = 0
+    outs = []
+    try:
+        for wide in (0, 1):
+            assert L.ts_tcs_pointwise_wide(wide) in (0, 1)
+            out = TS.arena(("wide_o", wide), b, co, t, "cuda")
+            out.fill_(7.0)
+            layer.run(xb, t, lens, out=out, in_tail_zero=True, zero_tail=True)
+            torch.cuda.synchronize()
+            outs.append(out[:, :, :t].clone())
+    finally:
+        assert L.ts_tcs_pointwise_wide(0) == 1
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0].float().abs().sum()) > 0
+    for i in range(b):
+        assert float(outs[1][i, :, int(lens[i]):].float().abs().sum()) == 0

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "ts_decoder_bwd", "ts_adamw_step", "ts_adamw_multi_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_dwconv_bwd_select", "ts_train_set_deterministic", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_workspace", "ts_train_pwconv_wgrad_mfma", "ts_train_pwconv_wgrad_multi", "ts_train_pwconv_wgrad_multi_parts", "ts_train_wgrad_reduce_multi",
     "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
-    "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_fwd_bn_tiles", "ts_tcs_pointwise_tile_frames", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_bn2_add_relu_chan_fwd", "ts_train_bn2_chan_bwd",
+    "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_fwd_bn_tiles", "ts_tcs_pointwise_tile_frames", "ts_tcs_pointwise_wide", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_bn2_add_relu_chan_fwd", "ts_train_bn2_chan_bwd",
     "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd",
     "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_groupconv_fwd", "ts_w2v_glu_fwd", "ts_w2v_attention_workspace_bytes",
     "ts_w2v_attention_fwd",
@@ -165,6 +165,8 @@ def lib() -> C.CDLL:
     L.ts_train_dwconv_fwd_bn_tiles.restype = C.c_int
     L.ts_tcs_pointwise_tile_frames.argtypes = [i32, i32, i32]
     L.ts_tcs_pointwise_tile_frames.restype = C.c_int
+    L.ts_tcs_pointwise_wide.argtypes = [i32]
+    L.ts_tcs_pointwise_wide.restype = C.c_int
     L.ts_train_dwconv_bwd_bn.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.ts_train_bn_bwd_sums.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.ts_train_bn2_add_relu_fwd.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, f32, vp] * 2 + [vp, i32, i32, i32, i32, i32, vp]

@@ -660,6 +660,8 @@ extern "C" int ts_tcs_pointwise_tile_frames(int32_t batch, int32_t c_out, int32_
   return (long long)batch * n_tt * ((round_up(c_out, 32) + 255) / 256) < cu_count() ? 64 : 128;
 }
 
+static int g_pw_wide = 0;          // ts_tcs_pointwise_wide: 1 = wide-frame consumers for tail-zero pointwise-only layers with c_out > 256 (measured: no gain, profiles/round6_tcs_256.txt), 0 (default) = the 96 x 512 tiles
+
 // one layer through the split kernel (csrc/tcs_split.hip)
 static int split_single(const ts::TcsArgs& w, int npass, int xe, int wm, int dil, hipStream_t stream) {
   using namespace ts;
@@ -680,6 +682,12 @@ static int split_single(const ts::TcsArgs& w, int npass, int xe, int wm, int dil
   a.kernel = w.kernel; a.padding = w.padding; a.dilation = w.dilation;
   a.woff = w.woff; a.padl8 = w.padl8; a.zero_tail = w.zero_tail;
   return launch_split_layer(a, npass, xe, wm, dil, stream);
+}
+
+extern "C" int ts_tcs_pointwise_wide(int32_t on) {
+  const int old = g_pw_wide;
+  g_pw_wide = on ? 1 : 0;
+  return old;
 }
 
 extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const int32_t* len_in, const void* x_res,
@@ -814,10 +822,18 @@ extern "C" int ts_tcs_subblock_fwd(const ts_tcs_desc* d, const void* x, const in
       // pointwise only: the split kernel with identity stages only (the layer's input plays the residual input's role)
       TcsArgs w = a;
       const int WM = round_up(d->c_out, 32) <= 256 ? 2 : 1;
-      const int TTp = 96 * WM;
-      const int n_ttp = (d->t_out + TTp - 1) / TTp;
       w.c_res = d->c_in; w.c_in = 0; w.xres = a.x; w.res_w = a.pw_w; w.res_w16 = a.pw_w16; w.kt_res = a.kt_main; w.pitch_res = d->pitch_in;
       w.len_res = a.len_in; w.woff = 0; w.padl8 = 0;
+      if (g_pw_wide && WM == 1) {
+        // wide-frame consumers for the layers of more than 256 output channels (see launch_split_layer, wm code 4)
+        const int n_ttw = (d->t_out + 191) / 192;
+        if (d->pitch_in >= n_ttw * 192 && d->pitch_out >= n_ttw * 192) {
+          const int st = split_single(w, 2, 128, 4, 1, stream);
+          if (st != TS_EUNSUPPORTED) return st;
+        }
+      }
+      const int TTp = 96 * WM;
+      const int n_ttp = (d->t_out + TTp - 1) / TTp;
       if (d->pitch_in >= (n_ttp - 1) * TTp + round_up(TTp, 64) && d->pitch_out >= n_ttp * TTp) {
         const int st = WM == 2 ? split_single(w, 2, 256, 2, 1, stream) : split_single(w, 2, 128, 1, 1, stream);
         if (st != TS_EUNSUPPORTED) return st;

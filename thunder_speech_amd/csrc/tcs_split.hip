@@ -75,7 +75,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
   constexpr int NTD = (16 * CST + 1023) / 1024;   // KiB (= DMA instructions) per 16-channel group and stage
   constexpr int TAPB = NTD * 1024;
   constexpr int XSB = 16 * (64 * XJ + 4) * 2;     // bytes of a producer's staged rows
-  constexpr int ER = (WM == 2 || DIL == 2) ? 16 : 32;   // output-channel rows of a consumer's epilogue tile
+  constexpr int ER = (WM == 2 || DIL == 2 || MT > 3) ? 16 : 32;   // output-channel rows of a consumer's epilogue tile
   constexpr int PHW = 32 * XJ;                    // DIL == 2: frames of a staged half row
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
     u32x4 X[ROWS2 ? 2 : 1][XP];
     // identity rows in flight: one stage ahead; TWO (a second register set, alternating statically) when the residual has an even number of
     // stages -- an identity stage is as short as the consumers' k-loop, shorter than a loaded HBM round trip.
-    constexpr bool ID2 = WM == 1;
+    constexpr bool ID2 = WM == 1 && MT <= 3;       // (the 192-frame identity rows are 6 registers per set: one set)
     u32x4 I[IDP], I2[ID2 ? IDP : 1];
     s16x4 P[NP];
     u32x2 T[NK];
@@ -381,7 +381,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
   int abase[MT16];
 #pragma unroll
   for (int mt = 0; mt < MT16; ++mt) abase[mt] = taddr(8 * kg + q4, wm * FW + 16 * mt + 4 * p4);
-  const int rsub = lane >> 4, csub = lane & 15;
+  constexpr int SEG = FW / 8 <= 16 ? 16 : 32;         // 16-byte segments of an epilogue row (FW frames), padded to a power of two
+  constexpr int RPI = 64 / SEG;                       // rows per wave instruction in the epilogue
+  const int rsub = lane / SEG, csub = lane % SEG;
   const int lane_w = lane * 16;
   const int lane_y = (rsub * a.pitch_out + csub * 8) * 2;
 
@@ -557,8 +559,8 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
           }
           // the rows leave in batches of four per lane (eight at once are 32 registers on top of the accumulators and the next tile's first weight
           // fragments: the squeeze-excite instantiation spilled 21 registers with them, 12 now)
-          constexpr int RB = 4, NB = ER / 4 / RB;
-          static_assert(NB * RB * 4 == ER, "row batches");
+          constexpr int RB = 4, NB = ER / RPI / RB;
+          static_assert(NB * RB * RPI == ER, "row batches");
           if (csub < FW / 8) {
             const int row0 = cob + half * ER;
             const int y_soff = ((b * a.c_out + row0) * a.pitch_out + tw) * 2;
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
               u32x4 v[RB];
 #pragma unroll
               for (int i = 0; i < RB; ++i) {
-                const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + 4 * (RB * bt + i) * EP);
+                const u32x2* const pr = reinterpret_cast<const u32x2*>(prow + RPI * (RB * bt + i) * EP);
                 v[i] = u32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
               }
               if constexpr (SE) {
@@ -579,9 +581,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
                 float gt[RB];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                  const int row = row0 + 4 * (RB * bt + i) + rsub;
+                  const int row = row0 + RPI * (RB * bt + i) + rsub;
                   const bool in = row < a.c_out;
-                  yv[i] = in ? __builtin_amdgcn_raw_buffer_load_b128(rse, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, 0) : u32x4{0u, 0u, 0u, 0u};
+                  yv[i] = in ? __builtin_amdgcn_raw_buffer_load_b128(rse, lane_y, y_soff + RPI * (RB * bt + i) * a.pitch_out * 2, 0) : u32x4{0u, 0u, 0u, 0u};
                   gt[i] = in ? L.se_gate[(size_t)b * a.c_out + row] : 0.f;
                 }
 #pragma unroll
@@ -599,14 +601,14 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
 #pragma unroll
               for (int i = 0; i < RB; ++i) {
                 if (partial) v[i] &= keep;
-                if (row0 + 4 * (RB * bt + i) + rsub < a.c_out)
+                if (row0 + RPI * (RB * bt + i) + rsub < a.c_out)
 #if TS_SPLIT_SWITCH_OFF == 8            // diagnostic build 8: the result stores switched off
                   asm volatile("" :: "v"(v[i]));
 #else
                   if (TS_SPLIT_STORE_AUX != 0 && a.c_out <= 512)      // (wave-uniform) -- see TS_SPLIT_STORE_AUX
-                    __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, TS_SPLIT_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + RPI * (RB * bt + i) * a.pitch_out * 2, TS_SPLIT_STORE_AUX);
                   else
-                    __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + 4 * (RB * bt + i) * a.pitch_out * 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, lane_y, y_soff + RPI * (RB * bt + i) * a.pitch_out * 2, 0);
 #endif
               }
             }
@@ -625,7 +627,7 @@ static int launch_split(SplitArgs& a, hipStream_t stream) {
   a.n_tt = (a.t_out + TT - 1) / TT;
   a.n_z = (round_up(a.c_out, 32) + CO_WG - 1) / CO_WG;
   a.n_tiles = a.batch * a.n_tt * a.n_z;
-  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2) ? 16 : 32) * (FW * 2 + 24) +
+  const size_t lds = (size_t)2 * KC * ROWB + (size_t)8 * ((WM == 2 || DIL == 2 || MT > 3) ? 16 : 32) * (FW * 2 + 24) +
                      (size_t)4 * (16 * (64 * XJ + 4) * 2 + 2 * TAPB);
   if (lds > 160 * 1024) return TS_EUNSUPPORTED;
   auto kern = tcs_split_kernel<NPASS, XJ, MT, WM, DIL, NT, SE>;
@@ -646,6 +648,14 @@ static int launch_split(SplitArgs& a, hipStream_t stream) {
 }
 
 int launch_split_layer(SplitArgs& a, int npass, int xe, int wm, int dil, hipStream_t stream) {
+  if (wm == 4) {
+    // wide-frame consumers (round 6): every consumer wave owns 192 frames x 32 channels (workgroup tile 192 x 256) instead of 96 x 64 -- half the
+    // weight-fragment loads per matrix instruction (profiles/round6_tcs_256.txt prices that stream at 15 % of the encoder); pointwise-only layers only
+    // (with a depthwise stage the 192-frame producer rows and tap images do not fit the LDS beside the 64 KB tile pair)
+    if (dil != 1 || npass != 2 || a.layer.c_in != 0) return TS_EUNSUPPORTED;
+    if (a.layer.se_y) return a.layer.se_gate ? launch_split<2, 2, 6, 1, 1, 1, true>(a, stream) : TS_EUNSUPPORTED;
+    return launch_split<2, 2, 6, 1, 1, 1>(a, stream);
+  }
   if (a.layer.se_y) {
     // squeeze-excite tail: the pointwise-only launches of the Citrinet blocks (512 / 256 output channels per workgroup)
     if (!a.layer.se_gate || dil != 1 || npass != 2) return TS_EUNSUPPORTED;

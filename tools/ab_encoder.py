@@ -6,6 +6,9 @@ CODE = r'''
 import sys, os, torch
 sys.path.insert(0, %r)
 import bench
+if os.environ.get("TS_AB_PW_WIDE"):
+    from thunder_speech_amd import _lib
+    _lib.lib().ts_tcs_pointwise_wide(int(os.environ["TS_AB_PW_WIDE"]))
 def time_graph(fn, steps):
     side = torch.cuda.Stream(); g = torch.cuda.CUDAGraph()
     side.wait_stream(torch.cuda.current_stream())
@@ -34,6 +37,8 @@ def main(names):
     for rep in range(2):
         for n in names:
             env = dict(os.environ, TS_LIB_VARIANT=n)
+            if n.startswith("pw_wide="):   # product library with the pointwise tile switch set (ts_tcs_pointwise_wide)
+                env = dict(os.environ, TS_LIB_VARIANT="", TS_AB_PW_WIDE=n.split("=")[1])
             out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, cwd=ROOT)
             line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
             res[n].append(float(line[0].split()[1]) if line else float("nan"))
