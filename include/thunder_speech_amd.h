@@ -552,7 +552,8 @@ int ts_gemm_nt_bf16_packed(const void* x, int64_t lda, const void* w, int64_t ld
 int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, const float* bias, const float* res, int64_t ld_res, float* y,
                       int64_t ldc, void* y_bf16, int64_t rows, int32_t n, int32_t k, int32_t act, int32_t precision, const void* w_frag, void* stream);
 /* y = act(LayerNorm(x + xbias + res) * w + b) over the last dimension; x, res (may be NULL), y f32 [rows][c]; xbias f32 [c] or
- * NULL: the bias of the linear layer that produced x, applied here instead of in a pass of its own; act 0 = none, 1 = GELU. */
+ * NULL: the bias of the linear layer that produced x, applied here instead of in a pass of its own; act 0 = none, 1 = GELU.  y may be NULL when
+ * y_bf16 is given (the pre-LayerNorm encoders only ever read the bf16 copy: a third of the launch's bytes less). */
 int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* xbias, const float* w, const float* b, float eps, int64_t rows,
                          int32_t c, int32_t act, float* y, void* y_bf16, void* stream);
 /* hidden_states[~attention_mask] = 0: rows >= len[b] of x [B][t][c] become 0. */

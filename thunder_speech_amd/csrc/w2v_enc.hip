@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void w2v_layernorm_kernel(const float* __restr
       float4 o4 = float4{(v[it].x - mu) * rs * w4.x + b4.x, (v[it].y - mu) * rs * w4.y + b4.y, (v[it].z - mu) * rs * w4.z + b4.z,
                          (v[it].w - mu) * rs * w4.w + b4.w};
       if (act) o4 = float4{gelu_erf(o4.x), gelu_erf(o4.y), gelu_erf(o4.z), gelu_erf(o4.w)};
-      *reinterpret_cast<float4*>(y + row * c + i) = o4;
+      if (y) *reinterpret_cast<float4*>(y + row * c + i) = o4;
       if (y16) *reinterpret_cast<uint2*>(y16 + row * c + i) = uint2{pack_bf16(o4.x, o4.y), pack_bf16(o4.z, o4.w)};
     }
   }
@@ -655,7 +655,7 @@ extern "C" int ts_w2v_linear_fwd(const void* x, int64_t lda, const void* w, cons
 
 extern "C" int ts_w2v_layernorm_fwd(const float* x, const float* res, const float* xbias, const float* w, const float* b, float eps,
                                     int64_t rows, int32_t c, int32_t act, float* y, void* y_bf16, void* stream_) {
-  if (!x || !w || !b || !y || rows <= 0 || c <= 0) return TS_EINVAL;
+  if (!x || !w || !b || (!y && !y_bf16) || rows <= 0 || c <= 0) return TS_EINVAL;
   if (c % 4 || c > 4096) return TS_EUNSUPPORTED;
   TS_STREAM;
   const dim3 grid((unsigned)((rows + 3) / 4));

@@ -194,11 +194,12 @@ class Wav2Vec2Plan:
         _lib.check(st, "ts_w2v_linear_fwd")
         return y, (y_op if self.prec else y)
 
-    def _ln(self, L, stream, x, wb, res=None, xbias=None, want_op=True, act=0, eps=None):
-        y = torch.empty_like(x)
+    def _ln(self, L, stream, x, wb, res=None, xbias=None, want_op=True, act=0, eps=None, want_f32=True):
+        """want_f32=False (bf16 mode only): the f32 result has no reader -- only the GEMM-operand copy is written."""
         y_op = self._op(*x.shape) if want_op else None
+        y = torch.empty_like(x) if (want_f32 or y_op is None) else None
         st = L.ts_w2v_layernorm_fwd(x.data_ptr(), self._ptr(res), self._ptr(xbias), wb[0].data_ptr(), wb[1].data_ptr(),
-                                    self.eps if eps is None else eps, x.shape[0] * x.shape[1], x.shape[2], act, y.data_ptr(),
+                                    self.eps if eps is None else eps, x.shape[0] * x.shape[1], x.shape[2], act, self._ptr(y),
                                     self._ptr(y_op), stream)
         _lib.check(st, "ts_w2v_layernorm_fwd")
         return y, (y_op if self.prec else y)
@@ -223,7 +224,7 @@ class Wav2Vec2Plan:
             h = self._buf(b, t, c0)
             _lib.check(L.ts_w2v_conv0_fwd(audio.data_ptr(), b, n, self.w0.data_ptr(), None, self._ptr(self.conv_b[0]), c0, k0, s0, 1e-5,
                                           h.data_ptr(), None, ws.data_ptr(), stream), "ts_w2v_conv0_fwd")
-            h, x_op = self._ln(L, stream, h, self.conv_ln[0], act=1, eps=1e-5, want_op=n_conv > 1 or want_op)
+            h, x_op = self._ln(L, stream, h, self.conv_ln[0], act=1, eps=1e-5, want_op=n_conv > 1 or want_op, want_f32=n_conv == 1)
             for i, w in enumerate(self.conv_w, start=1):
                 k, s = self.kernels[i], self.strides[i]
                 t_out = (t - k) // s + 1
@@ -232,7 +233,7 @@ class Wav2Vec2Plan:
                 y = self._buf(b, t_out, self.dims[i])
                 _lib.check(L.ts_w2v_conv_fwd(x_op.data_ptr(), b, t, self.dims[i - 1], w.data_ptr(), self._ptr(self.conv_b[i]), self.dims[i],
                                              k, s, 0, self.prec, y.data_ptr(), None, self._ptr(self._frag(w)), stream), "ts_w2v_conv_fwd")
-                h, x_op = self._ln(L, stream, y, self.conv_ln[i], act=1, eps=1e-5, want_op=i < n_conv - 1 or want_op)
+                h, x_op = self._ln(L, stream, y, self.conv_ln[i], act=1, eps=1e-5, want_op=i < n_conv - 1 or want_op, want_f32=i == n_conv - 1)
                 t = t_out
             return h, x_op
         last = n_conv == 1
@@ -266,7 +267,7 @@ class Wav2Vec2Plan:
         b, t, _ = feats.shape
         c = self.hidden
         if self.fp_has_ln:
-            _, ln_op = self._ln(L, stream, feats, self.fp_ln)
+            _, ln_op = self._ln(L, stream, feats, self.fp_ln, want_f32=False)
         h, _ = self._linear(L, stream, ln_op, self.fp_w, self.fp_b)
         key_len = None
         if lengths is not None:
@@ -301,9 +302,9 @@ class Wav2Vec2Plan:
             assert pos_res is None
             h = hp
             for lw in self.layers:
-                _, x_op = self._ln(L, stream, h, lw["ln1"])
+                _, x_op = self._ln(L, stream, h, lw["ln1"], want_f32=False)
                 self._linear(L, stream, attention(x_op), lw["wo"], lw["bo"], into=h)        # h += attn W^T (+ bias in the epilogue)
-                _, x_op = self._ln(L, stream, h, lw["ln2"])
+                _, x_op = self._ln(L, stream, h, lw["ln2"], want_f32=False)
                 _, f1_op = self._linear(L, stream, x_op, lw["w1"], lw["b1"], act=1, want_op=True)
                 self._linear(L, stream, f1_op, lw["w2"], lw["b2"], into=h)
             h, _ = self._ln(L, stream, h, self.enc_ln, want_op=False)
