@@ -27,6 +27,9 @@
 #ifndef TS_SPLIT_SWITCH_OFF
 #define TS_SPLIT_SWITCH_OFF 0
 #endif
+#ifndef TS_SPLIT_DIRECT_STORE
+#define TS_SPLIT_DIRECT_STORE 0    // 1: result stores straight from the accumulators (8 bytes per lane), no LDS transpose (experiment)
+#endif
 #ifndef TS_SPLIT_RING
 #define TS_SPLIT_RING 2            // consumer weight fragments: k-steps in flight (see the consumer's `ring`; 1 = the round 4-5 loop, kept for A/B builds)
 #endif
@@ -537,6 +540,32 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
       if (partial) keep = keep_first(keep, len_out - (tw + csub * 8));
       asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
       const s16x2 f2 = __builtin_bit_cast(s16x2, floor2);
+#if TS_SPLIT_DIRECT_STORE
+      // experiment: the accumulators leave as they are -- lane (channel n = lane & 15, frame group kg) stores its 4 frames (8 bytes) of every 16-frame
+      // tile; a store instruction covers 16 rows x 32 bytes, the six frame tiles of a row follow each other
+      if constexpr (!SE) {
+        const int lane_d = ((lane & 15) * a.pitch_out + 4 * kg) * 2;
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt) {
+          const int ch0 = (c16_0 + nt) * 16;
+          const bool chan_ok = ch0 + (lane & 15) < a.c_out;
+          const int soff = ((b * a.c_out + ch0) * a.pitch_out + tw) * 2;
+#pragma unroll
+          for (int mt = 0; mt < MT16; ++mt) {
+            unsigned lo = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+                pack_bf16_settled(acc[mt][nt][0], acc[mt][nt][1])), f2));
+            unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2,
+                pack_bf16_settled(acc[mt][nt][2], acc[mt][nt][3])), f2));
+            if (partial) {
+              const int n = len_out - (tw + 16 * mt + 4 * kg);
+              lo &= n >= 2 ? ~0u : (n == 1 ? 0xffffu : 0u);
+              hi &= n >= 4 ? ~0u : (n == 3 ? 0xffffu : 0u);
+            }
+            if (chan_ok) __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo, hi}, ry, lane_d, soff + 32 * mt, 0);
+          }
+        }
+      } else
+#endif
       // 32 output channels (two accumulator columns) at a time through the wave-private LDS tile: lane (channel n = lane & 15, frame group
       // kg) writes its 4 frames (8 bytes) of every 16-frame tile into row n (+ 16 for the second column), the rows leave as 16-byte segments
 #pragma unroll
@@ -563,7 +592,11 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
           static_assert(NB * RB * RPI == ER, "row batches");
           if (csub < FW / 8) {
             const int row0 = cob + half * ER;
+#if TS_SPLIT_SWITCH_OFF == 10           // diagnostic build 10: every result store of a workgroup lands in the same 16 KB (WRONG results): stores issued and acknowledged, no write traffic
+            const int y_soff = ((((b * a.c_out + row0) * a.pitch_out + tw) * 2) & 0x3ff0) + (int)blockIdx.x * 32768;
+#else
             const int y_soff = ((b * a.c_out + row0) * a.pitch_out + tw) * 2;
+#endif
             const char* const prow = priv + (size_t)rsub * EP + csub * 16;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
@@ -615,6 +648,9 @@ __global__ __launch_bounds__(768) void tcs_split_kernel(const SplitArgs a) {
           }
         }
       }
+#if TS_SPLIT_SWITCH_OFF == 9            // diagnostic build 9: the consumers wait for their result stores' acknowledgements before the next tile (results unchanged)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
   }
 }
