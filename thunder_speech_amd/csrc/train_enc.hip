@@ -618,24 +618,30 @@ __global__ __launch_bounds__(256) void dw_fwd_mfma_kernel(const bf16_t* __restri
   const int ob_lo = seg * per, ob_hi = ob_lo + per < n_blk ? ob_lo + per : n_blk;
   if (ob_lo >= ob_hi) return;
   const int pup = round_up(p, 16), sh = pup - p, R = (k + 30 + sh) / 16 + 1;          // R <= 2 NB (launcher)
-  // ---- taps -> LDS (zero guards) -> the R Toeplitz fragments of this lane
-  float* const tz = tapz[wave];
-  for (int i = lane; i < DWM_TAPN; i += 64) { const int j = i - DWM_TAPG; tz[i] = (j >= 0 && j < k) ? w[(size_t)c * k + j] : 0.f; }
-  __builtin_amdgcn_wave_barrier();
   const int m = lane & 31, h = lane >> 5;
-  s16x8 A[2 * NB];
-#pragma unroll
-  for (int r = 0; r < 2 * NB; ++r) {
-    const float* const tp = tz + DWM_TAPG + 16 * r + 8 * h - m - sh;                // >= -46, <= 16 (2 NB - 1) + 15
-    const u32x4 v = u32x4{pack_bf16(tp[0], tp[1]), pack_bf16(tp[2], tp[3]), pack_bf16(tp[4], tp[5]), pack_bf16(tp[6], tp[7])};
-    A[r] = r < R ? __builtin_bit_cast(s16x8, v) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  }
   // ---- this lane's clip
   const int b = cg * 32 + m;
   const bool clip_on = b < batch;
   const int li = clip_on ? clamp_len(len_in, b, t) : 0, lo = clip_on ? (len_out ? clamp_len(len_out, b, t) : t) : 0;
   const bf16_t* const xr = x + ((size_t)(clip_on ? b : 0) * ch + c) * pitch;
   bf16_t* const yr = y + ((size_t)(clip_on ? b : 0) * ch + c) * pitch;
+  // chunk pair q = chunks 2q (frames -pup + 32 q + 8 h ..) and 2q + 1 (+16): raw 16-byte loads, zero outside [0, li)
+  auto fetch = [&](int q, u32x4& e, u32x4& o) {
+    const int f0 = -pup + 32 * q + 8 * h, f1 = f0 + 16;
+    e = (f0 >= 0 && f0 < li) ? *reinterpret_cast<const u32x4*>(xr + f0) : u32x4{0u, 0u, 0u, 0u};
+    o = (f1 >= 0 && f1 < li) ? *reinterpret_cast<const u32x4*>(xr + f1) : u32x4{0u, 0u, 0u, 0u};
+  };
+  // the first chunk pairs are requested BEFORE the prologue below (tap fragments through LDS, the BatchNorm totals of 256 tiles): three dependent
+  // round trips to memory in a 13-us launch become one
+  const int q_lo = ob_lo, q_hi = ob_hi + NB - 1;           // block ob is complete after chunk pair ob + NB - 1
+  u32x4 ring_e[DWM_AHEAD], ring_o[DWM_AHEAD];
+#pragma unroll
+  for (int a = 0; a < DWM_AHEAD; ++a) fetch(q_lo + a, ring_e[a], ring_o[a]);
+  // the taps travel through registers so that their loads, too, are in flight before anything waits
+  constexpr int NTV = (DWM_TAPN + 63) / 64;
+  float tv[NTV];
+#pragma unroll
+  for (int i = 0; i < NTV; ++i) { const int j = lane + 64 * i - DWM_TAPG; tv[i] = (j >= 0 && j < k) ? w[(size_t)c * k + j] : 0.f; }
   // BatchNorm of the previous repeat on the fly (one channel: the pair helper on (c, c) would read c + 1 -> do it by hand)
   float sc = 1.f, hs = 0.f;
   bool aff_on = false, aff_relu = false;
@@ -657,12 +663,19 @@ __global__ __launch_bounds__(256) void dw_fwd_mfma_kernel(const bf16_t* __restri
       }
     }
   }
-  // chunk pair q = chunks 2q (frames -pup + 32 q + 8 h ..) and 2q + 1 (+16): raw 16-byte loads, zero outside [0, li)
-  auto fetch = [&](int q, u32x4& e, u32x4& o) {
-    const int f0 = -pup + 32 * q + 8 * h, f1 = f0 + 16;
-    e = (f0 >= 0 && f0 < li) ? *reinterpret_cast<const u32x4*>(xr + f0) : u32x4{0u, 0u, 0u, 0u};
-    o = (f1 >= 0 && f1 < li) ? *reinterpret_cast<const u32x4*>(xr + f1) : u32x4{0u, 0u, 0u, 0u};
-  };
+  // ---- taps -> LDS (zero guards) -> the R Toeplitz fragments of this lane
+  float* const tz = tapz[wave];
+#pragma unroll
+  for (int i = 0; i < NTV; ++i)
+    if (lane + 64 * i < DWM_TAPN) tz[lane + 64 * i] = tv[i];
+  __builtin_amdgcn_wave_barrier();
+  s16x8 A[2 * NB];
+#pragma unroll
+  for (int r = 0; r < 2 * NB; ++r) {
+    const float* const tp = tz + DWM_TAPG + 16 * r + 8 * h - m - sh;                // >= -46, <= 16 (2 NB - 1) + 15
+    const u32x4 v = u32x4{pack_bf16(tp[0], tp[1]), pack_bf16(tp[2], tp[3]), pack_bf16(tp[4], tp[5]), pack_bf16(tp[6], tp[7])};
+    A[r] = r < R ? __builtin_bit_cast(s16x8, v) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
   auto prep = [&](u32x4 v, int f0) {                      // input transform + length mask of one fragment
     if (f0 < 0 || f0 >= li) return s16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (aff_on) {
@@ -681,10 +694,6 @@ __global__ __launch_bounds__(256) void dw_fwd_mfma_kernel(const bf16_t* __restri
   for (int d = 0; d < NB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
-  const int q_lo = ob_lo, q_hi = ob_hi + NB - 1;           // block ob is complete after chunk pair ob + NB - 1
-  u32x4 ring_e[DWM_AHEAD], ring_o[DWM_AHEAD];
-#pragma unroll
-  for (int a = 0; a < DWM_AHEAD; ++a) fetch(q_lo + a, ring_e[a], ring_o[a]);
   for (int q0 = q_lo; q0 < q_hi; q0 += DWM_AHEAD) {
 #pragma unroll
     for (int a = 0; a < DWM_AHEAD; ++a) {
@@ -918,6 +927,31 @@ __global__ __launch_bounds__(256, TT <= 128 ? 2 : 1) void dw_bwd_mfma_kernel(con
   const int c = blockIdx.x * 16 + row;
   const int K = a.k, p = a.p, H = round_up(p, 8), p4 = round_up(p, 4), woff = H - p4, dl = p4 - p;
   const bool need_dw = a.dw != nullptr;
+  // the first unit's rows are requested BEFORE the tap image is built (tap loads -> LDS -> fragments: two dependent round trips otherwise, in a launch of
+  // 16-28 us); unit n + 1 is requested before the matrix work of unit n as before
+  const int unit0 = (blockIdx.y * 4 + wave) * a.upw, n_units = a.batch * a.n_tiles;
+  const int unit1 = unit0 + a.upw < n_units ? unit0 + a.upw : n_units;
+  // staging: 16-byte chunks, lane (row, q) takes chunks q, q + 4, ... of its row; the loads of unit n + 1 are issued (into registers) before the
+  // matrix work of unit n starts, the LDS writes follow when unit n is done
+  const int wxn = H - p4 + TT + 16 * G + 4 > TT + 2 * H ? H - p4 + TT + 16 * G + 4 : TT + 2 * H;
+  // (the data gradient's windows reach woff + TT + 4 NK frames into the dy rows whatever K is: a template NK larger than this K's k-steps meets
+  // zero taps there, and what they multiply must be staged zeros, not stale LDS)
+  const int wyn = woff + TT + 4 * NK > TT + 2 * H ? woff + TT + 4 * NK : TT + 2 * H;
+  const int ncy = (wyn + 7) / 8, ncx = (wxn + 7) / 8;
+  constexpr int NCQ = (WX / 8 + 3) / 4;
+  u32x4 gy[NCQ], gx[NCQ];
+  auto fetch = [&](int un) {
+    const int b = un / a.n_tiles, t0 = (un % a.n_tiles) * TT;
+    const int li = clamp_len(a.len_in, b, a.t), lo = a.len_out ? clamp_len(a.len_out, b, a.t) : a.t;
+    const size_t r0 = ((size_t)b * a.ch + c) * a.pitch;
+#pragma unroll
+    for (int it = 0; it < NCQ; ++it) {
+      const int ck = q + 4 * it, f = t0 - H + 8 * ck;
+      gy[it] = (ck < ncy && f >= 0 && f < lo) ? *reinterpret_cast<const u32x4*>(a.dy + r0 + f) : u32x4{0u, 0u, 0u, 0u};
+      gx[it] = (need_dw && ck < ncx && f >= 0 && f < li) ? *reinterpret_cast<const u32x4*>(a.x + r0 + f) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  if (unit0 < unit1) fetch(unit0);
   // ---- tap image of this wave's 16 channels: wp[x] = w[K + 2 + dl - x] for x in [3 + dl, K + 2 + dl], two copies (the second shifted by one
   // element), dwords interleaved: dword d of copy e at byte 8 d + 4 e
   {
@@ -971,29 +1005,6 @@ __global__ __launch_bounds__(256, TT <= 128 ? 2 : 1) void dw_bwd_mfma_kernel(con
   const char* const arow = dys + (size_t)row * RPY * 2 + ((H - q - (q & 1)) >> 1) * 4;          // + 8 s per step
   const char* const brow = xs + (size_t)row * RPX * 2 + (H - p4 + 4 * q) * 2;                   // + 8 s' per queue entry
   const char* const xrow = dys + (size_t)row * RPY * 2 + (woff + q * RUN) * 2;                  // dx windows: + 8 u
-  const int unit0 = (blockIdx.y * 4 + wave) * a.upw, n_units = a.batch * a.n_tiles;
-  const int unit1 = unit0 + a.upw < n_units ? unit0 + a.upw : n_units;
-  // staging: 16-byte chunks, lane (row, q) takes chunks q, q + 4, ... of its row; the loads of unit n + 1 are issued (into registers) before the
-  // matrix work of unit n starts, the LDS writes follow when unit n is done
-  const int wxn = H - p4 + TT + 16 * G + 4 > TT + 2 * H ? H - p4 + TT + 16 * G + 4 : TT + 2 * H;
-  // (the data gradient's windows reach woff + TT + 4 NK frames into the dy rows whatever K is: a template NK larger than this K's k-steps meets
-  // zero taps there, and what they multiply must be staged zeros, not stale LDS)
-  const int wyn = woff + TT + 4 * NK > TT + 2 * H ? woff + TT + 4 * NK : TT + 2 * H;
-  const int ncy = (wyn + 7) / 8, ncx = (wxn + 7) / 8;
-  constexpr int NCQ = (WX / 8 + 3) / 4;
-  u32x4 gy[NCQ], gx[NCQ];
-  auto fetch = [&](int un) {
-    const int b = un / a.n_tiles, t0 = (un % a.n_tiles) * TT;
-    const int li = clamp_len(a.len_in, b, a.t), lo = a.len_out ? clamp_len(a.len_out, b, a.t) : a.t;
-    const size_t r0 = ((size_t)b * a.ch + c) * a.pitch;
-#pragma unroll
-    for (int it = 0; it < NCQ; ++it) {
-      const int ck = q + 4 * it, f = t0 - H + 8 * ck;
-      gy[it] = (ck < ncy && f >= 0 && f < lo) ? *reinterpret_cast<const u32x4*>(a.dy + r0 + f) : u32x4{0u, 0u, 0u, 0u};
-      gx[it] = (need_dw && ck < ncx && f >= 0 && f < li) ? *reinterpret_cast<const u32x4*>(a.x + r0 + f) : u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-  if (unit0 < unit1) fetch(unit0);
   for (int un = unit0; un < unit1; ++un) {
     const int b = un / a.n_tiles, t0 = (un % a.n_tiles) * TT;
     const int li = clamp_len(a.len_in, b, a.t), lo = a.len_out ? clamp_len(a.len_out, b, a.t) : a.t;

@@ -1,28 +1,11 @@
-"""Same-box A/B of the C4 phase-2 step (local 32 x 10 s, bf16, one hipGraph): python tools/diag/c4_ab.py variant[:pw] ...   ('-' = product library;
-:0 / :1 = ts_tcs_pointwise_select).  Each configuration runs in its own process, interleaved twice."""
-import os, subprocess, sys
+"""Same-box A/B of library variants on the C4 steps (tools/bench_extra.py c4): python tools/diag/c4_ab.py variantA variantB ... ('' = product); each in its
+own process, interleaved twice."""
+import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-CODE = r'''
-import os, sys, json
-sys.path.insert(0, %r)
-import torch
-from thunder_speech_amd import _lib
-pass
-os.environ["TS_C4_ONLY"] = os.environ.get("TS_C4_ONLY", "c4_phase2")
-from tools import bench_extra
-r = bench_extra.c4(torch.device("cuda", 0), steps1=40, steps2=40)
-print("RESULT", json.dumps({k: round(v["ms_per_step"], 3) for k, v in r.items()}))
-''' % ROOT
-def main(names):
-    res = {n: [] for n in names}
-    for rep in range(2):
-        for n in names:
-            var, _, pw = n.partition(":")
-            env = dict(os.environ, TS_LIB_VARIANT="" if var == "-" else var, TS_PW_TILE=pw or "1")
-            out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, cwd=ROOT)
-            line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
-            res[n].append(line[0][7:] if line else "FAILED " + out.stderr[-1500:])
+names = sys.argv[1:] or ["", "old"]
+for rep in range(2):
     for n in names:
-        print(f"{n:14s} " + "   ".join(res[n]), flush=True)
-if __name__ == "__main__":
-    main(sys.argv[1:] or ["-"])
+        out = subprocess.run([sys.executable, "tools/bench_extra.py", "c4", "--no-check"], env=dict(os.environ, TS_LIB_VARIANT=n), capture_output=True, text=True, cwd=ROOT)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        d = json.loads(lines[-1]) if lines else {}
+        print(f"{n or 'product':10s}", {k: round(v["ms_per_step"], 3) for k, v in d.items() if isinstance(v, dict) and "ms_per_step" in v} or out.stderr[-500:], flush=True)
