@@ -601,6 +601,9 @@ __global__ __launch_bounds__(256) void dw_fwd_pair_kernel(const T* __restrict__ 
 // MFMA work: 2 NB instructions per 32 x 32 outputs (K63: 6, 63 / 94 of the products useful) against 64 packed FMAs per 8 x 2 outputs of
 // the pair kernel; the kernel is bound by its memory traffic, not by arithmetic or LDS.
 // ----------------------------------------------------------------------------------------------------------------------
+#ifndef TS_DWM_WAVES_PER_CU
+#define TS_DWM_WAVES_PER_CU 8      // time segments per (channel, clip group) are chosen for this many waves per CU (round-6 A/B of the C4 steps: 4 -> the same, 16 -> +4 %)
+#endif
 constexpr int DWM_AHEAD = 4;                             // chunk pairs in flight
 constexpr int DWM_TAPG = 48, DWM_TAPN = 48 + 176;        // taps in LDS per wave: zero guards in front / behind
 
@@ -1688,7 +1691,7 @@ static int dwconv_fwd_impl(const void* x, const int32_t* len_in, const int32_t* 
       // bf16 rows, enough clips to fill the MFMA's N dimension: the depthwise as Toeplitz x clips on the matrix cores
       const int pup = round_up(pad, 16), R = (k + 30 + pup - pad) / 16 + 1, NB = (R + 1) / 2;
       const int n_cg = (batch + 31) / 32, n_blk = (t_out + 31) / 32;
-      int n_seg = (8 * cu_count() + ch * n_cg - 1) / (ch * n_cg);                     // ~2 waves per SIMD
+      int n_seg = (TS_DWM_WAVES_PER_CU * cu_count() + ch * n_cg - 1) / (ch * n_cg);   // ~2 waves per SIMD
       n_seg = n_seg < 1 ? 1 : (n_seg > n_blk ? n_blk : n_seg);
       const dim3 gridm((unsigned)(((long long)ch * n_cg * n_seg + 3) / 4));
 #define TS_DWM(NB_) if (NB == NB_) { hipLaunchKernelGGL(dw_fwd_mfma_kernel<NB_>, gridm, dim3(256), 0, stream, (const bf16_t*)x, len_in, len_out, w, \
