@@ -39,7 +39,7 @@ def set_deterministic(on: bool, device=None, workspace_floats: int = 8 << 20) ->
     kernels then leave their per-workgroup sums of the weight / BatchNorm-parameter gradients in a workspace and a second launch adds them in a
     fixed order, instead of float atomics -- every other kernel of the step already sums in a fixed order (split-K partials + ordered reduce,
     per-tile statistics, one workgroup per channel).  A training run started from the same seeds is then bit-reproducible, at one extra tiny
-    launch per depthwise layer.  Process-wide (ts_train_set_deterministic); the workspace (32 MiB by default) lives until the mode is switched off."""
+    launch per depthwise layer (measured on QuartzNet15x5, local 32 x 10 s: 9.05 against 8.57 ms per step, +5.5 %; profiles/round6_c4_pointwise.md section 7).  Process-wide (ts_train_set_deterministic); the workspace (32 MiB by default) lives until the mode is switched off."""
     if on:
         dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
         ws = torch.empty(int(workspace_floats), dtype=torch.float32, device=dev)
