@@ -263,3 +263,63 @@ def test_split_k_product_equals_the_single_launch():
         scale = float(ref.abs().max())
         assert float((one - ref).abs().max()) <= 2e-3 * scale and float((out - ref).abs().max()) <= 2e-3 * scale
         assert L.ts_gemm_nt_bf16_splitk(a.data_ptr(), k, w.data_ptr(), k, parts.data_ptr(), rows, n, k, 3, st) != 0      # k / 3 is not a multiple of 32
+
+
+@pytest.mark.parametrize("b,t,heads,p,ragged", [(2, 130, 4, 0.0, False), (3, 499, 4, 0.0, True), (2, 499, 4, 0.1, False), (3, 200, 2, 0.25, True), (1, 33, 1, 0.5, False)])
+def test_fused_training_attention_matches_the_materialised_path_forward_and_backward(b, t, heads, p, ragged):
+    """csrc/w2v_attn_train.hip (no [T][T] matrix in either direction; bf16 operands) against huggingface/train.py's Attention (f32 products over materialised
+    probabilities): the context, the row statistic and dq / dk / dv within 2e-2 relative L2 -- WITH dropout too, i.e. the mask drawn inside the three fused
+    kernels is ts_train_dropout's for the same seed (a different mask would show as an error of the order of p) -- for ragged key lengths incl. a clip
+    with no valid key, frame counts that are no multiple of the 64-key / 128-query tiles, and every element of dqkv written."""
+    from thunder_speech_amd.huggingface import train as T
+    torch.manual_seed(b * 100 + t)
+    c = 64 * heads
+    qkv = (torch.randn(b, t, 3 * c, device="cuda") * 1.5).requires_grad_(True)
+    key_len = torch.tensor([t, t // 2, 0][:b], dtype=torch.int32, device="cuda") if ragged else None
+    seed = 987654321012345
+    ref = T.Attention.apply(qkv, key_len, heads, p, seed)
+    dout = torch.randn_like(ref)
+    ref.backward(dout)
+    dref = qkv.grad.clone()
+    qkv.grad = None
+    old = T._MIXED
+    T._MIXED = True
+    try:
+        out = T.attention(qkv, key_len, heads, p, seed)
+        assert isinstance(out.grad_fn, T.AttentionFused._backward_cls)
+        out.backward(dout)
+    finally:
+        T._MIXED = old
+    torch.cuda.synchronize()
+    rel = lambda a_, r_: float((a_ - r_).norm() / r_.norm())
+    assert rel(out.detach(), ref.detach()) <= 2e-2
+    for sl in (slice(0, c), slice(c, 2 * c), slice(2 * c, 3 * c)):
+        assert bool(torch.isfinite(qkv.grad[..., sl]).all())
+        assert rel(qkv.grad[..., sl], dref[..., sl]) <= 2e-2
+    if p > 0:                                            # the mask matters: another seed gives another result
+        T._MIXED = True
+        try:
+            other = T.attention(qkv.detach(), key_len, heads, p, seed + 1)
+        finally:
+            T._MIXED = old
+        assert rel(other, ref.detach()) > 5e-2
+
+
+def test_fused_training_attention_is_reproducible_bit_for_bit():
+    """No atomics in the fused attention kernels: two runs give the same bits (forward and all of dqkv)."""
+    from thunder_speech_amd.huggingface import train as T
+    torch.manual_seed(5)
+    qkv = torch.randn(2, 300, 3 * 128, device="cuda")
+    dout = torch.randn(2, 300, 128, device="cuda")
+    res = []
+    old = T._MIXED
+    T._MIXED = True
+    try:
+        for _ in range(2):
+            x = qkv.clone().requires_grad_(True)
+            y = T.attention(x, None, 2, 0.1, 42)
+            y.backward(dout)
+            res.append((y.detach().clone(), x.grad.clone()))
+    finally:
+        T._MIXED = old
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

@@ -362,6 +362,54 @@ class Attention(torch.autograd.Function):
         return dqkv, None, None, None, None
 
 
+class AttentionFused(torch.autograd.Function):
+    """The same attention in mixed precision WITHOUT the [T][T] matrices (csrc/w2v_attn_train.hip; head_dim 64): bf16 q / k / v / dO / probabilities, f32
+    softmax arithmetic, accumulation and results; the dropout mask is ts_train_dropout's (same seed -> same mask as `Attention`), re-drawn in the two backward
+    kernels; saved for the backward: the bf16 qkv, the f32 output and one f32 per (head, query)."""
+
+    @staticmethod
+    def supported(c: int, heads: int) -> bool:
+        return c % heads == 0 and c // heads == 64
+
+    @staticmethod
+    def forward(ctx, qkv, key_len, heads, p_drop, seed):
+        qkv = _f32c(qkv)
+        b, t, c3 = qkv.shape
+        c = c3 // 3
+        q16, _ = _cast(qkv.view(b * t, c3), b * t, c3, True, False)
+        out = torch.empty(b, t, c, dtype=torch.float32, device=qkv.device)
+        lse2 = torch.empty(b, heads, t, dtype=torch.float32, device=qkv.device)
+        st = _lib.lib().ts_w2v_attention_train_fwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, float(p_drop), int(seed),
+                                                   out.data_ptr(), lse2.data_ptr(), _s(qkv))
+        _lib.check(st, "ts_w2v_attention_train_fwd")
+        ctx.save_for_backward(q16, out, lse2, key_len)
+        ctx.geom = (b, t, c, heads, float(p_drop), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q16, out, lse2, key_len = ctx.saved_tensors
+        b, t, c, heads, p_drop, seed = ctx.geom
+        dout = _f32c(dout)
+        L = _lib.lib()
+        ws = torch.empty(L.ts_w2v_attention_train_bwd_workspace(b, t, c, heads), dtype=torch.uint8, device=dout.device)
+        dqkv = torch.empty(b, t, 3 * c, dtype=torch.float32, device=dout.device)
+        st = L.ts_w2v_attention_train_bwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, p_drop, seed, dout.data_ptr(),
+                                          out.data_ptr(), lse2.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), _s(dout))
+        _lib.check(st, "ts_w2v_attention_train_bwd")
+        return dqkv, None, None, None, None
+
+
+FUSED_ATTENTION = True      # mixed mode: AttentionFused where it applies (False: the materialised-probabilities path, for A/B)
+
+
+def attention(qkv: Tensor, key_len, heads: int, p_drop: float, seed: int) -> Tensor:
+    """Self-attention of the training path in the current precision mode."""
+    if _MIXED and FUSED_ATTENTION and AttentionFused.supported(qkv.shape[-1] // 3, heads):
+        return AttentionFused.apply(qkv, key_len, heads, p_drop, seed)
+    return Attention.apply(qkv, key_len, heads, p_drop, seed)
+
+
 class PosConvGelu(torch.autograd.Function):
     """y = x + gelu(grouped_conv1d(x, w, padding = k // 2)[..., :T] + b) (Wav2Vec2PositionalConvEmbedding + the residual add).
     wk: the effective (weight-normalised) conv weight as [k][groups][out][in] f32 -- computed from (g, v) by torch ops on the PARAMETERS, so that
@@ -536,7 +584,7 @@ def _train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
         bqkv = torch.cat([att.q_proj.bias, att.k_proj.bias, att.v_proj.bias], 0)
 
         def attend(x):
-            ctxt = Attention.apply(linear(x, wqkv, bqkv), key_len, heads, p_att, next_seed() if p_att > 0 else 0)
+            ctxt = attention(linear(x, wqkv, bqkv), key_len, heads, p_att, next_seed() if p_att > 0 else 0)
             return dropout(linear(ctxt, att.out_proj.weight, att.out_proj.bias), p_hid)
 
         def ffn(x):
