@@ -150,6 +150,9 @@ int ts_w2v_colsum(const float* x, int64_t rows, int32_t c, int64_t ld, float* ou
  * f32 gradients, bf16 GEMM operands): x f32 [rows][c] (pitch ldx) -> y bf16 [rows][c] (pitch ldy) and / or yt bf16 [c][rows_pad] (pitch ldt), the
  * transposed copy with its rows index zero-padded to rows_pad (a multiple of 32: ts_gemm_nt_bf16's contraction index).  Either output may be NULL. */
 int ts_w2v_cast_bf16_t(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad, void* stream);
+/* The same launch also ADDING the column sums of x to colsum (f32 [c]; NULL: none): the bias gradient of a linear layer is the column sum of the dy being cast. */
+int ts_w2v_cast_bf16_t_colsum(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad, float* colsum,
+                              void* stream);
 /* out[i] = sum_p parts[p * n + i], p in order (n % 4 == 0): the reduction behind ts_gemm_nt_bf16_splitk */
 int ts_w2v_sum_parts(const float* parts, float* out, int64_t n, int32_t n_parts, void* stream);
 int ts_w2v_gelu_fwd(const float* z, const float* bias, int32_t c, float* y, int64_t n, void* stream);
@@ -564,6 +567,14 @@ int ts_w2v_mask_rows(float* x, int32_t batch, int32_t t, int32_t c, const int32_
 int64_t ts_w2v_posconv_workspace_bytes(int32_t batch, int32_t t, int32_t c, int32_t kernel);
 int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, const void* w_taps, const float* bias, int32_t kernel,
                        int32_t groups, int32_t precision, float* y, void* y_bf16, void* workspace, void* stream);
+/* The positional conv of mixed-precision FINE-TUNING on the same matrix-core kernel (bf16 operands, f32 accumulation; c / groups == 64):
+ *   backward == 0:  y = res + gelu(conv(src) + bias), z = conv(src) (before bias and GELU: what the GELU backward needs; may be NULL); src == res == x
+ *   backward == 1:  y = res + conv(src) over a copy of src padded for the TRANSPOSED conv: with w_taps = the forward's taps flipped along the kernel axis and
+ *                   each [out][in] block transposed, and src = dz, res = dy, y is the data gradient dx = dy + conv^T(dz); bias NULL.
+ * w_taps bf16 [kernel][groups][64][64]; src, res, y, z f32 [B][t][c]; workspace: ts_w2v_posconv_train_workspace bytes (the padded bf16 copy of src). */
+int64_t ts_w2v_posconv_train_workspace(int32_t batch, int32_t t, int32_t c, int32_t kernel);
+int ts_w2v_posconv_train(const float* src, const float* res, int32_t batch, int32_t t, int32_t c, const void* w_taps_bf16, const float* bias, int32_t kernel,
+                         int32_t groups, int32_t backward, float* y, float* z, void* workspace, void* stream);
 /* the conv of ONE layer of Data2VecAudioPositionalConvEmbedding (transformers modeling_data2vec_audio.py, reached from
  * huggingface/compatibility.py:31-42 when the checkpoint is a data2vec-audio one -- tests/huggingface/test_module_huggingface.py:107-110):
  * y = Conv1d(c, c, kernel, padding = kernel / 2, groups)(x) + bias, last frame of an even kernel dropped; its LayerNorm (no affine) + GELU

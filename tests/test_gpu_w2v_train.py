@@ -323,3 +323,43 @@ def test_fused_training_attention_is_reproducible_bit_for_bit():
     finally:
         T._MIXED = old
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("b,t", [(2, 130), (3, 499)])
+def test_mixed_precision_positional_conv_matches_the_f32_path_forward_and_backward(b, t):
+    """PosConvGelu in mixed mode (forward and data gradient on the bf16 matrix-core kernel: ts_w2v_posconv_train; the transposed conv as the same product over
+    flipped, per-tap transposed weights and a copy of dz padded kernel - 1 - kernel / 2 rows in front) against its f32 products: y, dx, dw, db within 1.5e-2
+    relative L2; the bias gradient rides in the cast launch of LinearMixed the same way (ts_w2v_cast_bf16_t_colsum: checked against the separate pass)."""
+    from thunder_speech_amd import _lib
+    from thunder_speech_amd.huggingface import train as T
+    torch.manual_seed(t)
+    c, k, g = 1024, 128, 16
+    x = torch.randn(b, t, c, device="cuda")
+    wk = (torch.randn(k, g, 64, 64, device="cuda") * (64 * k) ** -0.5)
+    bias = torch.randn(c, device="cuda") * 0.1
+    dy = torch.randn(b, t, c, device="cuda")
+    res = {}
+    old = T._MIXED
+    try:
+        for mode in (False, True):
+            T._MIXED = mode
+            xi, wi, bi = x.clone().requires_grad_(True), wk.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+            y = T.PosConvGelu.apply(xi, wi, bi)
+            y.backward(dy)
+            res[mode] = (y.detach(), xi.grad, wi.grad, bi.grad)
+    finally:
+        T._MIXED = old
+    torch.cuda.synchronize()
+    for a_, r_, what in zip(res[True], res[False], ("y", "dx", "dw", "db")):
+        assert bool(torch.isfinite(a_).all()), what
+        assert float((a_ - r_).norm() / r_.norm()) <= 1.5e-2, what
+    # the column sums out of the cast launch
+    L = _lib.lib()
+    rows, n = 777, 320
+    m = torch.randn(rows, n, device="cuda")
+    out16 = torch.empty(rows, n, dtype=torch.bfloat16, device="cuda")
+    cs = torch.zeros(n, device="cuda")
+    assert L.ts_w2v_cast_bf16_t_colsum(m.data_ptr(), n, rows, n, out16.data_ptr(), n, None, 0, rows, cs.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out16, m.to(torch.bfloat16))
+    assert float((cs - m.sum(0)).abs().max()) <= 1e-3

@@ -476,6 +476,8 @@ struct PcArgs {
   const float* x;                  // [B][T][C] fp32 (residual)
   float* y;
   int t, c, k, groups;
+  float* z;                        // training (ts_w2v_posconv_train): the conv result before bias and GELU, or NULL
+  int plain;                       // training, data gradient: y = x + conv (no bias, no GELU)
 };
 
 __global__ __launch_bounds__(256) void w2v_posconv_mfma_kernel(const PcArgs a) {
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void w2v_posconv_mfma_kernel(const PcArgs a) {
     for (int ks = 0; ks < 4; ++ks) { bf[ks] = bn[ks]; bn[ks] = bnn[ks]; }
   }
   const int co = g * 64 + wn * 32 + n32;
-  const float bv = a.bias[co];
+  const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -531,7 +533,11 @@ __global__ __launch_bounds__(256) void w2v_posconv_mfma_kernel(const PcArgs a) {
       const int t = t0 + wm * 64 + 32 * mt + 8 * (i >> 2) + 4 * half + (i & 3);
       if (t < a.t) {
         const size_t o = ((size_t)b * a.t + t) * a.c + co;
-        a.y[o] = a.x[o] + gelu_erf(acc[mt][i] + bv);
+        if (a.plain) a.y[o] = a.x[o] + acc[mt][i];
+        else {
+          if (a.z) a.z[o] = acc[mt][i];
+          a.y[o] = a.x[o] + gelu_erf(acc[mt][i] + bv);
+        }
       }
     }
 }
@@ -756,6 +762,48 @@ static int ts::posconv_impl(const float* x, int32_t batch, int32_t t, int32_t c,
   }
   if (plain) hipLaunchKernelGGL(w2v_posconv_finish_kernel<true>, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, yp, bias, y, t, c, kernel);
   else hipLaunchKernelGGL(w2v_posconv_finish_kernel<false>, dim3(nblk((long long)t * c), batch), dim3(256), 0, stream, x, yp, bias, y, t, c, kernel);
+  return hip_status(hipGetLastError());
+}
+
+namespace ts {
+// bf16 copy of x [B][t][c] f32 with `front` zero rows before and prow - front - t after each clip (prow rows per clip), one row of zeros behind the last clip
+__global__ __launch_bounds__(256) void posconv_pad16_kernel(const float* __restrict__ x, unsigned short* __restrict__ xp, int t, int c, int prow, int front, long long total) {
+  const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (idx >= total) return;
+  const long long row = idx / c;
+  const int col = (int)(idx - row * c);
+  const long long b = row / prow;
+  const int r = (int)(row - b * prow) - front;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (r >= 0 && r < t && b * prow < total / c - 1) v = *reinterpret_cast<const f32x4*>(x + ((size_t)b * t + r) * c + col);
+  *reinterpret_cast<u32x2*>(xp + idx) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+}
+}  // namespace ts
+
+extern "C" int64_t ts_w2v_posconv_train_workspace(int32_t batch, int32_t t, int32_t c, int32_t kernel) {
+  if (batch <= 0 || t <= 0 || c <= 0 || kernel <= 0) return TS_EINVAL;
+  return ((int64_t)batch * (t + kernel) + 1) * c * 2;
+}
+
+/* Positional conv of mixed-precision fine-tuning on the matrix-core kernel; see include/thunder_speech_amd.h */
+extern "C" int ts_w2v_posconv_train(const float* src, const float* res, int32_t batch, int32_t t, int32_t c, const void* w_taps_bf16, const float* bias, int32_t kernel,
+                                    int32_t groups, int32_t backward, float* y, float* z, void* workspace, void* stream_) {
+  if (!src || !res || !w_taps_bf16 || !y || !workspace || batch <= 0 || t <= 0 || c <= 0 || kernel <= 1 || groups <= 0 || c % groups) return TS_EINVAL;
+  if (!backward && !bias) return TS_EINVAL;
+  const size_t win_lds = (size_t)(PC_TT + kernel - 1) * PC_PITCH;
+  if (c / groups != 64 || c % 4 || win_lds > 64 * 1024 || (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(src) & 15)) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  const int prow = t + kernel;
+  // forward: kernel / 2 zero rows in front (padding = kernel / 2).  Data gradient: out[s] = sum_j' dz[s + j' - (kernel - 1 - kernel / 2)] Wb[j'] with
+  // Wb[j'] = W[kernel - 1 - j']^T -- the same product over a copy padded with kernel - 1 - kernel / 2 rows in front
+  const int front = backward ? kernel - 1 - kernel / 2 : kernel / 2;
+  unsigned short* const xp = static_cast<unsigned short*>(workspace);
+  const long long total = ((long long)batch * prow + 1) * c;
+  hipLaunchKernelGGL(posconv_pad16_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, src, xp, t, c, prow, front, total);
+  PcArgs pa{};
+  pa.xp = xp; pa.w = static_cast<const unsigned short*>(w_taps_bf16); pa.bias = backward ? nullptr : bias; pa.x = res; pa.y = y;
+  pa.t = t; pa.c = c; pa.k = kernel; pa.groups = groups; pa.z = backward ? nullptr : z; pa.plain = backward ? 1 : 0;
+  hipLaunchKernelGGL(w2v_posconv_mfma_kernel, dim3((t + PC_TT - 1) / PC_TT, groups, batch), dim3(256), win_lds, stream, pa);
   return hip_status(hipGetLastError());
 }
 

@@ -243,21 +243,29 @@ namespace ts {
 //   y[r][j] = bf16(x[r][j]);   yt[j][r] = bf16(x[r][j]) for r < rows, 0 for rows <= r < rows_pad
 // (the transposed copy's contraction index -- the rows -- is padded with zeros to a multiple of 32, what ts_gemm_nt_bf16 wants).  64 x 64 tiles
 // through LDS: 256-byte row reads, 128-byte writes in both layouts.
+// colsum (may be NULL): colsum[j] += sum_r x[r][j] on the way (the bias gradient of a linear layer is the column sum of the very dy this kernel casts:
+// one pass over dy instead of two, and no launch of its own -- 97 launches + 97 zero fills of a wav2vec2-large fine-tuning step)
 __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ x, long long ldx, int rows, int c, unsigned short* __restrict__ y,
-                                                          long long ldy, unsigned short* __restrict__ yt, long long ldt, int rows_pad) {
+                                                          long long ldy, unsigned short* __restrict__ yt, long long ldt, int rows_pad, float* __restrict__ colsum) {
   __shared__ unsigned short tile[64][66];
+  __shared__ float csum[4][64];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  float acc = 0.f;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, cc = c0 + tx;
     unsigned short v = 0;
     if (r < rows && cc < c) {
-      v = (unsigned short)(pack_bf16(x[(size_t)r * ldx + cc], 0.f) & 0xffffu);
+      const float xv = x[(size_t)r * ldx + cc];
+      acc += xv;
+      v = (unsigned short)(pack_bf16(xv, 0.f) & 0xffffu);
       if (y) y[(size_t)r * ldy + cc] = v;
     }
     tile[i][tx] = v;
   }
+  if (colsum) csum[ty][tx] = acc;
   __syncthreads();
+  if (colsum && ty == 0 && c0 + tx < c && r0 < rows) atomicAdd(colsum + c0 + tx, (csum[0][tx] + csum[1][tx]) + (csum[2][tx] + csum[3][tx]));
   if (yt) {
     for (int i = ty; i < 64; i += 4) {
       const int cc = c0 + i, r = r0 + tx;
@@ -285,8 +293,9 @@ extern "C" int ts_w2v_sum_parts(const float* parts, float* out, int64_t n, int32
   return ts::hip_status(hipGetLastError());
 }
 
-extern "C" int ts_w2v_cast_bf16_t(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad,
-                                  void* stream_) {
+/* ts_w2v_cast_bf16_t that also ADDS the column sums of x to colsum (f32 [c], may be NULL); see include/thunder_speech_amd.h */
+extern "C" int ts_w2v_cast_bf16_t_colsum(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad,
+                                         float* colsum, void* stream_) {
   if (!x || (!y && !yt) || rows <= 0 || c <= 0 || ldx < c || rows >= (1ll << 31)) return TS_EINVAL;
   if (y && ldy < c) return TS_EINVAL;
   if (yt && (rows_pad < rows || ldt < rows_pad || rows_pad >= (1ll << 31))) return TS_EINVAL;
@@ -294,8 +303,13 @@ extern "C" int ts_w2v_cast_bf16_t(const float* x, int64_t ldx, int64_t rows, int
   const long long rp = yt ? rows_pad : rows;
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::cast_bf16_t_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)((rp + 63) / 64)), dim3(256), 0, stream, x, (long long)ldx, (int)rows, (int)c,
-                     static_cast<unsigned short*>(y), (long long)ldy, static_cast<unsigned short*>(yt), (long long)ldt, (int)rows_pad);
+                     static_cast<unsigned short*>(y), (long long)ldy, static_cast<unsigned short*>(yt), (long long)ldt, (int)rows_pad, colsum);
   return ts::hip_status(hipGetLastError());
+}
+
+extern "C" int ts_w2v_cast_bf16_t(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad,
+                                  void* stream_) {
+  return ts_w2v_cast_bf16_t_colsum(x, ldx, rows, c, y, ldy, yt, ldt, rows_pad, nullptr, stream_);
 }
 
 extern "C" int64_t ts_w2v_layernorm_bwd_workspace(int64_t rows, int32_t c) {

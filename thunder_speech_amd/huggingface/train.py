@@ -82,14 +82,16 @@ def _pad32(n: int) -> int:
     return (n + 255) // 256 * 256 if n > 1024 else (n + 31) // 32 * 32
 
 
-def _cast(x2: Tensor, rows: int, c: int, plain: bool, transposed: bool):
-    """(bf16 copy [rows][c] or None, transposed bf16 copy [c][pad32(rows)] or None) of the f32 matrix x2 (contiguous [rows][c]): ONE launch."""
+def _cast(x2: Tensor, rows: int, c: int, plain: bool, transposed: bool, colsum: Optional[Tensor] = None):
+    """(bf16 copy [rows][c] or None, transposed bf16 copy [c][pad32(rows)] or None) of the f32 matrix x2 (contiguous [rows][c]): ONE launch, which also
+    adds the column sums of x2 to `colsum` (f32 [c]) when given -- a linear layer's bias gradient out of the pass that casts dy."""
     dev = x2.device
     y = torch.empty(rows, c, dtype=torch.bfloat16, device=dev) if plain else None
     rp = _pad32(rows)
     yt = torch.empty(c, rp, dtype=torch.bfloat16, device=dev) if transposed else None
-    st = _lib.lib().ts_w2v_cast_bf16_t(x2.data_ptr(), c, rows, c, y.data_ptr() if plain else None, c, yt.data_ptr() if transposed else None, rp, rp, _s(x2))
-    _lib.check(st, "ts_w2v_cast_bf16_t")
+    st = _lib.lib().ts_w2v_cast_bf16_t_colsum(x2.data_ptr(), c, rows, c, y.data_ptr() if plain else None, c, yt.data_ptr() if transposed else None, rp, rp,
+                                              colsum.data_ptr() if colsum is not None else None, _s(x2))
+    _lib.check(st, "ts_w2v_cast_bf16_t_colsum")
     return y, yt
 
 
@@ -145,8 +147,12 @@ class LinearMixed(torch.autograd.Function):
         xt16, wt16 = ctx.saved_tensors
         rows, n, k, xshape = ctx.geom
         dy = _f32c(dy)
-        dy16, dyt16 = _cast(dy.view(rows, n), rows, n, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        fused_db = want_db and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])       # the bias gradient rides in the cast launch when there is one
+        if fused_db:
+            db = torch.zeros(n, dtype=torch.float32, device=dy.device)
+        dy16, dyt16 = _cast(dy.view(rows, n), rows, n, ctx.needs_input_grad[0], ctx.needs_input_grad[1], colsum=db if fused_db else None)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
             _gemm_nt(dy16, n, wt16, _pad32(n), dx, rows, k, n)                    # (n % 32 == 0: wT16's pitch is n)
@@ -154,7 +160,7 @@ class LinearMixed(torch.autograd.Function):
             dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
             rp = _pad32(rows)
             _gemm_nt_splitk(dyt16, rp, xt16, rp, dw, n, k, rp)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db and not fused_db:
             db = _colsum(dy, rows, n)
         return dx, dw, db
 
@@ -400,6 +406,7 @@ class AttentionFused(torch.autograd.Function):
         return dqkv, None, None, None, None
 
 
+MIXED_POSCONV = True        # mixed mode: the positional conv's forward and data gradient on the bf16 matrix-core kernel (False: f32 products, for A/B)
 FUSED_ATTENTION = True      # mixed mode: AttentionFused where it applies (False: the materialised-probabilities path, for A/B)
 
 
@@ -418,12 +425,28 @@ class PosConvGelu(torch.autograd.Function):
     of the rows."""
 
     @staticmethod
+    def _mixed_ok(k: int, cg: int) -> bool:
+        return _MIXED and MIXED_POSCONV and cg == 64 and (128 + k - 1) * 144 <= 64 * 1024
+
+    @staticmethod
     def forward(ctx, x, wk, bias):
         x, wk, bias = _f32c(x), _f32c(wk), _f32c(bias)
         b, t, c = x.shape
         k, g, cg, _ = wk.shape
         L = _lib.lib()
         tp = t + k
+        ctx.mixed = PosConvGelu._mixed_ok(k, cg)
+        if ctx.mixed:
+            # mixed precision: the conv on the inference path's matrix-core kernel (bf16 operands, f32 accumulation; csrc/w2v_enc.hip w2v_posconv_mfma_kernel),
+            # which also leaves the pre-activation z for the backward; bias + GELU + residual in its epilogue
+            w16 = wk.to(torch.bfloat16)
+            ws = torch.empty(L.ts_w2v_posconv_train_workspace(b, t, c, k), dtype=torch.uint8, device=x.device)
+            y, z = torch.empty_like(x), torch.empty_like(x)
+            _lib.check(L.ts_w2v_posconv_train(x.data_ptr(), x.data_ptr(), b, t, c, w16.data_ptr(), bias.data_ptr(), k, g, 0, y.data_ptr(), z.data_ptr(),
+                                              ws.data_ptr(), _s(x)), "ts_w2v_posconv_train")
+            ctx.save_for_backward(x, z, wk, bias)
+            ctx.geom = (b, t, c)
+            return y
         xp = torch.empty(b, tp, c, dtype=torch.float32, device=x.device)
         _lib.check(L.ts_w2v_pad_rows(x.data_ptr(), xp.data_ptr(), b, t, tp, k // 2, c, 0, _s(x)), "ts_w2v_pad_rows")
         m = b * tp - k                                                   # rows of the padded row space that have all k taps
@@ -449,6 +472,10 @@ class PosConvGelu(torch.autograd.Function):
         L = _lib.lib()
         tp = t + k
         m = b * tp - k
+        if ctx.mixed:                                    # the node kept x, not its padded copy
+            x = xp
+            xp = torch.empty(b, tp, c, dtype=torch.float32, device=x.device)
+            _lib.check(L.ts_w2v_pad_rows(x.data_ptr(), xp.data_ptr(), b, t, tp, k // 2, c, 0, _s(x)), "ts_w2v_pad_rows")
         dz = torch.empty_like(dy)
         _lib.check(L.ts_w2v_gelu_bwd(z.data_ptr(), bias.data_ptr(), c, dy.data_ptr(), dz.data_ptr(), dz.numel(), _s(dy)), "ts_w2v_gelu_bwd")
         db = _colsum(dz, b * t, c) if ctx.needs_input_grad[2] else None
@@ -458,7 +485,14 @@ class PosConvGelu(torch.autograd.Function):
         dzp = dbuf[k - 1:].view(b, tp, c)
         _lib.check(L.ts_w2v_pad_rows(dz.data_ptr(), dzp.data_ptr(), b, t, tp, 0, c, 0, _s(dy)), "ts_w2v_pad_rows")
         dx = dwk = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.mixed:
+            # dx = dy + conv^T(dz): the same matrix-core kernel over dz with the taps flipped and each tap's [out][in] block transposed
+            wb16 = wk.flip(0).transpose(2, 3).contiguous().to(torch.bfloat16)
+            ws = torch.empty(L.ts_w2v_posconv_train_workspace(b, t, c, k), dtype=torch.uint8, device=dy.device)
+            dx = torch.empty_like(dy)
+            _lib.check(L.ts_w2v_posconv_train(dz.data_ptr(), dy.data_ptr(), b, t, c, wb16.data_ptr(), None, k, g, 1, dx.data_ptr(), None, ws.data_ptr(), _s(dy)),
+                       "ts_w2v_posconv_train")
+        elif ctx.needs_input_grad[0]:
             # d xp[q][g cg + i] = sum_j' sum_o dbuf[q + j'][g cg + o] wk[k - 1 - j'][g][o][i]
             dxp = torch.empty(b, tp, c, dtype=torch.float32, device=dy.device)
             _gemm(dbuf, c, 1, wk, cg, 1, dxp, c, b * tp, cg, cg, sa=cg, ska=c, sb=cg * cg, skb=-g * cg * cg, sc=cg, nkb=k, batch=g,
