@@ -155,6 +155,8 @@ int ts_w2v_cast_bf16_t_colsum(const float* x, int64_t ldx, int64_t rows, int32_t
                               void* stream);
 /* out[i] = sum_p parts[p * n + i], p in order (n % 4 == 0): the reduction behind ts_gemm_nt_bf16_splitk */
 int ts_w2v_sum_parts(const float* parts, float* out, int64_t n, int32_t n_parts, void* stream);
+/* the same with a bias row added: out[r][j] = sum_p parts[p][r][j] + bias[j], rows of c floats (c % 4 == 0) -- the split-K form of a linear layer's forward product */
+int ts_w2v_sum_parts_bias(const float* parts, const float* bias, int32_t c, float* out, int64_t n, int32_t n_parts, void* stream);
 int ts_w2v_gelu_fwd(const float* z, const float* bias, int32_t c, float* y, int64_t n, void* stream);
 int ts_w2v_gelu_bwd(const float* z, const float* bias, int32_t c, const float* dy, float* dz, int64_t n, void* stream);
 int ts_w2v_softmax_fwd(float* s, const int32_t* key_len, int32_t batch, int32_t heads, int32_t t, int32_t pitch, float scale, void* stream);

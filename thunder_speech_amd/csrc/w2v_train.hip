@@ -276,20 +276,33 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restric
 }  // namespace ts
 
 namespace ts {
-__global__ __launch_bounds__(256) void w2v_sum_parts_kernel(const float* __restrict__ parts, float* __restrict__ out, long long n4, int n_parts, long long stride4) {
+__global__ __launch_bounds__(256) void w2v_sum_parts_kernel(const float* __restrict__ parts, float* __restrict__ out, long long n4, int n_parts, long long stride4,
+                                                            const float* __restrict__ bias, int c4) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   f32x4 acc = reinterpret_cast<const f32x4*>(parts)[i];
   for (int p = 1; p < n_parts; ++p) acc += reinterpret_cast<const f32x4*>(parts)[(long long)p * stride4 + i];      // fixed order: deterministic
+  if (bias) acc += reinterpret_cast<const f32x4*>(bias)[i % c4];
   reinterpret_cast<f32x4*>(out)[i] = acc;
 }
 }  // namespace ts
+
+/* out[r][j] = sum_p parts[p][r][j] + bias[j]  (rows of c floats, c % 4 == 0): the split-K form of a linear layer's forward product */
+extern "C" int ts_w2v_sum_parts_bias(const float* parts, const float* bias, int32_t c, float* out, int64_t n, int32_t n_parts, void* stream_) {
+  if (!parts || !bias || !out || n <= 0 || c <= 0 || c % 4 || n % c || n_parts < 1 || (reinterpret_cast<uintptr_t>(parts) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (reinterpret_cast<uintptr_t>(bias) & 15))
+    return TS_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ts::w2v_sum_parts_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), parts, out, (long long)(n / 4), (int)n_parts,
+                     (long long)(n / 4), bias, (int)(c / 4));
+  return ts::hip_status(hipGetLastError());
+}
 
 extern "C" int ts_w2v_sum_parts(const float* parts, float* out, int64_t n, int32_t n_parts, void* stream_) {
   if (!parts || !out || n <= 0 || n % 4 || n_parts < 1 || (reinterpret_cast<uintptr_t>(parts) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return TS_EINVAL;
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::w2v_sum_parts_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), parts, out, (long long)(n / 4), (int)n_parts,
-                     (long long)(n / 4));
+                     (long long)(n / 4), (const float*)nullptr, 1);
   return ts::hip_status(hipGetLastError());
 }
 

@@ -102,19 +102,22 @@ def _gemm_nt(a16: Tensor, lda: int, w16: Tensor, ldw: int, out: Tensor, rows: in
     _lib.check(st, "ts_gemm_nt_bf16")
 
 
-def _gemm_nt_splitk(a16: Tensor, lda: int, w16: Tensor, ldw: int, out: Tensor, rows: int, n: int, k: int):
+def _gemm_nt_splitk(a16: Tensor, lda: int, w16: Tensor, ldw: int, out: Tensor, rows: int, n: int, k: int, bias: Optional[Tensor] = None, min_k: int = 0):
     """The same product for FEW output tiles and a LONG contraction (the weight gradients: 1024 x 1024 outputs are 16 tiles of 256 x 256 on 256 compute
     units): split-K into f32 partials (ts_gemm_nt_bf16_splitk) + an ordered sum (ts_w2v_sum_parts), splits chosen for ~128 workgroups."""
     tiles = ((rows + 255) // 256) * ((n + 255) // 256)
     splits = 1
     while tiles * splits < 128 and k % (64 * splits) == 0 and k // (2 * splits) >= 256:
         splits *= 2
-    if splits == 1 or (rows * n) % 4:
-        return _gemm_nt(a16, lda, w16, ldw, out, rows, n, k)
+    if splits == 1 or (rows * n) % 4 or k < min_k or (bias is not None and n % 4):
+        return _gemm_nt(a16, lda, w16, ldw, out, rows, n, k, bias)
     parts = torch.empty(splits, rows, n, dtype=torch.float32, device=out.device)
     L = _lib.lib()
     _lib.check(L.ts_gemm_nt_bf16_splitk(a16.data_ptr(), lda, w16.data_ptr(), ldw, parts.data_ptr(), rows, n, k, splits, _s(out)), "ts_gemm_nt_bf16_splitk")
-    _lib.check(L.ts_w2v_sum_parts(parts.data_ptr(), out.data_ptr(), rows * n, splits, _s(out)), "ts_w2v_sum_parts")
+    if bias is not None:
+        _lib.check(L.ts_w2v_sum_parts_bias(parts.data_ptr(), bias.data_ptr(), n, out.data_ptr(), rows * n, splits, _s(out)), "ts_w2v_sum_parts_bias")
+    else:
+        _lib.check(L.ts_w2v_sum_parts(parts.data_ptr(), out.data_ptr(), rows * n, splits, _s(out)), "ts_w2v_sum_parts")
 
 
 class LinearMixed(torch.autograd.Function):
@@ -137,7 +140,8 @@ class LinearMixed(torch.autograd.Function):
         x16, xt16 = _cast(x.view(rows, k), rows, k, True, ctx.needs_input_grad[1])
         w16, wt16 = _cast(w, n, k, True, ctx.needs_input_grad[0])
         y = torch.empty(*x.shape[:-1], n, dtype=torch.float32, device=x.device)
-        _gemm_nt(x16, k, w16, k, y, rows, n, k, _f32c(b) if b is not None else None)
+        # few output tiles and a long contraction (the second feed-forward linear: 64 tiles, K = 4096): split-K fills the chip
+        _gemm_nt_splitk(x16, k, w16, k, y, rows, n, k, bias=_f32c(b) if b is not None else None, min_k=2048)
         ctx.save_for_backward(xt16, wt16)
         ctx.has_bias, ctx.geom = b is not None, (rows, n, k, x.shape)
         return y
@@ -155,7 +159,7 @@ class LinearMixed(torch.autograd.Function):
         dy16, dyt16 = _cast(dy.view(rows, n), rows, n, ctx.needs_input_grad[0], ctx.needs_input_grad[1], colsum=db if fused_db else None)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(xshape, dtype=torch.float32, device=dy.device)
-            _gemm_nt(dy16, n, wt16, _pad32(n), dx, rows, k, n)                    # (n % 32 == 0: wT16's pitch is n)
+            _gemm_nt_splitk(dy16, n, wt16, _pad32(n), dx, rows, k, n)             # (n % 32 == 0: wT16's pitch is n); split-K when the output has < 128 tiles
         if ctx.needs_input_grad[1]:
             dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
             rp = _pad32(rows)
