@@ -598,14 +598,16 @@ int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, int32_t c, i
  *   ts_w2v_attention_train_fwd   ctx = dropout(softmax(q k^T / 8 + key mask)) v;  qkv bf16 [B][t][3c], ctx f32 [B][t][c], lse2 f32 [B][heads][t] = the row
  *                                statistic max + log2(sum) in the log2 domain (scale folded in) the backward rebuilds probabilities from.  Dropout: the
  *                                mask of ts_train_dropout over the logical [B * heads * t][t] probability matrix (element e = row * t + key: word e & 3 of
- *                                Philox block e >> 2 under `seed`), kept entries scaled by 1 / (1 - p_drop); p_drop = 0 draws nothing.
+ *                                Philox block e >> 2 under `seed`), kept entries scaled by 1 / (1 - p_drop); drawn once per call as a bitstring into `workspace`
+ *                                (ts_w2v_attention_train_fwd_workspace bytes; unused and may be NULL when p_drop = 0).
  *   ts_w2v_attention_train_bwd   dqkv f32 [B][t][3c] (every element written) from dctx f32 [B][t][c], ctx, lse2 and the same qkv / key_len / p_drop / seed;
- *                                workspace: ts_w2v_attention_train_bwd_workspace bytes (bf16 copy of dctx + the row sums D).  Two launches that each rebuild
- *                                probabilities and mask: no atomics, fixed summation order.
+ *                                workspace: ts_w2v_attention_train_bwd_workspace bytes (bf16 copy of dctx, the row sums D, the re-drawn mask bits).  Two launches
+ *                                that each rebuild the probabilities: no atomics, fixed summation order.
  * key_len[b] <= 0 (no valid key): every probability of the clip is 0, ctx = 0 and all three gradients 0 -- ts_w2v_softmax_fwd's convention.
  * TS_EUNSUPPORTED unless c / heads == 64. */
+int64_t ts_w2v_attention_train_fwd_workspace(int32_t batch, int32_t t, int32_t c, int32_t heads);
 int ts_w2v_attention_train_fwd(const void* qkv_bf16, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len, float p_drop,
-                               uint64_t seed, float* ctx, float* lse2, void* stream);
+                               uint64_t seed, float* ctx, float* lse2, void* workspace, void* stream);
 int64_t ts_w2v_attention_train_bwd_workspace(int32_t batch, int32_t t, int32_t c, int32_t heads);
 int ts_w2v_attention_train_bwd(const void* qkv_bf16, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len, float p_drop,
                                uint64_t seed, const float* dctx, const float* ctx, const float* lse2, float* dqkv, void* workspace, void* stream);

@@ -36,19 +36,31 @@ struct TaArgs {
   float scale_log2e, scale;        // log2(e) / sqrt(hd), 1 / sqrt(hd)
   float p_drop, keep_scale;        // dropout probability, 1 / (1 - p)
   unsigned long long seed;
+  const unsigned* mask;            // keep bits of the whole [B H T][T] dropout stream, bit e of the flat bitstring (attn_mask_kernel); NULL when p_drop == 0
 };
 
-// keep bits of the 8 consecutive elements e0 .. e0 + 7 of the dropout stream (bit j: element e0 + j is kept) -- ts_train_dropout's rule: element e keeps
-// its value iff u01(word e & 3 of Philox block e >> 2) >= p.  e0 is not block-aligned in general (T is odd): three blocks cover any 8 elements.
-__device__ __forceinline__ unsigned keep8(unsigned long long seed, unsigned long long e0, float p) {
-  const unsigned long long blk = e0 >> 2;
-  const int off = (int)(e0 & 3);
-  const Philox4 r0 = philox(seed, PHILOX_DROPOUT, blk), r1 = philox(seed, PHILOX_DROPOUT, blk + 1), r2 = philox(seed, PHILOX_DROPOUT, blk + 2);
-  unsigned w[12] = {r0.v[0], r0.v[1], r0.v[2], r0.v[3], r1.v[0], r1.v[1], r1.v[2], r1.v[3], r2.v[0], r2.v[1], r2.v[2], r2.v[3]};
-  unsigned all = 0;
+// The dropout mask as a bitstring, drawn ONCE per call by its own small kernel: bit e is set iff element e of the logical [B * heads * T][T] probability
+// matrix keeps its value -- ts_train_dropout's rule: u01(word e & 3 of Philox block e >> 2) >= p.  A thread draws the 8 blocks of one 32-bit word.  Drawing
+// the mask inside the attention kernels cost three Philox blocks per 8 probabilities (T is odd: a lane's run of 8 keys straddles three blocks) in each of the
+// three kernels -- more than the attention arithmetic itself; now they read two words per run.
+__global__ __launch_bounds__(256) void attn_mask_kernel(unsigned* __restrict__ mask, long long n_words, unsigned long long seed, float p) {
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  unsigned bits = 0;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) all |= (u01(w[j]) >= p ? 1u : 0u) << j;
-  return (all >> off) & 0xffu;
+  for (int j = 0; j < 8; ++j) {
+    const Philox4 r = philox(seed, PHILOX_DROPOUT, (unsigned long long)w * 8 + j);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bits |= (u01(r.v[q]) >= p ? 1u : 0u) << (4 * j + q);
+  }
+  mask[w] = bits;
+}
+
+// keep bits of the 8 consecutive elements e0 .. e0 + 7 (bit j: element e0 + j is kept)
+__device__ __forceinline__ unsigned keep8(const unsigned* __restrict__ mask, unsigned long long e0) {
+  const unsigned long long w = e0 >> 5;
+  const unsigned long long both = ((unsigned long long)mask[w + 1] << 32) | mask[w];
+  return (unsigned)(both >> (e0 & 31)) & 0xffu;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       l_run = l_run * alpha + rs;                                             // the normaliser counts every key, dropped or not
       m_run = m_new;
       if (drop) {
-        const unsigned k_lo = keep8(a.seed, erow + kbase, a.p_drop), k_hi = keep8(a.seed, erow + kbase + 16, a.p_drop);
+        const unsigned k_lo = keep8(a.mask, erow + kbase), k_hi = keep8(a.mask, erow + kbase + 16);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           s[i] = (k_lo >> i) & 1u ? s[i] * a.keep_scale : 0.f;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(const float* __restric
 __device__ __forceinline__ void attn_bwd_tile(f32x16& s, f32x16& dp, int kbase, int lim, bool q_ok, float lse2, float dsum, const TaArgs& a, unsigned long long erow,
                                               bool drop) {
   unsigned k_lo = 0xffu, k_hi = 0xffu;
-  if (drop) { k_lo = keep8(a.seed, erow + kbase, a.p_drop); k_hi = keep8(a.seed, erow + kbase + 16, a.p_drop); }
+  if (drop) { k_lo = keep8(a.mask, erow + kbase); k_hi = keep8(a.mask, erow + kbase + 16); }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int key = kbase + 16 * (i >> 3) + (i & 7);
@@ -463,24 +475,38 @@ static int ta_check(const void* qkv, int32_t batch, int32_t t, int32_t c, int32_
 }
 
 /* see include/thunder_speech_amd.h */
+// words of the mask bitstring: every element + two words of slack for the 64-bit window of the last run
+static long long ta_mask_words(int batch, int t, int heads) { return ((long long)batch * heads * t * t + 31) / 32 + 2; }
+static void ta_draw_mask(unsigned* mask, int batch, int t, int heads, unsigned long long seed, float p, hipStream_t stream) {
+  const long long n = ta_mask_words(batch, t, heads);
+  hipLaunchKernelGGL(attn_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mask, n, seed, p);
+}
+
+extern "C" int64_t ts_w2v_attention_train_fwd_workspace(int32_t batch, int32_t t, int32_t c, int32_t heads) {
+  if (batch <= 0 || t <= 0 || c <= 0 || heads <= 0) return TS_EINVAL;
+  return (ta_mask_words(batch, t, heads) * 4 + 15) / 16 * 16;
+}
+
 extern "C" int ts_w2v_attention_train_fwd(const void* qkv_bf16, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len, float p_drop,
-                                          uint64_t seed, float* ctx, float* lse2, void* stream_) {
+                                          uint64_t seed, float* ctx, float* lse2, void* workspace, void* stream_) {
   if (int st = ta_check(qkv_bf16, batch, t, c, heads, p_drop)) return st;
-  if (!ctx || !lse2 || (reinterpret_cast<uintptr_t>(ctx) & 15)) return TS_EINVAL;
+  if (!ctx || !lse2 || (reinterpret_cast<uintptr_t>(ctx) & 15) || (p_drop > 0.f && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)))) return TS_EINVAL;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  (void)hipGetLastError();
+  if (p_drop > 0.f) ta_draw_mask(static_cast<unsigned*>(workspace), batch, t, heads, seed, p_drop, stream);
   TaArgs a{};
   a.qkv = static_cast<const unsigned short*>(qkv_bf16); a.key_len = key_len; a.ctx = ctx; a.lse2 = lse2;
   a.t = t; a.c = c; a.heads = heads;
   a.scale = 1.f / sqrtf(64.f); a.scale_log2e = 1.4426950408889634f * a.scale;
   a.p_drop = p_drop; a.keep_scale = 1.f / (1.f - p_drop); a.seed = seed;
-  (void)hipGetLastError();
+  a.mask = p_drop > 0.f ? static_cast<const unsigned*>(workspace) : nullptr;
   hipLaunchKernelGGL(attn_fwd_train_kernel, dim3((t + TA_QW - 1) / TA_QW, heads, batch), dim3(256), 0, stream, a);
   return hip_status(hipGetLastError());
 }
 
 extern "C" int64_t ts_w2v_attention_train_bwd_workspace(int32_t batch, int32_t t, int32_t c, int32_t heads) {
   if (batch <= 0 || t <= 0 || c <= 0 || heads <= 0) return TS_EINVAL;
-  return ((int64_t)batch * t * c * 2 + 15) / 16 * 16 + (int64_t)batch * heads * t * 4;
+  return ((int64_t)batch * t * c * 2 + 15) / 16 * 16 + ((int64_t)batch * heads * t * 4 + 15) / 16 * 16 + (ta_mask_words(batch, t, heads) * 4 + 15) / 16 * 16;
 }
 
 /* see include/thunder_speech_amd.h */
@@ -501,6 +527,11 @@ extern "C" int ts_w2v_attention_train_bwd(const void* qkv_bf16, int32_t batch, i
   a.scale = 1.f / sqrtf(64.f); a.scale_log2e = 1.4426950408889634f * a.scale;
   a.p_drop = p_drop; a.keep_scale = 1.f / (1.f - p_drop); a.seed = seed;
   (void)hipGetLastError();
+  if (p_drop > 0.f) {                                // the backward re-draws the forward's mask (a pure function of the seed) instead of keeping 4 MB per layer
+    unsigned* const mask = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dsum) + ((int64_t)batch * heads * t * 4 + 15) / 16 * 16);
+    ta_draw_mask(mask, batch, t, heads, seed, p_drop, stream);
+    a.mask = mask;
+  }
   const long long rows = (long long)batch * t;
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dctx, ctx, dout16, dsum, rows, t, c, heads);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((t + TA_QW - 1) / TA_QW, heads, batch), dim3(256), 0, stream, a);

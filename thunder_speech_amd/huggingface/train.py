@@ -389,8 +389,10 @@ class AttentionFused(torch.autograd.Function):
         q16, _ = _cast(qkv.view(b * t, c3), b * t, c3, True, False)
         out = torch.empty(b, t, c, dtype=torch.float32, device=qkv.device)
         lse2 = torch.empty(b, heads, t, dtype=torch.float32, device=qkv.device)
-        st = _lib.lib().ts_w2v_attention_train_fwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, float(p_drop), int(seed),
-                                                   out.data_ptr(), lse2.data_ptr(), _s(qkv))
+        L = _lib.lib()
+        ws = torch.empty(L.ts_w2v_attention_train_fwd_workspace(b, t, c, heads), dtype=torch.uint8, device=qkv.device) if p_drop > 0 else None
+        st = L.ts_w2v_attention_train_fwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, float(p_drop), int(seed),
+                                          out.data_ptr(), lse2.data_ptr(), ws.data_ptr() if ws is not None else None, _s(qkv))
         _lib.check(st, "ts_w2v_attention_train_fwd")
         ctx.save_for_backward(q16, out, lse2, key_len)
         ctx.geom = (b, t, c, heads, float(p_drop), int(seed))

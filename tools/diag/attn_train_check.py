@@ -17,7 +17,8 @@ for (b, t, heads, p, ragged) in [(2, 130, 4, 0.0, False), (3, 499, 4, 0.0, True)
     q16 = qkv.detach().to(torch.bfloat16).contiguous()
     ctx = torch.empty(b, t, c, device="cuda"); lse2 = torch.empty(b, heads, t, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    rc = L.ts_w2v_attention_train_fwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, p, seed, ctx.data_ptr(), lse2.data_ptr(), st)
+    wsf = torch.empty(L.ts_w2v_attention_train_fwd_workspace(b, t, c, heads), dtype=torch.uint8, device='cuda')
+    rc = L.ts_w2v_attention_train_fwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, p, seed, ctx.data_ptr(), lse2.data_ptr(), wsf.data_ptr(), st)
     torch.cuda.synchronize()
     err = float((ctx - ref).abs().max()) / float(ref.abs().max())
     rel = float((ctx - ref).norm() / ref.norm())
