@@ -601,7 +601,8 @@ int ts_w2v_attention_fwd(const void* qkv, int32_t batch, int32_t t, int32_t c, i
  *                                Philox block e >> 2 under `seed`), kept entries scaled by 1 / (1 - p_drop); drawn once per call as a bitstring into `workspace`
  *                                (ts_w2v_attention_train_fwd_workspace bytes; unused and may be NULL when p_drop = 0).
  *   ts_w2v_attention_train_bwd   dqkv f32 [B][t][3c] (every element written) from dctx f32 [B][t][c], ctx, lse2 and the same qkv / key_len / p_drop / seed;
- *                                workspace: ts_w2v_attention_train_bwd_workspace bytes (bf16 copy of dctx, the row sums D, the re-drawn mask bits).  Two launches
+ *                                fwd_mask: the forward call's workspace if the caller kept it, else NULL (the mask is then re-drawn from the seed);
+ *                                workspace: ts_w2v_attention_train_bwd_workspace bytes (bf16 copy of dctx, the row sums D, room for the mask bits).  Two launches
  *                                that each rebuild the probabilities: no atomics, fixed summation order.
  * key_len[b] <= 0 (no valid key): every probability of the clip is 0, ctx = 0 and all three gradients 0 -- ts_w2v_softmax_fwd's convention.
  * TS_EUNSUPPORTED unless c / heads == 64. */
@@ -610,7 +611,7 @@ int ts_w2v_attention_train_fwd(const void* qkv_bf16, int32_t batch, int32_t t, i
                                uint64_t seed, float* ctx, float* lse2, void* workspace, void* stream);
 int64_t ts_w2v_attention_train_bwd_workspace(int32_t batch, int32_t t, int32_t c, int32_t heads);
 int ts_w2v_attention_train_bwd(const void* qkv_bf16, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len, float p_drop,
-                               uint64_t seed, const float* dctx, const float* ctx, const float* lse2, float* dqkv, void* workspace, void* stream);
+                               uint64_t seed, const float* dctx, const float* ctx, const float* lse2, const void* fwd_mask, float* dqkv, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The steps either side of the hot path, on the device.

@@ -363,3 +363,28 @@ def test_mixed_precision_positional_conv_matches_the_f32_path_forward_and_backwa
     torch.cuda.synchronize()
     assert torch.equal(out16, m.to(torch.bfloat16))
     assert float((cs - m.sum(0)).abs().max()) <= 1e-3
+
+
+def test_fused_attention_backward_gives_the_same_bits_with_the_kept_and_the_redrawn_mask():
+    """ts_w2v_attention_train_bwd(fwd_mask = the forward's workspace) against fwd_mask = NULL (the mask re-drawn from the seed): the same dqkv, bit for bit."""
+    import ctypes as C
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(2)
+    b, t, heads, p, seed = 2, 211, 3, 0.2, 77
+    c = 64 * heads
+    st = torch.cuda.current_stream().cuda_stream
+    q16 = torch.randn(b, t, 3 * c, device="cuda").to(torch.bfloat16)
+    dout = torch.randn(b, t, c, device="cuda")
+    ctx_, lse2 = torch.empty(b, t, c, device="cuda"), torch.empty(b, heads, t, device="cuda")
+    wsf = torch.empty(L.ts_w2v_attention_train_fwd_workspace(b, t, c, heads), dtype=torch.uint8, device="cuda")
+    assert L.ts_w2v_attention_train_fwd(q16.data_ptr(), b, t, c, heads, None, p, seed, ctx_.data_ptr(), lse2.data_ptr(), wsf.data_ptr(), st) == 0
+    outs = []
+    for mask in (wsf, None):
+        ws = torch.empty(L.ts_w2v_attention_train_bwd_workspace(b, t, c, heads), dtype=torch.uint8, device="cuda")
+        dqkv = torch.full((b, t, 3 * c), float("nan"), device="cuda")
+        assert L.ts_w2v_attention_train_bwd(q16.data_ptr(), b, t, c, heads, None, p, seed, dout.data_ptr(), ctx_.data_ptr(), lse2.data_ptr(),
+                                            mask.data_ptr() if mask is not None else None, dqkv.data_ptr(), ws.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        outs.append(dqkv)
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())

@@ -142,7 +142,7 @@ def lib() -> C.CDLL:
     L.ts_w2v_posconv_train.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.ts_w2v_attention_train_bwd_workspace.argtypes = [i32, i32, i32, i32]
     L.ts_w2v_attention_train_bwd_workspace.restype = i64
-    L.ts_w2v_attention_train_bwd.argtypes = [vp, i32, i32, i32, i32, vp, f32, C.c_uint64, vp, vp, vp, vp, vp, vp]
+    L.ts_w2v_attention_train_bwd.argtypes = [vp, i32, i32, i32, i32, vp, f32, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     L.ts_w2v_mask_rows.argtypes = [vp, i32, i32, i32, vp, vp]
     L.ts_w2v_posconv_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.ts_w2v_posconv_workspace_bytes.restype = i64

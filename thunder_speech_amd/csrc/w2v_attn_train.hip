@@ -511,7 +511,8 @@ extern "C" int64_t ts_w2v_attention_train_bwd_workspace(int32_t batch, int32_t t
 
 /* see include/thunder_speech_amd.h */
 extern "C" int ts_w2v_attention_train_bwd(const void* qkv_bf16, int32_t batch, int32_t t, int32_t c, int32_t heads, const int32_t* key_len, float p_drop,
-                                          uint64_t seed, const float* dctx, const float* ctx, const float* lse2, float* dqkv, void* workspace, void* stream_) {
+                                          uint64_t seed, const float* dctx, const float* ctx, const float* lse2, const void* fwd_mask, float* dqkv, void* workspace,
+                                          void* stream_) {
   if (int st = ta_check(qkv_bf16, batch, t, c, heads, p_drop)) return st;
   if (!dctx || !ctx || !lse2 || !dqkv || !workspace) return TS_EINVAL;
   if ((reinterpret_cast<uintptr_t>(dctx) & 15) || (reinterpret_cast<uintptr_t>(ctx) & 15) || (reinterpret_cast<uintptr_t>(dqkv) & 15) ||
@@ -527,7 +528,8 @@ extern "C" int ts_w2v_attention_train_bwd(const void* qkv_bf16, int32_t batch, i
   a.scale = 1.f / sqrtf(64.f); a.scale_log2e = 1.4426950408889634f * a.scale;
   a.p_drop = p_drop; a.keep_scale = 1.f / (1.f - p_drop); a.seed = seed;
   (void)hipGetLastError();
-  if (p_drop > 0.f) {                                // the backward re-draws the forward's mask (a pure function of the seed) instead of keeping 4 MB per layer
+  if (p_drop > 0.f && fwd_mask) a.mask = static_cast<const unsigned*>(fwd_mask);      // the forward's workspace, kept by the caller (4 MB per layer at 8 x 10 s)
+  else if (p_drop > 0.f) {                           // or re-drawn: the mask is a pure function of the seed
     unsigned* const mask = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dsum) + ((int64_t)batch * heads * t * 4 + 15) / 16 * 16);
     ta_draw_mask(mask, batch, t, heads, seed, p_drop, stream);
     a.mask = mask;

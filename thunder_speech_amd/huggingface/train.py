@@ -394,20 +394,20 @@ class AttentionFused(torch.autograd.Function):
         st = L.ts_w2v_attention_train_fwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, float(p_drop), int(seed),
                                           out.data_ptr(), lse2.data_ptr(), ws.data_ptr() if ws is not None else None, _s(qkv))
         _lib.check(st, "ts_w2v_attention_train_fwd")
-        ctx.save_for_backward(q16, out, lse2, key_len)
+        ctx.save_for_backward(q16, out, lse2, key_len, ws)                       # ws: the mask bits (the backward would re-draw them otherwise)
         ctx.geom = (b, t, c, heads, float(p_drop), int(seed))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q16, out, lse2, key_len = ctx.saved_tensors
+        q16, out, lse2, key_len, mask = ctx.saved_tensors
         b, t, c, heads, p_drop, seed = ctx.geom
         dout = _f32c(dout)
         L = _lib.lib()
         ws = torch.empty(L.ts_w2v_attention_train_bwd_workspace(b, t, c, heads), dtype=torch.uint8, device=dout.device)
         dqkv = torch.empty(b, t, 3 * c, dtype=torch.float32, device=dout.device)
         st = L.ts_w2v_attention_train_bwd(q16.data_ptr(), b, t, c, heads, key_len.data_ptr() if key_len is not None else None, p_drop, seed, dout.data_ptr(),
-                                          out.data_ptr(), lse2.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), _s(dout))
+                                          out.data_ptr(), lse2.data_ptr(), mask.data_ptr() if mask is not None else None, dqkv.data_ptr(), ws.data_ptr(), _s(dout))
         _lib.check(st, "ts_w2v_attention_train_bwd")
         return dqkv, None, None, None, None
 

@@ -37,7 +37,7 @@ for (b, t, heads, p, ragged) in [(2, 130, 4, 0.0, False), (3, 499, 4, 0.0, True)
         ws = torch.empty(L.ts_w2v_attention_train_bwd_workspace(b, t, c, heads), dtype=torch.uint8, device="cuda")
         dqkv = torch.full_like(qkv.detach(), float("nan"))
         rc = L.ts_w2v_attention_train_bwd(C.c_void_p(q16.data_ptr()), b, t, c, heads, C.c_void_p(key_len.data_ptr() if key_len is not None else None), C.c_float(p), C.c_uint64(seed),
-                                          C.c_void_p(dout.data_ptr()), C.c_void_p(ctx.data_ptr()), C.c_void_p(lse2.data_ptr()), C.c_void_p(dqkv.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_void_p(st))
+                                          C.c_void_p(dout.data_ptr()), C.c_void_p(ctx.data_ptr()), C.c_void_p(lse2.data_ptr()), C.c_void_p(None), C.c_void_p(dqkv.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_void_p(st))
         torch.cuda.synchronize()
         for name, sl in (("dq", slice(0, c)), ("dk", slice(c, 2 * c)), ("dv", slice(2 * c, 3 * c))):
             g, r = dqkv[..., sl], dref[..., sl]
