@@ -577,6 +577,10 @@ int ts_w2v_posconv_fwd(const float* x, int32_t batch, int32_t t, int32_t c, cons
 int64_t ts_w2v_posconv_train_workspace(int32_t batch, int32_t t, int32_t c, int32_t kernel);
 int ts_w2v_posconv_train(const float* src, const float* res, int32_t batch, int32_t t, int32_t c, const void* w_taps_bf16, const float* bias, int32_t kernel,
                          int32_t groups, int32_t backward, float* y, float* z, void* workspace, void* stream);
+/* and its weight gradient: dw[j][g][o][i] = sum_b sum_t dz[b][t][64 g + o] x[b][t + j - kernel / 2][64 g + i] (frames outside [0, t) count as 0), dw f32
+ * [kernel][groups][64][64] (written, not accumulated), dz and x f32 [B][t][c]; bf16 operands, f32 accumulation, one workgroup per (8 taps, group): no atomics. */
+int64_t ts_w2v_posconv_wgrad_workspace(int32_t batch, int32_t t, int32_t c, int32_t kernel);
+int ts_w2v_posconv_wgrad(const float* dz, const float* x, int32_t batch, int32_t t, int32_t c, int32_t kernel, int32_t groups, float* dw, void* workspace, void* stream);
 /* the conv of ONE layer of Data2VecAudioPositionalConvEmbedding (transformers modeling_data2vec_audio.py, reached from
  * huggingface/compatibility.py:31-42 when the checkpoint is a data2vec-audio one -- tests/huggingface/test_module_huggingface.py:107-110):
  * y = Conv1d(c, c, kernel, padding = kernel / 2, groups)(x) + bias, last frame of an even kernel dropped; its LayerNorm (no affine) + GELU

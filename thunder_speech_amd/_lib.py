@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_dwconv_bwd_select", "ts_train_set_deterministic", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_workspace", "ts_train_pwconv_wgrad_mfma", "ts_train_pwconv_wgrad_multi", "ts_train_pwconv_wgrad_multi_parts", "ts_train_wgrad_reduce_multi",
     "ts_train_cast_bf16", "ts_train_bn_fwd", "ts_train_bn_bwd", "ts_train_add_relu_fwd", "ts_train_relu_bwd",
     "ts_train_bn_stats", "ts_train_dwconv_fwd_bn", "ts_train_dwconv_fwd_bn_tiles", "ts_tcs_pointwise_tile_frames", "ts_tcs_pointwise_wide", "ts_train_dwconv_bwd_bn", "ts_train_bn_bwd_sums", "ts_train_bn2_add_relu_fwd", "ts_train_bn2_add_relu_chan_fwd", "ts_train_bn2_chan_bwd",
-    "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd", "ts_w2v_posconv_train_workspace", "ts_w2v_posconv_train", "ts_w2v_attention_train_fwd_workspace", "ts_w2v_attention_train_fwd", "ts_w2v_attention_train_bwd_workspace", "ts_w2v_attention_train_bwd",
+    "ts_w2v_conv0_workspace_bytes", "ts_w2v_conv0_fwd", "ts_w2v_conv_fwd", "ts_w2v_linear_fwd", "ts_w2v_layernorm_fwd", "ts_w2v_posconv_train_workspace", "ts_w2v_posconv_train", "ts_w2v_posconv_wgrad_workspace", "ts_w2v_posconv_wgrad", "ts_w2v_attention_train_fwd_workspace", "ts_w2v_attention_train_fwd", "ts_w2v_attention_train_bwd_workspace", "ts_w2v_attention_train_bwd",
     "ts_w2v_mask_rows", "ts_w2v_posconv_workspace_bytes", "ts_w2v_posconv_fwd", "ts_w2v_groupconv_fwd", "ts_w2v_glu_fwd", "ts_w2v_attention_workspace_bytes",
     "ts_w2v_attention_fwd",
     "ts_spec_masks_draw", "ts_spec_mask_apply", "ts_train_dropout", "ts_counter_add", "ts_train_add", "ts_train_act_import", "ts_train_act_export",
@@ -140,6 +140,9 @@ def lib() -> C.CDLL:
     L.ts_w2v_posconv_train_workspace.argtypes = [i32, i32, i32, i32]
     L.ts_w2v_posconv_train_workspace.restype = i64
     L.ts_w2v_posconv_train.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.ts_w2v_posconv_wgrad_workspace.argtypes = [i32, i32, i32, i32]
+    L.ts_w2v_posconv_wgrad_workspace.restype = i64
+    L.ts_w2v_posconv_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.ts_w2v_attention_train_bwd_workspace.argtypes = [i32, i32, i32, i32]
     L.ts_w2v_attention_train_bwd_workspace.restype = i64
     L.ts_w2v_attention_train_bwd.argtypes = [vp, i32, i32, i32, i32, vp, f32, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]

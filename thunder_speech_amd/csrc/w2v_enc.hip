@@ -780,6 +780,127 @@ __global__ __launch_bounds__(256) void posconv_pad16_kernel(const float* __restr
 }
 }  // namespace ts
 
+namespace ts {
+// Weight gradient of the positional conv on the matrix cores (mixed-precision fine-tuning):
+//   dW[j][g][o][i] = sum_b sum_t dz[b][t][64 g + o] xp[b][t + j][64 g + i],   xp = x behind kernel / 2 zero rows per clip (the forward's padded copy)
+// -- for one (group, tap) a 64 x 64 product contracted over all B T frames; the f32 GEMM of round 5 needed 2.6 ms for the 2 048 of them.  Workgroup =
+// (8 taps, group), four waves of two taps each; a stage is 128 frames of one clip: the dz tile [128][64] and the xp window [128 + 8][64] (shared by the
+// eight taps) in LDS as bf16, both operands out of them with transposing reads (rows = the contraction index t), v_mfma_f32_32x32x16_bf16, 128 f32
+// accumulators per lane; the next stage's rows travel global -> registers while the current one is multiplied.  256 workgroups, each owning its
+// outputs: no partials, no atomics.
+constexpr int PW_TT = 128, PW_TAPS = 8, PW_WIN = PW_TT + PW_TAPS;
+struct PwArgs {
+  const unsigned short* dz;        // [B][T][C] bf16
+  const unsigned short* xp;        // [B][T + k][C] bf16
+  float* dw;                       // [k][G][64][64]
+  int batch, t, c, k, groups;
+};
+__global__ __launch_bounds__(256) void w2v_posconv_wgrad_kernel(const PwArgs a) {
+  __shared__ __attribute__((aligned(16))) char dzs[PW_TT * PC_PITCH];
+  __shared__ __attribute__((aligned(16))) char xps[PW_WIN * PC_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j0 = blockIdx.x * PW_TAPS, g = blockIdx.y;
+  const int prow = a.t + a.k, n_ch = (a.t + PW_TT - 1) / PW_TT, S = a.batch * n_ch;
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][mo][ni][r] = 0.f;
+  // staging: 16-byte chunks; the dz tile is 128 x 8 chunks = 4 per thread, the xp window 136 x 8 = 1 088 chunks = 4.25 per thread
+  uint4 rz[4], rx[5];
+  auto fetch = [&](int s) {
+    const int b = s / n_ch, t0 = (s % n_ch) * PW_TT;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int chunk = tid + 256 * q, r = chunk >> 3, cc = chunk & 7;
+      rz[q] = (t0 + r < a.t) ? *reinterpret_cast<const uint4*>(a.dz + ((size_t)b * a.t + t0 + r) * a.c + (size_t)g * 64 + cc * 8) : uint4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int chunk = tid + 256 * q, r = chunk >> 3, cc = chunk & 7;
+      const int row = t0 + j0 + r;                        // row of the clip's padded copy
+      rx[q] = (chunk < PW_WIN * 8 && row < prow) ? *reinterpret_cast<const uint4*>(a.xp + ((size_t)b * prow + row) * a.c + (size_t)g * 64 + cc * 8) : uint4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int chunk = tid + 256 * q; *reinterpret_cast<uint4*>(dzs + (chunk >> 3) * PC_PITCH + (chunk & 7) * 16) = rz[q]; }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { const int chunk = tid + 256 * q; if (chunk < PW_WIN * 8) *reinterpret_cast<uint4*>(xps + (chunk >> 3) * PC_PITCH + (chunk & 7) * 16) = rx[q]; }
+  };
+  const int half = lane >> 5, q4 = (lane >> 2) & 3, gq = (lane >> 4) & 1, p4 = lane & 3;
+  const int tr_off = (8 * half + q4) * PC_PITCH + (16 * gq + 4 * p4) * 2;        // transposing read: rows = contraction index, columns = M / N index
+  auto tr8 = [&](const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((TS_LDS s16x4*)((TS_LDS char*)p + 4 * PC_PITCH));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  if (S > 0) fetch(0);
+  for (int s = 0; s < S; ++s) {
+    __syncthreads();                                       // the previous stage has been multiplied
+    stage();
+    __syncthreads();
+    if (s + 1 < S) fetch(s + 1);
+#pragma unroll
+    for (int ks = 0; ks < PW_TT / 16; ++ks) {
+      s16x8 af[2], bf[2][2];
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo) af[mo] = tr8(dzs + 16 * ks * PC_PITCH + tr_off + 64 * mo);
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[tp][ni] = tr8(xps + (16 * ks + 2 * wave + tp) * PC_PITCH + tr_off + 64 * ni);
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[tp][mo][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mo], bf[tp][ni], acc[tp][mo][ni], 0, 0, 0);
+    }
+  }
+  // accumulator register r of block (mo, ni): o = 32 mo + (r & 3) + 8 (r >> 2) + 4 half, i = 32 ni + lane % 32
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp) {
+    const int j = j0 + 2 * wave + tp;
+    if (j >= a.k) continue;
+    float* const out = a.dw + ((size_t)j * a.groups + g) * 64 * 64;
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(size_t)(32 * mo + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 * ni + (lane & 31)] = acc[tp][mo][ni][r];
+  }
+}
+}  // namespace ts
+
+extern "C" int64_t ts_w2v_posconv_wgrad_workspace(int32_t batch, int32_t t, int32_t c, int32_t kernel) {
+  if (batch <= 0 || t <= 0 || c <= 0 || kernel <= 0) return TS_EINVAL;
+  return (((int64_t)batch * (t + kernel) + 1) * c * 2 + 15) / 16 * 16 + ((int64_t)batch * t + 1) * c * 2;
+}
+
+/* dw[j][g][o][i] = sum over clips and frames of dz[..][64 g + o] * x[.. + j - kernel / 2][64 g + i]; see include/thunder_speech_amd.h */
+extern "C" int ts_w2v_posconv_wgrad(const float* dz, const float* x, int32_t batch, int32_t t, int32_t c, int32_t kernel, int32_t groups, float* dw, void* workspace,
+                                    void* stream_) {
+  if (!dz || !x || !dw || !workspace || batch <= 0 || t <= 0 || c <= 0 || kernel <= 0 || groups <= 0 || c % groups) return TS_EINVAL;
+  if (c / groups != 64 || c % 4 || (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(dz) & 15) || (reinterpret_cast<uintptr_t>(x) & 15))
+    return TS_EUNSUPPORTED;
+  TS_STREAM;
+  const int prow = t + kernel;
+  unsigned short* const xp = static_cast<unsigned short*>(workspace);
+  unsigned short* const dz16 = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + (((int64_t)batch * prow + 1) * c * 2 + 15) / 16 * 16);
+  const long long total_x = ((long long)batch * prow + 1) * c, total_z = ((long long)batch * t + 1) * c;
+  hipLaunchKernelGGL(posconv_pad16_kernel, dim3((unsigned)((total_x / 4 + 255) / 256)), dim3(256), 0, stream, x, xp, t, c, prow, kernel / 2, total_x);
+  hipLaunchKernelGGL(posconv_pad16_kernel, dim3((unsigned)((total_z / 4 + 255) / 256)), dim3(256), 0, stream, dz, dz16, t, c, t, 0, total_z);
+  PwArgs a{dz16, xp, dw, batch, t, c, kernel, groups};
+  hipLaunchKernelGGL(w2v_posconv_wgrad_kernel, dim3((kernel + PW_TAPS - 1) / PW_TAPS, groups), dim3(256), 0, stream, a);
+  return hip_status(hipGetLastError());
+}
+
 extern "C" int64_t ts_w2v_posconv_train_workspace(int32_t batch, int32_t t, int32_t c, int32_t kernel) {
   if (batch <= 0 || t <= 0 || c <= 0 || kernel <= 0) return TS_EINVAL;
   return ((int64_t)batch * (t + kernel) + 1) * c * 2;

@@ -478,18 +478,16 @@ class PosConvGelu(torch.autograd.Function):
         L = _lib.lib()
         tp = t + k
         m = b * tp - k
-        if ctx.mixed:                                    # the node kept x, not its padded copy
-            x = xp
-            xp = torch.empty(b, tp, c, dtype=torch.float32, device=x.device)
-            _lib.check(L.ts_w2v_pad_rows(x.data_ptr(), xp.data_ptr(), b, t, tp, k // 2, c, 0, _s(x)), "ts_w2v_pad_rows")
+        x = xp if ctx.mixed else None                    # (mixed mode: the node kept x, not its padded copy)
         dz = torch.empty_like(dy)
         _lib.check(L.ts_w2v_gelu_bwd(z.data_ptr(), bias.data_ptr(), c, dy.data_ptr(), dz.data_ptr(), dz.numel(), _s(dy)), "ts_w2v_gelu_bwd")
         db = _colsum(dz, b * t, c) if ctx.needs_input_grad[2] else None
-        # d zp in the padded row space behind k - 1 zero rows: dbuf[k - 1 + r] = d zp[r]
-        dbuf = torch.empty((k - 1) + b * tp, c, dtype=torch.float32, device=dy.device)
-        dbuf[: k - 1].zero_()
-        dzp = dbuf[k - 1:].view(b, tp, c)
-        _lib.check(L.ts_w2v_pad_rows(dz.data_ptr(), dzp.data_ptr(), b, t, tp, 0, c, 0, _s(dy)), "ts_w2v_pad_rows")
+        if not ctx.mixed:
+            # d zp in the padded row space behind k - 1 zero rows: dbuf[k - 1 + r] = d zp[r]
+            dbuf = torch.empty((k - 1) + b * tp, c, dtype=torch.float32, device=dy.device)
+            dbuf[: k - 1].zero_()
+            dzp = dbuf[k - 1:].view(b, tp, c)
+            _lib.check(L.ts_w2v_pad_rows(dz.data_ptr(), dzp.data_ptr(), b, t, tp, 0, c, 0, _s(dy)), "ts_w2v_pad_rows")
         dx = dwk = None
         if ctx.needs_input_grad[0] and ctx.mixed:
             # dx = dy + conv^T(dz): the same matrix-core kernel over dz with the taps flipped and each tap's [out][in] block transposed
@@ -507,7 +505,12 @@ class PosConvGelu(torch.autograd.Function):
             _lib.check(L.ts_w2v_pad_rows(dxp.data_ptr(), dconv.data_ptr(), b, t, tp, k // 2, c, 1, _s(dy)), "ts_w2v_pad_rows")
             dx = torch.empty_like(dy)
             _lib.check(L.ts_w2v_add(dy.data_ptr(), dconv.data_ptr(), dx.data_ptr(), dy.numel(), _s(dy)), "ts_w2v_add")
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.mixed:
+            # the same sums on the matrix cores (bf16 operands): one workgroup per (8 taps, group), no partials
+            dwk = torch.empty_like(wk)
+            ws = torch.empty(L.ts_w2v_posconv_wgrad_workspace(b, t, c, k), dtype=torch.uint8, device=dy.device)
+            _lib.check(L.ts_w2v_posconv_wgrad(dz.data_ptr(), x.data_ptr(), b, t, c, k, g, dwk.data_ptr(), ws.data_ptr(), _s(dy)), "ts_w2v_posconv_wgrad")
+        elif ctx.needs_input_grad[1]:
             # d wk[j][g][o][i] = sum_r d zp[r][g cg + o] xp[r + j][g cg + i]   (rows between the clips hold d zp = 0)
             dwk = torch.empty_like(wk)
             _gemm(dzp, 1, c, xp, c, 1, dwk, cg, cg, cg, m, sa=cg, sa2=0, sb=cg, sb2=c, sc=cg * cg, sc2=g * cg * cg, batch=g, batch2=k)
