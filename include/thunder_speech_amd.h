@@ -145,6 +145,10 @@ int ts_gemm_f32_b2(const void* a, int64_t a_rs, int64_t a_cs, int64_t sa, int64_
 int64_t ts_w2v_layernorm_bwd_workspace(int64_t rows, int32_t c);
 int ts_w2v_layernorm_bwd(const float* x, const float* res, const float* gamma, const float* dy, float eps, int64_t rows, int32_t c, float* dx,
                          float* dgamma, float* dbeta, void* workspace, void* stream);
+/* The same with dgamma / dbeta WRITTEN instead of added to (the first launch zeroes them, ONE reducing launch adds the partials of both): callers that hand in fresh
+ * gradient tensors need no zero fill. */
+int ts_w2v_layernorm_bwd_set(const float* x, const float* res, const float* gamma, const float* dy, float eps, int64_t rows, int32_t c, float* dx,
+                             float* dgamma, float* dbeta, void* workspace, void* stream);
 int ts_w2v_colsum(const float* x, int64_t rows, int32_t c, int64_t ld, float* out, void* stream);
 /* Operand casts of the MIXED-PRECISION fine-tuning products (ABI v11; the reference under Lightning's precision="bf16-mixed": f32 master weights,
  * f32 gradients, bf16 GEMM operands): x f32 [rows][c] (pitch ldx) -> y bf16 [rows][c] (pitch ldy) and / or yt bf16 [c][rows_pad] (pitch ldt), the

@@ -42,9 +42,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ part, long long rows,
-                                                     int c, float eps) {
+                                                     int c, float eps, float* __restrict__ zero_a = nullptr, float* __restrict__ zero_b = nullptr) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  if (zero_a && blockIdx.x == 0)                     // ts_w2v_layernorm_bwd_set: the reducing launch behind this one adds with atomics -- its destinations are zeroed here
+    for (int i = threadIdx.x; i < c; i += 256) { zero_a[i] = 0.f; zero_b[i] = 0.f; }
   f32x4 dg[NV], db[NV], gm[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -347,6 +349,39 @@ extern "C" int ts_w2v_layernorm_bwd(const float* x, const float* res, const floa
   const dim3 cg((c + 63) / 64, 16);
   hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, stream, part, dgamma, waves, c, (long long)2 * c);
   hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, stream, part + c, dbeta, waves, c, (long long)2 * c);
+  return hip_status(hipGetLastError());
+}
+
+namespace ts {
+// dgamma[j] / dbeta[j] += sums over the partial rows of ts_w2v_layernorm_bwd's workspace [waves][2][c] (blockIdx.z: 0 = dgamma, 1 = dbeta; blockIdx.y: a slice of
+// the rows): ONE launch for both instead of two ts_w2v_colsum launches; the destinations were zeroed by ln_bwd_kernel (no fill launches).  (A single block per
+// column group with plain stores was built first: 1 024 dependent-latency loads per thread, 65 us per launch instead of 12.)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, long long waves, int c) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const float* const p = part + (size_t)blockIdx.z * c;
+  float s = 0.f;
+  if (col < c)
+    for (long long r = (long long)blockIdx.y * 4 + rg; r < waves; r += (long long)gridDim.y * 4) s += p[r * 2 * c + col];
+  __shared__ float sm[4][64];
+  sm[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && col < c) atomicAdd((blockIdx.z ? dbeta : dgamma) + col, (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]));
+}
+}  // namespace ts
+
+/* ts_w2v_layernorm_bwd with dgamma / dbeta WRITTEN (not added to): no zero fill by the caller, one reducing launch for both; see include/thunder_speech_amd.h */
+extern "C" int ts_w2v_layernorm_bwd_set(const float* x, const float* res, const float* gamma, const float* dy, float eps, int64_t rows, int32_t c, float* dx,
+                                        float* dgamma, float* dbeta, void* workspace, void* stream_) {
+  if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || c <= 0) return TS_EINVAL;
+  if (c % 4 || c > 4096 || !al16(x) || !al16(dy) || !al16(dx) || !al16(gamma) || (res && !al16(res)) || !al16(workspace)) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  const long long waves = (rows < 4096 ? (rows + 3) / 4 * 4 : 4096);
+  float* part = static_cast<float*>(workspace);
+  const dim3 grid((unsigned)(waves / 4));
+#define TS_LNB(NV_) hipLaunchKernelGGL(ln_bwd_kernel<NV_>, grid, dim3(256), 0, stream, x, res, gamma, dy, dx, part, (long long)rows, c, eps, dgamma, dbeta)
+  if (c <= 512) TS_LNB(2); else if (c <= 1024) TS_LNB(4); else if (c <= 2048) TS_LNB(8); else TS_LNB(16);
+#undef TS_LNB
+  hipLaunchKernelGGL(ts::ln_bwd_reduce_kernel, dim3((c + 63) / 64, 16, 2), dim3(256), 0, stream, part, dgamma, dbeta, waves, c);
   return hip_status(hipGetLastError());
 }
 
