@@ -15,7 +15,8 @@ agg = collections.defaultdict(lambda: [0, 0])
 for r in rows:
     a = agg[r["Kernel_Name"][:90]]; a[0] += 1; a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(v[1] for v in agg.values()); span = int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])
-print("launches", len(rows) / 5, "per step; kernel ms/step", tot / 5e6, "span ms/step", span / 5e6)
+N = 12   # timed steps of the mixed-precision run (tools/bench_extra.py c5_finetune)
+print("launches", len(rows) / N, "per step; kernel ms/step", tot / N / 1e6, "span ms/step", span / N / 1e6)
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
-    print(f"{v[0] / 5:7.1f} x {v[1] / v[0] / 1e3:8.1f} us = {v[1] / 5e6:7.2f} ms  {k}")
+    print(f"{v[0] / N:7.1f} x {v[1] / v[0] / 1e3:8.1f} us = {v[1] / N / 1e6:7.2f} ms  {k}")
 PY
