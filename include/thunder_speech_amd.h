@@ -154,6 +154,13 @@ int ts_w2v_colsum(const float* x, int64_t rows, int32_t c, int64_t ld, float* ou
  * f32 gradients, bf16 GEMM operands): x f32 [rows][c] (pitch ldx) -> y bf16 [rows][c] (pitch ldy) and / or yt bf16 [c][rows_pad] (pitch ldt), the
  * transposed copy with its rows index zero-padded to rows_pad (a multiple of 32: ts_gemm_nt_bf16's contraction index).  Either output may be NULL. */
 int ts_w2v_cast_bf16_t(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad, void* stream);
+/* The activation between the feed-forward linears of mixed-precision fine-tuning fused with the second linear's operand cast (transformers Wav2Vec2FeedForward:
+ * intermediate_dense -> GELU -> dropout -> output_dense): y16[r][j] = bf16(dropout(gelu(z[r][j] + bias[j]))) and / or its transposed copy yt16 (as ts_w2v_cast_bf16_t:
+ * rows >= `rows` zero up to rows_pad) -- the f32 activation is never stored.  Dropout: ts_train_dropout's mask over the dense [rows][c] matrix under `seed`
+ * (p_drop = 0: none); c % 4 == 0.  ts_w2v_ffn_act_bwd: dz = dropout_backward(da) * gelu'(z + bias) with the mask re-drawn. */
+int ts_w2v_ffn_act_cast(const float* z, const float* bias, int64_t rows, int32_t c, float p_drop, uint64_t seed, void* y_bf16, void* yt_bf16, int64_t ldt, int64_t rows_pad,
+                        void* stream);
+int ts_w2v_ffn_act_bwd(const float* z, const float* bias, int32_t c, const float* da, float p_drop, uint64_t seed, float* dz, int64_t n, void* stream);
 /* The same launch also ADDING the column sums of x to colsum (f32 [c]; NULL: none): the bias gradient of a linear layer is the column sum of the dy being cast. */
 int ts_w2v_cast_bf16_t_colsum(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad, float* colsum,
                               void* stream);

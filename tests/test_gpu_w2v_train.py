@@ -388,3 +388,40 @@ def test_fused_attention_backward_gives_the_same_bits_with_the_kept_and_the_redr
         torch.cuda.synchronize()
         outs.append(dqkv)
     assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+
+
+@pytest.mark.parametrize("rows_shape,k,n,p", [((2, 130), 256, 128, 0.1), ((3, 499), 4096, 1024, 0.1), ((1, 77), 512, 96, 0.0)])
+def test_fused_feed_forward_activation_node_equals_the_three_separate_nodes(rows_shape, k, n, p):
+    """FFNActLinear (gelu + dropout + the second linear's operand cast in one launch, ts_w2v_ffn_act_cast; dropout-backward x gelu' in one launch,
+    ts_w2v_ffn_act_bwd) against BiasGelu -> Dropout -> LinearMixed with the same seed: the same bf16 operands, so the same output and the same gradients
+    (bit for bit for y, dz, dw; the bias gradients are atomic sums: 1e-5)."""
+    from thunder_speech_amd.huggingface import train as T
+    torch.manual_seed(k + n)
+    z = torch.randn(*rows_shape, k, device="cuda")
+    b1 = torch.randn(k, device="cuda") * 0.1
+    w2 = torch.randn(n, k, device="cuda") * k ** -0.5
+    b2 = torch.randn(n, device="cuda") * 0.1
+    dy = torch.randn(*rows_shape, n, device="cuda")
+    seed = 424242
+    res = []
+    old = T._MIXED
+    T._MIXED = True
+    try:
+        for fused in (True, False):
+            zi, b1i, w2i, b2i = (t_.clone().requires_grad_(True) for t_ in (z, b1, w2, b2))
+            if fused:
+                y = T.FFNActLinear.apply(zi, b1i, w2i, b2i, p, seed)
+            else:
+                a = T.BiasGelu.apply(zi, b1i)
+                a = T.Dropout.apply(a, p, seed) if p > 0 else a
+                y = T.LinearMixed.apply(a, w2i, b2i)
+            y.backward(dy)
+            res.append((y.detach(), zi.grad, w2i.grad, b1i.grad, b2i.grad))
+    finally:
+        T._MIXED = old
+    torch.cuda.synchronize()
+    for i in (0, 1, 2):
+        assert torch.equal(res[0][i], res[1][i]), i
+    for i in (3, 4):
+        assert torch.allclose(res[0][i], res[1][i], rtol=1e-5, atol=1e-5 * float(res[1][i].abs().max()))
+    assert float(res[0][1].abs().sum()) > 0

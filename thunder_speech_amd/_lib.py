@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "ts_abi_version", "ts_build_target", "ts_time_pitch", "ts_tcs_subblock_fwd",
     "ts_frontend_workspace_bytes", "ts_mel_frontend_fwd", "ts_frontend_logmel_ptr",
     "ts_greedy_decode", "ts_ctc_workspace_bytes", "ts_ctc_loss", "ts_ctc_prepare",
-    "ts_pack_activation", "ts_unpack_activation", "ts_lengths_map", "ts_im2col_time", "ts_fe_preemph", "ts_fe_dither", "ts_fe_power_spectrum", "ts_fe_stft", "ts_fe_mel", "ts_fe_normalize", "ts_gemm_nt_bf16", "ts_gemm_nt_pack_w", "ts_gemm_nt_bf16_packed", "ts_gemm_f32", "ts_gemm_f32_b2", "ts_w2v_layernorm_bwd_workspace", "ts_w2v_layernorm_bwd", "ts_w2v_layernorm_bwd_set", "ts_w2v_colsum", "ts_w2v_cast_bf16_t", "ts_w2v_cast_bf16_t_colsum", "ts_w2v_sum_parts", "ts_w2v_sum_parts_bias", "ts_gemm_nt_bf16_splitk", "ts_w2v_gelu_fwd", "ts_w2v_gelu_bwd",
+    "ts_pack_activation", "ts_unpack_activation", "ts_lengths_map", "ts_im2col_time", "ts_fe_preemph", "ts_fe_dither", "ts_fe_power_spectrum", "ts_fe_stft", "ts_fe_mel", "ts_fe_normalize", "ts_gemm_nt_bf16", "ts_gemm_nt_pack_w", "ts_gemm_nt_bf16_packed", "ts_gemm_f32", "ts_gemm_f32_b2", "ts_w2v_layernorm_bwd_workspace", "ts_w2v_layernorm_bwd", "ts_w2v_layernorm_bwd_set", "ts_w2v_colsum", "ts_w2v_cast_bf16_t", "ts_w2v_cast_bf16_t_colsum", "ts_w2v_ffn_act_cast", "ts_w2v_ffn_act_bwd", "ts_w2v_sum_parts", "ts_w2v_sum_parts_bias", "ts_gemm_nt_bf16_splitk", "ts_w2v_gelu_fwd", "ts_w2v_gelu_bwd",
     "ts_w2v_softmax_fwd", "ts_w2v_softmax_bwd", "ts_w2v_pad_rows", "ts_w2v_mask_embed", "ts_w2v_add", "ts_se_gate_fwd", "ts_se_apply_fwd",
     "ts_decoder_bwd", "ts_adamw_step", "ts_adamw_multi_step", "ts_w2v_workspace_bytes", "ts_w2v_preprocess",
     "ts_train_dwconv_fwd", "ts_train_dwconv_bwd", "ts_train_dwconv_bwd_select", "ts_train_set_deterministic", "ts_train_mask_time", "ts_train_pwconv_fwd", "ts_train_pwconv_bwd", "ts_train_pack_pw_multi", "ts_train_pwconv_wgrad_workspace", "ts_train_pwconv_wgrad_mfma", "ts_train_pwconv_wgrad_multi", "ts_train_pwconv_wgrad_multi_parts", "ts_train_wgrad_reduce_multi",
@@ -229,6 +229,8 @@ def lib() -> C.CDLL:
     L.ts_w2v_colsum.argtypes = [vp, i64, i32, i64, vp, vp]
     L.ts_w2v_cast_bf16_t.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, i64, vp]
     L.ts_w2v_cast_bf16_t_colsum.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, i64, vp, vp]
+    L.ts_w2v_ffn_act_cast.argtypes = [vp, vp, i64, i32, f32, C.c_uint64, vp, vp, i64, i64, vp]
+    L.ts_w2v_ffn_act_bwd.argtypes = [vp, vp, i32, vp, f32, C.c_uint64, vp, i64, vp]
     L.ts_w2v_cast_bf16_t.restype = C.c_int
     L.ts_w2v_sum_parts.argtypes = [vp, vp, i64, i32, vp]
     L.ts_w2v_sum_parts_bias.argtypes = [vp, vp, i32, vp, i64, i32, vp]

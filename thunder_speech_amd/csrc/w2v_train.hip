@@ -14,6 +14,7 @@
 //   y = a + b                                                                      ts_w2v_add
 // Activations are f32 [rows][c], contiguous (the reference's arithmetic); rows = clips x frames.
 #include "ts_common.hpp"
+#include "ts_philox.hpp"
 
 namespace ts {
 
@@ -305,6 +306,92 @@ extern "C" int ts_w2v_sum_parts(const float* parts, float* out, int64_t n, int32
   (void)hipGetLastError();
   hipLaunchKernelGGL(ts::w2v_sum_parts_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), parts, out, (long long)(n / 4), (int)n_parts,
                      (long long)(n / 4), (const float*)nullptr, 1);
+  return ts::hip_status(hipGetLastError());
+}
+
+namespace ts {
+// The activation between the two feed-forward linears of mixed-precision fine-tuning, fused with the operand cast of the second one:
+//   a[r][j] = dropout(gelu(z[r][j] + bias[j]))  ->  y16[r][j] = bf16(a), yt16[j][r] = bf16(a)      (rows >= `rows` of the transposed copy: zeros)
+// -- the f32 activation (64 MB per layer at 8 x 10 s x 4096) has no other reader: gelu (read + write), dropout (read + write) and cast (read + 2 half writes)
+// were 448 MB per layer, this is 128.  Dropout: ts_train_dropout's mask (element e = r c + j: word e & 3 of Philox block e >> 2, keep iff u01 >= p); a
+// thread owns four consecutive columns = one block.  64 x 64 tiles through LDS for the transposed copy (as cast_bf16_t_kernel).
+__global__ __launch_bounds__(256) void ffn_act_cast_kernel(const float* __restrict__ z, const float* __restrict__ bias, int rows, int c, float p, float scale,
+                                                           unsigned long long seed, unsigned short* __restrict__ y, unsigned short* __restrict__ yt, long long ldt,
+                                                           int rows_pad) {
+  __shared__ unsigned short tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx4 = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int i = ty + 16 * pass, r = r0 + i, cc = c0 + 4 * tx4;
+    unsigned lo = 0, hi = 0;
+    if (r < rows && cc < c) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(z + (size_t)r * c + cc);
+      if (bias) v += *reinterpret_cast<const f32x4*>(bias + cc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+      if (p > 0.f) {
+        const Philox4 rn = philox(seed, PHILOX_DROPOUT, ((unsigned long long)r * c + cc) >> 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = u01(rn.v[k]) >= p ? v[k] * scale : 0.f;
+      }
+      lo = pack_bf16(v[0], v[1]); hi = pack_bf16(v[2], v[3]);
+      if (y) *reinterpret_cast<u32x2*>(y + (size_t)r * c + cc) = u32x2{lo, hi};
+    }
+    tile[i][4 * tx4 + 0] = (unsigned short)(lo & 0xffffu); tile[i][4 * tx4 + 1] = (unsigned short)(lo >> 16);
+    tile[i][4 * tx4 + 2] = (unsigned short)(hi & 0xffffu); tile[i][4 * tx4 + 3] = (unsigned short)(hi >> 16);
+  }
+  __syncthreads();
+  if (yt) {
+    const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    for (int i = tg; i < 64; i += 4) {
+      const int cc = c0 + i, r = r0 + tx;
+      if (cc < c && r < rows_pad) yt[(size_t)cc * ldt + r] = tile[tx][i];
+    }
+  }
+}
+
+// backward of the same: dz = dropout_bwd(da) * gelu'(z + bias)  (the mask re-drawn from the seed)
+__global__ __launch_bounds__(256) void ffn_act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ bias, int c, const float* __restrict__ da, float p, float scale,
+                                                          unsigned long long seed, float* __restrict__ dz, long long n4) {
+  const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= n4) return;
+  const long long e = i4 * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(z + e);
+  if (bias) v += *reinterpret_cast<const f32x4*>(bias + (e % c));
+  f32x4 g = *reinterpret_cast<const f32x4*>(da + e);
+  if (p > 0.f) {
+    const Philox4 rn = philox(seed, PHILOX_DROPOUT, (unsigned long long)i4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = u01(rn.v[k]) >= p ? g[k] * scale : 0.f;
+  }
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = g[k] * gelu_df(v[k]);
+  *reinterpret_cast<f32x4*>(dz + e) = o;
+}
+}  // namespace ts
+
+/* y16 / yt16 = bf16(dropout(gelu(z + bias))) as ts_w2v_cast_bf16_t would cast it; see include/thunder_speech_amd.h */
+extern "C" int ts_w2v_ffn_act_cast(const float* z, const float* bias, int64_t rows, int32_t c, float p_drop, uint64_t seed, void* y, void* yt, int64_t ldt, int64_t rows_pad,
+                                   void* stream_) {
+  if (!z || (!y && !yt) || rows <= 0 || c <= 0 || rows >= (1ll << 31) || !(p_drop >= 0.f && p_drop < 1.f)) return TS_EINVAL;
+  if (yt && (rows_pad < rows || ldt < rows_pad || rows_pad >= (1ll << 31))) return TS_EINVAL;
+  if (c % 4 || !al16(z) || (bias && !al16(bias)) || (y && (reinterpret_cast<uintptr_t>(y) & 7))) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  const long long rp = yt ? rows_pad : rows;
+  hipLaunchKernelGGL(ts::ffn_act_cast_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)((rp + 63) / 64)), dim3(256), 0, stream, z, bias, (int)rows, (int)c, p_drop,
+                     1.f / (1.f - p_drop), (unsigned long long)seed, static_cast<unsigned short*>(y), static_cast<unsigned short*>(yt), (long long)ldt, (int)rows_pad);
+  return ts::hip_status(hipGetLastError());
+}
+
+/* dz = dropout_backward(da) * gelu'(z + bias), n = rows * c elements; see include/thunder_speech_amd.h */
+extern "C" int ts_w2v_ffn_act_bwd(const float* z, const float* bias, int32_t c, const float* da, float p_drop, uint64_t seed, float* dz, int64_t n, void* stream_) {
+  if (!z || !da || !dz || n <= 0 || c <= 0 || n % c || !(p_drop >= 0.f && p_drop < 1.f)) return TS_EINVAL;
+  if (c % 4 || !al16(z) || !al16(da) || !al16(dz) || (bias && !al16(bias))) return TS_EUNSUPPORTED;
+  TS_STREAM;
+  hipLaunchKernelGGL(ts::ffn_act_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, z, bias, c, da, p_drop, 1.f / (1.f - p_drop), (unsigned long long)seed, dz,
+                     (long long)(n / 4));
   return ts::hip_status(hipGetLastError());
 }
 

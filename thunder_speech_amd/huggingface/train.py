@@ -169,6 +169,63 @@ class LinearMixed(torch.autograd.Function):
         return dx, dw, db
 
 
+class FFNActLinear(torch.autograd.Function):
+    """output_dense(dropout(gelu(z + b1))) of a wav2vec2 feed-forward block in mixed precision, as ONE node: the activation goes straight from z to the bf16
+    operands of the second linear (ts_w2v_ffn_act_cast: the f32 activation is never stored), and the backward runs the data-gradient product into a buffer that
+    the fused dropout-backward x gelu' launch (ts_w2v_ffn_act_bwd) turns into dz.  Same products, split-K rules and Philox mask as BiasGelu -> Dropout -> LinearMixed."""
+
+    @staticmethod
+    def supported(c_mid: int, n: int) -> bool:
+        return c_mid % 32 == 0 and n % 32 == 0
+
+    @staticmethod
+    def forward(ctx, z, b1, w2, b2, p_drop, seed):
+        z, w2 = _f32c(z), _f32c(w2)
+        n, k = w2.shape                                   # k = the intermediate width
+        rows = z.numel() // k
+        L = _lib.lib()
+        rp = _pad32(rows)
+        x16 = torch.empty(rows, k, dtype=torch.bfloat16, device=z.device)
+        xt16 = torch.empty(k, rp, dtype=torch.bfloat16, device=z.device) if ctx.needs_input_grad[2] else None
+        _lib.check(L.ts_w2v_ffn_act_cast(z.data_ptr(), b1.data_ptr() if b1 is not None else None, rows, k, float(p_drop), int(seed), x16.data_ptr(),
+                                         xt16.data_ptr() if xt16 is not None else None, rp, rp, _s(z)), "ts_w2v_ffn_act_cast")
+        w16, wt16 = _cast(w2, n, k, True, ctx.needs_input_grad[0])
+        y = torch.empty(*z.shape[:-1], n, dtype=torch.float32, device=z.device)
+        _gemm_nt_splitk(x16, k, w16, k, y, rows, n, k, bias=_f32c(b2) if b2 is not None else None, min_k=2048)
+        ctx.save_for_backward(z, b1, xt16, wt16)
+        ctx.geom = (rows, n, k, z.shape, float(p_drop), int(seed), b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, b1, xt16, wt16 = ctx.saved_tensors
+        rows, n, k, zshape, p_drop, seed, has_b2 = ctx.geom
+        dy = _f32c(dy)
+        L = _lib.lib()
+        dz = db1 = dw = db2 = None
+        want_db2 = has_b2 and ctx.needs_input_grad[3]
+        if want_db2:
+            db2 = torch.zeros(n, dtype=torch.float32, device=dy.device)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dy16, dyt16 = _cast(dy.view(rows, n), rows, n, ctx.needs_input_grad[0], ctx.needs_input_grad[2], colsum=db2)
+        elif want_db2:
+            db2 = _colsum(dy, rows, n)
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(rows, k, dtype=torch.float32, device=dy.device)
+            _gemm_nt_splitk(dy16, n, wt16, _pad32(n), da, rows, k, n)
+            dz = torch.empty(zshape, dtype=torch.float32, device=dy.device)
+            _lib.check(L.ts_w2v_ffn_act_bwd(z.data_ptr(), b1.data_ptr() if b1 is not None else None, k, da.data_ptr(), p_drop, seed, dz.data_ptr(), dz.numel(), _s(dy)),
+                       "ts_w2v_ffn_act_bwd")
+            if b1 is not None and ctx.needs_input_grad[1]:
+                db1 = _colsum(dz, rows, k)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty(n, k, dtype=torch.float32, device=dy.device)
+            rp = _pad32(rows)
+            _gemm_nt_splitk(dyt16, rp, xt16, rp, dw, n, k, rp)
+        return dz, db1, dw, db2, None, None
+
+
+FUSED_FFN_ACT = True        # mixed mode: FFNActLinear for gelu -> dropout -> output_dense (False: the three separate nodes, for A/B)
 _MIXED = False
 
 
@@ -632,8 +689,11 @@ def _train_forward(adapt, audio: Tensor, lengths: Optional[Tensor]) -> Tensor:
 
         def ffn(x):
             z = linear(x, ff.intermediate_dense.weight, None)
+            w2 = ff.output_dense.weight
+            if _MIXED and FUSED_FFN_ACT and FFNActLinear.supported(w2.shape[1], w2.shape[0]):
+                return dropout(FFNActLinear.apply(z, ff.intermediate_dense.bias, w2, ff.output_dense.bias, p_act, next_seed() if p_act > 0 else 0), p_hid)
             a = dropout(BiasGelu.apply(z, ff.intermediate_dense.bias), p_act)
-            return dropout(linear(a, ff.output_dense.weight, ff.output_dense.bias), p_hid)
+            return dropout(linear(a, w2, ff.output_dense.bias), p_hid)
 
         if stable:                                                  # pre-LN: h += attn(LN(h)); h += ffn(LN(h))
             h = Add.apply(h, attend(LayerNorm.apply(h, None, layer.layer_norm.weight, layer.layer_norm.bias, eps)))
