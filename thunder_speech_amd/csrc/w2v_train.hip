@@ -342,11 +342,12 @@ __global__ __launch_bounds__(256) void ffn_act_cast_kernel(const float* __restri
     tile[i][4 * tx4 + 2] = (unsigned short)(hi & 0xffffu); tile[i][4 * tx4 + 3] = (unsigned short)(hi >> 16);
   }
   __syncthreads();
-  if (yt) {
-    const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
-    for (int i = tg; i < 64; i += 4) {
-      const int cc = c0 + i, r = r0 + tx;
-      if (cc < c && r < rows_pad) yt[(size_t)cc * ldt + r] = tile[tx][i];
+  if (yt) {                                          // 4-byte stores of two consecutive rows (rows_pad and ldt are even)
+    const int tp = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    for (int i = tg; i < 64; i += 8) {
+      const int cc = c0 + i, r = r0 + 2 * tp;
+      if (cc < c && r + 1 < rows_pad) *reinterpret_cast<unsigned*>(yt + (size_t)cc * ldt + r) = (unsigned)tile[2 * tp][i] | ((unsigned)tile[2 * tp + 1][i] << 16);
+      else if (cc < c && r < rows_pad) yt[(size_t)cc * ldt + r] = tile[2 * tp][i];
     }
   }
 }
@@ -377,7 +378,7 @@ extern "C" int ts_w2v_ffn_act_cast(const float* z, const float* bias, int64_t ro
                                    void* stream_) {
   if (!z || (!y && !yt) || rows <= 0 || c <= 0 || rows >= (1ll << 31) || !(p_drop >= 0.f && p_drop < 1.f)) return TS_EINVAL;
   if (yt && (rows_pad < rows || ldt < rows_pad || rows_pad >= (1ll << 31))) return TS_EINVAL;
-  if (c % 4 || !al16(z) || (bias && !al16(bias)) || (y && (reinterpret_cast<uintptr_t>(y) & 7))) return TS_EUNSUPPORTED;
+  if (c % 4 || !al16(z) || (bias && !al16(bias)) || (y && (reinterpret_cast<uintptr_t>(y) & 7)) || (yt && (ldt % 2 || (reinterpret_cast<uintptr_t>(yt) & 3)))) return TS_EUNSUPPORTED;
   TS_STREAM;
   const long long rp = yt ? rows_pad : rows;
   hipLaunchKernelGGL(ts::ffn_act_cast_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)((rp + 63) / 64)), dim3(256), 0, stream, z, bias, (int)rows, (int)c, p_drop,
@@ -395,6 +396,56 @@ extern "C" int ts_w2v_ffn_act_bwd(const float* z, const float* bias, int32_t c, 
   return ts::hip_status(hipGetLastError());
 }
 
+namespace ts {
+// cast_bf16_t_kernel with 16-byte loads and 8-byte / 4-byte stores (c % 4 == 0, 16-byte aligned rows): a thread owns four consecutive columns of four rows of the
+// 64 x 64 tile; the transposed copy leaves as 4-byte stores of two consecutive rows.  The scalar form above moved 32 MB in 14.9 us (2.1 TB/s): 315 launches = 4.7 ms
+// of a 31-ms fine-tuning step.
+__global__ __launch_bounds__(256) void cast_bf16_t4_kernel(const float* __restrict__ x, long long ldx, int rows, int c, unsigned short* __restrict__ y, long long ldy,
+                                                           unsigned short* __restrict__ yt, long long ldt, int rows_pad, float* __restrict__ colsum) {
+  __shared__ unsigned short tile[64][66];
+  __shared__ float csum[16][64];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx4 = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int i = ty + 16 * pass, r = r0 + i, cc = c0 + 4 * tx4;
+    unsigned lo = 0, hi = 0;
+    if (r < rows && cc < c) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * ldx + cc);
+      acc += v;
+      lo = pack_bf16(v[0], v[1]); hi = pack_bf16(v[2], v[3]);
+      if (y) *reinterpret_cast<u32x2*>(y + (size_t)r * ldy + cc) = u32x2{lo, hi};
+    }
+    tile[i][4 * tx4 + 0] = (unsigned short)(lo & 0xffffu); tile[i][4 * tx4 + 1] = (unsigned short)(lo >> 16);
+    tile[i][4 * tx4 + 2] = (unsigned short)(hi & 0xffffu); tile[i][4 * tx4 + 3] = (unsigned short)(hi >> 16);
+  }
+  if (colsum) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) csum[ty][4 * tx4 + k] = acc[k];
+  }
+  __syncthreads();
+  if (colsum && threadIdx.x < 64 && c0 + (int)threadIdx.x < c && r0 < rows) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += csum[q][threadIdx.x];
+    atomicAdd(colsum + c0 + threadIdx.x, t);
+  }
+  if (yt) {
+    // lane pair-rows: thread (tp = tid & 31 -> rows 2 tp, 2 tp + 1; tg = tid >> 5 -> columns tg, tg + 8, ...)
+    const int tp = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    for (int i = tg; i < 64; i += 8) {
+      const int cc = c0 + i, r = r0 + 2 * tp;
+      if (cc < c && r < rows_pad) {
+        const unsigned v = (unsigned)tile[2 * tp][i] | ((unsigned)tile[2 * tp + 1][i] << 16);
+        if (r + 1 < rows_pad) *reinterpret_cast<unsigned*>(yt + (size_t)cc * ldt + r) = v;
+        else yt[(size_t)cc * ldt + r] = (unsigned short)(v & 0xffffu);
+      }
+    }
+  }
+}
+}  // namespace ts
+
 /* ts_w2v_cast_bf16_t that also ADDS the column sums of x to colsum (f32 [c], may be NULL); see include/thunder_speech_amd.h */
 extern "C" int ts_w2v_cast_bf16_t_colsum(const float* x, int64_t ldx, int64_t rows, int32_t c, void* y, int64_t ldy, void* yt, int64_t ldt, int64_t rows_pad,
                                          float* colsum, void* stream_) {
@@ -404,6 +455,12 @@ extern "C" int ts_w2v_cast_bf16_t_colsum(const float* x, int64_t ldx, int64_t ro
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const long long rp = yt ? rows_pad : rows;
   (void)hipGetLastError();
+  const bool vec = c % 4 == 0 && ldx % 4 == 0 && al16(x) && (!y || (ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0)) &&
+                   (!yt || (ldt % 2 == 0 && (reinterpret_cast<uintptr_t>(yt) & 3) == 0));
+  if (vec)
+    hipLaunchKernelGGL(ts::cast_bf16_t4_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)((rp + 63) / 64)), dim3(256), 0, stream, x, (long long)ldx, (int)rows, (int)c,
+                       static_cast<unsigned short*>(y), (long long)ldy, static_cast<unsigned short*>(yt), (long long)ldt, (int)rows_pad, colsum);
+  else
   hipLaunchKernelGGL(ts::cast_bf16_t_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)((rp + 63) / 64)), dim3(256), 0, stream, x, (long long)ldx, (int)rows, (int)c,
                      static_cast<unsigned short*>(y), (long long)ldy, static_cast<unsigned short*>(yt), (long long)ldt, (int)rows_pad, colsum);
   return ts::hip_status(hipGetLastError());
