@@ -102,12 +102,16 @@ def _gemm_nt(a16: Tensor, lda: int, w16: Tensor, ldw: int, out: Tensor, rows: in
     _lib.check(st, "ts_gemm_nt_bf16")
 
 
+SPLITK_TARGET_WGS = 192     # split-K while a product has fewer workgroups than this (256 x 256 tiles, one per CU; same-box sweep of the 8 x 10 s step,
+                            # tools/diag/splitk_ab.py: 128 -> 30.0 ms, 192 -> 28.9, 224 -> 29.8, 256 -> 29.6)
+
+
 def _gemm_nt_splitk(a16: Tensor, lda: int, w16: Tensor, ldw: int, out: Tensor, rows: int, n: int, k: int, bias: Optional[Tensor] = None, min_k: int = 0):
     """The same product for FEW output tiles and a LONG contraction (the weight gradients: 1024 x 1024 outputs are 16 tiles of 256 x 256 on 256 compute
     units): split-K into f32 partials (ts_gemm_nt_bf16_splitk) + an ordered sum (ts_w2v_sum_parts), splits chosen for ~128 workgroups."""
     tiles = ((rows + 255) // 256) * ((n + 255) // 256)
     splits = 1
-    while tiles * splits < 128 and k % (64 * splits) == 0 and k // (2 * splits) >= 256:
+    while tiles * splits < SPLITK_TARGET_WGS and k % (64 * splits) == 0 and k // (2 * splits) >= 256:
         splits *= 2
     if splits == 1 or (rows * n) % 4 or k < min_k or (bias is not None and n % 4):
         return _gemm_nt(a16, lda, w16, ldw, out, rows, n, k, bias)
