@@ -425,3 +425,82 @@ def test_fused_feed_forward_activation_node_equals_the_three_separate_nodes(rows
     for i in (3, 4):
         assert torch.allclose(res[0][i], res[1][i], rtol=1e-5, atol=1e-5 * float(res[1][i].abs().max()))
     assert float(res[0][1].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("b,t,c,k,g", [(1, 37, 128, 16, 2), (2, 130, 256, 13, 4), (3, 257, 1024, 128, 16)])
+def test_positional_conv_matrix_core_entry_points_against_f64_on_odd_geometries(b, t, c, k, g):
+    """ts_w2v_posconv_train (forward incl. the pre-activation z; data gradient as the same product over flipped, transposed taps) and ts_w2v_posconv_wgrad
+    against float64 einsums of the bf16-rounded operands: one clip, frame counts below / not multiples of the 128-frame tile, an ODD kernel (padding k / 2 on
+    both sides, nothing dropped) and one that is no multiple of the 8 taps a workgroup owns."""
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(b * 1000 + t)
+    cg = c // g
+    assert cg == 64
+    x = torch.randn(b, t, c, device="cuda")
+    wk = torch.randn(k, g, cg, cg, device="cuda") * (cg * k) ** -0.5
+    bias = torch.randn(c, device="cuda") * 0.1
+    dz = torch.randn(b, t, c, device="cuda")
+    bf = lambda v: v.to(torch.bfloat16).double()
+    # reference: y_conv[b][t][g cg + o] = sum_j sum_i x[b][t + j - k // 2][g cg + i] wk[j][g][o][i]
+    xp = torch.zeros(b, t + k, c, dtype=torch.float64, device="cuda")
+    xp[:, k // 2: k // 2 + t] = bf(x)
+    win = torch.stack([xp[:, j: j + t] for j in range(k)], 0).view(k, b, t, g, cg)                      # [j][b][t][g][i]
+    conv = torch.einsum("jbtgi,jgoi->btgo", win, bf(wk)).reshape(b, t, c)
+    ws = torch.empty(L.ts_w2v_posconv_train_workspace(b, t, c, k), dtype=torch.uint8, device="cuda")
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    assert L.ts_w2v_posconv_train(x.data_ptr(), x.data_ptr(), b, t, c, wk.to(torch.bfloat16).data_ptr(), bias.data_ptr(), k, g, 0, y.data_ptr(), z.data_ptr(), ws.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert float((z.double() - conv).abs().max()) <= 2e-5 * max(1.0, float(conv.abs().max()))
+    y_ref = x.double() + torch.nn.functional.gelu(conv + bias.double())
+    assert float((y.double() - y_ref).abs().max()) <= 1e-4
+    # data gradient: dx[b][s][g cg + i] = dy + sum_j sum_o dz[b][s - j + k // 2][g cg + o] wk[j][g][o][i]
+    dzp = torch.zeros(b, t + k, c, dtype=torch.float64, device="cuda")
+    front = k - 1 - k // 2
+    dzp[:, front: front + t] = bf(dz)
+    wb = wk.flip(0).transpose(2, 3).contiguous()
+    winz = torch.stack([dzp[:, j: j + t] for j in range(k)], 0).view(k, b, t, g, cg)
+    dconv = torch.einsum("jbtgo,jgio->btgi", winz, bf(wb)).reshape(b, t, c)
+    dy = torch.randn(b, t, c, device="cuda")
+    dx = torch.empty_like(x)
+    assert L.ts_w2v_posconv_train(dz.data_ptr(), dy.data_ptr(), b, t, c, wb.to(torch.bfloat16).data_ptr(), None, k, g, 1, dx.data_ptr(), None, ws.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert float((dx.double() - (dy.double() + dconv)).abs().max()) <= 2e-5 * max(1.0, float(dconv.abs().max()))
+    # the definition of the transposed product, independently: autograd of the forward reference
+    xr = bf(x).requires_grad_(True)
+    xpr = torch.nn.functional.pad(xr, (0, 0, k // 2, k - k // 2))
+    winr = torch.stack([xpr[:, j: j + t] for j in range(k)], 0).view(k, b, t, g, cg)
+    torch.einsum("jbtgi,jgoi->btgo", winr, bf(wk)).reshape(b, t, c).backward(bf(dz))
+    assert float((dconv - xr.grad).abs().max()) <= 1e-9 * max(1.0, float(xr.grad.abs().max()))
+    # weight gradient
+    dw = torch.full_like(wk, float("nan"))
+    ws2 = torch.empty(L.ts_w2v_posconv_wgrad_workspace(b, t, c, k), dtype=torch.uint8, device="cuda")
+    assert L.ts_w2v_posconv_wgrad(dz.data_ptr(), x.data_ptr(), b, t, c, k, g, dw.data_ptr(), ws2.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    dw_ref = torch.einsum("btgo,jbtgi->jgoi", bf(dz).view(b, t, g, cg), win)
+    assert bool(torch.isfinite(dw).all())
+    assert float((dw.double() - dw_ref).abs().max()) <= 2e-5 * max(1.0, float(dw_ref.abs().max()))
+
+
+def test_layernorm_backward_set_form_equals_the_accumulating_form():
+    """ts_w2v_layernorm_bwd_set (dgamma / dbeta zeroed by the first launch, one reducing launch) against ts_w2v_layernorm_bwd on zero-filled outputs; the
+    outputs handed to the set form hold NaN before the call."""
+    from thunder_speech_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(4)
+    rows, c = 3992, 1024
+    x, res, dy = (torch.randn(rows, c, device="cuda") for _ in range(3))
+    gamma = torch.rand(c, device="cuda") + 0.5
+    ws = torch.empty(L.ts_w2v_layernorm_bwd_workspace(rows, c), dtype=torch.uint8, device="cuda")
+    out = []
+    for fn, init in ((L.ts_w2v_layernorm_bwd, 0.0), (L.ts_w2v_layernorm_bwd_set, float("nan"))):
+        dx = torch.empty_like(x)
+        dg, db = torch.full((c,), init, device="cuda"), torch.full((c,), init, device="cuda")
+        assert fn(x.data_ptr(), res.data_ptr(), gamma.data_ptr(), dy.data_ptr(), 1e-5, rows, c, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        out.append((dx, dg, db))
+    assert torch.equal(out[0][0], out[1][0])
+    for i in (1, 2):
+        assert torch.allclose(out[0][i], out[1][i], rtol=1e-5, atol=1e-4)
