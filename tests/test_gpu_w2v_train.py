@@ -15,7 +15,11 @@ BASE = dict(vocab_size=32, hidden_size=64, num_hidden_layers=2, num_attention_he
             activation_dropout=0.0, attention_dropout=0.0, feat_proj_dropout=0.0, final_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0,
             mask_feature_prob=0.0)
 FAMILIES = {"group_postln": dict(feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False),
-            "layer_preln": dict(feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True)}
+            "layer_preln": dict(feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True),
+            # head_dim 64 and 64 channels per positional-conv group: the geometry on which mixed precision takes the fused attention (csrc/w2v_attn_train.hip) and the
+            # matrix-core positional conv (ts_w2v_posconv_train / _wgrad) -- the whole model against transformers' autograd with those kernels in the path
+            "group_postln_hd64": dict(feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False, hidden_size=128, num_attention_heads=2,
+                                      intermediate_size=256, num_conv_pos_embedding_groups=2)}
 
 
 def _model(family, seed=0, **over):
@@ -88,7 +92,7 @@ def test_training_forward_and_every_gradient_match_transformers_autograd(family,
     probe = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(5))
     (out_ref * probe).sum().backward()
     feats, out_len = adapt(x.cuda(), lengths.cuda())
-    assert feats.shape == (3, 64, out_ref.shape[1])
+    assert feats.shape == (3, out_ref.shape[2], out_ref.shape[1])
     got = feats.transpose(-1, -2)
     np.testing.assert_allclose(got.detach().cpu().numpy(), out_ref.detach().numpy(), atol=5e-4, rtol=1e-4)
     (got * probe.cuda()).sum().backward()
@@ -209,6 +213,17 @@ def test_mixed_precision_training_matches_transformers_autograd_within_bf16_tole
     err = float((got.detach().cpu() - out_ref.detach()).abs().max())
     assert err <= 3e-2 * max(1.0, float(out_ref.abs().max())), err
     assert err > 1e-6, "the mixed-precision path did not run (bit-level agreement with f32 is not what bf16 operands give)"
+    if family.endswith("hd64"):                      # the fused kernels are in this graph
+        from thunder_speech_amd.huggingface import train as T
+        seen, todo = set(), [got.grad_fn]
+        while todo:
+            fn = todo.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            todo += [f for f, _ in fn.next_functions]
+        names = {type(fn).__name__ for fn in seen}
+        assert {"AttentionFusedBackward", "FFNActLinearBackward", "PosConvGeluBackward"} <= names, names
     (got * probe.cuda()).sum().backward()
     worst = _compare_grads(ref, adapt, tol=4e-2)
     assert worst > 1e-5
