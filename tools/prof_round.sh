@@ -1,6 +1,6 @@
 # Per-round profiles (run on the GPU box through gpurun):  bash tools/prof_round.sh <round number>
 #   bench.py (C2 headline): rocprofv3 --kernel-trace --stats, then separate --pmc FETCH_SIZE / WRITE_SIZE passes
-#   C3 / C4 phase 1 / C4 phase 2 (bf16 + hipGraph) / C4 phase 2 fp32 (the f32 matrix-core GEMM) / C5 / wav2vec2 fine-tuning: rocprofv3 --kernel-trace --stats of tools/bench_extra.py, one configuration per process
+#   C3 / C4 phase 1 / C4 phase 2 (bf16 + hipGraph) / C4 phase 2 fp32 (the f32 matrix-core GEMM) / C5 / wav2vec2 fine-tuning (f32 and mixed precision, one process each): rocprofv3 --kernel-trace --stats of tools/bench_extra.py, one configuration per process
 # TS_PROF_MARK=1 brackets every timed loop with a marker kernel: the summary reports the TIMED REGION ONLY (per-step shares).
 # Every pass is bounded; the program itself follows `--` (no env / shell hop under the profiler).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -20,5 +20,9 @@ export TS_C4_ONLY=c4_phase2_fp32
 timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4p2f -- python3 tools/bench_extra.py c4 > $O/c4p2f.log 2>&1
 unset TS_C4_ONLY
 timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -- python3 tools/bench_extra.py c5 --no-check > $O/c5.log 2>&1
+export TS_C5FT_ONLY=fp32
 timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5ft -- python3 tools/bench_extra.py c5_finetune > $O/c5ft.log 2>&1
+export TS_C5FT_ONLY=bf16
+timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5ftb -- python3 tools/bench_extra.py c5_finetune > $O/c5ftb.log 2>&1
+unset TS_C5FT_ONLY
 python3 tools/prof_round_summary.py $O $R

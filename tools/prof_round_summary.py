@@ -96,7 +96,10 @@ for name, title, key, anchor in (("c3", "C3 Citrinet-1024 inference 32 x 20 s (`
                          ("c4p2f", "C4 phase 2 in fp32 (every GEMM on the f32 matrix-core kernel of csrc/gemm_f32.hip; no vendor library is linked) "
                                    "(`TS_C4_ONLY=c4_phase2_fp32 tools/bench_extra.py c4`)", "c4_phase2_fp32", "ctc_kernel"),
                          ("c5", "C5 wav2vec2-large inference 16 x 20 s, own GEMM (`tools/bench_extra.py c5`)", "c5", "w2v_posconv_mfma_kernel"),
-                         ("c5ft", "wav2vec2-large fine-tuning step 8 x 10 s, f32, eager launches (`tools/bench_extra.py c5_finetune`)", "c5_finetune", "w2v_conv0_finalize_kernel")):
+                         ("c5ft", "wav2vec2-large fine-tuning step 8 x 10 s, f32, eager launches (`TS_C5FT_ONLY=fp32 tools/bench_extra.py c5_finetune`)", "c5_finetune",
+                          "w2v_conv0_finalize_kernel"),
+                         ("c5ftb", "wav2vec2-large fine-tuning step 8 x 10 s, mixed precision (bf16 operands / f32 accumulation), eager launches "
+                                   "(`TS_C5FT_ONLY=bf16 tools/bench_extra.py c5_finetune`)", "c5_finetune_bf16", "w2v_conv0_finalize_kernel")):
     rows, span, traced = trace(name, anchor)
     if not rows:
         md += [f"## {title}", "", "(no trace)", ""]
